@@ -1,0 +1,131 @@
+"""
+ctypes binding of lib/libbfcnn_hip.so (the C ABI of include/bfcnn_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or fails to load, every
+entry point of the package that needs it raises.  Build it with
+`blind_image_denoising_amd/csrc/build.sh` (or `python -c "import __graft_entry__ as g; g.build()"`).
+"""
+import ctypes as C
+import os
+import pathlib
+
+_HERE = pathlib.Path(__file__).resolve().parent
+LIB_PATH = _HERE / "lib" / "libbfcnn_hip.so"
+
+BF_OK, BF_EINVAL, BF_EUNSUPPORTED, BF_EWORKSPACE, BF_EHIP = 0, -1, -2, -3, -4
+BF_ACT_LINEAR, BF_ACT_RELU, BF_ACT_LEAKY_RELU = 0, 1, 2
+BF_REG_NONE, BF_REG_L1, BF_REG_L2 = 0, 1, 2
+BF_MODE_INFERENCE, BF_MODE_TRAIN = 0, 1
+BF_LOSS_COUNT = 8
+(BF_LOSS_TOTAL, BF_LOSS_DENOISER_TOTAL, BF_LOSS_MAE, BF_LOSS_MSE, BF_LOSS_SSIM,
+ BF_LOSS_REGULARIZATION, BF_LOSS_MODEL_TOTAL, BF_LOSS_GRAD_NORM) = range(8)
+EPI_RELU, EPI_AFFINE, EPI_RES, EPI_MASK, EPI_STATS = 1, 2, 4, 8, 16
+
+
+class ResnetDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "struct_size", "in_channels", "filters", "kernel_size", "no_layers", "block_convs",
+        "block_kernel", "activation", "base_activation", "use_bn", "head_filters",
+        "head_activation", "out_channels", "denormalize", "reg_base", "reg_block", "reg_head")] + \
+        [(n, C.c_float) for n in ("v_min", "v_max", "bn_eps", "bn_momentum", "leaky_alpha")]
+
+
+class LossDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_int32)] + [(n, C.c_float) for n in (
+        "hinge", "cutoff", "mae_multiplier", "mse_multiplier", "ssim_multiplier",
+        "regularization", "depth_weight")]
+
+
+class TensorInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("offset", C.c_int64), ("rank", C.c_int32),
+                ("shape", C.c_int32 * 4), ("kind", C.c_int32), ("regularizer", C.c_int32)]
+
+
+_P, _I, _I64, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); exactly the declarations of include/bfcnn_hip.h
+SIGNATURES = {
+    "bf_abi_version": (_I, []),
+    "bf_create": (_I, [C.POINTER(ResnetDesc), C.POINTER(_P)]),
+    "bf_destroy": (None, [_P]),
+    "bf_last_error": (C.c_char_p, [_P]),
+    "bf_param_count": (_I64, [_P]),
+    "bf_state_count": (_I64, [_P]),
+    "bf_tensor_count": (_I, [_P, _I]),
+    "bf_tensor_at": (_I, [_P, _I, _I, C.POINTER(TensorInfo)]),
+    "bf_packed_bytes": (_I64, [_P]),
+    "bf_workspace_bytes": (_I64, [_P, _I, _I, _I, _I]),
+    "bf_pack_inference": (_I, [_P, _P, _P, _P, _P]),
+    "bf_forward_u8": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _I64, _P]),
+    "bf_forward_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _I64, _P]),
+    "bf_train_step": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, C.POINTER(LossDesc), _P, _P, _P, _P, _I64, _P]),
+    "bf_adam_step": (_I, [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _P, _P, _P]),
+    "bf_avgpool_s2_same": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "bf_avgpool2_valid": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "bf_upsample2x": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P]),
+    "bf_strided_slice2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "bf_set_option": (_I, [_P, C.c_char_p, _I]),
+    "bf_debug_conv3x3": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "bf_debug_conv3x3_grid": (_I, [_I, _I, _I]),
+    "bf_debug_fused_block": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "bf_debug_wgrad_partial_floats": (_I64, [_I, _I, _I]),
+    "bf_debug_wgrad3x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "bf_debug_mfma_probe": (_I, [_P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise ImportError(
+                f"{LIB_PATH} is missing: the gfx950 HIP library has not been built "
+                f"(run blind_image_denoising_amd/csrc/build.sh). There is no CPU fallback.")
+        handle = C.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if handle.bf_abi_version() != 1:
+            raise ImportError("libbfcnn_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def last_error(handle=None) -> str:
+    msg = lib().bf_last_error(handle)
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc: int, handle=None, what: str = ""):
+    """Maps the C status to the exception the reference raises for the same condition."""
+    if rc == BF_OK:
+        return
+    msg = f"{what}: {last_error(handle)}" if what else last_error(handle)
+    if rc == BF_EINVAL:
+        raise ValueError(msg)
+    if rc == BF_EUNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == BF_EWORKSPACE:
+        raise MemoryError(msg)
+    raise RuntimeError(f"HIP error ({rc}) {msg}")
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor / None."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(t=None):
+    """hipStream_t of torch's current stream on the tensor's device."""
+    import torch
+    if t is not None and t.is_cuda:
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,97 @@
+// Internal declarations shared by the gfx950 kernels and the C-ABI engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/bfcnn_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define BF_C 16             // feature channels of the MFMA path (filters == 16)
+#define BF_WPACK_FLOATS (36 * 64)   // one 3x3 16->16 kernel as MFMA A-operand register images
+
+// epilogue stages of the 3x3 C16 convolution: [scale+shift] -> [ReLU] -> [mask] -> [+residual]
+// (general form of SURVEY.md 8a "epilogue note"); STATS = per-channel sum / sum-of-squares of
+// the raw convolution output for training-mode batch norm.
+enum { EPI_RELU = 1, EPI_AFFINE = 2, EPI_RES = 4, EPI_MASK = 8, EPI_STATS = 16 };
+
+struct ConvArgs {
+    const float* in;      // [B,H,W,16]
+    float* out;           // [B,H,W,16]
+    const float* wpack;   // [36][64]
+    const float* scale;   // [16]  (EPI_AFFINE)
+    const float* shift;   // [16]
+    const float* res;     // [B,H,W,16] (EPI_RES)
+    const float* mask;    // [B,H,W,16] (EPI_MASK): out = mask > 0 ? out : 0
+    float* stats;         // [grid][32] (EPI_STATS)
+    int B, H, W;
+};
+
+struct FusedBlockArgs {
+    const float* in;      // [B,H,W,16] block input x
+    float* out;           // [B,H,W,16] x + scale*conv2(relu(conv1 x)) + shift
+    const float* w1pack;  // [36][64]
+    const float* w2pack;  // [36][64]
+    const float* scale;   // [16] folded BN scale
+    const float* shift;   // [16] folded BN shift
+    int B, H, W;
+    int tiles_x, tiles_y, ntiles;
+    int act1_relu;        // activation of conv1 (1 = relu, 0 = linear)
+};
+
+// ---- launchers (each returns hipGetLastError()) -------------------------------------------
+hipError_t bf_launch_conv3x3_c16(const ConvArgs& a, int epi, hipStream_t s);
+int        bf_conv3x3_c16_grid(int B, int H, int W);
+hipError_t bf_launch_fused_block(const FusedBlockArgs& a, hipStream_t s);
+hipError_t bf_launch_pack_conv(const float* w_hwio, float* wpack, int transpose_flip, hipStream_t s);
+hipError_t bf_launch_wgrad3x3_c16(const float* x, const float* dy, float* partial, float* dw,
+                                  int B, int H, int W, hipStream_t s);
+int        bf_wgrad_grid(int B, int H, int W);
+
+// base convolution k x k, Cin -> 16 on the normalised input (u8 or f32 source) with virtual
+// power-of-two padding: source image is [B,Hs,Ws,Cin]; activations are [B,H,W,16] with H>=Hs.
+struct BaseConvArgs {
+    const void* in; float* out; const float* w;  // w: [k,k,cin,16] HWIO
+    int B, Hs, Ws, H, W, cin, k, in_is_u8, act_relu;
+    float v_min, v_max;
+};
+hipError_t bf_launch_base_conv(const BaseConvArgs& a, hipStream_t s);
+// dW[k,k,cin,16] = sum xn (x) dy ; partial = [grid][k*k*cin*16]
+hipError_t bf_launch_base_wgrad(const float* in_f32, const float* dy, float* partial, float* dw,
+                                int B, int H, int W, int cin, int k, float v_min, float v_max, hipStream_t s);
+int        bf_base_wgrad_grid(int B, int H, int W);
+
+struct HeadArgs {
+    const float* feat;    // [B,H,W,16]
+    const float* w0;      // [16,hf]
+    const float* w1;      // [hf,cout]
+    const float* wh;      // [16,4] premultiplied (linear head) or NULL
+    void* out;            // u8 or f32 [B,Ho,Wo,cout]
+    int B, H, W, Ho, Wo, hf, cout, act, out_is_u8, denormalize;
+    float v_min, v_max, leaky_alpha;
+};
+hipError_t bf_launch_head(const HeadArgs& a, hipStream_t s);
+
+struct HeadTrainArgs {
+    const float* feat; const float* wh;      // [16,4]
+    const float* gt; float* pred;            // [B,H,W,cout]; pred may be NULL
+    float* dfeat;                            // [B,H,W,16]
+    float* partial;                          // [grid][64]: M[16][3] (48), sums (abs, hinge-abs, sq per block...)
+    int B, H, W, cout, denormalize;
+    float v_min, v_max, hinge, cutoff, dscale; // dscale = mae_multiplier*depth_weight/numel
+};
+hipError_t bf_launch_head_train(const HeadTrainArgs& a, int grid, hipStream_t s);
+int        bf_head_train_grid(int B, int H, int W);
+
+// elementwise / reductions
+hipError_t bf_launch_bn_finalize(const float* partial, int nblk, double count, const float* gamma,
+                                 float* moving_mean, float* moving_var, float eps, float momentum,
+                                 float* scale, float* shift, float* mean_inv /*[32]*/, hipStream_t s);
+hipError_t bf_launch_affine_add(const float* x, const float* c, const float* scale, const float* shift,
+                                float* y, int64_t npix, hipStream_t s);   // y = x + scale*c + shift
+hipError_t bf_launch_bn_bwd_reduce(const float* dy, const float* c, float* partial, int64_t npix, int grid, hipStream_t s);
+hipError_t bf_launch_bn_bwd_finalize(const float* partial, int nblk, double count, const float* gamma,
+                                     const float* mean_inv, float* coef /*[48]: k1,k2,k3*/, float* dgamma, hipStream_t s);
+hipError_t bf_launch_bn_bwd_apply(const float* dy, const float* c, const float* coef, float* dc, int64_t npix, hipStream_t s);
+hipError_t bf_launch_reduce_partials(const float* partial, int nblk, int width, float* out, float scale, hipStream_t s);
+hipError_t bf_launch_zero(float* p, int64_t n, hipStream_t s);

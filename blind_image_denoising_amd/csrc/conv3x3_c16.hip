@@ -1,0 +1,447 @@
+// 3x3, 16 -> 16 channel, stride-1 SAME convolutions on the gfx950 matrix cores.
+//
+// Reference semantics: keras Conv2D(3x3, use_bias=False, padding="same") inside conv2d_wrapper
+// (bfcnn/utilities.py:196) as the resnet blocks call it (bfcnn/backbone_blocks.py:174-196), the
+// BatchNormalization / activation that follow it (utilities.py:207-215) and the residual Add
+// (backbone_blocks.py:242).
+//
+// GEMM view per tap: D[cout][pixel] += W[cout][cin] * X[cin][pixel], exact fp32 on
+// v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain).  The weights are the A operand and live in 36
+// VGPRs per lane for the whole kernel; the activations are the B operand, one ds_read_b128 per
+// tap and 16-pixel group feeds four MFMAs (k-slot q of MFMA kk carries cin = 4q+kk).  The D
+// fragment leaves every lane with 4 consecutive output channels of one pixel, so stores are
+// 16 B per lane, 1 KiB contiguous per wave-instruction in NHWC.
+#include "bf_common.h"
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// ------------------------------------------------------------------------------------------
+// weight packing: HWIO [3,3,16,16] -> wpack[(tap*4+kk)*64 + lane] = W[tap][4*(lane>>4)+kk][lane&15]
+// transpose_flip = 1 packs the data-gradient kernel W'[tap][ci][co] = W[8-tap][co][ci].
+// ------------------------------------------------------------------------------------------
+__global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict__ wpack, int transpose_flip)
+{
+    for (int idx = threadIdx.x; idx < BF_WPACK_FLOATS; idx += blockDim.x) {
+        const int i = idx >> 6, l = idx & 63;
+        const int tap = i >> 2, kk = i & 3;
+        const int cin = 4 * (l >> 4) + kk, cout = l & 15;
+        wpack[idx] = transpose_flip ? w[((8 - tap) * 16 + cout) * 16 + cin]
+                                    : w[(tap * 16 + cin) * 16 + cout];
+    }
+}
+
+hipError_t bf_launch_pack_conv(const float* w_hwio, float* wpack, int transpose_flip, hipStream_t s)
+{
+    hipLaunchKernelGGL(pack_conv_kernel, dim3(1), dim3(256), 0, s, w_hwio, wpack, transpose_flip);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// generic single convolution with selectable epilogue
+// ------------------------------------------------------------------------------------------
+constexpr int CT_H = 16, CT_W = 32;            // output tile
+constexpr int CT_IH = CT_H + 2, CT_IW = CT_W + 2;
+
+template <int EPI>
+__global__ __launch_bounds__(256) void conv3x3_c16_kernel(ConvArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float tile[CT_IH * CT_IW * 16];   // 39,168 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (a.W + CT_W - 1) / CT_W, tiles_y = (a.H + CT_H - 1) / CT_H;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int y0 = ty * CT_H, x0 = tx * CT_W;
+    const size_t img = (size_t)b * a.H * a.W * 16;
+    const float* inb = a.in + img;
+
+    for (int n = tid; n < CT_IH * CT_IW * 4; n += 256) {
+        const int row = n / (CT_IW * 4);
+        const int rem = n - row * (CT_IW * 4);
+        const int gy = y0 - 1 + row, gx = x0 - 1 + (rem >> 2);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+            v = *reinterpret_cast<const float4*>(inb + ((size_t)gy * a.W + gx) * 16 + (rem & 3) * 4);
+        *reinterpret_cast<float4*>(tile + n * 4) = v;
+    }
+    float w[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) w[i] = a.wpack[i * 64 + lane];
+    __syncthreads();
+
+    const int p = lane & 15, q = lane >> 4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (EPI & EPI_AFFINE) {
+        sc = *reinterpret_cast<const f32x4*>(a.scale + q * 4);
+        sh = *reinterpret_cast<const f32x4*>(a.shift + q * 4);
+    }
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        f32x4 acc[4];
+        int base[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int gi = half * 4 + j;
+            const int r = 4 * wave + (gi >> 1), xo = (gi & 1) * 16;
+            base[j] = (r * CT_IW + xo + p) * 16 + q * 4;
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int off = ((tap / 3) * CT_IW + (tap % 3)) * 16;
+            f32x4 bv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const f32x4*>(tile + base[j] + off);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = MFMA(w[tap * 4 + kk], bv[j][kk], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gi = half * 4 + j;
+            const int gy = y0 + 4 * wave + (gi >> 1), gx = x0 + (gi & 1) * 16 + p;
+            if (gy < a.H && gx < a.W) {
+                const size_t idx = img + ((size_t)gy * a.W + gx) * 16 + q * 4;
+                f32x4 v = acc[j];
+                if (EPI & EPI_STATS) { s1 += v; s2 += v * v; }
+                if (EPI & EPI_AFFINE) v = v * sc + sh;
+                if (EPI & EPI_RELU) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                if (EPI & EPI_MASK) {
+                    const f32x4 m = *reinterpret_cast<const f32x4*>(a.mask + idx);
+                    v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+                    v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                }
+                if (EPI & EPI_RES) v += *reinterpret_cast<const f32x4*>(a.res + idx);
+                *reinterpret_cast<f32x4*>(a.out + idx) = v;
+            }
+        }
+    }
+
+    if (EPI & EPI_STATS) {
+        // reduce over the 16 pixel lanes that share a channel quad, then over the 4 waves
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s1[c] += __shfl_xor(s1[c], m);
+                s2[c] += __shfl_xor(s2[c], m);
+            }
+        }
+        __syncthreads();                       // tile no longer needed
+        float* red = tile;                     // [4 waves][32]
+        if (p == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                red[wave * 32 + q * 4 + c] = s1[c];
+                red[wave * 32 + 16 + q * 4 + c] = s2[c];
+            }
+        }
+        __syncthreads();
+        if (tid < 32)
+            a.stats[(size_t)blockIdx.x * 32 + tid] = (red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid]);
+    }
+}
+
+int bf_conv3x3_c16_grid(int B, int H, int W)
+{
+    return B * ((H + CT_H - 1) / CT_H) * ((W + CT_W - 1) / CT_W);
+}
+
+hipError_t bf_launch_conv3x3_c16(const ConvArgs& a, int epi, hipStream_t s)
+{
+    const dim3 grid(bf_conv3x3_c16_grid(a.B, a.H, a.W)), block(256);
+#define BF_CASE(E) case E: hipLaunchKernelGGL(conv3x3_c16_kernel<E>, grid, block, 0, s, a); break;
+    switch (epi) {
+        BF_CASE(0)
+        BF_CASE(EPI_RELU)
+        BF_CASE(EPI_STATS)
+        BF_CASE(EPI_AFFINE | EPI_RES)
+        BF_CASE(EPI_AFFINE)
+        BF_CASE(EPI_AFFINE | EPI_RELU)
+        BF_CASE(EPI_RES)
+        BF_CASE(EPI_MASK)
+        default: return hipErrorInvalidValue;
+    }
+#undef BF_CASE
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// fused residual block (inference): out = x + scale * conv2(act(conv1(x))) + shift
+// One HBM read and one HBM write of the 16-channel activation per BLOCK (72 FLOP/B instead of
+// 36); the intermediate activation only ever exists in LDS.  Tile 14x32 outputs: input tile
+// 18x36 px (41,472 B) + intermediate 16x34 px (34,816 B) = 76,288 B LDS -> two 4-wave
+// workgroups per CU, so one workgroup's tile load overlaps the other's MFMAs.  The 16x34 = 544
+// intermediate pixels are exactly 34 MFMA groups, the 14x32 = 448 outputs exactly 28.
+// Workgroups are persistent: weights (72 VGPRs) are fetched once; consecutive tiles of one
+// XCD-label (blockIdx % 8) are neighbours in the image so halos are L2 hits.
+// ------------------------------------------------------------------------------------------
+constexpr int FT_H = 14, FT_W = 32;
+constexpr int FT_MH = FT_H + 2, FT_MW = FT_W + 2;   // 16 x 34 intermediate
+constexpr int FT_IH = FT_H + 4, FT_IW = FT_W + 4;   // 18 x 36 input
+constexpr int FT_MG = FT_MH * FT_MW / 16;            // 34 groups
+constexpr int FT_OG = FT_H * FT_W / 16;              // 28 groups
+static_assert(FT_MH * FT_MW % 16 == 0 && FT_H * FT_W % 16 == 0, "tile must be whole MFMA groups");
+
+template <int NG>
+__device__ __forceinline__ void conv_groups(const float* __restrict__ src, const int (&base)[NG],
+                                            const int row_pitch, const float (&w)[36], f32x4 (&acc)[NG])
+{
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int off = ((tap / 3) * row_pitch + (tap % 3)) * 16;
+        f32x4 bv[NG];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) bv[j] = *reinterpret_cast<const f32x4*>(src + base[j] + off);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int j = 0; j < NG; ++j) acc[j] = MFMA(w[tap * 4 + kk], bv[j][kk], acc[j]);
+    }
+}
+
+template <int NG>
+__device__ __forceinline__ void conv2_pass(const FusedBlockArgs& a, const float* __restrict__ tin,
+                                           const float* __restrict__ tmid, const float (&w2)[36],
+                                           const f32x4 sc, const f32x4 sh, const int g_first,
+                                           const int p, const int q, const int y0, const int x0, const size_t img)
+{
+    int base[NG];
+    f32x4 acc[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int g = g_first + 4 * j;
+        const int oy = g >> 1, ox = (g & 1) * 16 + p;
+        base[j] = (oy * FT_MW + ox) * 16 + q * 4;
+        acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    conv_groups<NG>(tmid, base, FT_MW, w2, acc);
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int g = g_first + 4 * j;
+        const int oy = g >> 1, ox = (g & 1) * 16 + p;
+        const int gy = y0 + oy, gx = x0 + ox;
+        if (gy < a.H && gx < a.W) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(tin + ((oy + 2) * FT_IW + ox + 2) * 16 + q * 4);
+            const f32x4 v = acc[j] * sc + sh + r;
+            *reinterpret_cast<f32x4*>(a.out + img + ((size_t)gy * a.W + gx) * 16 + q * 4) = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void fused_block_kernel(FusedBlockArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* tin = lds;                                  // [18][36][16]
+    float* tmid = lds + FT_IH * FT_IW * 16;            // [16][34][16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 15, q = lane >> 4;
+
+    float w1[36], w2[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) { w1[i] = a.w1pack[i * 64 + lane]; w2[i] = a.w2pack[i * 64 + lane]; }
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + q * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + q * 4);
+
+    // XCD-aware persistent schedule: label = blockIdx % 8 owns a contiguous chunk of the tile
+    // sequence; its workgroups walk the chunk together (speed only, never correctness).
+    const int nxcd = gridDim.x >= 8 ? 8 : 1;
+    const int label = blockIdx.x % nxcd, slot = blockIdx.x / nxcd;
+    const int per_label = gridDim.x / nxcd;            // gridDim.x is a multiple of nxcd
+    const int chunk = (a.ntiles + nxcd - 1) / nxcd;
+    const int t_begin = label * chunk;
+    const int t_end = min(a.ntiles, t_begin + chunk);
+
+    for (int t = t_begin + slot; t < t_end; t += per_label) {
+        int tt = t;
+        const int tx = tt % a.tiles_x; tt /= a.tiles_x;
+        const int ty = tt % a.tiles_y;
+        const int b = tt / a.tiles_y;
+        const int y0 = ty * FT_H, x0 = tx * FT_W;
+        const size_t img = (size_t)b * a.H * a.W * 16;
+        const float* inb = a.in + img;
+
+        // ---- stage the input tile (2 px halo, zero outside the image) --------------------
+        for (int n = tid; n < FT_IH * FT_IW * 4; n += 256) {
+            const int row = n / (FT_IW * 4);
+            const int rem = n - row * (FT_IW * 4);
+            const int gy = y0 - 2 + row, gx = x0 - 2 + (rem >> 2);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                v = *reinterpret_cast<const float4*>(inb + ((size_t)gy * a.W + gx) * 16 + (rem & 3) * 4);
+            *reinterpret_cast<float4*>(tin + n * 4) = v;
+        }
+        __syncthreads();
+
+        // ---- conv1 (+activation) on the 16x34 intermediate region -> LDS -----------------
+        // group g covers flattened intermediate pixels 16g..16g+15; wave w takes g = w, w+4, ...
+        for (int g0 = wave; g0 < FT_MG; g0 += 12) {
+            // up to three groups per pass: g0, g0+4, g0+8
+            int base[3], f[3];
+            f32x4 acc[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                int g = g0 + 4 * j;
+                if (g >= FT_MG) g = g0;                    // duplicate work, result discarded
+                f[j] = g * 16 + p;
+                const int my = f[j] / FT_MW, mx = f[j] - my * FT_MW;
+                base[j] = (my * FT_IW + mx) * 16 + q * 4;
+                acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            conv_groups<3>(tin, base, FT_IW, w1, acc);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (g0 + 4 * j < FT_MG) {
+                    const int my = f[j] / FT_MW, mx = f[j] - my * FT_MW;
+                    const int gy = y0 - 1 + my, gx = x0 - 1 + mx;
+                    f32x4 v = acc[j];
+                    if (a.act1_relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    // conv2 sees ZERO padding outside the image, not conv1 evaluated there
+                    if (gy < 0 || gy >= a.H || gx < 0 || gx >= a.W) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4*>(tmid + f[j] * 16 + q * 4) = v;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- conv2 + folded BN + residual -> global ----------------------------------------
+        // 28 groups: wave w takes g = w, w+4, ..., w+24 (7 each): one pass of 4, one of 3
+        conv2_pass<4>(a, tin, tmid, w2, sc, sh, wave, p, q, y0, x0, img);
+        conv2_pass<3>(a, tin, tmid, w2, sc, sh, wave + 16, p, q, y0, x0, img);
+        __syncthreads();   // tin / tmid are overwritten by the next tile
+    }
+}
+
+hipError_t bf_launch_fused_block(const FusedBlockArgs& a0, hipStream_t s)
+{
+    FusedBlockArgs a = a0;
+    a.tiles_x = (a.W + FT_W - 1) / FT_W;
+    a.tiles_y = (a.H + FT_H - 1) / FT_H;
+    a.ntiles = a.B * a.tiles_x * a.tiles_y;
+    constexpr int lds_bytes = (FT_IH * FT_IW + FT_MH * FT_MW) * 16 * 4;   // 76,288
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_block_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    int grid = a.ntiles < 512 ? a.ntiles : 512;          // 2 workgroups per CU x 256 CUs
+    if (grid >= 8) grid -= grid % 8;
+    hipLaunchKernelGGL(fused_block_kernel, dim3(grid), dim3(256), lds_bytes, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient of the 3x3 16->16 convolution:
+//   dW[tap][ci][co] = sum over pixels of X[pixel + tap][ci] * dY[pixel][co]
+// GEMM view: M = ci, N = co, K = pixels (4 per MFMA; k-slot q of MFMA kk is pixel 4kk+q of a
+// 16-pixel group, which keeps the ds_read_b32 of both operands bank-conflict free).  One dY
+// fragment is shared by the nine taps (nine accumulators = 36 VGPRs).  Persistent workgroups
+// keep their partial dW in registers across tiles; partials are reduced in a fixed order
+// (no float atomics -> bitwise reproducible).
+// ------------------------------------------------------------------------------------------
+constexpr int WG_TH = 16, WG_TW = 32;
+constexpr int WG_IH = WG_TH + 2, WG_IW = WG_TW + 2;
+
+__global__ __launch_bounds__(256, 2) void wgrad3x3_c16_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              float* __restrict__ partial, int B, int H, int W,
+                                                              int tiles_x, int tiles_y, int ntiles)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* tx_ = lds;                               // [18][34][16]  x with halo
+    float* td = lds + WG_IH * WG_IW * 16;           // [16][32][16]  dy
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 15, q = lane >> 4;
+    f32x4 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int tt = t;
+        const int txi = tt % tiles_x; tt /= tiles_x;
+        const int tyi = tt % tiles_y;
+        const int b = tt / tiles_y;
+        const int y0 = tyi * WG_TH, x0 = txi * WG_TW;
+        const size_t img = (size_t)b * H * W * 16;
+        for (int n = tid; n < WG_IH * WG_IW * 4; n += 256) {
+            const int row = n / (WG_IW * 4);
+            const int rem = n - row * (WG_IW * 4);
+            const int gy = y0 - 1 + row, gx = x0 - 1 + (rem >> 2);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = *reinterpret_cast<const float4*>(x + img + ((size_t)gy * W + gx) * 16 + (rem & 3) * 4);
+            *reinterpret_cast<float4*>(tx_ + n * 4) = v;
+        }
+        for (int n = tid; n < WG_TH * WG_TW * 4; n += 256) {
+            const int row = n / (WG_TW * 4);
+            const int rem = n - row * (WG_TW * 4);
+            const int gy = y0 + row, gx = x0 + (rem >> 2);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy < H && gx < W)
+                v = *reinterpret_cast<const float4*>(dy + img + ((size_t)gy * W + gx) * 16 + (rem & 3) * 4);
+            *reinterpret_cast<float4*>(td + n * 4) = v;
+        }
+        __syncthreads();
+        // wave handles rows 4w..4w+3 of the tile: 8 groups of 16 pixels
+        for (int gi = 0; gi < 8; ++gi) {
+            const int r = 4 * wave + (gi >> 1), xo = (gi & 1) * 16;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int px = xo + 4 * kk + q;
+                const float bv = td[(r * WG_TW + px) * 16 + p];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float av = tx_[((r + tap / 3) * WG_IW + px + tap % 3) * 16 + p];
+                    acc[tap] = MFMA(av, bv, acc[tap]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // cross-wave reduction through LDS: [4][9][256]
+    float* red = lds;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            red[(wave * 9 + tap) * 256 + (4 * q + j) * 16 + p] = acc[tap][j];
+    __syncthreads();
+    for (int i = tid; i < 2304; i += 256)
+        partial[(size_t)blockIdx.x * 2304 + i] = (red[i] + red[2304 + i]) + (red[2 * 2304 + i] + red[3 * 2304 + i]);
+}
+
+int bf_wgrad_grid(int B, int H, int W)
+{
+    const int ntiles = B * ((H + WG_TH - 1) / WG_TH) * ((W + WG_TW - 1) / WG_TW);
+    return ntiles < 512 ? ntiles : 512;
+}
+
+hipError_t bf_launch_wgrad3x3_c16(const float* x, const float* dy, float* partial, float* dw,
+                                  int B, int H, int W, hipStream_t s)
+{
+    const int tiles_x = (W + WG_TW - 1) / WG_TW, tiles_y = (H + WG_TH - 1) / WG_TH;
+    const int ntiles = B * tiles_x * tiles_y;
+    const int grid = bf_wgrad_grid(B, H, W);
+    constexpr int lds_bytes = (WG_IH * WG_IW + WG_TH * WG_TW) * 16 * 4;   // 71,936
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_c16_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(wgrad3x3_c16_kernel, dim3(grid), dim3(256), lds_bytes, s, x, dy, partial, B, H, W,
+                       tiles_x, tiles_y, ntiles);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return bf_launch_reduce_partials(partial, grid, 2304, dw, 1.0f, s);
+}

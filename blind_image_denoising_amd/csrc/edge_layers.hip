@@ -1,0 +1,375 @@
+// The layers either side of the 3x3 C16 stack: input normalisation + base convolution, and the
+// denoiser head + denormalisation + uint8 store.  Both are HBM-bound (64 B/pixel of fp32
+// activations against <2 % of the FLOPs), so they are plain VALU kernels with 16-byte accesses.
+#include "bf_common.h"
+
+// ------------------------------------------------------------------------------------------
+// base convolution: [cast] -> [virtual pad_to_power_of_2] -> normalise -> conv k x k, Cin -> 16
+//   cast / pad : bfcnn/module_denoiser.py:53-56, bfcnn/utilities.py:736-751
+//   normalise  : bfcnn/model.py:100-102 -> bfcnn/utilities.py:449-461  clip(x)/(max-min) - 0.5
+//   conv       : bfcnn/backbone_resnet.py:137-147,258-262 (no BN on the base layer)
+// Source image [B,Hs,Ws,Cin] (u8 or f32); output [B,H,W,16] with H >= Hs, W >= Ws.  Pixels in
+// the padded band carry the value 0 (=> normalised -0.5), pixels outside HxW are conv zeros.
+// ------------------------------------------------------------------------------------------
+template <int CIN, int K, bool U8>
+__global__ __launch_bounds__(256) void base_conv_kernel(BaseConvArgs a)
+{
+    __shared__ float ws[K * K * CIN * 16];
+    for (int i = threadIdx.x; i < K * K * CIN * 16; i += 256) ws[i] = a.w[i];
+    __syncthreads();
+    const int64_t npix = (int64_t)a.B * a.H * a.W;
+    const float inv = 1.0f / (a.v_max - a.v_min);
+    for (int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * 256) {
+        const int x = (int)(pix % a.W);
+        const int64_t t = pix / a.W;
+        const int y = (int)(t % a.H);
+        const int b = (int)(t / a.H);
+        float acc[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int gy = y + ky - K / 2;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int gx = x + kx - K / 2;
+                if (gy < 0 || gy >= a.H || gx < 0 || gx >= a.W) continue;   // conv zero padding
+                float v[CIN];
+                if (gy < a.Hs && gx < a.Ws) {
+                    const int64_t si = (((int64_t)b * a.Hs + gy) * a.Ws + gx) * CIN;
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) {
+                        const float raw = U8 ? (float)reinterpret_cast<const uint8_t*>(a.in)[si + ci]
+                                             : reinterpret_cast<const float*>(a.in)[si + ci];
+                        v[ci] = (fminf(fmaxf(raw, a.v_min), a.v_max) - a.v_min) * inv - 0.5f;
+                    }
+                } else {
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci)       // pad_to_power_of_2 band: value 0
+                        v[ci] = (fminf(fmaxf(0.f, a.v_min), a.v_max) - a.v_min) * inv - 0.5f;
+                }
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) {
+                    const float* wr = ws + ((ky * K + kx) * CIN + ci) * 16;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) acc[c] = fmaf(v[ci], wr[c], acc[c]);
+                }
+            }
+        }
+        if (a.act_relu) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[c] = fmaxf(acc[c], 0.f);
+        }
+        float4* o = reinterpret_cast<float4*>(a.out + pix * 16);
+        o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        o[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
+        o[3] = make_float4(acc[12], acc[13], acc[14], acc[15]);
+    }
+}
+
+template <int CIN, int K>
+static hipError_t launch_base(const BaseConvArgs& a, hipStream_t s)
+{
+    const int64_t npix = (int64_t)a.B * a.H * a.W;
+    int64_t g = (npix + 255) / 256;
+    const int grid = (int)(g < 8192 ? g : 8192);
+    if (a.in_is_u8) hipLaunchKernelGGL((base_conv_kernel<CIN, K, true>), dim3(grid), dim3(256), 0, s, a);
+    else            hipLaunchKernelGGL((base_conv_kernel<CIN, K, false>), dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t bf_launch_base_conv(const BaseConvArgs& a, hipStream_t s)
+{
+#define BF_BASE(C, KK) if (a.cin == C && a.k == KK) return launch_base<C, KK>(a, s);
+    BF_BASE(3, 3) BF_BASE(3, 5) BF_BASE(3, 7) BF_BASE(3, 1)
+    BF_BASE(1, 3) BF_BASE(1, 5) BF_BASE(1, 7) BF_BASE(1, 1)
+#undef BF_BASE
+    return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------
+// base convolution weight gradient  dW[ky,kx,ci,co] = sum xn[pix + tap][ci] * dy[pix][co]
+// (tape.gradient of bfcnn/train_loop.py:302-304 for the base kernel).  Persistent workgroups,
+// LDS-staged tiles, one thread per (tap,ci,co) output, fixed-order partial reduction.
+// ------------------------------------------------------------------------------------------
+constexpr int BW_TH = 16, BW_TW = 32;
+
+template <int CIN, int K>
+__global__ __launch_bounds__(512) void base_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ dy,
+                                                         float* __restrict__ partial, int B, int H, int W,
+                                                         float v_min, float v_max, int tiles_x, int tiles_y, int ntiles)
+{
+    constexpr int R = K / 2, IH = BW_TH + 2 * R, IW = BW_TW + 2 * R;
+    constexpr int NOUT = K * K * CIN * 16, PER = (NOUT + 511) / 512;
+    __shared__ float tx_[IH * IW * CIN];
+    __shared__ __attribute__((aligned(16))) float td[BW_TH * BW_TW * 16];
+    const int tid = threadIdx.x;
+    const float inv = 1.0f / (v_max - v_min);
+    float acc[PER];
+    int xoff[PER], co[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        acc[i] = 0.f;
+        int o = tid + i * 512;
+        if (o >= NOUT) o = 0;
+        co[i] = o & 15;
+        const int ci = (o >> 4) % CIN, tap = (o >> 4) / CIN;
+        xoff[i] = ((tap / K) * IW + (tap % K)) * CIN + ci;
+    }
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int tt = t;
+        const int txi = tt % tiles_x; tt /= tiles_x;
+        const int tyi = tt % tiles_y;
+        const int b = tt / tiles_y;
+        const int y0 = tyi * BW_TH, x0 = txi * BW_TW;
+        for (int n = tid; n < IH * IW * CIN; n += 512) {
+            const int ci = n % CIN, px = (n / CIN) % IW, row = n / (CIN * IW);
+            const int gy = y0 - R + row, gx = x0 - R + px;
+            float v = 0.f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const float raw = in[(((int64_t)b * H + gy) * W + gx) * CIN + ci];
+                v = (fminf(fmaxf(raw, v_min), v_max) - v_min) * inv - 0.5f;
+            }
+            tx_[n] = v;
+        }
+        for (int n = tid; n < BW_TH * BW_TW * 4; n += 512) {
+            const int row = n / (BW_TW * 4), rem = n - row * (BW_TW * 4);
+            const int gy = y0 + row, gx = x0 + (rem >> 2);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy < H && gx < W)
+                v = *reinterpret_cast<const float4*>(dy + (((int64_t)b * H + gy) * W + gx) * 16 + (rem & 3) * 4);
+            *reinterpret_cast<float4*>(td + n * 4) = v;
+        }
+        __syncthreads();
+        for (int r = 0; r < BW_TH; ++r)
+            for (int c = 0; c < BW_TW; ++c) {
+                const int pb = (r * IW + c) * CIN, db = (r * BW_TW + c) * 16;
+#pragma unroll
+                for (int i = 0; i < PER; ++i) acc[i] = fmaf(tx_[pb + xoff[i]], td[db + co[i]], acc[i]);
+            }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int o = tid + i * 512;
+        if (o < NOUT) partial[(size_t)blockIdx.x * NOUT + o] = acc[i];
+    }
+}
+
+int bf_base_wgrad_grid(int B, int H, int W)
+{
+    const int ntiles = B * ((H + BW_TH - 1) / BW_TH) * ((W + BW_TW - 1) / BW_TW);
+    return ntiles < 512 ? ntiles : 512;
+}
+
+template <int CIN, int K>
+static hipError_t launch_base_wgrad(const float* in, const float* dy, float* partial, float* dw, int B, int H, int W,
+                                    float v_min, float v_max, hipStream_t s)
+{
+    const int tiles_x = (W + BW_TW - 1) / BW_TW, tiles_y = (H + BW_TH - 1) / BW_TH;
+    const int ntiles = B * tiles_x * tiles_y, grid = bf_base_wgrad_grid(B, H, W);
+    hipLaunchKernelGGL((base_wgrad_kernel<CIN, K>), dim3(grid), dim3(512), 0, s, in, dy, partial, B, H, W, v_min, v_max,
+                       tiles_x, tiles_y, ntiles);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return bf_launch_reduce_partials(partial, grid, K * K * CIN * 16, dw, 1.0f, s);
+}
+
+hipError_t bf_launch_base_wgrad(const float* in, const float* dy, float* partial, float* dw, int B, int H, int W,
+                                int cin, int k, float v_min, float v_max, hipStream_t s)
+{
+#define BF_BW(C, KK) if (cin == C && k == KK) return launch_base_wgrad<C, KK>(in, dy, partial, dw, B, H, W, v_min, v_max, s);
+    BF_BW(3, 3) BF_BW(3, 5) BF_BW(3, 7) BF_BW(3, 1)
+    BF_BW(1, 3) BF_BW(1, 5) BF_BW(1, 7) BF_BW(1, 1)
+#undef BF_BW
+    return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------
+// denoiser head (bfcnn/model.py:297-342): 1x1 16->hf (activation) -> 1x1 hf->cout -> tanh(2x)*0.51
+// then denormalise (model.py:136-139 / utilities.py:435-443), remove_padding (crop to Ho x Wo,
+// utilities.py:755-764), tf.round (half-to-even) and the uint8 cast (module_denoiser.py:71-73).
+// With a linear first 1x1 the two matrices are pre-multiplied at pack time (wh[16][4]).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf_act(float x, int act, float alpha)
+{
+    if (act == BF_ACT_RELU) return fmaxf(x, 0.f);
+    if (act == BF_ACT_LEAKY_RELU) return x > 0.f ? x : alpha * x;
+    return x;
+}
+
+template <bool U8>
+__global__ __launch_bounds__(256) void head_kernel(HeadArgs a)
+{
+    __shared__ float w0s[16 * 64];
+    __shared__ float w1s[64 * 4];
+    __shared__ float whs[64];
+    const bool fused = a.wh != nullptr;
+    if (fused) {
+        for (int i = threadIdx.x; i < 64; i += 256) whs[i] = a.wh[i];
+    } else {
+        for (int i = threadIdx.x; i < 16 * a.hf; i += 256) w0s[i] = a.w0[i];
+        for (int i = threadIdx.x; i < a.hf * a.cout; i += 256) w1s[i] = a.w1[i];
+    }
+    __syncthreads();
+    const int64_t npix = (int64_t)a.B * a.Ho * a.Wo;
+    for (int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * 256) {
+        const int x = (int)(pix % a.Wo);
+        const int64_t t = pix / a.Wo;
+        const int y = (int)(t % a.Ho);
+        const int b = (int)(t / a.Ho);
+        const float4* fp = reinterpret_cast<const float4*>(a.feat + (((int64_t)b * a.H + y) * a.W + x) * 16);
+        float f[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 v = fp[i];
+            f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
+        }
+        float h1[4] = {0.f, 0.f, 0.f, 0.f};
+        if (fused) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+#pragma unroll
+                for (int o = 0; o < 4; ++o) h1[o] = fmaf(f[c], whs[c * 4 + o], h1[o]);
+        } else {
+            for (int j = 0; j < a.hf; ++j) {
+                float h = 0.f;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) h = fmaf(f[c], w0s[c * a.hf + j], h);
+                h = bf_act(h, a.act, a.leaky_alpha);
+                for (int o = 0; o < a.cout; ++o) h1[o] = fmaf(h, w1s[j * a.cout + o], h1[o]);
+            }
+        }
+        for (int o = 0; o < a.cout; ++o) {
+            float v = tanhf(2.0f * h1[o]) * 0.51f;
+            if (a.denormalize) v = (fminf(fmaxf(v, -0.5f), 0.5f) + 0.5f) * (a.v_max - a.v_min) + a.v_min;
+            if (U8) {
+                const float r = fminf(fmaxf(rintf(v), 0.f), 255.f);     // rintf = round-half-even
+                reinterpret_cast<uint8_t*>(a.out)[pix * a.cout + o] = (uint8_t)r;
+            } else {
+                reinterpret_cast<float*>(a.out)[pix * a.cout + o] = v;
+            }
+        }
+    }
+}
+
+hipError_t bf_launch_head(const HeadArgs& a, hipStream_t s)
+{
+    const int64_t npix = (int64_t)a.B * a.Ho * a.Wo;
+    int64_t g = (npix + 255) / 256;
+    const int grid = (int)(g < 8192 ? g : 8192);
+    if (a.out_is_u8) hipLaunchKernelGGL(head_kernel<true>, dim3(grid), dim3(256), 0, s, a);
+    else             hipLaunchKernelGGL(head_kernel<false>, dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// training head: forward + L1 loss (bfcnn/loss.py:40-65,190-247) + backward to the features.
+// Linear head only: with h1 = feat.Wh every head weight gradient follows from
+// M[c][o] = sum_pix feat[c]*dh1[o]  (dW1 = W0^T M, dW0 = M W1^T), so a thread only carries
+// 16*cout accumulators.  One workgroup handles pixels of ONE image (per-image sum of squares
+// for the rmse metric, loss.py:92-113).  partial row layout (80 floats):
+//   [0,64) M[c*4+o] | 64 sum|e| | 65 sum relu(|e|,hinge,cutoff) | 66 sum e^2 | 67.. unused
+// ------------------------------------------------------------------------------------------
+constexpr int HT_BLOCKS_PER_IMAGE_MAX = 64;
+
+__global__ __launch_bounds__(256) void head_train_kernel(HeadTrainArgs a, int blocks_per_image)
+{
+    __shared__ float whs[64];
+    __shared__ float red[4][80];
+    if (threadIdx.x < 64) whs[threadIdx.x] = a.wh[threadIdx.x];
+    __syncthreads();
+    const int b = blockIdx.x / blocks_per_image, sub = blockIdx.x % blocks_per_image;
+    const int hw = a.H * a.W;
+    float M[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) M[i] = 0.f;
+    float s_abs = 0.f, s_hinge = 0.f, s_sq = 0.f;
+    for (int pi = sub * 256 + threadIdx.x; pi < hw; pi += blocks_per_image * 256) {
+        const int64_t pix = (int64_t)b * hw + pi;
+        const float4* fp = reinterpret_cast<const float4*>(a.feat + pix * 16);
+        float f[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 v = fp[i];
+            f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
+        }
+        float dh1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            if (o < a.cout) {
+                float h = 0.f;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) h = fmaf(f[c], whs[c * 4 + o], h);
+                const float th = tanhf(2.0f * h);
+                const float pv = th * 0.51f;
+                float pred = pv, dpred_dp = 1.0f;
+                if (a.denormalize) {
+                    pred = (fminf(fmaxf(pv, -0.5f), 0.5f) + 0.5f) * (a.v_max - a.v_min) + a.v_min;
+                    dpred_dp = (pv >= -0.5f && pv <= 0.5f) ? (a.v_max - a.v_min) : 0.f;
+                }
+                if (a.pred) a.pred[pix * a.cout + o] = pred;
+                const float e = a.gt[pix * a.cout + o] - pred;
+                const float ae = fabsf(e);
+                s_abs += fminf(ae, 255.0f);                  // mae_actual: hinge 0, cutoff 255
+                s_hinge += ae > a.hinge ? fminf(ae, a.cutoff) : 0.f;
+                const float ep = e > 0.f ? fminf(e, 255.0f) : 0.f;   // rmse_diff: relu on the signed error
+                s_sq += ep * ep;
+                float dpred = 0.f;
+                if (ae > a.hinge && ae < a.cutoff) dpred = (e > 0.f ? -1.f : (e < 0.f ? 1.f : 0.f)) * a.dscale;
+                dh1[o] = dpred * dpred_dp * (0.51f * 2.0f) * (1.0f - th * th);
+            }
+        }
+        float df[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float d = 0.f;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                d = fmaf(dh1[o], whs[c * 4 + o], d);
+                M[c * 4 + o] = fmaf(f[c], dh1[o], M[c * 4 + o]);
+            }
+            df[c] = d;
+        }
+        float4* dp = reinterpret_cast<float4*>(a.dfeat + pix * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dp[i] = make_float4(df[4 * i], df[4 * i + 1], df[4 * i + 2], df[4 * i + 3]);
+    }
+    // wave reduction then cross-wave through LDS (fixed order)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        float v = M[i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+        if (lane == 0) red[wave][i] = v;
+    }
+    float sv[3] = {s_abs, s_hinge, s_sq};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float v = sv[i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+        if (lane == 0) red[wave][64 + i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 80) {
+        const int i = threadIdx.x;
+        a.partial[(size_t)blockIdx.x * 80 + i] = i < 67 ? (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]) : 0.f;
+    }
+}
+
+int bf_head_train_grid(int B, int H, int W)
+{
+    int bpi = (H * W + 1023) / 1024;
+    if (bpi > HT_BLOCKS_PER_IMAGE_MAX) bpi = HT_BLOCKS_PER_IMAGE_MAX;
+    if (bpi < 1) bpi = 1;
+    return B * bpi;
+}
+
+hipError_t bf_launch_head_train(const HeadTrainArgs& a, int grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(head_train_kernel, dim3(grid), dim3(256), 0, s, a, grid / a.B);
+    return hipGetLastError();
+}

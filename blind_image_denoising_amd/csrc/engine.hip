@@ -1,0 +1,723 @@
+// C-ABI engine: validates the model description, lays out parameters exactly as keras creates
+// the trainable variables, and turns DenoiserModule.__call__ / hydra() / train_step_single_gpu /
+// apply_grads into stream-ordered launch sequences of the gfx950 kernels.
+// The library owns no device memory and never synchronises (include/bfcnn_hip.h).
+#include "bf_common.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+
+struct bf_engine {
+    bf_resnet_desc d;
+    std::string err;
+    std::vector<bf_tensor_info> tensors, states;
+    int64_t n_params = 0, n_state = 0;
+    // parameter offsets (floats)
+    int64_t p_base = 0, p_blocks = 0, p_block_stride = 0, p_head0 = 0, p_head1 = 0;
+    int64_t n_base = 0;
+    // packed-inference layout (floats)
+    int64_t k_base = 0, k_blocks = 0, k_block_stride = 0, k_w0 = 0, k_w1 = 0, k_wh = 0, k_total = 0;
+    int fused_blocks = 1;
+};
+
+static thread_local std::string g_create_error;
+
+static int fail(bf_handle h, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+static int hip_fail(bf_handle h, hipError_t e, const char* what)
+{
+    return fail(h, BF_EHIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define BF_HIP(call, what) do { hipError_t e__ = (call); if (e__ != hipSuccess) return hip_fail(h, e__, what); } while (0)
+
+static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+extern "C" int bf_abi_version(void) { return BFCNN_ABI_VERSION; }
+
+extern "C" const char* bf_last_error(bf_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+static void add_tensor(std::vector<bf_tensor_info>& v, const char* name, int64_t& off, int rank, int s0, int s1, int s2,
+                       int s3, int kind, int reg)
+{
+    bf_tensor_info t;
+    memset(&t, 0, sizeof(t));
+    snprintf(t.name, sizeof(t.name), "%s", name);
+    t.offset = off;
+    t.rank = rank;
+    t.shape[0] = s0; t.shape[1] = s1; t.shape[2] = s2; t.shape[3] = s3;
+    t.kind = kind;
+    t.regularizer = reg;
+    int64_t n = 1;
+    for (int i = 0; i < rank; ++i) n *= t.shape[i];
+    off += n;
+    v.push_back(t);
+}
+
+// model_builder (bfcnn/model.py:58-162) -> backbone_resnet.builder (backbone_resnet.py:19-298)
+// argument checks, restricted to the configurations the gfx950 kernels are built for.
+extern "C" int bf_create(const bf_resnet_desc* d, bf_handle* out)
+{
+    if (out) *out = nullptr;
+    if (!d || !out) return fail(nullptr, BF_EINVAL, "bf_create: desc/out must not be NULL");
+    if (d->struct_size != (int32_t)sizeof(bf_resnet_desc))
+        return fail(nullptr, BF_EINVAL, "bf_create: struct_size %d != %d (ABI mismatch)", d->struct_size, (int)sizeof(bf_resnet_desc));
+    if (d->no_layers < 0) return fail(nullptr, BF_EINVAL, "no_layers must be >= 0");              // backbone_blocks.py:122
+    if (d->block_convs <= 0) return fail(nullptr, BF_EINVAL, "len(block_kernels) must be >= 0 "); // backbone_resnet.py:111
+    if (d->block_convs > 3) return fail(nullptr, BF_EINVAL, "len(block_kernels) must be <= 3");   // backbone_resnet.py:113
+    if (d->in_channels != 1 && d->in_channels != 3)
+        return fail(nullptr, BF_EUNSUPPORTED, "in_channels %d: only 1 and 3 are built", d->in_channels);
+    if (d->filters != BF_C) return fail(nullptr, BF_EUNSUPPORTED, "filters %d: the MFMA path is built for 16", d->filters);
+    if (d->kernel_size != 1 && d->kernel_size != 3 && d->kernel_size != 5 && d->kernel_size != 7)
+        return fail(nullptr, BF_EUNSUPPORTED, "base kernel_size %d: only 1,3,5,7", d->kernel_size);
+    if (d->block_convs != 2 || d->block_kernel != 3)
+        return fail(nullptr, BF_EUNSUPPORTED, "block_kernels must be [3,3] (got %d convs of %d)", d->block_convs, d->block_kernel);
+    if (d->activation != BF_ACT_RELU && d->activation != BF_ACT_LINEAR)
+        return fail(nullptr, BF_EUNSUPPORTED, "block activation must be relu or linear");
+    if (d->base_activation != BF_ACT_LINEAR)
+        return fail(nullptr, BF_EUNSUPPORTED, "base_activation must be linear");
+    if (d->head_filters < 1 || d->head_filters > 64) return fail(nullptr, BF_EUNSUPPORTED, "head filters must be in 1..64");
+    if (d->out_channels < 1 || d->out_channels > 4) return fail(nullptr, BF_EUNSUPPORTED, "output_channels must be in 1..4");
+    if (!(d->v_max > d->v_min)) return fail(nullptr, BF_EINVAL, "value_range must have max > min");
+
+    bf_engine* h = new bf_engine();
+    h->d = *d;
+    const int k = d->kernel_size, cin = d->in_channels, hf = d->head_filters, co = d->out_channels;
+    int64_t off = 0;
+    h->p_base = off;
+    add_tensor(h->tensors, "base/kernel", off, 4, k, k, cin, BF_C, BF_KIND_CONV, d->reg_base);
+    h->n_base = off;
+    h->p_blocks = off;
+    h->p_block_stride = 2 * 2304 + (d->use_bn ? 16 : 0);
+    char name[64];
+    for (int i = 0; i < d->no_layers; ++i) {
+        snprintf(name, sizeof(name), "block%d/conv0/kernel", i);
+        add_tensor(h->tensors, name, off, 4, 3, 3, BF_C, BF_C, BF_KIND_CONV, d->reg_block);
+        snprintf(name, sizeof(name), "block%d/conv1/kernel", i);
+        add_tensor(h->tensors, name, off, 4, 3, 3, BF_C, BF_C, BF_KIND_CONV, d->reg_block);
+        if (d->use_bn) {
+            snprintf(name, sizeof(name), "block%d/bn1/gamma", i);
+            add_tensor(h->tensors, name, off, 1, BF_C, 0, 0, 0, BF_KIND_GAMMA, BF_REG_NONE);
+        }
+    }
+    h->p_head0 = off;
+    add_tensor(h->tensors, "head/conv0/kernel", off, 4, 1, 1, BF_C, hf, BF_KIND_CONV, d->reg_head);
+    h->p_head1 = off;
+    add_tensor(h->tensors, "head/conv1/kernel", off, 4, 1, 1, hf, co, BF_KIND_CONV, d->reg_head);
+    h->n_params = off;
+    int64_t soff = 0;
+    if (d->use_bn) {
+        for (int i = 0; i < d->no_layers; ++i) {
+            snprintf(name, sizeof(name), "block%d/bn1/moving_mean", i);
+            add_tensor(h->states, name, soff, 1, BF_C, 0, 0, 0, BF_KIND_MOVING_MEAN, BF_REG_NONE);
+            snprintf(name, sizeof(name), "block%d/bn1/moving_variance", i);
+            add_tensor(h->states, name, soff, 1, BF_C, 0, 0, 0, BF_KIND_MOVING_VAR, BF_REG_NONE);
+        }
+    }
+    h->n_state = soff;
+    // packed layout
+    int64_t ko = 0;
+    h->k_base = ko; ko += align_up(h->n_base, 64);
+    h->k_blocks = ko; h->k_block_stride = 2 * BF_WPACK_FLOATS + 32; ko += h->k_block_stride * d->no_layers;
+    h->k_w0 = ko; ko += align_up(16 * hf, 64);
+    h->k_w1 = ko; ko += align_up(hf * co, 64);
+    h->k_wh = ko; ko += 64;
+    h->k_total = ko;
+    *out = h;
+    return BF_OK;
+}
+
+extern "C" void bf_destroy(bf_handle h) { delete h; }
+extern "C" int64_t bf_param_count(bf_handle h) { return h ? h->n_params : -1; }
+extern "C" int64_t bf_state_count(bf_handle h) { return h ? h->n_state : -1; }
+extern "C" int bf_tensor_count(bf_handle h, int state) { return h ? (int)(state ? h->states.size() : h->tensors.size()) : -1; }
+
+extern "C" int bf_tensor_at(bf_handle h, int state, int index, bf_tensor_info* out)
+{
+    if (!h || !out) return BF_EINVAL;
+    const auto& v = state ? h->states : h->tensors;
+    if (index < 0 || index >= (int)v.size()) return fail(h, BF_EINVAL, "tensor index %d out of range", index);
+    *out = v[index];
+    return BF_OK;
+}
+
+extern "C" int bf_set_option(bf_handle h, const char* key, int value)
+{
+    if (!h || !key) return BF_EINVAL;
+    if (!strcmp(key, "fused_blocks")) { h->fused_blocks = value ? 1 : 0; return BF_OK; }
+    return fail(h, BF_EINVAL, "unknown option [%s]", key);
+}
+
+extern "C" int64_t bf_packed_bytes(bf_handle h) { return h ? h->k_total * 4 : -1; }
+
+// ------------------------------------------------------------------------------------------
+// pow2 target of pad_to_power_of_2 (bfcnn/utilities.py:736-751): the reference evaluates
+// 2^ceil(log(n)/log(2)) in float32; for every n <= 4096 that equals the exact next power of two
+// (checked in tests/test_oracle_properties.py), which is what is computed here.
+// ------------------------------------------------------------------------------------------
+static int pow2_target(int n)
+{
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+// ---- tiny pack kernels ---------------------------------------------------------------------
+__global__ void pack_all_convs_kernel(const float* __restrict__ params, int64_t p_blocks, int64_t p_stride, float* __restrict__ dst,
+                                      int64_t d_stride, int with_dgrad)
+{
+    // blockIdx.x = layer * (with_dgrad ? 4 : 2) + which ; which: 0 w1 fwd, 1 w2 fwd, 2 w1 dgrad, 3 w2 dgrad
+    const int per = with_dgrad ? 4 : 2;
+    const int layer = blockIdx.x / per, which = blockIdx.x % per;
+    const float* w = params + p_blocks + layer * p_stride + (which & 1) * 2304;
+    float* o = dst + layer * d_stride + which * BF_WPACK_FLOATS;
+    const int tf = which >> 1;
+    for (int idx = threadIdx.x; idx < BF_WPACK_FLOATS; idx += blockDim.x) {
+        const int i = idx >> 6, l = idx & 63;
+        const int tap = i >> 2, kk = i & 3;
+        const int cin = 4 * (l >> 4) + kk, cout = l & 15;
+        o[idx] = tf ? w[((8 - tap) * 16 + cout) * 16 + cin] : w[(tap * 16 + cin) * 16 + cout];
+    }
+}
+
+// folded inference BN: keras BatchNormalization(training=False): gamma*(x-mean)*rsqrt(var+eps)
+__global__ void fold_bn_kernel(const float* __restrict__ params, const float* __restrict__ state, int64_t p_blocks, int64_t p_stride,
+                               float* __restrict__ packed, int64_t k_blocks, int64_t k_stride, int layers, int use_bn, float eps)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= layers * 16) return;
+    const int layer = i / 16, c = i % 16;
+    float sc = 1.f, sh = 0.f;
+    if (use_bn) {
+        const float g = params[p_blocks + layer * p_stride + 4608 + c];
+        const float mean = state[layer * 32 + c], var = state[layer * 32 + 16 + c];
+        sc = g / sqrtf(var + eps);
+        sh = -sc * mean;
+    }
+    float* o = packed + k_blocks + layer * k_stride + 2 * BF_WPACK_FLOATS;
+    o[c] = sc;
+    o[16 + c] = sh;
+}
+
+__global__ void pack_edges_kernel(const float* __restrict__ params, float* __restrict__ packed, int64_t p_base, int64_t n_base,
+                                  int64_t p_head0, int64_t p_head1, int hf, int co, int64_t k_base, int64_t k_w0, int64_t k_w1,
+                                  int64_t k_wh)
+{
+    for (int i = threadIdx.x; i < n_base; i += blockDim.x) packed[k_base + i] = params[p_base + i];
+    for (int i = threadIdx.x; i < 16 * hf; i += blockDim.x) packed[k_w0 + i] = params[p_head0 + i];
+    for (int i = threadIdx.x; i < hf * co; i += blockDim.x) packed[k_w1 + i] = params[p_head1 + i];
+    if (threadIdx.x < 64) {
+        const int c = threadIdx.x >> 2, o = threadIdx.x & 3;
+        float s = 0.f;
+        if (o < co)
+            for (int j = 0; j < hf; ++j) s = fmaf(params[p_head0 + c * hf + j], params[p_head1 + j * co + o], s);
+        packed[k_wh + threadIdx.x] = s;
+    }
+}
+
+extern "C" int bf_pack_inference(bf_handle h, const float* params, const float* state, void* packed, void* stream)
+{
+    if (!h) return BF_EINVAL;
+    if (!params || !packed || (h->n_state > 0 && !state)) return fail(h, BF_EINVAL, "bf_pack_inference: NULL buffer");
+    if ((uintptr_t)packed % 16) return fail(h, BF_EWORKSPACE, "packed buffer must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    float* pk = (float*)packed;
+    const bf_resnet_desc& d = h->d;
+    if (d.no_layers > 0) {
+        hipLaunchKernelGGL(pack_all_convs_kernel, dim3(d.no_layers * 2), dim3(256), 0, s, params, h->p_blocks, h->p_block_stride,
+                           pk + h->k_blocks, h->k_block_stride, 0);
+        BF_HIP(hipGetLastError(), "pack_all_convs");
+        hipLaunchKernelGGL(fold_bn_kernel, dim3((d.no_layers * 16 + 255) / 256), dim3(256), 0, s, params, state, h->p_blocks,
+                           h->p_block_stride, pk, h->k_blocks, h->k_block_stride, d.no_layers, d.use_bn, d.bn_eps);
+        BF_HIP(hipGetLastError(), "fold_bn");
+    }
+    hipLaunchKernelGGL(pack_edges_kernel, dim3(1), dim3(256), 0, s, params, pk, h->p_base, h->n_base, h->p_head0, h->p_head1,
+                       d.head_filters, d.out_channels, h->k_base, h->k_w0, h->k_w1, h->k_wh);
+    BF_HIP(hipGetLastError(), "pack_edges");
+    return BF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// workspace layout
+// ------------------------------------------------------------------------------------------
+struct TrainLayout {
+    int64_t wpack, wh, bn_scale, bn_meaninv, coef, partial, acts, total;   // float offsets
+    int64_t act_floats, partial_floats;
+};
+
+static int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
+
+static TrainLayout train_layout(bf_handle h, int B, int H, int W)
+{
+    TrainLayout L;
+    const int N = h->d.no_layers;
+    int64_t o = 0;
+    L.wpack = o; o += (int64_t)N * 4 * BF_WPACK_FLOATS;
+    L.wh = o; o += 64;
+    L.bn_scale = o; o += (int64_t)N * 32 + 32;
+    L.bn_meaninv = o; o += (int64_t)N * 32 + 32;
+    L.coef = o; o += 64;
+    int64_t pf = (int64_t)bf_conv3x3_c16_grid(B, H, W) * 32;
+    pf = max64(pf, 4096 * 32);
+    pf = max64(pf, (int64_t)bf_wgrad_grid(B, H, W) * 2304);
+    pf = max64(pf, (int64_t)bf_base_wgrad_grid(B, H, W) * h->n_base);
+    pf = max64(pf, (int64_t)bf_head_train_grid(B, H, W) * 80);
+    L.partial_floats = align_up(pf, 64);
+    L.partial = o; o += L.partial_floats + 256;     // +256: reduced head sums / scratch
+    o = align_up(o, 64);
+    L.act_floats = (int64_t)B * H * W * 16;
+    L.acts = o; o += L.act_floats * (3 * (int64_t)N + 2);
+    L.total = o;
+    return L;
+}
+
+extern "C" int64_t bf_workspace_bytes(bf_handle h, int mode, int B, int H, int W)
+{
+    if (!h || B <= 0 || H <= 0 || W <= 0) return -1;
+    if (mode == BF_MODE_INFERENCE) {
+        const int Hp = pow2_target(H), Wp = pow2_target(W);      // u8 path pads; f32 path needs <= this
+        return (int64_t)B * Hp * Wp * 16 * 4 * 3;
+    }
+    return train_layout(h, B, H, W).total * 4;
+}
+
+// ------------------------------------------------------------------------------------------
+// inference
+// ------------------------------------------------------------------------------------------
+static int forward_common(bf_handle h, const float* pk, const void* in, int in_is_u8, void* out, int out_is_u8, int B, int Hs,
+                          int Ws, int H, int W, void* ws, int64_t ws_bytes, hipStream_t s)
+{
+    const bf_resnet_desc& d = h->d;
+    const int64_t act_bytes = (int64_t)B * H * W * 16 * 4;
+    if (!ws || (uintptr_t)ws % 16) return fail(h, BF_EWORKSPACE, "workspace must be a 16-byte aligned device buffer");
+    if (ws_bytes < act_bytes * 3) return fail(h, BF_EWORKSPACE, "workspace too small: %lld < %lld bytes", (long long)ws_bytes,
+                                              (long long)(act_bytes * 3));
+    float* buf[3] = {(float*)ws, (float*)((char*)ws + act_bytes), (float*)((char*)ws + 2 * act_bytes)};
+
+    BaseConvArgs ba;
+    ba.in = in; ba.out = buf[0]; ba.w = pk + h->k_base;
+    ba.B = B; ba.Hs = Hs; ba.Ws = Ws; ba.H = H; ba.W = W; ba.cin = d.in_channels; ba.k = d.kernel_size;
+    ba.in_is_u8 = in_is_u8; ba.act_relu = d.base_activation == BF_ACT_RELU;
+    ba.v_min = d.v_min; ba.v_max = d.v_max;
+    BF_HIP(bf_launch_base_conv(ba, s), "base_conv");
+
+    int cur = 0;
+    for (int i = 0; i < d.no_layers; ++i) {
+        const float* blk = pk + h->k_blocks + i * h->k_block_stride;
+        if (h->fused_blocks) {
+            FusedBlockArgs fa;
+            fa.in = buf[cur]; fa.out = buf[cur ^ 1];
+            fa.w1pack = blk; fa.w2pack = blk + BF_WPACK_FLOATS;
+            fa.scale = blk + 2 * BF_WPACK_FLOATS; fa.shift = fa.scale + 16;
+            fa.B = B; fa.H = H; fa.W = W; fa.tiles_x = fa.tiles_y = fa.ntiles = 0;
+            fa.act1_relu = d.activation == BF_ACT_RELU;
+            BF_HIP(bf_launch_fused_block(fa, s), "fused_block");
+            cur ^= 1;
+        } else {
+            // unfused: T = act(conv1 x) ; y = x + scale*conv2(T) + shift
+            const int t = (cur + 1) % 3, y = (cur + 2) % 3;
+            ConvArgs ca;
+            memset(&ca, 0, sizeof(ca));
+            ca.in = buf[cur]; ca.out = buf[t]; ca.wpack = blk; ca.B = B; ca.H = H; ca.W = W;
+            BF_HIP(bf_launch_conv3x3_c16(ca, d.activation == BF_ACT_RELU ? EPI_RELU : 0, s), "conv1");
+            ca.in = buf[t]; ca.out = buf[y]; ca.wpack = blk + BF_WPACK_FLOATS;
+            ca.scale = blk + 2 * BF_WPACK_FLOATS; ca.shift = ca.scale + 16; ca.res = buf[cur];
+            BF_HIP(bf_launch_conv3x3_c16(ca, EPI_AFFINE | EPI_RES, s), "conv2");
+            cur = y;
+        }
+    }
+    HeadArgs ha;
+    ha.feat = buf[cur];
+    ha.w0 = pk + h->k_w0; ha.w1 = pk + h->k_w1;
+    ha.wh = d.head_activation == BF_ACT_LINEAR ? pk + h->k_wh : nullptr;
+    ha.out = out;
+    ha.B = B; ha.H = H; ha.W = W; ha.Ho = Hs; ha.Wo = Ws; ha.hf = d.head_filters; ha.cout = d.out_channels;
+    ha.act = d.head_activation; ha.out_is_u8 = out_is_u8; ha.denormalize = d.denormalize;
+    ha.v_min = d.v_min; ha.v_max = d.v_max; ha.leaky_alpha = d.leaky_alpha;
+    BF_HIP(bf_launch_head(ha, s), "head");
+    return BF_OK;
+}
+
+static int check_dims(bf_handle h, const void* packed, const void* in, const void* out, int B, int H, int W)
+{
+    if (!packed || !in || !out) return fail(h, BF_EINVAL, "NULL tensor pointer");
+    if (B <= 0 || H <= 0 || W <= 0) return fail(h, BF_EINVAL, "batch/height/width must be positive (got %d,%d,%d)", B, H, W);
+    if ((int64_t)B * H * W * 16 >= ((int64_t)1 << 40)) return fail(h, BF_EINVAL, "tensor too large");
+    return BF_OK;
+}
+
+extern "C" int bf_forward_u8(bf_handle h, const void* packed, const uint8_t* in, uint8_t* out, int B, int H, int W, void* ws,
+                             int64_t ws_bytes, void* stream)
+{
+    if (!h) return BF_EINVAL;
+    int rc = check_dims(h, packed, in, out, B, H, W);
+    if (rc) return rc;
+    return forward_common(h, (const float*)packed, in, 1, out, 1, B, H, W, pow2_target(H), pow2_target(W), ws, ws_bytes,
+                          (hipStream_t)stream);
+}
+
+extern "C" int bf_forward_f32(bf_handle h, const void* packed, const float* in, float* out, int B, int H, int W, void* ws,
+                              int64_t ws_bytes, void* stream)
+{
+    if (!h) return BF_EINVAL;
+    int rc = check_dims(h, packed, in, out, B, H, W);
+    if (rc) return rc;
+    return forward_common(h, (const float*)packed, in, 0, out, 0, B, H, W, H, W, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// training
+// ------------------------------------------------------------------------------------------
+// reduces the head partials and writes the head gradients + the data-term losses
+//   partial rows: [0,64) M | 64 sum|e| | 65 hinge sum | 66 per-block sum e^2 (blocks of one image are contiguous)
+__global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restrict__ partial, int nblk, int blocks_per_image, int B,
+                                                            double numel, double per_image, const float* __restrict__ w0,
+                                                            const float* __restrict__ w1, int hf, int co, float* __restrict__ g0,
+                                                            float* __restrict__ g1, float* __restrict__ losses,
+                                                            float mae_multiplier, float depth_weight)
+{
+    __shared__ double M[64];
+    __shared__ double sums[2];
+    __shared__ double rm[256];
+    const int tid = threadIdx.x;
+    if (tid < 66) {
+        double s = 0.0;
+        for (int r = 0; r < nblk; ++r) s += (double)partial[(size_t)r * 80 + tid];
+        if (tid < 64) M[tid] = s; else sums[tid - 64] = s;
+    }
+    // rmse: mean over images of sqrt(mean_sq + DEFAULT_EPSILON)   (loss.py:92-113, constants.py:7)
+    double acc = 0.0;
+    for (int b = tid; b < B; b += 256) {
+        double sq = 0.0;
+        for (int k = 0; k < blocks_per_image; ++k) sq += (double)partial[(size_t)(b * blocks_per_image + k) * 80 + 66];
+        acc += sqrt(sq / per_image + 1e-3);
+    }
+    rm[tid] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) rm[tid] += rm[tid + st];
+        __syncthreads();
+    }
+    // dW0[c][j] = sum_o M[c][o] * W1[j][o] ; dW1[j][o] = sum_c W0[c][j] * M[c][o]
+    for (int i = tid; i < 16 * hf; i += 256) {
+        const int c = i / hf, j = i % hf;
+        double s = 0.0;
+        for (int o = 0; o < co; ++o) s += M[c * 4 + o] * (double)w1[j * co + o];
+        g0[i] = (float)s;
+    }
+    for (int i = tid; i < hf * co; i += 256) {
+        const int j = i / co, o = i % co;
+        double s = 0.0;
+        for (int c = 0; c < 16; ++c) s += (double)w0[c * hf + j] * M[c * 4 + o];
+        g1[i] = (float)s;
+    }
+    if (tid == 0) {
+        const double mae_actual = sums[0] / numel;
+        const double mae_loss = mae_multiplier > 0.f ? sums[1] / numel : 0.0;
+        losses[BF_LOSS_MAE] = (float)mae_actual;
+        losses[BF_LOSS_MSE] = (float)(rm[0] / (double)B);
+        losses[BF_LOSS_SSIM] = 0.f;
+        losses[BF_LOSS_DENOISER_TOTAL] = (float)(mae_loss * mae_multiplier);
+        losses[BF_LOSS_TOTAL] = (float)(mae_loss * mae_multiplier * depth_weight);     // + model loss added by reg kernel
+    }
+}
+
+// regularisers (keras "l1" -> 0.01*sum|w|, "l2" -> 0.01*sum w^2; bfcnn/loss.py:181-187):
+// adds d(reg*regularization)/dw to grads and finishes the loss slots.  Single workgroup,
+// fixed order.
+__global__ __launch_bounds__(1024) void regularizer_kernel(const float* __restrict__ params, float* __restrict__ grads, int64_t n,
+                                                           int64_t n_base, int64_t p_blocks, int64_t p_stride, int64_t p_head0,
+                                                           int reg_base, int reg_block, int reg_head, float regularization,
+                                                           float* __restrict__ losses)
+{
+    __shared__ double red[1024];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        int reg;
+        if (i < n_base) reg = reg_base;
+        else if (i >= p_head0) reg = reg_head;
+        else reg = ((i - p_blocks) % p_stride) < 4608 ? reg_block : BF_REG_NONE;
+        const float w = params[i];
+        if (reg == BF_REG_L1) {
+            acc += 0.01 * fabs((double)w);
+            grads[i] += regularization * 0.01f * (w > 0.f ? 1.f : (w < 0.f ? -1.f : 0.f));
+        } else if (reg == BF_REG_L2) {
+            acc += 0.01 * (double)w * (double)w;
+            grads[i] += regularization * 0.02f * w;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        losses[BF_LOSS_REGULARIZATION] = (float)red[0];
+        losses[BF_LOSS_MODEL_TOTAL] = (float)(red[0] * regularization);
+        losses[BF_LOSS_TOTAL] = losses[BF_LOSS_TOTAL] + (float)(red[0] * regularization);
+        losses[BF_LOSS_GRAD_NORM] = 0.f;
+    }
+}
+
+__global__ void premultiply_head_kernel(const float* __restrict__ w0, const float* __restrict__ w1, int hf, int co, float* __restrict__ wh)
+{
+    if (threadIdx.x < 64) {
+        const int c = threadIdx.x >> 2, o = threadIdx.x & 3;
+        float s = 0.f;
+        if (o < co)
+            for (int j = 0; j < hf; ++j) s = fmaf(w0[c * hf + j], w1[j * co + o], s);
+        wh[threadIdx.x] = s;
+    }
+}
+
+__global__ void fill_identity_affine_kernel(float* scale_shift)
+{
+    if (threadIdx.x < 16) { scale_shift[threadIdx.x] = 1.f; scale_shift[16 + threadIdx.x] = 0.f; }
+}
+
+extern "C" int bf_train_step(bf_handle h, const float* params, float* state, const float* gt, const float* noisy, int B, int H,
+                             int W, const bf_loss_desc* loss, float* predictions, float* grads, float* losses, void* ws,
+                             int64_t ws_bytes, void* stream)
+{
+    if (!h) return BF_EINVAL;
+    const bf_resnet_desc& d = h->d;
+    if (!params || !gt || !noisy || !loss || !grads || !losses || (h->n_state > 0 && !state))
+        return fail(h, BF_EINVAL, "bf_train_step: NULL argument");
+    if (loss->struct_size != (int32_t)sizeof(bf_loss_desc)) return fail(h, BF_EINVAL, "bf_loss_desc struct_size mismatch");
+    if (B <= 0 || H <= 0 || W <= 0) return fail(h, BF_EINVAL, "batch/height/width must be positive");
+    if (loss->ssim_multiplier > 0.f) return fail(h, BF_EUNSUPPORTED, "ssim_multiplier > 0: SSIM term is outside the hot path");
+    if (loss->mse_multiplier > 0.f) return fail(h, BF_EUNSUPPORTED, "mse_multiplier > 0: RMSE loss term is outside the hot path");
+    if (d.head_activation != BF_ACT_LINEAR) return fail(h, BF_EUNSUPPORTED, "training is built for the linear denoiser head");
+    if (d.out_channels != d.in_channels) return fail(h, BF_EINVAL, "gt/prediction channel mismatch");
+    const TrainLayout L = train_layout(h, B, H, W);
+    if (!ws || (uintptr_t)ws % 16) return fail(h, BF_EWORKSPACE, "workspace must be a 16-byte aligned device buffer");
+    if (ws_bytes < L.total * 4) return fail(h, BF_EWORKSPACE, "workspace too small: %lld < %lld bytes", (long long)ws_bytes,
+                                            (long long)(L.total * 4));
+    hipStream_t s = (hipStream_t)stream;
+    float* w = (float*)ws;
+    const int N = d.no_layers;
+    const int64_t npix = (int64_t)B * H * W;
+    const double count = (double)npix;
+    float* partial = w + L.partial;
+    auto ACT = [&](int64_t i) { return w + L.acts + i * L.act_floats; };
+    // buffer map: A_i = ACT(i) (i = 0..N) ; T_i = ACT(N+1+i) ; C_i = ACT(2N+1+i) ; dA = ACT(3N+1)
+    auto A = [&](int i) { return ACT(i); };
+    auto T = [&](int i) { return ACT(N + 1 + i); };
+    auto C = [&](int i) { return ACT(2 * (int64_t)N + 1 + i); };
+    float* dA = ACT(3 * (int64_t)N + 1);
+
+    if (N > 0) {
+        hipLaunchKernelGGL(pack_all_convs_kernel, dim3(N * 4), dim3(256), 0, s, params, h->p_blocks, h->p_block_stride, w + L.wpack,
+                           (int64_t)4 * BF_WPACK_FLOATS, 1);
+        BF_HIP(hipGetLastError(), "pack_all_convs");
+    }
+    hipLaunchKernelGGL(premultiply_head_kernel, dim3(1), dim3(64), 0, s, params + h->p_head0, params + h->p_head1, d.head_filters,
+                       d.out_channels, w + L.wh);
+    BF_HIP(hipGetLastError(), "premultiply_head");
+
+    // ---- forward, training mode (hydra(noisy, training=True), train_loop.py:249-251, 277) ----
+    BaseConvArgs ba;
+    ba.in = noisy; ba.out = A(0); ba.w = params + h->p_base;
+    ba.B = B; ba.Hs = H; ba.Ws = W; ba.H = H; ba.W = W; ba.cin = d.in_channels; ba.k = d.kernel_size; ba.in_is_u8 = 0;
+    ba.act_relu = 0; ba.v_min = d.v_min; ba.v_max = d.v_max;
+    BF_HIP(bf_launch_base_conv(ba, s), "base_conv");
+    const int conv_grid = bf_conv3x3_c16_grid(B, H, W);
+    for (int i = 0; i < N; ++i) {
+        const float* wp = w + L.wpack + (int64_t)i * 4 * BF_WPACK_FLOATS;
+        float* scale = w + L.bn_scale + i * 32;
+        ConvArgs ca;
+        memset(&ca, 0, sizeof(ca));
+        ca.B = B; ca.H = H; ca.W = W;
+        ca.in = A(i); ca.out = T(i); ca.wpack = wp;
+        BF_HIP(bf_launch_conv3x3_c16(ca, d.activation == BF_ACT_RELU ? EPI_RELU : 0, s), "conv1");
+        ca.in = T(i); ca.out = C(i); ca.wpack = wp + BF_WPACK_FLOATS; ca.stats = partial;
+        BF_HIP(bf_launch_conv3x3_c16(ca, d.use_bn ? EPI_STATS : 0, s), "conv2");
+        if (d.use_bn) {
+            BF_HIP(bf_launch_bn_finalize(partial, conv_grid, count, params + h->p_blocks + i * h->p_block_stride + 4608,
+                                         state + i * 32, state + i * 32 + 16, d.bn_eps, d.bn_momentum, scale, scale + 16,
+                                         w + L.bn_meaninv + i * 32, s), "bn_finalize");
+        } else {
+            hipLaunchKernelGGL(fill_identity_affine_kernel, dim3(1), dim3(64), 0, s, scale);
+            BF_HIP(hipGetLastError(), "identity_affine");
+        }
+        BF_HIP(bf_launch_affine_add(A(i), C(i), scale, scale + 16, A(i + 1), npix, s), "affine_add");
+    }
+
+    // ---- head forward + loss + head backward ---------------------------------------------------
+    const double numel = (double)npix * d.out_channels;
+    HeadTrainArgs ta;
+    ta.feat = A(N); ta.wh = w + L.wh; ta.gt = gt; ta.pred = predictions; ta.dfeat = dA; ta.partial = partial;
+    ta.B = B; ta.H = H; ta.W = W; ta.cout = d.out_channels; ta.denormalize = d.denormalize;
+    ta.v_min = d.v_min; ta.v_max = d.v_max; ta.hinge = loss->hinge; ta.cutoff = loss->cutoff;
+    ta.dscale = loss->mae_multiplier > 0.f ? (float)((double)loss->mae_multiplier * loss->depth_weight / numel) : 0.f;
+    const int hgrid = bf_head_train_grid(B, H, W);
+    BF_HIP(bf_launch_head_train(ta, hgrid, s), "head_train");
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, s, partial, hgrid, hgrid / B, B, numel,
+                       (double)H * W * d.out_channels, params + h->p_head0, params + h->p_head1, d.head_filters, d.out_channels,
+                       grads + h->p_head0, grads + h->p_head1, losses, loss->mae_multiplier, loss->depth_weight);
+    BF_HIP(hipGetLastError(), "head_finalize");
+
+    // ---- backward through the blocks -----------------------------------------------------------
+    int64_t n4 = npix * 4;
+    int bgrid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    for (int i = N - 1; i >= 0; --i) {
+        const float* wp = w + L.wpack + (int64_t)i * 4 * BF_WPACK_FLOATS;
+        float* gblk = grads + h->p_blocks + i * h->p_block_stride;
+        float* dC = dA;
+        if (d.use_bn) {
+            BF_HIP(bf_launch_bn_bwd_reduce(dA, C(i), partial, npix, bgrid, s), "bn_bwd_reduce");
+            BF_HIP(bf_launch_bn_bwd_finalize(partial, bgrid, count, params + h->p_blocks + i * h->p_block_stride + 4608,
+                                             w + L.bn_meaninv + i * 32, w + L.coef, gblk + 4608, s), "bn_bwd_finalize");
+            BF_HIP(bf_launch_bn_bwd_apply(dA, C(i), w + L.coef, C(i), npix, s), "bn_bwd_apply");
+            dC = C(i);
+        }
+        BF_HIP(bf_launch_wgrad3x3_c16(T(i), dC, partial, gblk + 2304, B, H, W, s), "wgrad2");
+        ConvArgs ca;
+        memset(&ca, 0, sizeof(ca));
+        ca.B = B; ca.H = H; ca.W = W;
+        ca.in = dC; ca.out = T(i); ca.wpack = wp + 3 * BF_WPACK_FLOATS; ca.mask = T(i);
+        BF_HIP(bf_launch_conv3x3_c16(ca, d.activation == BF_ACT_RELU ? EPI_MASK : 0, s), "dgrad2");
+        BF_HIP(bf_launch_wgrad3x3_c16(A(i), T(i), partial, gblk, B, H, W, s), "wgrad1");
+        ca.in = T(i); ca.out = dA; ca.wpack = wp + 2 * BF_WPACK_FLOATS; ca.mask = nullptr; ca.res = dA;
+        BF_HIP(bf_launch_conv3x3_c16(ca, EPI_RES, s), "dgrad1");
+    }
+    BF_HIP(bf_launch_base_wgrad(noisy, dA, partial, grads + h->p_base, B, H, W, d.in_channels, d.kernel_size, d.v_min, d.v_max, s),
+           "base_wgrad");
+    hipLaunchKernelGGL(regularizer_kernel, dim3(1), dim3(1024), 0, s, params, grads, h->n_params, h->n_base, h->p_blocks,
+                       h->p_block_stride, h->p_head0, d.reg_base, d.reg_block, d.reg_head, loss->regularization, losses);
+    BF_HIP(hipGetLastError(), "regularizer");
+    return BF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Adam (keras 2.13, bfcnn/optimizer.py:190-206) with global_clipnorm (tf.clip_by_global_norm)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void grad_norm_kernel(const float* __restrict__ g, int64_t n, float grad_scale, float* scratch,
+                                                         float* losses)
+{
+    __shared__ double red[1024];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const double v = (double)g[i] * grad_scale;
+        acc += v * v;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        scratch[0] = (float)sqrt(red[0]);
+        if (losses) losses[BF_LOSS_GRAD_NORM] = scratch[0];
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, float alpha, float beta_1, float beta_2,
+                                                   float epsilon, float clip, float grad_scale, const float* __restrict__ scratch)
+{
+    float factor = grad_scale;
+    if (clip > 0.f) {
+        const float norm = scratch[0];
+        factor *= clip / fmaxf(norm, clip);
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i] * factor;
+        const float mi = m[i] + (gi - m[i]) * (1.0f - beta_1);
+        const float vi = v[i] + (gi * gi - v[i]) * (1.0f - beta_2);
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - (mi * alpha) / (sqrtf(vi) + epsilon);
+    }
+}
+
+extern "C" int bf_adam_step(bf_handle h, float* params, const float* grads, float* m, float* v, int64_t iterations, float lr,
+                            float beta_1, float beta_2, float epsilon, float global_clipnorm, float grad_scale, float* losses,
+                            float* scratch, void* stream)
+{
+    if (!h) return BF_EINVAL;
+    if (!params || !grads || !m || !v || !scratch) return fail(h, BF_EINVAL, "bf_adam_step: NULL argument");
+    if (iterations < 0) return fail(h, BF_EINVAL, "iterations must be >= 0");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = h->n_params;
+    if (global_clipnorm > 0.f || losses) {
+        hipLaunchKernelGGL(grad_norm_kernel, dim3(1), dim3(1024), 0, s, grads, n, grad_scale, scratch, losses);
+        BF_HIP(hipGetLastError(), "grad_norm");
+    }
+    const double t = (double)iterations + 1.0;
+    const double alpha = (double)lr * sqrt(1.0 - pow((double)beta_2, t)) / (1.0 - pow((double)beta_1, t));
+    const int grid = (int)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, s, params, grads, m, v, n, (float)alpha, beta_1, beta_2, epsilon,
+                       global_clipnorm, grad_scale, scratch);
+    BF_HIP(hipGetLastError(), "adam");
+    return BF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// diagnostics used by tests/ (single-kernel entry points; not part of the drop-in surface)
+// ------------------------------------------------------------------------------------------
+extern "C" int bf_debug_conv3x3(const float* in, const float* w_hwio, float* out, const float* scale, const float* shift,
+                                const float* res, const float* mask, float* stats, float* wpack_scratch, int B, int H, int W,
+                                int epi, int transpose_flip, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (bf_launch_pack_conv(w_hwio, wpack_scratch, transpose_flip, s) != hipSuccess) return BF_EHIP;
+    ConvArgs ca;
+    ca.in = in; ca.out = out; ca.wpack = wpack_scratch; ca.scale = scale; ca.shift = shift; ca.res = res; ca.mask = mask;
+    ca.stats = stats; ca.B = B; ca.H = H; ca.W = W;
+    return bf_launch_conv3x3_c16(ca, epi, s) == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+extern "C" int bf_debug_conv3x3_grid(int B, int H, int W) { return bf_conv3x3_c16_grid(B, H, W); }
+
+extern "C" int bf_debug_fused_block(const float* in, const float* w1_hwio, const float* w2_hwio, const float* scale,
+                                    const float* shift, float* out, float* wpack_scratch, int B, int H, int W, int act1_relu,
+                                    void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (bf_launch_pack_conv(w1_hwio, wpack_scratch, 0, s) != hipSuccess) return BF_EHIP;
+    if (bf_launch_pack_conv(w2_hwio, wpack_scratch + BF_WPACK_FLOATS, 0, s) != hipSuccess) return BF_EHIP;
+    FusedBlockArgs fa;
+    fa.in = in; fa.out = out; fa.w1pack = wpack_scratch; fa.w2pack = wpack_scratch + BF_WPACK_FLOATS; fa.scale = scale;
+    fa.shift = shift; fa.B = B; fa.H = H; fa.W = W; fa.tiles_x = fa.tiles_y = fa.ntiles = 0; fa.act1_relu = act1_relu;
+    return bf_launch_fused_block(fa, s) == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+extern "C" int64_t bf_debug_wgrad_partial_floats(int B, int H, int W) { return (int64_t)bf_wgrad_grid(B, H, W) * 2304; }
+
+extern "C" int bf_debug_wgrad3x3(const float* x, const float* dy, float* partial, float* dw, int B, int H, int W, void* stream)
+{
+    return bf_launch_wgrad3x3_c16(x, dy, partial, dw, B, H, W, (hipStream_t)stream) == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// raw MFMA layout probe: D = A(16x4) * B(4x16) with A[m][k] = a_in[m*4+k], B[k][n] = b_in[k*16+n]
+__global__ void mfma_probe_kernel(const float* a_in, const float* b_in, float* d_out)
+{
+    const int l = threadIdx.x;
+    const float a = a_in[(l & 15) * 4 + (l >> 4)];
+    const float b = b_in[(l >> 4) * 16 + (l & 15)];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d_out[((l >> 4) * 4 + j) * 16 + (l & 15)] = acc[j];
+}
+
+extern "C" int bf_debug_mfma_probe(const float* a, const float* b, float* d, void* stream)
+{
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, d);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}

@@ -1,0 +1,204 @@
+/*
+ * bfcnn_hip.h -- C ABI of the MI355X (gfx950) engine for the bfcnn resnet-denoiser hot path.
+ *
+ * The reference (NikolasMarkou/blind_image_denoising, bfcnn 3.2.0) is pure Python on
+ * TensorFlow/Keras: it has no FFI of its own.  These entry points are what a binding for
+ * its hot path replaces; every declaration cites the reference interface (file:line under
+ * the reference root) whose behaviour it reproduces.  The reference-side stub a maintainer
+ * would add is shown in INTEGRATION.md (ctypes, because the reference host is Python).
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types in signatures (a stream is passed as void*
+ *     = hipStream_t, NULL = the null stream);
+ *   - every tensor pointer is DEVICE memory on the handle's device unless the name ends in
+ *     `_host`; activations are NHWC, contiguous; kernels are HWIO ([kh,kw,cin,cout]) exactly
+ *     as keras stores them;
+ *   - the caller owns every buffer, including the workspace (size from bf_workspace_bytes);
+ *     the library never allocates device memory, never synchronises and spawns no threads:
+ *     all work is enqueued on the given stream (graph-capturable);
+ *   - return value 0 = BF_OK, negative = error; text via bf_last_error().
+ */
+#ifndef BFCNN_HIP_H
+#define BFCNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BFCNN_ABI_VERSION 1
+
+typedef struct bf_engine* bf_handle;
+
+enum bf_status {
+    BF_OK = 0,
+    BF_EINVAL = -1,       /* bad argument (reference raises ValueError)            */
+    BF_EUNSUPPORTED = -2, /* config outside the hot path (NotImplementedError)     */
+    BF_EWORKSPACE = -3,   /* workspace / packed buffer too small or misaligned     */
+    BF_EHIP = -4          /* HIP runtime error on launch                           */
+};
+
+enum bf_activation { BF_ACT_LINEAR = 0, BF_ACT_RELU = 1, BF_ACT_LEAKY_RELU = 2 };
+enum bf_regularizer { BF_REG_NONE = 0, BF_REG_L1 = 1, BF_REG_L2 = 2 };
+enum bf_mode { BF_MODE_INFERENCE = 0, BF_MODE_TRAIN = 1 };
+enum bf_tensor_kind { BF_KIND_CONV = 0, BF_KIND_GAMMA = 1, BF_KIND_MOVING_MEAN = 2, BF_KIND_MOVING_VAR = 3 };
+
+/* The arguments of bfcnn/backbone_resnet.py:19-50 (builder) and bfcnn/model.py:251-275
+ * (model_denoiser_builder) that the hot path uses.  The host parses the reference's
+ * pipeline JSON (bfcnn/utilities.py:59-96) into this struct. */
+typedef struct bf_resnet_desc {
+    int32_t struct_size;      /* = sizeof(bf_resnet_desc)                                   */
+    int32_t in_channels;      /* input_shape[-1], 1..4                                       */
+    int32_t filters;          /* `filters`; the MFMA path is built for 16                    */
+    int32_t kernel_size;      /* base conv kernel_size: 1,3,5,7                              */
+    int32_t no_layers;        /* number of residual blocks                                   */
+    int32_t block_convs;      /* len(block_kernels); 2                                       */
+    int32_t block_kernel;     /* block_kernels[*]; 3                                         */
+    int32_t activation;       /* bf_activation of the first block conv                       */
+    int32_t base_activation;  /* bf_activation of base conv and last block conv (linear)     */
+    int32_t use_bn;           /* BatchNormalization(scale=True, center=False) after conv2    */
+    int32_t head_filters;     /* denoiser `filters` (default 32), <= 64                      */
+    int32_t head_activation;  /* denoiser `activation` (default linear)                      */
+    int32_t out_channels;     /* denoiser `output_channels`, 1..4                            */
+    int32_t denormalize;      /* 1: always denormalise; 0: literal snapshot graph (model.py:110-116) */
+    int32_t reg_base;         /* bf_regularizer: kernel_regularizer of the base conv         */
+    int32_t reg_block;        /* block_regularizer                                           */
+    int32_t reg_head;         /* denoiser kernel_regularizer                                 */
+    float v_min, v_max;       /* value_range                                                 */
+    float bn_eps, bn_momentum;/* constants.py:9,11                                           */
+    float leaky_alpha;        /* slope when an activation is BF_ACT_LEAKY_RELU               */
+} bf_resnet_desc;
+
+/* bfcnn/loss.py:162-179 + the depth weight of train_loop.py:284-285. */
+typedef struct bf_loss_desc {
+    int32_t struct_size;
+    float hinge, cutoff;
+    float mae_multiplier;
+    float mse_multiplier;     /* must be 0 (RMSE term outside the hot path)                  */
+    float ssim_multiplier;    /* must be 0 (SSIM term outside the hot path)                  */
+    float regularization;
+    float depth_weight;
+} bf_loss_desc;
+
+/* losses written by bf_train_step, device float[BF_LOSS_COUNT] (keys of constants.py:35-50). */
+enum bf_loss_slot {
+    BF_LOSS_TOTAL = 0,          /* p_total_loss (train_loop.py:299-301)                      */
+    BF_LOSS_DENOISER_TOTAL = 1, /* denoiser_loss[total_loss]                                 */
+    BF_LOSS_MAE = 2,            /* mae_loss (no hinge)                                       */
+    BF_LOSS_MSE = 3,            /* mse_loss = rmse (no hinge)                                */
+    BF_LOSS_SSIM = 4,           /* 0                                                         */
+    BF_LOSS_REGULARIZATION = 5, /* model_loss[regularization_loss]                           */
+    BF_LOSS_MODEL_TOTAL = 6,    /* model_loss[total_loss]                                    */
+    BF_LOSS_GRAD_NORM = 7,      /* global L2 norm of the last gradient given to bf_adam_step */
+    BF_LOSS_COUNT = 8
+};
+
+typedef struct bf_tensor_info {
+    char name[64];
+    int64_t offset;           /* element offset in the flat params (or state) buffer         */
+    int32_t rank;
+    int32_t shape[4];
+    int32_t kind;             /* bf_tensor_kind                                              */
+    int32_t regularizer;      /* bf_regularizer                                              */
+} bf_tensor_info;
+
+/* ---- lifetime ----------------------------------------------------------------------- */
+
+int bf_abi_version(void);
+
+/* model_builder(config) (bfcnn/model.py:58-162): validates the description and builds the
+ * launch plan.  No device memory is touched.  *out = NULL on failure; bf_last_error(NULL)
+ * then holds the reason. */
+int bf_create(const bf_resnet_desc* desc, bf_handle* out);
+void bf_destroy(bf_handle h);
+const char* bf_last_error(bf_handle h);
+
+/* ---- parameter inventory (keras trainable_variables / non-trainable BN stats) -------- */
+
+int64_t bf_param_count(bf_handle h);   /* trainable floats: conv kernels + BN gammas         */
+int64_t bf_state_count(bf_handle h);   /* BN moving_mean / moving_variance floats            */
+int bf_tensor_count(bf_handle h, int state);
+int bf_tensor_at(bf_handle h, int state, int index, bf_tensor_info* out);
+
+/* ---- inference ---------------------------------------------------------------------- */
+
+int64_t bf_packed_bytes(bf_handle h);
+int64_t bf_workspace_bytes(bf_handle h, int mode, int batch, int height, int width);
+
+/* Re-lays the weights for the kernels (MFMA operand images, BN folded to scale/shift with
+ * the inference formula of keras BatchNormalization: gamma*(x-moving_mean)*rsqrt(var+eps)).
+ * Call after every change of params/state. */
+int bf_pack_inference(bf_handle h, const float* params, const float* state, void* packed, void* stream);
+
+/* DenoiserModule.__call__ (bfcnn/module_denoiser.py:46-75): uint8 [B,H,W,C] -> uint8 [B,H,W,Cout]:
+ * cast, pad_to_power_of_2 (utilities.py:736-751), hydra, remove_padding, round-half-even, cast. */
+int bf_forward_u8(bf_handle h, const void* packed, const uint8_t* in, uint8_t* out,
+                  int batch, int height, int width, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* hydra(x, training=False) (bfcnn/model.py:91-151; test_step train_loop.py:253-257):
+ * float32 [B,H,W,C] in value_range -> float32 [B,H,W,Cout].  No power-of-two padding. */
+int bf_forward_f32(bf_handle h, const void* packed, const float* in, float* out,
+                   int batch, int height, int width, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- training ----------------------------------------------------------------------- */
+
+/* train_step_single_gpu (bfcnn/train_loop.py:259-312) for the single-output resnet hydra:
+ * training-mode forward (BN batch statistics, moving stats updated in `state`), L1 loss with
+ * hinge/cutoff (loss.py:40-65,190-247) * depth_weight + regularisation (loss.py:181-187),
+ * gradients of the total w.r.t. every trainable variable into `grads` (flat, same layout as
+ * params).  `predictions` may be NULL.  `losses` = device float[BF_LOSS_COUNT]. */
+int bf_train_step(bf_handle h, const float* params, float* state, const float* gt, const float* noisy,
+                  int batch, int height, int width, const bf_loss_desc* loss,
+                  float* predictions, float* grads, float* losses,
+                  void* workspace, int64_t workspace_bytes, void* stream);
+
+/* apply_grads (bfcnn/train_loop.py:314-321) with the optimizer of bfcnn/optimizer.py:190-206:
+ * keras-2.13 Adam, optional global_clipnorm (<=0 disables), grads pre-scaled by grad_scale
+ * (1/world_size after a sum all-reduce).  `iterations` = optimizer.iterations before the step;
+ * `lr` = schedule(iterations) evaluated by the host.  losses[BF_LOSS_GRAD_NORM] receives the
+ * (scaled) global norm when `losses` is not NULL.  scratch = device float[>=2] (may alias
+ * the workspace). */
+int bf_adam_step(bf_handle h, float* params, const float* grads, float* m, float* v,
+                 int64_t iterations, float lr, float beta_1, float beta_2, float epsilon,
+                 float global_clipnorm, float grad_scale, float* losses, float* scratch, void* stream);
+
+/* ---- pyramid / resampling (bfcnn/pyramid.py, upsampling.py, downsampling.py) ---------- */
+
+/* AveragePooling2D(pool_size=(kh,kw), strides=2, padding="same") (pyramid.py:266-270,374-378). */
+int bf_avgpool_s2_same(const float* in, float* out, int batch, int height, int width, int channels,
+                       int kh, int kw, void* stream);
+/* tf.nn.avg_pool2d(2x2, stride 2, VALID) [+clip 0..255][+round] (utilities.py:642-672). */
+int bf_avgpool2_valid(const float* in, float* out, int batch, int height, int width, int channels,
+                      int clip_values, int round_values, void* stream);
+/* UpSampling2D(2, "bilinear"|"nearest") (pyramid.py:319-325; upsampling.py:65,105):
+ * out = up(in) [+ add][- sub...]: out = alpha*up(in) + beta*other (other may be NULL). */
+int bf_upsample2x(const float* in, const float* other, float* out, int batch, int height, int width,
+                  int channels, int bilinear, float alpha, float beta, void* stream);
+/* x[:, ::2, ::2, :] (downsampling.py:61). */
+int bf_strided_slice2(const float* in, float* out, int batch, int height, int width, int channels, void* stream);
+
+/* ---- options and diagnostics (not part of the drop-in surface; used by tests/) ------------- */
+
+/* "fused_blocks" = 1 (default): one kernel per residual block; 0: one kernel per convolution. */
+int bf_set_option(bf_handle h, const char* key, int value);
+
+/* single 3x3 16->16 convolution with epilogue flags (1 relu, 2 affine, 4 residual, 8 mask,
+ * 16 stats); transpose_flip = 1 runs the data-gradient form.  wpack_scratch = 2*2304 floats. */
+int bf_debug_conv3x3(const float* in, const float* w_hwio, float* out, const float* scale, const float* shift,
+                     const float* res, const float* mask, float* stats, float* wpack_scratch,
+                     int batch, int height, int width, int epi, int transpose_flip, void* stream);
+int bf_debug_conv3x3_grid(int batch, int height, int width);
+int bf_debug_fused_block(const float* in, const float* w1_hwio, const float* w2_hwio, const float* scale,
+                         const float* shift, float* out, float* wpack_scratch,
+                         int batch, int height, int width, int act1_relu, void* stream);
+int64_t bf_debug_wgrad_partial_floats(int batch, int height, int width);
+int bf_debug_wgrad3x3(const float* x, const float* dy, float* partial, float* dw,
+                      int batch, int height, int width, void* stream);
+int bf_debug_mfma_probe(const float* a, const float* b, float* d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BFCNN_HIP_H */

@@ -1,0 +1,72 @@
+"""Shared test helpers: device transfer and the C-ABI diagnostic wrappers."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from blind_image_denoising_amd import _native as N
+
+
+def dev(a, dtype=np.float32):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu().numpy()
+
+
+def assert_close(got, ref, rel=2e-5, what=""):
+    """|got - ref| <= rel * max(1, max|ref|): fp32 accumulation against the fp64 oracle."""
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert np.isfinite(got).all(), f"{what}: non-finite values"
+    err = np.abs(got - ref).max() if got.size else 0.0
+    scale = max(1.0, np.abs(ref).max() if ref.size else 0.0)
+    assert err <= rel * scale, f"{what}: max err {err:.3e} > {rel:.1e} * {scale:.3e}"
+
+
+def conv3x3_gpu(x, w, epi=0, scale=None, shift=None, res=None, mask=None, transpose_flip=0, want_stats=False):
+    """single 3x3 C16 convolution through bf_debug_conv3x3."""
+    L = N.lib()
+    B, H, W, _ = x.shape
+    xd, wd = dev(x), dev(w)
+    out = torch.full((B, H, W, 16), float("nan"), dtype=torch.float32, device="cuda")
+    sd = dev(scale) if scale is not None else None
+    hd = dev(shift) if shift is not None else None
+    rd = dev(res) if res is not None else None
+    md = dev(mask) if mask is not None else None
+    grid = L.bf_debug_conv3x3_grid(B, H, W)
+    stats = torch.zeros(grid * 32, dtype=torch.float32, device="cuda") if want_stats else None
+    scratch = torch.zeros(2 * 2304, dtype=torch.float32, device="cuda")
+    rc = L.bf_debug_conv3x3(N.ptr(xd), N.ptr(wd), N.ptr(out), N.ptr(sd), N.ptr(hd), N.ptr(rd), N.ptr(md), N.ptr(stats),
+                            N.ptr(scratch), B, H, W, epi, transpose_flip, N.stream_ptr(xd))
+    assert rc == 0, rc
+    if want_stats:
+        return host(out), host(stats).reshape(grid, 32)
+    return host(out)
+
+
+def fused_block_gpu(x, w1, w2, scale, shift, act1_relu=1):
+    L = N.lib()
+    B, H, W, _ = x.shape
+    xd = dev(x)
+    out = torch.full((B, H, W, 16), float("nan"), dtype=torch.float32, device="cuda")
+    scratch = torch.zeros(2 * 2304, dtype=torch.float32, device="cuda")
+    w1d, w2d, sd, hd = dev(w1), dev(w2), dev(scale), dev(shift)
+    rc = L.bf_debug_fused_block(N.ptr(xd), N.ptr(w1d), N.ptr(w2d), N.ptr(sd), N.ptr(hd), N.ptr(out), N.ptr(scratch),
+                                B, H, W, act1_relu, N.stream_ptr(xd))
+    assert rc == 0, rc
+    return host(out)
+
+
+def wgrad_gpu(x, dy):
+    L = N.lib()
+    B, H, W, _ = x.shape
+    xd, dd = dev(x), dev(dy)
+    partial = torch.zeros(int(L.bf_debug_wgrad_partial_floats(B, H, W)), dtype=torch.float32, device="cuda")
+    dw = torch.full((3, 3, 16, 16), float("nan"), dtype=torch.float32, device="cuda")
+    rc = L.bf_debug_wgrad3x3(N.ptr(xd), N.ptr(dd), N.ptr(partial), N.ptr(dw), B, H, W, N.stream_ptr(xd))
+    assert rc == 0, rc
+    return host(dw)
