@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""
+bench.py -- denoised images/sec (256x256x3) of the resnet hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one DenoiserModule.__call__ pass (uint8 in -> uint8 out, one bf_forward_u8 C-ABI call)
+over one synthetic batch that is already resident in HBM.  Workload = BASELINE.json's metric
+config: resnet_color_1x18_bn_16x3x3, batch 128 per GPU, 256x256x3, random-init glorot weights with
+non-trivial BN statistics, smooth-field + gaussian-noise uint8 images.  The batch is
+sharded by replication across ranks (weak scaling: independent images, no data-path collective).
+
+The JSON line also carries
+  roofline     : dominant kernel = fused_block_kernel (one launch per residual block); achieved =
+                 algorithmic FLOPs per launch (B*H*W * 2 convs * 4608 FLOP/px) / its average launch
+                 duration measured with HIP events on the launch stream over the timed region;
+                 peak = dense fp32 MFMA peak of MI355X_MICROARCH.md (157.3 TFLOP/s).
+  cpu_baseline : the oracle's C port (oracle/bfcnn_port.c, fp32, OpenMP, all host cores) timed on
+                 a bounded sample of the same workload, rank 0 / N=1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+FLOP_PER_PX_BLOCK = 2 * 4608        # two 3x3 16->16 convolutions
+
+
+def gflop_per_image(no_layers, h, w, k=3, cin=3, hf=32, cout=3):
+    per_px = 2 * k * k * cin * 16 + no_layers * FLOP_PER_PX_BLOCK + 2 * (16 * hf + hf * cout)
+    return per_px * h * w / 1e9
+
+
+def cpu_baseline(spec, params, state, noisy_u8, budget_s=12.0):
+    """the oracle's C port on the host cores: bounded sample, ~budget_s of CPU work."""
+    from oracle import port
+    h = port.lib(rebuild=True)                       # -march=native on THIS box
+    port.forward_u8(spec, params, state, noisy_u8[:1], h)          # warm-up / page-in
+    t0 = time.perf_counter()
+    port.forward_u8(spec, params, state, noisy_u8[:1], h)
+    one = time.perf_counter() - t0
+    n = int(max(2, min(noisy_u8.shape[0], budget_s / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    port.forward_u8(spec, params, state, noisy_u8[:n], h)
+    dt = time.perf_counter() - t0
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    omp = os.environ.get("OMP_NUM_THREADS")
+    return {"value": n / dt, "unit": "images/s", "cores": int(omp) if omp else cores, "kind": "port",
+            "sample": f"{n} images of the same 1x18 256x256x3 uint8 workload, oracle/bfcnn_port.c fp32 OpenMP "
+                      f"(CPU restatement, not TensorFlow)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="images per GPU")
+    ap.add_argument("--layers", type=int, default=18)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="one kernel per convolution (A/B only)")
+    args = ap.parse_args()
+
+    import torch
+    import blind_image_denoising_amd as bf
+    from blind_image_denoising_amd import _native as N
+    from oracle import bfcnn_oracle as O          # checker + synthetic workload generator only
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU execution path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    cfg = O.canonical_config(no_layers=args.layers)
+    spec = O.ResnetSpec.from_config(cfg["model"])
+    params, state = O.init_params(spec, seed=42, nontrivial_bn=True)
+    model = bf.model_builder(cfg["model"], device=f"cuda:{local_rank}").hydra
+    model.set_weights(params, state)
+    if args.unfused:
+        model.set_option("fused_blocks", 0)
+    model.set_option("timing", 1)
+    module = bf.DenoiserModule(model)
+
+    B, S = args.batch, args.size
+    # 16 distinct synthetic images tiled to the batch (generation cost only; every image is processed)
+    _, base = O.synthetic_batch(min(B, 16), S, S, sigma=20.0, seed=1234 + rank)
+    reps = (B + base.shape[0] - 1) // base.shape[0]
+    noisy_host = np.concatenate([base] * reps, axis=0)[:B]
+    noisy = torch.from_numpy(noisy_host).cuda()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for _ in range(max(args.warmup, 1)):
+        out = module(noisy)
+    barrier()
+    block_ms, launches = [], 0
+    ms, ln = C.c_float(), C.c_int()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = module(noisy)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # the events of the LAST timed step bracket its residual-block launches on the launch stream
+    N.check(N.lib().bf_get_timing(model._h, C.byref(ms), C.byref(ln)), model._h)
+    block_ms, launches = float(ms.value), int(ln.value)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        # parity of the timed configuration: one image against the fp64 oracle (+-1 LSB bar)
+        ref = O.denoiser_module_call(spec, params, state, noisy_host[:1])
+        got = out[:1].cpu().numpy()
+        diff = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+        images = B * world * args.steps
+        value = images / elapsed
+        per_launch_flop = B * S * S * FLOP_PER_PX_BLOCK * (1 if not args.unfused else 0.5)
+        avg_launch_s = block_ms / 1e3 / max(launches, 1)
+        achieved = per_launch_flop / avg_launch_s / 1e12
+        result = {
+            "metric": "denoised images/sec (256x256x3) + MAE vs ref, resnet_1x18",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"resnet_color_1x{args.layers}_bn_16x3x3 inference, batch={B}/GPU {S}x{S}x3 uint8->uint8 "
+                                   f"(DenoiserModule.__call__ via bf_forward_u8)",
+                       "batch_per_gpu": B, "global_batch": B * world, "height": S, "width": S,
+                       "blocks": args.layers, "fused_blocks": not args.unfused, "parallelism": f"replicas x{world}, no collective"},
+            "parity": {"mae_vs_oracle_lsb": float(diff.mean()), "max_abs_lsb": int(diff.max()), "checked_images": 1},
+            "end_to_end_tflops": value / world * gflop_per_image(args.layers, S, S) / 1e3,
+            "roofline": {"bound": "mfma", "kernel": "fused_block_kernel" if not args.unfused else "conv3x3_c16_kernel",
+                         "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "launch_us": avg_launch_s * 1e6, "launches_per_step": launches,
+                         "algorithmic_gflop_per_launch": per_launch_flop / 1e9},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(spec, params, state, noisy_host)
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void base_conv_kernel(BaseConvArgs a)
     for (int i = threadIdx.x; i < K * K * CIN * 16; i += 256) ws[i] = a.w[i];
     __syncthreads();
     const int64_t npix = (int64_t)a.B * a.H * a.W;
-    const float inv = 1.0f / (a.v_max - a.v_min);
+    const float range = a.v_max - a.v_min;       // true division: (x - min) / (max - min) - 0.5 is exact for mid-grey
     for (int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * 256) {
         const int x = (int)(pix % a.W);
         const int64_t t = pix / a.W;
@@ -41,12 +41,12 @@ __global__ __launch_bounds__(256) void base_conv_kernel(BaseConvArgs a)
                     for (int ci = 0; ci < CIN; ++ci) {
                         const float raw = U8 ? (float)reinterpret_cast<const uint8_t*>(a.in)[si + ci]
                                              : reinterpret_cast<const float*>(a.in)[si + ci];
-                        v[ci] = (fminf(fmaxf(raw, a.v_min), a.v_max) - a.v_min) * inv - 0.5f;
+                        v[ci] = (fminf(fmaxf(raw, a.v_min), a.v_max) - a.v_min) / range - 0.5f;
                     }
                 } else {
 #pragma unroll
                     for (int ci = 0; ci < CIN; ++ci)       // pad_to_power_of_2 band: value 0
-                        v[ci] = (fminf(fmaxf(0.f, a.v_min), a.v_max) - a.v_min) * inv - 0.5f;
+                        v[ci] = (fminf(fmaxf(0.f, a.v_min), a.v_max) - a.v_min) / range - 0.5f;
                 }
 #pragma unroll
                 for (int ci = 0; ci < CIN; ++ci) {
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(512) void base_wgrad_kernel(const float* __restrict
     __shared__ float tx_[IH * IW * CIN];
     __shared__ __attribute__((aligned(16))) float td[BW_TH * BW_TW * 16];
     const int tid = threadIdx.x;
-    const float inv = 1.0f / (v_max - v_min);
+    const float range = v_max - v_min;
     float acc[PER];
     int xoff[PER], co[PER];
 #pragma unroll
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(512) void base_wgrad_kernel(const float* __restrict
             float v = 0.f;
             if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
                 const float raw = in[(((int64_t)b * H + gy) * W + gx) * CIN + ci];
-                v = (fminf(fmaxf(raw, v_min), v_max) - v_min) * inv - 0.5f;
+                v = (fminf(fmaxf(raw, v_min), v_max) - v_min) / range - 0.5f;
             }
             tx_[n] = v;
         }

@@ -21,6 +21,10 @@ struct bf_engine {
     // packed-inference layout (floats)
     int64_t k_base = 0, k_blocks = 0, k_block_stride = 0, k_w0 = 0, k_w1 = 0, k_wh = 0, k_total = 0;
     int fused_blocks = 1;
+    // optional HIP-event bracket around the residual-block launches of a forward (bench.py roofline)
+    int timing = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int timed_launches = 0;
 };
 
 static thread_local std::string g_create_error;
@@ -139,7 +143,13 @@ extern "C" int bf_create(const bf_resnet_desc* d, bf_handle* out)
     return BF_OK;
 }
 
-extern "C" void bf_destroy(bf_handle h) { delete h; }
+extern "C" void bf_destroy(bf_handle h)
+{
+    if (!h) return;
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    delete h;
+}
 extern "C" int64_t bf_param_count(bf_handle h) { return h ? h->n_params : -1; }
 extern "C" int64_t bf_state_count(bf_handle h) { return h ? h->n_state : -1; }
 extern "C" int bf_tensor_count(bf_handle h, int state) { return h ? (int)(state ? h->states.size() : h->tensors.size()) : -1; }
@@ -157,7 +167,27 @@ extern "C" int bf_set_option(bf_handle h, const char* key, int value)
 {
     if (!h || !key) return BF_EINVAL;
     if (!strcmp(key, "fused_blocks")) { h->fused_blocks = value ? 1 : 0; return BF_OK; }
+    if (!strcmp(key, "timing")) {
+        h->timing = value ? 1 : 0;
+        if (h->timing && !h->ev0) {
+            if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess)
+                return fail(h, BF_EHIP, "hipEventCreate failed");
+        }
+        return BF_OK;
+    }
     return fail(h, BF_EINVAL, "unknown option [%s]", key);
+}
+
+// elapsed ms between the events bracketing the residual-block launches of the LAST forward and
+// the number of kernel launches in that bracket.  The caller must have synchronised the stream.
+extern "C" int bf_get_timing(bf_handle h, float* ms, int* launches)
+{
+    if (!h || !ms || !launches) return BF_EINVAL;
+    if (!h->timing || !h->ev0) return fail(h, BF_EINVAL, "timing option is off");
+    hipError_t e = hipEventElapsedTime(ms, h->ev0, h->ev1);
+    if (e != hipSuccess) return hip_fail(h, e, "hipEventElapsedTime");
+    *launches = h->timed_launches;
+    return BF_OK;
 }
 
 extern "C" int64_t bf_packed_bytes(bf_handle h) { return h ? h->k_total * 4 : -1; }
@@ -314,6 +344,7 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
     BF_HIP(bf_launch_base_conv(ba, s), "base_conv");
 
     int cur = 0;
+    if (h->timing) BF_HIP(hipEventRecord(h->ev0, s), "hipEventRecord");
     for (int i = 0; i < d.no_layers; ++i) {
         const float* blk = pk + h->k_blocks + i * h->k_block_stride;
         if (h->fused_blocks) {
@@ -337,6 +368,10 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
             BF_HIP(bf_launch_conv3x3_c16(ca, EPI_AFFINE | EPI_RES, s), "conv2");
             cur = y;
         }
+    }
+    if (h->timing) {
+        BF_HIP(hipEventRecord(h->ev1, s), "hipEventRecord");
+        h->timed_launches = d.no_layers * (h->fused_blocks ? 1 : 2);
     }
     HeadArgs ha;
     ha.feat = buf[cur];

@@ -184,6 +184,11 @@ int bf_strided_slice2(const float* in, float* out, int batch, int height, int wi
 /* "fused_blocks" = 1 (default): one kernel per residual block; 0: one kernel per convolution. */
 int bf_set_option(bf_handle h, const char* key, int value);
 
+/* with option "timing" = 1 every forward brackets its residual-block launches with two HIP events on
+ * the caller's stream; after the caller has synchronised, this returns the elapsed milliseconds of
+ * the LAST forward's bracket and the number of kernel launches inside it (bench.py roofline). */
+int bf_get_timing(bf_handle h, float* ms, int* launches);
+
 /* single 3x3 16->16 convolution with epilogue flags (1 relu, 2 affine, 4 residual, 8 mask,
  * 16 stats); transpose_flip = 1 runs the data-gradient form.  wpack_scratch = 2*2304 floats. */
 int bf_debug_conv3x3(const float* in, const float* w_hwio, float* out, const float* scale, const float* shift,
