@@ -177,16 +177,22 @@ hipError_t bf_launch_conv3x3_c16(const ConvArgs& a, int epi, hipStream_t s)
 // One HBM read and one HBM write of the 16-channel activation per BLOCK (72 FLOP/B instead of
 // 36); the intermediate activation only ever exists in LDS.  Tile 14x32 outputs: input tile
 // 18x36 px (41,472 B) + intermediate 16x34 px (34,816 B) = 76,288 B LDS -> two 4-wave
-// workgroups per CU, so one workgroup's tile load overlaps the other's MFMAs.  The 16x34 = 544
-// intermediate pixels are exactly 34 MFMA groups, the 14x32 = 448 outputs exactly 28.
+// workgroups per CU.  The 16x34 = 544 intermediate pixels are exactly 34 MFMA groups, the
+// 14x32 = 448 outputs exactly 28 (groups that lie wholly outside the image are skipped).
 // Workgroups are persistent: weights (72 VGPRs) are fetched once; consecutive tiles of one
 // XCD-label (blockIdx % 8) are neighbours in the image so halos are L2 hits.
+// Software pipeline: the NEXT tile's 41 KB are fetched into registers (11 x 16 B per lane)
+// before conv1 of the current tile starts and only written to LDS after conv2 has finished, so
+// the HBM/L2 latency and the chip-wide load burst hide behind ~18k cycles of MFMA work per tile
+// (rocprof r01_v1: without it the MFMA pipe was 64 % busy, waves 29 % in s_waitcnt/s_barrier).
 // ------------------------------------------------------------------------------------------
 constexpr int FT_H = 14, FT_W = 32;
 constexpr int FT_MH = FT_H + 2, FT_MW = FT_W + 2;   // 16 x 34 intermediate
 constexpr int FT_IH = FT_H + 4, FT_IW = FT_W + 4;   // 18 x 36 input
 constexpr int FT_MG = FT_MH * FT_MW / 16;            // 34 groups
 constexpr int FT_OG = FT_H * FT_W / 16;              // 28 groups
+constexpr int FT_IN4 = FT_IH * FT_IW * 4;            // 2592 float4 per input tile
+constexpr int FT_PF = (FT_IN4 + 255) / 256;          // 11 float4 per lane
 static_assert(FT_MH * FT_MW % 16 == 0 && FT_H * FT_W % 16 == 0, "tile must be whole MFMA groups");
 
 template <int NG>
@@ -206,33 +212,121 @@ __device__ __forceinline__ void conv_groups(const float* __restrict__ src, const
     }
 }
 
+struct FusedTile {
+    int y0, x0;
+    size_t img;
+};
+
+__device__ __forceinline__ FusedTile fused_tile(const FusedBlockArgs& a, int t)
+{
+    FusedTile r;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int b = t / a.tiles_y;
+    r.y0 = ty * FT_H;
+    r.x0 = tx * FT_W;
+    r.img = (size_t)b * a.H * a.W * 16;
+    return r;
+}
+
+// issue the tile's global loads into registers (2 px halo, zeros outside the image); no wait
+__device__ __forceinline__ void fused_fetch(const FusedBlockArgs& a, const FusedTile& t, int tid, float4 (&pf)[FT_PF])
+{
+    const float* inb = a.in + t.img;
+#pragma unroll
+    for (int i = 0; i < FT_PF; ++i) {
+        const int n = tid + i * 256;
+        const int row = n / (FT_IW * 4);
+        const int rem = n - row * (FT_IW * 4);
+        const int gy = t.y0 - 2 + row, gx = t.x0 - 2 + (rem >> 2);
+        pf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < FT_IN4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+            pf[i] = *reinterpret_cast<const float4*>(inb + ((size_t)gy * a.W + gx) * 16 + (rem & 3) * 4);
+    }
+}
+
+__device__ __forceinline__ void fused_stage(float* __restrict__ tin, int tid, const float4 (&pf)[FT_PF])
+{
+#pragma unroll
+    for (int i = 0; i < FT_PF; ++i) {
+        const int n = tid + i * 256;
+        if (n < FT_IN4) *reinterpret_cast<float4*>(tin + n * 4) = pf[i];
+    }
+}
+
+// conv1 (+activation) of NG intermediate groups: input tile -> intermediate tile in LDS
+template <int NG>
+__device__ __forceinline__ void conv1_pass(const FusedBlockArgs& a, const float* __restrict__ tin, float* __restrict__ tmid,
+                                           const float (&w1)[36], const int (&g)[NG], const int p, const int q,
+                                           const FusedTile& t)
+{
+    int base[NG], f[NG];
+    f32x4 acc[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        f[j] = g[j] * 16 + p;
+        const int my = f[j] / FT_MW, mx = f[j] - my * FT_MW;
+        base[j] = (my * FT_IW + mx) * 16 + q * 4;
+        acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    conv_groups<NG>(tin, base, FT_IW, w1, acc);
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int my = f[j] / FT_MW, mx = f[j] - my * FT_MW;
+        const int gy = t.y0 - 1 + my, gx = t.x0 - 1 + mx;
+        f32x4 v = acc[j];
+        if (a.act1_relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        // conv2 sees ZERO padding outside the image, not conv1 evaluated there
+        if (gy < 0 || gy >= a.H || gx < 0 || gx >= a.W) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(tmid + f[j] * 16 + q * 4) = v;
+    }
+}
+
+// conv2 + folded BN + residual of NG output groups: intermediate tile -> global
 template <int NG>
 __device__ __forceinline__ void conv2_pass(const FusedBlockArgs& a, const float* __restrict__ tin,
                                            const float* __restrict__ tmid, const float (&w2)[36],
-                                           const f32x4 sc, const f32x4 sh, const int g_first,
-                                           const int p, const int q, const int y0, const int x0, const size_t img)
+                                           const f32x4 sc, const f32x4 sh, const int (&g)[NG],
+                                           const int p, const int q, const FusedTile& t)
 {
     int base[NG];
     f32x4 acc[NG];
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
-        const int g = g_first + 4 * j;
-        const int oy = g >> 1, ox = (g & 1) * 16 + p;
+        const int oy = g[j] >> 1, ox = (g[j] & 1) * 16 + p;
         base[j] = (oy * FT_MW + ox) * 16 + q * 4;
         acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     conv_groups<NG>(tmid, base, FT_MW, w2, acc);
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
-        const int g = g_first + 4 * j;
-        const int oy = g >> 1, ox = (g & 1) * 16 + p;
-        const int gy = y0 + oy, gx = x0 + ox;
+        const int oy = g[j] >> 1, ox = (g[j] & 1) * 16 + p;
+        const int gy = t.y0 + oy, gx = t.x0 + ox;
         if (gy < a.H && gx < a.W) {
             const f32x4 r = *reinterpret_cast<const f32x4*>(tin + ((oy + 2) * FT_IW + ox + 2) * 16 + q * 4);
             const f32x4 v = acc[j] * sc + sh + r;
-            *reinterpret_cast<f32x4*>(a.out + img + ((size_t)gy * a.W + gx) * 16 + q * 4) = v;
+            *reinterpret_cast<f32x4*>(a.out + t.img + ((size_t)gy * a.W + gx) * 16 + q * 4) = v;
         }
     }
+}
+
+// An intermediate group (flattened pixels 16g..16g+15 of the 16x34 region, origin (y0-1, x0-1)) is
+// needed iff one of its pixels can be read by an in-image output: image row <= H and col <= W.
+__device__ __forceinline__ bool mid_group_needed(const FusedBlockArgs& a, const FusedTile& t, int g)
+{
+    const int f0 = g * 16, f1 = f0 + 15;
+    const int r0 = f0 / FT_MW, r1 = f1 / FT_MW;
+    if (t.y0 - 1 + r0 > a.H) return false;
+    if (r0 == r1) return t.x0 - 1 + (f0 - r0 * FT_MW) <= a.W;
+    return true;                                  // spans two rows: its second row starts at column x0-1 <= W
+}
+
+__device__ __forceinline__ bool out_group_needed(const FusedBlockArgs& a, const FusedTile& t, int g)
+{
+    return t.y0 + (g >> 1) < a.H && t.x0 + (g & 1) * 16 < a.W;
 }
 
 __global__ __launch_bounds__(256, 2) void fused_block_kernel(FusedBlockArgs a)
@@ -240,7 +334,8 @@ __global__ __launch_bounds__(256, 2) void fused_block_kernel(FusedBlockArgs a)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* tin = lds;                                  // [18][36][16]
     float* tmid = lds + FT_IH * FT_IW * 16;            // [16][34][16]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p = lane & 15, q = lane >> 4;
 
     float w1[36], w2[36];
@@ -258,65 +353,54 @@ __global__ __launch_bounds__(256, 2) void fused_block_kernel(FusedBlockArgs a)
     const int t_begin = label * chunk;
     const int t_end = min(a.ntiles, t_begin + chunk);
 
-    for (int t = t_begin + slot; t < t_end; t += per_label) {
-        int tt = t;
-        const int tx = tt % a.tiles_x; tt /= a.tiles_x;
-        const int ty = tt % a.tiles_y;
-        const int b = tt / a.tiles_y;
-        const int y0 = ty * FT_H, x0 = tx * FT_W;
-        const size_t img = (size_t)b * a.H * a.W * 16;
-        const float* inb = a.in + img;
+    int t = t_begin + slot;
+    if (t >= t_end) return;                            // uniform per workgroup
+    float4 pf[FT_PF];
+    FusedTile cur = fused_tile(a, t);
+    fused_fetch(a, cur, tid, pf);
+    fused_stage(tin, tid, pf);
+    __syncthreads();
 
-        // ---- stage the input tile (2 px halo, zero outside the image) --------------------
-        for (int n = tid; n < FT_IH * FT_IW * 4; n += 256) {
-            const int row = n / (FT_IW * 4);
-            const int rem = n - row * (FT_IW * 4);
-            const int gy = y0 - 2 + row, gx = x0 - 2 + (rem >> 2);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                v = *reinterpret_cast<const float4*>(inb + ((size_t)gy * a.W + gx) * 16 + (rem & 3) * 4);
-            *reinterpret_cast<float4*>(tin + n * 4) = v;
+    for (; t < t_end; t += per_label) {
+        const int tn = t + per_label;
+        const bool has_next = tn < t_end;
+        FusedTile nxt = cur;
+        if (has_next) {                                // prefetch: in flight during conv1 + conv2
+            nxt = fused_tile(a, tn);
+            fused_fetch(a, nxt, tid, pf);
+        }
+
+        // ---- conv1: wave w takes groups w, w+4, ... ; up to three per pass ------------------
+        for (int g = wave; g < FT_MG;) {
+            int g0 = -1, g1 = -1, g2 = -1;
+            for (; g < FT_MG && g2 < 0; g += 4) {
+                if (!mid_group_needed(a, cur, g)) continue;
+                if (g0 < 0) g0 = g; else if (g1 < 0) g1 = g; else g2 = g;
+            }
+            if (g2 >= 0)      { const int gs[3] = {g0, g1, g2}; conv1_pass<3>(a, tin, tmid, w1, gs, p, q, cur); }
+            else if (g1 >= 0) { const int gs[2] = {g0, g1};     conv1_pass<2>(a, tin, tmid, w1, gs, p, q, cur); }
+            else if (g0 >= 0) { const int gs[1] = {g0};         conv1_pass<1>(a, tin, tmid, w1, gs, p, q, cur); }
         }
         __syncthreads();
 
-        // ---- conv1 (+activation) on the 16x34 intermediate region -> LDS -----------------
-        // group g covers flattened intermediate pixels 16g..16g+15; wave w takes g = w, w+4, ...
-        for (int g0 = wave; g0 < FT_MG; g0 += 12) {
-            // up to three groups per pass: g0, g0+4, g0+8
-            int base[3], f[3];
-            f32x4 acc[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                int g = g0 + 4 * j;
-                if (g >= FT_MG) g = g0;                    // duplicate work, result discarded
-                f[j] = g * 16 + p;
-                const int my = f[j] / FT_MW, mx = f[j] - my * FT_MW;
-                base[j] = (my * FT_IW + mx) * 16 + q * 4;
-                acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // ---- conv2 + folded BN + residual: wave w takes groups w, w+4, ... ; up to four per pass
+        for (int g = wave; g < FT_OG;) {
+            int g0 = -1, g1 = -1, g2 = -1, g3 = -1;
+            for (; g < FT_OG && g3 < 0; g += 4) {
+                if (!out_group_needed(a, cur, g)) continue;
+                if (g0 < 0) g0 = g; else if (g1 < 0) g1 = g; else if (g2 < 0) g2 = g; else g3 = g;
             }
-            conv_groups<3>(tin, base, FT_IW, w1, acc);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                if (g0 + 4 * j < FT_MG) {
-                    const int my = f[j] / FT_MW, mx = f[j] - my * FT_MW;
-                    const int gy = y0 - 1 + my, gx = x0 - 1 + mx;
-                    f32x4 v = acc[j];
-                    if (a.act1_relu) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    }
-                    // conv2 sees ZERO padding outside the image, not conv1 evaluated there
-                    if (gy < 0 || gy >= a.H || gx < 0 || gx >= a.W) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    *reinterpret_cast<f32x4*>(tmid + f[j] * 16 + q * 4) = v;
-                }
-            }
+            if (g3 >= 0)      { const int gs[4] = {g0, g1, g2, g3}; conv2_pass<4>(a, tin, tmid, w2, sc, sh, gs, p, q, cur); }
+            else if (g2 >= 0) { const int gs[3] = {g0, g1, g2};     conv2_pass<3>(a, tin, tmid, w2, sc, sh, gs, p, q, cur); }
+            else if (g1 >= 0) { const int gs[2] = {g0, g1};         conv2_pass<2>(a, tin, tmid, w2, sc, sh, gs, p, q, cur); }
+            else if (g0 >= 0) { const int gs[1] = {g0};             conv2_pass<1>(a, tin, tmid, w2, sc, sh, gs, p, q, cur); }
         }
-        __syncthreads();
-
-        // ---- conv2 + folded BN + residual -> global ----------------------------------------
-        // 28 groups: wave w takes g = w, w+4, ..., w+24 (7 each): one pass of 4, one of 3
-        conv2_pass<4>(a, tin, tmid, w2, sc, sh, wave, p, q, y0, x0, img);
-        conv2_pass<3>(a, tin, tmid, w2, sc, sh, wave + 16, p, q, y0, x0, img);
-        __syncthreads();   // tin / tmid are overwritten by the next tile
+        __syncthreads();                               // every wave is done with tin / tmid
+        if (has_next) {
+            fused_stage(tin, tid, pf);                 // waits for the prefetch here, one tile late
+            __syncthreads();
+        }
+        cur = nxt;
     }
 }
 

@@ -11,56 +11,62 @@
 // Source image [B,Hs,Ws,Cin] (u8 or f32); output [B,H,W,16] with H >= Hs, W >= Ws.  Pixels in
 // the padded band carry the value 0 (=> normalised -0.5), pixels outside HxW are conv zeros.
 // ------------------------------------------------------------------------------------------
+// One workgroup = one 16x16 output tile.  The (16+K-1)^2 input patch is normalised once into LDS
+// (3 B/px of HBM reads instead of K*K byte loads per output pixel); the K*K*Cin*16 weights are
+// wave-uniform and reach the FMAs through scalar loads; each lane writes its pixel's 16 channels
+// as four 16-byte stores.
+constexpr int BC_T = 16;
+
 template <int CIN, int K, bool U8>
 __global__ __launch_bounds__(256) void base_conv_kernel(BaseConvArgs a)
 {
-    __shared__ float ws[K * K * CIN * 16];
-    for (int i = threadIdx.x; i < K * K * CIN * 16; i += 256) ws[i] = a.w[i];
-    __syncthreads();
-    const int64_t npix = (int64_t)a.B * a.H * a.W;
+    constexpr int R = K / 2, IT = BC_T + 2 * R;
+    __shared__ float tile[IT * IT * CIN];
+    const float* __restrict__ wg = a.w;
+    const int tiles_x = (a.W + BC_T - 1) / BC_T, tiles_y = (a.H + BC_T - 1) / BC_T;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int y0 = ty * BC_T, x0 = tx * BC_T;
     const float range = a.v_max - a.v_min;       // true division: (x - min) / (max - min) - 0.5 is exact for mid-grey
-    for (int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * 256) {
-        const int x = (int)(pix % a.W);
-        const int64_t t = pix / a.W;
-        const int y = (int)(t % a.H);
-        const int b = (int)(t / a.H);
-        float acc[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) acc[c] = 0.f;
-#pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
-            const int gy = y + ky - K / 2;
-#pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const int gx = x + kx - K / 2;
-                if (gy < 0 || gy >= a.H || gx < 0 || gx >= a.W) continue;   // conv zero padding
-                float v[CIN];
-                if (gy < a.Hs && gx < a.Ws) {
-                    const int64_t si = (((int64_t)b * a.Hs + gy) * a.Ws + gx) * CIN;
-#pragma unroll
-                    for (int ci = 0; ci < CIN; ++ci) {
-                        const float raw = U8 ? (float)reinterpret_cast<const uint8_t*>(a.in)[si + ci]
-                                             : reinterpret_cast<const float*>(a.in)[si + ci];
-                        v[ci] = (fminf(fmaxf(raw, a.v_min), a.v_max) - a.v_min) / range - 0.5f;
-                    }
-                } else {
-#pragma unroll
-                    for (int ci = 0; ci < CIN; ++ci)       // pad_to_power_of_2 band: value 0
-                        v[ci] = (fminf(fmaxf(0.f, a.v_min), a.v_max) - a.v_min) / range - 0.5f;
-                }
-#pragma unroll
-                for (int ci = 0; ci < CIN; ++ci) {
-                    const float* wr = ws + ((ky * K + kx) * CIN + ci) * 16;
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) acc[c] = fmaf(v[ci], wr[c], acc[c]);
-                }
+    for (int n = threadIdx.x; n < IT * IT * CIN; n += 256) {
+        const int ci = n % CIN, px = (n / CIN) % IT, row = n / (CIN * IT);
+        const int gy = y0 - R + row, gx = x0 - R + px;
+        float v = 0.f;                                          // conv zero padding outside H x W
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+            float raw = 0.f;                                    // pad_to_power_of_2 band: value 0
+            if (gy < a.Hs && gx < a.Ws) {
+                const int64_t si = (((int64_t)b * a.Hs + gy) * a.Ws + gx) * CIN + ci;
+                raw = U8 ? (float)reinterpret_cast<const uint8_t*>(a.in)[si] : reinterpret_cast<const float*>(a.in)[si];
             }
+            v = (fminf(fmaxf(raw, a.v_min), a.v_max) - a.v_min) / range - 0.5f;
         }
+        tile[n] = v;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
+    const int y = y0 + ly, x = x0 + lx;
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                const float v = tile[((ly + ky) * IT + lx + kx) * CIN + ci];
+                const float* wr = wg + ((ky * K + kx) * CIN + ci) * 16;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) acc[c] = fmaf(v, wr[c], acc[c]);
+            }
+    if (y < a.H && x < a.W) {
         if (a.act_relu) {
 #pragma unroll
             for (int c = 0; c < 16; ++c) acc[c] = fmaxf(acc[c], 0.f);
         }
-        float4* o = reinterpret_cast<float4*>(a.out + pix * 16);
+        float4* o = reinterpret_cast<float4*>(a.out + (((int64_t)b * a.H + y) * a.W + x) * 16);
         o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
         o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
         o[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
@@ -71,9 +77,7 @@ __global__ __launch_bounds__(256) void base_conv_kernel(BaseConvArgs a)
 template <int CIN, int K>
 static hipError_t launch_base(const BaseConvArgs& a, hipStream_t s)
 {
-    const int64_t npix = (int64_t)a.B * a.H * a.W;
-    int64_t g = (npix + 255) / 256;
-    const int grid = (int)(g < 8192 ? g : 8192);
+    const int grid = a.B * ((a.H + BC_T - 1) / BC_T) * ((a.W + BC_T - 1) / BC_T);
     if (a.in_is_u8) hipLaunchKernelGGL((base_conv_kernel<CIN, K, true>), dim3(grid), dim3(256), 0, s, a);
     else            hipLaunchKernelGGL((base_conv_kernel<CIN, K, false>), dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
