@@ -22,6 +22,7 @@ run_bench() {
     timeout -k 10 600 python bench.py --steps 10 --warmup 3 2> "$out/bench.err" | tee "$out/bench.json"
 }
 run_prof() {
+    rm -rf "$out/prof"
     cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$out/prof" -- \
         python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/$out/prof_bench.log" 2>&1
     rc=$?
