@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="one kernel per convolution (A/B only)")
+    ap.add_argument("--fused-tile", type=int, default=None, help="fused-block tile geometry variant (A/B only)")
     args = ap.parse_args()
 
     import torch
@@ -98,6 +99,8 @@ def main():
     model.set_weights(params, state)
     if args.unfused:
         model.set_option("fused_blocks", 0)
+    if args.fused_tile is not None:
+        model.set_option("fused_tile", args.fused_tile)
     model.set_option("timing", 1)
     module = bf.DenoiserModule(model)
 

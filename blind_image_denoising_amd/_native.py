@@ -10,7 +10,8 @@ import os
 import pathlib
 
 _HERE = pathlib.Path(__file__).resolve().parent
-LIB_PATH = _HERE / "lib" / "libbfcnn_hip.so"
+# BFCNN_HIP_LIB selects another build of the SAME library (tools/ablate.sh timing experiments)
+LIB_PATH = pathlib.Path(os.environ.get("BFCNN_HIP_LIB", _HERE / "lib" / "libbfcnn_hip.so"))
 
 BF_OK, BF_EINVAL, BF_EUNSUPPORTED, BF_EWORKSPACE, BF_EHIP = 0, -1, -2, -3, -4
 BF_ACT_LINEAR, BF_ACT_RELU, BF_ACT_LEAKY_RELU = 0, 1, 2

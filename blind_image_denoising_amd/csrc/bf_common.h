@@ -43,6 +43,7 @@ struct FusedBlockArgs {
 hipError_t bf_launch_conv3x3_c16(const ConvArgs& a, int epi, hipStream_t s);
 int        bf_conv3x3_c16_grid(int B, int H, int W);
 hipError_t bf_launch_fused_block(const FusedBlockArgs& a, hipStream_t s);
+void       bf_set_fused_tile(int variant);   // A/B of tile geometries (process-wide, tools/ only)
 hipError_t bf_launch_pack_conv(const float* w_hwio, float* wpack, int transpose_flip, hipStream_t s);
 hipError_t bf_launch_wgrad3x3_c16(const float* x, const float* dy, float* partial, float* dw,
                                   int B, int H, int W, hipStream_t s);

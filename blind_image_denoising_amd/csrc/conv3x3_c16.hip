@@ -15,6 +15,17 @@
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// timing-only ablations of the fused kernel (tools/ablate.sh builds them into lib/variants/; results
+// are WRONG when any is set): 1 = no barriers, 2 = no next-tile fetch/stage, 4 = no global stores
+#ifndef BF_ABLATE
+#define BF_ABLATE 0
+#endif
+#if BF_ABLATE & 1
+#define FUSED_SYNC() __builtin_amdgcn_sched_barrier(0)
+#else
+#define FUSED_SYNC() __syncthreads()
+#endif
+
 // ------------------------------------------------------------------------------------------
 // weight packing: HWIO [3,3,16,16] -> wpack[(tap*4+kk)*64 + lane] = W[tap][4*(lane>>4)+kk][lane&15]
 // transpose_flip = 1 packs the data-gradient kernel W'[tap][ci][co] = W[8-tap][co][ci].
@@ -186,14 +197,21 @@ hipError_t bf_launch_conv3x3_c16(const ConvArgs& a, int epi, hipStream_t s)
 // the HBM/L2 latency and the chip-wide load burst hide behind ~18k cycles of MFMA work per tile
 // (rocprof r01_v1: without it the MFMA pipe was 64 % busy, waves 29 % in s_waitcnt/s_barrier).
 // ------------------------------------------------------------------------------------------
-constexpr int FT_H = 14, FT_W = 32;
-constexpr int FT_MH = FT_H + 2, FT_MW = FT_W + 2;   // 16 x 34 intermediate
-constexpr int FT_IH = FT_H + 4, FT_IW = FT_W + 4;   // 18 x 36 input
-constexpr int FT_MG = FT_MH * FT_MW / 16;            // 34 groups
-constexpr int FT_OG = FT_H * FT_W / 16;              // 28 groups
-constexpr int FT_IN4 = FT_IH * FT_IW * 4;            // 2592 float4 per input tile
-constexpr int FT_PF = (FT_IN4 + 255) / 256;          // 11 float4 per lane
-static_assert(FT_MH * FT_MW % 16 == 0 && FT_H * FT_W % 16 == 0, "tile must be whole MFMA groups");
+// Tile geometry is a template parameter (TH x TW outputs, NW waves per workgroup) so that shapes can
+// be A/B-ed in one binary (bf_set_option "fused_tile"); intermediate pixels are flattened into
+// 16-pixel MFMA groups, so any TH, TW works (a partial last group computes garbage that is never read).
+template <int TH_, int TW_, int NW_>
+struct FusedCfg {
+    static constexpr int TH = TH_, TW = TW_, NW = NW_, NT = NW_ * 64;
+    static constexpr int MH = TH + 2, MW = TW + 2;        // intermediate region
+    static constexpr int IH = TH + 4, IW = TW + 4;        // input region
+    static constexpr int MG = (MH * MW + 15) / 16;        // conv1 groups
+    static constexpr int OG = (TH * TW + 15) / 16;        // conv2 groups
+    static constexpr int IN4 = IH * IW * 4;               // float4 per input tile
+    static constexpr int PF = (IN4 + NT - 1) / NT;        // float4 per lane in the prefetch
+    static constexpr int TIN_FLOATS = IH * IW * 16;
+    static constexpr int LDS_BYTES = (TIN_FLOATS + MG * 256) * 4;
+};
 
 template <int NG>
 __device__ __forceinline__ void conv_groups(const float* __restrict__ src, const int (&base)[NG],
@@ -217,6 +235,7 @@ struct FusedTile {
     size_t img;
 };
 
+template <class Cfg>
 __device__ __forceinline__ FusedTile fused_tile(const FusedBlockArgs& a, int t)
 {
     FusedTile r;
@@ -224,39 +243,41 @@ __device__ __forceinline__ FusedTile fused_tile(const FusedBlockArgs& a, int t)
     t /= a.tiles_x;
     const int ty = t % a.tiles_y;
     const int b = t / a.tiles_y;
-    r.y0 = ty * FT_H;
-    r.x0 = tx * FT_W;
+    r.y0 = ty * Cfg::TH;
+    r.x0 = tx * Cfg::TW;
     r.img = (size_t)b * a.H * a.W * 16;
     return r;
 }
 
 // issue the tile's global loads into registers (2 px halo, zeros outside the image); no wait
-__device__ __forceinline__ void fused_fetch(const FusedBlockArgs& a, const FusedTile& t, int tid, float4 (&pf)[FT_PF])
+template <class Cfg>
+__device__ __forceinline__ void fused_fetch(const FusedBlockArgs& a, const FusedTile& t, int tid, float4 (&pf)[Cfg::PF])
 {
     const float* inb = a.in + t.img;
 #pragma unroll
-    for (int i = 0; i < FT_PF; ++i) {
-        const int n = tid + i * 256;
-        const int row = n / (FT_IW * 4);
-        const int rem = n - row * (FT_IW * 4);
+    for (int i = 0; i < Cfg::PF; ++i) {
+        const int n = tid + i * Cfg::NT;
+        const int row = n / (Cfg::IW * 4);
+        const int rem = n - row * (Cfg::IW * 4);
         const int gy = t.y0 - 2 + row, gx = t.x0 - 2 + (rem >> 2);
         pf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < FT_IN4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+        if (n < Cfg::IN4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
             pf[i] = *reinterpret_cast<const float4*>(inb + ((size_t)gy * a.W + gx) * 16 + (rem & 3) * 4);
     }
 }
 
-__device__ __forceinline__ void fused_stage(float* __restrict__ tin, int tid, const float4 (&pf)[FT_PF])
+template <class Cfg>
+__device__ __forceinline__ void fused_stage(float* __restrict__ tin, int tid, const float4 (&pf)[Cfg::PF])
 {
 #pragma unroll
-    for (int i = 0; i < FT_PF; ++i) {
-        const int n = tid + i * 256;
-        if (n < FT_IN4) *reinterpret_cast<float4*>(tin + n * 4) = pf[i];
+    for (int i = 0; i < Cfg::PF; ++i) {
+        const int n = tid + i * Cfg::NT;
+        if (n < Cfg::IN4) *reinterpret_cast<float4*>(tin + n * 4) = pf[i];
     }
 }
 
 // conv1 (+activation) of NG intermediate groups: input tile -> intermediate tile in LDS
-template <int NG>
+template <class Cfg, int NG>
 __device__ __forceinline__ void conv1_pass(const FusedBlockArgs& a, const float* __restrict__ tin, float* __restrict__ tmid,
                                            const float (&w1)[36], const int (&g)[NG], const int p, const int q,
                                            const FusedTile& t)
@@ -266,14 +287,14 @@ __device__ __forceinline__ void conv1_pass(const FusedBlockArgs& a, const float*
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
         f[j] = g[j] * 16 + p;
-        const int my = f[j] / FT_MW, mx = f[j] - my * FT_MW;
-        base[j] = (my * FT_IW + mx) * 16 + q * 4;
+        const int my = f[j] / Cfg::MW, mx = f[j] - my * Cfg::MW;
+        base[j] = (my * Cfg::IW + mx) * 16 + q * 4;
         acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    conv_groups<NG>(tin, base, FT_IW, w1, acc);
+    conv_groups<NG>(tin, base, Cfg::IW, w1, acc);
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
-        const int my = f[j] / FT_MW, mx = f[j] - my * FT_MW;
+        const int my = f[j] / Cfg::MW, mx = f[j] - my * Cfg::MW;
         const int gy = t.y0 - 1 + my, gx = t.x0 - 1 + mx;
         f32x4 v = acc[j];
         if (a.act1_relu) {
@@ -286,54 +307,66 @@ __device__ __forceinline__ void conv1_pass(const FusedBlockArgs& a, const float*
 }
 
 // conv2 + folded BN + residual of NG output groups: intermediate tile -> global
-template <int NG>
+template <class Cfg, int NG>
 __device__ __forceinline__ void conv2_pass(const FusedBlockArgs& a, const float* __restrict__ tin,
                                            const float* __restrict__ tmid, const float (&w2)[36],
                                            const f32x4 sc, const f32x4 sh, const int (&g)[NG],
                                            const int p, const int q, const FusedTile& t)
 {
-    int base[NG];
+    int base[NG], oy[NG], ox[NG];
+    bool ok[NG];
     f32x4 acc[NG];
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
-        const int oy = g[j] >> 1, ox = (g[j] & 1) * 16 + p;
-        base[j] = (oy * FT_MW + ox) * 16 + q * 4;
+        int f = g[j] * 16 + p;
+        ok[j] = f < Cfg::TH * Cfg::TW;
+        if (!ok[j]) f = 0;                               // partial last group: clamp, result discarded
+        oy[j] = f / Cfg::TW;
+        ox[j] = f - oy[j] * Cfg::TW;
+        base[j] = (oy[j] * Cfg::MW + ox[j]) * 16 + q * 4;
         acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    conv_groups<NG>(tmid, base, FT_MW, w2, acc);
+    conv_groups<NG>(tmid, base, Cfg::MW, w2, acc);
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
-        const int oy = g[j] >> 1, ox = (g[j] & 1) * 16 + p;
-        const int gy = t.y0 + oy, gx = t.x0 + ox;
-        if (gy < a.H && gx < a.W) {
-            const f32x4 r = *reinterpret_cast<const f32x4*>(tin + ((oy + 2) * FT_IW + ox + 2) * 16 + q * 4);
+        const int gy = t.y0 + oy[j], gx = t.x0 + ox[j];
+        if (ok[j] && gy < a.H && gx < a.W) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(tin + ((oy[j] + 2) * Cfg::IW + ox[j] + 2) * 16 + q * 4);
             const f32x4 v = acc[j] * sc + sh + r;
-            *reinterpret_cast<f32x4*>(a.out + t.img + ((size_t)gy * a.W + gx) * 16 + q * 4) = v;
+            if (BF_ABLATE & 4) { if (v.x == 12345.678f) a.out[0] = v.y; }       // keeps the MFMAs live
+            else *reinterpret_cast<f32x4*>(a.out + t.img + ((size_t)gy * a.W + gx) * 16 + q * 4) = v;
         }
     }
 }
 
-// An intermediate group (flattened pixels 16g..16g+15 of the 16x34 region, origin (y0-1, x0-1)) is
+// An intermediate group (flattened pixels 16g..16g+15 of the MH x MW region, origin (y0-1, x0-1)) is
 // needed iff one of its pixels can be read by an in-image output: image row <= H and col <= W.
+template <class Cfg>
 __device__ __forceinline__ bool mid_group_needed(const FusedBlockArgs& a, const FusedTile& t, int g)
 {
     const int f0 = g * 16, f1 = f0 + 15;
-    const int r0 = f0 / FT_MW, r1 = f1 / FT_MW;
+    const int r0 = f0 / Cfg::MW, r1 = f1 / Cfg::MW;
     if (t.y0 - 1 + r0 > a.H) return false;
-    if (r0 == r1) return t.x0 - 1 + (f0 - r0 * FT_MW) <= a.W;
+    if (r0 == r1) return t.x0 - 1 + (f0 - r0 * Cfg::MW) <= a.W;
     return true;                                  // spans two rows: its second row starts at column x0-1 <= W
 }
 
+template <class Cfg>
 __device__ __forceinline__ bool out_group_needed(const FusedBlockArgs& a, const FusedTile& t, int g)
 {
-    return t.y0 + (g >> 1) < a.H && t.x0 + (g & 1) * 16 < a.W;
+    const int f0 = g * 16;
+    const int r0 = f0 / Cfg::TW, r1 = (f0 + 15) / Cfg::TW;
+    if (t.y0 + r0 >= a.H) return false;
+    if (r0 == r1) return t.x0 + (f0 - r0 * Cfg::TW) < a.W;
+    return true;
 }
 
-__global__ __launch_bounds__(256, 2) void fused_block_kernel(FusedBlockArgs a)
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT, 2) void fused_block_kernel(FusedBlockArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* tin = lds;                                  // [18][36][16]
-    float* tmid = lds + FT_IH * FT_IW * 16;            // [16][34][16]
+    float* tin = lds;                                  // [IH][IW][16]
+    float* tmid = lds + Cfg::TIN_FLOATS;               // [MG*16][16]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p = lane & 15, q = lane >> 4;
@@ -355,73 +388,85 @@ __global__ __launch_bounds__(256, 2) void fused_block_kernel(FusedBlockArgs a)
 
     int t = t_begin + slot;
     if (t >= t_end) return;                            // uniform per workgroup
-    float4 pf[FT_PF];
-    FusedTile cur = fused_tile(a, t);
-    fused_fetch(a, cur, tid, pf);
-    fused_stage(tin, tid, pf);
-    __syncthreads();
+    float4 pf[Cfg::PF];
+    FusedTile cur = fused_tile<Cfg>(a, t);
+    fused_fetch<Cfg>(a, cur, tid, pf);
+    fused_stage<Cfg>(tin, tid, pf);
+    FUSED_SYNC();
 
     for (; t < t_end; t += per_label) {
         const int tn = t + per_label;
         const bool has_next = tn < t_end;
         FusedTile nxt = cur;
         if (has_next) {                                // prefetch: in flight during conv1 + conv2
-            nxt = fused_tile(a, tn);
-            fused_fetch(a, nxt, tid, pf);
+            nxt = fused_tile<Cfg>(a, tn);
+            if (!(BF_ABLATE & 2)) fused_fetch<Cfg>(a, nxt, tid, pf);
         }
 
-        // ---- conv1: wave w takes groups w, w+4, ... ; up to three per pass ------------------
-        for (int g = wave; g < FT_MG;) {
+        // ---- conv1: wave w takes groups w, w+NW, ... ; up to three per pass -----------------
+        for (int g = wave; g < Cfg::MG;) {
             int g0 = -1, g1 = -1, g2 = -1;
-            for (; g < FT_MG && g2 < 0; g += 4) {
-                if (!mid_group_needed(a, cur, g)) continue;
+            for (; g < Cfg::MG && g2 < 0; g += Cfg::NW) {
+                if (!mid_group_needed<Cfg>(a, cur, g)) continue;
                 if (g0 < 0) g0 = g; else if (g1 < 0) g1 = g; else g2 = g;
             }
-            if (g2 >= 0)      { const int gs[3] = {g0, g1, g2}; conv1_pass<3>(a, tin, tmid, w1, gs, p, q, cur); }
-            else if (g1 >= 0) { const int gs[2] = {g0, g1};     conv1_pass<2>(a, tin, tmid, w1, gs, p, q, cur); }
-            else if (g0 >= 0) { const int gs[1] = {g0};         conv1_pass<1>(a, tin, tmid, w1, gs, p, q, cur); }
+            if (g2 >= 0)      { const int gs[3] = {g0, g1, g2}; conv1_pass<Cfg, 3>(a, tin, tmid, w1, gs, p, q, cur); }
+            else if (g1 >= 0) { const int gs[2] = {g0, g1};     conv1_pass<Cfg, 2>(a, tin, tmid, w1, gs, p, q, cur); }
+            else if (g0 >= 0) { const int gs[1] = {g0};         conv1_pass<Cfg, 1>(a, tin, tmid, w1, gs, p, q, cur); }
         }
-        __syncthreads();
+        FUSED_SYNC();
 
-        // ---- conv2 + folded BN + residual: wave w takes groups w, w+4, ... ; up to four per pass
-        for (int g = wave; g < FT_OG;) {
+        // ---- conv2 + folded BN + residual: wave w takes groups w, w+NW, ... ; up to four per pass
+        for (int g = wave; g < Cfg::OG;) {
             int g0 = -1, g1 = -1, g2 = -1, g3 = -1;
-            for (; g < FT_OG && g3 < 0; g += 4) {
-                if (!out_group_needed(a, cur, g)) continue;
+            for (; g < Cfg::OG && g3 < 0; g += Cfg::NW) {
+                if (!out_group_needed<Cfg>(a, cur, g)) continue;
                 if (g0 < 0) g0 = g; else if (g1 < 0) g1 = g; else if (g2 < 0) g2 = g; else g3 = g;
             }
-            if (g3 >= 0)      { const int gs[4] = {g0, g1, g2, g3}; conv2_pass<4>(a, tin, tmid, w2, sc, sh, gs, p, q, cur); }
-            else if (g2 >= 0) { const int gs[3] = {g0, g1, g2};     conv2_pass<3>(a, tin, tmid, w2, sc, sh, gs, p, q, cur); }
-            else if (g1 >= 0) { const int gs[2] = {g0, g1};         conv2_pass<2>(a, tin, tmid, w2, sc, sh, gs, p, q, cur); }
-            else if (g0 >= 0) { const int gs[1] = {g0};             conv2_pass<1>(a, tin, tmid, w2, sc, sh, gs, p, q, cur); }
+            if (g3 >= 0)      { const int gs[4] = {g0, g1, g2, g3}; conv2_pass<Cfg, 4>(a, tin, tmid, w2, sc, sh, gs, p, q, cur); }
+            else if (g2 >= 0) { const int gs[3] = {g0, g1, g2};     conv2_pass<Cfg, 3>(a, tin, tmid, w2, sc, sh, gs, p, q, cur); }
+            else if (g1 >= 0) { const int gs[2] = {g0, g1};         conv2_pass<Cfg, 2>(a, tin, tmid, w2, sc, sh, gs, p, q, cur); }
+            else if (g0 >= 0) { const int gs[1] = {g0};             conv2_pass<Cfg, 1>(a, tin, tmid, w2, sc, sh, gs, p, q, cur); }
         }
-        __syncthreads();                               // every wave is done with tin / tmid
-        if (has_next) {
-            fused_stage(tin, tid, pf);                 // waits for the prefetch here, one tile late
-            __syncthreads();
+        FUSED_SYNC();                                  // every wave is done with tin / tmid
+        if (has_next && !(BF_ABLATE & 2)) {
+            fused_stage<Cfg>(tin, tid, pf);            // waits for the prefetch here, one tile late
+            FUSED_SYNC();
         }
         cur = nxt;
     }
 }
 
-hipError_t bf_launch_fused_block(const FusedBlockArgs& a0, hipStream_t s)
+static int g_fused_tile = 0;      // 0: 14x32 x4 waves (2 workgroups/CU) ; 1: 32x32 x8 waves ; 2: 16x64 x8 waves
+void bf_set_fused_tile(int v) { g_fused_tile = v; }
+
+template <class Cfg>
+static hipError_t launch_fused(FusedBlockArgs a, int wgs_per_cu, hipStream_t s)
 {
-    FusedBlockArgs a = a0;
-    a.tiles_x = (a.W + FT_W - 1) / FT_W;
-    a.tiles_y = (a.H + FT_H - 1) / FT_H;
+    a.tiles_x = (a.W + Cfg::TW - 1) / Cfg::TW;
+    a.tiles_y = (a.H + Cfg::TH - 1) / Cfg::TH;
     a.ntiles = a.B * a.tiles_x * a.tiles_y;
-    constexpr int lds_bytes = (FT_IH * FT_IW + FT_MH * FT_MW) * 16 * 4;   // 76,288
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_block_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_block_kernel<Cfg>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    int grid = a.ntiles < 512 ? a.ntiles : 512;          // 2 workgroups per CU x 256 CUs
+    const int resident = 256 * wgs_per_cu;
+    int grid = a.ntiles < resident ? a.ntiles : resident;
     if (grid >= 8) grid -= grid % 8;
-    hipLaunchKernelGGL(fused_block_kernel, dim3(grid), dim3(256), lds_bytes, s, a);
+    hipLaunchKernelGGL(fused_block_kernel<Cfg>, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, s, a);
     return hipGetLastError();
+}
+
+hipError_t bf_launch_fused_block(const FusedBlockArgs& a, hipStream_t s)
+{
+    switch (g_fused_tile) {
+        case 1: return launch_fused<FusedCfg<32, 32, 8>>(a, 1, s);
+        case 2: return launch_fused<FusedCfg<16, 64, 8>>(a, 1, s);
+        default: return launch_fused<FusedCfg<14, 32, 4>>(a, 2, s);
+    }
 }
 
 // ------------------------------------------------------------------------------------------

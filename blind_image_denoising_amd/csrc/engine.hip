@@ -167,6 +167,7 @@ extern "C" int bf_set_option(bf_handle h, const char* key, int value)
 {
     if (!h || !key) return BF_EINVAL;
     if (!strcmp(key, "fused_blocks")) { h->fused_blocks = value ? 1 : 0; return BF_OK; }
+    if (!strcmp(key, "fused_tile")) { bf_set_fused_tile(value); return BF_OK; }
     if (!strcmp(key, "timing")) {
         h->timing = value ? 1 : 0;
         if (h->timing && !h->ev0) {

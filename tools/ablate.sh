@@ -1,0 +1,14 @@
+#!/bin/bash
+# Builds timing-only ablation variants of the library into blind_image_denoising_amd/lib/variants/.
+set -euo pipefail
+cd "$(dirname "$0")/.."
+src=blind_image_denoising_amd/csrc
+out=blind_image_denoising_amd/lib/variants
+mkdir -p "$out"
+for v in "$@"; do
+    /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -DBF_ABLATE=$v \
+        $src/conv3x3_c16.hip $src/edge_layers.hip $src/train_ops.hip $src/pyramid.hip $src/engine.hip \
+        -o "$out/libbfcnn_hip_ablate$v.so" 2>/dev/null &
+done
+wait
+ls -la "$out"
