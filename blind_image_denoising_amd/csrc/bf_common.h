@@ -37,6 +37,7 @@ struct FusedBlockArgs {
     int B, H, W;
     int tiles_x, tiles_y, ntiles;
     int act1_relu;        // activation of conv1 (1 = relu, 0 = linear)
+    unsigned long long* dbg;  // diagnostic builds only (per-wave phase cycle sums), else NULL
 };
 
 // ---- launchers (each returns hipGetLastError()) -------------------------------------------

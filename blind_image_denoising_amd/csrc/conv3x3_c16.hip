@@ -20,6 +20,20 @@
 #ifndef BF_ABLATE
 #define BF_ABLATE 0
 #endif
+// 8 = in-kernel s_memtime stamps per phase (diagnostic build; sums per wave go to args.dbg)
+#if BF_ABLATE & 8
+#define STAMP(k)                                                                                         \
+    do {                                                                                                 \
+        unsigned long long now_;                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");                      \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        stamp_sum[k] += now_ - stamp_prev;                                                               \
+        stamp_prev = now_;                                                                               \
+    } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
 #if BF_ABLATE & 1
 #define FUSED_SYNC() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -198,19 +212,31 @@ hipError_t bf_launch_conv3x3_c16(const ConvArgs& a, int epi, hipStream_t s)
 // (rocprof r01_v1: without it the MFMA pipe was 64 % busy, waves 29 % in s_waitcnt/s_barrier).
 // ------------------------------------------------------------------------------------------
 // Tile geometry is a template parameter (TH x TW outputs, NW waves per workgroup) so that shapes can
-// be A/B-ed in one binary (bf_set_option "fused_tile"); intermediate pixels are flattened into
-// 16-pixel MFMA groups, so any TH, TW works (a partial last group computes garbage that is never read).
+// be A/B-ed in one binary (bf_set_option "fused_tile").  TW is a multiple of 16, so an output row
+// is TW/16 MFMA groups.  The intermediate region is (TH+2) x (TW+2): per row TW/16 "row groups"
+// (columns 0..TW-1) and the two remaining columns of every 8 rows form one "strip group"
+// (lane p -> row 8s + p/2, column TW + p%2).  With this decomposition EVERY LDS and global address
+// is (wave-uniform scalar) + (one of three per-lane constants): a pass prologue/epilogue costs a
+// handful of VALU instructions instead of ~30 (the MFMA + LDS micro-benchmark
+// tools/exp/mfma_loop.hip prices 30 epilogue VALU per group at 9 % of the kernel -- VALU work of a
+// pass is not hidden behind the partner wave's MFMAs).
 template <int TH_, int TW_, int NW_>
 struct FusedCfg {
     static constexpr int TH = TH_, TW = TW_, NW = NW_, NT = NW_ * 64;
     static constexpr int MH = TH + 2, MW = TW + 2;        // intermediate region
     static constexpr int IH = TH + 4, IW = TW + 4;        // input region
-    static constexpr int MG = (MH * MW + 15) / 16;        // conv1 groups
-    static constexpr int OG = (TH * TW + 15) / 16;        // conv2 groups
+    static constexpr int GPR = TW / 16;                   // groups per row
+    static constexpr int RG = MH * GPR;                   // conv1 row groups
+    static constexpr int SG = (MH + 7) / 8;               // conv1 strip groups
+    static constexpr int MG = RG + SG;                    // conv1 groups
+    static constexpr int OG = TH * GPR;                   // conv2 groups
+    static constexpr int C1K = (MG + NW - 1) / NW;        // conv1 groups per wave (max)
+    static constexpr int C2K = (OG + NW - 1) / NW;        // conv2 groups per wave (max)
     static constexpr int IN4 = IH * IW * 4;               // float4 per input tile
     static constexpr int PF = (IN4 + NT - 1) / NT;        // float4 per lane in the prefetch
     static constexpr int TIN_FLOATS = IH * IW * 16;
-    static constexpr int LDS_BYTES = (TIN_FLOATS + MG * 256) * 4;
+    static constexpr int LDS_BYTES = (TIN_FLOATS + MH * MW * 16) * 4;
+    static_assert(TW % 16 == 0, "output rows must be whole MFMA groups");
 };
 
 template <int NG>
@@ -249,116 +275,185 @@ __device__ __forceinline__ FusedTile fused_tile(const FusedBlockArgs& a, int t)
     return r;
 }
 
-// issue the tile's global loads into registers (2 px halo, zeros outside the image); no wait
+// a tile whose whole input region lies inside the image needs no bounds check anywhere
 template <class Cfg>
-__device__ __forceinline__ void fused_fetch(const FusedBlockArgs& a, const FusedTile& t, int tid, float4 (&pf)[Cfg::PF])
+__device__ __forceinline__ bool tile_interior(const FusedBlockArgs& a, const FusedTile& t)
 {
-    const float* inb = a.in + t.img;
+    return t.y0 >= 2 && t.y0 + Cfg::TH + 2 <= a.H && t.x0 >= 2 && t.x0 + Cfg::TW + 2 <= a.W;
+}
+
+// per-lane constants (tile-invariant)
+struct FusedLane {
+    int p, q;
+    int row_c;       // p*16 + q*4                       : row-group pixel p, channel quad q
+    int strip_in;    // ((p/2)*IW + p%2)*16 + q*4         : strip-group pixel in the input tile
+    int strip_mid;   // ((p/2)*MW + p%2)*16 + q*4         : strip-group pixel in the intermediate tile
+};
+
+// issue the tile's global loads into registers (2 px halo); no wait.  Every load is UNCONDITIONAL:
+// out-of-image elements read offset 0 of the image and are zeroed in fused_stage through the returned
+// bit mask.  (A per-element `if (inside) load` makes hipcc branch around each load and wait vmcnt(0)
+// per element: the 11 loads of a border tile were serialised, ~500 cycles each -- s_memtime stamps.)
+// (row, col) of element n = tid + i*NT advance incrementally; addresses are (uniform image base) +
+// (unsigned 32-bit per-lane byte offset) so the loads take the saddr form.
+template <class Cfg, bool INTERIOR>
+__device__ __forceinline__ unsigned fused_fetch(const FusedBlockArgs& a, const FusedTile& t, int tid, float4 (&pf)[Cfg::PF])
+{
+    constexpr int RW = Cfg::IW * 4;                                  // float4 per tile row
+    const char* img = reinterpret_cast<const char*>(a.in + t.img);
+    int row = tid / RW, rem = tid - row * RW;
+    unsigned zero_mask = 0;
 #pragma unroll
     for (int i = 0; i < Cfg::PF; ++i) {
-        const int n = tid + i * Cfg::NT;
-        const int row = n / (Cfg::IW * 4);
-        const int rem = n - row * (Cfg::IW * 4);
+        const bool in_tile = (i + 1) * Cfg::NT <= Cfg::IN4 || tid + i * Cfg::NT < Cfg::IN4;
         const int gy = t.y0 - 2 + row, gx = t.x0 - 2 + (rem >> 2);
-        pf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < Cfg::IN4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-            pf[i] = *reinterpret_cast<const float4*>(inb + ((size_t)gy * a.W + gx) * 16 + (rem & 3) * 4);
+        const bool inside = INTERIOR || (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W);
+        unsigned off = ((unsigned)(gy * a.W + gx) * 16u + (unsigned)(rem & 3) * 4u) * 4u;
+        if (!(in_tile && inside)) { off = 0; zero_mask |= 1u << i; }
+        pf[i] = *reinterpret_cast<const float4*>(img + off);
+        rem += Cfg::NT % RW;
+        row += Cfg::NT / RW;
+        if (rem >= RW) { rem -= RW; ++row; }
     }
+    return zero_mask;
 }
 
 template <class Cfg>
-__device__ __forceinline__ void fused_stage(float* __restrict__ tin, int tid, const float4 (&pf)[Cfg::PF])
+__device__ __forceinline__ void fused_stage(float* __restrict__ tin, int tid, const float4 (&pf)[Cfg::PF], const unsigned zero_mask)
 {
 #pragma unroll
     for (int i = 0; i < Cfg::PF; ++i) {
         const int n = tid + i * Cfg::NT;
-        if (n < Cfg::IN4) *reinterpret_cast<float4*>(tin + n * 4) = pf[i];
+        float4 v = pf[i];
+        if (zero_mask & (1u << i)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((i + 1) * Cfg::NT <= Cfg::IN4 || n < Cfg::IN4) *reinterpret_cast<float4*>(tin + n * 4) = v;
     }
 }
 
-// conv1 (+activation) of NG intermediate groups: input tile -> intermediate tile in LDS
-template <class Cfg, int NG>
+// conv1 (+activation) of NG intermediate groups g[j] (wave-uniform): input tile -> intermediate tile.
+// INTERIOR = false additionally zeroes pixels outside the image: conv2 must see ZERO padding there,
+// not conv1 evaluated outside the image.
+template <class Cfg, int NG, bool INTERIOR>
 __device__ __forceinline__ void conv1_pass(const FusedBlockArgs& a, const float* __restrict__ tin, float* __restrict__ tmid,
-                                           const float (&w1)[36], const int (&g)[NG], const int p, const int q,
-                                           const FusedTile& t)
+                                           const float (&w1)[36], const int (&g)[NG], const FusedLane& L, const FusedTile& t)
 {
-    int base[NG], f[NG];
+    int base[NG], dst[NG], my[NG], mx[NG];
     f32x4 acc[NG];
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
-        f[j] = g[j] * 16 + p;
-        const int my = f[j] / Cfg::MW, mx = f[j] - my * Cfg::MW;
-        base[j] = (my * Cfg::IW + mx) * 16 + q * 4;
+        if (g[j] < Cfg::RG) {                                        // wave-uniform branch
+            const int r = g[j] / Cfg::GPR, xg = (g[j] - r * Cfg::GPR) * 16;
+            base[j] = (r * Cfg::IW + xg) * 16 + L.row_c;
+            dst[j] = (r * Cfg::MW + xg) * 16 + L.row_c;
+            my[j] = r; mx[j] = xg + L.p;
+        } else {
+            const int r0 = (g[j] - Cfg::RG) * 8;
+            if (Cfg::MH % 8 == 0 || r0 + 8 <= Cfg::MH) {
+                base[j] = (r0 * Cfg::IW + Cfg::TW) * 16 + L.strip_in;
+                dst[j] = (r0 * Cfg::MW + Cfg::TW) * 16 + L.strip_mid;
+                my[j] = r0 + (L.p >> 1);
+            } else {                                                 // partial last strip: clamp the row
+                my[j] = min(r0 + (L.p >> 1), Cfg::MH - 1);
+                base[j] = (my[j] * Cfg::IW + Cfg::TW + (L.p & 1)) * 16 + L.q * 4;
+                dst[j] = (my[j] * Cfg::MW + Cfg::TW + (L.p & 1)) * 16 + L.q * 4;
+            }
+            mx[j] = Cfg::TW + (L.p & 1);
+        }
         acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     conv_groups<NG>(tin, base, Cfg::IW, w1, acc);
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
-        const int my = f[j] / Cfg::MW, mx = f[j] - my * Cfg::MW;
-        const int gy = t.y0 - 1 + my, gx = t.x0 - 1 + mx;
         f32x4 v = acc[j];
         if (a.act1_relu) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        // conv2 sees ZERO padding outside the image, not conv1 evaluated there
-        if (gy < 0 || gy >= a.H || gx < 0 || gx >= a.W) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(tmid + f[j] * 16 + q * 4) = v;
+        if (!INTERIOR) {
+            const int gy = t.y0 - 1 + my[j], gx = t.x0 - 1 + mx[j];
+            if (gy < 0 || gy >= a.H || gx < 0 || gx >= a.W) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        *reinterpret_cast<f32x4*>(tmid + dst[j]) = v;
     }
 }
 
 // conv2 + folded BN + residual of NG output groups: intermediate tile -> global
-template <class Cfg, int NG>
+template <class Cfg, int NG, bool INTERIOR>
 __device__ __forceinline__ void conv2_pass(const FusedBlockArgs& a, const float* __restrict__ tin,
-                                           const float* __restrict__ tmid, const float (&w2)[36],
-                                           const f32x4 sc, const f32x4 sh, const int (&g)[NG],
-                                           const int p, const int q, const FusedTile& t)
+                                           const float* __restrict__ tmid, float* __restrict__ out_tile,
+                                           const float (&w2)[36], const f32x4 sc, const f32x4 sh, const int (&g)[NG],
+                                           const FusedLane& L, const FusedTile& t)
 {
-    int base[NG], oy[NG], ox[NG];
-    bool ok[NG];
+    int base[NG];
     f32x4 acc[NG];
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
-        int f = g[j] * 16 + p;
-        ok[j] = f < Cfg::TH * Cfg::TW;
-        if (!ok[j]) f = 0;                               // partial last group: clamp, result discarded
-        oy[j] = f / Cfg::TW;
-        ox[j] = f - oy[j] * Cfg::TW;
-        base[j] = (oy[j] * Cfg::MW + ox[j]) * 16 + q * 4;
+        const int oy = g[j] / Cfg::GPR, xg = (g[j] - oy * Cfg::GPR) * 16;
+        base[j] = (oy * Cfg::MW + xg) * 16 + L.row_c;
         acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     conv_groups<NG>(tmid, base, Cfg::MW, w2, acc);
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
-        const int gy = t.y0 + oy[j], gx = t.x0 + ox[j];
-        if (ok[j] && gy < a.H && gx < a.W) {
-            const f32x4 r = *reinterpret_cast<const f32x4*>(tin + ((oy[j] + 2) * Cfg::IW + ox[j] + 2) * 16 + q * 4);
+        const int oy = g[j] / Cfg::GPR, xg = (g[j] - oy * Cfg::GPR) * 16;
+        if (INTERIOR || (t.y0 + oy < a.H && t.x0 + xg + L.p < a.W)) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(tin + ((oy + 2) * Cfg::IW + xg + 2) * 16 + L.row_c);
             const f32x4 v = acc[j] * sc + sh + r;
-            if (BF_ABLATE & 4) { if (v.x == 12345.678f) a.out[0] = v.y; }       // keeps the MFMAs live
-            else *reinterpret_cast<f32x4*>(a.out + t.img + ((size_t)gy * a.W + gx) * 16 + q * 4) = v;
+            if (BF_ABLATE & 4) { if (v.x == 12345.678f) out_tile[0] = v.y; }       // keeps the MFMAs live
+            else *reinterpret_cast<f32x4*>(out_tile + ((size_t)oy * a.W + xg) * 16 + (unsigned)L.row_c) = v;
         }
     }
 }
 
-// An intermediate group (flattened pixels 16g..16g+15 of the MH x MW region, origin (y0-1, x0-1)) is
-// needed iff one of its pixels can be read by an in-image output: image row <= H and col <= W.
+// An intermediate group is needed iff one of its pixels can be read by an in-image output:
+// image row <= H and column <= W (rows/columns beyond that are never read).
 template <class Cfg>
 __device__ __forceinline__ bool mid_group_needed(const FusedBlockArgs& a, const FusedTile& t, int g)
 {
-    const int f0 = g * 16, f1 = f0 + 15;
-    const int r0 = f0 / Cfg::MW, r1 = f1 / Cfg::MW;
-    if (t.y0 - 1 + r0 > a.H) return false;
-    if (r0 == r1) return t.x0 - 1 + (f0 - r0 * Cfg::MW) <= a.W;
-    return true;                                  // spans two rows: its second row starts at column x0-1 <= W
+    if (g < Cfg::RG) {
+        const int r = g / Cfg::GPR, xg = (g - r * Cfg::GPR) * 16;
+        return t.y0 - 1 + r <= a.H && t.x0 - 1 + xg <= a.W;
+    }
+    return t.y0 - 1 + (g - Cfg::RG) * 8 <= a.H && t.x0 - 1 + Cfg::TW <= a.W;
 }
 
 template <class Cfg>
 __device__ __forceinline__ bool out_group_needed(const FusedBlockArgs& a, const FusedTile& t, int g)
 {
-    const int f0 = g * 16;
-    const int r0 = f0 / Cfg::TW, r1 = (f0 + 15) / Cfg::TW;
-    if (t.y0 + r0 >= a.H) return false;
-    if (r0 == r1) return t.x0 + (f0 - r0 * Cfg::TW) < a.W;
-    return true;
+    const int oy = g / Cfg::GPR, xg = (g - oy * Cfg::GPR) * 16;
+    return t.y0 + oy < a.H && t.x0 + xg < a.W;
+}
+
+// this wave's groups slot K0.. of an interior tile, in passes of PASS (compile-time group slots)
+template <class Cfg, int K0>
+__device__ __forceinline__ void conv1_interior(const FusedBlockArgs& a, const float* __restrict__ tin, float* __restrict__ tmid,
+                                               const float (&w1)[36], const FusedLane& L, const FusedTile& t, const int wave,
+                                               const int n1)
+{
+    if constexpr (K0 < Cfg::C1K) {
+        const int rem = n1 - K0;
+        const int g0 = wave + Cfg::NW * K0, g1 = g0 + Cfg::NW, g2 = g1 + Cfg::NW;
+        if (rem >= 3)      { const int gs[3] = {g0, g1, g2}; conv1_pass<Cfg, 3, true>(a, tin, tmid, w1, gs, L, t); }
+        else if (rem == 2) { const int gs[2] = {g0, g1};     conv1_pass<Cfg, 2, true>(a, tin, tmid, w1, gs, L, t); }
+        else if (rem == 1) { const int gs[1] = {g0};         conv1_pass<Cfg, 1, true>(a, tin, tmid, w1, gs, L, t); }
+        conv1_interior<Cfg, K0 + 3>(a, tin, tmid, w1, L, t, wave, n1);
+    }
+}
+
+template <class Cfg, int K0>
+__device__ __forceinline__ void conv2_interior(const FusedBlockArgs& a, const float* __restrict__ tin,
+                                               const float* __restrict__ tmid, float* __restrict__ out_tile,
+                                               const float (&w2)[36], const f32x4 sc, const f32x4 sh, const FusedLane& L,
+                                               const FusedTile& t, const int wave, const int n2)
+{
+    if constexpr (K0 < Cfg::C2K) {
+        const int rem = n2 - K0;
+        const int g0 = wave + Cfg::NW * K0, g1 = g0 + Cfg::NW, g2 = g1 + Cfg::NW, g3 = g2 + Cfg::NW;
+        if (rem >= 4)      { const int gs[4] = {g0, g1, g2, g3}; conv2_pass<Cfg, 4, true>(a, tin, tmid, out_tile, w2, sc, sh, gs, L, t); }
+        else if (rem == 3) { const int gs[3] = {g0, g1, g2};     conv2_pass<Cfg, 3, true>(a, tin, tmid, out_tile, w2, sc, sh, gs, L, t); }
+        else if (rem == 2) { const int gs[2] = {g0, g1};         conv2_pass<Cfg, 2, true>(a, tin, tmid, out_tile, w2, sc, sh, gs, L, t); }
+        else if (rem == 1) { const int gs[1] = {g0};             conv2_pass<Cfg, 1, true>(a, tin, tmid, out_tile, w2, sc, sh, gs, L, t); }
+        conv2_interior<Cfg, K0 + 4>(a, tin, tmid, out_tile, w2, sc, sh, L, t, wave, n2);
+    }
 }
 
 template <class Cfg>
@@ -366,16 +461,21 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_kernel(FusedBlockArgs 
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* tin = lds;                                  // [IH][IW][16]
-    float* tmid = lds + Cfg::TIN_FLOATS;               // [MG*16][16]
+    float* tmid = lds + Cfg::TIN_FLOATS;               // [MH][MW][16]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int p = lane & 15, q = lane >> 4;
+    FusedLane L0;
+    L0.p = lane & 15;
+    L0.q = lane >> 4;
+    L0.row_c = L0.p * 16 + L0.q * 4;
+    L0.strip_in = ((L0.p >> 1) * Cfg::IW + (L0.p & 1)) * 16 + L0.q * 4;
+    L0.strip_mid = ((L0.p >> 1) * Cfg::MW + (L0.p & 1)) * 16 + L0.q * 4;
 
     float w1[36], w2[36];
 #pragma unroll
     for (int i = 0; i < 36; ++i) { w1[i] = a.w1pack[i * 64 + lane]; w2[i] = a.w2pack[i * 64 + lane]; }
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + q * 4);
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + q * 4);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + L0.q * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + L0.q * 4);
 
     // XCD-aware persistent schedule: label = blockIdx % 8 owns a contiguous chunk of the tile
     // sequence; its workgroups walk the chunk together (speed only, never correctness).
@@ -388,11 +488,18 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_kernel(FusedBlockArgs 
 
     int t = t_begin + slot;
     if (t >= t_end) return;                            // uniform per workgroup
+    const int n1 = (Cfg::MG - wave + Cfg::NW - 1) / Cfg::NW;      // this wave's conv1 / conv2 group counts
+    const int n2 = (Cfg::OG - wave + Cfg::NW - 1) / Cfg::NW;
+
     float4 pf[Cfg::PF];
     FusedTile cur = fused_tile<Cfg>(a, t);
-    fused_fetch<Cfg>(a, cur, tid, pf);
-    fused_stage<Cfg>(tin, tid, pf);
+    unsigned zero_mask = fused_fetch<Cfg, false>(a, cur, tid, pf);
+    fused_stage<Cfg>(tin, tid, pf, zero_mask);
     FUSED_SYNC();
+#if BF_ABLATE & 8
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
 
     for (; t < t_end; t += per_label) {
         const int tn = t + per_label;
@@ -400,41 +507,67 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_kernel(FusedBlockArgs 
         FusedTile nxt = cur;
         if (has_next) {                                // prefetch: in flight during conv1 + conv2
             nxt = fused_tile<Cfg>(a, tn);
-            if (!(BF_ABLATE & 2)) fused_fetch<Cfg>(a, nxt, tid, pf);
-        }
-
-        // ---- conv1: wave w takes groups w, w+NW, ... ; up to three per pass -----------------
-        for (int g = wave; g < Cfg::MG;) {
-            int g0 = -1, g1 = -1, g2 = -1;
-            for (; g < Cfg::MG && g2 < 0; g += Cfg::NW) {
-                if (!mid_group_needed<Cfg>(a, cur, g)) continue;
-                if (g0 < 0) g0 = g; else if (g1 < 0) g1 = g; else g2 = g;
+            STAMP(7);                                  // tile index arithmetic
+            if (!(BF_ABLATE & 2)) {
+                if (tile_interior<Cfg>(a, nxt)) zero_mask = fused_fetch<Cfg, true>(a, nxt, tid, pf);
+                else zero_mask = fused_fetch<Cfg, false>(a, nxt, tid, pf);
             }
-            if (g2 >= 0)      { const int gs[3] = {g0, g1, g2}; conv1_pass<Cfg, 3>(a, tin, tmid, w1, gs, p, q, cur); }
-            else if (g1 >= 0) { const int gs[2] = {g0, g1};     conv1_pass<Cfg, 2>(a, tin, tmid, w1, gs, p, q, cur); }
-            else if (g0 >= 0) { const int gs[1] = {g0};         conv1_pass<Cfg, 1>(a, tin, tmid, w1, gs, p, q, cur); }
         }
-        FUSED_SYNC();
+        STAMP(0);                                      // fetch issue
+        float* out_tile = a.out + cur.img + ((size_t)cur.y0 * a.W + cur.x0) * 16;
+        // make the per-lane constants opaque inside the loop body: otherwise LICM hoists every
+        // (scalar + lane constant) address of every unrolled pass out of the tile loop and the
+        // kernel spills (hipcc 7.2: 256 VGPRs + 160..476 B scratch per lane)
+        FusedLane L = L0;
+        asm volatile("" : "+v"(L.row_c), "+v"(L.strip_in), "+v"(L.strip_mid));
 
-        // ---- conv2 + folded BN + residual: wave w takes groups w, w+NW, ... ; up to four per pass
-        for (int g = wave; g < Cfg::OG;) {
-            int g0 = -1, g1 = -1, g2 = -1, g3 = -1;
-            for (; g < Cfg::OG && g3 < 0; g += Cfg::NW) {
-                if (!out_group_needed<Cfg>(a, cur, g)) continue;
-                if (g0 < 0) g0 = g; else if (g1 < 0) g1 = g; else if (g2 < 0) g2 = g; else g3 = g;
+        if (tile_interior<Cfg>(a, cur)) {
+            conv1_interior<Cfg, 0>(a, tin, tmid, w1, L, cur, wave, n1);
+            STAMP(1);                                  // conv1
+            FUSED_SYNC();
+            STAMP(2);                                  // barrier after conv1
+            conv2_interior<Cfg, 0>(a, tin, tmid, out_tile, w2, sc, sh, L, cur, wave, n2);
+            STAMP(3);                                  // conv2
+        } else {
+            // border tile: groups wholly outside the image are skipped, the rest is bounds-checked
+            for (int g = wave; g < Cfg::MG;) {
+                int g0 = -1, g1 = -1, g2 = -1;
+                for (; g < Cfg::MG && g2 < 0; g += Cfg::NW) {
+                    if (!mid_group_needed<Cfg>(a, cur, g)) continue;
+                    if (g0 < 0) g0 = g; else if (g1 < 0) g1 = g; else g2 = g;
+                }
+                if (g2 >= 0)      { const int gs[3] = {g0, g1, g2}; conv1_pass<Cfg, 3, false>(a, tin, tmid, w1, gs, L, cur); }
+                else if (g1 >= 0) { const int gs[2] = {g0, g1};     conv1_pass<Cfg, 2, false>(a, tin, tmid, w1, gs, L, cur); }
+                else if (g0 >= 0) { const int gs[1] = {g0};         conv1_pass<Cfg, 1, false>(a, tin, tmid, w1, gs, L, cur); }
             }
-            if (g3 >= 0)      { const int gs[4] = {g0, g1, g2, g3}; conv2_pass<Cfg, 4>(a, tin, tmid, w2, sc, sh, gs, p, q, cur); }
-            else if (g2 >= 0) { const int gs[3] = {g0, g1, g2};     conv2_pass<Cfg, 3>(a, tin, tmid, w2, sc, sh, gs, p, q, cur); }
-            else if (g1 >= 0) { const int gs[2] = {g0, g1};         conv2_pass<Cfg, 2>(a, tin, tmid, w2, sc, sh, gs, p, q, cur); }
-            else if (g0 >= 0) { const int gs[1] = {g0};             conv2_pass<Cfg, 1>(a, tin, tmid, w2, sc, sh, gs, p, q, cur); }
+            FUSED_SYNC();
+            for (int g = wave; g < Cfg::OG;) {
+                int g0 = -1, g1 = -1, g2 = -1, g3 = -1;
+                for (; g < Cfg::OG && g3 < 0; g += Cfg::NW) {
+                    if (!out_group_needed<Cfg>(a, cur, g)) continue;
+                    if (g0 < 0) g0 = g; else if (g1 < 0) g1 = g; else if (g2 < 0) g2 = g; else g3 = g;
+                }
+                if (g3 >= 0)      { const int gs[4] = {g0, g1, g2, g3}; conv2_pass<Cfg, 4, false>(a, tin, tmid, out_tile, w2, sc, sh, gs, L, cur); }
+                else if (g2 >= 0) { const int gs[3] = {g0, g1, g2};     conv2_pass<Cfg, 3, false>(a, tin, tmid, out_tile, w2, sc, sh, gs, L, cur); }
+                else if (g1 >= 0) { const int gs[2] = {g0, g1};         conv2_pass<Cfg, 2, false>(a, tin, tmid, out_tile, w2, sc, sh, gs, L, cur); }
+                else if (g0 >= 0) { const int gs[1] = {g0};             conv2_pass<Cfg, 1, false>(a, tin, tmid, out_tile, w2, sc, sh, gs, L, cur); }
+            }
         }
         FUSED_SYNC();                                  // every wave is done with tin / tmid
+        STAMP(4);                                      // barrier after conv2 (+ whole border tiles)
         if (has_next && !(BF_ABLATE & 2)) {
-            fused_stage<Cfg>(tin, tid, pf);            // waits for the prefetch here, one tile late
+            fused_stage<Cfg>(tin, tid, pf, zero_mask); // waits for the prefetch here, one tile late
+            STAMP(5);                                  // vmcnt wait + ds_write
             FUSED_SYNC();
+            STAMP(6);                                  // barrier after stage
         }
         cur = nxt;
     }
+#if BF_ABLATE & 8
+    if (a.dbg && lane == 0) {
+        for (int k = 0; k < 8; ++k) a.dbg[((size_t)blockIdx.x * Cfg::NW + wave) * 8 + k] = stamp_sum[k];
+    }
+#endif
 }
 
 static int g_fused_tile = 0;      // 0: 14x32 x4 waves (2 workgroups/CU) ; 1: 32x32 x8 waves ; 2: 16x64 x8 waves

@@ -354,7 +354,7 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
             fa.w1pack = blk; fa.w2pack = blk + BF_WPACK_FLOATS;
             fa.scale = blk + 2 * BF_WPACK_FLOATS; fa.shift = fa.scale + 16;
             fa.B = B; fa.H = H; fa.W = W; fa.tiles_x = fa.tiles_y = fa.ntiles = 0;
-            fa.act1_relu = d.activation == BF_ACT_RELU;
+            fa.act1_relu = d.activation == BF_ACT_RELU; fa.dbg = nullptr;
             BF_HIP(bf_launch_fused_block(fa, s), "fused_block");
             cur ^= 1;
         } else {
@@ -718,6 +718,10 @@ extern "C" int bf_debug_conv3x3(const float* in, const float* w_hwio, float* out
     return bf_launch_conv3x3_c16(ca, epi, s) == hipSuccess ? BF_OK : BF_EHIP;
 }
 
+static unsigned long long* g_fused_dbg = nullptr;
+// diagnostic builds (tools/ablate.sh 8): device buffer of 512*8*8 u64 that receives per-wave phase cycle sums
+extern "C" int bf_debug_set_fused_dbg(void* buf) { g_fused_dbg = (unsigned long long*)buf; return BF_OK; }
+
 extern "C" int bf_debug_conv3x3_grid(int B, int H, int W) { return bf_conv3x3_c16_grid(B, H, W); }
 
 extern "C" int bf_debug_fused_block(const float* in, const float* w1_hwio, const float* w2_hwio, const float* scale,
@@ -730,6 +734,7 @@ extern "C" int bf_debug_fused_block(const float* in, const float* w1_hwio, const
     FusedBlockArgs fa;
     fa.in = in; fa.out = out; fa.w1pack = wpack_scratch; fa.w2pack = wpack_scratch + BF_WPACK_FLOATS; fa.scale = scale;
     fa.shift = shift; fa.B = B; fa.H = H; fa.W = W; fa.tiles_x = fa.tiles_y = fa.ntiles = 0; fa.act1_relu = act1_relu;
+    fa.dbg = g_fused_dbg;
     return bf_launch_fused_block(fa, s) == hipSuccess ? BF_OK : BF_EHIP;
 }
 
