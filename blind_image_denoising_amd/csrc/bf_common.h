@@ -37,6 +37,7 @@ struct FusedBlockArgs {
     int B, H, W;
     int tiles_x, tiles_y, ntiles;
     int act1_relu;        // activation of conv1 (1 = relu, 0 = linear)
+    const float* zeros;   // >= 64 B of zeros, 16-B aligned (source of out-of-image elements for the LDS-DMA variant)
     unsigned long long* dbg;  // diagnostic builds only (per-wave phase cycle sums), else NULL
 };
 

@@ -376,28 +376,36 @@ __device__ __forceinline__ void conv1_pass(const FusedBlockArgs& a, const float*
     }
 }
 
-// conv2 + folded BN + residual of NG output groups: intermediate tile -> global
-template <class Cfg, int NG, bool INTERIOR>
+// conv2 + folded BN + residual of NG output groups: intermediate tile -> global.
+// RES_GLOBAL: the residual is re-read from global memory (an L2 hit, the workgroup fetched those
+// lines for its input tile one phase earlier) so the LDS input tile is free for the next tile's DMA.
+template <class Cfg, int NG, bool INTERIOR, bool RES_GLOBAL = false>
 __device__ __forceinline__ void conv2_pass(const FusedBlockArgs& a, const float* __restrict__ tin,
                                            const float* __restrict__ tmid, float* __restrict__ out_tile,
                                            const float (&w2)[36], const f32x4 sc, const f32x4 sh, const int (&g)[NG],
                                            const FusedLane& L, const FusedTile& t)
 {
     int base[NG];
-    f32x4 acc[NG];
+    f32x4 acc[NG], res[NG];
+    const float* in_tile = a.in + (out_tile - a.out);
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
         const int oy = g[j] / Cfg::GPR, xg = (g[j] - oy * Cfg::GPR) * 16;
         base[j] = (oy * Cfg::MW + xg) * 16 + L.row_c;
         acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (RES_GLOBAL) {
+            res[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (INTERIOR || (t.y0 + oy < a.H && t.x0 + xg + L.p < a.W))
+                res[j] = *reinterpret_cast<const f32x4*>(in_tile + ((size_t)oy * a.W + xg) * 16 + (unsigned)L.row_c);
+        }
     }
     conv_groups<NG>(tmid, base, Cfg::MW, w2, acc);
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
         const int oy = g[j] / Cfg::GPR, xg = (g[j] - oy * Cfg::GPR) * 16;
         if (INTERIOR || (t.y0 + oy < a.H && t.x0 + xg + L.p < a.W)) {
-            const f32x4 r = *reinterpret_cast<const f32x4*>(tin + ((oy + 2) * Cfg::IW + xg + 2) * 16 + L.row_c);
-            const f32x4 v = acc[j] * sc + sh + r;
+            if (!RES_GLOBAL) res[j] = *reinterpret_cast<const f32x4*>(tin + ((oy + 2) * Cfg::IW + xg + 2) * 16 + L.row_c);
+            const f32x4 v = acc[j] * sc + sh + res[j];
             if (BF_ABLATE & 4) { if (v.x == 12345.678f) out_tile[0] = v.y; }       // keeps the MFMAs live
             else *reinterpret_cast<f32x4*>(out_tile + ((size_t)oy * a.W + xg) * 16 + (unsigned)L.row_c) = v;
         }
@@ -439,7 +447,7 @@ __device__ __forceinline__ void conv1_interior(const FusedBlockArgs& a, const fl
     }
 }
 
-template <class Cfg, int K0>
+template <class Cfg, int K0, bool RES_GLOBAL = false>
 __device__ __forceinline__ void conv2_interior(const FusedBlockArgs& a, const float* __restrict__ tin,
                                                const float* __restrict__ tmid, float* __restrict__ out_tile,
                                                const float (&w2)[36], const f32x4 sc, const f32x4 sh, const FusedLane& L,
@@ -448,11 +456,11 @@ __device__ __forceinline__ void conv2_interior(const FusedBlockArgs& a, const fl
     if constexpr (K0 < Cfg::C2K) {
         const int rem = n2 - K0;
         const int g0 = wave + Cfg::NW * K0, g1 = g0 + Cfg::NW, g2 = g1 + Cfg::NW, g3 = g2 + Cfg::NW;
-        if (rem >= 4)      { const int gs[4] = {g0, g1, g2, g3}; conv2_pass<Cfg, 4, true>(a, tin, tmid, out_tile, w2, sc, sh, gs, L, t); }
-        else if (rem == 3) { const int gs[3] = {g0, g1, g2};     conv2_pass<Cfg, 3, true>(a, tin, tmid, out_tile, w2, sc, sh, gs, L, t); }
-        else if (rem == 2) { const int gs[2] = {g0, g1};         conv2_pass<Cfg, 2, true>(a, tin, tmid, out_tile, w2, sc, sh, gs, L, t); }
-        else if (rem == 1) { const int gs[1] = {g0};             conv2_pass<Cfg, 1, true>(a, tin, tmid, out_tile, w2, sc, sh, gs, L, t); }
-        conv2_interior<Cfg, K0 + 4>(a, tin, tmid, out_tile, w2, sc, sh, L, t, wave, n2);
+        if (rem >= 4)      { const int gs[4] = {g0, g1, g2, g3}; conv2_pass<Cfg, 4, true, RES_GLOBAL>(a, tin, tmid, out_tile, w2, sc, sh, gs, L, t); }
+        else if (rem == 3) { const int gs[3] = {g0, g1, g2};     conv2_pass<Cfg, 3, true, RES_GLOBAL>(a, tin, tmid, out_tile, w2, sc, sh, gs, L, t); }
+        else if (rem == 2) { const int gs[2] = {g0, g1};         conv2_pass<Cfg, 2, true, RES_GLOBAL>(a, tin, tmid, out_tile, w2, sc, sh, gs, L, t); }
+        else if (rem == 1) { const int gs[1] = {g0};             conv2_pass<Cfg, 1, true, RES_GLOBAL>(a, tin, tmid, out_tile, w2, sc, sh, gs, L, t); }
+        conv2_interior<Cfg, K0 + 4, RES_GLOBAL>(a, tin, tmid, out_tile, w2, sc, sh, L, t, wave, n2);
     }
 }
 
@@ -570,6 +578,148 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_kernel(FusedBlockArgs 
 #endif
 }
 
+// ---- LDS-DMA variant -----------------------------------------------------------------------------
+// The next tile goes global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction, no
+// VGPR staging, no ds_write pass): it is issued right after the conv1 -> conv2 barrier, when nobody
+// reads the input tile any more (the residual comes from global/L2), and lands while conv2 runs.
+// Two barriers per tile; 44 fewer VGPRs.  Out-of-image elements are sourced from a zero-filled
+// global line.  LDS = intermediate tile, then the input tile padded to whole wave-instructions.
+template <class Cfg>
+struct FusedDmaCfg {
+    static constexpr int TIN_PAD_FLOATS = Cfg::PF * Cfg::NT * 4;
+    static constexpr int TMID_FLOATS = Cfg::MH * Cfg::MW * 16;
+    static constexpr int LDS_BYTES = (TMID_FLOATS + TIN_PAD_FLOATS) * 4;
+};
+
+template <class Cfg, bool INTERIOR>
+__device__ __forceinline__ void fused_dma(const FusedBlockArgs& a, const FusedTile& t, float* __restrict__ tin, int tid, int wave)
+{
+    constexpr int RW = Cfg::IW * 4;
+    const char* img = reinterpret_cast<const char*>(a.in + t.img);
+    int row = tid / RW, rem = tid - row * RW;
+#pragma unroll
+    for (int i = 0; i < Cfg::PF; ++i) {
+        const bool in_tile = (i + 1) * Cfg::NT <= Cfg::IN4 || tid + i * Cfg::NT < Cfg::IN4;
+        const int gy = t.y0 - 2 + row, gx = t.x0 - 2 + (rem >> 2);
+        const bool inside = INTERIOR || (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W);
+        const unsigned off = ((unsigned)(gy * a.W + gx) * 16u + (unsigned)(rem & 3) * 4u) * 4u;
+        const char* src = (in_tile && inside) ? img + off : reinterpret_cast<const char*>(a.zeros);
+        // LDS destination = wave-uniform base + lane*16 (hardware); element n = tid + i*NT -> byte n*16
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(tin + (i * Cfg::NT + wave * 64) * 4),
+                                         16, 0, 0);
+        rem += Cfg::NT % RW;
+        row += Cfg::NT / RW;
+        if (rem >= RW) { rem -= RW; ++row; }
+    }
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT, 2) void fused_block_dma_kernel(FusedBlockArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* tmid = lds;                                       // [MH][MW][16]
+    float* tin = lds + FusedDmaCfg<Cfg>::TMID_FLOATS;        // [IH][IW][16] + pad
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    FusedLane L0;
+    L0.p = lane & 15;
+    L0.q = lane >> 4;
+    L0.row_c = L0.p * 16 + L0.q * 4;
+    L0.strip_in = ((L0.p >> 1) * Cfg::IW + (L0.p & 1)) * 16 + L0.q * 4;
+    L0.strip_mid = ((L0.p >> 1) * Cfg::MW + (L0.p & 1)) * 16 + L0.q * 4;
+
+    float w1[36], w2[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) { w1[i] = a.w1pack[i * 64 + lane]; w2[i] = a.w2pack[i * 64 + lane]; }
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + L0.q * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + L0.q * 4);
+
+    const int nxcd = gridDim.x >= 8 ? 8 : 1;
+    const int label = blockIdx.x % nxcd, slot = blockIdx.x / nxcd;
+    const int per_label = gridDim.x / nxcd;
+    const int chunk = (a.ntiles + nxcd - 1) / nxcd;
+    const int t_begin = label * chunk;
+    const int t_end = min(a.ntiles, t_begin + chunk);
+    int t = t_begin + slot;
+    if (t >= t_end) return;
+    const int n1 = (Cfg::MG - wave + Cfg::NW - 1) / Cfg::NW;
+    const int n2 = (Cfg::OG - wave + Cfg::NW - 1) / Cfg::NW;
+
+    FusedTile cur = fused_tile<Cfg>(a, t);
+    fused_dma<Cfg, false>(a, cur, tin, tid, wave);
+    __syncthreads();                                         // drains the DMA (vmcnt(0)) and publishes tin
+
+    for (; t < t_end; t += per_label) {
+        const int tn = t + per_label;
+        const bool has_next = tn < t_end;
+        FusedTile nxt = cur;
+        if (has_next) nxt = fused_tile<Cfg>(a, tn);
+        float* out_tile = a.out + cur.img + ((size_t)cur.y0 * a.W + cur.x0) * 16;
+        FusedLane L = L0;
+        asm volatile("" : "+v"(L.row_c), "+v"(L.strip_in), "+v"(L.strip_mid));
+        const bool interior = tile_interior<Cfg>(a, cur);
+
+        if (interior) {
+            conv1_interior<Cfg, 0>(a, tin, tmid, w1, L, cur, wave, n1);
+        } else {
+            for (int g = wave; g < Cfg::MG;) {
+                int g0 = -1, g1 = -1, g2 = -1;
+                for (; g < Cfg::MG && g2 < 0; g += Cfg::NW) {
+                    if (!mid_group_needed<Cfg>(a, cur, g)) continue;
+                    if (g0 < 0) g0 = g; else if (g1 < 0) g1 = g; else g2 = g;
+                }
+                if (g2 >= 0)      { const int gs[3] = {g0, g1, g2}; conv1_pass<Cfg, 3, false>(a, tin, tmid, w1, gs, L, cur); }
+                else if (g1 >= 0) { const int gs[2] = {g0, g1};     conv1_pass<Cfg, 2, false>(a, tin, tmid, w1, gs, L, cur); }
+                else if (g0 >= 0) { const int gs[1] = {g0};         conv1_pass<Cfg, 1, false>(a, tin, tmid, w1, gs, L, cur); }
+            }
+        }
+        __syncthreads();                                     // tmid complete; tin is dead (residual from global)
+        if (has_next) {
+            if (tile_interior<Cfg>(a, nxt)) fused_dma<Cfg, true>(a, nxt, tin, tid, wave);
+            else fused_dma<Cfg, false>(a, nxt, tin, tid, wave);
+        }
+        if (interior) {
+            conv2_interior<Cfg, 0, true>(a, tin, tmid, out_tile, w2, sc, sh, L, cur, wave, n2);
+        } else {
+            for (int g = wave; g < Cfg::OG;) {
+                int g0 = -1, g1 = -1, g2 = -1, g3 = -1;
+                for (; g < Cfg::OG && g3 < 0; g += Cfg::NW) {
+                    if (!out_group_needed<Cfg>(a, cur, g)) continue;
+                    if (g0 < 0) g0 = g; else if (g1 < 0) g1 = g; else if (g2 < 0) g2 = g; else g3 = g;
+                }
+                if (g3 >= 0)      { const int gs[4] = {g0, g1, g2, g3}; conv2_pass<Cfg, 4, false, true>(a, tin, tmid, out_tile, w2, sc, sh, gs, L, cur); }
+                else if (g2 >= 0) { const int gs[3] = {g0, g1, g2};     conv2_pass<Cfg, 3, false, true>(a, tin, tmid, out_tile, w2, sc, sh, gs, L, cur); }
+                else if (g1 >= 0) { const int gs[2] = {g0, g1};         conv2_pass<Cfg, 2, false, true>(a, tin, tmid, out_tile, w2, sc, sh, gs, L, cur); }
+                else if (g0 >= 0) { const int gs[1] = {g0};             conv2_pass<Cfg, 1, false, true>(a, tin, tmid, out_tile, w2, sc, sh, gs, L, cur); }
+            }
+        }
+        __syncthreads();                                     // drains the DMA; tin = next tile, tmid free
+        cur = nxt;
+    }
+}
+
+template <class Cfg>
+static hipError_t launch_fused_dma(FusedBlockArgs a, int wgs_per_cu, hipStream_t s)
+{
+    if (!a.zeros) return hipErrorInvalidValue;
+    a.tiles_x = (a.W + Cfg::TW - 1) / Cfg::TW;
+    a.tiles_y = (a.H + Cfg::TH - 1) / Cfg::TH;
+    a.ntiles = a.B * a.tiles_x * a.tiles_y;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_block_dma_kernel<Cfg>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, FusedDmaCfg<Cfg>::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int resident = 256 * wgs_per_cu;
+    int grid = a.ntiles < resident ? a.ntiles : resident;
+    if (grid >= 8) grid -= grid % 8;
+    hipLaunchKernelGGL(fused_block_dma_kernel<Cfg>, dim3(grid), dim3(Cfg::NT), FusedDmaCfg<Cfg>::LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
 static int g_fused_tile = 0;      // 0: 14x32 x4 waves (2 workgroups/CU) ; 1: 32x32 x8 waves ; 2: 16x64 x8 waves
 void bf_set_fused_tile(int v) { g_fused_tile = v; }
 
@@ -598,6 +748,7 @@ hipError_t bf_launch_fused_block(const FusedBlockArgs& a, hipStream_t s)
     switch (g_fused_tile) {
         case 1: return launch_fused<FusedCfg<32, 32, 8>>(a, 1, s);
         case 2: return launch_fused<FusedCfg<16, 64, 8>>(a, 1, s);
+        case 3: return launch_fused_dma<FusedCfg<14, 32, 4>>(a, 2, s);
         default: return launch_fused<FusedCfg<14, 32, 4>>(a, 2, s);
     }
 }

@@ -19,7 +19,7 @@ struct bf_engine {
     int64_t p_base = 0, p_blocks = 0, p_block_stride = 0, p_head0 = 0, p_head1 = 0;
     int64_t n_base = 0;
     // packed-inference layout (floats)
-    int64_t k_base = 0, k_blocks = 0, k_block_stride = 0, k_w0 = 0, k_w1 = 0, k_wh = 0, k_total = 0;
+    int64_t k_base = 0, k_blocks = 0, k_block_stride = 0, k_w0 = 0, k_w1 = 0, k_wh = 0, k_zero = 0, k_total = 0;
     int fused_blocks = 1;
     // optional HIP-event bracket around the residual-block launches of a forward (bench.py roofline)
     int timing = 0;
@@ -138,6 +138,7 @@ extern "C" int bf_create(const bf_resnet_desc* d, bf_handle* out)
     h->k_w0 = ko; ko += align_up(16 * hf, 64);
     h->k_w1 = ko; ko += align_up(hf * co, 64);
     h->k_wh = ko; ko += 64;
+    h->k_zero = ko; ko += 64;
     h->k_total = ko;
     *out = h;
     return BF_OK;
@@ -255,6 +256,7 @@ __global__ void pack_edges_kernel(const float* __restrict__ params, float* __res
         if (o < co)
             for (int j = 0; j < hf; ++j) s = fmaf(params[p_head0 + c * hf + j], params[p_head1 + j * co + o], s);
         packed[k_wh + threadIdx.x] = s;
+        packed[k_wh + 64 + threadIdx.x] = 0.f;     // k_zero line (directly behind k_wh)
     }
 }
 
@@ -354,7 +356,7 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
             fa.w1pack = blk; fa.w2pack = blk + BF_WPACK_FLOATS;
             fa.scale = blk + 2 * BF_WPACK_FLOATS; fa.shift = fa.scale + 16;
             fa.B = B; fa.H = H; fa.W = W; fa.tiles_x = fa.tiles_y = fa.ntiles = 0;
-            fa.act1_relu = d.activation == BF_ACT_RELU; fa.dbg = nullptr;
+            fa.act1_relu = d.activation == BF_ACT_RELU; fa.dbg = nullptr; fa.zeros = pk + h->k_zero;
             BF_HIP(bf_launch_fused_block(fa, s), "fused_block");
             cur ^= 1;
         } else {
@@ -731,7 +733,9 @@ extern "C" int bf_debug_fused_block(const float* in, const float* w1_hwio, const
     hipStream_t s = (hipStream_t)stream;
     if (bf_launch_pack_conv(w1_hwio, wpack_scratch, 0, s) != hipSuccess) return BF_EHIP;
     if (bf_launch_pack_conv(w2_hwio, wpack_scratch + BF_WPACK_FLOATS, 0, s) != hipSuccess) return BF_EHIP;
+    if (bf_launch_zero(wpack_scratch + 2 * BF_WPACK_FLOATS, 64, s) != hipSuccess) return BF_EHIP;
     FusedBlockArgs fa;
+    fa.zeros = wpack_scratch + 2 * BF_WPACK_FLOATS;
     fa.in = in; fa.out = out; fa.w1pack = wpack_scratch; fa.w2pack = wpack_scratch + BF_WPACK_FLOATS; fa.scale = scale;
     fa.shift = shift; fa.B = B; fa.H = H; fa.W = W; fa.tiles_x = fa.tiles_y = fa.ntiles = 0; fa.act1_relu = act1_relu;
     fa.dbg = g_fused_dbg;

@@ -190,7 +190,7 @@ int bf_set_option(bf_handle h, const char* key, int value);
 int bf_get_timing(bf_handle h, float* ms, int* launches);
 
 /* single 3x3 16->16 convolution with epilogue flags (1 relu, 2 affine, 4 residual, 8 mask,
- * 16 stats); transpose_flip = 1 runs the data-gradient form.  wpack_scratch = 2*2304 floats. */
+ * 16 stats); transpose_flip = 1 runs the data-gradient form.  wpack_scratch = 2*2304 + 64 floats. */
 int bf_debug_conv3x3(const float* in, const float* w_hwio, float* out, const float* scale, const float* shift,
                      const float* res, const float* mask, float* stats, float* wpack_scratch,
                      int batch, int height, int width, int epi, int transpose_flip, void* stream);

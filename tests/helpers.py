@@ -39,7 +39,7 @@ def conv3x3_gpu(x, w, epi=0, scale=None, shift=None, res=None, mask=None, transp
     md = dev(mask) if mask is not None else None
     grid = L.bf_debug_conv3x3_grid(B, H, W)
     stats = torch.zeros(grid * 32, dtype=torch.float32, device="cuda") if want_stats else None
-    scratch = torch.zeros(2 * 2304, dtype=torch.float32, device="cuda")
+    scratch = torch.zeros(2 * 2304 + 64, dtype=torch.float32, device="cuda")
     rc = L.bf_debug_conv3x3(N.ptr(xd), N.ptr(wd), N.ptr(out), N.ptr(sd), N.ptr(hd), N.ptr(rd), N.ptr(md), N.ptr(stats),
                             N.ptr(scratch), B, H, W, epi, transpose_flip, N.stream_ptr(xd))
     assert rc == 0, rc
@@ -53,7 +53,7 @@ def fused_block_gpu(x, w1, w2, scale, shift, act1_relu=1):
     B, H, W, _ = x.shape
     xd = dev(x)
     out = torch.full((B, H, W, 16), float("nan"), dtype=torch.float32, device="cuda")
-    scratch = torch.zeros(2 * 2304, dtype=torch.float32, device="cuda")
+    scratch = torch.zeros(2 * 2304 + 64, dtype=torch.float32, device="cuda")
     w1d, w2d, sd, hd = dev(w1), dev(w2), dev(scale), dev(shift)
     rc = L.bf_debug_fused_block(N.ptr(xd), N.ptr(w1d), N.ptr(w2d), N.ptr(sd), N.ptr(hd), N.ptr(out), N.ptr(scratch),
                                 B, H, W, act1_relu, N.stream_ptr(xd))

@@ -18,7 +18,7 @@ out = torch.empty_like(x)
 w1 = torch.randn((3, 3, 16, 16), device="cuda") * 0.1
 w2 = torch.randn((3, 3, 16, 16), device="cuda") * 0.1
 sc, sh = torch.ones(16, device="cuda"), torch.zeros(16, device="cuda")
-scratch = torch.zeros(2 * 2304, device="cuda")
+scratch = torch.zeros(2 * 2304 + 64, device="cuda")
 dbg = torch.zeros(512 * 8 * 8, dtype=torch.int64, device="cuda")
 L.bf_debug_set_fused_dbg(C.c_void_p(dbg.data_ptr()))
 for _ in range(3):
