@@ -14,6 +14,7 @@
  * State: per block moving_mean[16], moving_variance[16].
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -158,6 +159,9 @@ static int forward_image(const float* params, const float* state, int no_layers,
         }
     return 0;
 }
+
+void bfcnn_port_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int bfcnn_port_max_threads(void) { return omp_get_max_threads(); }
 
 int bfcnn_port_forward_u8(const float* params, const float* state, int no_layers, int kernel_size, int cin, int hf,
                           int cout, float bn_eps, const uint8_t* in, uint8_t* out, int B, int H, int W)

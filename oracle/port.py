@@ -3,6 +3,9 @@ import ctypes as C
 import pathlib
 import subprocess
 
+import math
+import os
+
 import numpy as np
 
 _HERE = pathlib.Path(__file__).resolve().parent
@@ -14,10 +17,26 @@ def build(march: str = "native"):
                    stdout=subprocess.DEVNULL)
 
 
+def effective_cores() -> int:
+    """host cores this process may really use: scheduler affinity capped by the cgroup CPU quota
+    (a GPU box gives one GPU's share, e.g. cpu.max = "1600000 100000" = 16 CPUs of 256 visible)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def lib(rebuild: bool = False):
     if rebuild or not _LIB.exists():
         build()
     h = C.CDLL(str(_LIB))
+    h.bfcnn_port_set_threads.argtypes = [C.c_int]
+    h.bfcnn_port_max_threads.restype = C.c_int
+    h.bfcnn_port_set_threads(int(os.environ.get("OMP_NUM_THREADS", effective_cores())))
     h.bfcnn_port_forward_u8.restype = C.c_int
     h.bfcnn_port_forward_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                         C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
