@@ -720,6 +720,298 @@ static hipError_t launch_fused_dma(FusedBlockArgs a, int wgs_per_cu, hipStream_t
     return hipGetLastError();
 }
 
+// ---- v4: LDS-DMA + immediate-offset addressing ------------------------------------------------------
+// Measured on MI355X (profiles/, tools/exp): a non-MFMA VALU instruction costs ~7 SIMD cycles of matrix
+// throughput, and the register-prefetch kernel executes 0.74 of them per MFMA (tile fetch address math,
+// LDS staging, pass prologues/epilogues) -- that, not barriers or tiling, held it at 61 %.  This variant
+// removes them structurally:
+//   * wave w owns groups g = w + NW*k.  With RG % NW == 0 and NW % GPR == 0 the group's row is
+//     (w/GPR) + (NW/GPR)*k and its column (w%GPR)*16, so every LDS address is ONE per-wave VGPR constant
+//     plus a compile-time immediate (ds_read/ds_write offset field); global addresses are a scalar base
+//     plus one per-wave VGPR constant.  A pass needs no address VALU at all.
+//   * the next tile goes global -> LDS by DMA (global_load_lds_dwordx4) with per-lane constant offsets:
+//     no VGPR staging, no ds_write pass, no fetch address math; it is issued after the conv1 -> conv2
+//     barrier (the residual is re-read from global/L2) and lands while conv2 runs.  Two barriers per tile.
+template <class Cfg>
+struct V4 {
+    static_assert(Cfg::RG % Cfg::NW == 0 && Cfg::NW % Cfg::GPR == 0, "v4 addressing needs RG % NW == 0 and NW % GPR == 0");
+    static constexpr int RSTEP = Cfg::NW / Cfg::GPR;              // rows between a wave's consecutive groups
+    static constexpr int K1R = Cfg::RG / Cfg::NW;                  // conv1 row groups per wave
+    static constexpr int K1S = (Cfg::SG + Cfg::NW - 1) / Cfg::NW;  // conv1 strip-group slots per wave
+    static constexpr int K2 = Cfg::OG / Cfg::NW;                   // conv2 groups per wave (OG % NW == 0 follows)
+    static_assert(Cfg::OG % Cfg::NW == 0, "conv2 groups must divide evenly");
+    static constexpr int TIN_PAD_FLOATS = Cfg::PF * Cfg::NT * 4;
+    static constexpr int TMID_FLOATS = Cfg::MH * Cfg::MW * 16;
+    static constexpr int LDS_BYTES = (TMID_FLOATS + TIN_PAD_FLOATS) * 4;
+};
+
+struct V4Lane {
+    int in_c;        // float offset in the input tile of this wave's row-group pixel (k = 0)
+    int mid_c;       // float offset in the intermediate tile (k = 0): conv1 writes, conv2 reads
+    int strip_in;    // float offset in the input tile of this wave's strip-group pixel (slot 0)
+    int strip_mid;   // float offset in the intermediate tile of this wave's strip-group pixel
+    unsigned glob_c; // byte offset in the image of this wave's output pixel (k = 0) relative to the tile origin
+    int px;          // column of the lane's pixel inside the tile for row groups: (w%GPR)*16 + p
+    int sp;          // p (strip groups: row 8s + p/2, column TW + p%2)
+};
+
+// K consecutive groups of this wave starting at slot K0: conv1 (+activation) -> intermediate tile
+template <class Cfg, int NG, int K0, bool INTERIOR>
+__device__ __forceinline__ void v4_conv1_rows(const FusedBlockArgs& a, const float* __restrict__ tin, float* __restrict__ tmid,
+                                              const float (&w1)[36], const V4Lane& L, const FusedTile& t, const int wrow)
+{
+    constexpr int RS = V4<Cfg>::RSTEP;
+    int base[NG];
+    f32x4 acc[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        base[j] = L.in_c + (K0 + j) * RS * Cfg::IW * 16;            // VGPR + immediate
+        acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    conv_groups<NG>(tin, base, Cfg::IW, w1, acc);
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        f32x4 v = acc[j];
+        if (a.act1_relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        if (!INTERIOR) {
+            // conv2 must see ZERO padding outside the image, not conv1 evaluated there
+            const int gy = t.y0 - 1 + wrow + (K0 + j) * RS;         // scalar
+            const int gx = t.x0 - 1 + L.px;
+            if (gy < 0 || gy >= a.H || gx < 0 || gx >= a.W) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        *reinterpret_cast<f32x4*>(tmid + L.mid_c + (K0 + j) * RS * Cfg::MW * 16) = v;
+    }
+}
+
+template <class Cfg, bool INTERIOR>
+__device__ __forceinline__ void v4_conv1_strip(const FusedBlockArgs& a, const float* __restrict__ tin, float* __restrict__ tmid,
+                                               const float (&w1)[36], const V4Lane& L, const FusedTile& t, const int s)
+{
+    // strip group s: rows 8s .. 8s+7 (clamped to MH-1 in a partial last group), columns TW, TW+1
+    int base[1];
+    f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+    int my = 8 * s + (L.sp >> 1);
+    int dst;
+    if (Cfg::MH % 8 == 0 || 8 * s + 8 <= Cfg::MH) {
+        base[0] = L.strip_in;
+        dst = L.strip_mid;
+    } else {
+        my = min(my, Cfg::MH - 1);
+        base[0] = (my * Cfg::IW + Cfg::TW + (L.sp & 1)) * 16 + (L.in_c & 12);
+        dst = (my * Cfg::MW + Cfg::TW + (L.sp & 1)) * 16 + (L.in_c & 12);
+    }
+    conv_groups<1>(tin, base, Cfg::IW, w1, acc);
+    f32x4 v = acc[0];
+    if (a.act1_relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    if (!INTERIOR) {
+        const int gy = t.y0 - 1 + my, gx = t.x0 - 1 + Cfg::TW + (L.sp & 1);
+        if (gy < 0 || gy >= a.H || gx < 0 || gx >= a.W) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    *reinterpret_cast<f32x4*>(tmid + dst) = v;
+}
+
+// conv2 + folded BN + residual (from global) of NG groups starting at slot K0
+template <class Cfg, int NG, int K0, bool INTERIOR>
+__device__ __forceinline__ void v4_conv2(const FusedBlockArgs& a, const float* __restrict__ tmid, const char* __restrict__ in_tile,
+                                         char* __restrict__ out_tile, const float (&w2)[36], const f32x4 sc, const f32x4 sh,
+                                         const V4Lane& L, const FusedTile& t, const int wrow)
+{
+    constexpr int RS = V4<Cfg>::RSTEP;
+    int base[NG];
+    f32x4 acc[NG], res[NG];
+    const size_t rowstep = (size_t)a.W * 64;                         // bytes per image row
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        base[j] = L.mid_c + (K0 + j) * RS * Cfg::MW * 16;
+        acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        res[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int gy = t.y0 + wrow + (K0 + j) * RS;                  // scalar
+        if (INTERIOR || (gy < a.H && t.x0 + L.px < a.W))
+            res[j] = *reinterpret_cast<const f32x4*>(in_tile + (K0 + j) * RS * rowstep + L.glob_c);
+    }
+    conv_groups<NG>(tmid, base, Cfg::MW, w2, acc);
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int gy = t.y0 + wrow + (K0 + j) * RS;
+        if (INTERIOR || (gy < a.H && t.x0 + L.px < a.W)) {
+            const f32x4 v = acc[j] * sc + sh + res[j];
+            *reinterpret_cast<f32x4*>(out_tile + (K0 + j) * RS * rowstep + L.glob_c) = v;
+        }
+    }
+}
+
+template <class Cfg, int K0, bool INTERIOR>
+__device__ __forceinline__ void v4_conv1_all(const FusedBlockArgs& a, const float* __restrict__ tin, float* __restrict__ tmid,
+                                             const float (&w1)[36], const V4Lane& L, const FusedTile& t, const int wrow)
+{
+    constexpr int K = V4<Cfg>::K1R;
+    if constexpr (K0 < K) {
+        constexpr int NG = K - K0 >= 4 ? (K - K0 == 4 || K - K0 >= 7 ? 4 : 3) : K - K0;   // 8 -> 4+4, 9 -> 3+3+3, 6 -> 3+3, 5 -> 3+2
+        const bool needed = INTERIOR || (t.y0 - 1 + wrow + K0 * V4<Cfg>::RSTEP <= a.H);  // rows beyond H+1 are never read
+        if (needed) v4_conv1_rows<Cfg, NG, K0, INTERIOR>(a, tin, tmid, w1, L, t, wrow);
+        v4_conv1_all<Cfg, K0 + NG, INTERIOR>(a, tin, tmid, w1, L, t, wrow);
+    }
+}
+
+template <class Cfg, int K0, bool INTERIOR>
+__device__ __forceinline__ void v4_conv2_all(const FusedBlockArgs& a, const float* __restrict__ tmid, const char* __restrict__ in_tile,
+                                             char* __restrict__ out_tile, const float (&w2)[36], const f32x4 sc, const f32x4 sh,
+                                             const V4Lane& L, const FusedTile& t, const int wrow)
+{
+    constexpr int K = V4<Cfg>::K2;
+    if constexpr (K0 < K) {
+        constexpr int NG = K - K0 >= 4 ? (K - K0 == 4 || K - K0 >= 7 ? 4 : 3) : K - K0;   // 7 -> 4+3
+        const bool needed = INTERIOR || (t.y0 + wrow + K0 * V4<Cfg>::RSTEP < a.H);
+        if (needed) v4_conv2<Cfg, NG, K0, INTERIOR>(a, tmid, in_tile, out_tile, w2, sc, sh, L, t, wrow);
+        v4_conv2_all<Cfg, K0 + NG, INTERIOR>(a, tmid, in_tile, out_tile, w2, sc, sh, L, t, wrow);
+    }
+}
+
+// DMA of a tile: interior = per-lane constant offsets from the tile origin, nothing else
+template <class Cfg, bool INTERIOR>
+__device__ __forceinline__ void v4_dma(const FusedBlockArgs& a, const FusedTile& t, float* __restrict__ tin, int tid, int wave,
+                                       const unsigned (&pfoff)[Cfg::PF])
+{
+    const char* origin = reinterpret_cast<const char*>(a.in + t.img) + ((ptrdiff_t)(t.y0 - 2) * a.W + (t.x0 - 2)) * 64;
+    constexpr int RW = Cfg::IW * 4;
+    int row = tid / RW, rem = tid - row * RW;
+#pragma unroll
+    for (int i = 0; i < Cfg::PF; ++i) {
+        const char* src = origin + pfoff[i];
+        if (!INTERIOR || (i + 1) * Cfg::NT > Cfg::IN4) {
+            const bool in_tile = (i + 1) * Cfg::NT <= Cfg::IN4 || tid + i * Cfg::NT < Cfg::IN4;
+            bool inside = true;
+            if (!INTERIOR) {
+                const int gy = t.y0 - 2 + row, gx = t.x0 - 2 + (rem >> 2);
+                inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                rem += Cfg::NT % RW;
+                row += Cfg::NT / RW;
+                if (rem >= RW) { rem -= RW; ++row; }
+            }
+            if (!(in_tile && inside)) src = reinterpret_cast<const char*>(a.zeros);
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(tin + (i * Cfg::NT + wave * 64) * 4),
+                                         16, 0, 0);
+    }
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT, 2) void fused_block_v4_kernel(FusedBlockArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* tmid = lds;                                       // [MH][MW][16]
+    float* tin = lds + V4<Cfg>::TMID_FLOATS;                 // [IH][IW][16] + pad to whole wave-instructions
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 15, q = lane >> 4;
+    const int wrow = wave / Cfg::GPR, wcol = (wave % Cfg::GPR) * 16;
+
+    V4Lane L0;
+    L0.in_c = (wrow * Cfg::IW + wcol + p) * 16 + q * 4;
+    L0.mid_c = (wrow * Cfg::MW + wcol + p) * 16 + q * 4;
+    L0.strip_in = ((8 * wave + (p >> 1)) * Cfg::IW + Cfg::TW + (p & 1)) * 16 + q * 4;     // strip slot 0: s = wave
+    L0.strip_mid = ((8 * wave + (p >> 1)) * Cfg::MW + Cfg::TW + (p & 1)) * 16 + q * 4;
+    L0.glob_c = ((unsigned)(wrow * a.W + wcol + p) * 16u + (unsigned)q * 4u) * 4u;
+    L0.px = wcol + p;
+    L0.sp = p;
+    unsigned pfoff[Cfg::PF];
+    {
+        constexpr int RW = Cfg::IW * 4;
+        int row = tid / RW, rem = tid - row * RW;
+#pragma unroll
+        for (int i = 0; i < Cfg::PF; ++i) {
+            pfoff[i] = ((unsigned)(row * a.W + (rem >> 2)) * 16u + (unsigned)(rem & 3) * 4u) * 4u;
+            rem += Cfg::NT % RW;
+            row += Cfg::NT / RW;
+            if (rem >= RW) { rem -= RW; ++row; }
+        }
+    }
+
+    float w1[36], w2[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) { w1[i] = a.w1pack[i * 64 + lane]; w2[i] = a.w2pack[i * 64 + lane]; }
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + q * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + q * 4);
+
+    const int nxcd = gridDim.x >= 8 ? 8 : 1;
+    const int label = blockIdx.x % nxcd, slot = blockIdx.x / nxcd;
+    const int per_label = gridDim.x / nxcd;
+    const int chunk = (a.ntiles + nxcd - 1) / nxcd;
+    const int t_begin = label * chunk;
+    const int t_end = min(a.ntiles, t_begin + chunk);
+    int t = t_begin + slot;
+    if (t >= t_end) return;
+
+    FusedTile cur = fused_tile<Cfg>(a, t);
+    v4_dma<Cfg, false>(a, cur, tin, tid, wave, pfoff);
+    __syncthreads();                                         // drains the DMA (vmcnt(0)) and publishes tin
+
+    for (; t < t_end; t += per_label) {
+        const int tn = t + per_label;
+        const bool has_next = tn < t_end;
+        FusedTile nxt = cur;
+        if (has_next) nxt = fused_tile<Cfg>(a, tn);
+        V4Lane L = L0;
+        // opaque inside the loop body: keeps LICM from hoisting every (constant + immediate) address
+        asm volatile("" : "+v"(L.in_c), "+v"(L.mid_c), "+v"(L.glob_c));
+        const bool interior = tile_interior<Cfg>(a, cur);
+        const char* in_tile = reinterpret_cast<const char*>(a.in + cur.img) + ((size_t)cur.y0 * a.W + cur.x0) * 64;
+        char* out_tile = reinterpret_cast<char*>(a.out + cur.img) + ((size_t)cur.y0 * a.W + cur.x0) * 64;
+
+        // ---- conv1: input tile -> intermediate tile -------------------------------------------
+        if (interior) v4_conv1_all<Cfg, 0, true>(a, tin, tmid, w1, L, cur, wrow);
+        else v4_conv1_all<Cfg, 0, false>(a, tin, tmid, w1, L, cur, wrow);
+#pragma unroll
+        for (int ks = 0; ks < V4<Cfg>::K1S; ++ks) {
+            const int s = wave + Cfg::NW * ks;               // strip group index
+            if (s < Cfg::SG) {
+                V4Lane Ls = L;
+                Ls.strip_in = L.strip_in + ks * Cfg::NW * 8 * Cfg::IW * 16;
+                Ls.strip_mid = L.strip_mid + ks * Cfg::NW * 8 * Cfg::MW * 16;
+                if (interior) v4_conv1_strip<Cfg, true>(a, tin, tmid, w1, Ls, cur, s);
+                else if (cur.y0 - 1 + 8 * s <= a.H && cur.x0 - 1 + Cfg::TW <= a.W) v4_conv1_strip<Cfg, false>(a, tin, tmid, w1, Ls, cur, s);
+            }
+        }
+        __syncthreads();                                     // tmid complete; tin is dead (residual comes from global)
+
+        if (has_next) {
+            if (tile_interior<Cfg>(a, nxt)) v4_dma<Cfg, true>(a, nxt, tin, tid, wave, pfoff);
+            else v4_dma<Cfg, false>(a, nxt, tin, tid, wave, pfoff);
+        }
+        // ---- conv2 + folded BN + residual -> global ---------------------------------------------
+        if (interior) v4_conv2_all<Cfg, 0, true>(a, tmid, in_tile, out_tile, w2, sc, sh, L, cur, wrow);
+        else v4_conv2_all<Cfg, 0, false>(a, tmid, in_tile, out_tile, w2, sc, sh, L, cur, wrow);
+        __syncthreads();                                     // drains the DMA; tin = next tile, tmid free
+        cur = nxt;
+    }
+}
+
+template <class Cfg>
+static hipError_t launch_fused_v4(FusedBlockArgs a, int wgs_per_cu, hipStream_t s)
+{
+    if (!a.zeros) return hipErrorInvalidValue;
+    a.tiles_x = (a.W + Cfg::TW - 1) / Cfg::TW;
+    a.tiles_y = (a.H + Cfg::TH - 1) / Cfg::TH;
+    a.ntiles = a.B * a.tiles_x * a.tiles_y;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_block_v4_kernel<Cfg>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, V4<Cfg>::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int resident = 256 * wgs_per_cu;
+    int grid = a.ntiles < resident ? a.ntiles : resident;
+    if (grid >= 8) grid -= grid % 8;
+    hipLaunchKernelGGL(fused_block_v4_kernel<Cfg>, dim3(grid), dim3(Cfg::NT), V4<Cfg>::LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
 static int g_fused_tile = 0;      // 0: 14x32 x4 waves (2 workgroups/CU) ; 1: 32x32 x8 waves ; 2: 16x64 x8 waves
 void bf_set_fused_tile(int v) { g_fused_tile = v; }
 
@@ -749,6 +1041,7 @@ hipError_t bf_launch_fused_block(const FusedBlockArgs& a, hipStream_t s)
         case 1: return launch_fused<FusedCfg<32, 32, 8>>(a, 1, s);
         case 2: return launch_fused<FusedCfg<16, 64, 8>>(a, 1, s);
         case 3: return launch_fused_dma<FusedCfg<14, 32, 4>>(a, 2, s);
+        case 4: return launch_fused_v4<FusedCfg<14, 32, 4>>(a, 2, s);
         default: return launch_fused<FusedCfg<14, 32, 4>>(a, 2, s);
     }
 }

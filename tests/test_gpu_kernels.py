@@ -86,7 +86,7 @@ def test_conv3x3_data_gradient_form(shape):
                  O.conv2d_same_grad_input(dy.astype(np.float64), w.astype(np.float64)), what="dgrad")
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=["tile14x32x4", "tile32x32x8", "tile16x64x8", "dma14x32x4"])
+@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["tile14x32x4", "tile32x32x8", "tile16x64x8", "dma14x32x4", "v4_14x32x4"])
 def fused_tile(request):
     """every fused-block tile geometry compiled into the library must pass the same parity tests."""
     import blind_image_denoising_amd as bf
