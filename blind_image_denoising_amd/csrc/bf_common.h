@@ -41,6 +41,29 @@ struct FusedBlockArgs {
     unsigned long long* dbg;  // diagnostic builds only (per-wave phase cycle sums), else NULL
 };
 
+// split-f16 ("f16x3") fused block on the f16 matrix cores (fused_h3.hip).  Activations are "split-planar":
+// per image 4 planes [H][W][8 x f16] = hi(c0..7), hi(c8..15), lo(c0..7), lo(c8..15), value = hi + lo.
+#define BF_H3_WPACK_FLOATS (10 * 64 * 4)                      // ten A-operand register images of 16 B per lane
+#define BF_H3_BLOCK_FLOATS (2 * BF_H3_WPACK_FLOATS + 64)      // w1, w2, aux (1/s1 | scale/s2 | shift | pad)
+struct FusedH3Args {
+    const void* in;       // split-planar block input x
+    void* out;            // split-planar x + scale*conv2(act(conv1 x)) + shift
+    const void* w1;       // [10][64] x 16 B
+    const void* w2;
+    const float* aux;     // [0..15] 1/s1, [16..31] scale/s2, [32..47] shift
+    int B, H, W;
+    int tiles_x, tiles_y, ntiles;
+    int act1_relu;
+    const void* zeros;    // >= 64 B of zeros, 16-B aligned (source of out-of-image elements)
+    void* dump;           // >= 512 B writable scratch (sink of out-of-image stores)
+};
+hipError_t bf_launch_fused_block_h3(const FusedH3Args& a, hipStream_t s);
+hipError_t bf_launch_pack_h3(const float* params, const float* state, int64_t p_blocks, int64_t p_stride, float* dst,
+                             int64_t d_stride, int layers, int use_bn, float eps, hipStream_t s);
+hipError_t bf_launch_h3_from_f32(const float* x, void* y, int B, int H, int W, hipStream_t s);
+hipError_t bf_launch_h3_to_f32(const void* y, float* x, int B, int H, int W, hipStream_t s);
+hipError_t bf_launch_affine_patch(float* aux, const float* scale, const float* shift, hipStream_t s);
+
 // ---- launchers (each returns hipGetLastError()) -------------------------------------------
 hipError_t bf_launch_conv3x3_c16(const ConvArgs& a, int epi, hipStream_t s);
 int        bf_conv3x3_c16_grid(int B, int H, int W);
@@ -57,6 +80,7 @@ struct BaseConvArgs {
     const void* in; float* out; const float* w;  // w: [k,k,cin,16] HWIO
     int B, Hs, Ws, H, W, cin, k, in_is_u8, act_relu;
     float v_min, v_max;
+    int out_split;        // 1: write split-planar f16 hi/lo (input of the f16x3 blocks) instead of fp32 NHWC
 };
 hipError_t bf_launch_base_conv(const BaseConvArgs& a, hipStream_t s);
 // dW[k,k,cin,16] = sum xn (x) dy ; partial = [grid][k*k*cin*16]
@@ -72,6 +96,7 @@ struct HeadArgs {
     void* out;            // u8 or f32 [B,Ho,Wo,cout]
     int B, H, W, Ho, Wo, hf, cout, act, out_is_u8, denormalize;
     float v_min, v_max, leaky_alpha;
+    int feat_split;       // 1: feat is split-planar f16 hi/lo
 };
 hipError_t bf_launch_head(const HeadArgs& a, hipStream_t s);
 

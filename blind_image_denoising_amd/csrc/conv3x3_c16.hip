@@ -1012,8 +1012,12 @@ static hipError_t launch_fused_v4(FusedBlockArgs a, int wgs_per_cu, hipStream_t 
     return hipGetLastError();
 }
 
-static int g_fused_tile = 0;      // 0: 14x32 x4 waves (2 workgroups/CU) ; 1: 32x32 x8 waves ; 2: 16x64 x8 waves
-void bf_set_fused_tile(int v) { g_fused_tile = v; }
+// 4 (default): v4 LDS-DMA + immediate-offset addressing, 14x32 x4 waves ; 0: register-prefetch 14x32 x4 waves
+// (2 workgroups/CU) ; 1: 32x32 x8 waves ; 2: 16x64 x8 waves ; 3: LDS-DMA 14x32 x4 waves.  A negative value
+// restores the default.
+constexpr int kDefaultFusedTile = 4;
+static int g_fused_tile = kDefaultFusedTile;
+void bf_set_fused_tile(int v) { g_fused_tile = v < 0 ? kDefaultFusedTile : v; }
 
 template <class Cfg>
 static hipError_t launch_fused(FusedBlockArgs a, int wgs_per_cu, hipStream_t s)
@@ -1041,8 +1045,8 @@ hipError_t bf_launch_fused_block(const FusedBlockArgs& a, hipStream_t s)
         case 1: return launch_fused<FusedCfg<32, 32, 8>>(a, 1, s);
         case 2: return launch_fused<FusedCfg<16, 64, 8>>(a, 1, s);
         case 3: return launch_fused_dma<FusedCfg<14, 32, 4>>(a, 2, s);
-        case 4: return launch_fused_v4<FusedCfg<14, 32, 4>>(a, 2, s);
-        default: return launch_fused<FusedCfg<14, 32, 4>>(a, 2, s);
+        case 0: return launch_fused<FusedCfg<14, 32, 4>>(a, 2, s);
+        default: return launch_fused_v4<FusedCfg<14, 32, 4>>(a, 2, s);
     }
 }
 

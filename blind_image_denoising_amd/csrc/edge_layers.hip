@@ -3,6 +3,8 @@
 // activations against <2 % of the FLOPs), so they are plain VALU kernels with 16-byte accesses.
 #include "bf_common.h"
 
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
 // ------------------------------------------------------------------------------------------
 // base convolution: [cast] -> [virtual pad_to_power_of_2] -> normalise -> conv k x k, Cin -> 16
 //   cast / pad : bfcnn/module_denoiser.py:53-56, bfcnn/utilities.py:736-751
@@ -65,6 +67,23 @@ __global__ __launch_bounds__(256) void base_conv_kernel(BaseConvArgs a)
         if (a.act_relu) {
 #pragma unroll
             for (int c = 0; c < 16; ++c) acc[c] = fmaxf(acc[c], 0.f);
+        }
+        if (a.out_split) {
+            // split-planar: 4 planes [H][W][8 x f16] per image = hi(c0..7), hi(c8..15), lo(c0..7), lo(c8..15)
+            const int64_t hw = (int64_t)a.H * a.W;
+            char* base = reinterpret_cast<char*>(a.out) + (int64_t)b * hw * 64 + ((int64_t)y * a.W + x) * 16;
+            h8 hi[2], lo[2];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const _Float16 h = (_Float16)acc[c];
+                hi[c >> 3][c & 7] = h;
+                lo[c >> 3][c & 7] = (_Float16)(acc[c] - (float)h);
+            }
+            *reinterpret_cast<h8*>(base) = hi[0];
+            *reinterpret_cast<h8*>(base + hw * 16) = hi[1];
+            *reinterpret_cast<h8*>(base + hw * 32) = lo[0];
+            *reinterpret_cast<h8*>(base + hw * 48) = lo[1];
+            return;
         }
         float4* o = reinterpret_cast<float4*>(a.out + (((int64_t)b * a.H + y) * a.W + x) * 16);
         o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -223,12 +242,24 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a)
         const int64_t t = pix / a.Wo;
         const int y = (int)(t % a.Ho);
         const int b = (int)(t / a.Ho);
-        const float4* fp = reinterpret_cast<const float4*>(a.feat + (((int64_t)b * a.H + y) * a.W + x) * 16);
         float f[16];
+        if (a.feat_split) {
+            const int64_t hw = (int64_t)a.H * a.W;
+            const char* base = reinterpret_cast<const char*>(a.feat) + (int64_t)b * hw * 64 + ((int64_t)y * a.W + x) * 16;
+            const h8 hi0 = *reinterpret_cast<const h8*>(base), hi1 = *reinterpret_cast<const h8*>(base + hw * 16);
+            const h8 lo0 = *reinterpret_cast<const h8*>(base + hw * 32), lo1 = *reinterpret_cast<const h8*>(base + hw * 48);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4 v = fp[i];
-            f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
+            for (int c = 0; c < 8; ++c) {
+                f[c] = (float)hi0[c] + (float)lo0[c];
+                f[8 + c] = (float)hi1[c] + (float)lo1[c];
+            }
+        } else {
+            const float4* fp = reinterpret_cast<const float4*>(a.feat + (((int64_t)b * a.H + y) * a.W + x) * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 v = fp[i];
+                f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
+            }
         }
         float h1[4] = {0.f, 0.f, 0.f, 0.f};
         if (fused) {

@@ -19,8 +19,11 @@ struct bf_engine {
     int64_t p_base = 0, p_blocks = 0, p_block_stride = 0, p_head0 = 0, p_head1 = 0;
     int64_t n_base = 0;
     // packed-inference layout (floats)
-    int64_t k_base = 0, k_blocks = 0, k_block_stride = 0, k_w0 = 0, k_w1 = 0, k_wh = 0, k_zero = 0, k_total = 0;
+    int64_t k_base = 0, k_blocks = 0, k_block_stride = 0, k_w0 = 0, k_w1 = 0, k_wh = 0, k_zero = 0, k_h3 = 0, k_total = 0;
     int fused_blocks = 1;
+    // arithmetic of the fused inference blocks: 1 = split-f16 on the f16 matrix cores (fused_h3.hip, needs
+    // |activation| < 65504), 0 = exact fp32 on the f32 matrix cores (conv3x3_c16.hip)
+    int arith = 1;
     // optional HIP-event bracket around the residual-block launches of a forward (bench.py roofline)
     int timing = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -139,6 +142,7 @@ extern "C" int bf_create(const bf_resnet_desc* d, bf_handle* out)
     h->k_w1 = ko; ko += align_up(hf * co, 64);
     h->k_wh = ko; ko += 64;
     h->k_zero = ko; ko += 64;
+    h->k_h3 = ko; ko += (int64_t)BF_H3_BLOCK_FLOATS * d->no_layers;
     h->k_total = ko;
     *out = h;
     return BF_OK;
@@ -169,6 +173,7 @@ extern "C" int bf_set_option(bf_handle h, const char* key, int value)
     if (!h || !key) return BF_EINVAL;
     if (!strcmp(key, "fused_blocks")) { h->fused_blocks = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "fused_tile")) { bf_set_fused_tile(value); return BF_OK; }
+    if (!strcmp(key, "arith")) { h->arith = value < 0 ? 1 : (value ? 1 : 0); return BF_OK; }
     if (!strcmp(key, "timing")) {
         h->timing = value ? 1 : 0;
         if (h->timing && !h->ev0) {
@@ -275,6 +280,8 @@ extern "C" int bf_pack_inference(bf_handle h, const float* params, const float* 
         hipLaunchKernelGGL(fold_bn_kernel, dim3((d.no_layers * 16 + 255) / 256), dim3(256), 0, s, params, state, h->p_blocks,
                            h->p_block_stride, pk, h->k_blocks, h->k_block_stride, d.no_layers, d.use_bn, d.bn_eps);
         BF_HIP(hipGetLastError(), "fold_bn");
+        BF_HIP(bf_launch_pack_h3(params, state, h->p_blocks, h->p_block_stride, pk + h->k_h3, BF_H3_BLOCK_FLOATS, d.no_layers,
+                                 d.use_bn, d.bn_eps, s), "pack_h3");
     }
     hipLaunchKernelGGL(pack_edges_kernel, dim3(1), dim3(256), 0, s, params, pk, h->p_base, h->n_base, h->p_head0, h->p_head1,
                        d.head_filters, d.out_channels, h->k_base, h->k_w0, h->k_w1, h->k_wh);
@@ -344,13 +351,25 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
     ba.B = B; ba.Hs = Hs; ba.Ws = Ws; ba.H = H; ba.W = W; ba.cin = d.in_channels; ba.k = d.kernel_size;
     ba.in_is_u8 = in_is_u8; ba.act_relu = d.base_activation == BF_ACT_RELU;
     ba.v_min = d.v_min; ba.v_max = d.v_max;
+    // split-f16 blocks keep the activations split-planar between base conv and head (same bytes as fp32)
+    const int h3 = h->fused_blocks && h->arith == 1 && d.no_layers > 0;
+    ba.out_split = h3;
     BF_HIP(bf_launch_base_conv(ba, s), "base_conv");
 
     int cur = 0;
     if (h->timing) BF_HIP(hipEventRecord(h->ev0, s), "hipEventRecord");
     for (int i = 0; i < d.no_layers; ++i) {
         const float* blk = pk + h->k_blocks + i * h->k_block_stride;
-        if (h->fused_blocks) {
+        if (h3) {
+            const float* b3 = pk + h->k_h3 + (int64_t)i * BF_H3_BLOCK_FLOATS;
+            FusedH3Args fa;
+            fa.in = buf[cur]; fa.out = buf[cur ^ 1];
+            fa.w1 = b3; fa.w2 = b3 + BF_H3_WPACK_FLOATS; fa.aux = b3 + 2 * BF_H3_WPACK_FLOATS;
+            fa.B = B; fa.H = H; fa.W = W; fa.tiles_x = fa.tiles_y = fa.ntiles = 0;
+            fa.act1_relu = d.activation == BF_ACT_RELU; fa.zeros = pk + h->k_zero; fa.dump = buf[2];
+            BF_HIP(bf_launch_fused_block_h3(fa, s), "fused_block_h3");
+            cur ^= 1;
+        } else if (h->fused_blocks) {
             FusedBlockArgs fa;
             fa.in = buf[cur]; fa.out = buf[cur ^ 1];
             fa.w1pack = blk; fa.w2pack = blk + BF_WPACK_FLOATS;
@@ -384,6 +403,7 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
     ha.B = B; ha.H = H; ha.W = W; ha.Ho = Hs; ha.Wo = Ws; ha.hf = d.head_filters; ha.cout = d.out_channels;
     ha.act = d.head_activation; ha.out_is_u8 = out_is_u8; ha.denormalize = d.denormalize;
     ha.v_min = d.v_min; ha.v_max = d.v_max; ha.leaky_alpha = d.leaky_alpha;
+    ha.feat_split = h3;
     BF_HIP(bf_launch_head(ha, s), "head");
     return BF_OK;
 }
@@ -570,7 +590,7 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     BaseConvArgs ba;
     ba.in = noisy; ba.out = A(0); ba.w = params + h->p_base;
     ba.B = B; ba.Hs = H; ba.Ws = W; ba.H = H; ba.W = W; ba.cin = d.in_channels; ba.k = d.kernel_size; ba.in_is_u8 = 0;
-    ba.act_relu = 0; ba.v_min = d.v_min; ba.v_max = d.v_max;
+    ba.act_relu = 0; ba.v_min = d.v_min; ba.v_max = d.v_max; ba.out_split = 0;
     BF_HIP(bf_launch_base_conv(ba, s), "base_conv");
     const int conv_grid = bf_conv3x3_c16_grid(B, H, W);
     for (int i = 0; i < N; ++i) {
@@ -740,6 +760,44 @@ extern "C" int bf_debug_fused_block(const float* in, const float* w1_hwio, const
     fa.shift = shift; fa.B = B; fa.H = H; fa.W = W; fa.tiles_x = fa.tiles_y = fa.ntiles = 0; fa.act1_relu = act1_relu;
     fa.dbg = g_fused_dbg;
     return bf_launch_fused_block(fa, s) == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// split-f16 fused block on fp32 NHWC tensors: convert in, run, convert out.  scratch: float buffer of at least
+// 2 * B*H*W*16 + BF_H3_BLOCK_FLOATS + 4608 + 32 + 64 + 128 floats (two split-planar activations, packed weights,
+// the two HWIO kernels + gamma-free BN stand-in, zero line, dump line).
+extern "C" int64_t bf_debug_fused_block_h3_scratch_floats(int B, int H, int W)
+{
+    return 2 * (int64_t)B * H * W * 16 + BF_H3_BLOCK_FLOATS + 4608 + 16 + 32 + 64 + 128;
+}
+
+extern "C" int bf_debug_fused_block_h3(const float* in, const float* w1_hwio, const float* w2_hwio, const float* scale,
+                                       const float* shift, float* out, float* scratch, int B, int H, int W, int act1_relu,
+                                       void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t act = (int64_t)B * H * W * 16;
+    float* xa = scratch;
+    float* ya = scratch + act;
+    float* pk = ya + act;                          // BF_H3_BLOCK_FLOATS
+    float* params = pk + BF_H3_BLOCK_FLOATS;       // [w1 2304][w2 2304][gamma 16]
+    float* state = params + 4608 + 16;             // [mean 16][var 16]
+    float* zeros = state + 32;                     // 64
+    float* dump = zeros + 64;                      // 128
+    // the pack kernel folds BN as gamma * rsqrt(var + eps), -scale * mean: gamma = scale, var = 1, eps = 0, mean = -shift/scale
+    // is not exact for scale == 0, so the debug entry passes scale/shift through use_bn = 0 and patches aux afterwards
+    if (hipMemcpyAsync(params, w1_hwio, 2304 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;
+    if (hipMemcpyAsync(params + 2304, w2_hwio, 2304 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;
+    if (bf_launch_zero(zeros, 64, s) != hipSuccess) return BF_EHIP;
+    if (bf_launch_pack_h3(params, state, 0, 4608 + 16, pk, BF_H3_BLOCK_FLOATS, 1, 0, 0.f, s) != hipSuccess) return BF_EHIP;
+    // aux[16..31] = 1/s2 (use_bn = 0 packs scale 1, shift 0): multiply in the caller's scale, set the shift
+    if (bf_launch_affine_patch(pk + 2 * BF_H3_WPACK_FLOATS, scale, shift, s) != hipSuccess) return BF_EHIP;
+    if (bf_launch_h3_from_f32(in, xa, B, H, W, s) != hipSuccess) return BF_EHIP;
+    FusedH3Args fa;
+    fa.in = xa; fa.out = ya; fa.w1 = pk; fa.w2 = pk + BF_H3_WPACK_FLOATS; fa.aux = pk + 2 * BF_H3_WPACK_FLOATS;
+    fa.B = B; fa.H = H; fa.W = W; fa.tiles_x = fa.tiles_y = fa.ntiles = 0; fa.act1_relu = act1_relu;
+    fa.zeros = zeros; fa.dump = dump;
+    if (bf_launch_fused_block_h3(fa, s) != hipSuccess) return BF_EHIP;
+    return bf_launch_h3_to_f32(ya, out, B, H, W, s) == hipSuccess ? BF_OK : BF_EHIP;
 }
 
 extern "C" int64_t bf_debug_wgrad_partial_floats(int B, int H, int W) { return (int64_t)bf_wgrad_grid(B, H, W) * 2304; }

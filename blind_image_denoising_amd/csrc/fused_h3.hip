@@ -1,0 +1,567 @@
+// Fused residual block on the f16 matrix cores with split-f16 ("f16x3") operands.
+//
+// Same reference semantics as fused_block_kernel in conv3x3_c16.hip (bfcnn/backbone_blocks.py:174-242 with
+// the inference BatchNormalization folded to scale/shift): out = x + scale * conv2(act(conv1 x)) + shift.
+//
+// Arithmetic.  An fp32 value v is carried as two f16 numbers hi = f16(v), lo = f16(v - hi) (22 mantissa
+// bits together).  A 3x3 16->16 convolution is evaluated as
+//     conv(x_hi, w_hi) + conv(x_lo, w_hi) + conv(x_hi, w_lo)          (the lo*lo term is < 2^-22 relative)
+// on v_mfma_f32_16x16x32_f16 with fp32 accumulation: 14 MFMAs of 16 cycles per 16-pixel group instead of
+// 36 MFMAs of 32 cycles on the f32 matrix path (5.1x fewer matrix cycles).  The weights of one kernel are
+// pre-scaled by a power of two (max |w| * s in [2^13, 2^14)) so that w_lo stays a normal f16 number; 1/s is
+// folded into the epilogues (exact).  tools/exp/emulate_f16x3.py sizes the error of this arithmetic against
+// the fp64 oracle: 2.2e-7 normalised MAE through 1x18 (exact-fp32 arithmetic: 1.9e-7; the bar is 1e-4).
+// Precondition: |activation| < 65504 (f16 range); the exact-fp32 kernels stay selectable.
+//
+// K packing.  One MFMA contracts K = 32 = 2 taps x 16 input channels: lanes q = 0,1 (k-slots 0..15) carry
+// tap A, lanes q = 2,3 tap B, each lane 8 consecutive channels of one pixel = ONE ds_read_b128.  Tap pairs:
+// (0,0)|(1,0), (0,1)|(1,1), (0,2)|(1,2), (2,0)|(2,1); the ninth tap (2,2) uses [w_hi | w_lo] x [x_hi | x_hi]
+// and [w_hi | 0] x [x_lo | x_lo]: 4*3 + 2 = 14 MFMAs per group.
+//
+// Layout ("split-planar", HBM and LDS alike): per image 4 planes [rows][cols][8 x f16] = hi(c0..7),
+// hi(c8..15), lo(c0..7), lo(c8..15); 64 B per pixel in total, the same as fp32 NHWC.  A b128 operand read
+// is bank-conflict free (16 consecutive pixels x 16 B per lane group, both channel halves one plane apart
+// = a multiple of 256 B), the D fragment (4 consecutive output channels of one pixel per lane) goes back
+// as one 8-byte hi and one 8-byte lo write, and tiles move HBM -> LDS by DMA without a conversion pass.
+//
+// Schedule.  One 8-wave workgroup per CU (2 waves per SIMD), persistent, XCD-contiguous tile chunks.  The
+// input tile is DOUBLE buffered: tile t+2 is requested right after the conv1 -> conv2 barrier of tile t
+// (into the buffer conv1 just finished with) and has a whole tile time to land.  The residual is re-read
+// from global (L2 hits) BEFORE the DMA is issued, because vmcnt retires in issue order: a residual issued
+// behind the DMA would drag the DMA's latency into the conv2 epilogue.  Barriers are bare s_barrier with
+// lgkmcnt(0) only (hipcc puts vmcnt(0) in front of every __syncthreads, which would drain the DMA).
+#include "bf_common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+#define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+template <int TH_, int TW_, int NW_>
+struct H3Cfg {
+    static constexpr int TH = TH_, TW = TW_, NW = NW_, NT = NW_ * 64;
+    static constexpr int MH = TH + 2, MW = TW + 2;             // intermediate region
+    static constexpr int IH = TH + 4, IW = TW + 4;             // input region
+    static constexpr int GPR = TW / 16;                        // 16-pixel groups per row
+    static constexpr int RSTEP = NW / GPR;                     // rows between a wave's consecutive groups
+    static constexpr int K1 = (MH + RSTEP - 1) / RSTEP;        // conv1 row-group slots per wave (last one partial)
+    static constexpr int K1_FULL = MH / RSTEP;                 // slots every wave has
+    static constexpr int K2 = TH / RSTEP;                      // conv2 groups per wave
+    static constexpr int SG = (MH + 7) / 8;                    // strip groups (columns TW, TW+1 of the intermediate region)
+    static constexpr int STRIP_W0 = (MH % RSTEP) * GPR;        // first wave with K1_FULL row groups only: strips go there
+    static constexpr int IN_PLANE = IH * IW * 16;              // bytes per input-tile plane
+    static constexpr int MID_PLANE = (MH * MW * 16 + 255) / 256 * 256;
+    static constexpr int IN_ELEMS = 4 * IH * IW;               // 16-byte elements per input tile
+    static constexpr int PF = (IN_ELEMS + NT - 1) / NT;        // DMA wave-instructions per wave (max)
+    static constexpr int TIN_BYTES = 4 * IN_PLANE;
+    static constexpr int LDS_BYTES = 4 * MID_PLANE + 2 * TIN_BYTES;
+    static_assert(TW % 16 == 0 && NW % GPR == 0, "rows must be whole MFMA groups, waves whole rows");
+    static_assert(TH % RSTEP == 0, "conv2 groups must divide evenly over the waves");
+    static_assert(K1 == K1_FULL + 1 && K1_FULL == K2, "wave plan below assumes K2 full conv1 slots + one partial slot");
+    static_assert(IN_PLANE % 256 == 0, "input planes must keep the two channel halves 256-B congruent");
+    static_assert(IN_ELEMS % 64 == 0, "DMA moves whole wave-instructions");
+    static_assert(STRIP_W0 + SG <= NW, "strip groups must fit on the waves with fewer row groups");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+struct H3Tile {
+    int y0, x0;
+    size_t img;      // byte offset of the image in the split-planar tensor
+};
+
+template <class Cfg>
+__device__ __forceinline__ H3Tile h3_tile(const FusedH3Args& a, int t)
+{
+    H3Tile r;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int b = t / a.tiles_y;
+    r.y0 = ty * Cfg::TH;
+    r.x0 = tx * Cfg::TW;
+    r.img = (size_t)b * a.H * a.W * 64;
+    return r;
+}
+
+template <class Cfg>
+__device__ __forceinline__ bool h3_interior(const FusedH3Args& a, const H3Tile& t)
+{
+    return t.y0 >= 2 && t.y0 + Cfg::TH + 2 <= a.H && t.x0 >= 2 && t.x0 + Cfg::TW + 2 <= a.W;
+}
+
+// workgroup barrier that publishes LDS writes but leaves vector-memory operations (the tile DMA) in flight
+__device__ __forceinline__ void h3_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ void h3_split(const f32x4 v, h4& hi, h4& lo)
+{
+    hi = __builtin_convertvector(v, h4);                         // round-to-nearest-even
+    const f32x4 back = __builtin_convertvector(hi, f32x4);
+    lo = __builtin_convertvector(v - back, h4);
+}
+
+// NG groups x 14 MFMAs.  va / vb / vc: per-group LDS byte address of the lane's 16-byte record of tap (0,0)
+// with the pair deltas of the upper lane half already added (va: +1 row, vb: +1 pixel, vc: none).
+template <int NG, int PITCH, int LO>
+__device__ __forceinline__ void h3_mma(const char* __restrict__ src, const int (&va)[NG], const int (&vb)[NG],
+                                       const int (&vc)[NG], const h8 (&w)[10], f32x4 (&acc)[NG])
+{
+#pragma unroll
+    for (int P = 0; P < 4; ++P) {
+        h8 bh[NG], bl[NG];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int ad = P < 3 ? va[j] + P * 16 : vb[j] + 2 * PITCH;
+            bh[j] = *reinterpret_cast<const h8*>(src + ad);
+            bl[j] = *reinterpret_cast<const h8*>(src + ad + LO);
+        }
+#pragma unroll
+        for (int j = 0; j < NG; ++j) acc[j] = MFMA_H(w[P], bh[j], acc[j]);          // w_hi x x_hi
+#pragma unroll
+        for (int j = 0; j < NG; ++j) acc[j] = MFMA_H(w[4 + P], bh[j], acc[j]);      // w_lo x x_hi
+#pragma unroll
+        for (int j = 0; j < NG; ++j) acc[j] = MFMA_H(w[P], bl[j], acc[j]);          // w_hi x x_lo
+    }
+    {
+        h8 bh[NG], bl[NG];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int ad = vc[j] + 2 * PITCH + 32;
+            bh[j] = *reinterpret_cast<const h8*>(src + ad);
+            bl[j] = *reinterpret_cast<const h8*>(src + ad + LO);
+        }
+#pragma unroll
+        for (int j = 0; j < NG; ++j) acc[j] = MFMA_H(w[8], bh[j], acc[j]);          // [w_hi | w_lo] x [x_hi | x_hi]
+#pragma unroll
+        for (int j = 0; j < NG; ++j) acc[j] = MFMA_H(w[9], bl[j], acc[j]);          // [w_hi | 0] x [x_lo | x_lo]
+    }
+}
+
+// per-lane constants (tile-invariant)
+struct H3Lane {
+    int r1;          // conv1 operand read: lane's record of (row wrow, column wcol + n) in the input tile (channel half q&1)
+    int s1;          // same for this wave's strip group
+    int w1;          // conv1 result write: (row wrow, column wcol + n) of the intermediate tile, plane q>>1, half q&1
+    int ws;          // same for the strip group
+    int r2;          // conv2 operand read in the intermediate tile
+    unsigned g;      // byte offset of the lane's 8-byte record of output (row wrow, column wcol + n) from the tile origin
+    int d_row_in, d_row_mid, d_px;   // upper-lane-half deltas: +1 row (input pitch / intermediate pitch), +1 pixel
+    int px;          // wcol + n
+    int srow, scol;  // strip group: intermediate row / column of this lane's pixel
+};
+
+// conv1 (+ activation) of NG groups -> intermediate tile (hi and lo planes)
+template <class Cfg, int NG, bool INTERIOR>
+__device__ __forceinline__ void h3_conv1(const FusedH3Args& a, const char* __restrict__ tin, char* __restrict__ tmid,
+                                         const h8 (&w)[10], const float inv_s, const int (&rd)[NG], const int (&wr)[NG],
+                                         const int (&my)[NG], const int (&mx)[NG], const H3Lane& L, const H3Tile& t)
+{
+    int va[NG], vb[NG];
+    f32x4 acc[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        va[j] = rd[j] + L.d_row_in;
+        vb[j] = rd[j] + L.d_px;
+        acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    h3_mma<NG, Cfg::IW * 16, 2 * Cfg::IN_PLANE>(tin, va, vb, rd, w, acc);
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        f32x4 v = acc[j] * inv_s;
+        if (a.act1_relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        if (!INTERIOR) {
+            // conv2 must see ZERO padding outside the image, not conv1 evaluated there
+            const int gy = t.y0 - 1 + my[j], gx = t.x0 - 1 + mx[j];
+            if (gy < 0 || gy >= a.H || gx < 0 || gx >= a.W) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        h4 hi, lo;
+        h3_split(v, hi, lo);
+        *reinterpret_cast<h4*>(tmid + wr[j]) = hi;
+        *reinterpret_cast<h4*>(tmid + wr[j] + 2 * Cfg::MID_PLANE) = lo;
+    }
+}
+
+// DMA of one input tile (2-pixel halo) into an LDS buffer.  Element e = tid + i*NT of the tile (plane-major,
+// then row, then column) comes from tile origin + pfoff[i]; out-of-image elements come from a zero line.
+template <class Cfg, bool INTERIOR>
+__device__ __forceinline__ void h3_dma(const FusedH3Args& a, const H3Tile& t, char* __restrict__ tin, const int tid,
+                                       const int wave, const unsigned (&pfoff)[Cfg::PF])
+{
+    const char* origin = reinterpret_cast<const char*>(a.in) + t.img + ((ptrdiff_t)(t.y0 - 2) * a.W + (t.x0 - 2)) * 16;
+#pragma unroll
+    for (int i = 0; i < Cfg::PF; ++i) {
+        if ((i + 1) * Cfg::NT <= Cfg::IN_ELEMS || (i * Cfg::NT + wave * 64) < Cfg::IN_ELEMS) {      // wave-uniform
+            const char* src = origin + pfoff[i];
+            if (!INTERIOR) {
+                const int e = tid + i * Cfg::NT;
+                const int r = e % (Cfg::IH * Cfg::IW);
+                const int row = r / Cfg::IW, col = r - row * Cfg::IW;
+                const int gy = t.y0 - 2 + row, gx = t.x0 - 2 + col;
+                if (gy < 0 || gy >= a.H || gx < 0 || gx >= a.W) src = reinterpret_cast<const char*>(a.zeros);
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(tin + (i * Cfg::NT + wave * 64) * 16),
+                                             16, 0, 0);
+        }
+    }
+}
+
+// number of DMA wave-instructions h3_dma issues on this wave
+template <class Cfg>
+__device__ __forceinline__ int h3_dma_count(const int wave)
+{
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < Cfg::PF; ++i)
+        if ((i + 1) * Cfg::NT <= Cfg::IN_ELEMS || (i * Cfg::NT + wave * 64) < Cfg::IN_ELEMS) ++n;
+    return n;
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3_kernel(FusedH3Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) char h3_lds[];
+    char* tmid = h3_lds;                                        // [4][MH][MW][8 f16] (+ pad per plane)
+    char* tin0 = h3_lds + 4 * Cfg::MID_PLANE;                   // [4][IH][IW][8 f16], two buffers
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int wrow = wave / Cfg::GPR, wcol = (wave % Cfg::GPR) * 16;
+    const unsigned plane_g = (unsigned)a.H * (unsigned)a.W * 16u;       // bytes per global plane
+
+    H3Lane L0;
+    L0.px = wcol + n;
+    const int sg = wave - Cfg::STRIP_W0;                        // this wave's strip group (valid if 0 <= sg < SG)
+    L0.srow = min(8 * max(sg, 0) + (n >> 1), Cfg::MH - 1);      // partial last group: clamp (duplicate work, same values)
+    L0.scol = Cfg::TW + (n & 1);
+    L0.r1 = (q & 1) * Cfg::IN_PLANE + (wrow * Cfg::IW + L0.px) * 16;
+    L0.s1 = (q & 1) * Cfg::IN_PLANE + (L0.srow * Cfg::IW + L0.scol) * 16;
+    L0.w1 = (q >> 1) * Cfg::MID_PLANE + (wrow * Cfg::MW + L0.px) * 16 + (q & 1) * 8;
+    L0.ws = (q >> 1) * Cfg::MID_PLANE + (L0.srow * Cfg::MW + L0.scol) * 16 + (q & 1) * 8;
+    L0.r2 = (q & 1) * Cfg::MID_PLANE + (wrow * Cfg::MW + L0.px) * 16;
+    L0.g = (unsigned)(q >> 1) * plane_g + (unsigned)(wrow * a.W + L0.px) * 16u + (unsigned)(q & 1) * 8u;
+    L0.d_row_in = (q >> 1) * Cfg::IW * 16;
+    L0.d_row_mid = (q >> 1) * Cfg::MW * 16;
+    L0.d_px = (q >> 1) * 16;
+
+    unsigned pfoff[Cfg::PF];
+#pragma unroll
+    for (int i = 0; i < Cfg::PF; ++i) {
+        const int e = tid + i * Cfg::NT;
+        const int pl = e / (Cfg::IH * Cfg::IW), r = e - pl * (Cfg::IH * Cfg::IW);
+        const int row = r / Cfg::IW, col = r - row * Cfg::IW;
+        pfoff[i] = (unsigned)pl * plane_g + (unsigned)(row * a.W + col) * 16u;
+    }
+    const int npf = h3_dma_count<Cfg>(wave);
+
+    h8 w1[10], w2[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        w1[i] = reinterpret_cast<const h8*>(a.w1)[i * 64 + lane];
+        w2[i] = reinterpret_cast<const h8*>(a.w2)[i * 64 + lane];
+    }
+    const float inv_s1 = a.aux[0];
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.aux + 16 + q * 4);     // folded BN scale / s2
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(a.aux + 32 + q * 4);
+
+    // XCD-aware persistent schedule (as fused_block_v4_kernel): label = blockIdx % 8 owns a contiguous chunk
+    const int nxcd = gridDim.x >= 8 ? 8 : 1;
+    const int label = blockIdx.x % nxcd, slot = blockIdx.x / nxcd;
+    const int per_label = gridDim.x / nxcd;
+    const int chunk = (a.ntiles + nxcd - 1) / nxcd;
+    const int t_begin = label * chunk;
+    const int t_end = min(a.ntiles, t_begin + chunk);
+    int t = t_begin + slot;
+    if (t >= t_end) return;
+
+    // prologue: tiles t and t + per_label into the two buffers
+    {
+        const H3Tile c0 = h3_tile<Cfg>(a, t);
+        h3_dma<Cfg, false>(a, c0, tin0, tid, wave, pfoff);
+        if (t + per_label < t_end) {
+            const H3Tile c1 = h3_tile<Cfg>(a, t + per_label);
+            h3_dma<Cfg, false>(a, c1, tin0 + Cfg::TIN_BYTES, tid, wave, pfoff);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        h3_barrier();
+    }
+
+    int buf = 0;
+    for (; t < t_end; t += per_label, buf ^= 1) {
+        const H3Tile cur = h3_tile<Cfg>(a, t);
+        const int t2 = t + 2 * per_label;
+        const bool has2 = t2 < t_end;
+        char* tin = tin0 + buf * Cfg::TIN_BYTES;
+        const bool interior = h3_interior<Cfg>(a, cur);
+        H3Lane L = L0;
+        // opaque inside the loop body: keeps LICM from hoisting every (constant + immediate) address
+        asm volatile("" : "+v"(L.r1), "+v"(L.s1), "+v"(L.w1), "+v"(L.ws), "+v"(L.r2), "+v"(L.g));
+
+        // ---- conv1: input tile -> intermediate tile --------------------------------------------------
+        // slots 0 .. K1_FULL-1 on every wave; slot K1_FULL on the waves with wrow < MH % RSTEP; strip group sg on
+        // waves STRIP_W0 .. STRIP_W0+SG-1.  Passes: {0,1}, then {2 .. K1_FULL-1 (+ the extra slot or the strip)}.
+        constexpr int RS_IN = Cfg::RSTEP * Cfg::IW * 16, RS_MID = Cfg::RSTEP * Cfg::MW * 16;
+        static_assert(Cfg::K1_FULL == 4, "pass plan below is written for 4 full slots");
+#define H3_CONV1(NGv, RD, WR, MY, MX)                                                                              \
+        do {                                                                                                       \
+            if (interior) h3_conv1<Cfg, NGv, true>(a, tin, tmid, w1, inv_s1, RD, WR, MY, MX, L, cur);               \
+            else h3_conv1<Cfg, NGv, false>(a, tin, tmid, w1, inv_s1, RD, WR, MY, MX, L, cur);                       \
+        } while (0)
+        {
+            const int rd[2] = {L.r1, L.r1 + RS_IN}, wr[2] = {L.w1, L.w1 + RS_MID};
+            const int my[2] = {wrow, wrow + Cfg::RSTEP}, mx[2] = {L.px, L.px};
+            H3_CONV1(2, rd, wr, my, mx);
+        }
+        if (wrow < Cfg::MH % Cfg::RSTEP) {                       // wave-uniform: 3 row groups
+            const int rd[3] = {L.r1 + 2 * RS_IN, L.r1 + 3 * RS_IN, L.r1 + 4 * RS_IN};
+            const int wr[3] = {L.w1 + 2 * RS_MID, L.w1 + 3 * RS_MID, L.w1 + 4 * RS_MID};
+            const int my[3] = {wrow + 2 * Cfg::RSTEP, wrow + 3 * Cfg::RSTEP, wrow + 4 * Cfg::RSTEP}, mx[3] = {L.px, L.px, L.px};
+            H3_CONV1(3, rd, wr, my, mx);
+        } else if (sg < Cfg::SG) {                               // 2 row groups + a strip group
+            const int rd[3] = {L.r1 + 2 * RS_IN, L.r1 + 3 * RS_IN, L.s1};
+            const int wr[3] = {L.w1 + 2 * RS_MID, L.w1 + 3 * RS_MID, L.ws};
+            const int my[3] = {wrow + 2 * Cfg::RSTEP, wrow + 3 * Cfg::RSTEP, L.srow}, mx[3] = {L.px, L.px, L.scol};
+            H3_CONV1(3, rd, wr, my, mx);
+        } else {
+            const int rd[2] = {L.r1 + 2 * RS_IN, L.r1 + 3 * RS_IN}, wr[2] = {L.w1 + 2 * RS_MID, L.w1 + 3 * RS_MID};
+            const int my[2] = {wrow + 2 * Cfg::RSTEP, wrow + 3 * Cfg::RSTEP}, mx[2] = {L.px, L.px};
+            H3_CONV1(2, rd, wr, my, mx);
+        }
+#undef H3_CONV1
+        h3_barrier();                                            // tmid complete; this tin buffer is dead
+
+        // ---- residual (re-read from global, L2 hits), THEN the DMA of tile t+2 -------------------------
+        static_assert(Cfg::K2 == 4, "conv2 pass below is written for 4 groups per wave");
+        const char* in_tile = reinterpret_cast<const char*>(a.in) + cur.img + ((size_t)cur.y0 * a.W + cur.x0) * 16;
+        char* out_tile = reinterpret_cast<char*>(a.out) + cur.img + ((size_t)cur.y0 * a.W + cur.x0) * 16;
+        const size_t rowstep = (size_t)a.W * 16 * Cfg::RSTEP;    // bytes between a wave's consecutive output rows
+        const size_t lo_g = 2 * (size_t)plane_g;
+        h4 res_hi[4], res_lo[4];
+        bool ok[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ok[j] = interior || (cur.y0 + wrow + j * Cfg::RSTEP < a.H && cur.x0 + L.px < a.W);
+            const char* p = in_tile + j * rowstep + L.g;
+            const char* pl = p + lo_g;
+            if (!interior && !ok[j]) { p = reinterpret_cast<const char*>(a.zeros); pl = p; }
+            res_hi[j] = *reinterpret_cast<const h4*>(p);
+            res_lo[j] = *reinterpret_cast<const h4*>(pl);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (has2) {
+            const H3Tile nx = h3_tile<Cfg>(a, t2);
+            if (h3_interior<Cfg>(a, nx)) h3_dma<Cfg, true>(a, nx, tin, tid, wave, pfoff);
+            else h3_dma<Cfg, false>(a, nx, tin, tid, wave, pfoff);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- conv2 + folded BN + residual -> global ---------------------------------------------------
+        {
+            int va[4], vb[4], vc[4];
+            f32x4 acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                vc[j] = L.r2 + j * RS_MID;
+                va[j] = vc[j] + L.d_row_mid;
+                vb[j] = vc[j] + L.d_px;
+                acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            h3_mma<4, Cfg::MW * 16, 2 * Cfg::MID_PLANE>(tmid, va, vb, vc, w2, acc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 res = __builtin_convertvector(res_hi[j], f32x4) + __builtin_convertvector(res_lo[j], f32x4);
+                const f32x4 v = acc[j] * sc + sh + res;
+                h4 hi, lo;
+                h3_split(v, hi, lo);
+                // out-of-image lanes store to a dump line so that every wave issues the same number of
+                // vector-memory operations per tile (the vmcnt below is exact)
+                char* p = out_tile + j * rowstep + L.g;
+                char* pl = p + lo_g;
+                if (!interior && !ok[j]) { p = reinterpret_cast<char*>(a.dump) + lane * 8; pl = p; }
+                *reinterpret_cast<h4*>(p) = hi;
+                *reinterpret_cast<h4*>(pl) = lo;
+            }
+        }
+        // Tile t+1's DMA (issued one tile ago) must have landed before the barrier publishes its buffer.
+        // Younger than it on this wave: this tile's 8 residual loads (consumed above), the DMA of tile t+2 and the 8
+        // stores above -> wait until at most (DMA of t+2) + 8 operations are outstanding.
+        if (!has2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (npf == Cfg::PF) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::PF + 8) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::PF - 1 + 8) : "memory");
+        h3_barrier();                                            // tmid free; next tile's input visible to all waves
+    }
+}
+
+using H3Default = H3Cfg<16, 32, 8>;
+
+hipError_t bf_launch_fused_block_h3(const FusedH3Args& args, hipStream_t s)
+{
+    using Cfg = H3Default;
+    FusedH3Args a = args;
+    if (!a.zeros || !a.dump) return hipErrorInvalidValue;
+    if ((int64_t)a.H * a.W * 64 >= ((int64_t)1 << 32)) return hipErrorInvalidValue;      // 32-bit in-image offsets
+    a.tiles_x = (a.W + Cfg::TW - 1) / Cfg::TW;
+    a.tiles_y = (a.H + Cfg::TH - 1) / Cfg::TH;
+    a.ntiles = a.B * a.tiles_x * a.tiles_y;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_block_h3_kernel<Cfg>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    int grid = a.ntiles < 256 ? a.ntiles : 256;                 // one persistent workgroup per CU
+    if (grid >= 8) grid -= grid % 8;
+    hipLaunchKernelGGL(fused_block_h3_kernel<Cfg>, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing for the kernel above.  One workgroup per (layer, conv): power-of-two scale from max |w|,
+// then the ten A-operand register images [i][lane][8 x f16]:
+//   i = 0..3  w_hi of tap pair i ; i = 4..7  w_lo of tap pair i-4 ; i = 8  [w_hi | w_lo] of tap (2,2) ;
+//   i = 9  [w_hi | 0] of tap (2,2).     lane l: output channel l & 15, k-slots 8*(l >> 4) .. +7
+//   (k-slot < 16: first tap of the pair, >= 16: second tap; input channel = k-slot & 15).
+// aux[0..15] = 1/s1, aux[16..31] = folded BN scale / s2, aux[32..47] = folded BN shift.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_h3_kernel(const float* __restrict__ params, const float* __restrict__ state,
+                                                      int64_t p_blocks, int64_t p_stride, float* __restrict__ dst,
+                                                      int64_t d_stride, int use_bn, float eps)
+{
+    __shared__ float red[256];
+    __shared__ float s_scale;
+    const int layer = blockIdx.x >> 1, which = blockIdx.x & 1;
+    const float* w = params + p_blocks + layer * p_stride + which * 2304;      // HWIO [3][3][16][16]
+    float m = 0.f;
+    for (int i = threadIdx.x; i < 2304; i += 256) m = fmaxf(m, fabsf(w[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float s = 1.f;
+        const float mx = red[0];
+        if (mx > 0.f && mx < 3.0e38f) {
+            int ex;
+            (void)frexpf(mx, &ex);                   // mx = f * 2^ex, f in [0.5, 1)
+            ex = max(-100, min(100, ex));
+            s = ldexpf(1.f, 14 - ex);                // mx * s in [2^13, 2^14)
+        }
+        s_scale = s;
+    }
+    __syncthreads();
+    const float s = s_scale;
+    _Float16* o = reinterpret_cast<_Float16*>(dst + layer * d_stride + which * BF_H3_WPACK_FLOATS);
+    const int tapA[4] = {0, 1, 2, 6}, tapB[4] = {3, 4, 5, 7};
+    for (int idx = threadIdx.x; idx < 10 * 64 * 8; idx += 256) {
+        const int i = idx >> 9, l = (idx >> 3) & 63, j = idx & 7;
+        const int cout = l & 15, kslot = 8 * (l >> 4) + j, half = kslot >> 4, cin = kslot & 15;
+        int tap, part;                                // part: 0 = hi, 1 = lo, 2 = zero
+        if (i < 4) { tap = half ? tapB[i] : tapA[i]; part = 0; }
+        else if (i < 8) { tap = half ? tapB[i - 4] : tapA[i - 4]; part = 1; }
+        else if (i == 8) { tap = 8; part = half; }
+        else { tap = 8; part = half ? 2 : 0; }
+        const float ws = w[(tap * 16 + cin) * 16 + cout] * s;
+        const _Float16 hi = (_Float16)ws;
+        const _Float16 lo = (_Float16)(ws - (float)hi);
+        o[idx] = part == 0 ? hi : (part == 1 ? lo : (_Float16)0.f);
+    }
+    float* aux = dst + layer * d_stride + 2 * BF_H3_WPACK_FLOATS;
+    if (threadIdx.x < 16) {
+        const int c = threadIdx.x;
+        if (which == 0) {
+            aux[c] = 1.0f / s;
+        } else {
+            float sc = 1.f, sh = 0.f;
+            if (use_bn) {     // keras BatchNormalization(training=False): gamma*(x-mean)*rsqrt(var+eps)
+                const float g = params[p_blocks + layer * p_stride + 4608 + c];
+                const float mean = state[layer * 32 + c], var = state[layer * 32 + 16 + c];
+                sc = g / sqrtf(var + eps);
+                sh = -sc * mean;
+            }
+            aux[16 + c] = sc * (1.0f / s);
+            aux[32 + c] = sh;
+        }
+    }
+}
+
+hipError_t bf_launch_pack_h3(const float* params, const float* state, int64_t p_blocks, int64_t p_stride, float* dst,
+                             int64_t d_stride, int layers, int use_bn, float eps, hipStream_t s)
+{
+    if (layers <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_h3_kernel, dim3(layers * 2), dim3(256), 0, s, params, state, p_blocks, p_stride, dst, d_stride,
+                       use_bn, eps);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// fp32 NHWC [B,H,W,16]  <->  split-planar [B][4][H][W][8 x f16]   (tests, debug entry points)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void h3_from_f32_kernel(const float* __restrict__ x, char* __restrict__ y, int64_t npix, int64_t hw)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix * 2; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = i >> 1;
+        const int half = (int)(i & 1);
+        const int64_t b = pix / hw, p = pix - b * hw;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + pix * 16 + half * 8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(x + pix * 16 + half * 8 + 4);
+        h4 h0, l0, h1, l1;
+        h3_split(v0, h0, l0);
+        h3_split(v1, h1, l1);
+        char* base = y + b * hw * 64 + p * 16;
+        h8 hi = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        h8 lo = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+        *reinterpret_cast<h8*>(base + (int64_t)half * hw * 16) = hi;
+        *reinterpret_cast<h8*>(base + (int64_t)(2 + half) * hw * 16) = lo;
+    }
+}
+
+__global__ __launch_bounds__(256) void h3_to_f32_kernel(const char* __restrict__ y, float* __restrict__ x, int64_t npix, int64_t hw)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix * 2; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = i >> 1;
+        const int half = (int)(i & 1);
+        const int64_t b = pix / hw, p = pix - b * hw;
+        const char* base = y + b * hw * 64 + p * 16;
+        const h8 hi = *reinterpret_cast<const h8*>(base + (int64_t)half * hw * 16);
+        const h8 lo = *reinterpret_cast<const h8*>(base + (int64_t)(2 + half) * hw * 16);
+        float* o = x + pix * 16 + half * 8;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = (float)hi[c] + (float)lo[c];
+    }
+}
+
+hipError_t bf_launch_h3_from_f32(const float* x, void* y, int B, int H, int W, hipStream_t s)
+{
+    const int64_t npix = (int64_t)B * H * W;
+    const int64_t g = (npix * 2 + 255) / 256;
+    hipLaunchKernelGGL(h3_from_f32_kernel, dim3((unsigned)(g < 16384 ? g : 16384)), dim3(256), 0, s, x, (char*)y, npix, (int64_t)H * W);
+    return hipGetLastError();
+}
+
+hipError_t bf_launch_h3_to_f32(const void* y, float* x, int B, int H, int W, hipStream_t s)
+{
+    const int64_t npix = (int64_t)B * H * W;
+    const int64_t g = (npix * 2 + 255) / 256;
+    hipLaunchKernelGGL(h3_to_f32_kernel, dim3((unsigned)(g < 16384 ? g : 16384)), dim3(256), 0, s, (const char*)y, x, npix, (int64_t)H * W);
+    return hipGetLastError();
+}
+
+// debug entry only: aux[16+c] *= scale[c], aux[32+c] = shift[c]
+__global__ void h3_affine_patch_kernel(float* aux, const float* scale, const float* shift)
+{
+    const int c = threadIdx.x;
+    if (c < 16) { aux[16 + c] *= scale[c]; aux[32 + c] = shift[c]; }
+}
+
+hipError_t bf_launch_affine_patch(float* aux, const float* scale, const float* shift, hipStream_t s)
+{
+    hipLaunchKernelGGL(h3_affine_patch_kernel, dim3(1), dim3(64), 0, s, aux, scale, shift);
+    return hipGetLastError();
+}

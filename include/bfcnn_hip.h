@@ -181,7 +181,11 @@ int bf_strided_slice2(const float* in, float* out, int batch, int height, int wi
 
 /* ---- options and diagnostics (not part of the drop-in surface; used by tests/) ------------- */
 
-/* "fused_blocks" = 1 (default): one kernel per residual block; 0: one kernel per convolution. */
+/* "fused_blocks" = 1 (default): one kernel per residual block; 0: one kernel per convolution.
+ * "arith" = 1 (default): fused inference blocks run split-f16 ("f16x3": x = hi + lo in f16, three products,
+ *   fp32 accumulation) on the f16 matrix cores, ~fp32 accuracy, needs |activation| < 65504;
+ *   0: exact fp32 on the f32 matrix cores.  Training and the unfused path are always exact fp32.
+ * "fused_tile": tile-geometry variant of the exact-fp32 fused block (A/B only; negative = default). */
 int bf_set_option(bf_handle h, const char* key, int value);
 
 /* with option "timing" = 1 every forward brackets its residual-block launches with two HIP events on
@@ -198,6 +202,11 @@ int bf_debug_conv3x3_grid(int batch, int height, int width);
 int bf_debug_fused_block(const float* in, const float* w1_hwio, const float* w2_hwio, const float* scale,
                          const float* shift, float* out, float* wpack_scratch,
                          int batch, int height, int width, int act1_relu, void* stream);
+/* the split-f16 fused block on fp32 NHWC tensors (converts in and out); scratch = the float count below */
+int64_t bf_debug_fused_block_h3_scratch_floats(int batch, int height, int width);
+int bf_debug_fused_block_h3(const float* in, const float* w1_hwio, const float* w2_hwio, const float* scale,
+                            const float* shift, float* out, float* scratch,
+                            int batch, int height, int width, int act1_relu, void* stream);
 int64_t bf_debug_wgrad_partial_floats(int batch, int height, int width);
 int bf_debug_wgrad3x3(const float* x, const float* dy, float* partial, float* dw,
                       int batch, int height, int width, void* stream);

@@ -61,6 +61,22 @@ def fused_block_gpu(x, w1, w2, scale, shift, act1_relu=1):
     return host(out)
 
 
+def fused_block_h3_gpu(x, w1, w2, scale, shift, act1_relu=1):
+    """the split-f16 fused block (fused_h3.hip) on fp32 NHWC tensors through bf_debug_fused_block_h3."""
+    L = N.lib()
+    B, H, W, _ = x.shape
+    xd = dev(x)
+    out = torch.full((B, H, W, 16), float("nan"), dtype=torch.float32, device="cuda")
+    # garbage-filled scratch: the kernel must not depend on pre-zeroed activations / dump lines
+    scratch = torch.full((int(L.bf_debug_fused_block_h3_scratch_floats(B, H, W)),), float("nan"), dtype=torch.float32,
+                         device="cuda")
+    w1d, w2d, sd, hd = dev(w1), dev(w2), dev(scale), dev(shift)
+    rc = L.bf_debug_fused_block_h3(N.ptr(xd), N.ptr(w1d), N.ptr(w2d), N.ptr(sd), N.ptr(hd), N.ptr(out), N.ptr(scratch),
+                                   B, H, W, act1_relu, N.stream_ptr(xd))
+    assert rc == 0, rc
+    return host(out)
+
+
 def wgrad_gpu(x, dy):
     L = N.lib()
     B, H, W, _ = x.shape

@@ -6,7 +6,7 @@ import torch
 
 from oracle import bfcnn_oracle as O
 from blind_image_denoising_amd import _native as N
-from helpers import assert_close, conv3x3_gpu, dev, fused_block_gpu, host, wgrad_gpu
+from helpers import assert_close, conv3x3_gpu, dev, fused_block_gpu, fused_block_h3_gpu, host, wgrad_gpu
 
 pytestmark = pytest.mark.gpu
 
@@ -93,7 +93,7 @@ def fused_tile(request):
     m = bf.model_builder(O.canonical_config(no_layers=0)["model"], device="cuda").hydra
     m.set_option("fused_tile", request.param)
     yield request.param
-    m.set_option("fused_tile", 0)
+    m.set_option("fused_tile", -1)        # back to the default variant
 
 
 @pytest.mark.parametrize("shape", SHAPES + [(1, 14, 32), (2, 28, 64), (1, 15, 33), (4, 70, 40)])
@@ -125,6 +125,65 @@ def test_fused_block_many_tiles_persistent_schedule(fused_tile):
     sub = slice(5, 7)
     t64 = np.maximum(O.conv2d_same(x[sub].astype(np.float64), w1.astype(np.float64)), 0)
     assert_close(got[sub], x[sub] + O.conv2d_same(t64, w2.astype(np.float64)), what="fused vs oracle (2 images)")
+
+
+# ---- split-f16 ("f16x3") fused block: same oracle, same bar as the exact-fp32 kernels ---------------------
+@pytest.mark.parametrize("shape", SHAPES + [(1, 16, 32), (2, 32, 64), (1, 17, 33), (4, 70, 40), (1, 2, 2), (3, 48, 100)])
+@pytest.mark.parametrize("relu", [1, 0])
+def test_fused_block_h3(shape, relu):
+    B, H, W = shape
+    x = _rand((B, H, W, 16), 15)
+    w1, w2 = _rand((3, 3, 16, 16), 16) * 0.1, _rand((3, 3, 16, 16), 17) * 0.1
+    sc, sh = _rand(16, 18), _rand(16, 19)
+    x64 = x.astype(np.float64)
+    t = O.conv2d_same(x64, w1.astype(np.float64))
+    if relu:
+        t = np.maximum(t, 0)
+    ref = x64 + O.conv2d_same(t, w2.astype(np.float64)) * sc + sh
+    assert_close(fused_block_h3_gpu(x, w1, w2, sc, sh, relu), ref, what=f"fused h3 {shape}")
+
+
+def test_fused_block_h3_is_exact_on_small_integers():
+    """integers that f16 holds exactly: every product and sum is exact, so the result must equal the oracle
+    bit for bit (pins the K packing / tap pairing / lane maps of the f16 MFMA path)."""
+    rng = np.random.default_rng(5)
+    x = rng.integers(-4, 5, (2, 24, 40, 16)).astype(np.float32)
+    w1 = rng.integers(-2, 3, (3, 3, 16, 16)).astype(np.float32)
+    w2 = rng.integers(-2, 3, (3, 3, 16, 16)).astype(np.float32)
+    sc, sh = np.ones(16, np.float32), rng.integers(-3, 4, 16).astype(np.float32)
+    t = np.maximum(O.conv2d_same(x.astype(np.float64), w1.astype(np.float64)), 0)
+    ref = x + O.conv2d_same(t, w2.astype(np.float64)) + sh
+    assert np.abs(t).max() < 2048 and np.abs(ref).max() < 2 ** 22        # exactly representable as hi + lo
+    assert np.array_equal(fused_block_h3_gpu(x, w1, w2, sc, sh, 1).astype(np.float64), ref)
+
+
+def test_fused_block_h3_wide_dynamic_range():
+    """weights of very different magnitudes (power-of-two pre-scale + lo part) and activations spanning
+    1e-3 .. 1e2: the split must hold ~22 bits relative to the largest term."""
+    rng = np.random.default_rng(6)
+    x = (rng.standard_normal((1, 40, 72, 16)) * np.exp(rng.uniform(-7, 4.5, (1, 40, 72, 16)))).astype(np.float32)
+    w1 = (rng.standard_normal((3, 3, 16, 16)) * np.exp(rng.uniform(-6, 0, (3, 3, 16, 16)))).astype(np.float32)
+    w2 = (rng.standard_normal((3, 3, 16, 16)) * 3e-3).astype(np.float32)
+    sc, sh = _rand(16, 18), _rand(16, 19)
+    t = np.maximum(O.conv2d_same(x.astype(np.float64), w1.astype(np.float64)), 0)
+    ref = x + O.conv2d_same(t, w2.astype(np.float64)) * sc + sh
+    assert_close(fused_block_h3_gpu(x, w1, w2, sc, sh, 1), ref, what="fused h3 wide range")
+
+
+def test_fused_block_h3_many_tiles_persistent_schedule():
+    """more tiles than persistent workgroups: the double-buffered DMA pipeline, the XCD chunking and every
+    chunk length (1, 2, 3+ tiles per workgroup) must cover each tile exactly once."""
+    for B, H, W in [(24, 128, 160), (3, 100, 70), (9, 64, 96)]:
+        x = _rand((B, H, W, 16), 20)
+        w1, w2 = _rand((3, 3, 16, 16), 21) * 0.1, _rand((3, 3, 16, 16), 22) * 0.1
+        sc, sh = np.ones(16, np.float32), np.zeros(16, np.float32)
+        got = fused_block_h3_gpu(x, w1, w2, sc, sh, 1)
+        t = conv3x3_gpu(x, w1, N.EPI_RELU)                  # exact-fp32 GPU path as the comparator at this size
+        ref = conv3x3_gpu(t, w2, N.EPI_RES, res=x)
+        assert_close(got, ref, rel=1e-5, what=f"h3 vs unfused {(B, H, W)}")
+    sub = slice(1, 2)
+    t64 = np.maximum(O.conv2d_same(x[sub].astype(np.float64), w1.astype(np.float64)), 0)
+    assert_close(got[sub], x[sub] + O.conv2d_same(t64, w2.astype(np.float64)), what="h3 vs oracle")
 
 
 @pytest.mark.parametrize("shape", SHAPES + [(8, 64, 64)])

@@ -1,0 +1,56 @@
+"""CPU emulation of the split-f16 ("f16x3") arithmetic of the fused block, to size its error against
+the fp64 oracle BEFORE building the kernel: every 3x3 16->16 conv becomes
+  conv(x_hi, w_hi) + conv(x_lo, w_hi) + conv(x_hi, w_lo)      (x = x_hi + x_lo, both f16; w pre-scaled by 2^k)
+accumulated in fp32, activations stored between blocks as (hi, lo) f16 pairs."""
+import sys, os
+import numpy as np
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+from oracle import bfcnn_oracle as O
+
+def split(x):
+    hi = x.to(torch.float16)
+    lo = (x - hi.to(torch.float32)).to(torch.float16)
+    return hi.to(torch.float32), lo.to(torch.float32)
+
+def conv(x, w):   # x NHWC f32 tensor, w HWIO
+    return torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), padding=w.shape[0] // 2).permute(0, 2, 3, 1)
+
+def conv3(xh, xl, w):
+    m = float(w.abs().max())
+    s = 2.0 ** np.floor(np.log2(32768.0 / m))          # power of two: max |w*s| in [16384, 32768)
+    wh, wl = split(w * s)
+    return (conv(xh, wh) + conv(xl, wh) + conv(xh, wl)) / s
+
+def run(no_layers=18, size=128, mode="f16x3", seed=1234):
+    cfg = O.canonical_config(no_layers=no_layers)
+    spec = O.ResnetSpec.from_config(cfg["model"])
+    params, state = O.init_params(spec, seed=42, nontrivial_bn=True)
+    _, noisy = O.synthetic_batch(1, size, size, sigma=20.0, seed=seed)
+    ref = O.denoiser_module_call(spec, params, state, noisy, cast_to_uint8=False)
+    P = O._views(spec, params, np.float32); S = O._state_views(spec, state, np.float32)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    x = T(noisy.astype(np.float32)) / 255.0 - 0.5
+    f = conv(x, T(P["base/kernel"]))
+    for i in range(no_layers):
+        w1, w2 = T(P[f"block{i}/conv0/kernel"]), T(P[f"block{i}/conv1/kernel"])
+        g, mu, var = (T(P[f"block{i}/bn1/gamma"]), T(S[f"block{i}/bn1/moving_mean"]), T(S[f"block{i}/bn1/moving_variance"]))
+        a = g / torch.sqrt(var + 1e-3); sh = -a * mu
+        if mode == "f32":
+            t = torch.relu(conv(f, w1)); f = f + conv(t, w2) * a + sh
+        else:
+            fh, fl = split(f)
+            f22 = fh + fl                                  # what the split storage carries
+            t = torch.relu(conv3(fh, fl, w1))
+            th, tl = split(t)
+            f = f22 + conv3(th, tl, w2) * a + sh
+    h = conv(conv(f, T(P["head/conv0/kernel"])), T(P["head/conv1/kernel"]))
+    y = (torch.clamp(torch.tanh(2 * h) * 0.51, -0.5, 0.5) + 0.5) * 255.0
+    y = y.numpy().astype(np.float64)
+    d = np.abs(y - ref)
+    u = np.abs(np.clip(np.rint(y), 0, 255) - np.clip(np.rint(ref), 0, 255))
+    print(f"{mode:6s} layers={no_layers} size={size}: MAE(normalised)={d.mean()/255:.3e} max={d.max()/255:.3e}  u8 diff: mean={u.mean():.2e} max={u.max():.0f}  max|act|={float(f.abs().max()):.2f}")
+
+if __name__ == "__main__":
+    for mode in ("f32", "f16x3"):
+        run(18, 128, mode)
