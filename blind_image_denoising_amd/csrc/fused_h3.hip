@@ -25,11 +25,11 @@
 // as one 8-byte hi and one 8-byte lo write, and tiles move HBM -> LDS by DMA without a conversion pass.
 //
 // Schedule.  One 8-wave workgroup per CU (2 waves per SIMD), persistent, XCD-contiguous tile chunks.  The
-// input tile is DOUBLE buffered: tile t+2 is requested right after the conv1 -> conv2 barrier of tile t
-// (into the buffer conv1 just finished with) and has a whole tile time to land.  The residual is re-read
-// from global (L2 hits) BEFORE the DMA is issued, because vmcnt retires in issue order: a residual issued
-// behind the DMA would drag the DMA's latency into the conv2 epilogue.  Barriers are bare s_barrier with
-// lgkmcnt(0) only (hipcc puts vmcnt(0) in front of every __syncthreads, which would drain the DMA).
+// input tile is DOUBLE buffered: tile t+1 is requested at the top of tile t and has the whole tile to land;
+// the residual comes from the LDS input tile (its centre), so the loop holds no vector-memory operation
+// except the DMA and the 8 result stores per wave, and the one explicit vmcnt(8) per tile is exact.
+// Barriers are bare s_barrier with lgkmcnt(0) only (hipcc puts vmcnt(0) in front of every __syncthreads it
+// can see, which would drain the DMA).
 #include "bf_common.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -53,7 +53,7 @@ struct H3Cfg {
     static constexpr int MID_PLANE = (MH * MW * 16 + 255) / 256 * 256;
     static constexpr int IN_ELEMS = 4 * IH * IW;               // 16-byte elements per input tile
     static constexpr int PF = (IN_ELEMS + NT - 1) / NT;        // DMA wave-instructions per wave (max)
-    static constexpr int TIN_BYTES = 4 * IN_PLANE;
+    static constexpr int TIN_BYTES = PF * NT * 16;             // 4 planes + pad to PF whole workgroup-instructions
     static constexpr int LDS_BYTES = 4 * MID_PLANE + 2 * TIN_BYTES;
     static_assert(TW % 16 == 0 && NW % GPR == 0, "rows must be whole MFMA groups, waves whole rows");
     static_assert(TH % RSTEP == 0, "conv2 groups must divide evenly over the waves");
@@ -89,10 +89,20 @@ __device__ __forceinline__ bool h3_interior(const FusedH3Args& a, const H3Tile& 
     return t.y0 >= 2 && t.y0 + Cfg::TH + 2 <= a.H && t.x0 >= 2 && t.x0 + Cfg::TW + 2 <= a.W;
 }
 
+// s_waitcnt immediates (gfx9 encoding: vmcnt [3:0] + [15:14], expcnt [6:4], lgkmcnt [11:8]).  The waits go through
+// the builtin, not inline asm, so that hipcc's own waitcnt bookkeeping sees them: with an asm wait in the prologue
+// it believed the weight / scale loads issued before the tile loop were still pending at the loop header and put a
+// vmcnt(0) in front of the first MFMA of conv1 AND conv2 of every tile -- which drained the tile DMA right after
+// it had been issued (385 us per launch instead of the numbers in DESIGN.md).
+constexpr int h3_vmcnt(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
+constexpr int H3_LGKMCNT0 = 0xC07F;
+
 // workgroup barrier that publishes LDS writes but leaves vector-memory operations (the tile DMA) in flight
+// (s_barrier stays inline asm: hipcc puts "s_waitcnt vmcnt(0) lgkmcnt(0)" in front of every barrier it can see)
 __device__ __forceinline__ void h3_barrier()
 {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(H3_LGKMCNT0);
+    asm volatile("s_barrier" ::: "memory");
 }
 
 __device__ __forceinline__ void h3_split(const f32x4 v, h4& hi, h4& lo)
@@ -146,6 +156,7 @@ struct H3Lane {
     int w1;          // conv1 result write: (row wrow, column wcol + n) of the intermediate tile, plane q>>1, half q&1
     int ws;          // same for the strip group
     int r2;          // conv2 operand read in the intermediate tile
+    int rr;          // residual read: lane's 8-byte record of output (row wrow, column wcol + n) in the INPUT tile
     unsigned g;      // byte offset of the lane's 8-byte record of output (row wrow, column wcol + n) from the tile origin
     int d_row_in, d_row_mid, d_px;   // upper-lane-half deltas: +1 row (input pitch / intermediate pitch), +1 pixel
     int px;          // wcol + n
@@ -187,38 +198,32 @@ __device__ __forceinline__ void h3_conv1(const FusedH3Args& a, const char* __res
 
 // DMA of one input tile (2-pixel halo) into an LDS buffer.  Element e = tid + i*NT of the tile (plane-major,
 // then row, then column) comes from tile origin + pfoff[i]; out-of-image elements come from a zero line.
+// EVERY wave issues exactly PF wave-instructions per call, whatever the tile (elements past the tile's end
+// and the whole tile when !live are zero-line reads into the buffer's pad), so that the number of operations
+// younger than a tile's DMA is a compile-time constant for the vmcnt at the end of the tile.
 template <class Cfg, bool INTERIOR>
 __device__ __forceinline__ void h3_dma(const FusedH3Args& a, const H3Tile& t, char* __restrict__ tin, const int tid,
-                                       const int wave, const unsigned (&pfoff)[Cfg::PF])
+                                       const int wave, const unsigned (&pfoff)[Cfg::PF], const bool live)
 {
     const char* origin = reinterpret_cast<const char*>(a.in) + t.img + ((ptrdiff_t)(t.y0 - 2) * a.W + (t.x0 - 2)) * 16;
+    const char* zeros = reinterpret_cast<const char*>(a.zeros);
 #pragma unroll
     for (int i = 0; i < Cfg::PF; ++i) {
-        if ((i + 1) * Cfg::NT <= Cfg::IN_ELEMS || (i * Cfg::NT + wave * 64) < Cfg::IN_ELEMS) {      // wave-uniform
-            const char* src = origin + pfoff[i];
-            if (!INTERIOR) {
-                const int e = tid + i * Cfg::NT;
-                const int r = e % (Cfg::IH * Cfg::IW);
-                const int row = r / Cfg::IW, col = r - row * Cfg::IW;
-                const int gy = t.y0 - 2 + row, gx = t.x0 - 2 + col;
-                if (gy < 0 || gy >= a.H || gx < 0 || gx >= a.W) src = reinterpret_cast<const char*>(a.zeros);
-            }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(tin + (i * Cfg::NT + wave * 64) * 16),
-                                             16, 0, 0);
+        const char* src = origin + pfoff[i];
+        bool use = live;
+        if ((i + 1) * Cfg::NT > Cfg::IN_ELEMS) use = use && (i * Cfg::NT + wave * 64) < Cfg::IN_ELEMS;     // wave-uniform
+        if (!INTERIOR) {
+            const int e = tid + i * Cfg::NT;
+            const int r = e % (Cfg::IH * Cfg::IW);
+            const int row = r / Cfg::IW, col = r - row * Cfg::IW;
+            const int gy = t.y0 - 2 + row, gx = t.x0 - 2 + col;
+            use = use && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         }
+        if (!use) src = zeros;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(tin + (i * Cfg::NT + wave * 64) * 16),
+                                         16, 0, 0);
     }
-}
-
-// number of DMA wave-instructions h3_dma issues on this wave
-template <class Cfg>
-__device__ __forceinline__ int h3_dma_count(const int wave)
-{
-    int n = 0;
-#pragma unroll
-    for (int i = 0; i < Cfg::PF; ++i)
-        if ((i + 1) * Cfg::NT <= Cfg::IN_ELEMS || (i * Cfg::NT + wave * 64) < Cfg::IN_ELEMS) ++n;
-    return n;
 }
 
 template <class Cfg>
@@ -243,6 +248,7 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3_kernel(FusedH3Args 
     L0.w1 = (q >> 1) * Cfg::MID_PLANE + (wrow * Cfg::MW + L0.px) * 16 + (q & 1) * 8;
     L0.ws = (q >> 1) * Cfg::MID_PLANE + (L0.srow * Cfg::MW + L0.scol) * 16 + (q & 1) * 8;
     L0.r2 = (q & 1) * Cfg::MID_PLANE + (wrow * Cfg::MW + L0.px) * 16;
+    L0.rr = (q >> 1) * Cfg::IN_PLANE + ((wrow + 2) * Cfg::IW + L0.px + 2) * 16 + (q & 1) * 8;
     L0.g = (unsigned)(q >> 1) * plane_g + (unsigned)(wrow * a.W + L0.px) * 16u + (unsigned)(q & 1) * 8u;
     L0.d_row_in = (q >> 1) * Cfg::IW * 16;
     L0.d_row_mid = (q >> 1) * Cfg::MW * 16;
@@ -256,7 +262,6 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3_kernel(FusedH3Args 
         const int row = r / Cfg::IW, col = r - row * Cfg::IW;
         pfoff[i] = (unsigned)pl * plane_g + (unsigned)(row * a.W + col) * 16u;
     }
-    const int npf = h3_dma_count<Cfg>(wave);
 
     h8 w1[10], w2[10];
 #pragma unroll
@@ -278,28 +283,33 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3_kernel(FusedH3Args 
     int t = t_begin + slot;
     if (t >= t_end) return;
 
-    // prologue: tiles t and t + per_label into the two buffers
+    // prologue: the first tile
     {
         const H3Tile c0 = h3_tile<Cfg>(a, t);
-        h3_dma<Cfg, false>(a, c0, tin0, tid, wave, pfoff);
-        if (t + per_label < t_end) {
-            const H3Tile c1 = h3_tile<Cfg>(a, t + per_label);
-            h3_dma<Cfg, false>(a, c1, tin0 + Cfg::TIN_BYTES, tid, wave, pfoff);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        h3_dma<Cfg, false>(a, c0, tin0, tid, wave, pfoff, true);
+        __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));               // also retires the weight / scale loads above
         h3_barrier();
     }
 
     int buf = 0;
     for (; t < t_end; t += per_label, buf ^= 1) {
         const H3Tile cur = h3_tile<Cfg>(a, t);
-        const int t2 = t + 2 * per_label;
-        const bool has2 = t2 < t_end;
+        const int t1 = t + per_label;
+        const bool has1 = t1 < t_end;
         char* tin = tin0 + buf * Cfg::TIN_BYTES;
         const bool interior = h3_interior<Cfg>(a, cur);
         H3Lane L = L0;
         // opaque inside the loop body: keeps LICM from hoisting every (constant + immediate) address
-        asm volatile("" : "+v"(L.r1), "+v"(L.s1), "+v"(L.w1), "+v"(L.ws), "+v"(L.r2), "+v"(L.g));
+        asm volatile("" : "+v"(L.r1), "+v"(L.s1), "+v"(L.w1), "+v"(L.ws), "+v"(L.r2), "+v"(L.rr), "+v"(L.g));
+
+        // ---- next tile: global -> the other LDS buffer, in flight for this whole tile --------------------
+        // (that buffer was last read by the previous tile's conv2 residual, one barrier ago)
+        {
+            const H3Tile nx = h3_tile<Cfg>(a, has1 ? t1 : t);  // !has1: PF zero-line reads into the dead buffer
+            char* tnx = tin0 + (buf ^ 1) * Cfg::TIN_BYTES;
+            if (h3_interior<Cfg>(a, nx)) h3_dma<Cfg, true>(a, nx, tnx, tid, wave, pfoff, has1);
+            else h3_dma<Cfg, false>(a, nx, tnx, tid, wave, pfoff, has1);
+        }
 
         // ---- conv1: input tile -> intermediate tile --------------------------------------------------
         // slots 0 .. K1_FULL-1 on every wave; slot K1_FULL on the waves with wrow < MH % RSTEP; strip group sg on
@@ -332,35 +342,14 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3_kernel(FusedH3Args 
             H3_CONV1(2, rd, wr, my, mx);
         }
 #undef H3_CONV1
-        h3_barrier();                                            // tmid complete; this tin buffer is dead
+        h3_barrier();                                            // tmid complete
 
-        // ---- residual (re-read from global, L2 hits), THEN the DMA of tile t+2 -------------------------
+        // ---- conv2 + folded BN + residual (from the LDS input tile) -> global ---------------------------
         static_assert(Cfg::K2 == 4, "conv2 pass below is written for 4 groups per wave");
-        const char* in_tile = reinterpret_cast<const char*>(a.in) + cur.img + ((size_t)cur.y0 * a.W + cur.x0) * 16;
-        char* out_tile = reinterpret_cast<char*>(a.out) + cur.img + ((size_t)cur.y0 * a.W + cur.x0) * 16;
-        const size_t rowstep = (size_t)a.W * 16 * Cfg::RSTEP;    // bytes between a wave's consecutive output rows
-        const size_t lo_g = 2 * (size_t)plane_g;
-        h4 res_hi[4], res_lo[4];
-        bool ok[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            ok[j] = interior || (cur.y0 + wrow + j * Cfg::RSTEP < a.H && cur.x0 + L.px < a.W);
-            const char* p = in_tile + j * rowstep + L.g;
-            const char* pl = p + lo_g;
-            if (!interior && !ok[j]) { p = reinterpret_cast<const char*>(a.zeros); pl = p; }
-            res_hi[j] = *reinterpret_cast<const h4*>(p);
-            res_lo[j] = *reinterpret_cast<const h4*>(pl);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (has2) {
-            const H3Tile nx = h3_tile<Cfg>(a, t2);
-            if (h3_interior<Cfg>(a, nx)) h3_dma<Cfg, true>(a, nx, tin, tid, wave, pfoff);
-            else h3_dma<Cfg, false>(a, nx, tin, tid, wave, pfoff);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-
-        // ---- conv2 + folded BN + residual -> global ---------------------------------------------------
         {
+            char* out_tile = reinterpret_cast<char*>(a.out) + cur.img + ((size_t)cur.y0 * a.W + cur.x0) * 16;
+            const size_t rowstep = (size_t)a.W * 16 * Cfg::RSTEP;    // bytes between a wave's consecutive output rows
+            const size_t lo_g = 2 * (size_t)plane_g;
             int va[4], vb[4], vc[4];
             f32x4 acc[4];
 #pragma unroll
@@ -373,7 +362,9 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3_kernel(FusedH3Args 
             h3_mma<4, Cfg::MW * 16, 2 * Cfg::MID_PLANE>(tmid, va, vb, vc, w2, acc);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const f32x4 res = __builtin_convertvector(res_hi[j], f32x4) + __builtin_convertvector(res_lo[j], f32x4);
+                const h4 rh = *reinterpret_cast<const h4*>(tin + L.rr + j * RS_IN);
+                const h4 rl = *reinterpret_cast<const h4*>(tin + L.rr + j * RS_IN + 2 * Cfg::IN_PLANE);
+                const f32x4 res = __builtin_convertvector(rh, f32x4) + __builtin_convertvector(rl, f32x4);
                 const f32x4 v = acc[j] * sc + sh + res;
                 h4 hi, lo;
                 h3_split(v, hi, lo);
@@ -381,17 +372,19 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3_kernel(FusedH3Args 
                 // vector-memory operations per tile (the vmcnt below is exact)
                 char* p = out_tile + j * rowstep + L.g;
                 char* pl = p + lo_g;
-                if (!interior && !ok[j]) { p = reinterpret_cast<char*>(a.dump) + lane * 8; pl = p; }
+                if (!interior && !(cur.y0 + wrow + j * Cfg::RSTEP < a.H && cur.x0 + L.px < a.W)) {
+                    p = reinterpret_cast<char*>(a.dump) + lane * 8;
+                    pl = p;
+                }
                 *reinterpret_cast<h4*>(p) = hi;
                 *reinterpret_cast<h4*>(pl) = lo;
             }
         }
-        // Tile t+1's DMA (issued one tile ago) must have landed before the barrier publishes its buffer.
-        // Younger than it on this wave: this tile's 8 residual loads (consumed above), the DMA of tile t+2 and the 8
-        // stores above -> wait until at most (DMA of t+2) + 8 operations are outstanding.
-        if (!has2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (npf == Cfg::PF) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::PF + 8) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::PF - 1 + 8) : "memory");
+        // The next tile's DMA (issued at the top) must have landed before the barrier publishes its buffer.  Younger
+        // than it on this wave: exactly the 8 stores above.  No other vector-memory operation exists in the loop --
+        // in particular no ordinary global LOAD: hipcc waits vmcnt(0) for any load that is pending together with
+        // LDS-DMA (measured: tools/exp/dma_waitcnt.hip), which would drain the DMA in the conv2 epilogue.
+        __builtin_amdgcn_s_waitcnt(h3_vmcnt(8));
         h3_barrier();                                            // tmid free; next tile's input visible to all waves
     }
 }
