@@ -12,10 +12,14 @@ non-trivial BN statistics, smooth-field + gaussian-noise uint8 images (SURVEY.md
 sharded by replication across ranks (weak scaling: independent images, no data-path collective).
 
 The JSON line also carries
-  roofline     : dominant kernel = fused_block_kernel (one launch per residual block); achieved =
-                 algorithmic FLOPs per launch (B*H*W * 2 convs * 4608 FLOP/px) / its average launch
-                 duration measured with HIP events on the launch stream over the timed region;
-                 peak = dense fp32 MFMA peak of MI355X_MICROARCH.md (157.3 TFLOP/s).
+  roofline     : dominant kernel = the fused residual block (one launch per block), its average launch
+                 duration measured with HIP events on the launch stream over the timed region.
+                 Default arithmetic (split-f16 on the f16 matrix cores, fused_block_h3r_kernel): the
+                 kernel's nearer roof is HBM -- bound "hbm", achieved = algorithmic bytes per launch
+                 (B*H*W * 128 B/px: read x, write y, fp32-equivalent storage) / launch duration, peak
+                 8 TB/s; the matrix-pipe view of the same launch is reported beside it ("mfma").
+                 --arith 0 (exact fp32 on the f32 matrix cores, fused_block_v4_kernel): bound "mfma",
+                 achieved = B*H*W * 9216 FLOP/px / duration against the 157.3 TFLOP/s fp32 MFMA peak.
   cpu_baseline : the oracle's C port (oracle/bfcnn_port.c, fp32, OpenMP, all host cores) timed on
                  a bounded sample of the same workload, rank 0 / N=1 only.
 """
@@ -32,6 +36,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+MFMA_F16_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md, BF16/F16 dense
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md, HBM3E
+BYTES_PER_PX_BLOCK = 128            # read x + write y, 16 channels x 4 B (fp32 NHWC or split-f16 hi/lo planes)
+H3_MFMA_FLOP_PER_PX = 2 * 15 * 16384 / 16 + 16384 / 16   # issued f16 MFMA FLOPs: 15 (+1 residual) MFMAs of 16x16x32 per 16 px and conv
 FLOP_PER_PX_BLOCK = 2 * 4608        # two 3x3 16->16 convolutions
 
 
@@ -57,14 +65,15 @@ def cpu_baseline(spec, params, state, noisy_u8, budget_s=12.0):
                       f"(CPU restatement, not TensorFlow)"}
 
 
-def pmc_traffic(layers, batch, size, fused):
+def pmc_traffic(layers, batch, size, fused, kernel=None):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass of THIS
     workload (profiles/pmc_traffic.json: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
     coalesced reads on gfx950, plus WRITE_SIZE); None when no matching profile is committed."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             for e in json.load(f):
-                if (e["layers"], e["batch"], e["size"], e["fused"]) == (layers, batch, size, fused):
+                if (e["layers"], e["batch"], e["size"], e["fused"]) == (layers, batch, size, fused) and \
+                        (kernel is None or e.get("kernel") == kernel):
                     return e["hbm_bytes_per_launch"]
     except Exception:
         pass
@@ -81,7 +90,9 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="one kernel per convolution (A/B only)")
-    ap.add_argument("--fused-tile", type=int, default=None, help="fused-block tile geometry variant (A/B only)")
+    ap.add_argument("--fused-tile", type=int, default=None, help="exact-fp32 fused-block tile geometry variant (A/B only)")
+    ap.add_argument("--arith", type=int, default=1, help="1 = split-f16 fused blocks (default), 0 = exact-fp32 fused blocks")
+    ap.add_argument("--h3-variant", type=int, default=None, help="split-f16 kernel variant (A/B only)")
     args = ap.parse_args()
 
     import torch
@@ -113,6 +124,10 @@ def main():
         model.set_option("fused_blocks", 0)
     if args.fused_tile is not None:
         model.set_option("fused_tile", args.fused_tile)
+    if args.h3_variant is not None:
+        model.set_option("h3_variant", args.h3_variant)
+    model.set_option("arith", args.arith)
+    h3 = bool(args.arith) and not args.unfused
     model.set_option("timing", 1)
     module = bf.DenoiserModule(model)
 
@@ -156,26 +171,42 @@ def main():
         images = B * world * args.steps
         value = images / elapsed
         per_launch_flop = B * S * S * FLOP_PER_PX_BLOCK * (1 if not args.unfused else 0.5)
+        per_launch_bytes = B * S * S * BYTES_PER_PX_BLOCK
         avg_launch_s = block_ms / 1e3 / max(launches, 1)
         achieved = per_launch_flop / avg_launch_s / 1e12
+        if h3:
+            kernel = "fused_block_h3r_kernel" if args.h3_variant in (None, 1) else "fused_block_h3_kernel"
+            gbs = per_launch_bytes / avg_launch_s / 1e9
+            roofline = {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(args.layers, B, S, True, kernel),
+                        "algorithmic_bytes_per_launch": per_launch_bytes,
+                        "launch_us": avg_launch_s * 1e6, "launches_per_step": launches,
+                        "mfma": {"dtype": "f16 (split hi/lo, 3 products)", "algorithmic_tflops": achieved,
+                                 "issued_tflops": B * S * S * H3_MFMA_FLOP_PER_PX / avg_launch_s / 1e12,
+                                 "peak_tflops": MFMA_F16_PEAK_TFLOPS,
+                                 "issued_frac": B * S * S * H3_MFMA_FLOP_PER_PX / avg_launch_s / 1e12 / MFMA_F16_PEAK_TFLOPS}}
+        else:
+            kernel = "fused_block_v4_kernel" if not args.unfused else "conv3x3_c16_kernel"
+            roofline = {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+                        "traffic": pmc_traffic(args.layers, B, S, not args.unfused, kernel),
+                        "algorithmic_bytes_per_launch": per_launch_bytes,
+                        "launch_us": avg_launch_s * 1e6, "launches_per_step": launches,
+                        "algorithmic_gflop_per_launch": per_launch_flop / 1e9}
         result = {
             "metric": "denoised images/sec (256x256x3) + MAE vs ref, resnet_1x18",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16x2 split (hi+lo, fp32 accumulate)" if h3 else "f32", "data": "synthetic",
             "config": {"workload": f"resnet_color_1x{args.layers}_bn_16x3x3 inference, batch={B}/GPU {S}x{S}x3 uint8->uint8 "
                                    f"(DenoiserModule.__call__ via bf_forward_u8)",
                        "batch_per_gpu": B, "global_batch": B * world, "height": S, "width": S,
-                       "blocks": args.layers, "fused_blocks": not args.unfused, "parallelism": f"replicas x{world}, no collective"},
+                       "blocks": args.layers, "fused_blocks": not args.unfused,
+                       "arithmetic": "split-f16 MFMA (f16x3), fp32 accumulate" if h3 else "exact fp32 MFMA",
+                       "parallelism": f"replicas x{world}, no collective"},
             "parity": {"mae_vs_oracle_lsb": float(diff.mean()), "max_abs_lsb": int(diff.max()), "checked_images": 1},
             "end_to_end_tflops": value / world * gflop_per_image(args.layers, S, S) / 1e3,
-            "roofline": {"bound": "mfma", "kernel": "fused_block_kernel" if not args.unfused else "conv3x3_c16_kernel",
-                         "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-                         "traffic": pmc_traffic(args.layers, B, S, not args.unfused),
-                         "algorithmic_bytes_per_launch": B * S * S * 128,
-                         "launch_us": avg_launch_s * 1e6, "launches_per_step": launches,
-                         "algorithmic_gflop_per_launch": per_launch_flop / 1e9},
+            "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(spec, params, state, noisy_host)

@@ -44,25 +44,31 @@ struct FusedBlockArgs {
 // split-f16 ("f16x3") fused block on the f16 matrix cores (fused_h3.hip).  Activations are "split-planar":
 // per image 4 planes [H][W][8 x f16] = hi(c0..7), hi(c8..15), lo(c0..7), lo(c8..15), value = hi + lo.
 #define BF_H3_WPACK_FLOATS (10 * 64 * 4)                      // ten A-operand register images of 16 B per lane
-#define BF_H3_BLOCK_FLOATS (2 * BF_H3_WPACK_FLOATS + 64)      // w1, w2, aux (1/s1 | scale/s2 | shift | pad)
+#define BF_H3R_WPACK_FLOATS (13 * 64 * 4)                     // row-streaming kernel: 12 A-operand images + s2 * identity
+// per block: w1, w2 (group kernel), aux (1/s1 | scale/s2 | shift | pad), w1r, w2r (row-streaming kernel)
+#define BF_H3_BLOCK_FLOATS (2 * BF_H3_WPACK_FLOATS + 64 + 2 * BF_H3R_WPACK_FLOATS)
 struct FusedH3Args {
     const void* in;       // split-planar block input x
     void* out;            // split-planar x + scale*conv2(act(conv1 x)) + shift
     const void* w1;       // [10][64] x 16 B
     const void* w2;
-    const float* aux;     // [0..15] 1/s1, [16..31] scale/s2, [32..47] shift
+    const void* w1r;      // [13][64] x 16 B (row-streaming kernel)
+    const void* w2r;
+    const float* aux;     // [0..15] 1/s1, [16..31] scale/s2 (group kernel), [32..47] shift, [48..63] 1/s2r (row kernel)
     int B, H, W;
     int tiles_x, tiles_y, ntiles;
     int act1_relu;
     const void* zeros;    // >= 64 B of zeros, 16-B aligned (source of out-of-image elements)
     void* dump;           // >= 512 B writable scratch (sink of out-of-image stores)
+    unsigned long long* dbg;  // diagnostic builds only (per-wave phase cycle sums), else NULL
 };
 hipError_t bf_launch_fused_block_h3(const FusedH3Args& a, hipStream_t s);
+void       bf_set_h3_variant(int v);   // 1 (default) row-streaming kernel, 0 group-per-pass kernel (A/B only)
 hipError_t bf_launch_pack_h3(const float* params, const float* state, int64_t p_blocks, int64_t p_stride, float* dst,
-                             int64_t d_stride, int layers, int use_bn, float eps, hipStream_t s);
+                             int64_t d_stride, int layers, int use_bn, float eps, const float* ext_scale,
+                             const float* ext_shift, hipStream_t s);
 hipError_t bf_launch_h3_from_f32(const float* x, void* y, int B, int H, int W, hipStream_t s);
 hipError_t bf_launch_h3_to_f32(const void* y, float* x, int B, int H, int W, hipStream_t s);
-hipError_t bf_launch_affine_patch(float* aux, const float* scale, const float* shift, hipStream_t s);
 
 // ---- launchers (each returns hipGetLastError()) -------------------------------------------
 hipError_t bf_launch_conv3x3_c16(const ConvArgs& a, int epi, hipStream_t s);

@@ -173,6 +173,7 @@ extern "C" int bf_set_option(bf_handle h, const char* key, int value)
     if (!h || !key) return BF_EINVAL;
     if (!strcmp(key, "fused_blocks")) { h->fused_blocks = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "fused_tile")) { bf_set_fused_tile(value); return BF_OK; }
+    if (!strcmp(key, "h3_variant")) { bf_set_h3_variant(value); return BF_OK; }
     if (!strcmp(key, "arith")) { h->arith = value < 0 ? 1 : (value ? 1 : 0); return BF_OK; }
     if (!strcmp(key, "timing")) {
         h->timing = value ? 1 : 0;
@@ -281,7 +282,7 @@ extern "C" int bf_pack_inference(bf_handle h, const float* params, const float* 
                            h->p_block_stride, pk, h->k_blocks, h->k_block_stride, d.no_layers, d.use_bn, d.bn_eps);
         BF_HIP(hipGetLastError(), "fold_bn");
         BF_HIP(bf_launch_pack_h3(params, state, h->p_blocks, h->p_block_stride, pk + h->k_h3, BF_H3_BLOCK_FLOATS, d.no_layers,
-                                 d.use_bn, d.bn_eps, s), "pack_h3");
+                                 d.use_bn, d.bn_eps, nullptr, nullptr, s), "pack_h3");
     }
     hipLaunchKernelGGL(pack_edges_kernel, dim3(1), dim3(256), 0, s, params, pk, h->p_base, h->n_base, h->p_head0, h->p_head1,
                        d.head_filters, d.out_channels, h->k_base, h->k_w0, h->k_w1, h->k_wh);
@@ -365,8 +366,9 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
             FusedH3Args fa;
             fa.in = buf[cur]; fa.out = buf[cur ^ 1];
             fa.w1 = b3; fa.w2 = b3 + BF_H3_WPACK_FLOATS; fa.aux = b3 + 2 * BF_H3_WPACK_FLOATS;
+            fa.w1r = fa.aux + 64; fa.w2r = fa.aux + 64 + BF_H3R_WPACK_FLOATS;
             fa.B = B; fa.H = H; fa.W = W; fa.tiles_x = fa.tiles_y = fa.ntiles = 0;
-            fa.act1_relu = d.activation == BF_ACT_RELU; fa.zeros = pk + h->k_zero; fa.dump = buf[2];
+            fa.act1_relu = d.activation == BF_ACT_RELU; fa.zeros = pk + h->k_zero; fa.dump = buf[2]; fa.dbg = nullptr;
             BF_HIP(bf_launch_fused_block_h3(fa, s), "fused_block_h3");
             cur ^= 1;
         } else if (h->fused_blocks) {
@@ -783,19 +785,17 @@ extern "C" int bf_debug_fused_block_h3(const float* in, const float* w1_hwio, co
     float* state = params + 4608 + 16;             // [mean 16][var 16]
     float* zeros = state + 32;                     // 64
     float* dump = zeros + 64;                      // 128
-    // the pack kernel folds BN as gamma * rsqrt(var + eps), -scale * mean: gamma = scale, var = 1, eps = 0, mean = -shift/scale
-    // is not exact for scale == 0, so the debug entry passes scale/shift through use_bn = 0 and patches aux afterwards
+    // the caller's scale / shift stand in for the folded BN (ext_scale / ext_shift of the pack kernel)
     if (hipMemcpyAsync(params, w1_hwio, 2304 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;
     if (hipMemcpyAsync(params + 2304, w2_hwio, 2304 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;
     if (bf_launch_zero(zeros, 64, s) != hipSuccess) return BF_EHIP;
-    if (bf_launch_pack_h3(params, state, 0, 4608 + 16, pk, BF_H3_BLOCK_FLOATS, 1, 0, 0.f, s) != hipSuccess) return BF_EHIP;
-    // aux[16..31] = 1/s2 (use_bn = 0 packs scale 1, shift 0): multiply in the caller's scale, set the shift
-    if (bf_launch_affine_patch(pk + 2 * BF_H3_WPACK_FLOATS, scale, shift, s) != hipSuccess) return BF_EHIP;
+    if (bf_launch_pack_h3(params, state, 0, 4608 + 16, pk, BF_H3_BLOCK_FLOATS, 1, 0, 0.f, scale, shift, s) != hipSuccess) return BF_EHIP;
     if (bf_launch_h3_from_f32(in, xa, B, H, W, s) != hipSuccess) return BF_EHIP;
     FusedH3Args fa;
     fa.in = xa; fa.out = ya; fa.w1 = pk; fa.w2 = pk + BF_H3_WPACK_FLOATS; fa.aux = pk + 2 * BF_H3_WPACK_FLOATS;
+    fa.w1r = fa.aux + 64; fa.w2r = fa.aux + 64 + BF_H3R_WPACK_FLOATS;
     fa.B = B; fa.H = H; fa.W = W; fa.tiles_x = fa.tiles_y = fa.ntiles = 0; fa.act1_relu = act1_relu;
-    fa.zeros = zeros; fa.dump = dump;
+    fa.zeros = zeros; fa.dump = dump; fa.dbg = g_fused_dbg;
     if (bf_launch_fused_block_h3(fa, s) != hipSuccess) return BF_EHIP;
     return bf_launch_h3_to_f32(ya, out, B, H, W, s) == hipSuccess ? BF_OK : BF_EHIP;
 }

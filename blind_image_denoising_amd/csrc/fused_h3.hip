@@ -37,6 +37,26 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 #define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
+// timing-only ablations of fused_block_h3r_kernel (tools/ablate.sh; results are WRONG when any is set):
+// 1 = no next-tile DMA, 2 = no global stores, 4 = no conv2 MFMA work, 8 = no conv1 MFMA work, 16 = no barriers
+// 32 = s_memtime stamps per phase (diagnostic build; per-wave sums go to args.dbg, tools/stamp_h3.py)
+#ifndef H3_ABLATE
+#define H3_ABLATE 0
+#endif
+#if H3_ABLATE & 32
+#define H3_STAMP(k)                                                                                      \
+    do {                                                                                                 \
+        unsigned long long now_;                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");                      \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        stamp_sum[k] += now_ - stamp_prev;                                                               \
+        stamp_prev = now_;                                                                               \
+    } while (0)
+#else
+#define H3_STAMP(k) do { } while (0)
+#endif
+
 template <int TH_, int TW_, int NW_>
 struct H3Cfg {
     static constexpr int TH = TH_, TW = TW_, NW = NW_, NT = NW_ * 64;
@@ -102,14 +122,30 @@ constexpr int H3_LGKMCNT0 = 0xC07F;
 __device__ __forceinline__ void h3_barrier()
 {
     __builtin_amdgcn_s_waitcnt(H3_LGKMCNT0);
+#if H3_ABLATE & 16
+    asm volatile("" ::: "memory");
+#else
     asm volatile("s_barrier" ::: "memory");
+#endif
 }
 
+// v - float(one half of the packed f16 pair hh) in ONE instruction (hipcc never selects v_fma_mix_f32 for this)
+__device__ __forceinline__ float h3_sub_half(const float v, const unsigned hh, const bool high)
+{
+    float r;
+    if (high) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(v));
+    else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(v));
+    return r;
+}
+
+// hi = f16(v) (round-to-nearest-even), lo = f16(v - hi): 2 x v_cvt_pk + 4 x v_fma_mix + 2 x v_cvt_pk
 __device__ __forceinline__ void h3_split(const f32x4 v, h4& hi, h4& lo)
 {
-    hi = __builtin_convertvector(v, h4);                         // round-to-nearest-even
-    const f32x4 back = __builtin_convertvector(hi, f32x4);
-    lo = __builtin_convertvector(v - back, h4);
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    hi = __builtin_convertvector(v, h4);
+    const unsigned a = __builtin_bit_cast(unsigned, (h2){hi[0], hi[1]}), b = __builtin_bit_cast(unsigned, (h2){hi[2], hi[3]});
+    const f32x4 d = {h3_sub_half(v[0], a, false), h3_sub_half(v[1], a, true), h3_sub_half(v[2], b, false), h3_sub_half(v[3], b, true)};
+    lo = __builtin_convertvector(d, h4);
 }
 
 // NG groups x 14 MFMAs.  va / vb / vc: per-group LDS byte address of the lane's 16-byte record of tap (0,0)
@@ -224,6 +260,29 @@ __device__ __forceinline__ void h3_dma(const FusedH3Args& a, const H3Tile& t, ch
                                          (__attribute__((address_space(3))) void*)(tin + (i * Cfg::NT + wave * 64) * 16),
                                          16, 0, 0);
     }
+}
+
+// one of the PF wave-instructions of h3_dma (I compile-time): lets the row-streaming kernel spread the DMA issue
+// over conv1's rows.  Measured with s_memtime stamps (tools/stamp_h3.py): issuing the 6 instructions back to back
+// at the top of the tile costs a wave 1000-2100 cycles -- the 48 KB of the 8 waves queue up in the vector-memory
+// issue path (~32 cycles per 1-KiB wave-instruction per CU) and every wave stalls in-order behind its own.
+template <class Cfg, bool INTERIOR, int I>
+__device__ __forceinline__ void h3_dma_one(const FusedH3Args& a, const H3Tile& t, const char* origin, char* __restrict__ tin,
+                                           const int tid, const int wave, const unsigned (&pfoff)[Cfg::PF], const bool live)
+{
+    const char* src = origin + pfoff[I];
+    bool use = live;
+    if ((I + 1) * Cfg::NT > Cfg::IN_ELEMS) use = use && (I * Cfg::NT + wave * 64) < Cfg::IN_ELEMS;     // wave-uniform
+    if (!INTERIOR) {
+        const int e = tid + I * Cfg::NT;
+        const int r = e % (Cfg::IH * Cfg::IW);
+        const int row = r / Cfg::IW, col = r - row * Cfg::IW;
+        const int gy = t.y0 - 2 + row, gx = t.x0 - 2 + col;
+        use = use && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    }
+    if (!use) src = reinterpret_cast<const char*>(a.zeros);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(tin + (I * Cfg::NT + wave * 64) * 16), 16, 0, 0);
 }
 
 template <class Cfg>
@@ -389,7 +448,353 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3_kernel(FusedH3Args 
     }
 }
 
+// ==========================================================================================================
+// Row-streaming variant (fused_block_h3r_kernel): same arithmetic, layout, DMA pipeline and barriers as above, but
+// a wave owns a RUN of R consecutive rows of one 16-column strip and walks down the rows.  Taps are paired
+// HORIZONTALLY -- (dy,0)|(dy,1) in one K=32 MFMA, tap (dy,2) as [w_hi | w_lo] x [x_hi | x_hi] and [w_hi | 0] x
+// [x_lo | x_lo] -- so a B fragment depends on the INPUT ROW only: the four fragments of input row i (pair hi, pair
+// lo, single hi, single lo = 4 ds_read_b128) serve the three output rows i, i-1, i-2.  Per output row that is
+// 4*(R+2)/R reads instead of 10 (6 for R = 4) against 15 MFMAs instead of 14; the next row's fragments are in
+// flight while the current row's 15 MFMAs run (16 VGPRs of prefetch), and only three accumulators are live.
+// rocprof of the group-per-pass kernel above (profiles/r01_h3_groups_pmc.txt): matrix pipe 36 % busy, LDS 34 %,
+// waves parked in s_waitcnt 40 % of their cycles -- latency, not throughput; this variant attacks exactly that.
+// ==========================================================================================================
+template <int PITCH, int LO>
+struct H3RowFrag {
+    h8 ph, pl, sh, sl;
+    __device__ __forceinline__ void load(const char* __restrict__ src, const int vp, const int vs, const int row)
+    {
+        ph = *reinterpret_cast<const h8*>(src + vp + row * PITCH);
+        pl = *reinterpret_cast<const h8*>(src + vp + row * PITCH + LO);
+        sh = *reinterpret_cast<const h8*>(src + vs + row * PITCH);
+        sl = *reinterpret_cast<const h8*>(src + vs + row * PITCH + LO);
+    }
+};
+
+// the five MFMAs of one (input row, dy) pair; w: [dy*4 + {pair hi, pair lo, single [hi|lo], single [hi|0]}]
+template <int PITCH, int LO>
+__device__ __forceinline__ f32x4 h3r_tap_row(const H3RowFrag<PITCH, LO>& x, const h8 (&w)[13], const int dy, f32x4 acc)
+{
+    // ablations 4 / 8: conv2 reads the intermediate tile (PITCH = MW*16 is not a multiple of 64 for TW = 32), conv1 the input tile
+    if (((H3_ABLATE & 4) && PITCH % 64 != 0) || ((H3_ABLATE & 8) && PITCH % 64 == 0)) {
+        acc[0] += (float)x.ph[0] + (float)x.pl[1] + (float)x.sh[2] + (float)x.sl[3];      // keeps the LDS reads live
+        return acc;
+    }
+    acc = MFMA_H(w[dy * 4 + 0], x.ph, acc);
+    acc = MFMA_H(w[dy * 4 + 1], x.ph, acc);
+    acc = MFMA_H(w[dy * 4 + 0], x.pl, acc);
+    acc = MFMA_H(w[dy * 4 + 2], x.sh, acc);
+    acc = MFMA_H(w[dy * 4 + 3], x.sl, acc);
+    return acc;
+}
+
+// R output rows of one strip: vp / vs = lane's LDS byte address of input row 0 for the pair / single fragments
+struct H3NoHook {
+    template <int I> __device__ __forceinline__ void row() const {}
+};
+
+// hook.row<I>() runs after the MFMAs of input row I have been issued (I = 0 .. R+1)
+template <int R, int PITCH, int LO, int I, class Epi, class Hook>
+__device__ __forceinline__ void h3r_rows_step(const char* __restrict__ src, const int vp, const int vs, const h8 (&w)[13],
+                                              f32x4 (&acc)[R], H3RowFrag<PITCH, LO>& cur, Epi& epi, const Hook& hook)
+{
+    if constexpr (I < R + 2) {
+        H3RowFrag<PITCH, LO> nxt;
+        if (I + 1 < R + 2) nxt.load(src, vp, vs, I + 1);
+#pragma unroll
+        for (int dy = 2; dy >= 0; --dy) {                       // oldest accumulator first: it finishes in this row
+            const int o = I - dy;
+            if (o >= 0 && o < R) {
+                if (dy == 0) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc[o] = h3r_tap_row<PITCH, LO>(cur, w, dy, acc[o]);
+            }
+        }
+        hook.template row<I>();
+        if (I >= 2) epi(I - 2, acc[I >= 2 ? I - 2 : 0]);
+        cur = nxt;
+        h3r_rows_step<R, PITCH, LO, I + 1>(src, vp, vs, w, acc, cur, epi, hook);
+    }
+}
+
+template <int R, int PITCH, int LO, class Epi, class Hook>
+__device__ __forceinline__ void h3r_rows(const char* __restrict__ src, const int vp, const int vs, const h8 (&w)[13], Epi&& epi,
+                                         const Hook& hook)
+{
+    f32x4 acc[R];
+    H3RowFrag<PITCH, LO> cur;
+    cur.load(src, vp, vs, 0);
+    h3r_rows_step<R, PITCH, LO, 0>(src, vp, vs, w, acc, cur, epi, hook);
+}
+
+// one 16-pixel group of arbitrary shape (the 2-column strip groups): 12 reads, 15 MFMAs, no row reuse
+template <int PITCH, int LO>
+__device__ __forceinline__ f32x4 h3r_group(const char* __restrict__ src, const int vp, const int vs, const h8 (&w)[13])
+{
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        H3RowFrag<PITCH, LO> x;
+        x.load(src, vp, vs, dy);
+        acc = h3r_tap_row<PITCH, LO>(x, w, dy, acc);
+    }
+    return acc;
+}
+
+template <class Cfg>
+struct H3RPlan {
+    static constexpr int NRUN = Cfg::RSTEP;                            // row runs per strip = waves per strip
+    static constexpr int R1_SMALL = Cfg::MH / NRUN, R1_BIG = R1_SMALL + 1, N_BIG = Cfg::MH % NRUN;   // conv1: 18 = 5+5+4+4
+    static constexpr int R2 = Cfg::TH / NRUN;                          // conv2: 16 = 4x4
+    static_assert(Cfg::TH % NRUN == 0, "conv2 rows must divide over the runs");
+    static_assert(N_BIG > 0 && N_BIG < NRUN, "plan assumes both run lengths occur");
+    static_assert((NRUN - N_BIG) * Cfg::GPR >= Cfg::SG, "strip groups go to the waves with the short runs");
+};
+
+template <class Cfg, bool INTERIOR>
+__device__ __forceinline__ void h3r_conv1_store(const FusedH3Args& a, char* __restrict__ tmid, const int wr, f32x4 v,
+                                                const float inv_s, const int gy, const int gx)
+{
+    v = v * inv_s;
+    if (a.act1_relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    if (!INTERIOR) {
+        // conv2 must see ZERO padding outside the image, not conv1 evaluated there
+        if (gy < 0 || gy >= a.H || gx < 0 || gx >= a.W) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    h4 hi, lo;
+    h3_split(v, hi, lo);
+    *reinterpret_cast<h4*>(tmid + wr) = hi;
+    *reinterpret_cast<h4*>(tmid + wr + 2 * Cfg::MID_PLANE) = lo;
+}
+
+struct H3RLane {
+    int p1, s1;      // conv1 pair / single fragment address of the run's first input row (input tile)
+    int w1;          // conv1 result write of the run's first row (intermediate tile)
+    int gp1, gs1, gw;    // strip group: pair / single read, write
+    int p2, s2;      // conv2 pair / single fragment address (intermediate tile)
+    int rr;          // residual read of the run's first output row (input tile centre)
+    unsigned g;      // global byte offset of the lane's 8-byte record of the run's first output row from the tile origin
+    int px, srow, scol;
+};
+
+// issues DMA wave-instruction I of the next tile after conv1's input row I
+template <class Cfg, bool NX_INTERIOR>
+struct H3DmaHook {
+    const FusedH3Args& a;
+    const H3Tile& nx;
+    const char* origin;
+    char* tnx;
+    int tid, wave;
+    const unsigned (&pfoff)[Cfg::PF];
+    bool live;
+    template <int I> __device__ __forceinline__ void row() const
+    {
+        if constexpr (I < Cfg::PF) {
+            if (!(H3_ABLATE & 1)) h3_dma_one<Cfg, NX_INTERIOR, I>(a, nx, origin, tnx, tid, wave, pfoff, live);
+        }
+    }
+};
+
+template <class Cfg, int R, bool INTERIOR, class Hook>
+__device__ __forceinline__ void h3r_conv1_run(const FusedH3Args& a, const char* __restrict__ tin, char* __restrict__ tmid,
+                                              const h8 (&w)[13], const float inv_s, const H3RLane& L, const H3Tile& t,
+                                              const int o0, const Hook& hook)
+{
+    static_assert(R + 2 >= Cfg::PF, "one DMA instruction per input row must cover the tile");
+    auto epi = [&](const int o, const f32x4 v) {
+        h3r_conv1_store<Cfg, INTERIOR>(a, tmid, L.w1 + o * Cfg::MW * 16, v, inv_s, t.y0 - 1 + o0 + o, t.x0 - 1 + L.px);
+    };
+    h3r_rows<R, Cfg::IW * 16, 2 * Cfg::IN_PLANE>(tin, L.p1, L.s1, w, epi, hook);
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args a)
+{
+    using Plan = H3RPlan<Cfg>;
+    extern __shared__ __attribute__((aligned(16))) char h3_lds[];
+    char* tmid = h3_lds;                                        // [4][MH][MW][8 f16] (+ pad per plane)
+    char* tin0 = h3_lds + 4 * Cfg::MID_PLANE;                   // [4][IH][IW][8 f16] (+ pad), two buffers
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int run = wave / Cfg::GPR, wcol = (wave % Cfg::GPR) * 16;
+    const unsigned plane_g = (unsigned)a.H * (unsigned)a.W * 16u;       // bytes per global plane
+    const bool big = run < Plan::N_BIG;
+    const int o1 = big ? run * Plan::R1_BIG : Plan::N_BIG * Plan::R1_BIG + (run - Plan::N_BIG) * Plan::R1_SMALL;   // conv1 first row
+    const int o2 = run * Plan::R2;                                                                               // conv2 first row
+    const int sg = wave - Plan::N_BIG * Cfg::GPR;               // strip group of this wave (valid if 0 <= sg < SG)
+
+    H3RLane L0;
+    L0.px = wcol + n;
+    L0.srow = min(8 * max(sg, 0) + (n >> 1), Cfg::MH - 1);      // partial last group: clamp (duplicate work, same values)
+    L0.scol = Cfg::TW + (n & 1);
+    {
+        const int b1 = (q & 1) * Cfg::IN_PLANE + (o1 * Cfg::IW + L0.px) * 16;
+        L0.p1 = b1 + (q >> 1) * 16;
+        L0.s1 = b1 + 32;
+        L0.w1 = (q >> 1) * Cfg::MID_PLANE + (o1 * Cfg::MW + L0.px) * 16 + (q & 1) * 8;
+        const int bg = (q & 1) * Cfg::IN_PLANE + (L0.srow * Cfg::IW + L0.scol) * 16;
+        L0.gp1 = bg + (q >> 1) * 16;
+        L0.gs1 = bg + 32;
+        L0.gw = (q >> 1) * Cfg::MID_PLANE + (L0.srow * Cfg::MW + L0.scol) * 16 + (q & 1) * 8;
+        const int b2 = (q & 1) * Cfg::MID_PLANE + (o2 * Cfg::MW + L0.px) * 16;
+        L0.p2 = b2 + (q >> 1) * 16;
+        L0.s2 = b2 + 32;
+        // residual operand [x_hi | x_lo] of the centre pixel: lanes q < 2 read the hi planes, q >= 2 the lo planes
+        L0.rr = ((q & 1) + 2 * (q >> 1)) * Cfg::IN_PLANE + ((o2 + 2) * Cfg::IW + L0.px + 2) * 16;
+        L0.g = (unsigned)(q >> 1) * plane_g + (unsigned)(o2 * a.W + L0.px) * 16u + (unsigned)(q & 1) * 8u;
+    }
+
+    unsigned pfoff[Cfg::PF];
+#pragma unroll
+    for (int i = 0; i < Cfg::PF; ++i) {
+        const int e = tid + i * Cfg::NT;
+        const int pl = e / (Cfg::IH * Cfg::IW), r = e - pl * (Cfg::IH * Cfg::IW);
+        const int row = r / Cfg::IW, col = r - row * Cfg::IW;
+        pfoff[i] = (unsigned)pl * plane_g + (unsigned)(row * a.W + col) * 16u;
+    }
+
+    h8 w1[13], w2[13];                                          // [12]: s2 * identity (conv2 only: adds the residual)
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        w1[i] = reinterpret_cast<const h8*>(a.w1)[i * 64 + lane];
+        w2[i] = reinterpret_cast<const h8*>(a.w2)[i * 64 + lane];
+    }
+    const float inv_s1 = a.aux[0];
+    const float inv_s2 = a.aux[48];                             // BN scale is folded into the row-layout w2
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(a.aux + 32 + q * 4);
+
+    const int nxcd = gridDim.x >= 8 ? 8 : 1;
+    const int label = blockIdx.x % nxcd, slot = blockIdx.x / nxcd;
+    const int per_label = gridDim.x / nxcd;
+    const int chunk = (a.ntiles + nxcd - 1) / nxcd;
+    const int t_begin = label * chunk;
+    const int t_end = min(a.ntiles, t_begin + chunk);
+    int t = t_begin + slot;
+    if (t >= t_end) return;
+
+    {
+        const H3Tile c0 = h3_tile<Cfg>(a, t);
+        h3_dma<Cfg, false>(a, c0, tin0, tid, wave, pfoff, true);
+        __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));               // also retires the weight / scale loads above
+        h3_barrier();
+    }
+
+#if H3_ABLATE & 32
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
+    int buf = 0;
+    for (; t < t_end; t += per_label, buf ^= 1) {
+        const H3Tile cur = h3_tile<Cfg>(a, t);
+        const int t1 = t + per_label;
+        const bool has1 = t1 < t_end;
+        char* tin = tin0 + buf * Cfg::TIN_BYTES;
+        const bool interior = h3_interior<Cfg>(a, cur);
+        H3RLane L = L0;
+        asm volatile("" : "+v"(L.p1), "+v"(L.w1), "+v"(L.gp1), "+v"(L.gw), "+v"(L.p2), "+v"(L.rr), "+v"(L.g));
+        H3_STAMP(6);                                             // tile index math
+
+        // next tile: global -> the other LDS buffer (last read by the previous tile's conv2 residual, one barrier
+        // ago); its PF DMA instructions are issued one per input row inside conv1 and land during conv2
+        const H3Tile nx = h3_tile<Cfg>(a, has1 ? t1 : t);
+        const char* nx_origin = reinterpret_cast<const char*>(a.in) + nx.img + ((ptrdiff_t)(nx.y0 - 2) * a.W + (nx.x0 - 2)) * 16;
+        char* tnx = tin0 + (buf ^ 1) * Cfg::TIN_BYTES;
+        const bool nx_interior = h3_interior<Cfg>(a, nx);
+        H3_STAMP(0);                                             // next-tile index math
+        // ---- conv1: input tile -> intermediate tile ------------------------------------------------------
+#define H3R_CONV1(RV)                                                                                                       \
+        do {                                                                                                               \
+            if (nx_interior) {                                                                                             \
+                const H3DmaHook<Cfg, true> hook{a, nx, nx_origin, tnx, tid, wave, pfoff, has1};                            \
+                if (interior) h3r_conv1_run<Cfg, RV, true>(a, tin, tmid, w1, inv_s1, L, cur, o1, hook);                    \
+                else h3r_conv1_run<Cfg, RV, false>(a, tin, tmid, w1, inv_s1, L, cur, o1, hook);                            \
+            } else {                                                                                                       \
+                const H3DmaHook<Cfg, false> hook{a, nx, nx_origin, tnx, tid, wave, pfoff, has1};                           \
+                if (interior) h3r_conv1_run<Cfg, RV, true>(a, tin, tmid, w1, inv_s1, L, cur, o1, hook);                    \
+                else h3r_conv1_run<Cfg, RV, false>(a, tin, tmid, w1, inv_s1, L, cur, o1, hook);                            \
+            }                                                                                                              \
+        } while (0)
+        if (big) {
+            H3R_CONV1(Plan::R1_BIG);
+        } else {
+            // strip group FIRST: at the end of conv1 its read -> MFMA -> write chain ran alone (the partner wave on the
+            // SIMD was already parked at the barrier) and cost ~1100 cycles, all of it barrier time for the other waves
+            if (sg < Cfg::SG) {
+                const f32x4 v = h3r_group<Cfg::IW * 16, 2 * Cfg::IN_PLANE>(tin, L.gp1, L.gs1, w1);
+                if (interior) h3r_conv1_store<Cfg, true>(a, tmid, L.gw, v, inv_s1, 0, 0);
+                else h3r_conv1_store<Cfg, false>(a, tmid, L.gw, v, inv_s1, cur.y0 - 1 + L.srow, cur.x0 - 1 + L.scol);
+            }
+            H3R_CONV1(Plan::R1_SMALL);
+        }
+#undef H3R_CONV1
+        H3_STAMP(1);                                             // conv1 (+ DMA issue)
+        h3_barrier();                                            // tmid complete
+        H3_STAMP(2);                                             // barrier A
+
+        // ---- conv2 + folded BN + residual (from the LDS input tile) -> global ---------------------------
+        {
+            char* out_row0 = reinterpret_cast<char*>(a.out) + cur.img + ((size_t)cur.y0 * a.W + cur.x0) * 16;
+            const size_t rowbytes = (size_t)a.W * 16;
+            const size_t lo_g = 2 * (size_t)plane_g;
+            auto epi2 = [&](const int o, f32x4 acc) {
+                // residual on the matrix pipe: acc += (s2 * I) x [x_hi | x_lo] -- exact (power-of-two times f16 in fp32)
+                // and one MFMA + one ds_read_b128 instead of two ds_read_b64 and 12 conversions / additions
+                const h8 xr = *reinterpret_cast<const h8*>(tin + L.rr + o * Cfg::IW * 16);
+                acc = MFMA_H(w2[12], xr, acc);
+                const f32x4 v = acc * inv_s2 + sh;
+                h4 hi, lo;
+                h3_split(v, hi, lo);
+                // out-of-image lanes store to a dump line: every wave issues exactly 2*R2 stores per tile
+                char* p = out_row0 + o * rowbytes + L.g;
+                char* pl = p + lo_g;
+                if (!interior && !(cur.y0 + o2 + o < a.H && cur.x0 + L.px < a.W)) {
+                    p = reinterpret_cast<char*>(a.dump) + lane * 8;
+                    pl = p;
+                }
+                if (H3_ABLATE & 2) { if (v.x == 12345.678f) *reinterpret_cast<h4*>(p) = hi + lo; }   // keeps the work live
+                else {
+                    *reinterpret_cast<h4*>(p) = hi;
+                    *reinterpret_cast<h4*>(pl) = lo;
+                }
+            };
+            h3r_rows<Plan::R2, Cfg::MW * 16, 2 * Cfg::MID_PLANE>(tmid, L.p2, L.s2, w2, epi2, H3NoHook{});
+        }
+        // next tile's DMA landed <=> at most the 2*R2 stores above are outstanding (see fused_block_h3_kernel)
+        H3_STAMP(3);                                             // conv2 + stores
+        __builtin_amdgcn_s_waitcnt(h3_vmcnt((H3_ABLATE & 2) ? 0 : 2 * Plan::R2));
+        H3_STAMP(4);                                             // wait for the next tile's DMA
+        h3_barrier();
+        H3_STAMP(5);                                             // barrier B
+    }
+#if H3_ABLATE & 32
+    if (a.dbg && lane == 0) {
+        for (int k = 0; k < 8; ++k) a.dbg[((size_t)blockIdx.x * Cfg::NW + wave) * 8 + k] = stamp_sum[k];
+    }
+#endif
+}
+
 using H3Default = H3Cfg<16, 32, 8>;
+
+static int g_h3_variant = 1;      // 1 (default): row-streaming kernel ; 0: group-per-pass kernel
+void bf_set_h3_variant(int v) { g_h3_variant = v < 0 ? 1 : v; }
+
+template <class Cfg, int VARIANT>      // VARIANT keeps one attr_done per kernel (both kernels have the same function type)
+static hipError_t launch_h3(void (*kernel)(FusedH3Args), const FusedH3Args& a, hipStream_t s)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    int grid = a.ntiles < 256 ? a.ntiles : 256;                 // one persistent workgroup per CU
+    if (grid >= 8) grid -= grid % 8;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, s, a);
+    return hipGetLastError();
+}
 
 hipError_t bf_launch_fused_block_h3(const FusedH3Args& args, hipStream_t s)
 {
@@ -400,17 +805,9 @@ hipError_t bf_launch_fused_block_h3(const FusedH3Args& args, hipStream_t s)
     a.tiles_x = (a.W + Cfg::TW - 1) / Cfg::TW;
     a.tiles_y = (a.H + Cfg::TH - 1) / Cfg::TH;
     a.ntiles = a.B * a.tiles_x * a.tiles_y;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_block_h3_kernel<Cfg>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    int grid = a.ntiles < 256 ? a.ntiles : 256;                 // one persistent workgroup per CU
-    if (grid >= 8) grid -= grid % 8;
-    hipLaunchKernelGGL(fused_block_h3_kernel<Cfg>, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, s, a);
-    return hipGetLastError();
+    if (g_h3_variant == 0) return launch_h3<Cfg, 0>(fused_block_h3_kernel<Cfg>, a, s);
+    a.w1 = a.w1r; a.w2 = a.w2r;                                 // horizontally paired weights
+    return launch_h3<Cfg, 1>(fused_block_h3r_kernel<Cfg>, a, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -423,7 +820,8 @@ hipError_t bf_launch_fused_block_h3(const FusedH3Args& args, hipStream_t s)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_h3_kernel(const float* __restrict__ params, const float* __restrict__ state,
                                                       int64_t p_blocks, int64_t p_stride, float* __restrict__ dst,
-                                                      int64_t d_stride, int use_bn, float eps)
+                                                      int64_t d_stride, int use_bn, float eps,
+                                                      const float* __restrict__ ext_scale, const float* __restrict__ ext_shift)
 {
     __shared__ float red[256];
     __shared__ float s_scale;
@@ -465,31 +863,91 @@ __global__ __launch_bounds__(256) void pack_h3_kernel(const float* __restrict__ 
         const _Float16 lo = (_Float16)(ws - (float)hi);
         o[idx] = part == 0 ? hi : (part == 1 ? lo : (_Float16)0.f);
     }
+    // row-streaming layout: [dy*4 + {pair hi, pair lo, single [hi | lo], single [hi | 0]}][lane][8], [12] = sr * identity.
+    // conv2 (which == 1): the folded BN scale is multiplied INTO the weights (per output channel) and the kernel adds the
+    // residual as (sr * I) x [x_hi | x_lo] on the matrix pipe, so sr must itself be an f16 number: sr <= 2^15.
+    __shared__ float s_fold[16];
+    __shared__ float s_scale_r;
+    if (threadIdx.x < 16) {
+        float f = 1.f;
+        if (which == 1) {
+            if (ext_scale) f = ext_scale[threadIdx.x];
+            else if (use_bn) f = params[p_blocks + layer * p_stride + 4608 + threadIdx.x] / sqrtf(state[layer * 32 + 16 + threadIdx.x] + eps);
+        }
+        s_fold[threadIdx.x] = f;
+    }
+    __syncthreads();
+    m = 0.f;
+    for (int i = threadIdx.x; i < 2304; i += 256) m = fmaxf(m, fabsf(w[i] * s_fold[i & 15]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float sr = 1.f;
+        const float mx = red[0];
+        if (mx > 0.f && mx < 3.0e38f) {
+            int ex;
+            (void)frexpf(mx, &ex);
+            ex = max(-100, min(100, ex));
+            sr = ldexpf(1.f, 14 - ex);
+        }
+        if (which == 1) sr = fminf(sr, 32768.f);
+        s_scale_r = sr;
+    }
+    __syncthreads();
+    const float sr = s_scale_r;
+    _Float16* orow = reinterpret_cast<_Float16*>(dst + layer * d_stride + 2 * BF_H3_WPACK_FLOATS + 64 + which * BF_H3R_WPACK_FLOATS);
+    for (int idx = threadIdx.x; idx < 13 * 64 * 8; idx += 256) {
+        const int i = idx >> 9, l = (idx >> 3) & 63, j = idx & 7;
+        const int cout = l & 15, kslot = 8 * (l >> 4) + j, half = kslot >> 4, cin = kslot & 15;
+        if (i == 12) {
+            orow[idx] = (which == 1 && cin == cout) ? (_Float16)sr : (_Float16)0.f;
+            continue;
+        }
+        const int dy = i >> 2, kind = i & 3;
+        int tap, part;
+        if (kind == 0) { tap = dy * 3 + half; part = 0; }
+        else if (kind == 1) { tap = dy * 3 + half; part = 1; }
+        else if (kind == 2) { tap = dy * 3 + 2; part = half; }
+        else { tap = dy * 3 + 2; part = half ? 2 : 0; }
+        const float ws = w[(tap * 16 + cin) * 16 + cout] * s_fold[cout] * sr;
+        const _Float16 hi = (_Float16)ws;
+        const _Float16 lo = (_Float16)(ws - (float)hi);
+        orow[idx] = part == 0 ? hi : (part == 1 ? lo : (_Float16)0.f);
+    }
     float* aux = dst + layer * d_stride + 2 * BF_H3_WPACK_FLOATS;
     if (threadIdx.x < 16) {
         const int c = threadIdx.x;
         if (which == 0) {
-            aux[c] = 1.0f / s;
+            aux[c] = 1.0f / sr;                       // == 1/s: conv1 folds nothing
         } else {
             float sc = 1.f, sh = 0.f;
-            if (use_bn) {     // keras BatchNormalization(training=False): gamma*(x-mean)*rsqrt(var+eps)
+            if (ext_scale) {                          // debug entry: caller's scale / shift
+                sc = ext_scale[c];
+                sh = ext_shift[c];
+            } else if (use_bn) {     // keras BatchNormalization(training=False): gamma*(x-mean)*rsqrt(var+eps)
                 const float g = params[p_blocks + layer * p_stride + 4608 + c];
                 const float mean = state[layer * 32 + c], var = state[layer * 32 + 16 + c];
                 sc = g / sqrtf(var + eps);
                 sh = -sc * mean;
             }
-            aux[16 + c] = sc * (1.0f / s);
+            aux[16 + c] = sc * (1.0f / s);            // group-per-pass kernel: scale in the epilogue
             aux[32 + c] = sh;
+            aux[48 + c] = 1.0f / sr;                  // row-streaming kernel: scale folded into the weights
         }
     }
 }
 
 hipError_t bf_launch_pack_h3(const float* params, const float* state, int64_t p_blocks, int64_t p_stride, float* dst,
-                             int64_t d_stride, int layers, int use_bn, float eps, hipStream_t s)
+                             int64_t d_stride, int layers, int use_bn, float eps, const float* ext_scale,
+                             const float* ext_shift, hipStream_t s)
 {
     if (layers <= 0) return hipSuccess;
     hipLaunchKernelGGL(pack_h3_kernel, dim3(layers * 2), dim3(256), 0, s, params, state, p_blocks, p_stride, dst, d_stride,
-                       use_bn, eps);
+                       use_bn, eps, ext_scale, ext_shift);
     return hipGetLastError();
 }
 
@@ -543,18 +1001,5 @@ hipError_t bf_launch_h3_to_f32(const void* y, float* x, int B, int H, int W, hip
     const int64_t npix = (int64_t)B * H * W;
     const int64_t g = (npix * 2 + 255) / 256;
     hipLaunchKernelGGL(h3_to_f32_kernel, dim3((unsigned)(g < 16384 ? g : 16384)), dim3(256), 0, s, (const char*)y, x, npix, (int64_t)H * W);
-    return hipGetLastError();
-}
-
-// debug entry only: aux[16+c] *= scale[c], aux[32+c] = shift[c]
-__global__ void h3_affine_patch_kernel(float* aux, const float* scale, const float* shift)
-{
-    const int c = threadIdx.x;
-    if (c < 16) { aux[16 + c] *= scale[c]; aux[32 + c] = shift[c]; }
-}
-
-hipError_t bf_launch_affine_patch(float* aux, const float* scale, const float* shift, hipStream_t s)
-{
-    hipLaunchKernelGGL(h3_affine_patch_kernel, dim3(1), dim3(64), 0, s, aux, scale, shift);
     return hipGetLastError();
 }

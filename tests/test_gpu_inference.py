@@ -49,21 +49,26 @@ def test_golden_net_f32_and_u8():
     _check_u8(mod(z["ragged"]), z["ragged_u8"])          # 40x50 -> padded to 64x64 -> cropped
 
 
-@pytest.mark.parametrize("fused", [1, 0])
+# (fused_blocks, arith): fused split-f16 blocks on the f16 matrix cores (default), fused exact-fp32 blocks,
+# one exact-fp32 kernel per convolution -- all three against the same oracle with the same bars
+@pytest.mark.parametrize("fused,arith", [(1, 1), (1, 0), (0, 0)], ids=["fused-f16x3", "fused-f32", "unfused-f32"])
 @pytest.mark.parametrize("no_layers,shape", [(0, (1, 16, 16)), (1, (2, 32, 48)), (3, (2, 30, 45)), (6, (1, 64, 64))])
-def test_hydra_f32_matches_oracle(no_layers, shape, fused):
+def test_hydra_f32_matches_oracle(no_layers, shape, fused, arith):
     cfg, spec, params, state, m = _model(no_layers)
     m.set_option("fused_blocks", fused)
+    m.set_option("arith", arith)
     _, noisy = O.synthetic_batch(shape[0], shape[1], shape[2], seed=no_layers + 3)
     x = noisy.astype(np.float32)
     _check_f32(m(x), O.hydra_forward(spec, params, state, x.astype(np.float64)))
 
 
+@pytest.mark.parametrize("arith", [1, 0], ids=["f16x3", "f32"])
 @pytest.mark.parametrize("hw", [(32, 32), (64, 64), (128, 128), (256, 256), (17, 23), (1, 1), (5, 130)])
-def test_denoiser_module_u8_shapes_and_values(hw):
+def test_denoiser_module_u8_shapes_and_values(hw, arith):
     """tests/bfcnn/test_model_denoiser.py:61-70 (same shape, uint8) + value parity, incl. ragged
     sizes that need pad_to_power_of_2."""
     cfg, spec, params, state, m = _model(2, seed=7)
+    m.set_option("arith", arith)
     _, noisy = O.synthetic_batch(1, hw[0], hw[1], seed=hw[0] * 7 + hw[1])
     got = bf.DenoiserModule(m)(noisy)
     assert got.shape == noisy.shape and got.dtype == np.uint8

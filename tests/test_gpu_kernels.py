@@ -128,9 +128,19 @@ def test_fused_block_many_tiles_persistent_schedule(fused_tile):
 
 
 # ---- split-f16 ("f16x3") fused block: same oracle, same bar as the exact-fp32 kernels ---------------------
+@pytest.fixture(params=[1, 0], ids=["rows", "groups"], autouse=False)
+def h3_variant(request):
+    """both split-f16 kernels (row-streaming = default, group-per-pass) must pass the same parity tests."""
+    import blind_image_denoising_amd as bf
+    m = bf.model_builder(O.canonical_config(no_layers=0)["model"], device="cuda").hydra
+    m.set_option("h3_variant", request.param)
+    yield request.param
+    m.set_option("h3_variant", -1)
+
+
 @pytest.mark.parametrize("shape", SHAPES + [(1, 16, 32), (2, 32, 64), (1, 17, 33), (4, 70, 40), (1, 2, 2), (3, 48, 100)])
 @pytest.mark.parametrize("relu", [1, 0])
-def test_fused_block_h3(shape, relu):
+def test_fused_block_h3(shape, relu, h3_variant):
     B, H, W = shape
     x = _rand((B, H, W, 16), 15)
     w1, w2 = _rand((3, 3, 16, 16), 16) * 0.1, _rand((3, 3, 16, 16), 17) * 0.1
@@ -143,7 +153,7 @@ def test_fused_block_h3(shape, relu):
     assert_close(fused_block_h3_gpu(x, w1, w2, sc, sh, relu), ref, what=f"fused h3 {shape}")
 
 
-def test_fused_block_h3_is_exact_on_small_integers():
+def test_fused_block_h3_is_exact_on_small_integers(h3_variant):
     """integers that f16 holds exactly: every product and sum is exact, so the result must equal the oracle
     bit for bit (pins the K packing / tap pairing / lane maps of the f16 MFMA path)."""
     rng = np.random.default_rng(5)
@@ -157,7 +167,7 @@ def test_fused_block_h3_is_exact_on_small_integers():
     assert np.array_equal(fused_block_h3_gpu(x, w1, w2, sc, sh, 1).astype(np.float64), ref)
 
 
-def test_fused_block_h3_wide_dynamic_range():
+def test_fused_block_h3_wide_dynamic_range(h3_variant):
     """weights of very different magnitudes (power-of-two pre-scale + lo part) and activations spanning
     1e-3 .. 1e2: the split must hold ~22 bits relative to the largest term."""
     rng = np.random.default_rng(6)
@@ -170,7 +180,7 @@ def test_fused_block_h3_wide_dynamic_range():
     assert_close(fused_block_h3_gpu(x, w1, w2, sc, sh, 1), ref, what="fused h3 wide range")
 
 
-def test_fused_block_h3_many_tiles_persistent_schedule():
+def test_fused_block_h3_many_tiles_persistent_schedule(h3_variant):
     """more tiles than persistent workgroups: the double-buffered DMA pipeline, the XCD chunking and every
     chunk length (1, 2, 3+ tiles per workgroup) must cover each tile exactly once."""
     for B, H, W in [(24, 128, 160), (3, 100, 70), (9, 64, 96)]:
