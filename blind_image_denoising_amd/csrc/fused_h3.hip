@@ -38,7 +38,8 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
 // timing-only ablations of fused_block_h3r_kernel (tools/ablate.sh; results are WRONG when any is set):
-// 1 = no next-tile DMA, 2 = no global stores, 4 = no conv2 MFMA work, 8 = no conv1 MFMA work, 16 = no barriers
+// 1 = no next-tile DMA, 2 = no global stores, 4 = no conv2 MFMA work, 8 = no conv1 MFMA work, 16 = no barriers,
+// 64 = no epilogue arithmetic (raw accumulator bits are stored)
 // 32 = s_memtime stamps per phase (diagnostic build; per-wave sums go to args.dbg, tools/stamp_h3.py)
 #ifndef H3_ABLATE
 #define H3_ABLATE 0
@@ -76,11 +77,10 @@ struct H3Cfg {
     static constexpr int TIN_BYTES = PF * NT * 16;             // 4 planes + pad to PF whole workgroup-instructions
     static constexpr int LDS_BYTES = 4 * MID_PLANE + 2 * TIN_BYTES;
     static_assert(TW % 16 == 0 && NW % GPR == 0, "rows must be whole MFMA groups, waves whole rows");
+    static constexpr int WG_PER_CU = (160 * 1024) / LDS_BYTES >= 2 && NW <= 4 ? 2 : 1;
     static_assert(TH % RSTEP == 0, "conv2 groups must divide evenly over the waves");
-    static_assert(K1 == K1_FULL + 1 && K1_FULL == K2, "wave plan below assumes K2 full conv1 slots + one partial slot");
     static_assert(IN_PLANE % 256 == 0, "input planes must keep the two channel halves 256-B congruent");
     static_assert(IN_ELEMS % 64 == 0, "DMA moves whole wave-instructions");
-    static_assert(STRIP_W0 + SG <= NW, "strip groups must fit on the waves with fewer row groups");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
@@ -142,6 +142,12 @@ __device__ __forceinline__ float h3_sub_half(const float v, const unsigned hh, c
 __device__ __forceinline__ void h3_split(const f32x4 v, h4& hi, h4& lo)
 {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#if H3_ABLATE & 64
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(h4, (f32x2){v[0], v[1]});           // timing only: no conversion VALU at all
+    lo = __builtin_bit_cast(h4, (f32x2){v[2], v[3]});
+    return;
+#endif
     hi = __builtin_convertvector(v, h4);
     const unsigned a = __builtin_bit_cast(unsigned, (h2){hi[0], hi[1]}), b = __builtin_bit_cast(unsigned, (h2){hi[2], hi[3]});
     const f32x4 d = {h3_sub_half(v[0], a, false), h3_sub_half(v[1], a, true), h3_sub_half(v[2], b, false), h3_sub_half(v[3], b, true)};
@@ -288,6 +294,8 @@ __device__ __forceinline__ void h3_dma_one(const FusedH3Args& a, const H3Tile& t
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3_kernel(FusedH3Args a)
 {
+    static_assert(Cfg::K1 == Cfg::K1_FULL + 1 && Cfg::K1_FULL == Cfg::K2, "wave plan assumes K2 full conv1 slots + one partial slot");
+    static_assert(Cfg::STRIP_W0 + Cfg::SG <= Cfg::NW, "strip groups must fit on the waves with fewer row groups");
     extern __shared__ __attribute__((aligned(16))) char h3_lds[];
     char* tmid = h3_lds;                                        // [4][MH][MW][8 f16] (+ pad per plane)
     char* tin0 = h3_lds + 4 * Cfg::MID_PLANE;                   // [4][IH][IW][8 f16], two buffers
@@ -488,42 +496,100 @@ __device__ __forceinline__ f32x4 h3r_tap_row(const H3RowFrag<PITCH, LO>& x, cons
     return acc;
 }
 
+// MFMA m (0..4) of the five of one (input row, dy) pair
+template <int PITCH, int LO>
+__device__ __forceinline__ f32x4 h3r_tap_mfma(const H3RowFrag<PITCH, LO>& x, const h8 (&w)[13], const int dy, const int m, f32x4 acc)
+{
+    if (((H3_ABLATE & 4) && PITCH % 64 != 0) || ((H3_ABLATE & 8) && PITCH % 64 == 0)) {
+        if (m == 0) acc[0] += (float)x.ph[0] + (float)x.pl[1] + (float)x.sh[2] + (float)x.sl[3];
+        return acc;
+    }
+    switch (m) {
+        case 0: return MFMA_H(w[dy * 4 + 0], x.ph, acc);
+        case 1: return MFMA_H(w[dy * 4 + 1], x.ph, acc);
+        case 2: return MFMA_H(w[dy * 4 + 0], x.pl, acc);
+        case 3: return MFMA_H(w[dy * 4 + 2], x.sh, acc);
+        default: return MFMA_H(w[dy * 4 + 3], x.sl, acc);
+    }
+}
+
 // R output rows of one strip: vp / vs = lane's LDS byte address of input row 0 for the pair / single fragments
 struct H3NoHook {
     template <int I> __device__ __forceinline__ void row() const {}
 };
 
-// hook.row<I>() runs after the MFMAs of input row I have been issued (I = 0 .. R+1)
+// One input row I (= 0 .. R+1) of a run.  Issue order, pinned with a scheduling barrier because hipcc otherwise sinks
+// the prefetch below the MFMAs and every row step then eats a full LDS round trip (tools/ablate.sh 76: with NO MFMA
+// and NO epilogue arithmetic the kernel still took 216 us of 320 -- it was LDS-latency bound, 16 row steps per tile):
+//   1. ds_reads of row I+1 (+ whatever the epilogue wants early: epi.pre(O) for output row O = I-2)
+//   2. the 5 MFMAs that COMPLETE output row I-2 (+ epi.finish), the 5 MFMAs of output row I-1, the epilogue of row I-2
+//      interleaved with the 5 MFMAs of output row I
+//   3. hook.row<I>()
 template <int R, int PITCH, int LO, int I, class Epi, class Hook>
 __device__ __forceinline__ void h3r_rows_step(const char* __restrict__ src, const int vp, const int vs, const h8 (&w)[13],
-                                              f32x4 (&acc)[R], H3RowFrag<PITCH, LO>& cur, Epi& epi, const Hook& hook)
+                                              f32x4 acc_m2, f32x4 acc_m1, const H3RowFrag<PITCH, LO> cur,
+                                              const H3RowFrag<PITCH, LO> nxt, const typename Epi::Pre pre_m2, const Epi& epi,
+                                              const Hook& hook)
 {
+    // acc_m2 / acc_m1: accumulators of output rows I-2 / I-1 (rolling values, not an array: hipcc left a 5-row
+    // accumulator array in scratch memory once the epilogue call moved, and scratch traffic drains the tile DMA)
     if constexpr (I < R + 2) {
-        H3RowFrag<PITCH, LO> nxt;
-        if (I + 1 < R + 2) nxt.load(src, vp, vs, I + 1);
+        // prefetch distance 2: the fragments of row I+2 are requested while rows I and I+1 are already in registers / in
+        // flight.  With distance 1 the run's first and last steps (5 and 10 MFMAs) were LDS-latency bound: 7 steps of
+        // ~480 cycles for 75 MFMAs (stamps), 480 = what 2 x 15 MFMAs of the two waves of a SIMD need in steady state.
+        H3RowFrag<PITCH, LO> nx2;
+        if (I + 2 < R + 2) nx2.load(src, vp, vs, I + 2);
+        typename Epi::Pre pre_m1 = {};
+        if constexpr (I >= 1 && I - 1 < R) pre_m1 = epi.pre(I - 1);   // consumed in the NEXT step: a full row of MFMAs away
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc_0 = {0.f, 0.f, 0.f, 0.f};
+#if H3_ABLATE & 512
+        if constexpr (I >= 2) {
+            acc_m2 = h3r_tap_row<PITCH, LO>(cur, w, 2, acc_m2);
+            acc_m2 = epi.finish(acc_m2, pre_m2);                // conv2: + residual MFMA
+        }
+        if constexpr (I >= 1 && I - 1 < R) acc_m1 = h3r_tap_row<PITCH, LO>(cur, w, 1, acc_m1);
+        if constexpr (I >= 2) epi(I - 2, acc_m2);               // its result is 5 MFMAs old: no s_nop for the read
+        if constexpr (I < R) acc_0 = h3r_tap_row<PITCH, LO>(cur, w, 0, acc_0);
+#else
+        // the three accumulators round-robin: consecutive MFMAs are independent (a chain on one accumulator only
+        // issues back to back when hipcc happens to keep vDst == SrcC)
 #pragma unroll
-        for (int dy = 2; dy >= 0; --dy) {                       // oldest accumulator first: it finishes in this row
-            const int o = I - dy;
-            if (o >= 0 && o < R) {
-                if (dy == 0) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                acc[o] = h3r_tap_row<PITCH, LO>(cur, w, dy, acc[o]);
+        for (int m = 0; m < 5; ++m) {
+            if constexpr (I >= 2) acc_m2 = h3r_tap_mfma<PITCH, LO>(cur, w, 2, m, acc_m2);
+            if constexpr (I >= 1 && I - 1 < R) acc_m1 = h3r_tap_mfma<PITCH, LO>(cur, w, 1, m, acc_m1);
+            if constexpr (I < R) acc_0 = h3r_tap_mfma<PITCH, LO>(cur, w, 0, m, acc_0);
+        }
+        if constexpr (I >= 2) {
+            acc_m2 = epi.finish(acc_m2, pre_m2);                // conv2: + residual MFMA
+            epi(I - 2, acc_m2);
+        }
+#endif
+        hook.template row<I>();
+#if !(H3_ABLATE & 128)
+        // interleave: the first ~10 MFMAs back to back, then 3 vector instructions in the shadow of each further MFMA
+        if constexpr (I >= 2 && I < R) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 10 + Epi::EXTRA_MFMA, 0);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
         }
-        hook.template row<I>();
-        if (I >= 2) epi(I - 2, acc[I >= 2 ? I - 2 : 0]);
-        cur = nxt;
-        h3r_rows_step<R, PITCH, LO, I + 1>(src, vp, vs, w, acc, cur, epi, hook);
+#endif
+        h3r_rows_step<R, PITCH, LO, I + 1>(src, vp, vs, w, acc_m1, acc_0, nxt, nx2, pre_m1, epi, hook);
     }
 }
 
 template <int R, int PITCH, int LO, class Epi, class Hook>
-__device__ __forceinline__ void h3r_rows(const char* __restrict__ src, const int vp, const int vs, const h8 (&w)[13], Epi&& epi,
-                                         const Hook& hook)
+__device__ __forceinline__ void h3r_rows(const char* __restrict__ src, const int vp, const int vs, const h8 (&w)[13],
+                                         const Epi& epi, const Hook& hook)
 {
-    f32x4 acc[R];
-    H3RowFrag<PITCH, LO> cur;
+    H3RowFrag<PITCH, LO> cur, nxt;
     cur.load(src, vp, vs, 0);
-    h3r_rows_step<R, PITCH, LO, 0>(src, vp, vs, w, acc, cur, epi, hook);
+    nxt.load(src, vp, vs, 1);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    h3r_rows_step<R, PITCH, LO, 0>(src, vp, vs, w, z, z, cur, nxt, typename Epi::Pre{}, epi, hook);
 }
 
 // one 16-pixel group of arbitrary shape (the 2-column strip groups): 12 reads, 15 MFMAs, no row reuse
@@ -545,18 +611,23 @@ struct H3RPlan {
     static constexpr int NRUN = Cfg::RSTEP;                            // row runs per strip = waves per strip
     static constexpr int R1_SMALL = Cfg::MH / NRUN, R1_BIG = R1_SMALL + 1, N_BIG = Cfg::MH % NRUN;   // conv1: 18 = 5+5+4+4
     static constexpr int R2 = Cfg::TH / NRUN;                          // conv2: 16 = 4x4
+    static constexpr int N_SHORT = (NRUN - N_BIG) * Cfg::GPR;          // waves with the short run: they take the strip groups,
+    static constexpr int SG_PER_WAVE = (Cfg::SG + N_SHORT - 1) / N_SHORT;  // strip group sg + k * N_SHORT on short wave sg
+    static constexpr int NROWS_MIN = R1_SMALL + 2;                      // conv1 input rows of the shortest run (DMA issue slots)
     static_assert(Cfg::TH % NRUN == 0, "conv2 rows must divide over the runs");
     static_assert(N_BIG > 0 && N_BIG < NRUN, "plan assumes both run lengths occur");
-    static_assert((NRUN - N_BIG) * Cfg::GPR >= Cfg::SG, "strip groups go to the waves with the short runs");
 };
 
 template <class Cfg, bool INTERIOR>
 __device__ __forceinline__ void h3r_conv1_store(const FusedH3Args& a, char* __restrict__ tmid, const int wr, f32x4 v,
-                                                const float inv_s, const int gy, const int gx)
+                                                const float inv_s, const float relu_floor, const int gy, const int gx)
 {
-    v = v * inv_s;
-    if (a.act1_relu) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    if (!(H3_ABLATE & 64)) {
+        // activation without a branch and without the canonicalising v_max x,x hipcc puts in front of fmaxf:
+        // max(v, floor) with floor = 0 (relu) or -inf (linear) as median(v, floor, +inf)
+        v = v * inv_s;
+        v.x = __builtin_amdgcn_fmed3f(v.x, relu_floor, __builtin_inff()); v.y = __builtin_amdgcn_fmed3f(v.y, relu_floor, __builtin_inff());
+        v.z = __builtin_amdgcn_fmed3f(v.z, relu_floor, __builtin_inff()); v.w = __builtin_amdgcn_fmed3f(v.w, relu_floor, __builtin_inff());
     }
     if (!INTERIOR) {
         // conv2 must see ZERO padding outside the image, not conv1 evaluated there
@@ -571,15 +642,14 @@ __device__ __forceinline__ void h3r_conv1_store(const FusedH3Args& a, char* __re
 struct H3RLane {
     int p1, s1;      // conv1 pair / single fragment address of the run's first input row (input tile)
     int w1;          // conv1 result write of the run's first row (intermediate tile)
-    int gp1, gs1, gw;    // strip group: pair / single read, write
     int p2, s2;      // conv2 pair / single fragment address (intermediate tile)
     int rr;          // residual read of the run's first output row (input tile centre)
     unsigned g;      // global byte offset of the lane's 8-byte record of the run's first output row from the tile origin
-    int px, srow, scol;
+    int px;
 };
 
-// issues DMA wave-instruction I of the next tile after conv1's input row I
-template <class Cfg, bool NX_INTERIOR>
+// issues the next tile's DMA wave-instructions I, I + NROWS, ... after conv1's input row I
+template <class Cfg, bool NX_INTERIOR, int NROWS>
 struct H3DmaHook {
     const FusedH3Args& a;
     const H3Tile& nx;
@@ -590,21 +660,33 @@ struct H3DmaHook {
     bool live;
     template <int I> __device__ __forceinline__ void row() const
     {
-        if constexpr (I < Cfg::PF) {
+        if constexpr (I < NROWS && I < Cfg::PF) {
             if (!(H3_ABLATE & 1)) h3_dma_one<Cfg, NX_INTERIOR, I>(a, nx, origin, tnx, tid, wave, pfoff, live);
+            if constexpr (I + NROWS < Cfg::PF) {
+                static_assert(I + 2 * NROWS >= Cfg::PF, "at most two DMA instructions per row");
+                if (!(H3_ABLATE & 1)) h3_dma_one<Cfg, NX_INTERIOR, I + NROWS>(a, nx, origin, tnx, tid, wave, pfoff, live);
+            }
         }
     }
 };
 
 template <class Cfg, int R, bool INTERIOR, class Hook>
 __device__ __forceinline__ void h3r_conv1_run(const FusedH3Args& a, const char* __restrict__ tin, char* __restrict__ tmid,
-                                              const h8 (&w)[13], const float inv_s, const H3RLane& L, const H3Tile& t,
-                                              const int o0, const Hook& hook)
+                                              const h8 (&w)[13], const float inv_s, const float relu_floor, const H3RLane& L,
+                                              const H3Tile& t, const int o0, const Hook& hook)
 {
-    static_assert(R + 2 >= Cfg::PF, "one DMA instruction per input row must cover the tile");
-    auto epi = [&](const int o, const f32x4 v) {
-        h3r_conv1_store<Cfg, INTERIOR>(a, tmid, L.w1 + o * Cfg::MW * 16, v, inv_s, t.y0 - 1 + o0 + o, t.x0 - 1 + L.px);
-    };
+    // (plain values, no references to the lane-constant struct: a reference member kept the whole struct in scratch memory)
+    struct Epi {
+        struct Pre {};
+        enum { EXTRA_MFMA = 0 };
+        const FusedH3Args& a; char* __restrict__ tmid; float inv_s, relu_floor; int w1, gy0, gx;
+        __device__ __forceinline__ Pre pre(const int) const { return Pre{}; }
+        __device__ __forceinline__ f32x4 finish(const f32x4 acc, const Pre&) const { return acc; }
+        __device__ __forceinline__ void operator()(const int o, const f32x4 v) const
+        {
+            h3r_conv1_store<Cfg, INTERIOR>(a, tmid, w1 + o * Cfg::MW * 16, v, inv_s, relu_floor, gy0 + o, gx);
+        }
+    } const epi{a, tmid, inv_s, relu_floor, L.w1, t.y0 - 1 + o0, t.x0 - 1 + L.px};
     h3r_rows<R, Cfg::IW * 16, 2 * Cfg::IN_PLANE>(tin, L.p1, L.s1, w, epi, hook);
 }
 
@@ -619,25 +701,22 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
     const int run = wave / Cfg::GPR, wcol = (wave % Cfg::GPR) * 16;
+#if H3_ABLATE & 256
+    if (wave >= Cfg::NW / 2) __builtin_amdgcn_s_setprio(1);    // experiment: favour the younger wave of each SIMD
+#endif
     const unsigned plane_g = (unsigned)a.H * (unsigned)a.W * 16u;       // bytes per global plane
     const bool big = run < Plan::N_BIG;
     const int o1 = big ? run * Plan::R1_BIG : Plan::N_BIG * Plan::R1_BIG + (run - Plan::N_BIG) * Plan::R1_SMALL;   // conv1 first row
     const int o2 = run * Plan::R2;                                                                               // conv2 first row
-    const int sg = wave - Plan::N_BIG * Cfg::GPR;               // strip group of this wave (valid if 0 <= sg < SG)
+    const int sg = wave - Plan::N_BIG * Cfg::GPR;               // first strip group of this wave (short-run waves: sg >= 0)
 
     H3RLane L0;
     L0.px = wcol + n;
-    L0.srow = min(8 * max(sg, 0) + (n >> 1), Cfg::MH - 1);      // partial last group: clamp (duplicate work, same values)
-    L0.scol = Cfg::TW + (n & 1);
     {
         const int b1 = (q & 1) * Cfg::IN_PLANE + (o1 * Cfg::IW + L0.px) * 16;
         L0.p1 = b1 + (q >> 1) * 16;
         L0.s1 = b1 + 32;
         L0.w1 = (q >> 1) * Cfg::MID_PLANE + (o1 * Cfg::MW + L0.px) * 16 + (q & 1) * 8;
-        const int bg = (q & 1) * Cfg::IN_PLANE + (L0.srow * Cfg::IW + L0.scol) * 16;
-        L0.gp1 = bg + (q >> 1) * 16;
-        L0.gs1 = bg + 32;
-        L0.gw = (q >> 1) * Cfg::MID_PLANE + (L0.srow * Cfg::MW + L0.scol) * 16 + (q & 1) * 8;
         const int b2 = (q & 1) * Cfg::MID_PLANE + (o2 * Cfg::MW + L0.px) * 16;
         L0.p2 = b2 + (q >> 1) * 16;
         L0.s2 = b2 + 32;
@@ -663,6 +742,7 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args
     }
     const float inv_s1 = a.aux[0];
     const float inv_s2 = a.aux[48];                             // BN scale is folded into the row-layout w2
+    const float relu_floor = a.act1_relu ? 0.f : -__builtin_inff();
     const f32x4 sh = *reinterpret_cast<const f32x4*>(a.aux + 32 + q * 4);
 
     const int nxcd = gridDim.x >= 8 ? 8 : 1;
@@ -686,19 +766,37 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
     int buf = 0;
+    H3Tile carry = h3_tile<Cfg>(a, t);
+    // tile coordinates advance incrementally: per_label = (sb * tiles_y + sy) * tiles_x + sx, two carries per step
+    // (the three integer divisions of h3_tile cost ~350 scalar-dependent cycles per tile on every wave)
+    int c_tx = carry.x0 / Cfg::TW, c_ty = carry.y0 / Cfg::TH;
+    const int sx = per_label % a.tiles_x, sy = (per_label / a.tiles_x) % a.tiles_y;
+    const size_t img_bytes = (size_t)a.H * a.W * 64;
+    const size_t sb_bytes = (size_t)(per_label / a.tiles_x / a.tiles_y) * img_bytes;
     for (; t < t_end; t += per_label, buf ^= 1) {
-        const H3Tile cur = h3_tile<Cfg>(a, t);
+        const H3Tile cur = carry;                                // (a fresh const per iteration: the epilogue structs hold references)
         const int t1 = t + per_label;
         const bool has1 = t1 < t_end;
         char* tin = tin0 + buf * Cfg::TIN_BYTES;
         const bool interior = h3_interior<Cfg>(a, cur);
         H3RLane L = L0;
-        asm volatile("" : "+v"(L.p1), "+v"(L.w1), "+v"(L.gp1), "+v"(L.gw), "+v"(L.p2), "+v"(L.rr), "+v"(L.g));
+        asm volatile("" : "+v"(L.p1), "+v"(L.w1), "+v"(L.p2), "+v"(L.rr), "+v"(L.g));
         H3_STAMP(6);                                             // tile index math
 
         // next tile: global -> the other LDS buffer (last read by the previous tile's conv2 residual, one barrier
         // ago); its PF DMA instructions are issued one per input row inside conv1 and land during conv2
-        const H3Tile nx = h3_tile<Cfg>(a, has1 ? t1 : t);
+        H3Tile nx = cur;
+        if (has1) {
+            c_tx += sx;
+            const int cx = c_tx >= a.tiles_x;
+            c_tx -= cx ? a.tiles_x : 0;
+            c_ty += sy + cx;
+            const int cy = c_ty >= a.tiles_y;
+            c_ty -= cy ? a.tiles_y : 0;
+            nx.x0 = c_tx * Cfg::TW;
+            nx.y0 = c_ty * Cfg::TH;
+            nx.img = cur.img + sb_bytes + (cy ? img_bytes : 0);
+        }
         const char* nx_origin = reinterpret_cast<const char*>(a.in) + nx.img + ((ptrdiff_t)(nx.y0 - 2) * a.W + (nx.x0 - 2)) * 16;
         char* tnx = tin0 + (buf ^ 1) * Cfg::TIN_BYTES;
         const bool nx_interior = h3_interior<Cfg>(a, nx);
@@ -707,13 +805,13 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args
 #define H3R_CONV1(RV)                                                                                                       \
         do {                                                                                                               \
             if (nx_interior) {                                                                                             \
-                const H3DmaHook<Cfg, true> hook{a, nx, nx_origin, tnx, tid, wave, pfoff, has1};                            \
-                if (interior) h3r_conv1_run<Cfg, RV, true>(a, tin, tmid, w1, inv_s1, L, cur, o1, hook);                    \
-                else h3r_conv1_run<Cfg, RV, false>(a, tin, tmid, w1, inv_s1, L, cur, o1, hook);                            \
+                const H3DmaHook<Cfg, true, Plan::NROWS_MIN> hook{a, nx, nx_origin, tnx, tid, wave, pfoff, has1};           \
+                if (interior) h3r_conv1_run<Cfg, RV, true>(a, tin, tmid, w1, inv_s1, relu_floor, L, cur, o1, hook);                    \
+                else h3r_conv1_run<Cfg, RV, false>(a, tin, tmid, w1, inv_s1, relu_floor, L, cur, o1, hook);                            \
             } else {                                                                                                       \
-                const H3DmaHook<Cfg, false> hook{a, nx, nx_origin, tnx, tid, wave, pfoff, has1};                           \
-                if (interior) h3r_conv1_run<Cfg, RV, true>(a, tin, tmid, w1, inv_s1, L, cur, o1, hook);                    \
-                else h3r_conv1_run<Cfg, RV, false>(a, tin, tmid, w1, inv_s1, L, cur, o1, hook);                            \
+                const H3DmaHook<Cfg, false, Plan::NROWS_MIN> hook{a, nx, nx_origin, tnx, tid, wave, pfoff, has1};          \
+                if (interior) h3r_conv1_run<Cfg, RV, true>(a, tin, tmid, w1, inv_s1, relu_floor, L, cur, o1, hook);                    \
+                else h3r_conv1_run<Cfg, RV, false>(a, tin, tmid, w1, inv_s1, relu_floor, L, cur, o1, hook);                            \
             }                                                                                                              \
         } while (0)
         if (big) {
@@ -721,10 +819,19 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args
         } else {
             // strip group FIRST: at the end of conv1 its read -> MFMA -> write chain ran alone (the partner wave on the
             // SIMD was already parked at the barrier) and cost ~1100 cycles, all of it barrier time for the other waves
-            if (sg < Cfg::SG) {
-                const f32x4 v = h3r_group<Cfg::IW * 16, 2 * Cfg::IN_PLANE>(tin, L.gp1, L.gs1, w1);
-                if (interior) h3r_conv1_store<Cfg, true>(a, tmid, L.gw, v, inv_s1, 0, 0);
-                else h3r_conv1_store<Cfg, false>(a, tmid, L.gw, v, inv_s1, cur.y0 - 1 + L.srow, cur.x0 - 1 + L.scol);
+            // (8 rows x 2 columns per group; its lane addresses are rebuilt here, ~10 VALU, instead of living in VGPRs)
+#pragma unroll
+            for (int k = 0; k < Plan::SG_PER_WAVE; ++k) {
+                const int g = sg + k * Plan::N_SHORT;
+                if (g < Cfg::SG) {
+                    const int srow = min(8 * g + (n >> 1), Cfg::MH - 1);      // partial last group: clamp (same values twice)
+                    const int scol = Cfg::TW + (n & 1);
+                    const int bg = (q & 1) * Cfg::IN_PLANE + (srow * Cfg::IW + scol) * 16;
+                    const int gw = (q >> 1) * Cfg::MID_PLANE + (srow * Cfg::MW + scol) * 16 + (q & 1) * 8;
+                    const f32x4 v = h3r_group<Cfg::IW * 16, 2 * Cfg::IN_PLANE>(tin, bg + (q >> 1) * 16, bg + 32, w1);
+                    if (interior) h3r_conv1_store<Cfg, true>(a, tmid, gw, v, inv_s1, relu_floor, 0, 0);
+                    else h3r_conv1_store<Cfg, false>(a, tmid, gw, v, inv_s1, relu_floor, cur.y0 - 1 + srow, cur.x0 - 1 + scol);
+                }
             }
             H3R_CONV1(Plan::R1_SMALL);
         }
@@ -738,27 +845,35 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args
             char* out_row0 = reinterpret_cast<char*>(a.out) + cur.img + ((size_t)cur.y0 * a.W + cur.x0) * 16;
             const size_t rowbytes = (size_t)a.W * 16;
             const size_t lo_g = 2 * (size_t)plane_g;
-            auto epi2 = [&](const int o, f32x4 acc) {
-                // residual on the matrix pipe: acc += (s2 * I) x [x_hi | x_lo] -- exact (power-of-two times f16 in fp32)
-                // and one MFMA + one ds_read_b128 instead of two ds_read_b64 and 12 conversions / additions
-                const h8 xr = *reinterpret_cast<const h8*>(tin + L.rr + o * Cfg::IW * 16);
-                acc = MFMA_H(w2[12], xr, acc);
-                const f32x4 v = acc * inv_s2 + sh;
-                h4 hi, lo;
-                h3_split(v, hi, lo);
-                // out-of-image lanes store to a dump line: every wave issues exactly 2*R2 stores per tile
-                char* p = out_row0 + o * rowbytes + L.g;
-                char* pl = p + lo_g;
-                if (!interior && !(cur.y0 + o2 + o < a.H && cur.x0 + L.px < a.W)) {
-                    p = reinterpret_cast<char*>(a.dump) + lane * 8;
-                    pl = p;
+            struct Epi2 {
+                typedef h8 Pre;
+                enum { EXTRA_MFMA = 1 };
+                const FusedH3Args& a; const char* __restrict__ tin; h8 wres; char* out_row0; size_t rowbytes, lo_g;
+                float inv_s2; f32x4 sh; bool interior; int rr, y_base, x_px, lane; unsigned g;
+                // residual operand [x_hi | x_lo] of the centre pixel of output row o: requested one row step early
+                __device__ __forceinline__ Pre pre(const int o) const { return *reinterpret_cast<const h8*>(tin + rr + o * Cfg::IW * 16); }
+                // residual on the matrix pipe: acc += (s2 * I) x [x_hi | x_lo] -- exact (power-of-two times f16 in
+                // fp32) and one MFMA + one ds_read_b128 instead of two ds_read_b64 and 12 conversions / additions
+                __device__ __forceinline__ f32x4 finish(const f32x4 acc, const Pre& xr) const { return MFMA_H(wres, xr, acc); }
+                __device__ __forceinline__ void operator()(const int o, const f32x4 acc) const
+                {
+                    const f32x4 v = (H3_ABLATE & 64) ? acc : acc * inv_s2 + sh;
+                    h4 hi, lo;
+                    h3_split(v, hi, lo);
+                    // out-of-image lanes store to a dump line: every wave issues exactly 2*R2 stores per tile
+                    char* p = out_row0 + o * rowbytes + g;
+                    char* pl = p + lo_g;
+                    if (!interior && !(y_base + o < a.H && x_px < a.W)) {
+                        p = reinterpret_cast<char*>(a.dump) + lane * 8;
+                        pl = p;
+                    }
+                    if (H3_ABLATE & 2) { if (v.x == 12345.678f) *reinterpret_cast<h4*>(p) = hi + lo; }   // keeps the work live
+                    else {
+                        *reinterpret_cast<h4*>(p) = hi;
+                        *reinterpret_cast<h4*>(pl) = lo;
+                    }
                 }
-                if (H3_ABLATE & 2) { if (v.x == 12345.678f) *reinterpret_cast<h4*>(p) = hi + lo; }   // keeps the work live
-                else {
-                    *reinterpret_cast<h4*>(p) = hi;
-                    *reinterpret_cast<h4*>(pl) = lo;
-                }
-            };
+            } const epi2{a, tin, w2[12], out_row0, rowbytes, lo_g, inv_s2, sh, interior, L.rr, cur.y0 + o2, cur.x0 + L.px, lane, L.g};
             h3r_rows<Plan::R2, Cfg::MW * 16, 2 * Cfg::MID_PLANE>(tmid, L.p2, L.s2, w2, epi2, H3NoHook{});
         }
         // next tile's DMA landed <=> at most the 2*R2 stores above are outstanding (see fused_block_h3_kernel)
@@ -767,6 +882,7 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args
         H3_STAMP(4);                                             // wait for the next tile's DMA
         h3_barrier();
         H3_STAMP(5);                                             // barrier B
+        carry = nx;                                              // tile coordinates are computed once per tile
     }
 #if H3_ABLATE & 32
     if (a.dbg && lane == 0) {
@@ -776,6 +892,7 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args
 }
 
 using H3Default = H3Cfg<16, 32, 8>;
+using H3Small = H3Cfg<16, 16, 4>;
 
 static int g_h3_variant = 1;      // 1 (default): row-streaming kernel ; 0: group-per-pass kernel
 void bf_set_h3_variant(int v) { g_h3_variant = v < 0 ? 1 : v; }
@@ -790,7 +907,8 @@ static hipError_t launch_h3(void (*kernel)(FusedH3Args), const FusedH3Args& a, h
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    int grid = a.ntiles < 256 ? a.ntiles : 256;                 // one persistent workgroup per CU
+    const int resident = 256 * Cfg::WG_PER_CU;                  // persistent: every workgroup resident at once
+    int grid = a.ntiles < resident ? a.ntiles : resident;
     if (grid >= 8) grid -= grid % 8;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, s, a);
     return hipGetLastError();
@@ -798,10 +916,18 @@ static hipError_t launch_h3(void (*kernel)(FusedH3Args), const FusedH3Args& a, h
 
 hipError_t bf_launch_fused_block_h3(const FusedH3Args& args, hipStream_t s)
 {
-    using Cfg = H3Default;
     FusedH3Args a = args;
     if (!a.zeros || !a.dump) return hipErrorInvalidValue;
     if ((int64_t)a.H * a.W * 64 >= ((int64_t)1 << 32)) return hipErrorInvalidValue;      // 32-bit in-image offsets
+    if (g_h3_variant == 2) {                                    // two 4-wave workgroups per CU on 16x16 tiles
+        using Cfg = H3Small;
+        a.tiles_x = (a.W + Cfg::TW - 1) / Cfg::TW;
+        a.tiles_y = (a.H + Cfg::TH - 1) / Cfg::TH;
+        a.ntiles = a.B * a.tiles_x * a.tiles_y;
+        a.w1 = a.w1r; a.w2 = a.w2r;
+        return launch_h3<Cfg, 2>(fused_block_h3r_kernel<Cfg>, a, s);
+    }
+    using Cfg = H3Default;
     a.tiles_x = (a.W + Cfg::TW - 1) / Cfg::TW;
     a.tiles_y = (a.H + Cfg::TH - 1) / Cfg::TH;
     a.ntiles = a.B * a.tiles_x * a.tiles_y;
