@@ -80,6 +80,60 @@ def pmc_traffic(layers, batch, size, fused, kernel=None):
     return None
 
 
+def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
+    """configs[3]: resnet_color_1x18 training step, L1 loss (hinge 0.5), additive-gaussian synthetic batch, global batch =
+    --batch x world sharded over the ranks, one sum-all-reduce of the flat fp32 gradient buffer, fused clip + Adam."""
+    B = 32 if args.batch == 128 else args.batch            # per-GPU shard (256 global on 8 GPUs)
+    S = args.size
+    cfg = O.canonical_config(no_layers=args.layers)
+    spec = O.ResnetSpec.from_config(cfg["model"])
+    params, state = O.init_params(spec, seed=42, nontrivial_bn=False)
+    model = bf.model_builder(cfg["model"], device=f"cuda:{local_rank}").hydra
+    model.set_weights(params, state)
+    opt, _ = bf.optimizer_builder(cfg["train"]["optimizer"])
+    trainer = bf.DataParallelTrainer(model, bf.loss_function_builder(cfg["loss"]), opt)
+    trainer.broadcast_parameters()
+    clean, noisy = O.synthetic_batch(min(B, 8), S, S, sigma=20.0, seed=1234 + rank)
+    reps = (B + clean.shape[0] - 1) // clean.shape[0]
+    gt = torch.from_numpy(np.concatenate([clean] * reps)[:B].astype(np.float32)).cuda()
+    x = torch.from_numpy(np.concatenate([noisy] * reps)[:B].astype(np.float32)).cuda()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    total = None
+    for _ in range(max(args.warmup, 1)):
+        total = trainer.step(gt, x)[0]
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        total = trainer.step(gt, x)[0]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        # algorithmic FLOPs per image: fwd + dgrad + wgrad of every 3x3 16->16 conv, fwd + wgrad of the base conv, head fwd + bwd
+        per_px = 3 * args.layers * FLOP_PER_PX_BLOCK + 2 * 2 * 9 * 3 * 16 + 3 * 2 * (16 * 32 + 32 * 3)
+        value = B * world * args.steps / elapsed
+        print(json.dumps({
+            "metric": "training images/sec (256x256x3), resnet_1x18 data-parallel step", "value": value, "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"resnet_color_1x{args.layers}_bn_16x3x3 training step (L1 hinge 0.5, Adam, global clipnorm 1), "
+                                   f"batch={B}/GPU {S}x{S}x3 float32, one all-reduce of {model.n_params} fp32 gradients",
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+            "last_total_loss": float(total.item()),
+            "end_to_end_tflops": value / world * per_px * S * S / 1e12}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +147,9 @@ def main():
     ap.add_argument("--fused-tile", type=int, default=None, help="exact-fp32 fused-block tile geometry variant (A/B only)")
     ap.add_argument("--arith", type=int, default=1, help="1 = split-f16 fused blocks (default), 0 = exact-fp32 fused blocks")
     ap.add_argument("--h3-variant", type=int, default=None, help="split-f16 kernel variant (A/B only)")
+    ap.add_argument("--mode", choices=["inference", "train"], default="inference",
+                    help="train: BASELINE.json configs[3] -- one data-parallel training step per step (L1 loss, "
+                         "batch sharded over the ranks, ONE gradient all-reduce, clip + Adam); not the headline metric")
     args = ap.parse_args()
 
     import torch
@@ -115,6 +172,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    if args.mode == "train":
+        return train_bench(args, torch, bf, O, rank, local_rank, world, dist)
     cfg = O.canonical_config(no_layers=args.layers)
     spec = O.ResnetSpec.from_config(cfg["model"])
     params, state = O.init_params(spec, seed=42, nontrivial_bn=True)

@@ -546,7 +546,7 @@ __device__ __forceinline__ void h3r_rows_step(const char* __restrict__ src, cons
 #if H3_ABLATE & 512
         if constexpr (I >= 2) {
             acc_m2 = h3r_tap_row<PITCH, LO>(cur, w, 2, acc_m2);
-            acc_m2 = epi.finish(acc_m2, pre_m2);                // conv2: + residual MFMA
+            acc_m2 = epi.finish(I - 2, acc_m2, pre_m2);                // conv2: + residual MFMA
         }
         if constexpr (I >= 1 && I - 1 < R) acc_m1 = h3r_tap_row<PITCH, LO>(cur, w, 1, acc_m1);
         if constexpr (I >= 2) epi(I - 2, acc_m2);               // its result is 5 MFMAs old: no s_nop for the read
@@ -561,7 +561,7 @@ __device__ __forceinline__ void h3r_rows_step(const char* __restrict__ src, cons
             if constexpr (I < R) acc_0 = h3r_tap_mfma<PITCH, LO>(cur, w, 0, m, acc_0);
         }
         if constexpr (I >= 2) {
-            acc_m2 = epi.finish(acc_m2, pre_m2);                // conv2: + residual MFMA
+            acc_m2 = epi.finish(I - 2, acc_m2, pre_m2);                // conv2: + residual MFMA
             epi(I - 2, acc_m2);
         }
 #endif
@@ -681,7 +681,7 @@ __device__ __forceinline__ void h3r_conv1_run(const FusedH3Args& a, const char* 
         enum { EXTRA_MFMA = 0 };
         const FusedH3Args& a; char* __restrict__ tmid; float inv_s, relu_floor; int w1, gy0, gx;
         __device__ __forceinline__ Pre pre(const int) const { return Pre{}; }
-        __device__ __forceinline__ f32x4 finish(const f32x4 acc, const Pre&) const { return acc; }
+        __device__ __forceinline__ f32x4 finish(const int, const f32x4 acc, const Pre&) const { return acc; }
         __device__ __forceinline__ void operator()(const int o, const f32x4 v) const
         {
             h3r_conv1_store<Cfg, INTERIOR>(a, tmid, w1 + o * Cfg::MW * 16, v, inv_s, relu_floor, gy0 + o, gx);
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args
                 __device__ __forceinline__ Pre pre(const int o) const { return *reinterpret_cast<const h8*>(tin + rr + o * Cfg::IW * 16); }
                 // residual on the matrix pipe: acc += (s2 * I) x [x_hi | x_lo] -- exact (power-of-two times f16 in
                 // fp32) and one MFMA + one ds_read_b128 instead of two ds_read_b64 and 12 conversions / additions
-                __device__ __forceinline__ f32x4 finish(const f32x4 acc, const Pre& xr) const { return MFMA_H(wres, xr, acc); }
+                __device__ __forceinline__ f32x4 finish(const int, const f32x4 acc, const Pre& xr) const { return MFMA_H(wres, xr, acc); }
                 __device__ __forceinline__ void operator()(const int o, const f32x4 acc) const
                 {
                     const f32x4 v = (H3_ABLATE & 64) ? acc : acc * inv_s2 + sh;
@@ -891,6 +891,303 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args
 #endif
 }
 
+// ==========================================================================================================
+// Wave-specialised variant (fused_block_h3s_kernel): same arithmetic, layout and row streaming, but the workgroup's
+// waves split into conv1 waves (0..3) and conv2 waves (4..7) -- wave w and w+4 share a SIMD -- and the two
+// convolutions of CONSECUTIVE tiles run concurrently: in iteration k the conv1 waves turn tile k's input into its
+// intermediate tile while the conv2 waves finish tile k-1.  Both the input tile and the intermediate tile are double
+// buffered (14x32 tiles: 2 x 45 KB + 2 x 34 KB of LDS).  Versus the kernel above:
+//   * ONE barrier per tile instead of two, and the fill / drain steps of the two row pipelines are out of phase on
+//     every SIMD (stamps of the kernel above: 13 % of a wave's cycles at barriers; run fill/drain = R+2 steps per R rows);
+//   * runs of 8 and 7 rows instead of 5 and 4 (fewer fill/drain steps per row);
+//   * a wave holds ONE kernel's weights (52 VGPRs instead of 104), which pays for the 7 residual fragments a conv2
+//     wave fetches from the input tile one iteration early (so that the input buffer is free for the DMA of tile k+1
+//     right after the barrier).
+// The conv1 waves own the DMA (next tile, spread over their row steps, vmcnt(0) before the barrier: nothing else is
+// in their vector-memory queue); the conv2 waves own the stores and never wait for them.
+// ==========================================================================================================
+template <int TH_, int TW_>
+struct H3SCfg {
+    static constexpr int TH = TH_, TW = TW_, NW = 8, NT = 512, NA = 4, NB = 4;
+    static constexpr int MH = TH + 2, MW = TW + 2, IH = TH + 4, IW = TW + 4;
+    static constexpr int GPR = TW / 16;                                 // strips
+    static constexpr int IN_PLANE = (IH * IW * 16 + 255) / 256 * 256;   // bytes per input-tile plane (padded)
+    static constexpr int IN_PLANE_ELEMS = IN_PLANE / 16;
+    static constexpr int MID_PLANE = (MH * MW * 16 + 255) / 256 * 256;
+    static constexpr int IN_ELEMS = 4 * IN_PLANE_ELEMS;                 // 16-byte elements per input tile incl. plane pads
+    static constexpr int DMA_LANES = NA * 64;                           // the conv1 waves move the tile
+    static constexpr int PF = (IN_ELEMS + DMA_LANES - 1) / DMA_LANES;
+    static constexpr int TIN_BYTES = PF * DMA_LANES * 16;
+    static constexpr int TMID_BYTES = 4 * MID_PLANE;
+    static constexpr int LDS_BYTES = 2 * TIN_BYTES + 2 * TMID_BYTES;
+    static constexpr int R1 = MH / (NA / GPR), R2 = TH / (NB / GPR);    // rows per conv1 / conv2 wave
+    static constexpr int SG = (MH + 7) / 8;                             // strip groups
+    static constexpr int WG_PER_CU = 1;
+    static_assert(GPR == 2 && NA % GPR == 0 && MH % (NA / GPR) == 0 && TH % (NB / GPR) == 0, "wave plan");
+    static_assert(SG <= NA, "one strip group per conv1 wave at most");
+    static_assert(IN_ELEMS % 64 == 0, "DMA moves whole wave-instructions");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+template <class Cfg>
+__device__ __forceinline__ bool h3s_interior(const FusedH3Args& a, const H3Tile& t)
+{
+    return t.y0 >= 2 && t.y0 + Cfg::TH + 2 <= a.H && t.x0 >= 2 && t.x0 + Cfg::TW + 2 <= a.W;
+}
+
+// DMA wave-instruction I (of PF) of one conv1 wave: element e = (wave*64 + lane) + I*DMA_LANES of the padded tile
+template <class Cfg, bool INTERIOR, int I>
+__device__ __forceinline__ void h3s_dma_one(const FusedH3Args& a, const H3Tile& t, const char* origin, char* __restrict__ tin,
+                                            const int dlane, const int wave, const unsigned (&pfoff)[Cfg::PF], const bool live)
+{
+    const char* src = origin + pfoff[I];
+    const int e = dlane + I * Cfg::DMA_LANES;
+    const int r = e % Cfg::IN_PLANE_ELEMS;
+    bool use = live && r < Cfg::IH * Cfg::IW;                       // plane pad -> zero line
+    if ((I + 1) * Cfg::DMA_LANES > Cfg::IN_ELEMS) use = use && e < Cfg::IN_ELEMS;
+    if (!INTERIOR) {
+        const int row = r / Cfg::IW, col = r - row * Cfg::IW;
+        const int gy = t.y0 - 2 + row, gx = t.x0 - 2 + col;
+        use = use && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    }
+    if (!use) src = reinterpret_cast<const char*>(a.zeros);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(tin + (I * Cfg::DMA_LANES + wave * 64) * 16), 16, 0, 0);
+}
+
+// DMA instructions I, I + NROWS, ... after conv1's input row I
+template <class Cfg, bool NX_INTERIOR, int NROWS>
+struct H3SDmaHook {
+    const FusedH3Args& a;
+    const H3Tile& nx;
+    const char* origin;
+    char* tnx;
+    int dlane, wave;
+    const unsigned (&pfoff)[Cfg::PF];
+    bool live;
+    template <int I> __device__ __forceinline__ void row() const
+    {
+        if constexpr (I < NROWS && I < Cfg::PF) {
+            h3s_dma_one<Cfg, NX_INTERIOR, I>(a, nx, origin, tnx, dlane, wave, pfoff, live);
+            if constexpr (I + NROWS < Cfg::PF) {
+                static_assert(I + 2 * NROWS >= Cfg::PF, "at most two DMA instructions per row");
+                h3s_dma_one<Cfg, NX_INTERIOR, I + NROWS>(a, nx, origin, tnx, dlane, wave, pfoff, live);
+            }
+        }
+    }
+};
+
+// next tile of this workgroup's sequence (incremental: no divisions in the loop)
+struct H3SWalk {
+    int tx, ty, sx, sy, tiles_x, tiles_y;
+    size_t img, sb_bytes, img_bytes;
+    template <class Cfg> __device__ __forceinline__ H3Tile tile() const
+    {
+        H3Tile r;
+        r.x0 = tx * Cfg::TW; r.y0 = ty * Cfg::TH; r.img = img;
+        return r;
+    }
+    __device__ __forceinline__ void advance()
+    {
+        tx += sx;
+        const int cx = tx >= tiles_x;
+        tx -= cx ? tiles_x : 0;
+        ty += sy + cx;
+        const int cy = ty >= tiles_y;
+        ty -= cy ? tiles_y : 0;
+        img += sb_bytes + (cy ? img_bytes : 0);
+    }
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3s_kernel(FusedH3Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) char h3_lds[];
+    char* tmid0 = h3_lds;                                       // 2 x [4][MH][MW][8 f16]
+    char* tin0 = h3_lds + 2 * Cfg::TMID_BYTES;                  // 2 x [4][IH][IW][8 f16] (+ pad)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const bool role_a = wave < Cfg::NA;                         // conv1 waves
+    const int rw = role_a ? wave : wave - Cfg::NA;              // index within the role
+    const int wcol = (rw % Cfg::GPR) * 16, half = rw / Cfg::GPR;
+    const int px = wcol + n;
+    const unsigned plane_g = (unsigned)a.H * (unsigned)a.W * 16u;       // bytes per global plane
+
+    const int nxcd = gridDim.x >= 8 ? 8 : 1;
+    const int label = blockIdx.x % nxcd, slot = blockIdx.x / nxcd;
+    const int per_label = gridDim.x / nxcd;
+    const int chunk = (a.ntiles + nxcd - 1) / nxcd;
+    const int t_begin = label * chunk;
+    const int t_end = min(a.ntiles, t_begin + chunk);
+    const int t0 = t_begin + slot;
+    if (t0 >= t_end) return;
+    const int ntl = (t_end - t0 + per_label - 1) / per_label;   // tiles of this workgroup
+
+    H3SWalk walk;
+    {
+        const H3Tile c0 = h3_tile<Cfg>(a, t0);
+        walk.tx = c0.x0 / Cfg::TW; walk.ty = c0.y0 / Cfg::TH; walk.img = c0.img;
+        walk.tiles_x = a.tiles_x; walk.tiles_y = a.tiles_y;
+        walk.sx = per_label % a.tiles_x; walk.sy = (per_label / a.tiles_x) % a.tiles_y;
+        walk.img_bytes = (size_t)a.H * a.W * 64;
+        walk.sb_bytes = (size_t)(per_label / a.tiles_x / a.tiles_y) * walk.img_bytes;
+    }
+
+    if (role_a) {
+        // ------------------------------------------------------------------ conv1 waves --------------------------
+        const int o1 = half * Cfg::R1;
+        const int dlane = wave * 64 + lane;
+        unsigned pfoff[Cfg::PF];
+#pragma unroll
+        for (int i = 0; i < Cfg::PF; ++i) {
+            const int e = dlane + i * Cfg::DMA_LANES;
+            const int pl = e / Cfg::IN_PLANE_ELEMS, r = e - pl * Cfg::IN_PLANE_ELEMS;
+            const int row = r / Cfg::IW, col = r - row * Cfg::IW;
+            pfoff[i] = (unsigned)pl * plane_g + (unsigned)(row * a.W + col) * 16u;
+        }
+        h8 w1[13];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) w1[i] = reinterpret_cast<const h8*>(a.w1)[i * 64 + lane];
+        const float inv_s1 = a.aux[0];
+        const float relu_floor = a.act1_relu ? 0.f : -__builtin_inff();
+        const int b1 = (q & 1) * Cfg::IN_PLANE + (o1 * Cfg::IW + px) * 16;
+        int c_p1 = b1 + (q >> 1) * 16, c_w1 = (q >> 1) * Cfg::MID_PLANE + (o1 * Cfg::MW + px) * 16 + (q & 1) * 8;
+
+        H3Tile cur = walk.tile<Cfg>();
+        {   // prologue: the first tile, all PF instructions at once
+            const char* origin = reinterpret_cast<const char*>(a.in) + cur.img + ((ptrdiff_t)(cur.y0 - 2) * a.W + (cur.x0 - 2)) * 16;
+            const H3SDmaHook<Cfg, false, Cfg::PF> all{a, cur, origin, tin0, dlane, wave, pfoff, true};
+            all.template row<0>(); all.template row<1>(); all.template row<2>(); all.template row<3>(); all.template row<4>();
+            all.template row<5>(); all.template row<6>(); all.template row<7>(); all.template row<8>(); all.template row<9>();
+            all.template row<10>(); all.template row<11>();
+            static_assert(Cfg::PF <= 12, "prologue issues rows 0..11");
+            __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));               // also retires the weight / scale loads above
+            h3_barrier();
+        }
+        for (int k = 0; k <= ntl; ++k) {
+            if (k < ntl) {
+                const int buf = k & 1;
+                const char* tin = tin0 + buf * Cfg::TIN_BYTES;
+                char* tmid = tmid0 + buf * Cfg::TMID_BYTES;
+                const bool interior = h3s_interior<Cfg>(a, cur);
+                const bool has1 = k + 1 < ntl;
+                H3Tile nx = cur;
+                if (has1) { walk.advance(); nx = walk.tile<Cfg>(); }
+                const char* nx_origin = reinterpret_cast<const char*>(a.in) + nx.img + ((ptrdiff_t)(nx.y0 - 2) * a.W + (nx.x0 - 2)) * 16;
+                char* tnx = tin0 + (buf ^ 1) * Cfg::TIN_BYTES;
+                const bool nx_interior = h3s_interior<Cfg>(a, nx);
+                int p1 = c_p1, wr1 = c_w1;
+                asm volatile("" : "+v"(p1), "+v"(wr1));           // keeps LICM from hoisting every (constant + immediate) address
+                // strip group first (8 rows x 2 columns), on the first SG conv1 waves
+                if (wave < Cfg::SG) {
+                    const int srow = min(8 * wave + (n >> 1), Cfg::MH - 1);
+                    const int scol = Cfg::TW + (n & 1);
+                    const int bg = (q & 1) * Cfg::IN_PLANE + (srow * Cfg::IW + scol) * 16;
+                    const int gw = (q >> 1) * Cfg::MID_PLANE + (srow * Cfg::MW + scol) * 16 + (q & 1) * 8;
+                    const f32x4 v = h3r_group<Cfg::IW * 16, 2 * Cfg::IN_PLANE>(tin, bg + (q >> 1) * 16, bg + 32, w1);
+                    if (interior) h3r_conv1_store<Cfg, true>(a, tmid, gw, v, inv_s1, relu_floor, 0, 0);
+                    else h3r_conv1_store<Cfg, false>(a, tmid, gw, v, inv_s1, relu_floor, cur.y0 - 1 + srow, cur.x0 - 1 + scol);
+                }
+#define H3S_CONV1(INT, NXI)                                                                                                  \
+                do {                                                                                                         \
+                    const H3SDmaHook<Cfg, NXI, Cfg::R1 + 2> hook{a, nx, nx_origin, tnx, dlane, wave, pfoff, has1};            \
+                    struct Epi {                                                                                              \
+                        struct Pre {};                                                                                        \
+                        enum { EXTRA_MFMA = 0 };                                                                              \
+                        const FusedH3Args& a; char* __restrict__ tmid; float inv_s, relu_floor; int w1, gy0, gx;              \
+                        __device__ __forceinline__ Pre pre(const int) const { return Pre{}; }                                 \
+                        __device__ __forceinline__ f32x4 finish(const int, const f32x4 acc, const Pre&) const { return acc; } \
+                        __device__ __forceinline__ void operator()(const int o, const f32x4 v) const                          \
+                        {                                                                                                     \
+                            h3r_conv1_store<Cfg, INT>(a, tmid, w1 + o * Cfg::MW * 16, v, inv_s, relu_floor, gy0 + o, gx);     \
+                        }                                                                                                     \
+                    } const epi{a, tmid, inv_s1, relu_floor, wr1, cur.y0 - 1 + o1, cur.x0 - 1 + px};                          \
+                    h3r_rows<Cfg::R1, Cfg::IW * 16, 2 * Cfg::IN_PLANE>(tin, p1, p1 - (q >> 1) * 16 + 32, w1, epi, hook);      \
+                } while (0)
+                if (interior) { if (nx_interior) H3S_CONV1(true, true); else H3S_CONV1(true, false); }
+                else { if (nx_interior) H3S_CONV1(false, true); else H3S_CONV1(false, false); }
+#undef H3S_CONV1
+                cur = nx;
+                __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));           // the next tile has landed (only DMA in this wave's queue)
+            }
+            h3_barrier();
+        }
+    } else {
+        // ------------------------------------------------------------------ conv2 waves --------------------------
+        const int o2 = half * Cfg::R2;
+        h8 w2[13];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) w2[i] = reinterpret_cast<const h8*>(a.w2)[i * 64 + lane];
+        const float inv_s2 = a.aux[48];                             // BN scale is folded into the row-layout w2
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.aux + 32 + q * 4);
+        const int b2 = (q & 1) * Cfg::MID_PLANE + (o2 * Cfg::MW + px) * 16;
+        int c_p2 = b2 + (q >> 1) * 16;
+        // residual operand [x_hi | x_lo] of the centre pixel: lanes q < 2 read the hi planes, q >= 2 the lo planes
+        int c_rr = ((q & 1) + 2 * (q >> 1)) * Cfg::IN_PLANE + ((o2 + 2) * Cfg::IW + px + 2) * 16;
+        unsigned c_g = (unsigned)(q >> 1) * plane_g + (unsigned)(o2 * a.W + px) * 16u + (unsigned)(q & 1) * 8u;
+
+        __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));                   // weight / scale loads
+        h3_barrier();                                            // prologue barrier: tile 0 is in tin0
+        h8 res[Cfg::R2];
+        H3Tile prev = walk.tile<Cfg>();                          // tile k-1 of iteration k
+        for (int k = 0; k <= ntl; ++k) {
+            if (k >= 1) {
+                const int buf = (k - 1) & 1;
+                const char* tmid = tmid0 + buf * Cfg::TMID_BYTES;
+                const bool interior = h3s_interior<Cfg>(a, prev);
+                char* out_row0 = reinterpret_cast<char*>(a.out) + prev.img + ((size_t)prev.y0 * a.W + prev.x0) * 16;
+                int p2 = c_p2;
+                unsigned g = c_g;
+                asm volatile("" : "+v"(p2), "+v"(g));
+                struct Epi2 {
+                    struct Pre {};
+                    enum { EXTRA_MFMA = 1 };
+                    const FusedH3Args& a; h8 wres; char* out_row0; size_t rowbytes, lo_g;
+                    float inv_s2; f32x4 sh; bool interior; int y_base, x_px, lane; unsigned g;
+                    h8 res[Cfg::R2];
+                    __device__ __forceinline__ Pre pre(const int) const { return Pre{}; }
+                    // residual on the matrix pipe: acc += (s2 * I) x [x_hi | x_lo] (exact)
+                    __device__ __forceinline__ f32x4 finish(const int o, const f32x4 acc, const Pre&) const { return MFMA_H(wres, res[o], acc); }
+                    __device__ __forceinline__ void operator()(const int o, const f32x4 acc) const
+                    {
+                        const f32x4 v = acc * inv_s2 + sh;
+                        h4 hi, lo;
+                        h3_split(v, hi, lo);
+                        char* p = out_row0 + o * rowbytes + g;
+                        char* pl = p + lo_g;
+                        if (!interior && !(y_base + o < a.H && x_px < a.W)) {
+                            p = reinterpret_cast<char*>(a.dump) + lane * 8;
+                            pl = p;
+                        }
+                        *reinterpret_cast<h4*>(p) = hi;
+                        *reinterpret_cast<h4*>(pl) = lo;
+                    }
+                };
+                Epi2 epi2{a, w2[12], out_row0, (size_t)a.W * 16, 2 * (size_t)plane_g, inv_s2, sh, interior,
+                          prev.y0 + o2, prev.x0 + px, lane, g, {}};
+#pragma unroll
+                for (int o = 0; o < Cfg::R2; ++o) epi2.res[o] = res[o];
+                h3r_rows<Cfg::R2, Cfg::MW * 16, 2 * Cfg::MID_PLANE>(tmid, p2, p2 - (q >> 1) * 16 + 32, w2, epi2, H3NoHook{});
+                prev = walk.tile<Cfg>();
+            }
+            if (k < ntl) {
+                // residual fragments of tile k, one iteration early: the input buffer is then free for the DMA of
+                // tile k+2 right after the barrier below
+                if (k >= 1) { walk.advance(); prev = walk.tile<Cfg>(); }
+                const char* tin = tin0 + (k & 1) * Cfg::TIN_BYTES;
+                int rr = c_rr;
+                asm volatile("" : "+v"(rr));
+#pragma unroll
+                for (int o = 0; o < Cfg::R2; ++o) res[o] = *reinterpret_cast<const h8*>(tin + rr + o * Cfg::IW * 16);
+            }
+            h3_barrier();
+        }
+    }
+}
+
+using H3Spec = H3SCfg<14, 32>;
+
 using H3Default = H3Cfg<16, 32, 8>;
 using H3Small = H3Cfg<16, 16, 4>;
 
@@ -926,6 +1223,14 @@ hipError_t bf_launch_fused_block_h3(const FusedH3Args& args, hipStream_t s)
         a.ntiles = a.B * a.tiles_x * a.tiles_y;
         a.w1 = a.w1r; a.w2 = a.w2r;
         return launch_h3<Cfg, 2>(fused_block_h3r_kernel<Cfg>, a, s);
+    }
+    if (g_h3_variant == 3) {                                    // wave-specialised: conv1 waves / conv2 waves, 14x32 tiles
+        using Cfg = H3Spec;
+        a.tiles_x = (a.W + Cfg::TW - 1) / Cfg::TW;
+        a.tiles_y = (a.H + Cfg::TH - 1) / Cfg::TH;
+        a.ntiles = a.B * a.tiles_x * a.tiles_y;
+        a.w1 = a.w1r; a.w2 = a.w2r;
+        return launch_h3<Cfg, 3>(fused_block_h3s_kernel<Cfg>, a, s);
     }
     using Cfg = H3Default;
     a.tiles_x = (a.W + Cfg::TW - 1) / Cfg::TW;

@@ -50,21 +50,23 @@ hipError_t bf_launch_zero(float* p, int64_t n, hipStream_t s)
 // partial = [nblk][32] (sum[16], sumsq[16]) from the conv epilogue.  Outputs the folded
 // scale/shift for the apply pass and mean/inv for the backward pass.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, double count,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, double count,
                                                           const float* __restrict__ gamma, float* moving_mean,
                                                           float* moving_var, float eps, float momentum,
                                                           float* scale, float* shift, float* mean_inv)
 {
-    __shared__ double red[8][32];
+    // 32 stripes x 32 columns: one workgroup of 1024 threads (with 8 stripes this tiny kernel took 138 us per
+    // BatchNorm at 4096 partial rows -- 10 % of a training step); fixed summation order, fp64
+    __shared__ double red[32][32];
     const int ch = threadIdx.x & 31, stripe = threadIdx.x >> 5;
     double s = 0.0;
-    for (int r = stripe; r < nblk; r += 8) s += (double)partial[(size_t)r * 32 + ch];
+    for (int r = stripe; r < nblk; r += 32) s += (double)partial[(size_t)r * 32 + ch];
     red[stripe][ch] = s;
     __syncthreads();
     if (threadIdx.x < 16) {
         const int c = threadIdx.x;
         double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < 8; ++k) { s1 += red[k][c]; s2 += red[k][16 + c]; }
+        for (int k = 0; k < 32; ++k) { s1 += red[k][c]; s2 += red[k][16 + c]; }
         const double mean = s1 / count;
         double var = s2 / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -84,7 +86,7 @@ hipError_t bf_launch_bn_finalize(const float* partial, int nblk, double count, c
                                  float* moving_var, float eps, float momentum, float* scale, float* shift,
                                  float* mean_inv, hipStream_t s)
 {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, s, partial, nblk, count, gamma, moving_mean, moving_var,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, s, partial, nblk, count, gamma, moving_mean, moving_var,
                        eps, momentum, scale, shift, mean_inv);
     return hipGetLastError();
 }
@@ -162,20 +164,22 @@ hipError_t bf_launch_bn_bwd_reduce(const float* dy, const float* c, float* parti
 
 // pass 2: dgamma = sum dy*xhat ; dc = k1*dy + k2*c + k3 with
 //   k1 = gamma*inv, k2 = -gamma*inv^2*mean(dy*xhat), k3 = -gamma*inv*mean(dy) + gamma*inv^2*mean*mean(dy*xhat)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, double count,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, double count,
                                                               const float* __restrict__ gamma, const float* __restrict__ mean_inv,
                                                               float* coef, float* dgamma)
 {
-    __shared__ double red[8][32];
+    // 32 stripes x 32 columns: one workgroup of 1024 threads (with 8 stripes this tiny kernel took 138 us per
+    // BatchNorm at 4096 partial rows -- 10 % of a training step); fixed summation order, fp64
+    __shared__ double red[32][32];
     const int ch = threadIdx.x & 31, stripe = threadIdx.x >> 5;
     double s = 0.0;
-    for (int r = stripe; r < nblk; r += 8) s += (double)partial[(size_t)r * 32 + ch];
+    for (int r = stripe; r < nblk; r += 32) s += (double)partial[(size_t)r * 32 + ch];
     red[stripe][ch] = s;
     __syncthreads();
     if (threadIdx.x < 16) {
         const int c = threadIdx.x;
         double sdy = 0.0, sdyc = 0.0;
-        for (int k = 0; k < 8; ++k) { sdy += red[k][c]; sdyc += red[k][16 + c]; }
+        for (int k = 0; k < 32; ++k) { sdy += red[k][c]; sdyc += red[k][16 + c]; }
         const double mean = mean_inv[c], inv = mean_inv[16 + c], g = gamma[c];
         const double sdyx = (sdyc - mean * sdy) * inv;          // sum dy*xhat
         dgamma[c] = (float)sdyx;
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 hipError_t bf_launch_bn_bwd_finalize(const float* partial, int nblk, double count, const float* gamma,
                                      const float* mean_inv, float* coef, float* dgamma, hipStream_t s)
 {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, s, partial, nblk, count, gamma, mean_inv, coef, dgamma);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, s, partial, nblk, count, gamma, mean_inv, coef, dgamma);
     return hipGetLastError();
 }
 

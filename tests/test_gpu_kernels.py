@@ -128,7 +128,7 @@ def test_fused_block_many_tiles_persistent_schedule(fused_tile):
 
 
 # ---- split-f16 ("f16x3") fused block: same oracle, same bar as the exact-fp32 kernels ---------------------
-@pytest.fixture(params=[1, 0, 2], ids=["rows", "groups", "rows16x16"], autouse=False)
+@pytest.fixture(params=[1, 0, 2, 3], ids=["rows", "groups", "rows16x16", "specialised"], autouse=False)
 def h3_variant(request):
     """both split-f16 kernels (row-streaming = default, group-per-pass) must pass the same parity tests."""
     import blind_image_denoising_amd as bf
