@@ -87,6 +87,7 @@ struct BaseConvArgs {
     int B, Hs, Ws, H, W, cin, k, in_is_u8, act_relu;
     float v_min, v_max;
     int out_split;        // 1: write split-planar f16 hi/lo (input of the f16x3 blocks) instead of fp32 NHWC
+    int* status;          // inference: forward status word, zeroed here (first kernel of a forward); may be NULL
 };
 hipError_t bf_launch_base_conv(const BaseConvArgs& a, hipStream_t s);
 // dW[k,k,cin,16] = sum xn (x) dy ; partial = [grid][k*k*cin*16]
@@ -103,7 +104,10 @@ struct HeadArgs {
     int B, H, W, Ho, Wo, hf, cout, act, out_is_u8, denormalize;
     float v_min, v_max, leaky_alpha;
     int feat_split;       // 1: feat is split-planar f16 hi/lo
+    int* status;          // |= BF_STATUS_F16_RANGE when a split-planar feature is not finite (f16 overflow upstream); may be NULL
 };
+#define BF_STATUS_BYTES 1024  // tail of the inference workspace: [0] status word, [256, 768) store sink of out-of-image lanes
+
 hipError_t bf_launch_head(const HeadArgs& a, hipStream_t s);
 
 struct HeadTrainArgs {

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256) void base_conv_kernel(BaseConvArgs a)
     const int ty = t % tiles_y;
     const int b = t / tiles_y;
     const int y0 = ty * BC_T, x0 = tx * BC_T;
+    if (a.status && blockIdx.x == 0 && threadIdx.x == 0) *a.status = 0;       // first kernel of a forward
     const float range = a.v_max - a.v_min;       // true division: (x - min) / (max - min) - 0.5 is exact for mid-grey
     for (int n = threadIdx.x; n < IT * IT * CIN; n += 256) {
         const int ci = n % CIN, px = (n / CIN) % IT, row = n / (CIN * IT);
@@ -248,11 +249,15 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a)
             const char* base = reinterpret_cast<const char*>(a.feat) + (int64_t)b * hw * 64 + ((int64_t)y * a.W + x) * 16;
             const h8 hi0 = *reinterpret_cast<const h8*>(base), hi1 = *reinterpret_cast<const h8*>(base + hw * 16);
             const h8 lo0 = *reinterpret_cast<const h8*>(base + hw * 32), lo1 = *reinterpret_cast<const h8*>(base + hw * 48);
+            bool finite = true;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 f[c] = (float)hi0[c] + (float)lo0[c];
                 f[8 + c] = (float)hi1[c] + (float)lo1[c];
+                finite = finite && fabsf(f[c]) <= 3.0e38f && fabsf(f[8 + c]) <= 3.0e38f;      // false for inf and NaN
             }
+            // an activation left the f16 range somewhere in the split-f16 blocks (inf / NaN propagate to here)
+            if (!finite && a.status) atomicOr(a.status, BF_STATUS_F16_RANGE);
         } else {
             const float4* fp = reinterpret_cast<const float4*>(a.feat + (((int64_t)b * a.H + y) * a.W + x) * 16);
 #pragma unroll

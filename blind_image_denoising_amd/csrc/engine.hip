@@ -329,7 +329,7 @@ extern "C" int64_t bf_workspace_bytes(bf_handle h, int mode, int B, int H, int W
     if (!h || B <= 0 || H <= 0 || W <= 0) return -1;
     if (mode == BF_MODE_INFERENCE) {
         const int Hp = pow2_target(H), Wp = pow2_target(W);      // u8 path pads; f32 path needs <= this
-        return (int64_t)B * Hp * Wp * 16 * 4 * 3;
+        return (int64_t)B * Hp * Wp * 16 * 4 * 3 + BF_STATUS_BYTES;
     }
     return train_layout(h, B, H, W).total * 4;
 }
@@ -343,8 +343,10 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
     const bf_resnet_desc& d = h->d;
     const int64_t act_bytes = (int64_t)B * H * W * 16 * 4;
     if (!ws || (uintptr_t)ws % 16) return fail(h, BF_EWORKSPACE, "workspace must be a 16-byte aligned device buffer");
-    if (ws_bytes < act_bytes * 3) return fail(h, BF_EWORKSPACE, "workspace too small: %lld < %lld bytes", (long long)ws_bytes,
-                                              (long long)(act_bytes * 3));
+    if (ws_bytes < act_bytes * 3 + BF_STATUS_BYTES)
+        return fail(h, BF_EWORKSPACE, "workspace too small: %lld < %lld bytes", (long long)ws_bytes,
+                    (long long)(act_bytes * 3 + BF_STATUS_BYTES));
+    int* status = (int*)((char*)ws + (ws_bytes - BF_STATUS_BYTES) / 4 * 4);
     float* buf[3] = {(float*)ws, (float*)((char*)ws + act_bytes), (float*)((char*)ws + 2 * act_bytes)};
 
     BaseConvArgs ba;
@@ -355,6 +357,7 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
     // split-f16 blocks keep the activations split-planar between base conv and head (same bytes as fp32)
     const int h3 = h->fused_blocks && h->arith == 1 && d.no_layers > 0;
     ba.out_split = h3;
+    ba.status = status;
     BF_HIP(bf_launch_base_conv(ba, s), "base_conv");
 
     int cur = 0;
@@ -368,7 +371,7 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
             fa.w1 = b3; fa.w2 = b3 + BF_H3_WPACK_FLOATS; fa.aux = b3 + 2 * BF_H3_WPACK_FLOATS;
             fa.w1r = fa.aux + 64; fa.w2r = fa.aux + 64 + BF_H3R_WPACK_FLOATS;
             fa.B = B; fa.H = H; fa.W = W; fa.tiles_x = fa.tiles_y = fa.ntiles = 0;
-            fa.act1_relu = d.activation == BF_ACT_RELU; fa.zeros = pk + h->k_zero; fa.dump = buf[2]; fa.dbg = nullptr;
+            fa.act1_relu = d.activation == BF_ACT_RELU; fa.zeros = pk + h->k_zero; fa.dump = (char*)status + 256; fa.dbg = nullptr;
             BF_HIP(bf_launch_fused_block_h3(fa, s), "fused_block_h3");
             cur ^= 1;
         } else if (h->fused_blocks) {
@@ -406,6 +409,7 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
     ha.act = d.head_activation; ha.out_is_u8 = out_is_u8; ha.denormalize = d.denormalize;
     ha.v_min = d.v_min; ha.v_max = d.v_max; ha.leaky_alpha = d.leaky_alpha;
     ha.feat_split = h3;
+    ha.status = status;
     BF_HIP(bf_launch_head(ha, s), "head");
     return BF_OK;
 }
@@ -600,7 +604,7 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     BaseConvArgs ba;
     ba.in = noisy; ba.out = A(0); ba.w = params + h->p_base;
     ba.B = B; ba.Hs = H; ba.Ws = W; ba.H = H; ba.W = W; ba.cin = d.in_channels; ba.k = d.kernel_size; ba.in_is_u8 = 0;
-    ba.act_relu = 0; ba.v_min = d.v_min; ba.v_max = d.v_max; ba.out_split = 0;
+    ba.act_relu = 0; ba.v_min = d.v_min; ba.v_max = d.v_max; ba.out_split = 0; ba.status = nullptr;
     BF_HIP(bf_launch_base_conv(ba, s), "base_conv");
     const int conv_grid = bf_conv3x3_c16_grid(B, H, W);
     for (int i = 0; i < N; ++i) {

@@ -327,7 +327,23 @@ class HydraModel:
             ws = self.workspace(N.BF_MODE_INFERENCE, B, H, W)
             N.check(self._lib.bf_forward_f32(self._h, N.ptr(self.packed()), N.ptr(x), N.ptr(out), B, H, W,
                                              N.ptr(ws), ws.numel(), N.stream_ptr(x)), self._h, "bf_forward_f32")
+            if was_numpy:
+                self.check_status()
         return out.cpu().numpy() if was_numpy else out
+
+    def check_status(self):
+        """Reads the status word of the last inference forward (synchronises the stream): raises when an
+        activation left the f16 range inside the split-f16 blocks -- the result is then not trustworthy and the
+        exact-fp32 kernels (`set_option("arith", 0)`) are the ones to use for these weights."""
+        ws = self._workspace
+        if ws is None:
+            return
+        n = ws.numel()
+        off = (n - N.BF_STATUS_BYTES) // 4 * 4
+        status = int(ws[off:off + 4].view(torch.int32).item())
+        if status & N.BF_STATUS_F16_RANGE:
+            raise FloatingPointError("an activation left the f16 range (|x| >= 65504) inside the split-f16 residual "
+                                     "blocks; call set_option('arith', 0) to run the exact-fp32 kernels")
 
     def predict(self, x):
         return self(x, training=False)

@@ -53,4 +53,6 @@ class DenoiserModule:
             x = torch.zeros((B, Hp, Wp, C), dtype=torch.float32, device=hydra.device)
             x[:, :H, :W, :] = image.to(torch.float32)
             out = hydra(x, training=False)[:, :H, :W, :].contiguous()
+        if was_numpy:
+            hydra.check_status()          # host arrays are handed back: the stream is synchronised anyway
         return out.cpu().numpy() if was_numpy else out

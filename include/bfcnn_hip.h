@@ -181,6 +181,12 @@ int bf_strided_slice2(const float* in, float* out, int batch, int height, int wi
 
 /* ---- options and diagnostics (not part of the drop-in surface; used by tests/) ------------- */
 
+/* Inference forwards keep a status word in the LAST 1024 bytes of the workspace they are given (ws + ws_bytes - 1024,
+ * int32; the rest of that tail is kernel scratch): 0 after a clean forward; bit BF_STATUS_F16_RANGE is set when an activation left the f16 range inside the
+ * split-f16 blocks (the output is then not trustworthy: re-run with option "arith" = 0).  Reading it needs a stream
+ * synchronisation, which is the caller's decision (the Python host checks it whenever it hands back host arrays). */
+#define BF_STATUS_F16_RANGE 1
+
 /* "fused_blocks" = 1 (default): one kernel per residual block; 0: one kernel per convolution.
  * "arith" = 1 (default): fused inference blocks run split-f16 ("f16x3": x = hi + lo in f16, three products,
  *   fp32 accumulation) on the f16 matrix cores, ~fp32 accuracy, needs |activation| < 65504;

@@ -146,6 +146,32 @@ def test_full_size_config_properties():
     assert out.min() >= 0 and out.max() <= 255
 
 
+def test_f16_range_guard():
+    """split-f16 blocks need |activation| < 65504: weights that blow the activations up must be reported (status
+    word -> FloatingPointError when host arrays are handed back), and the exact-fp32 kernels must still be right."""
+    cfg, spec, params, state, m = _model(3, seed=9)
+    big = params.copy()
+    off = spec.offsets()
+    for name in ("base/kernel", "block0/conv0/kernel"):
+        o, shape = off[name]
+        big[o:o + int(np.prod(shape))] *= 3000.0
+    m.set_weights(big, state)
+    _, noisy = O.synthetic_batch(1, 32, 32, seed=4)
+    x = noisy.astype(np.float32)
+    ref = O.hydra_forward(spec, big, state, x.astype(np.float64))
+    assert np.isfinite(ref).all()
+    with pytest.raises(FloatingPointError):
+        m(x)
+    with pytest.raises(FloatingPointError):
+        bf.DenoiserModule(m)(noisy)
+    m.set_option("arith", 0)
+    got = m(x)                                        # exact fp32: no range limit
+    assert np.isfinite(got).all() and np.abs(got - ref).max() <= 0.6     # saturated tanh head: coarse bar
+    m.set_option("arith", 1)
+    m.set_weights(params, state)
+    _check_f32(m(x), O.hydra_forward(spec, params, state, x.astype(np.float64)))    # status word is cleared by the next forward
+
+
 def test_errors_surface_as_python_exceptions():
     cfg, spec, params, state, m = _model(1)
     with pytest.raises(ValueError):

@@ -98,8 +98,8 @@ def test_create_rejects_what_the_reference_rejects():
 def test_workspace_and_packed_queries():
     m = bf.model_builder(O.canonical_config(no_layers=6)["model"], device="cpu").hydra
     L = N.lib()
-    assert L.bf_workspace_bytes(m._h, N.BF_MODE_INFERENCE, 64, 256, 256) == 3 * 64 * 256 * 256 * 16 * 4
-    assert L.bf_workspace_bytes(m._h, N.BF_MODE_INFERENCE, 1, 200, 300) == 3 * 256 * 512 * 16 * 4   # pow2 padded
+    assert L.bf_workspace_bytes(m._h, N.BF_MODE_INFERENCE, 64, 256, 256) == 3 * 64 * 256 * 256 * 16 * 4 + N.BF_STATUS_BYTES
+    assert L.bf_workspace_bytes(m._h, N.BF_MODE_INFERENCE, 1, 200, 300) == 3 * 256 * 512 * 16 * 4 + N.BF_STATUS_BYTES   # pow2 padded
     assert L.bf_workspace_bytes(m._h, N.BF_MODE_TRAIN, 2, 32, 32) > (3 * 6 + 2) * 2 * 32 * 32 * 16 * 4
     assert L.bf_workspace_bytes(m._h, 0, 0, 8, 8) == -1
     assert L.bf_packed_bytes(m._h) % 256 == 0
