@@ -469,30 +469,32 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3_kernel(FusedH3Args 
 // ==========================================================================================================
 template <int PITCH, int LO>
 struct H3RowFrag {
-    h8 ph, pl, sh, sl;
+    // ph / pl: taps (dy,0)|(dy,1) from the hi / lo planes.  s: tap (dy,2) as [x_hi | x_lo] -- lanes q < 2 read the hi plane,
+    // q >= 2 the lo plane of the SAME pixel (the caller's vs carries the + LO of the upper lane half): one read where
+    // [x_hi | x_hi] and [x_lo | x_lo] took two, and an LDS read costs a wave ~16 issue cycles it cannot spend on MFMAs
+    h8 ph, pl, s;
     __device__ __forceinline__ void load(const char* __restrict__ src, const int vp, const int vs, const int row)
     {
         ph = *reinterpret_cast<const h8*>(src + vp + row * PITCH);
         pl = *reinterpret_cast<const h8*>(src + vp + row * PITCH + LO);
-        sh = *reinterpret_cast<const h8*>(src + vs + row * PITCH);
-        sl = *reinterpret_cast<const h8*>(src + vs + row * PITCH + LO);
+        s = *reinterpret_cast<const h8*>(src + vs + row * PITCH);
     }
 };
 
-// the five MFMAs of one (input row, dy) pair; w: [dy*4 + {pair hi, pair lo, single [hi|lo], single [hi|0]}]
+// the five MFMAs of one (input row, dy) pair; w: [dy*4 + {pair hi, pair lo, single [hi|hi], single [lo|0]}]
 template <int PITCH, int LO>
 __device__ __forceinline__ f32x4 h3r_tap_row(const H3RowFrag<PITCH, LO>& x, const h8 (&w)[13], const int dy, f32x4 acc)
 {
     // ablations 4 / 8: conv2 reads the intermediate tile (PITCH = MW*16 is not a multiple of 64 for TW = 32), conv1 the input tile
     if (((H3_ABLATE & 4) && PITCH % 64 != 0) || ((H3_ABLATE & 8) && PITCH % 64 == 0)) {
-        acc[0] += (float)x.ph[0] + (float)x.pl[1] + (float)x.sh[2] + (float)x.sl[3];      // keeps the LDS reads live
+        acc[0] += (float)x.ph[0] + (float)x.pl[1] + (float)x.s[2];      // keeps the LDS reads live
         return acc;
     }
     acc = MFMA_H(w[dy * 4 + 0], x.ph, acc);
     acc = MFMA_H(w[dy * 4 + 1], x.ph, acc);
     acc = MFMA_H(w[dy * 4 + 0], x.pl, acc);
-    acc = MFMA_H(w[dy * 4 + 2], x.sh, acc);
-    acc = MFMA_H(w[dy * 4 + 3], x.sl, acc);
+    acc = MFMA_H(w[dy * 4 + 2], x.s, acc);
+    acc = MFMA_H(w[dy * 4 + 3], x.s, acc);
     return acc;
 }
 
@@ -501,15 +503,15 @@ template <int PITCH, int LO>
 __device__ __forceinline__ f32x4 h3r_tap_mfma(const H3RowFrag<PITCH, LO>& x, const h8 (&w)[13], const int dy, const int m, f32x4 acc)
 {
     if (((H3_ABLATE & 4) && PITCH % 64 != 0) || ((H3_ABLATE & 8) && PITCH % 64 == 0)) {
-        if (m == 0) acc[0] += (float)x.ph[0] + (float)x.pl[1] + (float)x.sh[2] + (float)x.sl[3];
+        if (m == 0) acc[0] += (float)x.ph[0] + (float)x.pl[1] + (float)x.s[2];
         return acc;
     }
     switch (m) {
         case 0: return MFMA_H(w[dy * 4 + 0], x.ph, acc);
         case 1: return MFMA_H(w[dy * 4 + 1], x.ph, acc);
         case 2: return MFMA_H(w[dy * 4 + 0], x.pl, acc);
-        case 3: return MFMA_H(w[dy * 4 + 2], x.sh, acc);
-        default: return MFMA_H(w[dy * 4 + 3], x.sl, acc);
+        case 3: return MFMA_H(w[dy * 4 + 2], x.s, acc);
+        default: return MFMA_H(w[dy * 4 + 3], x.s, acc);
     }
 }
 
@@ -715,11 +717,11 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args
     {
         const int b1 = (q & 1) * Cfg::IN_PLANE + (o1 * Cfg::IW + L0.px) * 16;
         L0.p1 = b1 + (q >> 1) * 16;
-        L0.s1 = b1 + 32;
+        L0.s1 = b1 + 32 + (q >> 1) * 2 * Cfg::IN_PLANE;
         L0.w1 = (q >> 1) * Cfg::MID_PLANE + (o1 * Cfg::MW + L0.px) * 16 + (q & 1) * 8;
         const int b2 = (q & 1) * Cfg::MID_PLANE + (o2 * Cfg::MW + L0.px) * 16;
         L0.p2 = b2 + (q >> 1) * 16;
-        L0.s2 = b2 + 32;
+        L0.s2 = b2 + 32 + (q >> 1) * 2 * Cfg::MID_PLANE;
         // residual operand [x_hi | x_lo] of the centre pixel: lanes q < 2 read the hi planes, q >= 2 the lo planes
         L0.rr = ((q & 1) + 2 * (q >> 1)) * Cfg::IN_PLANE + ((o2 + 2) * Cfg::IW + L0.px + 2) * 16;
         L0.g = (unsigned)(q >> 1) * plane_g + (unsigned)(o2 * a.W + L0.px) * 16u + (unsigned)(q & 1) * 8u;
@@ -828,7 +830,7 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args
                     const int scol = Cfg::TW + (n & 1);
                     const int bg = (q & 1) * Cfg::IN_PLANE + (srow * Cfg::IW + scol) * 16;
                     const int gw = (q >> 1) * Cfg::MID_PLANE + (srow * Cfg::MW + scol) * 16 + (q & 1) * 8;
-                    const f32x4 v = h3r_group<Cfg::IW * 16, 2 * Cfg::IN_PLANE>(tin, bg + (q >> 1) * 16, bg + 32, w1);
+                    const f32x4 v = h3r_group<Cfg::IW * 16, 2 * Cfg::IN_PLANE>(tin, bg + (q >> 1) * 16, bg + 32 + (q >> 1) * 2 * Cfg::IN_PLANE, w1);
                     if (interior) h3r_conv1_store<Cfg, true>(a, tmid, gw, v, inv_s1, relu_floor, 0, 0);
                     else h3r_conv1_store<Cfg, false>(a, tmid, gw, v, inv_s1, relu_floor, cur.y0 - 1 + srow, cur.x0 - 1 + scol);
                 }
@@ -1085,7 +1087,7 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3s_kernel(FusedH3Args
                     const int scol = Cfg::TW + (n & 1);
                     const int bg = (q & 1) * Cfg::IN_PLANE + (srow * Cfg::IW + scol) * 16;
                     const int gw = (q >> 1) * Cfg::MID_PLANE + (srow * Cfg::MW + scol) * 16 + (q & 1) * 8;
-                    const f32x4 v = h3r_group<Cfg::IW * 16, 2 * Cfg::IN_PLANE>(tin, bg + (q >> 1) * 16, bg + 32, w1);
+                    const f32x4 v = h3r_group<Cfg::IW * 16, 2 * Cfg::IN_PLANE>(tin, bg + (q >> 1) * 16, bg + 32 + (q >> 1) * 2 * Cfg::IN_PLANE, w1);
                     if (interior) h3r_conv1_store<Cfg, true>(a, tmid, gw, v, inv_s1, relu_floor, 0, 0);
                     else h3r_conv1_store<Cfg, false>(a, tmid, gw, v, inv_s1, relu_floor, cur.y0 - 1 + srow, cur.x0 - 1 + scol);
                 }
@@ -1103,7 +1105,7 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3s_kernel(FusedH3Args
                             h3r_conv1_store<Cfg, INT>(a, tmid, w1 + o * Cfg::MW * 16, v, inv_s, relu_floor, gy0 + o, gx);     \
                         }                                                                                                     \
                     } const epi{a, tmid, inv_s1, relu_floor, wr1, cur.y0 - 1 + o1, cur.x0 - 1 + px};                          \
-                    h3r_rows<Cfg::R1, Cfg::IW * 16, 2 * Cfg::IN_PLANE>(tin, p1, p1 - (q >> 1) * 16 + 32, w1, epi, hook);      \
+                    h3r_rows<Cfg::R1, Cfg::IW * 16, 2 * Cfg::IN_PLANE>(tin, p1, p1 - (q >> 1) * 16 + 32 + (q >> 1) * 2 * Cfg::IN_PLANE, w1, epi, hook); \
                 } while (0)
                 if (interior) { if (nx_interior) H3S_CONV1(true, true); else H3S_CONV1(true, false); }
                 else { if (nx_interior) H3S_CONV1(false, true); else H3S_CONV1(false, false); }
@@ -1168,7 +1170,7 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3s_kernel(FusedH3Args
                           prev.y0 + o2, prev.x0 + px, lane, g, {}};
 #pragma unroll
                 for (int o = 0; o < Cfg::R2; ++o) epi2.res[o] = res[o];
-                h3r_rows<Cfg::R2, Cfg::MW * 16, 2 * Cfg::MID_PLANE>(tmid, p2, p2 - (q >> 1) * 16 + 32, w2, epi2, H3NoHook{});
+                h3r_rows<Cfg::R2, Cfg::MW * 16, 2 * Cfg::MID_PLANE>(tmid, p2, p2 - (q >> 1) * 16 + 32 + (q >> 1) * 2 * Cfg::MID_PLANE, w2, epi2, H3NoHook{});
                 prev = walk.tile<Cfg>();
             }
             if (k < ntl) {
@@ -1294,7 +1296,7 @@ __global__ __launch_bounds__(256) void pack_h3_kernel(const float* __restrict__ 
         const _Float16 lo = (_Float16)(ws - (float)hi);
         o[idx] = part == 0 ? hi : (part == 1 ? lo : (_Float16)0.f);
     }
-    // row-streaming layout: [dy*4 + {pair hi, pair lo, single [hi | lo], single [hi | 0]}][lane][8], [12] = sr * identity.
+    // row-streaming layout: [dy*4 + {pair hi, pair lo, single [hi | hi], single [lo | 0]}][lane][8], [12] = sr * identity.
     // conv2 (which == 1): the folded BN scale is multiplied INTO the weights (per output channel) and the kernel adds the
     // residual as (sr * I) x [x_hi | x_lo] on the matrix pipe, so sr must itself be an f16 number: sr <= 2^15.
     __shared__ float s_fold[16];
@@ -1342,8 +1344,8 @@ __global__ __launch_bounds__(256) void pack_h3_kernel(const float* __restrict__ 
         int tap, part;
         if (kind == 0) { tap = dy * 3 + half; part = 0; }
         else if (kind == 1) { tap = dy * 3 + half; part = 1; }
-        else if (kind == 2) { tap = dy * 3 + 2; part = half; }
-        else { tap = dy * 3 + 2; part = half ? 2 : 0; }
+        else if (kind == 2) { tap = dy * 3 + 2; part = 0; }                 // [w_hi | w_hi] x [x_hi | x_lo]
+        else { tap = dy * 3 + 2; part = half ? 2 : 1; }                       // [w_lo | 0]    x [x_hi | x_lo]
         const float ws = w[(tap * 16 + cin) * 16 + cout] * s_fold[cout] * sr;
         const _Float16 hi = (_Float16)ws;
         const _Float16 lo = (_Float16)(ws - (float)hi);
