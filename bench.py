@@ -80,6 +80,42 @@ def pmc_traffic(layers, batch, size, fused, kernel=None):
     return None
 
 
+def pyramid_bench(args, torch, bf, O, rank, local_rank, world, dist):
+    """configs[4]'s resampling part (pyramid.py + upsampling.py): 3-level Laplacian pyramid + its inverse on a
+    [32,512,512,3] float32 batch; HBM-bound kernels, so the figure of merit is algorithmic GB/s against the 8 TB/s roof.
+    Algorithmic bytes (4 B elements, n = B*H*W*C): split level l (n_l elements): avg-pool reads n_l writes n_l/4, the fused
+    x - up(down) reads n_l/4 + n_l and writes n_l -> 3.5 n_l; merge level l: reads n_l/4 + n_l, writes n_l -> 2.25 n_l."""
+    B, S, C, levels = (32 if args.batch == 128 else args.batch), (512 if args.size == 256 else args.size), 3, 3
+    x = (torch.rand((B, S, S, C), device=f"cuda:{local_rank}") - 0.5).contiguous()
+    cfg = {"type": "laplacian", "levels": levels, "kernel_size": (5, 5)}
+    pyr, inv = bf.build_pyramid_model((S, S, C), cfg), bf.build_inverse_pyramid_model((S, S, C), cfg)
+
+    def step():
+        return inv(pyr(x))
+    for _ in range(max(args.warmup, 1)):
+        y = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    n = B * S * S * C
+    nbytes = 4 * sum((3.5 + 2.25) * n / 4 ** l for l in range(levels - 1))
+    err = float((y - x).abs().mean().item())
+    if rank == 0:
+        gbs = nbytes * args.steps / elapsed / 1e9
+        print(json.dumps({
+            "metric": "laplacian pyramid split + merge images/sec (512x512x3, 3 levels)", "value": B * args.steps / elapsed,
+            "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"laplacian pyramid (avg-pool 5x5 s2 SAME, bilinear x2) + inverse, batch={B} {S}x{S}x{C} float32"},
+            "round_trip_mean_abs_error": err,      # reference test bar: < 1e-7 (tests/bfcnn/test_pyramid.py)
+            "roofline": {"bound": "hbm", "kernel": "avgpool_s2_same + upsample2x (4 launches per level pair)", "achieved": gbs,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_step": nbytes}}), flush=True)
+
+
 def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
     """configs[3]: resnet_color_1x18 training step, L1 loss (hinge 0.5), additive-gaussian synthetic batch, global batch =
     --batch x world sharded over the ranks, one sum-all-reduce of the flat fp32 gradient buffer, fused clip + Adam."""
@@ -147,7 +183,7 @@ def main():
     ap.add_argument("--fused-tile", type=int, default=None, help="exact-fp32 fused-block tile geometry variant (A/B only)")
     ap.add_argument("--arith", type=int, default=1, help="1 = split-f16 fused blocks (default), 0 = exact-fp32 fused blocks")
     ap.add_argument("--h3-variant", type=int, default=None, help="split-f16 kernel variant (A/B only)")
-    ap.add_argument("--mode", choices=["inference", "train"], default="inference",
+    ap.add_argument("--mode", choices=["inference", "train", "pyramid"], default="inference",
                     help="train: BASELINE.json configs[3] -- one data-parallel training step per step (L1 loss, "
                          "batch sharded over the ranks, ONE gradient all-reduce, clip + Adam); not the headline metric")
     args = ap.parse_args()
@@ -174,6 +210,8 @@ def main():
 
     if args.mode == "train":
         return train_bench(args, torch, bf, O, rank, local_rank, world, dist)
+    if args.mode == "pyramid":
+        return pyramid_bench(args, torch, bf, O, rank, local_rank, world, dist)
     cfg = O.canonical_config(no_layers=args.layers)
     spec = O.ResnetSpec.from_config(cfg["model"])
     params, state = O.init_params(spec, seed=42, nontrivial_bn=True)
