@@ -77,7 +77,7 @@ SIGNATURES = {
     "bf_debug_mfma_probe": (_I, [_P, _P, _P, _P]),
 }
 
-BF_STATUS_BYTES = 1024         # tail of an inference workspace: int32 status word + kernel scratch
+BF_STATUS_BYTES = 2048         # tail of an inference workspace: int32 status word + kernel scratch
 BF_STATUS_F16_RANGE = 1
 
 _lib = None

@@ -59,7 +59,7 @@ struct FusedH3Args {
     int tiles_x, tiles_y, ntiles;
     int act1_relu;
     const void* zeros;    // >= 64 B of zeros, 16-B aligned (source of out-of-image elements)
-    void* dump;           // >= 512 B writable scratch (sink of out-of-image stores)
+    void* dump;           // >= 1024 B writable scratch (sink of out-of-image stores)
     unsigned long long* dbg;  // diagnostic builds only (per-wave phase cycle sums), else NULL
 };
 hipError_t bf_launch_fused_block_h3(const FusedH3Args& a, hipStream_t s);
@@ -106,7 +106,7 @@ struct HeadArgs {
     int feat_split;       // 1: feat is split-planar f16 hi/lo
     int* status;          // |= BF_STATUS_F16_RANGE when a split-planar feature is not finite (f16 overflow upstream); may be NULL
 };
-#define BF_STATUS_BYTES 1024  // tail of the inference workspace: [0] status word, [256, 768) store sink of out-of-image lanes
+#define BF_STATUS_BYTES 2048  // tail of the inference workspace: [0] status word, [1024, 2048) store sink of out-of-image lanes
 
 hipError_t bf_launch_head(const HeadArgs& a, hipStream_t s);
 

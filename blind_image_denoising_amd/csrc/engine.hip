@@ -371,7 +371,7 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
             fa.w1 = b3; fa.w2 = b3 + BF_H3_WPACK_FLOATS; fa.aux = b3 + 2 * BF_H3_WPACK_FLOATS;
             fa.w1r = fa.aux + 64; fa.w2r = fa.aux + 64 + BF_H3R_WPACK_FLOATS;
             fa.B = B; fa.H = H; fa.W = W; fa.tiles_x = fa.tiles_y = fa.ntiles = 0;
-            fa.act1_relu = d.activation == BF_ACT_RELU; fa.zeros = pk + h->k_zero; fa.dump = (char*)status + 256; fa.dbg = nullptr;
+            fa.act1_relu = d.activation == BF_ACT_RELU; fa.zeros = pk + h->k_zero; fa.dump = (char*)status + 1024; fa.dbg = nullptr;
             BF_HIP(bf_launch_fused_block_h3(fa, s), "fused_block_h3");
             cur ^= 1;
         } else if (h->fused_blocks) {
@@ -781,7 +781,7 @@ extern "C" int bf_debug_fused_block(const float* in, const float* w1_hwio, const
 // the two HWIO kernels + gamma-free BN stand-in, zero line, dump line).
 extern "C" int64_t bf_debug_fused_block_h3_scratch_floats(int B, int H, int W)
 {
-    return 2 * (int64_t)B * H * W * 16 + BF_H3_BLOCK_FLOATS + 4608 + 16 + 32 + 64 + 128;
+    return 2 * (int64_t)B * H * W * 16 + BF_H3_BLOCK_FLOATS + 4608 + 16 + 32 + 64 + 256;
 }
 
 extern "C" int bf_debug_fused_block_h3(const float* in, const float* w1_hwio, const float* w2_hwio, const float* scale,
@@ -796,7 +796,7 @@ extern "C" int bf_debug_fused_block_h3(const float* in, const float* w1_hwio, co
     float* params = pk + BF_H3_BLOCK_FLOATS;       // [w1 2304][w2 2304][gamma 16]
     float* state = params + 4608 + 16;             // [mean 16][var 16]
     float* zeros = state + 32;                     // 64
-    float* dump = zeros + 64;                      // 128
+    float* dump = zeros + 64;                      // 256
     // the caller's scale / shift stand in for the folded BN (ext_scale / ext_shift of the pack kernel)
     if (hipMemcpyAsync(params, w1_hwio, 2304 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;
     if (hipMemcpyAsync(params + 2304, w2_hwio, 2304 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;

@@ -37,6 +37,16 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 #define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
+// Eight wait states that cannot move away from the accumulator they protect (the asm takes it as an in/out operand):
+// put in front of every epilogue's first read of a just-finished accumulator.  hipcc's hazard recognizer pads
+// "MFMA writes VGPR -> VALU reads it" correctly in straight-line code, but when the epilogue contains a uniform branch
+// or an EXEC-masked select it padded only the fall-through path (one wait state on the taken path: stale .zw halves).
+__device__ __forceinline__ f32x4 h3_acc_ready(f32x4 acc)
+{
+    asm volatile("s_nop 7" : "+v"(acc));
+    return acc;
+}
+
 // timing-only ablations of fused_block_h3r_kernel (tools/ablate.sh; results are WRONG when any is set):
 // 1 = no next-tile DMA, 2 = no global stores, 4 = no conv2 MFMA work, 8 = no conv1 MFMA work, 16 = no barriers,
 // 64 = no epilogue arithmetic (raw accumulator bits are stored)
@@ -152,6 +162,33 @@ __device__ __forceinline__ void h3_split(const f32x4 v, h4& hi, h4& lo)
     const unsigned a = __builtin_bit_cast(unsigned, (h2){hi[0], hi[1]}), b = __builtin_bit_cast(unsigned, (h2){hi[2], hi[3]});
     const f32x4 d = {h3_sub_half(v[0], a, false), h3_sub_half(v[1], a, true), h3_sub_half(v[2], b, false), h3_sub_half(v[3], b, true)};
     lo = __builtin_convertvector(d, h4);
+}
+
+// NOTE on `interior` shortcuts in the conv2 epilogues: `if (!interior && out_of_image) p = dump` made hipcc branch over the
+// select on the uniform `interior`, and on the taken path its hazard recognizer left ONE wait state between the last
+// MFMA of a row and the v_pk_fma that reads the accumulator: stale .zw halves on interior tiles of the wave-specialised
+// kernel (caught by the parity tests).  The out-of-image select is therefore unconditional (per-lane condition, no branch).
+//
+// hi / lo of the lane's four channels, then a row exchange (v_permlane16_swap_b32: result 0 = [a.row0, b.row0, a.row2,
+// b.row2], result 1 = [a.row1, b.row1, a.row3, b.row3], rows = 16-lane groups = q) so that every lane ends up with ONE
+// 16-byte record of EIGHT channels: q = 0 -> hi(c0..7), q = 1 -> lo(c0..7), q = 2 -> hi(c8..15), q = 3 -> lo(c8..15) of its
+// pixel, i.e. plane (q >> 1) + 2 * (q & 1).  One 16-byte store (ds_write_b128 / global dwordx4) per group instead of
+// two 8-byte ones: half the LDS-write and vector-memory instructions of the epilogues.  Needs EXEC all ones.
+__device__ __forceinline__ h8 h3_split_record(const f32x4 v)
+{
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    h4 hi, lo;
+    h3_split(v, hi, lo);
+    u2 H = __builtin_bit_cast(u2, hi), L = __builtin_bit_cast(u2, lo);
+    // inline asm with explicit wait states on both sides: with the builtin, hipcc 7.2 issued the swap in the slot right
+    // after the v_cvt_pk that produces its operand (and the store right after the swap) in the tightest code paths and
+    // the wave-specialised kernel then stored stale halves on interior tiles (parity tests) -- a data hazard of this
+    // new gfx950 instruction the compiler does not pad
+    unsigned h0 = H[0], l0 = L[0], h1 = H[1], l1 = L[1];
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
+                 : "+v"(h0), "+v"(l0), "+v"(h1), "+v"(l1));
+    return __builtin_bit_cast(h8, (u4){h0, h1, l0, l1});
 }
 
 // NG groups x 14 MFMAs.  va / vb / vc: per-group LDS byte address of the lane's 16-byte record of tap (0,0)
@@ -624,6 +661,7 @@ template <class Cfg, bool INTERIOR>
 __device__ __forceinline__ void h3r_conv1_store(const FusedH3Args& a, char* __restrict__ tmid, const int wr, f32x4 v,
                                                 const float inv_s, const float relu_floor, const int gy, const int gx)
 {
+    v = h3_acc_ready(v);
     if (!(H3_ABLATE & 64)) {
         // activation without a branch and without the canonicalising v_max x,x hipcc puts in front of fmaxf:
         // max(v, floor) with floor = 0 (relu) or -inf (linear) as median(v, floor, +inf)
@@ -635,10 +673,7 @@ __device__ __forceinline__ void h3r_conv1_store(const FusedH3Args& a, char* __re
         // conv2 must see ZERO padding outside the image, not conv1 evaluated there
         if (gy < 0 || gy >= a.H || gx < 0 || gx >= a.W) v = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    h4 hi, lo;
-    h3_split(v, hi, lo);
-    *reinterpret_cast<h4*>(tmid + wr) = hi;
-    *reinterpret_cast<h4*>(tmid + wr + 2 * Cfg::MID_PLANE) = lo;
+    *reinterpret_cast<h8*>(tmid + wr) = h3_split_record(v);      // wr: plane (q>>1) + 2*(q&1), pixel * 16
 }
 
 struct H3RLane {
@@ -718,13 +753,13 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args
         const int b1 = (q & 1) * Cfg::IN_PLANE + (o1 * Cfg::IW + L0.px) * 16;
         L0.p1 = b1 + (q >> 1) * 16;
         L0.s1 = b1 + 32 + (q >> 1) * 2 * Cfg::IN_PLANE;
-        L0.w1 = (q >> 1) * Cfg::MID_PLANE + (o1 * Cfg::MW + L0.px) * 16 + (q & 1) * 8;
+        L0.w1 = ((q >> 1) + 2 * (q & 1)) * Cfg::MID_PLANE + (o1 * Cfg::MW + L0.px) * 16;
         const int b2 = (q & 1) * Cfg::MID_PLANE + (o2 * Cfg::MW + L0.px) * 16;
         L0.p2 = b2 + (q >> 1) * 16;
         L0.s2 = b2 + 32 + (q >> 1) * 2 * Cfg::MID_PLANE;
         // residual operand [x_hi | x_lo] of the centre pixel: lanes q < 2 read the hi planes, q >= 2 the lo planes
         L0.rr = ((q & 1) + 2 * (q >> 1)) * Cfg::IN_PLANE + ((o2 + 2) * Cfg::IW + L0.px + 2) * 16;
-        L0.g = (unsigned)(q >> 1) * plane_g + (unsigned)(o2 * a.W + L0.px) * 16u + (unsigned)(q & 1) * 8u;
+        L0.g = (unsigned)((q >> 1) + 2 * (q & 1)) * plane_g + (unsigned)(o2 * a.W + L0.px) * 16u;
     }
 
     unsigned pfoff[Cfg::PF];
@@ -829,7 +864,7 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args
                     const int srow = min(8 * g + (n >> 1), Cfg::MH - 1);      // partial last group: clamp (same values twice)
                     const int scol = Cfg::TW + (n & 1);
                     const int bg = (q & 1) * Cfg::IN_PLANE + (srow * Cfg::IW + scol) * 16;
-                    const int gw = (q >> 1) * Cfg::MID_PLANE + (srow * Cfg::MW + scol) * 16 + (q & 1) * 8;
+                    const int gw = ((q >> 1) + 2 * (q & 1)) * Cfg::MID_PLANE + (srow * Cfg::MW + scol) * 16;
                     const f32x4 v = h3r_group<Cfg::IW * 16, 2 * Cfg::IN_PLANE>(tin, bg + (q >> 1) * 16, bg + 32 + (q >> 1) * 2 * Cfg::IN_PLANE, w1);
                     if (interior) h3r_conv1_store<Cfg, true>(a, tmid, gw, v, inv_s1, relu_floor, 0, 0);
                     else h3r_conv1_store<Cfg, false>(a, tmid, gw, v, inv_s1, relu_floor, cur.y0 - 1 + srow, cur.x0 - 1 + scol);
@@ -859,28 +894,21 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args
                 __device__ __forceinline__ f32x4 finish(const int, const f32x4 acc, const Pre& xr) const { return MFMA_H(wres, xr, acc); }
                 __device__ __forceinline__ void operator()(const int o, const f32x4 acc) const
                 {
-                    const f32x4 v = (H3_ABLATE & 64) ? acc : acc * inv_s2 + sh;
-                    h4 hi, lo;
-                    h3_split(v, hi, lo);
-                    // out-of-image lanes store to a dump line: every wave issues exactly 2*R2 stores per tile
+                    const f32x4 accr = h3_acc_ready(acc);
+                    const f32x4 v = (H3_ABLATE & 64) ? accr : accr * inv_s2 + sh;
+                    const h8 rec = h3_split_record(v);
+                    // out-of-image lanes store to a dump line: every wave issues exactly R2 stores per tile
                     char* p = out_row0 + o * rowbytes + g;
-                    char* pl = p + lo_g;
-                    if (!interior && !(y_base + o < a.H && x_px < a.W)) {
-                        p = reinterpret_cast<char*>(a.dump) + lane * 8;
-                        pl = p;
-                    }
-                    if (H3_ABLATE & 2) { if (v.x == 12345.678f) *reinterpret_cast<h4*>(p) = hi + lo; }   // keeps the work live
-                    else {
-                        *reinterpret_cast<h4*>(p) = hi;
-                        *reinterpret_cast<h4*>(pl) = lo;
-                    }
+                    if (!(y_base + o < a.H && x_px < a.W))   /* branch-free on purpose: see h3_split_record's neighbour comment */ p = reinterpret_cast<char*>(a.dump) + lane * 16;
+                    if (H3_ABLATE & 2) { if (v.x == 12345.678f) *reinterpret_cast<h8*>(p) = rec; }   // keeps the work live
+                    else *reinterpret_cast<h8*>(p) = rec;
                 }
             } const epi2{a, tin, w2[12], out_row0, rowbytes, lo_g, inv_s2, sh, interior, L.rr, cur.y0 + o2, cur.x0 + L.px, lane, L.g};
             h3r_rows<Plan::R2, Cfg::MW * 16, 2 * Cfg::MID_PLANE>(tmid, L.p2, L.s2, w2, epi2, H3NoHook{});
         }
-        // next tile's DMA landed <=> at most the 2*R2 stores above are outstanding (see fused_block_h3_kernel)
+        // next tile's DMA landed <=> at most the R2 stores above are outstanding (see fused_block_h3_kernel)
         H3_STAMP(3);                                             // conv2 + stores
-        __builtin_amdgcn_s_waitcnt(h3_vmcnt((H3_ABLATE & 2) ? 0 : 2 * Plan::R2));
+        __builtin_amdgcn_s_waitcnt(h3_vmcnt((H3_ABLATE & 2) ? 0 : Plan::R2));
         H3_STAMP(4);                                             // wait for the next tile's DMA
         h3_barrier();
         H3_STAMP(5);                                             // barrier B
@@ -1054,7 +1082,7 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3s_kernel(FusedH3Args
         const float inv_s1 = a.aux[0];
         const float relu_floor = a.act1_relu ? 0.f : -__builtin_inff();
         const int b1 = (q & 1) * Cfg::IN_PLANE + (o1 * Cfg::IW + px) * 16;
-        int c_p1 = b1 + (q >> 1) * 16, c_w1 = (q >> 1) * Cfg::MID_PLANE + (o1 * Cfg::MW + px) * 16 + (q & 1) * 8;
+        int c_p1 = b1 + (q >> 1) * 16, c_w1 = ((q >> 1) + 2 * (q & 1)) * Cfg::MID_PLANE + (o1 * Cfg::MW + px) * 16;
 
         H3Tile cur = walk.tile<Cfg>();
         {   // prologue: the first tile, all PF instructions at once
@@ -1086,7 +1114,7 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3s_kernel(FusedH3Args
                     const int srow = min(8 * wave + (n >> 1), Cfg::MH - 1);
                     const int scol = Cfg::TW + (n & 1);
                     const int bg = (q & 1) * Cfg::IN_PLANE + (srow * Cfg::IW + scol) * 16;
-                    const int gw = (q >> 1) * Cfg::MID_PLANE + (srow * Cfg::MW + scol) * 16 + (q & 1) * 8;
+                    const int gw = ((q >> 1) + 2 * (q & 1)) * Cfg::MID_PLANE + (srow * Cfg::MW + scol) * 16;
                     const f32x4 v = h3r_group<Cfg::IW * 16, 2 * Cfg::IN_PLANE>(tin, bg + (q >> 1) * 16, bg + 32 + (q >> 1) * 2 * Cfg::IN_PLANE, w1);
                     if (interior) h3r_conv1_store<Cfg, true>(a, tmid, gw, v, inv_s1, relu_floor, 0, 0);
                     else h3r_conv1_store<Cfg, false>(a, tmid, gw, v, inv_s1, relu_floor, cur.y0 - 1 + srow, cur.x0 - 1 + scol);
@@ -1127,7 +1155,7 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3s_kernel(FusedH3Args
         int c_p2 = b2 + (q >> 1) * 16;
         // residual operand [x_hi | x_lo] of the centre pixel: lanes q < 2 read the hi planes, q >= 2 the lo planes
         int c_rr = ((q & 1) + 2 * (q >> 1)) * Cfg::IN_PLANE + ((o2 + 2) * Cfg::IW + px + 2) * 16;
-        unsigned c_g = (unsigned)(q >> 1) * plane_g + (unsigned)(o2 * a.W + px) * 16u + (unsigned)(q & 1) * 8u;
+        unsigned c_g = (unsigned)((q >> 1) + 2 * (q & 1)) * plane_g + (unsigned)(o2 * a.W + px) * 16u;
 
         __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));                   // weight / scale loads
         h3_barrier();                                            // prologue barrier: tile 0 is in tin0
@@ -1153,17 +1181,10 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3s_kernel(FusedH3Args
                     __device__ __forceinline__ f32x4 finish(const int o, const f32x4 acc, const Pre&) const { return MFMA_H(wres, res[o], acc); }
                     __device__ __forceinline__ void operator()(const int o, const f32x4 acc) const
                     {
-                        const f32x4 v = acc * inv_s2 + sh;
-                        h4 hi, lo;
-                        h3_split(v, hi, lo);
+                        const f32x4 v = h3_acc_ready(acc) * inv_s2 + sh;
                         char* p = out_row0 + o * rowbytes + g;
-                        char* pl = p + lo_g;
-                        if (!interior && !(y_base + o < a.H && x_px < a.W)) {
-                            p = reinterpret_cast<char*>(a.dump) + lane * 8;
-                            pl = p;
-                        }
-                        *reinterpret_cast<h4*>(p) = hi;
-                        *reinterpret_cast<h4*>(pl) = lo;
+                        if (!(y_base + o < a.H && x_px < a.W))   /* branch-free on purpose: see h3_split_record's neighbour comment */ p = reinterpret_cast<char*>(a.dump) + lane * 16;
+                        *reinterpret_cast<h8*>(p) = h3_split_record(v);
                     }
                 };
                 Epi2 epi2{a, w2[12], out_row0, (size_t)a.W * 16, 2 * (size_t)plane_g, inv_s2, sh, interior,

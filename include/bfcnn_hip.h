@@ -181,7 +181,7 @@ int bf_strided_slice2(const float* in, float* out, int batch, int height, int wi
 
 /* ---- options and diagnostics (not part of the drop-in surface; used by tests/) ------------- */
 
-/* Inference forwards keep a status word in the LAST 1024 bytes of the workspace they are given (ws + ws_bytes - 1024,
+/* Inference forwards keep a status word in the LAST 2048 bytes of the workspace they are given (ws + ws_bytes - 2048,
  * int32; the rest of that tail is kernel scratch): 0 after a clean forward; bit BF_STATUS_F16_RANGE is set when an activation left the f16 range inside the
  * split-f16 blocks (the output is then not trustworthy: re-run with option "arith" = 0).  Reading it needs a stream
  * synchronisation, which is the caller's decision (the Python host checks it whenever it hands back host arrays). */
