@@ -7,6 +7,16 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Eight wait states that cannot move away from the accumulator they protect (the asm takes it as an in/out operand), put in
+// front of an epilogue's first read of a just-finished MFMA accumulator.  hipcc pads "MFMA writes VGPR -> VALU reads it"
+// in straight-line code, but with a uniform branch or an EXEC-masked select between the two it padded only the
+// fall-through path (found in fused_h3.hip: one wait state on the taken path, stale halves of the accumulator).
+__device__ __forceinline__ f32x4 bf_acc_ready(f32x4 acc)
+{
+    asm volatile("s_nop 7" : "+v"(acc));
+    return acc;
+}
+
 #define BF_C 16             // feature channels of the MFMA path (filters == 16)
 #define BF_WPACK_FLOATS (36 * 64)   // one 3x3 16->16 kernel as MFMA A-operand register images
 

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(ConvArgs a)
             const int gy = y0 + 4 * wave + (gi >> 1), gx = x0 + (gi & 1) * 16 + p;
             if (gy < a.H && gx < a.W) {
                 const size_t idx = img + ((size_t)gy * a.W + gx) * 16 + q * 4;
-                f32x4 v = acc[j];
+                f32x4 v = bf_acc_ready(acc[j]);
                 if (EPI & EPI_STATS) { s1 += v; s2 += v * v; }
                 if (EPI & EPI_AFFINE) v = v * sc + sh;
                 if (EPI & EPI_RELU) {
@@ -364,7 +364,7 @@ __device__ __forceinline__ void conv1_pass(const FusedBlockArgs& a, const float*
     conv_groups<NG>(tin, base, Cfg::IW, w1, acc);
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
-        f32x4 v = acc[j];
+        f32x4 v = bf_acc_ready(acc[j]);
         if (a.act1_relu) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
@@ -405,7 +405,7 @@ __device__ __forceinline__ void conv2_pass(const FusedBlockArgs& a, const float*
         const int oy = g[j] / Cfg::GPR, xg = (g[j] - oy * Cfg::GPR) * 16;
         if (INTERIOR || (t.y0 + oy < a.H && t.x0 + xg + L.p < a.W)) {
             if (!RES_GLOBAL) res[j] = *reinterpret_cast<const f32x4*>(tin + ((oy + 2) * Cfg::IW + xg + 2) * 16 + L.row_c);
-            const f32x4 v = acc[j] * sc + sh + res[j];
+            const f32x4 v = bf_acc_ready(acc[j]) * sc + sh + res[j];
             if (BF_ABLATE & 4) { if (v.x == 12345.678f) out_tile[0] = v.y; }       // keeps the MFMAs live
             else *reinterpret_cast<f32x4*>(out_tile + ((size_t)oy * a.W + xg) * 16 + (unsigned)L.row_c) = v;
         }
@@ -771,7 +771,7 @@ __device__ __forceinline__ void v4_conv1_rows(const FusedBlockArgs& a, const flo
     conv_groups<NG>(tin, base, Cfg::IW, w1, acc);
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
-        f32x4 v = acc[j];
+        f32x4 v = bf_acc_ready(acc[j]);
         if (a.act1_relu) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
@@ -803,7 +803,7 @@ __device__ __forceinline__ void v4_conv1_strip(const FusedBlockArgs& a, const fl
         dst = (my * Cfg::MW + Cfg::TW + (L.sp & 1)) * 16 + (L.in_c & 12);
     }
     conv_groups<1>(tin, base, Cfg::IW, w1, acc);
-    f32x4 v = acc[0];
+    f32x4 v = bf_acc_ready(acc[0]);
     if (a.act1_relu) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
@@ -838,7 +838,7 @@ __device__ __forceinline__ void v4_conv2(const FusedBlockArgs& a, const float* _
     for (int j = 0; j < NG; ++j) {
         const int gy = t.y0 + wrow + (K0 + j) * RS;
         if (INTERIOR || (gy < a.H && t.x0 + L.px < a.W)) {
-            const f32x4 v = acc[j] * sc + sh + res[j];
+            const f32x4 v = bf_acc_ready(acc[j]) * sc + sh + res[j];
             *reinterpret_cast<f32x4*>(out_tile + (K0 + j) * RS * rowstep + L.glob_c) = v;
         }
     }

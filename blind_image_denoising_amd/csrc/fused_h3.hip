@@ -37,16 +37,6 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 #define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
-// Eight wait states that cannot move away from the accumulator they protect (the asm takes it as an in/out operand):
-// put in front of every epilogue's first read of a just-finished accumulator.  hipcc's hazard recognizer pads
-// "MFMA writes VGPR -> VALU reads it" correctly in straight-line code, but when the epilogue contains a uniform branch
-// or an EXEC-masked select it padded only the fall-through path (one wait state on the taken path: stale .zw halves).
-__device__ __forceinline__ f32x4 h3_acc_ready(f32x4 acc)
-{
-    asm volatile("s_nop 7" : "+v"(acc));
-    return acc;
-}
-
 // timing-only ablations of fused_block_h3r_kernel (tools/ablate.sh; results are WRONG when any is set):
 // 1 = no next-tile DMA, 2 = no global stores, 4 = no conv2 MFMA work, 8 = no conv1 MFMA work, 16 = no barriers,
 // 64 = no epilogue arithmetic (raw accumulator bits are stored)
@@ -661,7 +651,7 @@ template <class Cfg, bool INTERIOR>
 __device__ __forceinline__ void h3r_conv1_store(const FusedH3Args& a, char* __restrict__ tmid, const int wr, f32x4 v,
                                                 const float inv_s, const float relu_floor, const int gy, const int gx)
 {
-    v = h3_acc_ready(v);
+    v = bf_acc_ready(v);
     if (!(H3_ABLATE & 64)) {
         // activation without a branch and without the canonicalising v_max x,x hipcc puts in front of fmaxf:
         // max(v, floor) with floor = 0 (relu) or -inf (linear) as median(v, floor, +inf)
@@ -894,7 +884,7 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args
                 __device__ __forceinline__ f32x4 finish(const int, const f32x4 acc, const Pre& xr) const { return MFMA_H(wres, xr, acc); }
                 __device__ __forceinline__ void operator()(const int o, const f32x4 acc) const
                 {
-                    const f32x4 accr = h3_acc_ready(acc);
+                    const f32x4 accr = bf_acc_ready(acc);
                     const f32x4 v = (H3_ABLATE & 64) ? accr : accr * inv_s2 + sh;
                     const h8 rec = h3_split_record(v);
                     // out-of-image lanes store to a dump line: every wave issues exactly R2 stores per tile
@@ -1181,7 +1171,7 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3s_kernel(FusedH3Args
                     __device__ __forceinline__ f32x4 finish(const int o, const f32x4 acc, const Pre&) const { return MFMA_H(wres, res[o], acc); }
                     __device__ __forceinline__ void operator()(const int o, const f32x4 acc) const
                     {
-                        const f32x4 v = h3_acc_ready(acc) * inv_s2 + sh;
+                        const f32x4 v = bf_acc_ready(acc) * inv_s2 + sh;
                         char* p = out_row0 + o * rowbytes + g;
                         if (!(y_base + o < a.H && x_px < a.W))   /* branch-free on purpose: see h3_split_record's neighbour comment */ p = reinterpret_cast<char*>(a.dump) + lane * 16;
                         *reinterpret_cast<h8*>(p) = h3_split_record(v);
