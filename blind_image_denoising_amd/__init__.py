@@ -23,6 +23,7 @@ from .loss import loss_function_builder
 from .optimizer import optimizer_builder, schedule_builder, deep_supervision_schedule_builder
 from .train_loop import (train_loop, build_train_functions, DataParallelTrainer, shard_batch, allreduce_gradients)
 from .pyramid import (build_pyramid_model, build_inverse_pyramid_model, multiscales_generator_fn)
+from .dataset import dataset_builder, PrepareData, noise_augment
 
 current_dir = pathlib.Path(__file__).parent.resolve()
 

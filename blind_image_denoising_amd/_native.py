@@ -65,6 +65,7 @@ SIGNATURES = {
     "bf_avgpool2_valid": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "bf_upsample2x": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P]),
     "bf_strided_slice2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "bf_noise_augment": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, C.c_uint64, _P]),
     "bf_set_option": (_I, [_P, C.c_char_p, _I]),
     "bf_get_timing": (_I, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "bf_debug_conv3x3": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -1,0 +1,88 @@
+"""
+The corruption half of the reference's input pipeline on the device: `prepare_data_fn` of
+bfcnn/dataset.py:126-239 (whole-batch flips, multiplicative and additive truncated-normal noise, rounding) as ONE
+HIP kernel (`bf_noise_augment`), so that a training step is not fed by a host pipeline.  The tf.data part of
+`dataset_builder` (file listing, decoding, cropping, shuffling, batching) is out of scope: `dataset_builder` here
+takes an iterable of clean batches and yields (input_batch, noisy_batch) pairs, which is what `train_loop` consumes.
+
+Random numbers: the per-BATCH choices of the reference (two flips, whether each noise is applied, the two standard
+deviations ~ U[min, max]) come from a seeded host generator; the per-element noise is Philox4x32-10 indexed by the
+element, keyed by a per-batch seed from the same generator (TensorFlow's own stream cannot be reproduced outside
+TensorFlow; the distribution and the order of operations are the reference's).
+"""
+from typing import Dict, Iterable, Iterator, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .custom_logger import logger
+
+
+def noise_augment(input_batch: torch.Tensor, flip_left_right: bool = False, flip_up_down: bool = False,
+                  mult_std: float = 0.0, add_std: float = 0.0, seed: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """one bf_noise_augment call: (round(flip(x)), round(round(flip(x)) * tn(1, mult_std) + tn(0, add_std)))."""
+    if input_batch.dim() != 4:
+        raise ValueError(f"expected a [B,H,W,C] batch, got {tuple(input_batch.shape)}")
+    if not input_batch.is_cuda:
+        raise RuntimeError("noise_augment runs on the MI355X: the engine has no CPU execution path")
+    x = input_batch.to(torch.float32).contiguous()
+    B, H, W, C = x.shape
+    clean, noisy = torch.empty_like(x), torch.empty_like(x)
+    flip = (1 if flip_left_right else 0) | (2 if flip_up_down else 0)
+    N.check(N.lib().bf_noise_augment(N.ptr(x), N.ptr(clean), N.ptr(noisy), B, H, W, C, flip, float(mult_std), float(add_std),
+                                     int(seed) & 0xFFFFFFFFFFFFFFFF, N.stream_ptr(x)), None, "bf_noise_augment")
+    return clean, noisy
+
+
+class PrepareData:
+    """`prepare_data_fn` (bfcnn/dataset.py:126-239) built from the same `dataset` config section
+    (dataset.py:92-121): random_left_right, random_up_down, additional_noise, multiplicative_noise."""
+
+    def __init__(self, config: Dict, seed: Optional[int] = None):
+        self.use_left_right = bool(config.get("random_left_right", False))
+        self.use_up_down = bool(config.get("random_up_down", False))
+        additional = list(config.get("additional_noise", []))
+        multiplicative = list(config.get("multiplicative_noise", []))
+        self.use_additive = len(additional) > 0                         # dataset.py:99-104
+        self.use_multiplicative = len(multiplicative) > 0
+        self.additive = (min(additional), max(additional)) if additional else (1.0, 1.0)
+        self.multiplicative = (min(multiplicative), max(multiplicative)) if multiplicative else (1.0, 1.0)
+        for key in ("random_blur", "use_jpeg_noise"):
+            if config.get(key, False):
+                raise NotImplementedError(f"dataset option [{key}] is outside the hot path")
+        if float(config.get("random_rotate", 0.0)) > 0.0 or float(config.get("inpaint_drop_rate", 0.0)) > 0.0 \
+                or int(config.get("quantization", -1)) > 1:
+            raise NotImplementedError("random_rotate / inpaint_drop_rate / quantization are outside the hot path")
+        self.rng = np.random.default_rng(seed)
+
+    def draw(self) -> Dict:
+        """the per-batch scalars, in the order the reference draws them (dataset.py:141-142, 170-187)."""
+        r = self.rng
+        flip_lr, flip_ud = r.uniform() > 0.5, r.uniform() > 0.5
+        opt_add, opt_mult = r.uniform() > 0.5, r.uniform() > 0.5
+        add_std = r.uniform(self.additive[0], self.additive[1])
+        mult_std = r.uniform(self.multiplicative[0], self.multiplicative[1])
+        return {"flip_left_right": bool(flip_lr and self.use_left_right), "flip_up_down": bool(flip_ud and self.use_up_down),
+                "add_std": float(add_std) if (opt_add and self.use_additive) else 0.0,
+                "mult_std": float(mult_std) if (opt_mult and self.use_multiplicative) else 0.0,
+                "seed": int(r.integers(0, 2 ** 63 - 1))}
+
+    def __call__(self, input_batch: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        return noise_augment(input_batch, **self.draw())
+
+
+def dataset_builder(config: Dict, clean_batches: Iterable = None, device=None, seed: Optional[int] = None) -> Iterator:
+    """bfcnn/dataset.py:40-305 reduced to the corruption stage: `clean_batches` is any iterable of clean [B,H,W,C]
+    batches in value range (numpy or torch); yields (input_image_batch, noisy_image_batch) device tensors."""
+    if clean_batches is None:
+        raise ValueError("clean_batches must be an iterable of clean image batches (image I/O is out of scope)")
+    prepare = PrepareData(config, seed)
+    logger.info(f"creating dataset_builder with configuration [{config}]")
+
+    def gen():
+        for batch in clean_batches:
+            t = torch.as_tensor(np.asarray(batch) if not isinstance(batch, torch.Tensor) else batch)
+            dev = device if device is not None else (t.device if t.is_cuda else torch.device("cuda", torch.cuda.current_device()))
+            yield prepare(t.to(dev))
+    return gen()

@@ -179,6 +179,17 @@ int bf_upsample2x(const float* in, const float* other, float* out, int batch, in
 /* x[:, ::2, ::2, :] (downsampling.py:61). */
 int bf_strided_slice2(const float* in, float* out, int batch, int height, int width, int channels, void* stream);
 
+/* prepare_data_fn of bfcnn/dataset.py:126-239 on a device batch [B,H,W,C] of floats in value range (not in place):
+ *   out_clean = round(flip(in))                               (geometric_augmentation_fn :131-159, tf.round :234)
+ *   out_noisy = round(out_clean * (1 + mult_std * tn) + add_std * tn')   (noise_augmentation_fn :161-230)
+ * tn, tn' = standard normals truncated at +-2 (tf.random.truncated_normal re-picks outside 2 sigma), drawn per element
+ * from Philox4x32-10 (counter = element index, key = seed).  The per-BATCH random choices of the reference -- the two
+ * flips (flip_mask bit 0 left-right, bit 1 up-down), whether each noise is applied (std = 0 disables it) and the
+ * standard deviations ~ U[min,max] -- are the caller's (blind_image_denoising_amd.dataset draws them on the host).
+ * out_clean may be NULL. */
+int bf_noise_augment(const float* in, float* out_clean, float* out_noisy, int batch, int height, int width, int channels,
+                     int flip_mask, float mult_std, float add_std, uint64_t seed, void* stream);
+
 /* ---- options and diagnostics (not part of the drop-in surface; used by tests/) ------------- */
 
 /* Inference forwards keep a status word in the LAST 2048 bytes of the workspace they are given (ws + ws_bytes - 2048,

@@ -808,3 +808,75 @@ def synthetic_batch(batch: int, height: int, width: int, channels: int = 3, sigm
         bad = np.abs(n) > 2.0
     noisy = np.clip(np.rint(clean + sigma * n), 0, 255)
     return clean.astype(np.uint8), noisy.astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------
+# training-data corruption (bfcnn/dataset.py:126-239, prepare_data_fn)
+# ---------------------------------------------------------------------------
+
+def _philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon et al., the counter-based generator TF's stateless ops use) on uint32 arrays."""
+    c0, c1, c2, c3 = (np.asarray(v, np.uint64) for v in (c0, c1, c2, c3))
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    m32 = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c0
+        p1 = np.uint64(0xCD9E8D57) * c2
+        n0 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & m32
+        n1 = p1 & m32
+        n2 = ((p0 >> np.uint64(32)) ^ c3 ^ k1) & m32
+        n3 = p0 & m32
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & m32
+    return c0, c1, c2, c3
+
+
+def truncated_standard_normal(n: int, stream: int, seed: int) -> np.ndarray:
+    """tf.random.truncated_normal semantics (dataset.py:199-204, 218-223: values beyond 2 sigma are re-picked) on the
+    element-indexed Philox stream the HIP kernel uses: attempt a = 0, 1, ... of element i takes Philox(counter =
+    (i lo, i hi, a, stream), key = seed), Box-Muller on (r0, r1) and (r2, r3), first |z| <= 2 in the order
+    z0, z1, z2, z3."""
+    idx = np.arange(n, dtype=np.uint64)
+    lo, hi = idx & np.uint64(0xFFFFFFFF), idx >> np.uint64(32)
+    out = np.zeros(n, np.float64)
+    todo = np.ones(n, bool)
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    for attempt in range(16):
+        if not todo.any():
+            break
+        sel = np.nonzero(todo)[0]
+        r = _philox4x32_10(lo[sel], hi[sel], np.full(sel.size, attempt, np.uint64), np.full(sel.size, stream, np.uint64), k0, k1)
+        done = np.zeros(sel.size, bool)
+        val = np.zeros(sel.size, np.float64)
+        for h in range(2):
+            u1 = ((r[2 * h] >> np.uint64(8)).astype(np.float64) + 1.0) / 16777216.0
+            u2 = (r[2 * h + 1] >> np.uint64(8)).astype(np.float64) / 16777216.0
+            rad = np.sqrt(-2.0 * np.log(u1))
+            for z in (rad * np.cos(2.0 * np.pi * u2), rad * np.sin(2.0 * np.pi * u2)):
+                take = ~done & (np.abs(z) <= 2.0)
+                val[take] = z[take]
+                done |= take
+        out[sel[done]] = val[done]
+        todo[sel[done]] = False
+    return out
+
+
+def prepare_data(input_batch: np.ndarray, flip_left_right: bool, flip_up_down: bool, mult_std: float, add_std: float,
+                 seed: int) -> Tuple[np.ndarray, np.ndarray]:
+    """dataset.py:126-239 with the per-batch random choices made by the caller: flips (:131-159), tf.round (:234),
+    x * truncated_normal(1, mult_std) (:193-208) then + truncated_normal(0, add_std) (:211-227) -- a std of 0 means the
+    term is not applied -- and tf.round (:230).  Returns (input_batch, noisy_batch)."""
+    x = np.asarray(input_batch, np.float64)
+    if flip_left_right:
+        x = x[:, :, ::-1, :]
+    if flip_up_down:
+        x = x[:, ::-1, :, :]
+    clean = round_half_even(x)
+    v = clean.copy()
+    n = v.size
+    if mult_std > 0:
+        v = v * (1.0 + mult_std * truncated_standard_normal(n, 0, seed).reshape(v.shape))
+    if add_std > 0:
+        v = v + add_std * truncated_standard_normal(n, 1, seed).reshape(v.shape)
+    return clean, round_half_even(v)
