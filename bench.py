@@ -131,8 +131,10 @@ def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
     trainer.broadcast_parameters()
     clean, noisy = O.synthetic_batch(min(B, 8), S, S, sigma=20.0, seed=1234 + rank)
     reps = (B + clean.shape[0] - 1) // clean.shape[0]
-    gt = torch.from_numpy(np.concatenate([clean] * reps)[:B].astype(np.float32)).cuda()
-    x = torch.from_numpy(np.concatenate([noisy] * reps)[:B].astype(np.float32)).cuda()
+    clean_dev = torch.from_numpy(np.concatenate([clean] * reps)[:B].astype(np.float32)).cuda()
+    # fresh corruption every step, on the device (bfcnn/dataset.py:126-239 -> bf_noise_augment): additive truncated-normal
+    # noise sigma ~ U[5, 40] and whole-batch flips, each with probability 1/2 -- inside the timed region
+    prep = bf.PrepareData({"random_left_right": True, "random_up_down": True, "additional_noise": [5, 40]}, seed=77 + rank)
 
     def barrier():
         if dist is not None:
@@ -141,11 +143,11 @@ def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
 
     total = None
     for _ in range(max(args.warmup, 1)):
-        total = trainer.step(gt, x)[0]
+        total = trainer.step(*prep(clean_dev))[0]
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        total = trainer.step(gt, x)[0]
+        total = trainer.step(*prep(clean_dev))[0]
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -161,7 +163,7 @@ def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"resnet_color_1x{args.layers}_bn_16x3x3 training step (L1 hinge 0.5, Adam, global clipnorm 1), "
-                                   f"batch={B}/GPU {S}x{S}x3 float32, one all-reduce of {model.n_params} fp32 gradients",
+                                   f"batch={B}/GPU {S}x{S}x3 float32 corrupted on the device every step, one all-reduce of {model.n_params} fp32 gradients",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
             "last_total_loss": float(total.item()),
             "end_to_end_tflops": value / world * per_px * S * S / 1e12}), flush=True)
