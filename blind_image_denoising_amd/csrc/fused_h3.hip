@@ -176,7 +176,7 @@ __device__ __forceinline__ h8 h3_split_record(const f32x4 v)
     // the wave-specialised kernel then stored stale halves on interior tiles (parity tests) -- a data hazard of this
     // new gfx950 instruction the compiler does not pad
     unsigned h0 = H[0], l0 = L[0], h1 = H[1], l1 = L[1];
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
                  : "+v"(h0), "+v"(l0), "+v"(h1), "+v"(l1));
     return __builtin_bit_cast(h8, (u4){h0, h1, l0, l1});
 }
@@ -551,17 +551,18 @@ struct H3NoHook {
 // the prefetch below the MFMAs and every row step then eats a full LDS round trip (tools/ablate.sh 76: with NO MFMA
 // and NO epilogue arithmetic the kernel still took 216 us of 320 -- it was LDS-latency bound, 16 row steps per tile):
 //   1. ds_reads of row I+1 (+ whatever the epilogue wants early: epi.pre(O) for output row O = I-2)
-//   2. the 5 MFMAs that COMPLETE output row I-2 (+ epi.finish), the 5 MFMAs of output row I-1, the epilogue of row I-2
-//      interleaved with the 5 MFMAs of output row I
+//   2. the epilogue of output row I-3 (finished in the previous step) interleaved with the 15 MFMAs of output rows
+//      I-2 (which completes: + epi.finish), I-1 and I
 //   3. hook.row<I>()
 template <int R, int PITCH, int LO, int I, class Epi, class Hook>
 __device__ __forceinline__ void h3r_rows_step(const char* __restrict__ src, const int vp, const int vs, const h8 (&w)[13],
-                                              f32x4 acc_m2, f32x4 acc_m1, const H3RowFrag<PITCH, LO> cur,
+                                              const f32x4 acc_done, f32x4 acc_m2, f32x4 acc_m1, const H3RowFrag<PITCH, LO> cur,
                                               const H3RowFrag<PITCH, LO> nxt, const typename Epi::Pre pre_m2, const Epi& epi,
                                               const Hook& hook)
 {
-    // acc_m2 / acc_m1: accumulators of output rows I-2 / I-1 (rolling values, not an array: hipcc left a 5-row
-    // accumulator array in scratch memory once the epilogue call moved, and scratch traffic drains the tile DMA)
+    // acc_done / acc_m2 / acc_m1: accumulators of output rows I-3 (complete) / I-2 / I-1 (rolling values, not an array:
+    // hipcc left a 5-row accumulator array in scratch memory once the epilogue call moved, and scratch traffic drains
+    // the tile DMA)
     if constexpr (I < R + 2) {
         // prefetch distance 2: the fragments of row I+2 are requested while rows I and I+1 are already in registers / in
         // flight.  With distance 1 the run's first and last steps (5 and 10 MFMAs) were LDS-latency bound: 7 steps of
@@ -571,16 +572,13 @@ __device__ __forceinline__ void h3r_rows_step(const char* __restrict__ src, cons
         typename Epi::Pre pre_m1 = {};
         if constexpr (I >= 1 && I - 1 < R) pre_m1 = epi.pre(I - 1);   // consumed in the NEXT step: a full row of MFMAs away
         __builtin_amdgcn_sched_barrier(0);
+#if !(H3_ABLATE & 2048)
+        // epilogue of the row that finished ONE STEP AGO: its arithmetic, LDS write / global store are independent of this
+        // step's MFMAs, so they can issue in the MFMAs' shadows (8 of every 16 cycles of the vector issue port are free)
+        // instead of between two MFMA bursts; no hazard padding needed either (the accumulator is a whole step old)
+        if constexpr (I >= 3) epi(I - 3, acc_done);
+#endif
         f32x4 acc_0 = {0.f, 0.f, 0.f, 0.f};
-#if H3_ABLATE & 512
-        if constexpr (I >= 2) {
-            acc_m2 = h3r_tap_row<PITCH, LO>(cur, w, 2, acc_m2);
-            acc_m2 = epi.finish(I - 2, acc_m2, pre_m2);                // conv2: + residual MFMA
-        }
-        if constexpr (I >= 1 && I - 1 < R) acc_m1 = h3r_tap_row<PITCH, LO>(cur, w, 1, acc_m1);
-        if constexpr (I >= 2) epi(I - 2, acc_m2);               // its result is 5 MFMAs old: no s_nop for the read
-        if constexpr (I < R) acc_0 = h3r_tap_row<PITCH, LO>(cur, w, 0, acc_0);
-#else
         // the three accumulators round-robin: consecutive MFMAs are independent (a chain on one accumulator only
         // issues back to back when hipcc happens to keep vDst == SrcC)
 #pragma unroll
@@ -589,24 +587,26 @@ __device__ __forceinline__ void h3r_rows_step(const char* __restrict__ src, cons
             if constexpr (I >= 1 && I - 1 < R) acc_m1 = h3r_tap_mfma<PITCH, LO>(cur, w, 1, m, acc_m1);
             if constexpr (I < R) acc_0 = h3r_tap_mfma<PITCH, LO>(cur, w, 0, m, acc_0);
         }
-        if constexpr (I >= 2) {
-            acc_m2 = epi.finish(I - 2, acc_m2, pre_m2);                // conv2: + residual MFMA
-            epi(I - 2, acc_m2);
-        }
+        if constexpr (I >= 2) acc_m2 = epi.finish(I - 2, acc_m2, pre_m2);     // conv2: + residual MFMA
+#if H3_ABLATE & 2048
+        if constexpr (I >= 2) epi(I - 2, bf_acc_ready(acc_m2));
 #endif
         hook.template row<I>();
-#if !(H3_ABLATE & 128)
-        // interleave: the first ~10 MFMAs back to back, then 3 vector instructions in the shadow of each further MFMA
-        if constexpr (I >= 2 && I < R) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 10 + Epi::EXTRA_MFMA, 0);
+#if !(H3_ABLATE & 128) && !(H3_ABLATE & 2048)
+        // one vector instruction in the shadow of every MFMA
+        if constexpr (I >= 3) {
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            for (int k = 0; k < 16; ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
             }
         }
 #endif
-        h3r_rows_step<R, PITCH, LO, I + 1>(src, vp, vs, w, acc_m1, acc_0, nxt, nx2, pre_m1, epi, hook);
+        h3r_rows_step<R, PITCH, LO, I + 1>(src, vp, vs, w, acc_m2, acc_m1, acc_0, nxt, nx2, pre_m1, epi, hook);
+    } else {
+#if !(H3_ABLATE & 2048)
+        epi(R - 1, bf_acc_ready(acc_done));                     // last row: nothing left to hide it under
+#endif
     }
 }
 
@@ -618,7 +618,7 @@ __device__ __forceinline__ void h3r_rows(const char* __restrict__ src, const int
     cur.load(src, vp, vs, 0);
     nxt.load(src, vp, vs, 1);
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    h3r_rows_step<R, PITCH, LO, 0>(src, vp, vs, w, z, z, cur, nxt, typename Epi::Pre{}, epi, hook);
+    h3r_rows_step<R, PITCH, LO, 0>(src, vp, vs, w, z, z, z, cur, nxt, typename Epi::Pre{}, epi, hook);
 }
 
 // one 16-pixel group of arbitrary shape (the 2-column strip groups): 12 reads, 15 MFMAs, no row reuse
@@ -651,7 +651,6 @@ template <class Cfg, bool INTERIOR>
 __device__ __forceinline__ void h3r_conv1_store(const FusedH3Args& a, char* __restrict__ tmid, const int wr, f32x4 v,
                                                 const float inv_s, const float relu_floor, const int gy, const int gx)
 {
-    v = bf_acc_ready(v);
     if (!(H3_ABLATE & 64)) {
         // activation without a branch and without the canonicalising v_max x,x hipcc puts in front of fmaxf:
         // max(v, floor) with floor = 0 (relu) or -inf (linear) as median(v, floor, +inf)
@@ -855,7 +854,7 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args
                     const int scol = Cfg::TW + (n & 1);
                     const int bg = (q & 1) * Cfg::IN_PLANE + (srow * Cfg::IW + scol) * 16;
                     const int gw = ((q >> 1) + 2 * (q & 1)) * Cfg::MID_PLANE + (srow * Cfg::MW + scol) * 16;
-                    const f32x4 v = h3r_group<Cfg::IW * 16, 2 * Cfg::IN_PLANE>(tin, bg + (q >> 1) * 16, bg + 32 + (q >> 1) * 2 * Cfg::IN_PLANE, w1);
+                    const f32x4 v = bf_acc_ready(h3r_group<Cfg::IW * 16, 2 * Cfg::IN_PLANE>(tin, bg + (q >> 1) * 16, bg + 32 + (q >> 1) * 2 * Cfg::IN_PLANE, w1));
                     if (interior) h3r_conv1_store<Cfg, true>(a, tmid, gw, v, inv_s1, relu_floor, 0, 0);
                     else h3r_conv1_store<Cfg, false>(a, tmid, gw, v, inv_s1, relu_floor, cur.y0 - 1 + srow, cur.x0 - 1 + scol);
                 }
@@ -884,8 +883,7 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args
                 __device__ __forceinline__ f32x4 finish(const int, const f32x4 acc, const Pre& xr) const { return MFMA_H(wres, xr, acc); }
                 __device__ __forceinline__ void operator()(const int o, const f32x4 acc) const
                 {
-                    const f32x4 accr = bf_acc_ready(acc);
-                    const f32x4 v = (H3_ABLATE & 64) ? accr : accr * inv_s2 + sh;
+                    const f32x4 v = (H3_ABLATE & 64) ? acc : acc * inv_s2 + sh;
                     const h8 rec = h3_split_record(v);
                     // out-of-image lanes store to a dump line: every wave issues exactly R2 stores per tile
                     char* p = out_row0 + o * rowbytes + g;
@@ -1105,7 +1103,7 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3s_kernel(FusedH3Args
                     const int scol = Cfg::TW + (n & 1);
                     const int bg = (q & 1) * Cfg::IN_PLANE + (srow * Cfg::IW + scol) * 16;
                     const int gw = ((q >> 1) + 2 * (q & 1)) * Cfg::MID_PLANE + (srow * Cfg::MW + scol) * 16;
-                    const f32x4 v = h3r_group<Cfg::IW * 16, 2 * Cfg::IN_PLANE>(tin, bg + (q >> 1) * 16, bg + 32 + (q >> 1) * 2 * Cfg::IN_PLANE, w1);
+                    const f32x4 v = bf_acc_ready(h3r_group<Cfg::IW * 16, 2 * Cfg::IN_PLANE>(tin, bg + (q >> 1) * 16, bg + 32 + (q >> 1) * 2 * Cfg::IN_PLANE, w1));
                     if (interior) h3r_conv1_store<Cfg, true>(a, tmid, gw, v, inv_s1, relu_floor, 0, 0);
                     else h3r_conv1_store<Cfg, false>(a, tmid, gw, v, inv_s1, relu_floor, cur.y0 - 1 + srow, cur.x0 - 1 + scol);
                 }
@@ -1171,7 +1169,7 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3s_kernel(FusedH3Args
                     __device__ __forceinline__ f32x4 finish(const int o, const f32x4 acc, const Pre&) const { return MFMA_H(wres, res[o], acc); }
                     __device__ __forceinline__ void operator()(const int o, const f32x4 acc) const
                     {
-                        const f32x4 v = bf_acc_ready(acc) * inv_s2 + sh;
+                        const f32x4 v = acc * inv_s2 + sh;
                         char* p = out_row0 + o * rowbytes + g;
                         if (!(y_base + o < a.H && x_px < a.W))   /* branch-free on purpose: see h3_split_record's neighbour comment */ p = reinterpret_cast<char*>(a.dump) + lane * 16;
                         *reinterpret_cast<h8*>(p) = h3_split_record(v);

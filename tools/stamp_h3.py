@@ -26,6 +26,20 @@ for _ in range(3):
     rc = L.bf_debug_fused_block_h3(N.ptr(x), N.ptr(w1), N.ptr(w2), N.ptr(sc), N.ptr(sh), N.ptr(out), N.ptr(scratch), B, H, W, 1, None)
     assert rc == 0
 torch.cuda.synchronize()
+# wall time of the whole debug call (pack + 2 conversions + block) and of the conversions alone -> shader clock estimate
+def timed(fn, n=5):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+t_all = timed(lambda: L.bf_debug_fused_block_h3(N.ptr(x), N.ptr(w1), N.ptr(w2), N.ptr(sc), N.ptr(sh), N.ptr(out), N.ptr(scratch), B, H, W, 1, None))
+dbg.zero_()
+rc = L.bf_debug_fused_block_h3(N.ptr(x), N.ptr(w1), N.ptr(w2), N.ptr(sc), N.ptr(sh), N.ptr(out), N.ptr(scratch), B, H, W, 1, None)
+torch.cuda.synchronize()
+print(f"debug call (pack + fp32->split + block + split->fp32): {t_all:.1f} us")
 d = dbg.cpu().numpy().reshape(NWG, NW, 8).astype(np.float64)      # [block][wave][phase]
 tiles = B * 16 * 8 / NWG
 names = ["next-tile index math", "conv1 (+ DMA issue)", "barrier A", "conv2 + stores", "vmcnt (next tile's DMA)", "barrier B", "tile index math", "-"]
