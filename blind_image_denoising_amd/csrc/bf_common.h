@@ -77,6 +77,12 @@ void       bf_set_h3_variant(int v);   // 1 (default) row-streaming kernel, 0 gr
 hipError_t bf_launch_pack_h3(const float* params, const float* state, int64_t p_blocks, int64_t p_stride, float* dst,
                              int64_t d_stride, int layers, int use_bn, float eps, const float* ext_scale,
                              const float* ext_shift, hipStream_t s);
+// training: single 3x3 C16 convolution on fp32 NHWC with the split-f16 arithmetic (same ConvArgs / epilogue flags / grid
+// as bf_launch_conv3x3_c16; a.wpack = one BF_H3_TRAIN_PACK_FLOATS pack of bf_launch_pack_h3_train)
+#define BF_H3_TRAIN_PACK_FLOATS (BF_H3R_WPACK_FLOATS + 64)    // 13 A-operand images (12 used) + 1/s
+#define BF_TRAIN_PACK_STRIDE BF_H3_TRAIN_PACK_FLOATS           // per-convolution slot of the training pack area (>= BF_WPACK_FLOATS)
+hipError_t bf_launch_conv3x3_h3(const ConvArgs& a, int epi, hipStream_t s);
+hipError_t bf_launch_pack_h3_train(const float* params, int64_t p_blocks, int64_t p_stride, float* dst, int layers, hipStream_t s);
 hipError_t bf_launch_h3_from_f32(const float* x, void* y, int B, int H, int W, hipStream_t s);
 hipError_t bf_launch_h3_to_f32(const void* y, float* x, int B, int H, int W, hipStream_t s);
 

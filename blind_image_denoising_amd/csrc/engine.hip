@@ -24,6 +24,9 @@ struct bf_engine {
     // arithmetic of the fused inference blocks: 1 = split-f16 on the f16 matrix cores (fused_h3.hip, needs
     // |activation| < 65504), 0 = exact fp32 on the f32 matrix cores (conv3x3_c16.hip)
     int arith = 1;
+    // arithmetic of the training convolutions (forward + data gradient): 1 = split-f16 on the f16 matrix cores (default),
+    // 0 = exact fp32 on the f32 matrix cores; weight gradients are always exact fp32
+    int train_arith = 1;
     // optional HIP-event bracket around the residual-block launches of a forward (bench.py roofline)
     int timing = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -174,6 +177,7 @@ extern "C" int bf_set_option(bf_handle h, const char* key, int value)
     if (!strcmp(key, "fused_blocks")) { h->fused_blocks = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "fused_tile")) { bf_set_fused_tile(value); return BF_OK; }
     if (!strcmp(key, "h3_variant")) { bf_set_h3_variant(value); return BF_OK; }
+    if (!strcmp(key, "train_arith")) { h->train_arith = value < 0 ? 1 : (value ? 1 : 0); return BF_OK; }
     if (!strcmp(key, "arith")) { h->arith = value < 0 ? 1 : (value ? 1 : 0); return BF_OK; }
     if (!strcmp(key, "timing")) {
         h->timing = value ? 1 : 0;
@@ -220,7 +224,7 @@ __global__ void pack_all_convs_kernel(const float* __restrict__ params, int64_t 
     const int per = with_dgrad ? 4 : 2;
     const int layer = blockIdx.x / per, which = blockIdx.x % per;
     const float* w = params + p_blocks + layer * p_stride + (which & 1) * 2304;
-    float* o = dst + layer * d_stride + which * BF_WPACK_FLOATS;
+    float* o = dst + layer * d_stride + which * (with_dgrad ? (int64_t)BF_TRAIN_PACK_STRIDE : (int64_t)BF_WPACK_FLOATS);
     const int tf = which >> 1;
     for (int idx = threadIdx.x; idx < BF_WPACK_FLOATS; idx += blockDim.x) {
         const int i = idx >> 6, l = idx & 63;
@@ -305,7 +309,7 @@ static TrainLayout train_layout(bf_handle h, int B, int H, int W)
     TrainLayout L;
     const int N = h->d.no_layers;
     int64_t o = 0;
-    L.wpack = o; o += (int64_t)N * 4 * BF_WPACK_FLOATS;
+    L.wpack = o; o += (int64_t)N * 4 * BF_TRAIN_PACK_STRIDE;
     L.wh = o; o += 64;
     L.bn_scale = o; o += (int64_t)N * 32 + 32;
     L.bn_meaninv = o; o += (int64_t)N * 32 + 32;
@@ -591,11 +595,17 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     auto C = [&](int i) { return ACT(2 * (int64_t)N + 1 + i); };
     float* dA = ACT(3 * (int64_t)N + 1);
 
+    const int h3t = h->train_arith == 1;
     if (N > 0) {
-        hipLaunchKernelGGL(pack_all_convs_kernel, dim3(N * 4), dim3(256), 0, s, params, h->p_blocks, h->p_block_stride, w + L.wpack,
-                           (int64_t)4 * BF_WPACK_FLOATS, 1);
-        BF_HIP(hipGetLastError(), "pack_all_convs");
+        if (h3t) {
+            BF_HIP(bf_launch_pack_h3_train(params, h->p_blocks, h->p_block_stride, w + L.wpack, N, s), "pack_h3_train");
+        } else {
+            hipLaunchKernelGGL(pack_all_convs_kernel, dim3(N * 4), dim3(256), 0, s, params, h->p_blocks, h->p_block_stride,
+                               w + L.wpack, (int64_t)4 * BF_TRAIN_PACK_STRIDE, 1);
+            BF_HIP(hipGetLastError(), "pack_all_convs");
+        }
     }
+    auto conv = [&](const ConvArgs& ca, int epi) { return h3t ? bf_launch_conv3x3_h3(ca, epi, s) : bf_launch_conv3x3_c16(ca, epi, s); };
     hipLaunchKernelGGL(premultiply_head_kernel, dim3(1), dim3(64), 0, s, params + h->p_head0, params + h->p_head1, d.head_filters,
                        d.out_channels, w + L.wh);
     BF_HIP(hipGetLastError(), "premultiply_head");
@@ -608,15 +618,15 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     BF_HIP(bf_launch_base_conv(ba, s), "base_conv");
     const int conv_grid = bf_conv3x3_c16_grid(B, H, W);
     for (int i = 0; i < N; ++i) {
-        const float* wp = w + L.wpack + (int64_t)i * 4 * BF_WPACK_FLOATS;
+        const float* wp = w + L.wpack + (int64_t)i * 4 * BF_TRAIN_PACK_STRIDE;
         float* scale = w + L.bn_scale + i * 32;
         ConvArgs ca;
         memset(&ca, 0, sizeof(ca));
         ca.B = B; ca.H = H; ca.W = W;
         ca.in = A(i); ca.out = T(i); ca.wpack = wp;
-        BF_HIP(bf_launch_conv3x3_c16(ca, d.activation == BF_ACT_RELU ? EPI_RELU : 0, s), "conv1");
-        ca.in = T(i); ca.out = C(i); ca.wpack = wp + BF_WPACK_FLOATS; ca.stats = partial;
-        BF_HIP(bf_launch_conv3x3_c16(ca, d.use_bn ? EPI_STATS : 0, s), "conv2");
+        BF_HIP(conv(ca, d.activation == BF_ACT_RELU ? EPI_RELU : 0), "conv1");
+        ca.in = T(i); ca.out = C(i); ca.wpack = wp + BF_TRAIN_PACK_STRIDE; ca.stats = partial;
+        BF_HIP(conv(ca, d.use_bn ? EPI_STATS : 0), "conv2");
         if (d.use_bn) {
             BF_HIP(bf_launch_bn_finalize(partial, conv_grid, count, params + h->p_blocks + i * h->p_block_stride + 4608,
                                          state + i * 32, state + i * 32 + 16, d.bn_eps, d.bn_momentum, scale, scale + 16,
@@ -646,7 +656,7 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     int64_t n4 = npix * 4;
     int bgrid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
     for (int i = N - 1; i >= 0; --i) {
-        const float* wp = w + L.wpack + (int64_t)i * 4 * BF_WPACK_FLOATS;
+        const float* wp = w + L.wpack + (int64_t)i * 4 * BF_TRAIN_PACK_STRIDE;
         float* gblk = grads + h->p_blocks + i * h->p_block_stride;
         float* dC = dA;
         if (d.use_bn) {
@@ -660,11 +670,11 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
         ConvArgs ca;
         memset(&ca, 0, sizeof(ca));
         ca.B = B; ca.H = H; ca.W = W;
-        ca.in = dC; ca.out = T(i); ca.wpack = wp + 3 * BF_WPACK_FLOATS; ca.mask = T(i);
-        BF_HIP(bf_launch_conv3x3_c16(ca, d.activation == BF_ACT_RELU ? EPI_MASK : 0, s), "dgrad2");
+        ca.in = dC; ca.out = T(i); ca.wpack = wp + 3 * BF_TRAIN_PACK_STRIDE; ca.mask = T(i);
+        BF_HIP(conv(ca, d.activation == BF_ACT_RELU ? EPI_MASK : 0), "dgrad2");
         BF_HIP(bf_launch_wgrad3x3_c16(A(i), T(i), partial, gblk, B, H, W, s), "wgrad1");
-        ca.in = T(i); ca.out = dA; ca.wpack = wp + 2 * BF_WPACK_FLOATS; ca.mask = nullptr; ca.res = dA;
-        BF_HIP(bf_launch_conv3x3_c16(ca, EPI_RES, s), "dgrad1");
+        ca.in = T(i); ca.out = dA; ca.wpack = wp + 2 * BF_TRAIN_PACK_STRIDE; ca.mask = nullptr; ca.res = dA;
+        BF_HIP(conv(ca, EPI_RES), "dgrad1");
     }
     BF_HIP(bf_launch_base_wgrad(noisy, dA, partial, grads + h->p_base, B, H, W, d.in_channels, d.kernel_size, d.v_min, d.v_max, s),
            "base_wgrad");
@@ -810,6 +820,23 @@ extern "C" int bf_debug_fused_block_h3(const float* in, const float* w1_hwio, co
     fa.zeros = zeros; fa.dump = dump; fa.dbg = g_fused_dbg;
     if (bf_launch_fused_block_h3(fa, s) != hipSuccess) return BF_EHIP;
     return bf_launch_h3_to_f32(ya, out, B, H, W, s) == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// single split-f16 3x3 convolution on fp32 NHWC (the training convolution); scratch = 4 * BF_H3_TRAIN_PACK floats + 2304
+extern "C" int64_t bf_debug_conv3x3_h3_scratch_floats(void) { return 4 * (int64_t)BF_H3_TRAIN_PACK_FLOATS + 2 * 2304 + 16; }
+extern "C" int bf_debug_conv3x3_h3(const float* in, const float* w_hwio, float* out, const float* res, const float* mask,
+                                   float* stats, float* scratch, int B, int H, int W, int epi, int transpose_flip, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    float* params = scratch + 4 * BF_H3_TRAIN_PACK_FLOATS;        // [w 2304][unused 2304][gamma 16]: one "layer"
+    if (hipMemcpyAsync(params, w_hwio, 2304 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;
+    if (hipMemcpyAsync(params + 2304, w_hwio, 2304 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;
+    if (bf_launch_pack_h3_train(params, 0, 4608 + 16, scratch, 1, s) != hipSuccess) return BF_EHIP;
+    ConvArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.in = in; ca.out = out; ca.wpack = scratch + (transpose_flip ? 2 : 0) * BF_H3_TRAIN_PACK_FLOATS;
+    ca.res = res; ca.mask = mask; ca.stats = stats; ca.B = B; ca.H = H; ca.W = W;
+    return bf_launch_conv3x3_h3(ca, epi, s) == hipSuccess ? BF_OK : BF_EHIP;
 }
 
 extern "C" int64_t bf_debug_wgrad_partial_floats(int B, int H, int W) { return (int64_t)bf_wgrad_grid(B, H, W) * 2304; }

@@ -1199,6 +1199,203 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3s_kernel(FusedH3Args
 
 using H3Spec = H3SCfg<14, 32>;
 
+// ==========================================================================================================
+// Single 3x3 16->16 convolution on fp32 NHWC tensors with the split-f16 arithmetic and the row-streaming inner loop of
+// the fused kernels above: the training convolutions (forward conv1 / conv2, data gradients) -- same epilogue stages
+// as conv3x3_c16_kernel ([ReLU] [mask] [+residual] [BN statistics]), same 16x32 tiles and grid, so it is a drop-in.
+// The fp32 tile is split into hi / lo f16 planes while it is staged into LDS (8 vector instructions per 4 values);
+// a wave streams 8 rows of one 16-column strip; the fp32 result goes straight from the accumulator to HBM.
+// 15 MFMAs of 16 cycles per 16 pixels instead of 36 MFMAs of 32 cycles.
+// ==========================================================================================================
+struct ConvH3Geom {
+    static constexpr int TH = 16, TW = 32, IH = TH + 2, IW = TW + 2, R = 8;
+    static constexpr int PLANE = (IH * IW * 16 + 255) / 256 * 256;
+    static constexpr int LDS_BYTES = 4 * PLANE;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void conv3x3_h3_kernel(ConvArgs a)
+{
+    using G = ConvH3Geom;
+    __shared__ __attribute__((aligned(16))) char tile[G::LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int tiles_x = (a.W + G::TW - 1) / G::TW, tiles_y = (a.H + G::TH - 1) / G::TH;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int y0 = ty * G::TH, x0 = tx * G::TW;
+    const size_t img = (size_t)b * a.H * a.W * 16;
+    const float* inb = a.in + img;
+
+    // weights: 12 A-operand images + 1/s (pack_h3_train_kernel)
+    h8 w[13];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) w[i] = reinterpret_cast<const h8*>(a.wpack)[i * 64 + lane];
+    w[12] = w[0];
+    const float inv_s = a.wpack[BF_H3R_WPACK_FLOATS];
+
+    // stage: fp32 NHWC (1-pixel halo, zero outside the image) -> hi / lo planes [4][IH][IW][8 x f16]
+    for (int e = tid; e < G::IH * G::IW * 4; e += 256) {
+        const int px = e >> 2, quad = e & 3;
+        const int row = px / G::IW, col = px - row * G::IW;
+        const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+            v = *reinterpret_cast<const f32x4*>(inb + ((size_t)gy * a.W + gx) * 16 + quad * 4);
+        h4 hi, lo;
+        h3_split(v, hi, lo);
+        char* p = tile + (quad >> 1) * G::PLANE + px * 16 + (quad & 1) * 8;
+        *reinterpret_cast<h4*>(p) = hi;
+        *reinterpret_cast<h4*>(p + 2 * G::PLANE) = lo;
+    }
+    __syncthreads();
+
+    const int strip = wave & 1, half = wave >> 1;
+    const int px_l = strip * 16 + n;                              // column inside the tile
+    const int o0 = half * G::R;                                   // first output row of this wave
+    const int b1 = (q & 1) * G::PLANE + (o0 * G::IW + px_l) * 16;
+    const int gx = x0 + px_l;
+    struct Epi {
+        struct Pre {};
+        enum { EXTRA_MFMA = 0 };
+        const ConvArgs& a; size_t base; int gy0, gx, q; float inv_s; f32x4 sc, sh;
+        f32x4* s1; f32x4* s2;
+        __device__ __forceinline__ Pre pre(const int) const { return Pre{}; }
+        __device__ __forceinline__ f32x4 finish(const int, const f32x4 acc, const Pre&) const { return acc; }
+        __device__ __forceinline__ void operator()(const int o, const f32x4 acc) const
+        {
+            if (gy0 + o < a.H && gx < a.W) {
+                const size_t idx = base + (size_t)o * a.W * 16;
+                f32x4 v = acc * inv_s;
+                if (EPI & EPI_STATS) { *s1 += v; *s2 += v * v; }
+                if (EPI & EPI_AFFINE) v = v * sc + sh;
+                if (EPI & EPI_RELU) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                if (EPI & EPI_MASK) {
+                    const f32x4 m = *reinterpret_cast<const f32x4*>(a.mask + idx);
+                    v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+                    v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                }
+                if (EPI & EPI_RES) v += *reinterpret_cast<const f32x4*>(a.res + idx);
+                *reinterpret_cast<f32x4*>(a.out + idx) = v;
+            }
+        }
+    };
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (EPI & EPI_AFFINE) {
+        sc = *reinterpret_cast<const f32x4*>(a.scale + q * 4);
+        sh = *reinterpret_cast<const f32x4*>(a.shift + q * 4);
+    }
+    const Epi epi{a, img + ((size_t)(y0 + o0) * a.W + gx) * 16 + q * 4, y0 + o0, gx, q, inv_s, sc, sh, &s1, &s2};
+    h3r_rows<G::R, G::IW * 16, 2 * G::PLANE>(tile, b1 + (q >> 1) * 16, b1 + 32 + (q >> 1) * 2 * G::PLANE, w, epi, H3NoHook{});
+
+    if (EPI & EPI_STATS) {
+        // reduce over the 16 pixel lanes that share a channel quad, then over the 4 waves (fixed order)
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s1[c] += __shfl_xor(s1[c], m);
+                s2[c] += __shfl_xor(s2[c], m);
+            }
+        }
+        __syncthreads();                       // tile no longer needed
+        float* red = reinterpret_cast<float*>(tile);      // [4 waves][32]
+        if (n == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                red[wave * 32 + q * 4 + c] = s1[c];
+                red[wave * 32 + 16 + q * 4 + c] = s2[c];
+            }
+        }
+        __syncthreads();
+        if (tid < 32)
+            a.stats[(size_t)blockIdx.x * 32 + tid] = (red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid]);
+    }
+}
+
+hipError_t bf_launch_conv3x3_h3(const ConvArgs& a, int epi, hipStream_t s)
+{
+    const dim3 grid(bf_conv3x3_c16_grid(a.B, a.H, a.W)), block(256);
+#define BF_CASE(E) case E: hipLaunchKernelGGL(conv3x3_h3_kernel<E>, grid, block, 0, s, a); break;
+    switch (epi) {
+        BF_CASE(0)
+        BF_CASE(EPI_RELU)
+        BF_CASE(EPI_STATS)
+        BF_CASE(EPI_RES)
+        BF_CASE(EPI_MASK)
+        default: return hipErrorInvalidValue;
+    }
+#undef BF_CASE
+    return hipGetLastError();
+}
+
+// training packs: one workgroup per (layer, which) with which = 0 w1 forward, 1 w2 forward, 2 w1 data gradient,
+// 3 w2 data gradient (W'[tap][ci][co] = W[8-tap][co][ci]); row layout of the fused kernels without BN folding or
+// identity; dst = [12 x 64 x 16 B][1/s broadcast x 64 floats]
+__global__ __launch_bounds__(256) void pack_h3_train_kernel(const float* __restrict__ params, int64_t p_blocks, int64_t p_stride,
+                                                            float* __restrict__ dst, int64_t d_stride)
+{
+    __shared__ float red[256];
+    __shared__ float s_scale;
+    const int layer = blockIdx.x >> 2, which = blockIdx.x & 3;
+    const float* w = params + p_blocks + layer * p_stride + (which & 1) * 2304;
+    const int tf = which >> 1;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < 2304; i += 256) m = fmaxf(m, fabsf(w[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float sr = 1.f;
+        const float mx = red[0];
+        if (mx > 0.f && mx < 3.0e38f) {
+            int ex;
+            (void)frexpf(mx, &ex);
+            ex = max(-100, min(100, ex));
+            sr = ldexpf(1.f, 14 - ex);
+        }
+        s_scale = sr;
+    }
+    __syncthreads();
+    const float sr = s_scale;
+    float* out = dst + (layer * 4 + which) * d_stride;
+    _Float16* orow = reinterpret_cast<_Float16*>(out);
+    for (int idx = threadIdx.x; idx < 12 * 64 * 8; idx += 256) {
+        const int i = idx >> 9, l = (idx >> 3) & 63, j = idx & 7;
+        const int cout = l & 15, kslot = 8 * (l >> 4) + j, half = kslot >> 4, cin = kslot & 15;
+        const int dy = i >> 2, kind = i & 3;
+        int tap, part;
+        if (kind == 0) { tap = dy * 3 + half; part = 0; }
+        else if (kind == 1) { tap = dy * 3 + half; part = 1; }
+        else if (kind == 2) { tap = dy * 3 + 2; part = 0; }
+        else { tap = dy * 3 + 2; part = half ? 2 : 1; }
+        const float wv = tf ? w[((8 - tap) * 16 + cout) * 16 + cin] : w[(tap * 16 + cin) * 16 + cout];
+        const float ws = wv * sr;
+        const _Float16 hi = (_Float16)ws;
+        const _Float16 lo = (_Float16)(ws - (float)hi);
+        orow[idx] = part == 0 ? hi : (part == 1 ? lo : (_Float16)0.f);
+    }
+    for (int idx = 12 * 64 * 8 + threadIdx.x; idx < 13 * 64 * 8; idx += 256) orow[idx] = (_Float16)0.f;     // unused 13th image
+    if (threadIdx.x < 64) out[BF_H3R_WPACK_FLOATS + threadIdx.x] = 1.0f / sr;
+}
+
+hipError_t bf_launch_pack_h3_train(const float* params, int64_t p_blocks, int64_t p_stride, float* dst, int layers, hipStream_t s)
+{
+    if (layers <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_h3_train_kernel, dim3(layers * 4), dim3(256), 0, s, params, p_blocks, p_stride, dst,
+                       (int64_t)BF_H3_TRAIN_PACK_FLOATS);
+    return hipGetLastError();
+}
+
 using H3Default = H3Cfg<16, 32, 8>;
 using H3Small = H3Cfg<16, 16, 4>;
 

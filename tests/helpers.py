@@ -48,6 +48,25 @@ def conv3x3_gpu(x, w, epi=0, scale=None, shift=None, res=None, mask=None, transp
     return host(out)
 
 
+def conv3x3_h3_gpu(x, w, epi=0, res=None, mask=None, transpose_flip=0, want_stats=False):
+    """single split-f16 3x3 C16 convolution on fp32 NHWC (the training convolution) through bf_debug_conv3x3_h3."""
+    L = N.lib()
+    B, H, W, _ = x.shape
+    xd, wd = dev(x), dev(w)
+    out = torch.full((B, H, W, 16), float("nan"), dtype=torch.float32, device="cuda")
+    rd = dev(res) if res is not None else None
+    md = dev(mask) if mask is not None else None
+    grid = L.bf_debug_conv3x3_grid(B, H, W)
+    stats = torch.zeros(grid * 32, dtype=torch.float32, device="cuda") if want_stats else None
+    scratch = torch.full((int(L.bf_debug_conv3x3_h3_scratch_floats()),), float("nan"), dtype=torch.float32, device="cuda")
+    rc = L.bf_debug_conv3x3_h3(N.ptr(xd), N.ptr(wd), N.ptr(out), N.ptr(rd), N.ptr(md), N.ptr(stats), N.ptr(scratch),
+                               B, H, W, epi, transpose_flip, N.stream_ptr(xd))
+    assert rc == 0, rc
+    if want_stats:
+        return host(out), host(stats).reshape(grid, 32)
+    return host(out)
+
+
 def fused_block_gpu(x, w1, w2, scale, shift, act1_relu=1):
     L = N.lib()
     B, H, W, _ = x.shape

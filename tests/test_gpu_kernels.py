@@ -6,7 +6,7 @@ import torch
 
 from oracle import bfcnn_oracle as O
 from blind_image_denoising_amd import _native as N
-from helpers import assert_close, conv3x3_gpu, dev, fused_block_gpu, fused_block_h3_gpu, host, wgrad_gpu
+from helpers import assert_close, conv3x3_gpu, conv3x3_h3_gpu, dev, fused_block_gpu, fused_block_h3_gpu, host, wgrad_gpu
 
 pytestmark = pytest.mark.gpu
 
@@ -84,6 +84,39 @@ def test_conv3x3_data_gradient_form(shape):
     dy, w = _rand((B, H, W, 16), 13), _rand((3, 3, 16, 16), 14) * 0.1
     assert_close(conv3x3_gpu(dy, w, transpose_flip=1),
                  O.conv2d_same_grad_input(dy.astype(np.float64), w.astype(np.float64)), what="dgrad")
+
+
+# ---- the split-f16 single convolution of the training step: same oracle, same bars as conv3x3_c16_kernel -------
+@pytest.mark.parametrize("shape", SHAPES + [(2, 40, 70)])
+def test_conv3x3_h3_plain_and_dgrad(shape):
+    B, H, W = shape
+    x, w = _rand((B, H, W, 16), 1), _rand((3, 3, 16, 16), 2) * 0.1
+    x64, w64 = x.astype(np.float64), w.astype(np.float64)
+    assert_close(conv3x3_h3_gpu(x, w), O.conv2d_same(x64, w64), what=f"h3 conv {shape}")
+    assert_close(conv3x3_h3_gpu(x, w, transpose_flip=1), O.conv2d_same_grad_input(x64, w64), what=f"h3 dgrad {shape}")
+
+
+def test_conv3x3_h3_is_exact_on_integers():
+    rng = np.random.default_rng(3)
+    x = rng.integers(-4, 5, (2, 21, 40, 16)).astype(np.float32)
+    w = rng.integers(-3, 4, (3, 3, 16, 16)).astype(np.float32)
+    assert np.array_equal(conv3x3_h3_gpu(x, w), O.conv2d_same(x.astype(np.float64), w.astype(np.float64)))
+
+
+@pytest.mark.parametrize("shape", SHAPES[:4])
+def test_conv3x3_h3_epilogues_and_stats(shape):
+    B, H, W = shape
+    x, w = _rand((B, H, W, 16), 5), _rand((3, 3, 16, 16), 6) * 0.1
+    res, mask = _rand((B, H, W, 16), 9), _rand((B, H, W, 16), 10)
+    c = O.conv2d_same(x.astype(np.float64), w.astype(np.float64))
+    assert_close(conv3x3_h3_gpu(x, w, N.EPI_RELU), np.maximum(c, 0), what="relu")
+    assert_close(conv3x3_h3_gpu(x, w, N.EPI_RES, res=res), c + res, what="res")
+    assert_close(conv3x3_h3_gpu(x, w, N.EPI_MASK, mask=mask), c * (mask > 0), what="mask")
+    out, stats = conv3x3_h3_gpu(x, w, N.EPI_STATS, want_stats=True)
+    assert_close(out, c, what="raw output")
+    tot = stats.astype(np.float64).sum(axis=0)
+    assert_close(tot[:16], c.sum(axis=(0, 1, 2)), rel=1e-5 * np.sqrt(c.size), what="sum")
+    assert_close(tot[16:], (c * c).sum(axis=(0, 1, 2)), rel=2e-5, what="sumsq")
 
 
 @pytest.fixture(params=[0, 1, 2, 3, 4], ids=["tile14x32x4", "tile32x32x8", "tile16x64x8", "dma14x32x4", "v4_14x32x4"])

@@ -37,9 +37,12 @@ def _cmp_grads(spec, got, ref, rel=2e-4):
         assert err <= rel * scale, f"{name}: grad err {err:.3e} vs scale {scale:.3e}"
 
 
+# both arithmetics of the training convolutions (split-f16 default, exact fp32): same oracle, same bars
+@pytest.mark.parametrize("train_arith", [1, 0], ids=["f16x3", "f32"])
 @pytest.mark.parametrize("no_layers,shape", [(1, (2, 16, 32)), (2, (2, 24, 32)), (3, (3, 33, 47))])
-def test_train_step_matches_oracle(no_layers, shape):
+def test_train_step_matches_oracle(no_layers, shape, train_arith):
     cfg, spec, ls, params, state, m, fns = _setup(no_layers)
+    m.set_option("train_arith", train_arith)
     clean, noisy = O.synthetic_batch(*shape, seed=7)
     gt, x = clean.astype(np.float32), noisy.astype(np.float32)
     total, ml, dl, pred, grads = fns.train_step_single_gpu(torch.from_numpy(gt), torch.from_numpy(x), (1.0,), 0.0, None)
