@@ -77,6 +77,7 @@ SIGNATURES = {
     "bf_debug_conv3x3_h3": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "bf_debug_wgrad_partial_floats": (_I64, [_I, _I, _I]),
     "bf_debug_wgrad3x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "bf_debug_wgrad3x3_h3": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "bf_debug_mfma_probe": (_I, [_P, _P, _P, _P]),
 }
 

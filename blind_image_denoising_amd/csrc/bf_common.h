@@ -82,6 +82,7 @@ hipError_t bf_launch_pack_h3(const float* params, const float* state, int64_t p_
 #define BF_H3_TRAIN_PACK_FLOATS (BF_H3R_WPACK_FLOATS + 64)    // 13 A-operand images (12 used) + 1/s
 #define BF_TRAIN_PACK_STRIDE BF_H3_TRAIN_PACK_FLOATS           // per-convolution slot of the training pack area (>= BF_WPACK_FLOATS)
 hipError_t bf_launch_conv3x3_h3(const ConvArgs& a, int epi, hipStream_t s);
+hipError_t bf_launch_wgrad3x3_h3(const float* x, const float* dy, float* partial, float* dw, int B, int H, int W, hipStream_t s);
 hipError_t bf_launch_pack_h3_train(const float* params, int64_t p_blocks, int64_t p_stride, float* dst, int layers, hipStream_t s);
 hipError_t bf_launch_h3_from_f32(const float* x, void* y, int B, int H, int W, hipStream_t s);
 hipError_t bf_launch_h3_to_f32(const void* y, float* x, int B, int H, int W, hipStream_t s);

@@ -25,7 +25,7 @@ struct bf_engine {
     // |activation| < 65504), 0 = exact fp32 on the f32 matrix cores (conv3x3_c16.hip)
     int arith = 1;
     // arithmetic of the training convolutions (forward + data gradient): 1 = split-f16 on the f16 matrix cores (default),
-    // 0 = exact fp32 on the f32 matrix cores; weight gradients are always exact fp32
+    // 0 = exact fp32 on the f32 matrix cores; the weight gradients follow the same switch
     int train_arith = 1;
     // optional HIP-event bracket around the residual-block launches of a forward (bench.py roofline)
     int timing = 0;
@@ -606,6 +606,9 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
         }
     }
     auto conv = [&](const ConvArgs& ca, int epi) { return h3t ? bf_launch_conv3x3_h3(ca, epi, s) : bf_launch_conv3x3_c16(ca, epi, s); };
+    auto wgrad = [&](const float* xx, const float* dyy, float* dw) {
+        return h3t ? bf_launch_wgrad3x3_h3(xx, dyy, partial, dw, B, H, W, s) : bf_launch_wgrad3x3_c16(xx, dyy, partial, dw, B, H, W, s);
+    };
     hipLaunchKernelGGL(premultiply_head_kernel, dim3(1), dim3(64), 0, s, params + h->p_head0, params + h->p_head1, d.head_filters,
                        d.out_channels, w + L.wh);
     BF_HIP(hipGetLastError(), "premultiply_head");
@@ -666,13 +669,13 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
             BF_HIP(bf_launch_bn_bwd_apply(dA, C(i), w + L.coef, C(i), npix, s), "bn_bwd_apply");
             dC = C(i);
         }
-        BF_HIP(bf_launch_wgrad3x3_c16(T(i), dC, partial, gblk + 2304, B, H, W, s), "wgrad2");
+        BF_HIP(wgrad(T(i), dC, gblk + 2304), "wgrad2");
         ConvArgs ca;
         memset(&ca, 0, sizeof(ca));
         ca.B = B; ca.H = H; ca.W = W;
         ca.in = dC; ca.out = T(i); ca.wpack = wp + 3 * BF_TRAIN_PACK_STRIDE; ca.mask = T(i);
         BF_HIP(conv(ca, d.activation == BF_ACT_RELU ? EPI_MASK : 0), "dgrad2");
-        BF_HIP(bf_launch_wgrad3x3_c16(A(i), T(i), partial, gblk, B, H, W, s), "wgrad1");
+        BF_HIP(wgrad(A(i), T(i), gblk), "wgrad1");
         ca.in = T(i); ca.out = dA; ca.wpack = wp + 2 * BF_TRAIN_PACK_STRIDE; ca.mask = nullptr; ca.res = dA;
         BF_HIP(conv(ca, EPI_RES), "dgrad1");
     }
@@ -840,6 +843,11 @@ extern "C" int bf_debug_conv3x3_h3(const float* in, const float* w_hwio, float* 
 }
 
 extern "C" int64_t bf_debug_wgrad_partial_floats(int B, int H, int W) { return (int64_t)bf_wgrad_grid(B, H, W) * 2304; }
+
+extern "C" int bf_debug_wgrad3x3_h3(const float* x, const float* dy, float* partial, float* dw, int B, int H, int W, void* stream)
+{
+    return bf_launch_wgrad3x3_h3(x, dy, partial, dw, B, H, W, (hipStream_t)stream) == hipSuccess ? BF_OK : BF_EHIP;
+}
 
 extern "C" int bf_debug_wgrad3x3(const float* x, const float* dy, float* partial, float* dw, int B, int H, int W, void* stream)
 {

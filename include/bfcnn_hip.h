@@ -202,8 +202,8 @@ int bf_noise_augment(const float* in, float* out_clean, float* out_noisy, int ba
  * "arith" = 1 (default): fused inference blocks run split-f16 ("f16x3": x = hi + lo in f16, three products,
  *   fp32 accumulation) on the f16 matrix cores, ~fp32 accuracy, needs |activation| < 65504;
  *   0: exact fp32 on the f32 matrix cores.  Training and the unfused path are always exact fp32.
- * "train_arith" = 1 (default): the training convolutions (forward and data gradient) run split-f16 on the f16 matrix
- *   cores; 0: exact fp32.  Weight gradients are exact fp32 either way.
+ * "train_arith" = 1 (default): the training convolutions (forward, data gradient, weight gradient) run split-f16 on the
+ *   f16 matrix cores; 0: exact fp32.
  * "fused_tile": tile-geometry variant of the exact-fp32 fused block (A/B only; negative = default). */
 int bf_set_option(bf_handle h, const char* key, int value);
 
@@ -232,6 +232,8 @@ int bf_debug_conv3x3_h3(const float* in, const float* w_hwio, float* out, const 
 int64_t bf_debug_wgrad_partial_floats(int batch, int height, int width);
 int bf_debug_wgrad3x3(const float* x, const float* dy, float* partial, float* dw,
                       int batch, int height, int width, void* stream);
+int bf_debug_wgrad3x3_h3(const float* x, const float* dy, float* partial, float* dw,
+                         int batch, int height, int width, void* stream);
 int bf_debug_mfma_probe(const float* a, const float* b, float* d, void* stream);
 
 #ifdef __cplusplus

@@ -96,12 +96,13 @@ def fused_block_h3_gpu(x, w1, w2, scale, shift, act1_relu=1):
     return host(out)
 
 
-def wgrad_gpu(x, dy):
+def wgrad_gpu(x, dy, h3=False):
     L = N.lib()
     B, H, W, _ = x.shape
     xd, dd = dev(x), dev(dy)
     partial = torch.zeros(int(L.bf_debug_wgrad_partial_floats(B, H, W)), dtype=torch.float32, device="cuda")
     dw = torch.full((3, 3, 16, 16), float("nan"), dtype=torch.float32, device="cuda")
-    rc = L.bf_debug_wgrad3x3(N.ptr(xd), N.ptr(dd), N.ptr(partial), N.ptr(dw), B, H, W, N.stream_ptr(xd))
+    fn = L.bf_debug_wgrad3x3_h3 if h3 else L.bf_debug_wgrad3x3
+    rc = fn(N.ptr(xd), N.ptr(dd), N.ptr(partial), N.ptr(dw), B, H, W, N.stream_ptr(xd))
     assert rc == 0, rc
     return host(dw)

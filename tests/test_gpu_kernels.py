@@ -230,18 +230,20 @@ def test_fused_block_h3_many_tiles_persistent_schedule(h3_variant):
 
 
 @pytest.mark.parametrize("shape", SHAPES + [(8, 64, 64)])
-def test_wgrad3x3(shape):
+@pytest.mark.parametrize("h3", [False, True], ids=["f32", "f16x3"])
+def test_wgrad3x3(shape, h3):
     B, H, W = shape
     x, dy = _rand((B, H, W, 16), 23), _rand((B, H, W, 16), 24)
     ref = O.conv2d_same_grad_kernel(x.astype(np.float64), dy.astype(np.float64), 3, 3)
-    assert_close(wgrad_gpu(x, dy), ref, rel=3e-6 * np.sqrt(B * H * W), what=f"wgrad {shape}")
+    assert_close(wgrad_gpu(x, dy, h3), ref, rel=3e-6 * np.sqrt(B * H * W), what=f"wgrad {shape}")
 
 
-def test_wgrad3x3_exact_on_integers_and_deterministic():
+@pytest.mark.parametrize("h3", [False, True], ids=["f32", "f16x3"])
+def test_wgrad3x3_exact_on_integers_and_deterministic(h3):
     rng = np.random.default_rng(25)
     x = rng.integers(-3, 4, (3, 40, 70, 16)).astype(np.float32)
     dy = rng.integers(-3, 4, (3, 40, 70, 16)).astype(np.float32)
-    a = wgrad_gpu(x, dy)
+    a = wgrad_gpu(x, dy, h3)
     assert np.array_equal(a, O.conv2d_same_grad_kernel(x.astype(np.float64), dy.astype(np.float64), 3, 3))
     xr, dr = _rand((3, 40, 70, 16), 26), _rand((3, 40, 70, 16), 27)
-    assert np.array_equal(wgrad_gpu(xr, dr), wgrad_gpu(xr, dr))      # fixed-order reduction
+    assert np.array_equal(wgrad_gpu(xr, dr, h3), wgrad_gpu(xr, dr, h3))      # fixed-order reduction
