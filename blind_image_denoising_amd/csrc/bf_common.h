@@ -141,12 +141,14 @@ int        bf_head_train_grid(int B, int H, int W);
 // elementwise / reductions
 hipError_t bf_launch_bn_finalize(const float* partial, int nblk, double count, const float* gamma,
                                  float* moving_mean, float* moving_var, float eps, float momentum,
-                                 float* scale, float* shift, float* mean_inv /*[32]*/, hipStream_t s);
+                                 float* scale, float* shift, float* mean_inv /*[32]*/, double* stage1 /*[64*32] or NULL*/,
+                                 hipStream_t s);
 hipError_t bf_launch_affine_add(const float* x, const float* c, const float* scale, const float* shift,
                                 float* y, int64_t npix, hipStream_t s);   // y = x + scale*c + shift
 hipError_t bf_launch_bn_bwd_reduce(const float* dy, const float* c, float* partial, int64_t npix, int grid, hipStream_t s);
 hipError_t bf_launch_bn_bwd_finalize(const float* partial, int nblk, double count, const float* gamma,
-                                     const float* mean_inv, float* coef /*[48]: k1,k2,k3*/, float* dgamma, hipStream_t s);
+                                     const float* mean_inv, float* coef /*[48]: k1,k2,k3*/, float* dgamma,
+                                     double* stage1 /*[64*32] or NULL*/, hipStream_t s);
 hipError_t bf_launch_bn_bwd_apply(const float* dy, const float* c, const float* coef, float* dc, int64_t npix, hipStream_t s);
 hipError_t bf_launch_reduce_partials(const float* partial, int nblk, int width, float* out, float scale, hipStream_t s);
 hipError_t bf_launch_zero(float* p, int64_t n, hipStream_t s);

@@ -298,7 +298,7 @@ extern "C" int bf_pack_inference(bf_handle h, const float* params, const float* 
 // workspace layout
 // ------------------------------------------------------------------------------------------
 struct TrainLayout {
-    int64_t wpack, wh, bn_scale, bn_meaninv, coef, partial, acts, total;   // float offsets
+    int64_t wpack, wh, bn_scale, bn_meaninv, coef, stage1, partial, acts, total;   // float offsets
     int64_t act_floats, partial_floats;
 };
 
@@ -314,6 +314,7 @@ static TrainLayout train_layout(bf_handle h, int B, int H, int W)
     L.bn_scale = o; o += (int64_t)N * 32 + 32;
     L.bn_meaninv = o; o += (int64_t)N * 32 + 32;
     L.coef = o; o += 64;
+    L.stage1 = o; o += 64 * 32 * 2;            // doubles
     int64_t pf = (int64_t)bf_conv3x3_c16_grid(B, H, W) * 32;
     pf = max64(pf, 4096 * 32);
     pf = max64(pf, (int64_t)bf_wgrad_grid(B, H, W) * 2304);
@@ -588,6 +589,7 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     const int64_t npix = (int64_t)B * H * W;
     const double count = (double)npix;
     float* partial = w + L.partial;
+    double* stage1 = reinterpret_cast<double*>(w + L.stage1);     // (offset is a multiple of 2 floats: 8-byte aligned)
     auto ACT = [&](int64_t i) { return w + L.acts + i * L.act_floats; };
     // buffer map: A_i = ACT(i) (i = 0..N) ; T_i = ACT(N+1+i) ; C_i = ACT(2N+1+i) ; dA = ACT(3N+1)
     auto A = [&](int i) { return ACT(i); };
@@ -633,7 +635,7 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
         if (d.use_bn) {
             BF_HIP(bf_launch_bn_finalize(partial, conv_grid, count, params + h->p_blocks + i * h->p_block_stride + 4608,
                                          state + i * 32, state + i * 32 + 16, d.bn_eps, d.bn_momentum, scale, scale + 16,
-                                         w + L.bn_meaninv + i * 32, s), "bn_finalize");
+                                         w + L.bn_meaninv + i * 32, stage1, s), "bn_finalize");
         } else {
             hipLaunchKernelGGL(fill_identity_affine_kernel, dim3(1), dim3(64), 0, s, scale);
             BF_HIP(hipGetLastError(), "identity_affine");
@@ -665,7 +667,7 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
         if (d.use_bn) {
             BF_HIP(bf_launch_bn_bwd_reduce(dA, C(i), partial, npix, bgrid, s), "bn_bwd_reduce");
             BF_HIP(bf_launch_bn_bwd_finalize(partial, bgrid, count, params + h->p_blocks + i * h->p_block_stride + 4608,
-                                             w + L.bn_meaninv + i * 32, w + L.coef, gblk + 4608, s), "bn_bwd_finalize");
+                                             w + L.bn_meaninv + i * 32, w + L.coef, gblk + 4608, stage1, s), "bn_bwd_finalize");
             BF_HIP(bf_launch_bn_bwd_apply(dA, C(i), w + L.coef, C(i), npix, s), "bn_bwd_apply");
             dC = C(i);
         }

@@ -7,26 +7,37 @@
 // ------------------------------------------------------------------------------------------
 // out[i] = scale * sum_{r<nblk} partial[r*width + i]
 // ------------------------------------------------------------------------------------------
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nblk, int width,
-                                       float* __restrict__ out, float scale)
+// 64 columns x 16 row stripes per workgroup (one thread per column walking all rows alone needed 40 us for the 512 x 2304
+// partials of a weight gradient: 9 workgroups, 512 dependent-ish loads each).  Fixed summation order: stripe s adds rows
+// s, s+16, ... ; the 16 stripe sums are then added in order.
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partial, int nblk, int width,
+                                                               float* __restrict__ out, float scale)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= width) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int r = 0;
-    for (; r + 3 < nblk; r += 4) {
-        s0 += partial[(size_t)r * width + i];
-        s1 += partial[(size_t)(r + 1) * width + i];
-        s2 += partial[(size_t)(r + 2) * width + i];
-        s3 += partial[(size_t)(r + 3) * width + i];
+    __shared__ float red[16][64];
+    const int col = threadIdx.x & 63, stripe = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + col;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < width) {
+        int r = stripe;
+        for (; r + 16 < nblk; r += 32) {
+            s0 += partial[(size_t)r * width + i];
+            s1 += partial[(size_t)(r + 16) * width + i];
+        }
+        if (r < nblk) s0 += partial[(size_t)r * width + i];
     }
-    for (; r < nblk; ++r) s0 += partial[(size_t)r * width + i];
-    out[i] = ((s0 + s1) + (s2 + s3)) * scale;
+    red[stripe][col] = s0 + s1;
+    __syncthreads();
+    if (stripe == 0 && i < width) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += red[k][col];
+        out[i] = a * scale;
+    }
 }
 
 hipError_t bf_launch_reduce_partials(const float* partial, int nblk, int width, float* out, float scale, hipStream_t s)
 {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 255) / 256), dim3(256), 0, s, partial, nblk, width, out, scale);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 63) / 64), dim3(1024), 0, s, partial, nblk, width, out, scale);
     return hipGetLastError();
 }
 
@@ -50,7 +61,25 @@ hipError_t bf_launch_zero(float* p, int64_t n, hipStream_t s)
 // partial = [nblk][32] (sum[16], sumsq[16]) from the conv epilogue.  Outputs the folded
 // scale/shift for the apply pass and mean/inv for the backward pass.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, double count,
+// stage 1 of the [nblk][32] reductions: 64 workgroups, each sums its share of the rows in fp64 (fixed order) -> [64][32]
+constexpr int BN_STAGE1 = 64;
+__global__ __launch_bounds__(1024) void reduce_rows32_kernel(const float* __restrict__ partial, int nblk, double* __restrict__ out)
+{
+    __shared__ double red[32][32];
+    const int ch = threadIdx.x & 31, stripe = threadIdx.x >> 5;
+    double s = 0.0;
+    for (int r = blockIdx.x * 32 + stripe; r < nblk; r += BN_STAGE1 * 32) s += (double)partial[(size_t)r * 32 + ch];
+    red[stripe][ch] = s;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double a = 0.0;
+        for (int k = 0; k < 32; ++k) a += red[k][threadIdx.x];
+        out[blockIdx.x * 32 + threadIdx.x] = a;
+    }
+}
+
+template <typename PT>
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const PT* __restrict__ partial, int nblk, double count,
                                                           const float* __restrict__ gamma, float* moving_mean,
                                                           float* moving_var, float eps, float momentum,
                                                           float* scale, float* shift, float* mean_inv)
@@ -84,10 +113,16 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
 
 hipError_t bf_launch_bn_finalize(const float* partial, int nblk, double count, const float* gamma, float* moving_mean,
                                  float* moving_var, float eps, float momentum, float* scale, float* shift,
-                                 float* mean_inv, hipStream_t s)
+                                 float* mean_inv, double* stage1, hipStream_t s)
 {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, s, partial, nblk, count, gamma, moving_mean, moving_var,
-                       eps, momentum, scale, shift, mean_inv);
+    if (nblk > 512 && stage1) {      // 4096 tile partials at B=32, 256x256: one workgroup alone needed 40 us
+        hipLaunchKernelGGL(reduce_rows32_kernel, dim3(BN_STAGE1), dim3(1024), 0, s, partial, nblk, stage1);
+        hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(1), dim3(1024), 0, s, stage1, BN_STAGE1, count, gamma, moving_mean,
+                           moving_var, eps, momentum, scale, shift, mean_inv);
+    } else {
+        hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(1), dim3(1024), 0, s, partial, nblk, count, gamma, moving_mean, moving_var,
+                           eps, momentum, scale, shift, mean_inv);
+    }
     return hipGetLastError();
 }
 
@@ -164,7 +199,8 @@ hipError_t bf_launch_bn_bwd_reduce(const float* dy, const float* c, float* parti
 
 // pass 2: dgamma = sum dy*xhat ; dc = k1*dy + k2*c + k3 with
 //   k1 = gamma*inv, k2 = -gamma*inv^2*mean(dy*xhat), k3 = -gamma*inv*mean(dy) + gamma*inv^2*mean*mean(dy*xhat)
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, double count,
+template <typename PT>
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const PT* __restrict__ partial, int nblk, double count,
                                                               const float* __restrict__ gamma, const float* __restrict__ mean_inv,
                                                               float* coef, float* dgamma)
 {
@@ -191,9 +227,15 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
 }
 
 hipError_t bf_launch_bn_bwd_finalize(const float* partial, int nblk, double count, const float* gamma,
-                                     const float* mean_inv, float* coef, float* dgamma, hipStream_t s)
+                                     const float* mean_inv, float* coef, float* dgamma, double* stage1, hipStream_t s)
 {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, s, partial, nblk, count, gamma, mean_inv, coef, dgamma);
+    if (nblk > 512 && stage1) {
+        hipLaunchKernelGGL(reduce_rows32_kernel, dim3(BN_STAGE1), dim3(1024), 0, s, partial, nblk, stage1);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(1), dim3(1024), 0, s, stage1, BN_STAGE1, count, gamma, mean_inv, coef,
+                           dgamma);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3(1), dim3(1024), 0, s, partial, nblk, count, gamma, mean_inv, coef, dgamma);
+    }
     return hipGetLastError();
 }
 

@@ -58,6 +58,20 @@ def test_train_step_matches_oracle(no_layers, shape, train_arith):
     assert np.abs(m.state.cpu().numpy() - r_state).max() < 1e-5          # BN moving statistics updated
 
 
+def test_train_step_many_tiles_two_stage_reductions():
+    """more than 512 tile partials per BatchNorm (the two-stage fp64 reductions) and several tiles per persistent
+    weight-gradient workgroup: loss, BN state and gradients against the oracle at a larger shape."""
+    cfg, spec, ls, params, state, m, fns = _setup(1)
+    clean, noisy = O.synthetic_batch(17, 128, 160, seed=11)
+    gt, x = clean.astype(np.float32), noisy.astype(np.float32)
+    total, ml, dl, pred, grads = fns.train_step_single_gpu(torch.from_numpy(gt), torch.from_numpy(x), (1.0,), 0.0, None)
+    r_total, r_ml, r_dl, r_pred, r_grads, r_state = O.train_step_single_gpu(
+        spec, ls, params, state, gt.astype(np.float64), x.astype(np.float64))
+    assert abs(total.item() - r_total) <= 1e-5 * abs(r_total)
+    _cmp_grads(spec, grads.cpu().numpy().astype(np.float64), r_grads)
+    assert np.abs(m.state.cpu().numpy() - r_state).max() < 1e-5
+
+
 def test_golden_train_step_and_adam():
     z, n = np.load(G / "train_step.npz"), np.load(G / "net_2blocks.npz")
     cfg = O.canonical_config(no_layers=2)
