@@ -327,23 +327,35 @@ class HydraModel:
             ws = self.workspace(N.BF_MODE_INFERENCE, B, H, W)
             N.check(self._lib.bf_forward_f32(self._h, N.ptr(self.packed()), N.ptr(x), N.ptr(out), B, H, W,
                                              N.ptr(ws), ws.numel(), N.stream_ptr(x)), self._h, "bf_forward_f32")
-            if was_numpy:
-                self.check_status()
+            if was_numpy and not self.check_status(raise_on_overflow=not self.auto_exact_fallback):
+                # an activation left the f16 range: these weights need the exact-fp32 kernels -- switch for good, re-run
+                logger.warning("activations exceed the f16 range: switching this model to the exact-fp32 kernels (arith = 0)")
+                self.set_option("arith", 0)
+                return self(x, training=False).cpu().numpy()
         return out.cpu().numpy() if was_numpy else out
 
-    def check_status(self):
-        """Reads the status word of the last inference forward (synchronises the stream): raises when an
-        activation left the f16 range inside the split-f16 blocks -- the result is then not trustworthy and the
-        exact-fp32 kernels (`set_option("arith", 0)`) are the ones to use for these weights."""
+    # True: when host arrays are handed back and the status word reports an f16-range overflow, the model switches to the
+    # exact-fp32 kernels and the forward is repeated (a drop-in must not fail on weights the reference handles);
+    # False: raise FloatingPointError instead.
+    auto_exact_fallback = True
+
+    def check_status(self, raise_on_overflow: bool = True) -> bool:
+        """Reads the status word of the last inference forward (synchronises the stream).  Returns True when it is
+        clean; when an activation left the f16 range inside the split-f16 blocks -- the result is then not trustworthy
+        and the exact-fp32 kernels (`set_option("arith", 0)`) are the ones to use for these weights -- raises
+        FloatingPointError or returns False."""
         ws = self._workspace
         if ws is None:
-            return
+            return True
         n = ws.numel()
         off = (n - N.BF_STATUS_BYTES) // 4 * 4
         status = int(ws[off:off + 4].view(torch.int32).item())
         if status & N.BF_STATUS_F16_RANGE:
-            raise FloatingPointError("an activation left the f16 range (|x| >= 65504) inside the split-f16 residual "
-                                     "blocks; call set_option('arith', 0) to run the exact-fp32 kernels")
+            if raise_on_overflow:
+                raise FloatingPointError("an activation left the f16 range (|x| >= 65504) inside the split-f16 residual "
+                                         "blocks; call set_option('arith', 0) to run the exact-fp32 kernels")
+            return False
+        return True
 
     def predict(self, x):
         return self(x, training=False)

@@ -53,6 +53,9 @@ class DenoiserModule:
             x = torch.zeros((B, Hp, Wp, C), dtype=torch.float32, device=hydra.device)
             x[:, :H, :W, :] = image.to(torch.float32)
             out = hydra(x, training=False)[:, :H, :W, :].contiguous()
-        if was_numpy:
-            hydra.check_status()          # host arrays are handed back: the stream is synchronised anyway
+        if was_numpy and not hydra.check_status(raise_on_overflow=not hydra.auto_exact_fallback):
+            # host arrays are handed back (the stream is synchronised anyway) and an activation left the f16 range:
+            # switch this model to the exact-fp32 kernels for good and repeat the call
+            hydra.set_option("arith", 0)
+            return self(image.cpu().numpy())
         return out.cpu().numpy() if was_numpy else out

@@ -160,12 +160,19 @@ def test_f16_range_guard():
     x = noisy.astype(np.float32)
     ref = O.hydra_forward(spec, big, state, x.astype(np.float64))
     assert np.isfinite(ref).all()
+    m.auto_exact_fallback = False
     with pytest.raises(FloatingPointError):
         m(x)
     with pytest.raises(FloatingPointError):
         bf.DenoiserModule(m)(noisy)
+    m.auto_exact_fallback = True                      # default: switch to the exact-fp32 kernels and repeat the forward
+    got_auto = m(x)
+    assert np.isfinite(got_auto).all() and np.abs(got_auto - ref).max() <= 0.6
+    u8 = bf.DenoiserModule(m)(noisy)
+    assert u8.dtype == np.uint8 and u8.shape == noisy.shape
     m.set_option("arith", 0)
     got = m(x)                                        # exact fp32: no range limit
+    assert np.array_equal(got, got_auto)
     assert np.isfinite(got).all() and np.abs(got - ref).max() <= 0.6     # saturated tanh head: coarse bar
     m.set_option("arith", 1)
     m.set_weights(params, state)
