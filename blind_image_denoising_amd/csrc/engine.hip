@@ -10,6 +10,8 @@
 #include <string>
 #include <vector>
 
+constexpr int BF_TIMING_RING = 256;
+
 struct bf_engine {
     bf_resnet_desc d;
     std::string err;
@@ -29,7 +31,9 @@ struct bf_engine {
     int train_arith = 1;
     // optional HIP-event bracket around the residual-block launches of a forward (bench.py roofline)
     int timing = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // ring of event pairs: one pair per timed forward since the option was (re)set, BF_TIMING_RING forwards at most
+    std::vector<hipEvent_t> ev;
+    int64_t n_timed = 0;
     int timed_launches = 0;
 };
 
@@ -154,8 +158,7 @@ extern "C" int bf_create(const bf_resnet_desc* d, bf_handle* out)
 extern "C" void bf_destroy(bf_handle h)
 {
     if (!h) return;
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
-    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     delete h;
 }
 extern "C" int64_t bf_param_count(bf_handle h) { return h ? h->n_params : -1; }
@@ -181,9 +184,11 @@ extern "C" int bf_set_option(bf_handle h, const char* key, int value)
     if (!strcmp(key, "arith")) { h->arith = value < 0 ? 1 : (value ? 1 : 0); return BF_OK; }
     if (!strcmp(key, "timing")) {
         h->timing = value ? 1 : 0;
-        if (h->timing && !h->ev0) {
-            if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess)
-                return fail(h, BF_EHIP, "hipEventCreate failed");
+        h->n_timed = 0;                             // (re)setting the option restarts the measurement window
+        if (h->timing && h->ev.empty()) {
+            h->ev.resize(2 * BF_TIMING_RING, nullptr);
+            for (hipEvent_t& e : h->ev)
+                if (hipEventCreate(&e) != hipSuccess) return fail(h, BF_EHIP, "hipEventCreate failed");
         }
         return BF_OK;
     }
@@ -195,10 +200,18 @@ extern "C" int bf_set_option(bf_handle h, const char* key, int value)
 extern "C" int bf_get_timing(bf_handle h, float* ms, int* launches)
 {
     if (!h || !ms || !launches) return BF_EINVAL;
-    if (!h->timing || !h->ev0) return fail(h, BF_EINVAL, "timing option is off");
-    hipError_t e = hipEventElapsedTime(ms, h->ev0, h->ev1);
-    if (e != hipSuccess) return hip_fail(h, e, "hipEventElapsedTime");
-    *launches = h->timed_launches;
+    if (!h->timing || h->ev.empty()) return fail(h, BF_EINVAL, "timing option is off");
+    const int64_t n = h->n_timed < BF_TIMING_RING ? h->n_timed : BF_TIMING_RING;
+    if (n == 0) return fail(h, BF_EINVAL, "no forward has run since the timing option was set");
+    double total = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        float one = 0.f;
+        hipError_t e = hipEventElapsedTime(&one, h->ev[2 * i], h->ev[2 * i + 1]);
+        if (e != hipSuccess) return hip_fail(h, e, "hipEventElapsedTime");
+        total += one;
+    }
+    *ms = (float)total;
+    *launches = (int)(h->timed_launches * n);
     return BF_OK;
 }
 
@@ -366,7 +379,8 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
     BF_HIP(bf_launch_base_conv(ba, s), "base_conv");
 
     int cur = 0;
-    if (h->timing) BF_HIP(hipEventRecord(h->ev0, s), "hipEventRecord");
+    const int64_t tslot = h->n_timed % BF_TIMING_RING;
+    if (h->timing) BF_HIP(hipEventRecord(h->ev[2 * tslot], s), "hipEventRecord");
     for (int i = 0; i < d.no_layers; ++i) {
         const float* blk = pk + h->k_blocks + i * h->k_block_stride;
         if (h3) {
@@ -402,8 +416,9 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
         }
     }
     if (h->timing) {
-        BF_HIP(hipEventRecord(h->ev1, s), "hipEventRecord");
+        BF_HIP(hipEventRecord(h->ev[2 * tslot + 1], s), "hipEventRecord");
         h->timed_launches = d.no_layers * (h->fused_blocks ? 1 : 2);
+        ++h->n_timed;
     }
     HeadArgs ha;
     ha.feat = buf[cur];

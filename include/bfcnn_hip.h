@@ -208,8 +208,10 @@ int bf_noise_augment(const float* in, float* out_clean, float* out_noisy, int ba
 int bf_set_option(bf_handle h, const char* key, int value);
 
 /* with option "timing" = 1 every forward brackets its residual-block launches with two HIP events on
- * the caller's stream; after the caller has synchronised, this returns the elapsed milliseconds of
- * the LAST forward's bracket and the number of kernel launches inside it (bench.py roofline). */
+ * the caller's stream (a ring of 256 pairs; setting the option again restarts the window); after the
+ * caller has synchronised, this returns the SUM of the elapsed milliseconds of the brackets of all
+ * forwards since the option was set (the last 256 at most) and the number of kernel launches inside
+ * them (bench.py roofline: average launch duration over the timed region). */
 int bf_get_timing(bf_handle h, float* ms, int* launches);
 
 /* single 3x3 16->16 convolution with epilogue flags (1 relu, 2 affine, 4 residual, 8 mask,
