@@ -40,6 +40,28 @@ def test_prepare_data_semantics():
     assert np.abs(n2 - clean).max() <= 0.1 * 255 + 0.5
 
 
+def test_prepare_data_draws_follow_the_reference_config():
+    """per-batch scalars of dataset.py:141-142, 170-187 (host side, no GPU): options fire with probability 1/2, the
+    standard deviations are uniform in [min, max] of the configured lists, disabled terms never fire."""
+    import blind_image_denoising_amd as bf
+    prep = bf.PrepareData({"random_left_right": True, "random_up_down": False, "additional_noise": [20, 5, 10],
+                           "multiplicative_noise": []}, seed=0)
+    draws = [prep.draw() for _ in range(4000)]
+    assert not any(d["flip_up_down"] for d in draws) and all(d["mult_std"] == 0.0 for d in draws)
+    assert abs(np.mean([d["flip_left_right"] for d in draws]) - 0.5) < 0.03
+    adds = np.array([d["add_std"] for d in draws])
+    assert abs((adds > 0).mean() - 0.5) < 0.03
+    on = adds[adds > 0]
+    assert on.min() >= 5 and on.max() <= 20 and abs(on.mean() - 12.5) < 0.4
+    assert len({d["seed"] for d in draws}) == len(draws)
+    assert bf.PrepareData({}, seed=1).draw()["add_std"] == 0.0
+    for bad in ({"random_blur": True}, {"use_jpeg_noise": True}, {"random_rotate": 0.1}, {"quantization": 4}, {"inpaint_drop_rate": 0.1}):
+        with pytest.raises(NotImplementedError):
+            bf.PrepareData(bad)
+    with pytest.raises(ValueError):
+        bf.dataset_builder({}, None)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("flip", [(False, False), (True, False), (False, True), (True, True)])
 @pytest.mark.parametrize("stds", [(0.0, 0.0), (0.0, 20.0), (0.1, 0.0), (0.05, 7.5)])
