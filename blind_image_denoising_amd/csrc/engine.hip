@@ -96,8 +96,10 @@ extern "C" int bf_create(const bf_resnet_desc* d, bf_handle* out)
     if (d->filters != BF_C) return fail(nullptr, BF_EUNSUPPORTED, "filters %d: the MFMA path is built for 16", d->filters);
     if (d->kernel_size != 1 && d->kernel_size != 3 && d->kernel_size != 5 && d->kernel_size != 7)
         return fail(nullptr, BF_EUNSUPPORTED, "base kernel_size %d: only 1,3,5,7", d->kernel_size);
-    if (d->block_convs != 2 || d->block_kernel != 3)
-        return fail(nullptr, BF_EUNSUPPORTED, "block_kernels must be [3,3] (got %d convs of %d)", d->block_convs, d->block_kernel);
+    // [3,3] is the fused / trainable path; [3] and [3,3,3] (conv1 no-BN+act, conv2 BN+act, conv3 BN+linear, backbone_blocks.py:
+    // 174-213) run inference through the single-convolution kernel with the general epilogue [affine][ReLU][+residual]
+    if (d->block_kernel != 3)
+        return fail(nullptr, BF_EUNSUPPORTED, "block_kernels must be 3x3 (got %d convs of %d)", d->block_convs, d->block_kernel);
     if (d->activation != BF_ACT_RELU && d->activation != BF_ACT_LINEAR)
         return fail(nullptr, BF_EUNSUPPORTED, "block activation must be relu or linear");
     if (d->base_activation != BF_ACT_LINEAR)
@@ -114,16 +116,17 @@ extern "C" int bf_create(const bf_resnet_desc* d, bf_handle* out)
     add_tensor(h->tensors, "base/kernel", off, 4, k, k, cin, BF_C, BF_KIND_CONV, d->reg_base);
     h->n_base = off;
     h->p_blocks = off;
-    h->p_block_stride = 2 * 2304 + (d->use_bn ? 16 : 0);
+    const int nb = d->block_convs;
+    h->p_block_stride = nb * 2304 + (d->use_bn ? (nb - 1) * 16 : 0);
     char name[64];
     for (int i = 0; i < d->no_layers; ++i) {
-        snprintf(name, sizeof(name), "block%d/conv0/kernel", i);
-        add_tensor(h->tensors, name, off, 4, 3, 3, BF_C, BF_C, BF_KIND_CONV, d->reg_block);
-        snprintf(name, sizeof(name), "block%d/conv1/kernel", i);
-        add_tensor(h->tensors, name, off, 4, 3, 3, BF_C, BF_C, BF_KIND_CONV, d->reg_block);
-        if (d->use_bn) {
-            snprintf(name, sizeof(name), "block%d/bn1/gamma", i);
-            add_tensor(h->tensors, name, off, 1, BF_C, 0, 0, 0, BF_KIND_GAMMA, BF_REG_NONE);
+        for (int j = 0; j < nb; ++j) {             // keras creation order: conv j, then its BN gamma (first conv has no BN)
+            snprintf(name, sizeof(name), "block%d/conv%d/kernel", i, j);
+            add_tensor(h->tensors, name, off, 4, 3, 3, BF_C, BF_C, BF_KIND_CONV, d->reg_block);
+            if (j >= 1 && d->use_bn) {
+                snprintf(name, sizeof(name), "block%d/bn%d/gamma", i, j);
+                add_tensor(h->tensors, name, off, 1, BF_C, 0, 0, 0, BF_KIND_GAMMA, BF_REG_NONE);
+            }
         }
     }
     h->p_head0 = off;
@@ -133,18 +136,21 @@ extern "C" int bf_create(const bf_resnet_desc* d, bf_handle* out)
     h->n_params = off;
     int64_t soff = 0;
     if (d->use_bn) {
-        for (int i = 0; i < d->no_layers; ++i) {
-            snprintf(name, sizeof(name), "block%d/bn1/moving_mean", i);
-            add_tensor(h->states, name, soff, 1, BF_C, 0, 0, 0, BF_KIND_MOVING_MEAN, BF_REG_NONE);
-            snprintf(name, sizeof(name), "block%d/bn1/moving_variance", i);
-            add_tensor(h->states, name, soff, 1, BF_C, 0, 0, 0, BF_KIND_MOVING_VAR, BF_REG_NONE);
-        }
+        for (int i = 0; i < d->no_layers; ++i)
+            for (int j = 1; j < nb; ++j) {
+                snprintf(name, sizeof(name), "block%d/bn%d/moving_mean", i, j);
+                add_tensor(h->states, name, soff, 1, BF_C, 0, 0, 0, BF_KIND_MOVING_MEAN, BF_REG_NONE);
+                snprintf(name, sizeof(name), "block%d/bn%d/moving_variance", i, j);
+                add_tensor(h->states, name, soff, 1, BF_C, 0, 0, 0, BF_KIND_MOVING_VAR, BF_REG_NONE);
+            }
     }
     h->n_state = soff;
     // packed layout
     int64_t ko = 0;
     h->k_base = ko; ko += align_up(h->n_base, 64);
-    h->k_blocks = ko; h->k_block_stride = 2 * BF_WPACK_FLOATS + 32; ko += h->k_block_stride * d->no_layers;
+    // per block: nb weight images, then one folded (scale, shift) pair per convolution (identity for the BN-less first one)
+    h->k_blocks = ko; h->k_block_stride = nb == 2 ? 2 * BF_WPACK_FLOATS + 32 : nb * (BF_WPACK_FLOATS + 32);
+    ko += h->k_block_stride * d->no_layers;
     h->k_w0 = ko; ko += align_up(16 * hf, 64);
     h->k_w1 = ko; ko += align_up(hf * co, 64);
     h->k_wh = ko; ko += 64;
@@ -283,6 +289,35 @@ __global__ void pack_edges_kernel(const float* __restrict__ params, float* __res
     }
 }
 
+// block_kernels of length 1 or 3: per block [nb weight images][nb x (scale16, shift16)]
+__global__ void pack_generic_blocks_kernel(const float* __restrict__ params, const float* __restrict__ state, int64_t p_blocks,
+                                           int64_t p_stride, float* __restrict__ dst, int64_t d_stride, int nb, int use_bn, float eps)
+{
+    const int layer = blockIdx.x / nb, j = blockIdx.x % nb;
+    const int64_t conv_off = (int64_t)j * 2304 + (use_bn && j >= 2 ? (j - 1) * 16 : 0);   // gamma j-1 sits before conv j (j >= 2)
+    const float* w = params + p_blocks + layer * p_stride + conv_off;
+    float* o = dst + layer * d_stride + (int64_t)j * BF_WPACK_FLOATS;
+    for (int idx = threadIdx.x; idx < BF_WPACK_FLOATS; idx += blockDim.x) {
+        const int i = idx >> 6, l = idx & 63;
+        const int tap = i >> 2, kk = i & 3;
+        const int cin = 4 * (l >> 4) + kk, cout = l & 15;
+        o[idx] = w[(tap * 16 + cin) * 16 + cout];
+    }
+    if (threadIdx.x < 16) {
+        const int c = threadIdx.x;
+        float sc = 1.f, sh = 0.f;
+        if (use_bn && j >= 1) {
+            const float g = w[2304 + c];                                   // gamma follows its convolution
+            const float* st = state + ((int64_t)layer * (nb - 1) + (j - 1)) * 32;
+            sc = g / sqrtf(st[16 + c] + eps);
+            sh = -sc * st[c];
+        }
+        float* aff = dst + layer * d_stride + (int64_t)nb * BF_WPACK_FLOATS + j * 32;
+        aff[c] = sc;
+        aff[16 + c] = sh;
+    }
+}
+
 extern "C" int bf_pack_inference(bf_handle h, const float* params, const float* state, void* packed, void* stream)
 {
     if (!h) return BF_EINVAL;
@@ -291,7 +326,11 @@ extern "C" int bf_pack_inference(bf_handle h, const float* params, const float* 
     hipStream_t s = (hipStream_t)stream;
     float* pk = (float*)packed;
     const bf_resnet_desc& d = h->d;
-    if (d.no_layers > 0) {
+    if (d.no_layers > 0 && d.block_convs != 2) {
+        hipLaunchKernelGGL(pack_generic_blocks_kernel, dim3(d.no_layers * d.block_convs), dim3(256), 0, s, params, state, h->p_blocks,
+                           h->p_block_stride, pk + h->k_blocks, h->k_block_stride, d.block_convs, d.use_bn, d.bn_eps);
+        BF_HIP(hipGetLastError(), "pack_generic_blocks");
+    } else if (d.no_layers > 0) {
         hipLaunchKernelGGL(pack_all_convs_kernel, dim3(d.no_layers * 2), dim3(256), 0, s, params, h->p_blocks, h->p_block_stride,
                            pk + h->k_blocks, h->k_block_stride, 0);
         BF_HIP(hipGetLastError(), "pack_all_convs");
@@ -373,7 +412,7 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
     ba.in_is_u8 = in_is_u8; ba.act_relu = d.base_activation == BF_ACT_RELU;
     ba.v_min = d.v_min; ba.v_max = d.v_max;
     // split-f16 blocks keep the activations split-planar between base conv and head (same bytes as fp32)
-    const int h3 = h->fused_blocks && h->arith == 1 && d.no_layers > 0;
+    const int h3 = h->fused_blocks && h->arith == 1 && d.no_layers > 0 && d.block_convs == 2;
     ba.out_split = h3;
     ba.status = status;
     BF_HIP(bf_launch_base_conv(ba, s), "base_conv");
@@ -383,7 +422,27 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
     if (h->timing) BF_HIP(hipEventRecord(h->ev[2 * tslot], s), "hipEventRecord");
     for (int i = 0; i < d.no_layers; ++i) {
         const float* blk = pk + h->k_blocks + i * h->k_block_stride;
-        if (h3) {
+        if (d.block_convs != 2) {
+            // general block: conv1 (no BN) + act, [conv2 + BN + act,] conv_last + BN + linear, + skip (backbone_blocks.py:174-242;
+            // a one-convolution block is conv (no BN, linear) + skip: the last activation is forced to base_activation)
+            const int nbk = d.block_convs;
+            const float* aff = blk + (int64_t)nbk * BF_WPACK_FLOATS;
+            int src = cur;
+            for (int j = 0; j < nbk; ++j) {
+                const bool last = j == nbk - 1;
+                int dst = (src + 1) % 3;
+                if (dst == cur) dst = (dst + 1) % 3;                 // the block input stays alive for the skip
+                ConvArgs ca;
+                memset(&ca, 0, sizeof(ca));
+                ca.in = buf[src]; ca.out = buf[dst]; ca.wpack = blk + (int64_t)j * BF_WPACK_FLOATS; ca.B = B; ca.H = H; ca.W = W;
+                ca.scale = aff + j * 32; ca.shift = ca.scale + 16; ca.res = buf[cur];
+                const bool relu = !last && d.activation == BF_ACT_RELU;
+                int epi = (j >= 1 ? EPI_AFFINE : 0) | (relu ? EPI_RELU : 0) | (last ? EPI_RES : 0);
+                BF_HIP(bf_launch_conv3x3_c16(ca, epi, s), "block conv");
+                src = dst;
+            }
+            cur = src;
+        } else if (h3) {
             const float* b3 = pk + h->k_h3 + (int64_t)i * BF_H3_BLOCK_FLOATS;
             FusedH3Args fa;
             fa.in = buf[cur]; fa.out = buf[cur ^ 1];
@@ -417,7 +476,7 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
     }
     if (h->timing) {
         BF_HIP(hipEventRecord(h->ev[2 * tslot + 1], s), "hipEventRecord");
-        h->timed_launches = d.no_layers * (h->fused_blocks ? 1 : 2);
+        h->timed_launches = d.no_layers * (d.block_convs != 2 ? d.block_convs : (h->fused_blocks ? 1 : 2));
         ++h->n_timed;
     }
     HeadArgs ha;
@@ -593,6 +652,7 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     if (loss->ssim_multiplier > 0.f) return fail(h, BF_EUNSUPPORTED, "ssim_multiplier > 0: SSIM term is outside the hot path");
     if (loss->mse_multiplier > 0.f) return fail(h, BF_EUNSUPPORTED, "mse_multiplier > 0: RMSE loss term is outside the hot path");
     if (d.head_activation != BF_ACT_LINEAR) return fail(h, BF_EUNSUPPORTED, "training is built for the linear denoiser head");
+    if (d.block_convs != 2) return fail(h, BF_EUNSUPPORTED, "training is built for block_kernels [3,3] (got %d convolutions)", d.block_convs);
     if (d.out_channels != d.in_channels) return fail(h, BF_EINVAL, "gt/prediction channel mismatch");
     const TrainLayout L = train_layout(h, B, H, W);
     if (!ws || (uintptr_t)ws % 16) return fail(h, BF_EWORKSPACE, "workspace must be a 16-byte aligned device buffer");

@@ -54,7 +54,7 @@ typedef struct bf_resnet_desc {
     int32_t filters;          /* `filters`; the MFMA path is built for 16                    */
     int32_t kernel_size;      /* base conv kernel_size: 1,3,5,7                              */
     int32_t no_layers;        /* number of residual blocks                                   */
-    int32_t block_convs;      /* len(block_kernels); 2                                       */
+    int32_t block_convs;      /* len(block_kernels); 2 (fused, trainable) | 1 | 3 (inference)  */
     int32_t block_kernel;     /* block_kernels[*]; 3                                         */
     int32_t activation;       /* bf_activation of the first block conv                       */
     int32_t base_activation;  /* bf_activation of base conv and last block conv (linear)     */

@@ -62,6 +62,24 @@ def test_hydra_f32_matches_oracle(no_layers, shape, fused, arith):
     _check_f32(m(x), O.hydra_forward(spec, params, state, x.astype(np.float64)))
 
 
+@pytest.mark.parametrize("nb", [1, 3])
+@pytest.mark.parametrize("no_layers,shape", [(1, (1, 16, 16)), (3, (2, 30, 45)), (4, (1, 64, 96))])
+def test_block_variants_match_oracle(nb, no_layers, shape):
+    """block_kernels of length 1 and 3 (backbone_resnet.py:111-113 allows 1..3; backbone_blocks.py:174-214:
+    first conv without BN, BN on the second and third, last activation = base_activation) -- inference only."""
+    cfg = O.canonical_config(no_layers=no_layers)
+    cfg["model"]["backbone"].update(block_kernels=[3] * nb, block_filters=[16] * nb)
+    spec = O.ResnetSpec.from_config(cfg["model"])
+    params, state = O.init_params(spec, seed=nb * 10 + no_layers, nontrivial_bn=True)
+    m = bf.model_builder(cfg["model"], device="cuda").hydra
+    assert [v.name for v in m.trainable_variables] == [t[0] for t in spec.tensors()]
+    m.set_weights(params, state)
+    _, noisy = O.synthetic_batch(shape[0], shape[1], shape[2], seed=nb + no_layers)
+    x = noisy.astype(np.float32)
+    _check_f32(m(x), O.hydra_forward(spec, params, state, x.astype(np.float64)))
+    _check_u8(bf.DenoiserModule(m)(noisy), O.denoiser_module_call(spec, params, state, noisy))
+
+
 @pytest.mark.parametrize("arith", [1, 0], ids=["f16x3", "f32"])
 @pytest.mark.parametrize("hw", [(32, 32), (64, 64), (128, 128), (256, 256), (17, 23), (1, 1), (5, 130)])
 def test_denoiser_module_u8_shapes_and_values(hw, arith):

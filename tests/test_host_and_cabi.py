@@ -57,6 +57,21 @@ def test_parameter_inventory_matches_oracle(n, count):
         assert v.name == name and v.shape == tuple(shape)
 
 
+@pytest.mark.parametrize("nb", [1, 3])
+def test_parameter_inventory_of_block_variants(nb):
+    """block_kernels of length 1 / 3: variable order conv0, (conv j, bn j gamma) for j >= 1; one BN state pair per j >= 1."""
+    cfg = O.canonical_config(no_layers=3)["model"]
+    cfg["backbone"].update(block_kernels=[3] * nb, block_filters=[16] * nb)
+    m = bf.model_builder(cfg, device="cpu", seed=0).hydra
+    spec = O.ResnetSpec.from_config(cfg)
+    assert m.n_params == spec.param_count() and m.n_state == spec.state_count() == 3 * (nb - 1) * 32
+    off = spec.offsets()
+    assert [v.name for v in m.trainable_variables] == [t[0] for t in spec.tensors()]
+    for v in m.trainable_variables:
+        assert (v.offset, v.shape) == (off[v.name][0], tuple(off[v.name][1])), v.name
+    assert [(v.name, v.shape) for v in m.non_trainable_variables] == [(n, tuple(s)) for n, s in spec.state_tensors()]
+
+
 def test_initial_values_follow_keras_defaults():
     m = bf.model_builder(O.canonical_config(no_layers=2)["model"], device="cpu", seed=3).hydra
     for v in m.trainable_variables:
