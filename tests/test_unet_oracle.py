@@ -1,0 +1,95 @@
+"""CPU checks of the unet_laplacian oracle (oracle/unet_oracle.py): each elementary op against an independent
+torch-CPU fp64 implementation, and structural properties of the whole graph."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import bfcnn_oracle as O
+from oracle import unet_oracle as U
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).permute(0, 3, 1, 2)
+
+
+def _n(t):
+    return t.permute(0, 2, 3, 1).numpy()
+
+
+def test_depthwise_matches_torch_grouped_conv():
+    rng = np.random.default_rng(0)
+    for k in (1, 3, 5):
+        x = rng.normal(size=(2, 9, 11, 8))
+        w = rng.normal(size=(k, k, 8, 1))
+        ref = F.conv2d(_t(x), torch.from_numpy(w).permute(2, 3, 0, 1).contiguous(), padding=k // 2, groups=8)
+        assert np.abs(U.depthwise_same(x, w) - _n(ref)).max() < 1e-12
+
+
+def test_layer_norm_matches_torch():
+    rng = np.random.default_rng(1)
+    x, g = rng.normal(size=(2, 5, 7, 32)) * 3 + 1, rng.uniform(0.5, 1.5, 32)
+    ref = F.layer_norm(torch.from_numpy(x), (32,), torch.from_numpy(g), None, eps=1e-3).numpy()
+    assert np.abs(U.layer_norm(x, g) - ref).max() < 1e-12
+
+
+@pytest.mark.parametrize("shape,out", [((1, 128, 128, 4), (16, 16)), ((2, 16, 16, 4), (128, 128)), ((1, 20, 36, 3), (16, 16)),
+                                       ((1, 16, 16, 3), (20, 36)), ((1, 5, 7, 2), (16, 16))])
+def test_resize_bilinear_matches_torch_half_pixel(shape, out):
+    x = np.random.default_rng(2).normal(size=shape)
+    ref = F.interpolate(_t(x), size=out, mode="bilinear", align_corners=False, antialias=False)
+    assert np.abs(U.resize_bilinear(x, *out) - _n(ref)).max() < 1e-12
+
+
+def test_resize_2x_equals_the_pyramid_upsample():
+    x = np.random.default_rng(3).normal(size=(1, 6, 9, 5))
+    assert np.abs(U.resize_bilinear(x, 12, 18) - O.upsample_bilinear_2x(x)).max() < 1e-12
+
+
+def test_attention_matches_torch_sdpa_without_scale():
+    rng = np.random.default_rng(4)
+    q, v, k = (rng.normal(size=(2, 256, 32)) for _ in range(3))
+    ref = F.scaled_dot_product_attention(torch.from_numpy(q), torch.from_numpy(k), torch.from_numpy(v), scale=1.0).numpy()
+    assert np.abs(U.dot_attention(q, v, k) - ref).max() < 1e-10
+
+
+def test_gaussian_kernel_and_avgpool_divisor():
+    g = U.gaussian_kernel_3()
+    assert abs(g.sum() - 1) < 1e-6 and g[1, 1] == g.max() and np.allclose(g, g.T)
+    x = np.ones((1, 4, 5, 2))
+    assert np.allclose(O.avg_pool_same(x, (3, 3), 1), 1.0)          # divisor = valid taps: constant stays constant
+
+
+def test_parameter_inventory_of_v5():
+    spec = U.UnetLaplacianSpec.from_config(U.canonical_config()["model"])
+    names = [n for n, _, _ in spec.tensors()]
+    assert len(names) == len(set(names))
+    # 3 levels x 3 encoder blocks (last level attention), 2 x 3 decoder blocks, 3 heads
+    assert sum(n.endswith("/dw/kernel") for n in names) == 12 and sum(n.endswith("/query/kernel") for n in names) == 3
+    assert spec.level_filters(0) == 32 and spec.level_filters(2) == 128
+    off = spec.offsets()
+    assert off["enc0_0/pw1/kernel"][1] == (1, 1, 32, 128) and off["enc2_0/out/kernel"][1] == (1, 1, 32, 128)
+    assert off["up0/kernel"][1] == (1, 1, 64, 32) and off["head2/conv0/kernel"][1] == (1, 1, 128, 32)
+
+
+def test_forward_shapes_scales_and_bias_free_midgrey():
+    spec = U.UnetLaplacianSpec.from_config(U.canonical_config()["model"])
+    p = U.init_params(spec, seed=3)
+    _, noisy = O.synthetic_batch(1, 64, 64, seed=5)
+    outs = U.hydra_forward(spec, p, noisy.astype(np.float64))
+    assert [o.shape for o in outs] == [(1, 64, 64, 3), (1, 32, 32, 3), (1, 16, 16, 3)]
+    assert all(np.isfinite(o).all() and o.min() >= 0 and o.max() <= 255 for o in outs)
+    # bias free + LN(center=False): a mid-grey image normalises to 0 and stays 0 -> 127.5 everywhere
+    mid = U.hydra_forward(spec, p, np.full((1, 64, 64, 3), 127.5))
+    assert all(np.allclose(o, 127.5) for o in mid)
+    u8 = U.denoiser_module_call(spec, p, noisy[:, :40, :50])
+    assert u8.shape == (1, 40, 50, 3) and u8.dtype == np.uint8
+
+
+def test_batch_independence():
+    spec = U.UnetLaplacianSpec.from_config(U.canonical_config(depth=2, width=1)["model"])
+    p = U.init_params(spec, seed=1)
+    _, noisy = O.synthetic_batch(3, 32, 32, seed=2)
+    full = U.hydra_forward(spec, p, noisy.astype(np.float64))[0]
+    one = U.hydra_forward(spec, p, noisy[1:2].astype(np.float64))[0]
+    assert np.abs(full[1:2] - one).max() < 1e-9

@@ -16,13 +16,23 @@ def split(x):
 def conv(x, w):   # x NHWC f32 tensor, w HWIO
     return torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), padding=w.shape[0] // 2).permute(0, 2, 3, 1)
 
+MODE = "f16x3"
+
 def conv3(xh, xl, w):
     m = float(w.abs().max())
     s = 2.0 ** np.floor(np.log2(32768.0 / m))          # power of two: max |w*s| in [16384, 32768)
     wh, wl = split(w * s)
+    if MODE == "f16x2w":                               # weights rounded to one f16, activations split
+        return (conv(xh, wh) + conv(xl, wh)) / s
+    if MODE == "f16x2a":                               # activations rounded to one f16, weights split
+        return (conv(xh, wh) + conv(xh, wl)) / s
+    if MODE == "f16x1":
+        return conv(xh, wh) / s
     return (conv(xh, wh) + conv(xl, wh) + conv(xh, wl)) / s
 
 def run(no_layers=18, size=128, mode="f16x3", seed=1234):
+    global MODE
+    MODE = mode
     cfg = O.canonical_config(no_layers=no_layers)
     spec = O.ResnetSpec.from_config(cfg["model"])
     params, state = O.init_params(spec, seed=42, nontrivial_bn=True)
@@ -40,7 +50,7 @@ def run(no_layers=18, size=128, mode="f16x3", seed=1234):
             t = torch.relu(conv(f, w1)); f = f + conv(t, w2) * a + sh
         else:
             fh, fl = split(f)
-            f22 = fh + fl                                  # what the split storage carries
+            f22 = fh if mode in ("f16x2a", "f16x1") else fh + fl   # what the activation storage carries
             t = torch.relu(conv3(fh, fl, w1))
             th, tl = split(t)
             f = f22 + conv3(th, tl, w2) * a + sh
@@ -52,5 +62,5 @@ def run(no_layers=18, size=128, mode="f16x3", seed=1234):
     print(f"{mode:6s} layers={no_layers} size={size}: MAE(normalised)={d.mean()/255:.3e} max={d.max()/255:.3e}  u8 diff: mean={u.mean():.2e} max={u.max():.0f}  max|act|={float(f.abs().max()):.2f}")
 
 if __name__ == "__main__":
-    for mode in ("f32", "f16x3"):
+    for mode in ("f32", "f16x3", "f16x2w", "f16x2a", "f16x1"):
         run(18, 128, mode)
