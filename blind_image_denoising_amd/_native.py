@@ -66,6 +66,17 @@ SIGNATURES = {
     "bf_upsample2x": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P]),
     "bf_strided_slice2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "bf_noise_augment": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, C.c_uint64, _P]),
+    "bf_op_pack_pointwise": (_I, [_P, _P, _I, _I, _P]),
+    "bf_op_pointwise": (_I, [_P, _P, _P, _P, _P, C.c_int64, _I, _I, _I, _F, _P]),
+    "bf_op_convnext_mlp": (_I, [_P, _P, _P, _P, _P, _P, C.c_int64, _I, _I, _F, _P]),
+    "bf_op_dwconv_ln": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _P]),
+    "bf_op_smooth_split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "bf_op_upsample_act_add": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "bf_op_resize_bilinear": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "bf_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "bf_op_first_conv": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _F, _P]),
+    "bf_op_head_out": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
+    "bf_op_channel_multiplier": (_I, [_P, _P, _I, _P]),
     "bf_set_option": (_I, [_P, C.c_char_p, _I]),
     "bf_get_timing": (_I, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "bf_debug_conv3x3": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -1,0 +1,747 @@
+// Operators of the `unet_laplacian` backbone (bfcnn/backbone_unet_laplacian.py, bfcnn/custom_layers.py ConvNextBlock /
+// ConvolutionalSelfAttention / ChannelLearnableMultiplier / GaussianFilter, bfcnn/upsampling.py, bfcnn/downsampling.py,
+// bfcnn/model.py denoiser heads) for gfx950.  fp32 NHWC, inference.
+//
+//   * the 1x1 convolutions (92 % of the FLOPs) run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32
+//     products, fp32 accumulate): M = 16 output channels, N = 16 pixels, K = 4 input channels per instruction.  A lane
+//     fetches 4 consecutive channels of its pixel with one 16-byte load; the K order inside a 16-channel chunk is
+//     permuted (k = 4q + j in step j) and the weights are pre-packed in the same order, so neither operand is shuffled.
+//   * the ConvNext MLP (1x1 C->4C, activation, 1x1 4C->C, channel multiplier, + skip) is ONE kernel: the accumulator
+//     layout of the first GEMM (lane (q, n), register r <-> channel 16t + 4q + r of pixel n) is a legal B operand of the
+//     second with the weights packed to match, so the 4C-wide intermediate never leaves the registers.
+//   * depthwise k x k + LayerNorm, LayerNorm + activation, the Laplacian split, resize and the heads are HBM-bound
+//     vector kernels: C/4 lanes per pixel, 16-byte accesses, channel reductions with DPP shuffles inside a wave.
+#include "bf_common.h"
+#include <math.h>
+
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define UO_RING 4     // weight tiles requested ahead of their use
+
+static int uo_grid(int64_t n, int per_block, int cap = 256 * 32)
+{
+    int64_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (int)(g > cap ? cap : g);
+}
+
+// activation codes of the C ABI (BF_ACT_*): 0 linear, 1 relu, 2 leaky relu (alpha), 3 gelu (erf form), 4 tanh
+template <int ACT>
+__device__ __forceinline__ float uo_act(float v, float alpha)
+{
+    if (ACT == 1) return fmaxf(v, 0.f);
+    if (ACT == 2) return v > 0.f ? v : alpha * v;
+    if (ACT == 3) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    if (ACT == 4) return tanhf(v);
+    return v;
+}
+__device__ __forceinline__ float uo_act_rt(float v, int act, float alpha)
+{
+    switch (act) {
+    case 1: return fmaxf(v, 0.f);
+    case 2: return v > 0.f ? v : alpha * v;
+    case 3: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    case 4: return tanhf(v);
+    default: return v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing for the MFMA GEMMs: w [cin][cout] (HWIO of a 1x1 kernel) -> [cin/16][cout/16][64 lanes][4]
+// element (c, t, lane = 16q + m, j) = w[16c + 4q + j][16t + m]
+// ------------------------------------------------------------------------------------------
+__global__ void uo_pack_pointwise_kernel(const float* __restrict__ w, float* __restrict__ wp, int cin, int cout)
+{
+    const int n = cin * cout;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int j = i & 3, lane = (i >> 2) & 63;
+        const int ct = i >> 8;
+        const int T = cout >> 4;
+        const int t = ct % T, c = ct / T;
+        const int q = lane >> 4, m = lane & 15;
+        wp[i] = w[(16 * c + 4 * q + j) * cout + 16 * t + m];
+    }
+}
+
+extern "C" int bf_op_pack_pointwise(const float* w, float* wp, int cin, int cout, void* stream)
+{
+    if (!w || !wp || cin <= 0 || cout <= 0 || cin % 16 || cout % 16) return BF_EINVAL;
+    hipLaunchKernelGGL(uo_pack_pointwise_kernel, dim3(uo_grid((int64_t)cin * cout, 256)), dim3(256), 0, (hipStream_t)stream, w, wp,
+                       cin, cout);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// ------------------------------------------------------------------------------------------
+// 1x1 convolution: out[p][co] = res[p][co] + mult[co] * act(sum_ci in[p][ci] w[ci][co])
+// one wave = NP groups of 16 pixels, all output channels; 4 waves per workgroup
+// ------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int NP, int ACT>
+__global__ __launch_bounds__(256, 2) void uo_pointwise_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           const float* __restrict__ wp, const float* __restrict__ mult,
+                                                           const float* __restrict__ res, int64_t npix, float alpha)
+{
+    constexpr int KC = CIN / 16, T = COUT / 16;
+    const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t ngroups = (npix + 16 * NP - 1) / (16 * NP);
+    for (int64_t g = wave; g < ngroups; g += nwaves) {
+        const int64_t p0 = g * 16 * NP;
+        // opaque per iteration: the weights do not depend on g, and hipcc would otherwise hoist ALL their loads out of
+        // this loop and hold every tile in registers (spills)
+        const float* wpo = wp;
+        asm volatile("" : "+s"(wpo));
+        const f32x4* wv = reinterpret_cast<const f32x4*>(wpo) + lane;
+        const float* src[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            int64_t p = p0 + 16 * i + n;
+            p = p < npix ? p : npix - 1;                          // tail: clamp the read, predicate the store
+            src[i] = in + p * CIN + 4 * q;
+        }
+        f32x4 acc[T][NP];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int i = 0; i < NP; ++i) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // weight tiles stream through a ring of D registers (requested D steps ahead), the pixel chunks through a
+        // double buffer; a scheduling barrier per step keeps hipcc from hoisting every load to the top (it spills)
+        constexpr int S = KC * T, D = UO_RING;
+        f32x4 ring[D], bcur[NP], bnext[NP];
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (d < S) ring[d] = wv[d * 64];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) bcur[i] = *reinterpret_cast<const f32x4*>(src[i]);
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            if (c + 1 < KC) {
+#pragma unroll
+                for (int i = 0; i < NP; ++i) bnext[i] = *reinterpret_cast<const f32x4*>(src[i] + 16 * (c + 1));
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int st = c * T + t;
+                const f32x4 a = ring[st % D];
+                if (st + D < S) ring[st % D] = wv[(st + D) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) acc[t][i] = MFMA4(a[j], bcur[i][j], acc[t][i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < NP; ++i) bcur[i] = bnext[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int64_t p = p0 + 16 * i + n;
+            if (p >= npix) continue;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                f32x4 v = bf_acc_ready(acc[t][i]);
+                const int co = 16 * t + 4 * q;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = uo_act<ACT>(v[r], alpha);
+                if (mult) v *= *reinterpret_cast<const f32x4*>(mult + co);
+                if (res) v += *reinterpret_cast<const f32x4*>(res + p * COUT + co);
+                *reinterpret_cast<f32x4*>(out + p * COUT + co) = v;
+            }
+        }
+    }
+}
+
+template <int CIN, int COUT, int NP>
+static hipError_t uo_launch_pointwise(const float* in, float* out, const float* wp, const float* mult, const float* res, int64_t npix,
+                                      int act, float alpha, hipStream_t s)
+{
+    const int grid = uo_grid(npix, 4 * 16 * NP, 256 * 8);
+#define UO_PW(A) hipLaunchKernelGGL((uo_pointwise_kernel<CIN, COUT, NP, A>), dim3(grid), dim3(256), 0, s, in, out, wp, mult, res, npix, alpha)
+    switch (act) {
+    case 0: UO_PW(0); break;
+    case 1: UO_PW(1); break;
+    case 2: UO_PW(2); break;
+    case 3: UO_PW(3); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef UO_PW
+    return hipGetLastError();
+}
+
+extern "C" int bf_op_pointwise(const float* in, float* out, const float* wp, const float* mult, const float* res, int64_t npix,
+                               int cin, int cout, int act, float alpha, void* stream)
+{
+    if (!in || !out || !wp || npix <= 0) return BF_EINVAL;
+    if (((uintptr_t)in | (uintptr_t)out | (uintptr_t)wp | (uintptr_t)mult | (uintptr_t)res) % 16) return BF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipErrorInvalidValue;
+#define UO_CASE(CI, CO, NP) if (cin == CI && cout == CO) e = uo_launch_pointwise<CI, CO, NP>(in, out, wp, mult, res, npix, act, alpha, s)
+    UO_CASE(32, 32, 4); UO_CASE(32, 64, 4); UO_CASE(32, 128, 4); UO_CASE(64, 32, 4); UO_CASE(64, 64, 4); UO_CASE(64, 128, 4);
+    UO_CASE(128, 32, 4); UO_CASE(128, 64, 4); UO_CASE(128, 128, 4);
+#undef UO_CASE
+    if (e == hipErrorInvalidValue) return BF_EUNSUPPORTED;
+    return e == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// ------------------------------------------------------------------------------------------
+// ConvNext MLP in one kernel: out = skip + mult * (act(in . w1) . w2)     in: [npix][C] (LayerNorm output), w1 [C][4C],
+// w2 [4C][C] (both packed by bf_op_pack_pointwise)
+// ------------------------------------------------------------------------------------------
+template <int C, int NP, int ACT>
+__global__ __launch_bounds__(256, 2) void uo_convnext_mlp_kernel(const float* __restrict__ in, const float* __restrict__ skip,
+                                                              float* __restrict__ out, const float* __restrict__ w1p,
+                                                              const float* __restrict__ w2p, const float* __restrict__ mult,
+                                                              int64_t npix, float alpha)
+{
+    constexpr int KC = C / 16, T1 = 4 * C / 16, T2 = C / 16;
+    const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t ngroups = (npix + 16 * NP - 1) / (16 * NP);
+    for (int64_t g = wave; g < ngroups; g += nwaves) {
+        const int64_t p0 = g * 16 * NP;
+        const float *w1o = w1p, *w2o = w2p;                       // opaque per iteration (see uo_pointwise_kernel)
+        asm volatile("" : "+s"(w1o), "+s"(w2o));
+        const f32x4* w1v = reinterpret_cast<const f32x4*>(w1o) + lane;
+        const f32x4* w2v = reinterpret_cast<const f32x4*>(w2o) + lane;
+        const float* src[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            int64_t p = p0 + 16 * i + n;
+            p = p < npix ? p : npix - 1;
+            src[i] = in + p * C + 4 * q;
+        }
+        f32x4 h[T1][NP];
+#pragma unroll
+        for (int t = 0; t < T1; ++t)
+#pragma unroll
+            for (int i = 0; i < NP; ++i) h[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        constexpr int D = UO_RING;
+        {
+            constexpr int S = KC * T1;
+            f32x4 ring[D], bcur[NP], bnext[NP];
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+                if (d < S) ring[d] = w1v[d * 64];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) bcur[i] = *reinterpret_cast<const f32x4*>(src[i]);
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                if (c + 1 < KC) {
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) bnext[i] = *reinterpret_cast<const f32x4*>(src[i] + 16 * (c + 1));
+                }
+#pragma unroll
+                for (int t = 0; t < T1; ++t) {
+                    const int st = c * T1 + t;
+                    const f32x4 a = ring[st % D];
+                    if (st + D < S) ring[st % D] = w1v[(st + D) * 64];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int i = 0; i < NP; ++i) h[t][i] = MFMA4(a[j], bcur[i][j], h[t][i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < NP; ++i) bcur[i] = bnext[i];
+            }
+        }
+        f32x4 acc[T2][NP];
+#pragma unroll
+        for (int t = 0; t < T2; ++t)
+#pragma unroll
+            for (int i = 0; i < NP; ++i) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // second GEMM: chunk c of K = hidden tile c; its register r of lane (q, n) is hidden channel 16c + 4q + r
+        {
+            constexpr int S = T1 * T2;
+            f32x4 ring[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+                if (d < S) ring[d] = w2v[d * 64];
+#pragma unroll
+            for (int c = 0; c < T1; ++c) {
+                f32x4 b[NP];
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    b[i] = bf_acc_ready(h[c][i]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) b[i][r] = uo_act<ACT>(b[i][r], alpha);
+                }
+#pragma unroll
+                for (int t = 0; t < T2; ++t) {
+                    const int st = c * T2 + t;
+                    const f32x4 a = ring[st % D];
+                    if (st + D < S) ring[st % D] = w2v[(st + D) * 64];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int i = 0; i < NP; ++i) acc[t][i] = MFMA4(a[j], b[i][j], acc[t][i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int64_t p = p0 + 16 * i + n;
+            if (p >= npix) continue;
+#pragma unroll
+            for (int t = 0; t < T2; ++t) {
+                f32x4 v = bf_acc_ready(acc[t][i]);
+                const int co = 16 * t + 4 * q;
+                if (mult) v *= *reinterpret_cast<const f32x4*>(mult + co);
+                if (skip) v += *reinterpret_cast<const f32x4*>(skip + p * C + co);
+                *reinterpret_cast<f32x4*>(out + p * C + co) = v;
+            }
+        }
+    }
+}
+
+template <int C, int NP>
+static hipError_t uo_launch_mlp(const float* in, const float* skip, float* out, const float* w1p, const float* w2p, const float* mult,
+                                int64_t npix, int act, float alpha, hipStream_t s)
+{
+    const int grid = uo_grid(npix, 4 * 16 * NP, 256 * 8);
+#define UO_MLP(A) hipLaunchKernelGGL((uo_convnext_mlp_kernel<C, NP, A>), dim3(grid), dim3(256), 0, s, in, skip, out, w1p, w2p, mult, npix, alpha)
+    switch (act) {
+    case 0: UO_MLP(0); break;
+    case 1: UO_MLP(1); break;
+    case 2: UO_MLP(2); break;
+    case 3: UO_MLP(3); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef UO_MLP
+    return hipGetLastError();
+}
+
+extern "C" int bf_op_convnext_mlp(const float* in, const float* skip, float* out, const float* w1p, const float* w2p,
+                                  const float* mult, int64_t npix, int C, int act, float alpha, void* stream)
+{
+    if (!in || !out || !w1p || !w2p || npix <= 0) return BF_EINVAL;
+    if (((uintptr_t)in | (uintptr_t)out | (uintptr_t)w1p | (uintptr_t)w2p | (uintptr_t)mult | (uintptr_t)skip) % 16) return BF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if (C == 32) e = uo_launch_mlp<32, 4>(in, skip, out, w1p, w2p, mult, npix, act, alpha, s);
+    else if (C == 64) e = uo_launch_mlp<64, 2>(in, skip, out, w1p, w2p, mult, npix, act, alpha, s);
+    else if (C == 128) e = uo_launch_mlp<128, 1>(in, skip, out, w1p, w2p, mult, npix, act, alpha, s);
+    else return BF_EUNSUPPORTED;
+    return e == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// ------------------------------------------------------------------------------------------
+// depthwise k x k (zero SAME padding) -> [LayerNorm(center=False) * gamma] -> [activation]
+// thread = 4 channels of one pixel, C/4 consecutive lanes = one pixel; w [k][k][C] or NULL (k = 0: no convolution)
+// ------------------------------------------------------------------------------------------
+template <int LPP>   // lanes per pixel = C / 4
+__device__ __forceinline__ float uo_pixel_sum(float v)
+{
+#pragma unroll
+    for (int m = 1; m < LPP; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+template <int C, int K>
+__global__ __launch_bounds__(256) void uo_dwconv_ln_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           const float* __restrict__ w, const float* __restrict__ gamma, int B, int H,
+                                                           int W, float eps, int act, float alpha)
+{
+    constexpr int LPP = C / 4, PPB = 256 / LPP;        // pixels per workgroup pass
+    const int cl = threadIdx.x % LPP, pl = threadIdx.x / LPP;
+    const int c0 = 4 * cl;
+    f32x4 wk[K * K > 0 ? K * K : 1];
+    if (K > 0) {
+#pragma unroll
+        for (int i = 0; i < K * K; ++i) wk[i] = *reinterpret_cast<const f32x4*>(w + i * C + c0);
+    }
+    f32x4 gm = {1.f, 1.f, 1.f, 1.f};
+    if (gamma) gm = *reinterpret_cast<const f32x4*>(gamma + c0);
+    const int64_t npix = (int64_t)B * H * W;
+    const int64_t nsteps = (npix + PPB - 1) / PPB;
+    for (int64_t st = blockIdx.x; st < nsteps; st += gridDim.x) {
+        const int64_t p = st * PPB + pl;
+        const bool live = p < npix;
+        const int64_t pc = live ? p : npix - 1;
+        const int x = (int)(pc % W);
+        const int y = (int)((pc / W) % H);
+        const float* img = in + (pc - (int64_t)y * W - x) * C + c0;      // image base + channel
+        f32x4 v;
+        if (K > 0) {
+            v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            constexpr int R = K / 2;
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                const int yy = y + ky - R;
+                if (yy < 0 || yy >= H) continue;
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const int xx = x + kx - R;
+                    if (xx < 0 || xx >= W) continue;
+                    v += wk[ky * K + kx] * *reinterpret_cast<const f32x4*>(img + ((int64_t)yy * W + xx) * C);
+                }
+            }
+        } else {
+            v = *reinterpret_cast<const f32x4*>(img + ((int64_t)y * W + x) * C);
+        }
+        if (gamma) {
+            const float mean = uo_pixel_sum<LPP>(v[0] + v[1] + v[2] + v[3]) * (1.f / C);
+            const f32x4 d = v - mean;
+            const float var = uo_pixel_sum<LPP>(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / C);
+            v = d * (gm * rsqrtf(var + eps));
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = uo_act_rt(v[r], act, alpha);
+        if (live) *reinterpret_cast<f32x4*>(out + p * C + c0) = v;
+    }
+}
+
+extern "C" int bf_op_dwconv_ln(const float* in, float* out, const float* w, const float* ln_gamma, int B, int H, int W, int C, int k,
+                               float eps, int act, float alpha, void* stream)
+{
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0 || (k > 0 && !w)) return BF_EINVAL;
+    if (((uintptr_t)in | (uintptr_t)out | (uintptr_t)w | (uintptr_t)ln_gamma) % 16) return BF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t npix = (int64_t)B * H * W;
+    bool ok = false;
+#define UO_DW(CC, KK)                                                                                                         \
+    if (C == CC && k == KK) {                                                                                                 \
+        hipLaunchKernelGGL((uo_dwconv_ln_kernel<CC, KK>), dim3(uo_grid(npix, 256 / (CC / 4))), dim3(256), 0, s, in, out, w,   \
+                           ln_gamma, B, H, W, eps, act, alpha);                                                               \
+        ok = true;                                                                                                            \
+    }
+    UO_DW(32, 0) UO_DW(32, 1) UO_DW(32, 3) UO_DW(32, 5) UO_DW(64, 0) UO_DW(64, 1) UO_DW(64, 3) UO_DW(64, 5)
+    UO_DW(128, 0) UO_DW(128, 1) UO_DW(128, 3) UO_DW(128, 5)
+#undef UO_DW
+    if (!ok) return BF_EUNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// ------------------------------------------------------------------------------------------
+// Laplacian split between the levels (backbone_unet_laplacian.py:366-386): smooth = AveragePooling2D(k, strides 1, same)
+// (divisor = in-bounds taps) or GaussianFilter (fixed kernel, zero padding); lap = x - smooth at full resolution;
+// down = smooth[:, ::2, ::2, :] (the "strides" downsample reads nothing else).  gauss: [k][k] or NULL (= average)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void uo_smooth_split_kernel(const float* __restrict__ in, float* __restrict__ lap,
+                                                              float* __restrict__ down, const float* __restrict__ gauss, int B, int H,
+                                                              int W, int C, int k)
+{
+    const int Cv = C / 4, OH = (H + 1) / 2, OW = (W + 1) / 2, R = k / 2;
+    const int64_t n = (int64_t)B * H * W * Cv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % Cv);
+        int64_t t = i / Cv;
+        const int x = (int)(t % W); t /= W;
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        const f32x4* img = reinterpret_cast<const f32x4*>(in) + (int64_t)b * H * W * Cv + c;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        int cnt = 0;
+        for (int ky = 0; ky < k; ++ky) {
+            const int yy = y + ky - R;
+            if (yy < 0 || yy >= H) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int xx = x + kx - R;
+                if (xx < 0 || xx >= W) continue;
+                const f32x4 v = img[((int64_t)yy * W + xx) * Cv];
+                if (gauss) acc += gauss[ky * k + kx] * v;
+                else acc += v;
+                ++cnt;
+            }
+        }
+        if (!gauss) acc = acc / (float)cnt;
+        const f32x4 ctr = img[((int64_t)y * W + x) * Cv];
+        reinterpret_cast<f32x4*>(lap)[i] = ctr - acc;
+        if (!((x | y) & 1)) reinterpret_cast<f32x4*>(down)[(((int64_t)b * OH + (y >> 1)) * OW + (x >> 1)) * Cv + c] = acc;
+    }
+}
+
+extern "C" int bf_op_smooth_split(const float* in, float* lap, float* down, const float* gauss, int B, int H, int W, int C, int k,
+                                  void* stream)
+{
+    if (!in || !lap || !down || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || k <= 0 || !(k & 1)) return BF_EINVAL;
+    if (((uintptr_t)in | (uintptr_t)lap | (uintptr_t)down) % 16) return BF_EINVAL;
+    const int64_t n = (int64_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(uo_smooth_split_kernel, dim3(uo_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, in, lap, down, gauss, B, H, W,
+                       C, k);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// ------------------------------------------------------------------------------------------
+// out = other + act(UpSampling2D(2, bilinear)(in))   (decoder: Add(skip, activation(1x1(upsample(x)))) with the linear 1x1
+// commuted in front of the linear resize, as upsampling.py:80-90 does itself for a linear activation)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void uo_upsample_act_add_kernel(const float* __restrict__ in, const float* __restrict__ other,
+                                                                  float* __restrict__ out, int B, int H, int W, int C, int act,
+                                                                  float alpha)
+{
+    const int Cv = C / 4, OH = 2 * H, OW = 2 * W;
+    const int64_t n = (int64_t)B * OH * OW * Cv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % Cv);
+        int64_t t = i / Cv;
+        const int ox = (int)(t % OW); t /= OW;
+        const int oy = (int)(t % OH);
+        const int b = (int)(t / OH);
+        const int iy = oy >> 1, ix = ox >> 1;
+        const int y1 = (oy & 1) ? min(iy + 1, H - 1) : max(iy - 1, 0);
+        const int x1 = (ox & 1) ? min(ix + 1, W - 1) : max(ix - 1, 0);
+        const f32x4* base = reinterpret_cast<const f32x4*>(in) + (int64_t)b * H * W * Cv + c;
+        const f32x4 v00 = base[((int64_t)iy * W + ix) * Cv], v01 = base[((int64_t)iy * W + x1) * Cv];
+        const f32x4 v10 = base[((int64_t)y1 * W + ix) * Cv], v11 = base[((int64_t)y1 * W + x1) * Cv];
+        f32x4 r = 0.75f * (0.75f * v00 + 0.25f * v10) + 0.25f * (0.75f * v01 + 0.25f * v11);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = uo_act_rt(r[j], act, alpha);
+        if (other) r += reinterpret_cast<const f32x4*>(other)[i];
+        reinterpret_cast<f32x4*>(out)[i] = r;
+    }
+}
+
+extern "C" int bf_op_upsample_act_add(const float* in, const float* other, float* out, int B, int H, int W, int C, int act,
+                                      float alpha, void* stream)
+{
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4) return BF_EINVAL;
+    if (((uintptr_t)in | (uintptr_t)other | (uintptr_t)out) % 16) return BF_EINVAL;
+    const int64_t n = (int64_t)B * 4 * H * W * (C / 4);
+    hipLaunchKernelGGL(uo_upsample_act_add_kernel, dim3(uo_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, in, other, out, B, H, W, C,
+                       act, alpha);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// ------------------------------------------------------------------------------------------
+// tf.image.resize(BILINEAR, antialias=False): half-pixel centres (custom_layers.py:1328-1334, 1351-1357)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void uo_resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H,
+                                                                 int W, int C, int OH, int OW, float sy, float sx)
+{
+    const int Cv = C / 4;
+    const int64_t n = (int64_t)B * OH * OW * Cv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % Cv);
+        int64_t t = i / Cv;
+        const int ox = (int)(t % OW); t /= OW;
+        const int oy = (int)(t % OH);
+        const int b = (int)(t / OH);
+        const float fy = ((float)oy + 0.5f) * sy - 0.5f, fx = ((float)ox + 0.5f) * sx - 0.5f;
+        const float fly = floorf(fy), flx = floorf(fx);
+        const int y0 = max((int)fly, 0), y1 = min((int)ceilf(fy), H - 1);
+        const int x0 = max((int)flx, 0), x1 = min((int)ceilf(fx), W - 1);
+        const float ty = fy - fly, tx = fx - flx;
+        const f32x4* base = reinterpret_cast<const f32x4*>(in) + (int64_t)b * H * W * Cv + c;
+        const f32x4 v00 = base[((int64_t)y0 * W + x0) * Cv], v01 = base[((int64_t)y0 * W + x1) * Cv];
+        const f32x4 v10 = base[((int64_t)y1 * W + x0) * Cv], v11 = base[((int64_t)y1 * W + x1) * Cv];
+        const f32x4 top = v00 + (v01 - v00) * tx, bot = v10 + (v11 - v10) * tx;
+        reinterpret_cast<f32x4*>(out)[i] = top + (bot - top) * ty;
+    }
+}
+
+extern "C" int bf_op_resize_bilinear(const float* in, float* out, int B, int H, int W, int C, int OH, int OW, void* stream)
+{
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || C <= 0 || C % 4) return BF_EINVAL;
+    if (((uintptr_t)in | (uintptr_t)out) % 16) return BF_EINVAL;
+    const int64_t n = (int64_t)B * OH * OW * (C / 4);
+    hipLaunchKernelGGL(uo_resize_bilinear_kernel, dim3(uo_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, C, OH, OW,
+                       (float)H / (float)OH, (float)W / (float)OW);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// ------------------------------------------------------------------------------------------
+// keras.layers.Attention(use_scale=False, score_mode="dot"): out = softmax(q k^T) v per image; q, k, v [B][T][A],
+// A = 32.  One workgroup = up to 256 queries of one image (one per thread, online softmax); K and V of the image sit in LDS
+// and every key / value row is an LDS broadcast.  (256 tokens x 32 channels per image: 8 MFLOP, negligible.)
+// ------------------------------------------------------------------------------------------
+constexpr int UO_ATT_A = 32;
+__global__ __launch_bounds__(256) void uo_attention_kernel(const float* __restrict__ q, const float* __restrict__ v,
+                                                           const float* __restrict__ k, float* __restrict__ out, int T)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* ks = lds;                       // [T][A]
+    float* vs = lds + (size_t)T * UO_ATT_A;
+    const int b = blockIdx.y;
+    const float* kb = k + (int64_t)b * T * UO_ATT_A;
+    const float* vb = v + (int64_t)b * T * UO_ATT_A;
+    for (int i = threadIdx.x; i < T * UO_ATT_A / 4; i += 256) {
+        reinterpret_cast<f32x4*>(ks)[i] = reinterpret_cast<const f32x4*>(kb)[i];
+        reinterpret_cast<f32x4*>(vs)[i] = reinterpret_cast<const f32x4*>(vb)[i];
+    }
+    __syncthreads();
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= T) return;
+    float qr[UO_ATT_A], acc[UO_ATT_A];
+    const float* qp = q + ((int64_t)b * T + row) * UO_ATT_A;
+#pragma unroll
+    for (int i = 0; i < UO_ATT_A; i += 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(qp + i);
+        qr[i] = t[0]; qr[i + 1] = t[1]; qr[i + 2] = t[2]; qr[i + 3] = t[3];
+        acc[i] = acc[i + 1] = acc[i + 2] = acc[i + 3] = 0.f;
+    }
+    float m = -INFINITY, l = 0.f;
+    for (int j = 0; j < T; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < UO_ATT_A; ++i) s += qr[i] * ks[j * UO_ATT_A + i];
+        const float mn = fmaxf(m, s);
+        const float corr = __expf(m - mn), pj = __expf(s - mn);
+        l = l * corr + pj;
+#pragma unroll
+        for (int i = 0; i < UO_ATT_A; ++i) acc[i] = acc[i] * corr + pj * vs[j * UO_ATT_A + i];
+        m = mn;
+    }
+    const float inv = 1.f / l;
+    float* op = out + ((int64_t)b * T + row) * UO_ATT_A;
+#pragma unroll
+    for (int i = 0; i < UO_ATT_A; i += 4)
+        *reinterpret_cast<f32x4*>(op + i) = (f32x4){acc[i] * inv, acc[i + 1] * inv, acc[i + 2] * inv, acc[i + 3] * inv};
+}
+
+extern "C" int bf_op_attention(const float* q, const float* v, const float* k, float* out, int B, int T, int A, void* stream)
+{
+    if (!q || !v || !k || !out || B <= 0 || T <= 0) return BF_EINVAL;
+    if (A != UO_ATT_A) return BF_EUNSUPPORTED;
+    if (((uintptr_t)q | (uintptr_t)v | (uintptr_t)k | (uintptr_t)out) % 16) return BF_EINVAL;
+    const size_t lds = (size_t)2 * T * UO_ATT_A * sizeof(float);
+    if (lds > 160 * 1024) return BF_EUNSUPPORTED;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(uo_attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return BF_EHIP;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(uo_attention_kernel, dim3((T + 255) / 256, B), dim3(256), lds, (hipStream_t)stream, q, v, k, out, T);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// ------------------------------------------------------------------------------------------
+// first convolution: k x k, Cin (<= 4) -> COUT on the normalised image, SAME zero padding, activation.
+// The source image [B,Hs,Ws,cin] (u8 or f32, 0..255) is virtually zero-padded to [H,W] BEFORE normalisation
+// (pad_to_power_of_2, utilities.py:736-751: padded pixels normalise to -0.5); outside [H,W] the convolution pads with 0.
+// thread = one pixel, all output channels; weights broadcast from LDS.
+// ------------------------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256) void uo_first_conv_kernel(const void* __restrict__ in, int in_is_u8, float* __restrict__ out,
+                                                            const float* __restrict__ w, int B, int Hs, int Ws, int H, int W, int cin,
+                                                            int k, int normalize, float v_min, float v_max, int act, float alpha)
+{
+    extern __shared__ __attribute__((aligned(16))) float wl[];     // [k][k][cin][COUT]
+    const int nw = k * k * cin * COUT;
+    for (int i = threadIdx.x; i < nw; i += 256) wl[i] = w[i];
+    __syncthreads();
+    const int64_t npix = (int64_t)B * H * W;
+    const int R = k / 2;
+    const float range = v_max - v_min;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+        const int x = (int)(p % W);
+        const int y = (int)((p / W) % H);
+        const int b = (int)(p / ((int64_t)W * H));
+        float acc[COUT];
+#pragma unroll
+        for (int i = 0; i < COUT; ++i) acc[i] = 0.f;
+        for (int ky = 0; ky < k; ++ky) {
+            const int yy = y + ky - R;
+            if (yy < 0 || yy >= H) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int xx = x + kx - R;
+                if (xx < 0 || xx >= W) continue;
+                const bool inside = yy < Hs && xx < Ws;
+                const int64_t o = (((int64_t)b * Hs + yy) * Ws + xx) * cin;
+                for (int ci = 0; ci < cin; ++ci) {
+                    float v = 0.f;
+                    if (inside) v = in_is_u8 ? (float)reinterpret_cast<const unsigned char*>(in)[o + ci]
+                                             : reinterpret_cast<const float*>(in)[o + ci];
+                    if (normalize) v = (fminf(fmaxf(v, v_min), v_max) - v_min) / range - 0.5f;
+                    const f32x4* wr = reinterpret_cast<const f32x4*>(wl + ((ky * k + kx) * cin + ci) * COUT);
+#pragma unroll
+                    for (int i = 0; i < COUT / 4; ++i) {
+                        const f32x4 ww = wr[i];
+                        acc[4 * i] += v * ww[0]; acc[4 * i + 1] += v * ww[1]; acc[4 * i + 2] += v * ww[2]; acc[4 * i + 3] += v * ww[3];
+                    }
+                }
+            }
+        }
+        f32x4* op = reinterpret_cast<f32x4*>(out + p * COUT);
+#pragma unroll
+        for (int i = 0; i < COUT / 4; ++i)
+            op[i] = (f32x4){uo_act_rt(acc[4 * i], act, alpha), uo_act_rt(acc[4 * i + 1], act, alpha),
+                            uo_act_rt(acc[4 * i + 2], act, alpha), uo_act_rt(acc[4 * i + 3], act, alpha)};
+    }
+}
+
+extern "C" int bf_op_first_conv(const void* in, int in_is_u8, float* out, const float* w, int B, int Hs, int Ws, int H, int W, int cin,
+                                int cout, int k, int normalize, float v_min, float v_max, int act, float alpha, void* stream)
+{
+    if (!in || !out || !w || B <= 0 || Hs <= 0 || Ws <= 0 || H < Hs || W < Ws || cin <= 0 || k <= 0 || !(k & 1)) return BF_EINVAL;
+    if (normalize && !(v_max > v_min)) return BF_EINVAL;
+    if ((uintptr_t)out % 16) return BF_EINVAL;
+    const size_t lds = (size_t)k * k * cin * cout * sizeof(float);
+    if (lds > 64 * 1024) return BF_EUNSUPPORTED;
+    const int64_t npix = (int64_t)B * H * W;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = uo_grid(npix, 256);
+    if (cout == 32)
+        hipLaunchKernelGGL((uo_first_conv_kernel<32>), dim3(grid), dim3(256), lds, s, in, in_is_u8, out, w, B, Hs, Ws, H, W, cin, k,
+                           normalize, v_min, v_max, act, alpha);
+    else if (cout == 64)
+        hipLaunchKernelGGL((uo_first_conv_kernel<64>), dim3(grid), dim3(256), lds, s, in, in_is_u8, out, w, B, Hs, Ws, H, W, cin, k,
+                           normalize, v_min, v_max, act, alpha);
+    else if (cout == 16)
+        hipLaunchKernelGGL((uo_first_conv_kernel<16>), dim3(grid), dim3(256), lds, s, in, in_is_u8, out, w, B, Hs, Ws, H, W, cin, k,
+                           normalize, v_min, v_max, act, alpha);
+    else return BF_EUNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// ------------------------------------------------------------------------------------------
+// last convolution of a denoiser head (model.py:321-342): 1x1 hf -> cout (<= 4), tanh(2x) * 0.51, [denormalise:
+// (clip(y, -.5, .5) + .5) * (v_max - v_min) + v_min], [round half to even, clip, uint8], crop to [Ho,Wo]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void uo_head_out_kernel(const float* __restrict__ in, const float* __restrict__ w, void* __restrict__ out,
+                                                          int out_is_u8, int B, int H, int W, int Ho, int Wo, int hf, int cout,
+                                                          int denormalize, float v_min, float v_max)
+{
+    __shared__ float wl[4 * 256];
+    for (int i = threadIdx.x; i < hf * cout; i += 256) wl[i] = w[i];
+    __syncthreads();
+    const int64_t n = (int64_t)B * Ho * Wo;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % Wo);
+        const int y = (int)((i / Wo) % Ho);
+        const int b = (int)(i / ((int64_t)Wo * Ho));
+        const float* src = in + (((int64_t)b * H + y) * W + x) * hf;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < hf; c += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                for (int o = 0; o < cout; ++o) acc[o] += v[j] * wl[(c + j) * cout + o];
+        }
+        for (int o = 0; o < cout; ++o) {
+            float r = tanhf(2.f * acc[o]) * 0.51f;
+            if (denormalize) r = (fminf(fmaxf(r, -0.5f), 0.5f) + 0.5f) * (v_max - v_min) + v_min;
+            if (out_is_u8) reinterpret_cast<unsigned char*>(out)[i * cout + o] = (unsigned char)fminf(fmaxf(rintf(r), 0.f), 255.f);
+            else reinterpret_cast<float*>(out)[i * cout + o] = r;
+        }
+    }
+}
+
+extern "C" int bf_op_head_out(const float* in, const float* w, void* out, int out_is_u8, int B, int H, int W, int Ho, int Wo, int hf,
+                              int cout, int denormalize, float v_min, float v_max, void* stream)
+{
+    if (!in || !w || !out || B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Ho > H || Wo > W) return BF_EINVAL;
+    if (hf <= 0 || hf % 4 || hf > 256 || cout <= 0 || cout > 4) return BF_EUNSUPPORTED;
+    if ((uintptr_t)in % 16) return BF_EINVAL;
+    const int64_t n = (int64_t)B * Ho * Wo;
+    hipLaunchKernelGGL(uo_head_out_kernel, dim3(uo_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, in, w, out, out_is_u8, B, H, W, Ho,
+                       Wo, hf, cout, denormalize, v_min, v_max);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// mult[c] = tanh(relu(1 + w[c]))   (ChannelLearnableMultiplier, custom_layers.py:304-306)
+__global__ void uo_channel_multiplier_kernel(const float* __restrict__ w, float* __restrict__ m, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) m[i] = tanhf(fmaxf(1.f + w[i], 0.f));
+}
+
+extern "C" int bf_op_channel_multiplier(const float* w, float* mult, int n, void* stream)
+{
+    if (!w || !mult || n <= 0) return BF_EINVAL;
+    hipLaunchKernelGGL(uo_channel_multiplier_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, mult, n);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}

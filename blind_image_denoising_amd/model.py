@@ -59,9 +59,11 @@ def describe_resnet(config: Dict, strict_snapshot: bool = False) -> N.ResnetDesc
     config_backbone = copy.deepcopy(config[BACKBONE_STR])
     config_denoiser = copy.deepcopy(config[DENOISER_STR])
     model_type = config_backbone[TYPE_STR].strip().lower()
-    if model_type in ("unet", "unet_laplacian", "convnext"):
+    if model_type in ("unet", "convnext"):
         raise NotImplementedError(
-            f"backbone [{model_type}] is outside the MI355X hot path (resnet only)")
+            f"backbone [{model_type}] is outside the MI355X hot path (resnet and unet_laplacian only)")
+    if model_type == "unet_laplacian":
+        raise ValueError("unet_laplacian models are described by blind_image_denoising_amd.unet_laplacian")
     if model_type == "efficientnet":
         raise NotImplementedError("efficientnet not implemented yet")          # model.py:213
     if model_type != "resnet":
@@ -443,6 +445,14 @@ class _SubModelView:
 
 def model_builder(config: Dict, device=None, strict_snapshot: bool = False, seed: Optional[int] = None) -> BuilderResults:
     """bfcnn/model.py:58-162.  `config` is the `model` section ({"backbone":…, "denoiser":…})."""
+    if str(config[BACKBONE_STR].get(TYPE_STR, "")).strip().lower() == "unet_laplacian":
+        from .unet_laplacian import UnetLaplacianHydra
+        hydra = UnetLaplacianHydra(config, device=device, seed=seed)
+        logger.warning(f"Backbone model has [{hydra.depth}] outputs, probably of different scale or depth")
+        return BuilderResults(
+            backbone=None, denoiser=None, hydra=hydra, options={},
+            normalizer=build_normalize_model(min_value=hydra.v_min, max_value=hydra.v_max),
+            denormalizer=build_denormalize_model(min_value=hydra.v_min, max_value=hydra.v_max))
     hydra = HydraModel(config, device=device, strict_snapshot=strict_snapshot, seed=seed)
     vr = config[BACKBONE_STR].get("value_range", (0, 255))
     logger.warning(f"Backbone model has [1] outputs, probably of different scale or depth")
@@ -464,6 +474,13 @@ def save_model(hydra: HydraModel, directory: str, pipeline_config: Optional[Dict
     os.makedirs(directory, exist_ok=True)
     cfg = copy.deepcopy(pipeline_config) if pipeline_config else {MODEL_STR: hydra.config}
     cfg.setdefault(MODEL_STR, hydra.config)
+    if getattr(hydra, "multi_output", False):                   # unet_laplacian: flat parameter vector, no state
+        with open(os.path.join(directory, PIPELINE_FILE_STR), "w") as f:
+            json.dump(cfg, f, indent=4)
+        tv = hydra.trainable_variables
+        np.savez(os.path.join(directory, WEIGHTS_FILE_STR), params=hydra.get_weights(), state=np.zeros(0, np.float32),
+                 names=np.array([v[0] for v in tv]), offsets=np.array([v[3] for v in tv]))
+        return
     cfg["strict_snapshot"] = not bool(hydra.desc.denormalize)
     with open(os.path.join(directory, PIPELINE_FILE_STR), "w") as f:
         json.dump(cfg, f, indent=4)
@@ -478,6 +495,12 @@ def load_hydra(directory: str, device=None) -> HydraModel:
     if not os.path.isfile(cfg_path) or not os.path.isfile(w_path):
         raise ValueError(f"model_path [{directory}] does not hold {PIPELINE_FILE_STR} + {WEIGHTS_FILE_STR}")
     cfg = load_config(cfg_path)
+    if str(cfg[MODEL_STR][BACKBONE_STR].get(TYPE_STR, "")).strip().lower() == "unet_laplacian":
+        from .unet_laplacian import UnetLaplacianHydra
+        hydra = UnetLaplacianHydra(cfg[MODEL_STR], device=device)
+        with np.load(w_path) as z:
+            hydra.set_weights(z["params"])
+        return hydra
     hydra = HydraModel(cfg[MODEL_STR], device=device, strict_snapshot=bool(cfg.get("strict_snapshot", False)))
     with np.load(w_path) as z:
         hydra.set_weights(z["params"], z["state"])

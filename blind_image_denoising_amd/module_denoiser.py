@@ -44,7 +44,10 @@ class DenoiserModule:
             return out.numpy() if was_numpy else out
         hydra._require_gpu()
         image = image.to(hydra.device).contiguous()
-        if self._cast_to_uint8:
+        if getattr(hydra, "multi_output", False):
+            # several outputs (one per scale): the module keeps the first, full-resolution one (module_denoiser.py:62-65)
+            out = hydra.infer_u8(image, self._cast_to_uint8)
+        elif self._cast_to_uint8:
             out = hydra.infer_u8(image)
         else:
             # float output: explicit pad -> hydra -> crop (no rounding)

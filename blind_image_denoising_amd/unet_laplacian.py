@@ -1,0 +1,458 @@
+"""`unet_laplacian` backbone + one denoiser head per scale (bfcnn/backbone_unet_laplacian.py:35-615,
+bfcnn/model.py:58-162, 251-359) on the operators of csrc/unet_ops.hip.  Inference only.
+
+The builder walks the same graph the reference builder assembles from keras layers and issues one C-ABI operator
+per fused group (torch tensors are the containers of the intermediate activations, nothing is computed by torch):
+
+    first conv 5x5 (+normalise, +activation)
+    per level d:   width x [dw kxk + LayerNorm] -> [1x1 C->4C, act, 1x1 4C->C, multiplier, +skip]   (ConvNextBlock)
+                   or, on the deepest level with use_self_attention, ConvolutionalSelfAttention
+                   LayerNorm + activation;  Laplacian split (smooth, x - smooth, ::2 slice);  1x1 + activation
+    decoder d:     skip + act(bilinear x2 (1x1 (lower)))  ->  width x ConvNextBlock(dw 1x1)  ->  LayerNorm
+    head i:        1x1 C_i -> 32 + activation,  1x1 32 -> 3, tanh(2x)*0.51, denormalise
+"""
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .custom_logger import logger
+
+LN_EPSILON = 1e-3          # DEFAULT_LN_EPSILON (bfcnn/constants.py:10); keras LayerNormalization default as well
+ACT_CODES = {"linear": (0, 0.0), "relu": (1, 0.0), "leaky_relu": (2, 0.3), "leakyrelu": (2, 0.3),
+             "leaky_relu_01": (2, 0.1), "leakyrelu_01": (2, 0.1), "leaky_relu_001": (2, 0.01), "leakyrelu_001": (2, 0.01),
+             "gelu": (3, 0.0)}      # bfcnn/utilities.py:229-267
+
+
+def _act(name: Optional[str]) -> Tuple[int, float]:
+    name = (name or "linear").strip().lower()
+    if name not in ACT_CODES:
+        raise NotImplementedError(f"activation [{name}] is outside the hot path")
+    return ACT_CODES[name]
+
+
+def _call(fn_name: str, *args):
+    N.check(getattr(N.lib(), fn_name)(*args), None, fn_name)
+
+
+# ---------------------------------------------------------------------------------------------
+# operator wrappers (float32 NHWC cuda tensors in, new tensor out)
+# ---------------------------------------------------------------------------------------------
+
+def pack_pointwise(w: torch.Tensor) -> torch.Tensor:
+    """[1,1,cin,cout] / [cin,cout] kernel -> matrix-core operand order."""
+    cin, cout = w.shape[-2], w.shape[-1]
+    out = torch.empty(cin * cout, dtype=torch.float32, device=w.device)
+    _call("bf_op_pack_pointwise", N.ptr(w.contiguous()), N.ptr(out), cin, cout, N.stream_ptr(w))
+    return out
+
+
+def pointwise(x: torch.Tensor, wp: torch.Tensor, cout: int, act: str = "linear", mult: torch.Tensor = None,
+              res: torch.Tensor = None, alpha: Optional[float] = None) -> torch.Tensor:
+    cin = x.shape[-1]
+    npix = x.numel() // cin
+    out = torch.empty(x.shape[:-1] + (cout,), dtype=torch.float32, device=x.device)
+    code, a = _act(act)
+    _call("bf_op_pointwise", N.ptr(x), N.ptr(out), N.ptr(wp), N.ptr(mult), N.ptr(res), npix, cin, cout, code,
+          a if alpha is None else alpha, N.stream_ptr(x))
+    return out
+
+
+def convnext_mlp(x: torch.Tensor, skip: Optional[torch.Tensor], w1p: torch.Tensor, w2p: torch.Tensor,
+                 mult: Optional[torch.Tensor], act: str) -> torch.Tensor:
+    C = x.shape[-1]
+    out = torch.empty_like(x)
+    code, a = _act(act)
+    _call("bf_op_convnext_mlp", N.ptr(x), N.ptr(skip), N.ptr(out), N.ptr(w1p), N.ptr(w2p), N.ptr(mult), x.numel() // C, C,
+          code, a, N.stream_ptr(x))
+    return out
+
+
+def dwconv_ln(x: torch.Tensor, w: Optional[torch.Tensor], gamma: Optional[torch.Tensor], act: str = "linear",
+              eps: float = LN_EPSILON) -> torch.Tensor:
+    """depthwise k x k (w [k,k,C,1] or None) -> LayerNorm(center=False) * gamma (or None) -> activation."""
+    B, H, W, C = x.shape
+    k = 0 if w is None else int(w.shape[0])
+    out = torch.empty_like(x)
+    code, a = _act(act)
+    _call("bf_op_dwconv_ln", N.ptr(x), N.ptr(out), N.ptr(w), N.ptr(gamma), B, H, W, C, k, eps, code, a, N.stream_ptr(x))
+    return out
+
+
+def smooth_split(x: torch.Tensor, k: int, gauss: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(x - smooth(x), smooth(x)[:, ::2, ::2, :])."""
+    B, H, W, C = x.shape
+    lap = torch.empty_like(x)
+    down = torch.empty((B, (H + 1) // 2, (W + 1) // 2, C), dtype=torch.float32, device=x.device)
+    _call("bf_op_smooth_split", N.ptr(x), N.ptr(lap), N.ptr(down), N.ptr(gauss), B, H, W, C, k, N.stream_ptr(x))
+    return lap, down
+
+
+def upsample_act_add(x: torch.Tensor, other: Optional[torch.Tensor], act: str = "linear") -> torch.Tensor:
+    B, H, W, C = x.shape
+    out = torch.empty((B, 2 * H, 2 * W, C), dtype=torch.float32, device=x.device)
+    code, a = _act(act)
+    _call("bf_op_upsample_act_add", N.ptr(x), N.ptr(other), N.ptr(out), B, H, W, C, code, a, N.stream_ptr(x))
+    return out
+
+
+def resize_bilinear(x: torch.Tensor, oh: int, ow: int) -> torch.Tensor:
+    B, H, W, C = x.shape
+    out = torch.empty((B, oh, ow, C), dtype=torch.float32, device=x.device)
+    _call("bf_op_resize_bilinear", N.ptr(x), N.ptr(out), B, H, W, C, oh, ow, N.stream_ptr(x))
+    return out
+
+
+def attention(q: torch.Tensor, v: torch.Tensor, k: torch.Tensor) -> torch.Tensor:
+    B, T, A = q.shape
+    out = torch.empty_like(q)
+    _call("bf_op_attention", N.ptr(q), N.ptr(v), N.ptr(k), N.ptr(out), B, T, A, N.stream_ptr(q))
+    return out
+
+
+def first_conv(x: torch.Tensor, w: torch.Tensor, H: int, W: int, act: str, normalize: bool, v_min: float, v_max: float
+               ) -> torch.Tensor:
+    """x [B,Hs,Ws,cin] uint8 / float32 (0..255 scale), zero-padded to [H,W] before normalisation."""
+    B, Hs, Ws, cin = x.shape
+    k, cout = int(w.shape[0]), int(w.shape[-1])
+    out = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device)
+    code, a = _act(act)
+    _call("bf_op_first_conv", N.ptr(x), int(x.dtype == torch.uint8), N.ptr(out), N.ptr(w), B, Hs, Ws, H, W, cin, cout, k,
+          int(normalize), v_min, v_max, code, a, N.stream_ptr(x))
+    return out
+
+
+def head_out(x: torch.Tensor, w: torch.Tensor, Ho: int, Wo: int, as_uint8: bool, denormalize: bool, v_min: float,
+             v_max: float) -> torch.Tensor:
+    B, H, W, hf = x.shape
+    cout = int(w.shape[-1])
+    out = torch.empty((B, Ho, Wo, cout), dtype=torch.uint8 if as_uint8 else torch.float32, device=x.device)
+    _call("bf_op_head_out", N.ptr(x), N.ptr(w), N.ptr(out), int(as_uint8), B, H, W, Ho, Wo, hf, cout, int(denormalize),
+          v_min, v_max, N.stream_ptr(x))
+    return out
+
+
+def channel_multiplier(w: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(w)
+    _call("bf_op_channel_multiplier", N.ptr(w), N.ptr(out), w.numel(), N.stream_ptr(w))
+    return out
+
+
+def gaussian_kernel(kernel_size: Tuple[int, int]) -> np.ndarray:
+    """GaussianFilter's fixed kernel (custom_layers.py:146-158; utilities.py:272-321): nsig = (k-1)/2, sigma 1."""
+    ax = [np.linspace(-(k - 1) / 2, (k - 1) / 2, k, dtype=np.float64) for k in kernel_size]
+    gx, gy = np.meshgrid(ax[0], ax[1])
+    g = np.exp(-(gx * gx + gy * gy) / 2.0)
+    return (g / g.sum()).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# the model
+# ---------------------------------------------------------------------------------------------
+
+class UnetLaplacianHydra:
+    """hydra(x) for backbone type "unet_laplacian": returns one denormalised output per scale, full resolution first
+    (model.py:117-142).  Trainable tensors live in one flat float32 vector (`params`) in graph-construction order;
+    `trainable_variables` lists (name, shape, kind, offset)."""
+
+    multi_output = True           # DenoiserModule keeps output 0
+    auto_exact_fallback = False   # exact fp32 throughout: no reduced-range arithmetic to fall back from
+
+    class _Desc:
+        def __init__(self, cin, cout):
+            self.in_channels, self.out_channels = cin, cout
+
+    def check_status(self, raise_on_overflow: bool = True) -> bool:
+        return True
+
+    def __init__(self, config: Dict, device=None, seed: Optional[int] = None):
+        bb, dn = config["backbone"], config["denoiser"]
+        self.config = config
+        for key, want in dict(use_bn=False, use_bias=False, use_concat=False, use_attention_gates=False,
+                              use_complex_base=False, use_value_compressor=False, use_global_pool_information=False,
+                              multiple_scale_outputs=True).items():
+            default = True if key in ("use_concat", "multiple_scale_outputs") else False
+            if bb.get(key, default) != want:
+                raise NotImplementedError(f"unet_laplacian: {key}={bb.get(key, default)} is outside the built graph")
+        if bb.get("downsample_type", "strides").strip().lower() != "strides":
+            raise NotImplementedError("unet_laplacian: downsample_type must be 'strides'")
+        if dn.get("use_bn", False) or dn.get("use_ln", False) or dn.get("use_bias", False):
+            raise NotImplementedError("denoiser head: use_bn / use_ln / use_bias are outside the built graph")
+        self.depth = int(bb.get("depth", 5))
+        self.width = int(bb.get("width", 1) or 1)
+        if self.width <= 0:
+            self.width = 1
+        if self.depth <= 0:
+            raise ValueError("depth and width must be > 0")                        # backbone_unet_laplacian.py:125-126
+        rate = bb.get("convolutional_self_attention_dropout_rate", 0.0)
+        if rate < 0 or rate > 1:
+            raise ValueError("convolutional_self_attention_dropout_rate must be >= 0 and <= 1")
+        if bb.get("use_soft_orthonormal_regularization", False) and bb.get("use_soft_orthogonal_regularization", False):
+            raise ValueError("only one use_soft_orthonormal_regularization or use_soft_orthogonal_regularization "
+                             "must be turned on")
+        self.filters = int(bb.get("filters", 32))
+        self.max_filters = int(bb.get("max_filters", -1))
+        self.multiplier = float(bb.get("filters_level_multiplier", 2.0))
+        self.in_channels = int(bb["input_shape"][-1])
+        self.enc_k = int(bb.get("encoder_kernel_size", 5))
+        self.dec_k = int(bb.get("decoder_kernel_size", 3))
+        self.gauss_k = int(bb.get("gaussian_kernel_size", 3))
+        self.activation = (bb.get("activation", "leaky_relu_01") or "leaky_relu_01").strip().lower()
+        _act(self.activation)
+        self.upsample_type = bb.get("upsample_type", "bilinear").strip().lower()
+        if self.upsample_type not in ("upsample_laplacian_conv2d", "bilinear"):
+            raise NotImplementedError(f"unet_laplacian: upsample_type [{self.upsample_type}]")
+        self.use_ln = bool(bb.get("use_ln", True))
+        self.use_gamma = bool(bb.get("use_gamma", True))
+        self.use_laplacian = bool(bb.get("use_laplacian", True))
+        self.use_laplacian_averaging = bool(bb.get("use_laplacian_averaging", True))
+        if not (self.use_laplacian or self.use_laplacian_averaging):
+            raise NotImplementedError("unet_laplacian without the Laplacian split")
+        self.use_mix_project = bool(bb.get("use_mix_project", True))
+        self.use_self_attention = bool(bb.get("use_self_attention", False))
+        self.use_output_normalization = bool(bb.get("use_output_normalization", False))
+        # keras 2.13 cannot resolve the string "leaky_relu" ConvolutionalSelfAttention gives its Conv2D layers
+        # (custom_layers.py:1272-1282); later keras resolve it to negative_slope 0.2, which is what is built here
+        self.attention_alpha = float(bb.get("attention_alpha", 0.2))
+        self.attention_resolution = (16, 16)
+        vr = bb.get("value_range", [0, 255])
+        self.v_min, self.v_max = float(vr[0]), float(vr[1])
+        self.head_filters = int(dn.get("filters", 32))
+        self.head_activation = (dn.get("activation", "linear") or "linear").strip().lower()
+        _act(self.head_activation)
+        self.out_channels = int(dn.get("output_channels", 3))
+        for d in range(self.depth):
+            if self.level_filters(d) not in (32, 64, 128):
+                raise NotImplementedError(f"unet_laplacian: level {d} has {self.level_filters(d)} channels (32/64/128 are built)")
+        if self.head_filters not in (32, 64, 128):
+            raise NotImplementedError("denoiser head filters must be 32, 64 or 128")
+
+        self.desc = self._Desc(self.in_channels, self.out_channels)
+        self.device = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self._inventory = self._build_inventory()
+        self.n_params = sum(int(np.prod(s)) for _, s, _ in self._inventory)
+        self.params = torch.from_numpy(self._initial_values(seed)).to(self.device)
+        self._packed = None
+
+    # -- inventory ---------------------------------------------------------------------------
+    def level_filters(self, d: int) -> int:
+        f = int(round(self.filters * max(1, self.multiplier ** d)))              # backbone_unet_laplacian.py:198-201
+        return min(self.max_filters, f) if self.max_filters > 0 else f
+
+    def _is_attention(self, d: int) -> bool:
+        return self.use_self_attention and d == self.depth - 1                    # :324
+
+    def _build_inventory(self) -> List[Tuple[str, Tuple[int, ...], str]]:
+        out = [("base/kernel", (5, 5, self.in_channels, self.filters), "conv")]
+        A = self.filters
+
+        def block(prefix, C, k, attn):
+            if attn:
+                if self.use_ln:
+                    out.append((f"{prefix}/ln/gamma", (C,), "ln_gamma"))
+                for n in ("key", "query", "value"):
+                    out.append((f"{prefix}/{n}/kernel", (1, 1, C, A), "conv"))
+                out.append((f"{prefix}/out/kernel", (1, 1, A, C), "conv"))
+                out.append((f"{prefix}/gamma/w", (C,), "multiplier"))
+                return
+            out.append((f"{prefix}/dw/kernel", (k, k, C, 1), "depthwise"))
+            if self.use_ln:
+                out.append((f"{prefix}/ln/gamma", (C,), "ln_gamma"))
+            out.append((f"{prefix}/pw1/kernel", (1, 1, C, 4 * C), "conv"))
+            out.append((f"{prefix}/pw2/kernel", (1, 1, 4 * C, C), "conv"))
+            if self.use_gamma:
+                out.append((f"{prefix}/gamma/w", (C,), "multiplier"))
+
+        for d in range(self.depth):
+            C = self.level_filters(d)
+            for w in range(self.width):
+                block(f"enc{d}_{w}", C, self.enc_k, self._is_attention(d))
+            if self.use_output_normalization and self.use_ln:
+                out.append((f"enc{d}/out_ln/gamma", (C,), "ln_gamma"))
+            if d != self.depth - 1:
+                out.append((f"down{d}/kernel", (1, 1, C, self.level_filters(d + 1)), "conv"))
+        for d in reversed(range(self.depth - 1)):
+            C = self.level_filters(d)
+            if self.upsample_type == "upsample_laplacian_conv2d":
+                out.append((f"up{d}/kernel", (1, 1, self.level_filters(d + 1), C), "conv"))
+            if self.use_mix_project:
+                out.append((f"mix{d}/kernel", (1, 1, C, C), "conv"))
+            for w in range(self.width):
+                block(f"dec{d}_{w}", C, self.dec_k, False)
+            if self.use_output_normalization and self.use_ln:
+                out.append((f"dec{d}/out_ln/gamma", (C,), "ln_gamma"))
+        for i in range(self.depth):
+            out.append((f"head{i}/conv0/kernel", (1, 1, self.level_filters(i), self.head_filters), "conv"))
+            out.append((f"head{i}/conv1/kernel", (1, 1, self.head_filters, self.out_channels), "conv"))
+        return out
+
+    @property
+    def trainable_variables(self):
+        o, res = 0, []
+        for name, shape, kind in self._inventory:
+            res.append((name, shape, kind, o))
+            o += int(np.prod(shape))
+        return res
+
+    def count_params(self) -> int:
+        return self.n_params
+
+    def _initial_values(self, seed) -> np.ndarray:
+        from .model import glorot_normal
+        rng = np.random.default_rng(seed)
+        parts = []
+        for _, shape, kind in self._inventory:
+            if kind in ("conv", "depthwise"):
+                a = glorot_normal(shape, rng)
+            elif kind == "ln_gamma":
+                a = np.ones(shape)
+            else:                                                # truncated_normal(0, 0.01) (custom_layers.py:271)
+                a = rng.normal(0.0, 0.01, shape)
+                bad = np.abs(a) > 0.02
+                while bad.any():
+                    a[bad] = rng.normal(0.0, 0.01, int(bad.sum()))
+                    bad = np.abs(a) > 0.02
+            parts.append(np.asarray(a, np.float32).ravel())
+        return np.concatenate(parts)
+
+    def get_weights(self) -> np.ndarray:
+        return self.params.detach().cpu().numpy()
+
+    def set_weights(self, params: np.ndarray):
+        params = np.ascontiguousarray(params, np.float32).ravel()
+        if params.size != self.n_params:
+            raise ValueError(f"expected {self.n_params} parameters, got {params.size}")
+        self.params.copy_(torch.from_numpy(params))
+        self._packed = None
+
+    # -- packing -----------------------------------------------------------------------------
+    def _pack(self) -> Dict[str, torch.Tensor]:
+        """device views of the tensors; 1x1 kernels additionally in matrix-core order, multipliers as tanh(relu(1+w))."""
+        if self._packed is not None:
+            return self._packed
+        P: Dict[str, torch.Tensor] = {}
+        for name, shape, kind, off in self.trainable_variables:
+            n = int(np.prod(shape))
+            t = self.params[off:off + n]
+            if off % 4:                                          # operators want 16-byte aligned buffers
+                t = t.clone()
+            t = t.view(shape)
+            if kind == "conv" and shape[0] == 1 and shape[2] % 16 == 0 and shape[3] % 16 == 0:
+                P[name] = pack_pointwise(t)
+            elif kind == "multiplier":
+                P[name] = channel_multiplier(t)
+            elif kind == "depthwise":
+                P[name] = t.reshape(shape[0], shape[1], shape[2]).contiguous()
+            else:
+                P[name] = t.contiguous()
+        if not self.use_laplacian_averaging:
+            P["gauss"] = torch.from_numpy(gaussian_kernel((self.gauss_k, self.gauss_k))).to(self.device)
+        self._packed = P
+        return P
+
+    # -- forward -----------------------------------------------------------------------------
+    def _require_gpu(self):
+        if self.device.type != "cuda":
+            raise RuntimeError("unet_laplacian inference needs the GPU: there is no CPU execution path")
+
+    def _convnext(self, P, prefix: str, x: torch.Tensor) -> torch.Tensor:
+        t = dwconv_ln(x, P[f"{prefix}/dw/kernel"], P.get(f"{prefix}/ln/gamma") if self.use_ln else None)
+        return convnext_mlp(t, x, P[f"{prefix}/pw1/kernel"], P[f"{prefix}/pw2/kernel"],
+                            P.get(f"{prefix}/gamma/w") if self.use_gamma else None, self.activation)
+
+    def _attention(self, P, prefix: str, x: torch.Tensor) -> torch.Tensor:
+        B, H, W, C = x.shape
+        rh, rw = self.attention_resolution
+        A = self.filters
+        t = resize_bilinear(x, rh, rw)
+        if self.use_ln:
+            t = dwconv_ln(t, None, P[f"{prefix}/ln/gamma"])
+        q, v, k = (pointwise(t, P[f"{prefix}/{n}/kernel"], A, "leaky_relu", alpha=self.attention_alpha).view(B, rh * rw, A)
+                   for n in ("query", "value", "key"))
+        t = attention(q, v, k).view(B, rh, rw, A)
+        t = resize_bilinear(t, H, W)
+        return pointwise(t, P[f"{prefix}/out/kernel"], C, "linear", mult=P[f"{prefix}/gamma/w"], res=x)
+
+    def backbone(self, x: torch.Tensor, H: int, W: int) -> List[torch.Tensor]:
+        """x: [B,Hs,Ws,cin] image on the value_range scale (zero-padded to [H,W]); returns the per-scale feature maps."""
+        P = self._pack()
+        step = 2 ** (self.depth - 1)
+        if H % step or W % step:
+            raise ValueError(f"height and width must be multiples of {step} (the decoder adds x2-upsampled maps to the "
+                             f"::2-sliced ones; got {H}x{W})")
+        a = self.activation
+        f = first_conv(x, P["base/kernel"], H, W, a, True, self.v_min, self.v_max)
+        nodes = {}
+        for d in range(self.depth):
+            for w in range(self.width):
+                f = self._attention(P, f"enc{d}_{w}", f) if self._is_attention(d) else self._convnext(P, f"enc{d}_{w}", f)
+            gamma = P[f"enc{d}/out_ln/gamma"] if (self.use_output_normalization and self.use_ln) else None
+            f = dwconv_ln(f, None, gamma, a)
+            nodes[d] = f
+            if d != self.depth - 1:
+                lap, down = smooth_split(f, self.gauss_k, None if self.use_laplacian_averaging else P["gauss"])
+                nodes[d] = lap
+                f = pointwise(down, P[f"down{d}/kernel"], self.level_filters(d + 1), a)
+        outs = {self.depth - 1: nodes[self.depth - 1]}
+        for d in reversed(range(self.depth - 1)):
+            low = outs[d + 1]
+            if self.upsample_type == "upsample_laplacian_conv2d":
+                # 1x1 and the bilinear resize are both linear: the 1x1 runs on the low-resolution map (1/4 of the work;
+                # upsampling.py:80-90 makes the same exchange itself when the activation is linear)
+                low = pointwise(low, P[f"up{d}/kernel"], self.level_filters(d), "linear")
+                f = upsample_act_add(low, nodes[d], a)
+            else:
+                f = upsample_act_add(low, nodes[d], "linear")
+            if self.use_mix_project:
+                f = pointwise(f, P[f"mix{d}/kernel"], self.level_filters(d), a)
+            for w in range(self.width):
+                f = self._convnext(P, f"dec{d}_{w}", f)
+            if self.use_output_normalization and self.use_ln:
+                f = dwconv_ln(f, None, P[f"dec{d}/out_ln/gamma"])
+            outs[d] = f
+        return [outs[d] for d in range(self.depth)]
+
+    def _head(self, P, i: int, f: torch.Tensor, Ho: int, Wo: int, as_uint8: bool) -> torch.Tensor:
+        h = pointwise(f, P[f"head{i}/conv0/kernel"], self.head_filters, self.head_activation)
+        return head_out(h, P[f"head{i}/conv1/kernel"], Ho, Wo, as_uint8, True, self.v_min, self.v_max)
+
+    def _as_device(self, x):
+        was_numpy = isinstance(x, np.ndarray)
+        if was_numpy:
+            x = torch.from_numpy(np.ascontiguousarray(x))
+        if x.dim() != 4 or x.shape[-1] != self.in_channels:
+            raise ValueError(f"expected [B,H,W,{self.in_channels}], got {tuple(x.shape)}")
+        if x.dtype != torch.uint8:
+            x = x.to(torch.float32)
+        return x.to(self.device).contiguous(), was_numpy
+
+    def __call__(self, x, training: bool = False):
+        """float32 (or uint8) [B,H,W,3] on the 0..255 scale -> list of float32 outputs, full resolution first."""
+        if training:
+            raise NotImplementedError("unet_laplacian: only inference is built")
+        self._require_gpu()
+        x, was_numpy = self._as_device(x)
+        B, H, W, _ = x.shape
+        P = self._pack()
+        outs = []
+        for i, f in enumerate(self.backbone(x, H, W)):
+            outs.append(self._head(P, i, f, f.shape[1], f.shape[2], False))
+        if was_numpy:
+            torch.cuda.synchronize(self.device)
+            return [o.cpu().numpy() for o in outs]
+        return outs
+
+    def predict(self, x):
+        return self(x)
+
+    def infer_u8(self, image: torch.Tensor, cast_to_uint8: bool = True) -> torch.Tensor:
+        """DenoiserModule.__call__ for this model (module_denoiser.py:46-75): pad to a power of two, hydra, first output,
+        crop, round half to even, cast.  Only the full-resolution head is evaluated."""
+        from .utilities import next_power_of_2
+        self._require_gpu()
+        B, Hs, Ws, _ = image.shape
+        H, W = next_power_of_2(Hs), next_power_of_2(Ws)
+        P = self._pack()
+        f = self.backbone(image, H, W)[0]
+        return self._head(P, 0, f, Hs, Ws, cast_to_uint8)

@@ -1,0 +1,229 @@
+"""GPU parity of the unet_laplacian operators (csrc/unet_ops.hip, through the C ABI) and of the whole
+hydra / DenoiserModule path against the fp64 oracle (oracle/unet_oracle.py).
+Bars as for the resnet path: f32 outputs MAE <= 1e-4 on the normalised scale, uint8 within +-1 LSB."""
+import numpy as np
+import pytest
+import torch
+
+import blind_image_denoising_amd as bf
+from blind_image_denoising_amd import unet_laplacian as UL
+from oracle import bfcnn_oracle as O
+from oracle import unet_oracle as U
+from helpers import dev, host, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _rng(seed):
+    return np.random.default_rng(seed)
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 128), (128, 64), (64, 32), (128, 32), (32, 128), (128, 128), (64, 64)])
+@pytest.mark.parametrize("npix", [1, 63, 64, 1000])
+def test_pointwise_gemm(cin, cout, npix):
+    r = _rng(cin + cout + npix)
+    x, w = r.normal(size=(1, 1, npix, cin)), r.normal(size=(1, 1, cin, cout)) / np.sqrt(cin)
+    mult, res = r.uniform(0.2, 1.0, cout), r.normal(size=(1, 1, npix, cout))
+    wp = UL.pack_pointwise(dev(w))
+    for act, alpha in (("linear", None), ("leaky_relu_01", None), ("gelu", None), ("leaky_relu", 0.2)):
+        ref = O.conv2d_same(x, w)
+        ref = U.leaky(ref, alpha) if alpha is not None else U.act(ref, act)
+        got = UL.pointwise(dev(x), wp, cout, act, alpha=alpha)
+        assert_close(host(got), ref, what=f"pointwise {act}")
+        got = UL.pointwise(dev(x), wp, cout, act, mult=dev(mult), res=dev(res), alpha=alpha)
+        assert_close(host(got), res + mult * ref, what=f"pointwise {act} mult res")
+
+
+def test_pointwise_small_integers_exact():
+    r = _rng(5)
+    x = r.integers(-8, 9, size=(1, 1, 200, 64)).astype(np.float64)
+    w = r.integers(-4, 5, size=(1, 1, 64, 128)).astype(np.float64)
+    got = host(UL.pointwise(dev(x), UL.pack_pointwise(dev(w)), 128))
+    assert np.array_equal(got, O.conv2d_same(x, w))
+
+
+@pytest.mark.parametrize("C", [32, 64, 128])
+@pytest.mark.parametrize("npix", [1, 17, 64, 129, 777])
+def test_convnext_mlp_fused(C, npix):
+    r = _rng(C + npix)
+    x, skip = r.normal(size=(1, 1, npix, C)), r.normal(size=(1, 1, npix, C))
+    w1, w2 = r.normal(size=(1, 1, C, 4 * C)) / np.sqrt(C), r.normal(size=(1, 1, 4 * C, C)) / np.sqrt(4 * C)
+    mult = r.uniform(0.2, 1.0, C)
+    w1p, w2p = UL.pack_pointwise(dev(w1)), UL.pack_pointwise(dev(w2))
+    for act in ("leaky_relu_01", "gelu", "linear"):
+        ref = skip + mult * O.conv2d_same(U.act(O.conv2d_same(x, w1), act), w2)
+        got = UL.convnext_mlp(dev(x), dev(skip), w1p, w2p, dev(mult), act)
+        assert_close(host(got), ref, what=f"mlp C={C} {act}")
+    got = UL.convnext_mlp(dev(x), None, w1p, w2p, None, "relu")
+    assert_close(host(got), O.conv2d_same(np.maximum(O.conv2d_same(x, w1), 0), w2), what="mlp plain")
+
+
+@pytest.mark.parametrize("C", [32, 64, 128])
+@pytest.mark.parametrize("k", [0, 1, 3, 5])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (2, 7, 9), (1, 16, 40)])
+def test_dwconv_layernorm(C, k, shape):
+    r = _rng(C * 10 + k)
+    x = r.normal(size=shape + (C,)) * 2 + 0.5
+    w = r.normal(size=(k, k, C, 1)) if k else None
+    g = r.uniform(0.5, 1.5, C)
+    t = U.depthwise_same(x, w) if k else x
+    wd = dev(w.reshape(k, k, C)) if k else None
+    assert_close(host(UL.dwconv_ln(dev(x), wd, dev(g))), U.layer_norm(t, g), rel=5e-5, what="dw+ln")
+    assert_close(host(UL.dwconv_ln(dev(x), wd, None, "leaky_relu_01")), U.act(t, "leaky_relu_01"), what="dw+act")
+    assert_close(host(UL.dwconv_ln(dev(x), wd, dev(g), "leaky_relu_01")), U.act(U.layer_norm(t, g), "leaky_relu_01"),
+                 rel=5e-5, what="dw+ln+act")
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 2, 32), (2, 8, 12, 32), (1, 16, 16, 64), (1, 6, 10, 128)])
+def test_smooth_split_average_and_gaussian(shape):
+    x = _rng(3).normal(size=shape)
+    smooth = O.avg_pool_same(x, (3, 3), 1)
+    lap, down = UL.smooth_split(dev(x), 3)
+    assert_close(host(lap), x - smooth, what="lap avg")
+    assert_close(host(down), smooth[:, ::2, ::2], what="down avg")
+    g = U.gaussian_kernel_3()
+    assert np.array_equal(g.astype(np.float32), UL.gaussian_kernel((3, 3)))
+    smooth = U.depthwise_same(x, np.repeat(g[:, :, None, None], shape[-1], axis=2))
+    lap, down = UL.smooth_split(dev(x), 3, dev(g))
+    assert_close(host(lap), x - smooth, what="lap gauss")
+    assert_close(host(down), smooth[:, ::2, ::2], what="down gauss")
+
+
+@pytest.mark.parametrize("shape,out", [((1, 128, 128, 32), (16, 16)), ((2, 16, 16, 32), (128, 128)), ((1, 20, 36, 64), (16, 16)),
+                                       ((1, 16, 16, 32), (20, 36)), ((1, 4, 4, 128), (16, 16)), ((1, 16, 16, 32), (16, 16))])
+def test_resize_bilinear(shape, out):
+    x = _rng(7).normal(size=shape)
+    assert_close(host(UL.resize_bilinear(dev(x), *out)), U.resize_bilinear(x, *out), what="resize")
+
+
+def test_upsample_act_add():
+    r = _rng(8)
+    x, other = r.normal(size=(2, 5, 7, 32)), r.normal(size=(2, 10, 14, 32))
+    assert_close(host(UL.upsample_act_add(dev(x), dev(other), "leaky_relu_01")),
+                 other + U.act(O.upsample_bilinear_2x(x), "leaky_relu_01"), what="up+act+add")
+    assert_close(host(UL.upsample_act_add(dev(x), None)), O.upsample_bilinear_2x(x), what="up")
+
+
+@pytest.mark.parametrize("B,T", [(1, 256), (3, 256), (2, 64)])
+def test_attention(B, T):
+    r = _rng(9)
+    q, v, k = (r.normal(size=(B, T, 32)) for _ in range(3))
+    assert_close(host(UL.attention(dev(q), dev(v), dev(k))), U.dot_attention(q, v, k), rel=5e-5, what="attention")
+
+
+@pytest.mark.parametrize("u8", [True, False])
+def test_first_conv_normalise_and_virtual_padding(u8):
+    r = _rng(10)
+    img = r.integers(0, 256, size=(2, 13, 21, 3)).astype(np.uint8)
+    w = r.normal(size=(5, 5, 3, 32)) * 0.2
+    padded = np.zeros((2, 16, 32, 3)); padded[:, :13, :21] = img
+    ref = U.act(O.conv2d_same(O.layer_normalize(padded, 0.0, 255.0), w), "leaky_relu_01")
+    x = torch.from_numpy(img).cuda() if u8 else dev(img)
+    got = UL.first_conv(x, dev(w), 16, 32, "leaky_relu_01", True, 0.0, 255.0)
+    assert_close(host(got), ref, what="first conv")
+
+
+def test_head_out_f32_u8_and_crop():
+    r = _rng(11)
+    x, w = r.normal(size=(2, 8, 8, 32)), r.normal(size=(1, 1, 32, 3)) * 0.3
+    ref = O.layer_denormalize(np.tanh(2 * O.conv2d_same(x, w)) * 0.51, 0.0, 255.0)
+    assert_close(host(UL.head_out(dev(x), dev(w), 8, 8, False, True, 0.0, 255.0)), ref, rel=2e-6 * 255, what="head f32")
+    got = host(UL.head_out(dev(x), dev(w), 5, 7, True, True, 0.0, 255.0))
+    want = np.clip(np.rint(ref[:, :5, :7]), 0, 255)
+    assert got.dtype == np.uint8 and np.abs(got.astype(int) - want).max() <= 1 and (got != want).mean() < 0.01
+
+
+def test_channel_multiplier():
+    w = np.linspace(-2.0, 1.0, 64)
+    assert_close(host(UL.channel_multiplier(dev(w))), np.tanh(np.maximum(1 + w, 0)), what="multiplier")
+
+
+# ---- whole model ---------------------------------------------------------------------------------
+
+def _model(depth=3, width=3, seed=42, **bb):
+    cfg = U.canonical_config(depth=depth, width=width)
+    cfg["model"]["backbone"].update(bb)
+    spec = U.UnetLaplacianSpec.from_config(cfg["model"])
+    params = U.init_params(spec, seed=seed)
+    m = bf.model_builder(cfg["model"], device="cuda").hydra
+    assert [(v[0], tuple(v[1])) for v in m.trainable_variables] == [(n, tuple(s)) for n, s, _ in spec.tensors()]
+    m.set_weights(params)
+    return cfg, spec, params, m
+
+
+def _check_f32(got, ref):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    mae = np.abs(got - ref).mean() / 255.0
+    assert mae <= 1e-4, f"normalised MAE {mae:.3e}"
+    assert np.abs(got - ref).max() <= 0.05, f"max err {np.abs(got - ref).max():.3e} (0..255 scale)"
+
+
+def _check_u8(got, ref):
+    assert got.dtype == np.uint8 and got.shape == ref.shape
+    d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 0.01, (d.max(), (d > 0).mean())
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 64), (2, 32, 96), (1, 128, 128)])
+def test_v5_hydra_all_scales_match_oracle(shape):
+    cfg, spec, params, m = _model()
+    _, noisy = O.synthetic_batch(*shape, seed=shape[1])
+    x = noisy.astype(np.float32)
+    got, ref = m(x), U.hydra_forward(spec, params, x.astype(np.float64))
+    assert len(got) == 3
+    for g, r in zip(got, ref):
+        _check_f32(g, r)
+
+
+@pytest.mark.parametrize("bb", [dict(use_self_attention=False, depth=2), dict(use_laplacian_averaging=False),
+                                dict(use_mix_project=True, width=1), dict(upsample_type="bilinear", filters=32, depth=1),
+                                dict(use_output_normalization=False, use_gamma=False, width=2),
+                                dict(decoder_kernel_size=3, encoder_kernel_size=3, width=1),
+                                dict(use_self_attention=False, width=1)],
+                         ids=["no-attn-d2", "gaussian", "mix-project", "depth1", "no-outnorm-no-gamma", "k3", "convnext-c128"])
+def test_builder_variants_match_oracle(bb):
+    depth, width = bb.pop("depth", 3), bb.pop("width", 2)
+    cfg, spec, params, m = _model(depth=depth, width=width, seed=7, **bb)
+    _, noisy = O.synthetic_batch(1, 64, 64, seed=3)
+    x = noisy.astype(np.float32)
+    for g, r in zip(m(x), U.hydra_forward(spec, params, x.astype(np.float64))):
+        _check_f32(g, r)
+
+
+@pytest.mark.parametrize("hw", [(64, 64), (40, 50), (17, 100), (128, 128)])
+def test_denoiser_module_u8(hw):
+    cfg, spec, params, m = _model(seed=11)
+    _, noisy = O.synthetic_batch(1, hw[0], hw[1], seed=hw[0] + hw[1])
+    got = bf.DenoiserModule(m)(noisy)
+    assert got.shape == noisy.shape and got.dtype == np.uint8
+    _check_u8(got, U.denoiser_module_call(spec, params, noisy))
+    f = bf.DenoiserModule(m, cast_to_uint8=False)(noisy)
+    _check_f32(f, U.denoiser_module_call(spec, params, noisy, cast_to_uint8=False))
+
+
+def test_midgrey_fixed_point_and_determinism():
+    cfg, spec, params, m = _model(seed=2)
+    y = m(np.full((1, 64, 64, 3), 127.5, np.float32))
+    assert all(np.array_equal(o, np.full_like(o, 127.5)) for o in y)
+    _, noisy = O.synthetic_batch(3, 64, 64, seed=1)
+    mod = bf.DenoiserModule(m)
+    a = mod(noisy)
+    assert np.array_equal(a, mod(noisy)) and np.array_equal(a[1:2], mod(noisy[1:2]))
+
+
+def test_shape_and_config_errors():
+    cfg, spec, params, m = _model(seed=2)
+    with pytest.raises(ValueError, match="multiples of 4"):
+        m(np.zeros((1, 30, 64, 3), np.float32))
+    bad = U.canonical_config()["model"]; bad["backbone"]["use_concat"] = True
+    with pytest.raises(NotImplementedError):
+        bf.model_builder(bad, device="cuda")
+
+
+def test_save_and_load_model_roundtrip(tmp_path):
+    cfg, spec, params, m = _model(depth=2, width=1, seed=5)
+    bf.save_model(m, str(tmp_path / "unet"))
+    mod = bf.load_model(str(tmp_path / "unet"))
+    _, noisy = O.synthetic_batch(1, 32, 32, seed=4)
+    assert np.array_equal(mod(noisy), bf.DenoiserModule(m)(noisy))
