@@ -116,6 +116,78 @@ def pyramid_bench(args, torch, bf, O, rank, local_rank, world, dist):
                          "algorithmic_bytes_per_step": nbytes}}), flush=True)
 
 
+def unet_flop_per_px(m):
+    """algorithmic FLOP (2 x MAC) per level-0 pixel of the built unet_laplacian graph: 1x1 / k x k convolutions only
+    (LayerNorm, resize, adds and the fixed-size attention are not counted)."""
+    total = 2.0 * 25 * m.in_channels * m.filters
+    for d in range(m.depth):
+        C, frac = m.level_filters(d), 0.25 ** d
+        if m._is_attention(d):
+            per = 0.0          # fixed 16x16 token grid: q, k, v, out 1x1s and the attention do not scale with the image
+        else:
+            per = m.width * (2.0 * m.enc_k ** 2 * C + 2 * 2.0 * C * 4 * C)
+        if d < m.depth - 1:
+            per += m.width * (2.0 * m.dec_k ** 2 * C + 2 * 2.0 * C * 4 * C)          # decoder blocks of this level
+            per += 0.25 * 2.0 * C * m.level_filters(d + 1) * 2                         # down 1x1 + up 1x1 (both at 1/4 res)
+        per += 2.0 * C * m.head_filters + 2.0 * m.head_filters * m.out_channels if d == 0 else 0.0
+        total += per * frac
+    return total
+
+
+def unet_bench(args, torch, bf, O, rank, local_rank, world, dist):
+    """configs[4]: unet_laplacian (v5 graph: depth 3, width 3, 32/64/128 filters) inference, batch 32 512x512x3,
+    uint8 -> uint8 through DenoiserModule.__call__ (only the full-resolution head is evaluated, as the module keeps
+    output 0).  Images are independent: N ranks = N replicas, no collective."""
+    from oracle import unet_oracle as U
+    B, S = (32 if args.batch == 128 else args.batch), (512 if args.size == 256 else args.size)
+    cfg = U.canonical_config()
+    spec = U.UnetLaplacianSpec.from_config(cfg["model"])
+    params = U.init_params(spec, seed=42)
+    model = bf.model_builder(cfg["model"], device=f"cuda:{local_rank}").hydra
+    model.set_weights(params)
+    module = bf.DenoiserModule(model)
+    _, base = O.synthetic_batch(4, S, S, sigma=20.0, seed=1234 + rank)
+    noisy = torch.from_numpy(np.concatenate([base] * ((B + 3) // 4), axis=0)[:B]).cuda()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(max(args.warmup, 1)):
+        out = module(noisy)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = module(noisy)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return
+    # parity of one small crop against the oracle (the full 512^2 image takes the fp64 NumPy oracle minutes)
+    crop = base[:1, :64, :64]
+    ref = U.denoiser_module_call(spec, params, crop)
+    got = module(torch.from_numpy(np.ascontiguousarray(crop)).cuda()).cpu().numpy()
+    diff = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+    flop = unet_flop_per_px(model) * B * S * S
+    tf = flop * args.steps / elapsed / 1e12
+    print(json.dumps({
+        "metric": "denoised images/sec (512x512x3), unet_laplacian 3-scale", "value": world * B * args.steps / elapsed,
+        "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"unet_laplacian v5 graph (depth 3, width 3, filters 32/64/128, attention on the deepest "
+                               f"level) inference, batch={B}/GPU {S}x{S}x3 uint8->uint8 (DenoiserModule.__call__)",
+                   "batch_per_gpu": B, "parallelism": f"replicas x{world}, no collective"},
+        "parity": {"max_abs_lsb": int(diff.max()), "mean_abs_lsb": float(diff.mean()), "checked": "one 64x64 crop vs oracle"},
+        "roofline": {"bound": "mfma", "kernel": "uo_convnext_mlp_kernel + uo_pointwise_kernel (fp32 16x16x4 MFMA)",
+                     "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                     "note": "whole-step algorithmic FLOP / whole-step time (all kernels, HBM-bound ones included)"}}), flush=True)
+
+
 def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
     """configs[3]: resnet_color_1x18 training step, L1 loss (hinge 0.5), additive-gaussian synthetic batch, global batch =
     --batch x world sharded over the ranks, one sum-all-reduce of the flat fp32 gradient buffer, fused clip + Adam."""
@@ -185,7 +257,7 @@ def main():
     ap.add_argument("--fused-tile", type=int, default=None, help="exact-fp32 fused-block tile geometry variant (A/B only)")
     ap.add_argument("--arith", type=int, default=1, help="1 = split-f16 fused blocks (default), 0 = exact-fp32 fused blocks")
     ap.add_argument("--h3-variant", type=int, default=None, help="split-f16 kernel variant (A/B only)")
-    ap.add_argument("--mode", choices=["inference", "train", "pyramid"], default="inference",
+    ap.add_argument("--mode", choices=["inference", "train", "pyramid", "unet"], default="inference",
                     help="train: BASELINE.json configs[3] -- one data-parallel training step per step (L1 loss, "
                          "batch sharded over the ranks, ONE gradient all-reduce, clip + Adam); not the headline metric")
     args = ap.parse_args()
@@ -214,6 +286,8 @@ def main():
         return train_bench(args, torch, bf, O, rank, local_rank, world, dist)
     if args.mode == "pyramid":
         return pyramid_bench(args, torch, bf, O, rank, local_rank, world, dist)
+    if args.mode == "unet":
+        return unet_bench(args, torch, bf, O, rank, local_rank, world, dist)
     cfg = O.canonical_config(no_layers=args.layers)
     spec = O.ResnetSpec.from_config(cfg["model"])
     params, state = O.init_params(spec, seed=42, nontrivial_bn=True)
