@@ -1,0 +1,290 @@
+// ConvNext MLP of the unet_laplacian backbone on the f16 matrix cores with split-f16 ("f16x3") arithmetic:
+//   out = skip + mult * (act(x . W1) . W2)        x [npix][C] fp32 (LayerNorm output), W1 [C][4C], W2 [4C][C]
+// (bfcnn/custom_layers.py:990-1008 conv_2 -> activation -> conv_3 -> ChannelLearnableMultiplier; the Add of
+// backbone_unet_laplacian.py:351-354.)  Same arithmetic as the resnet blocks (fused_h3.hip): every fp32
+// operand v is carried as hi = f16(v), lo = f16(v - hi) (22 mantissa bits), a product is w_hi x_hi + w_lo x_hi + w_hi x_lo
+// on v_mfma_f32_16x16x32_f16 with fp32 accumulation; the weights are pre-scaled by a power of two so that their lo parts
+// stay normal f16 numbers.  3 MFMAs of 16 cycles contract K = 32 where the fp32 path (unet_ops.hip) needs 8 MFMAs of 32
+// cycles: 5.3x fewer matrix-pipe cycles, which makes the kernel HBM-bound (x + skip + out = 12 C bytes per pixel).
+//
+// Data flow per wave and 16 pixels (N = pixel, M = output channel of a tile):
+//   GEMM1  B = x^T: lane (q, n) loads channels 32c + 8q .. +7 of pixel n (two 16-byte loads) and splits them;
+//          A = W1 fragments from LDS.  Two hidden tiles (2c2, 2c2+1) are produced at a time:
+//          lane (q, n), register r of tile t = hidden channel 16t + 4q + r of pixel n.
+//   GEMM2  those 8 values of a lane, activated and split, ARE a legal B fragment of the next GEMM for the K order
+//          k(q, i) = 32 c2 + 16 (i / 4) + 4 q + (i % 4); W2 is packed in that order.  The 4C-wide hidden tensor never
+//          exists outside a pair of accumulators.
+#include "bf_common.h"
+#include <math.h>
+
+typedef _Float16 uh8 __attribute__((ext_vector_type(8)));
+typedef _Float16 uh4 __attribute__((ext_vector_type(4)));
+typedef _Float16 uh2 __attribute__((ext_vector_type(2)));
+#define UH_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+// v - float(one half of the packed f16 pair hh) in one instruction (v_fma_mix_f32)
+__device__ __forceinline__ float uh_sub_half(const float v, const unsigned hh, const bool high)
+{
+    float r;
+    if (high) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(v));
+    else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(v));
+    return r;
+}
+
+// 8 fp32 values -> hi / lo f16 fragments
+__device__ __forceinline__ void uh_split8(const f32x4 a, const f32x4 b, uh8& hi, uh8& lo)
+{
+    const uh4 ha = __builtin_convertvector(a, uh4), hb = __builtin_convertvector(b, uh4);
+    const unsigned p0 = __builtin_bit_cast(unsigned, (uh2){ha[0], ha[1]}), p1 = __builtin_bit_cast(unsigned, (uh2){ha[2], ha[3]});
+    const unsigned p2 = __builtin_bit_cast(unsigned, (uh2){hb[0], hb[1]}), p3 = __builtin_bit_cast(unsigned, (uh2){hb[2], hb[3]});
+    const f32x4 da = {uh_sub_half(a[0], p0, false), uh_sub_half(a[1], p0, true), uh_sub_half(a[2], p1, false), uh_sub_half(a[3], p1, true)};
+    const f32x4 db = {uh_sub_half(b[0], p2, false), uh_sub_half(b[1], p2, true), uh_sub_half(b[2], p3, false), uh_sub_half(b[3], p3, true)};
+    const uh4 la = __builtin_convertvector(da, uh4), lb = __builtin_convertvector(db, uh4);
+    hi = (uh8){ha[0], ha[1], ha[2], ha[3], hb[0], hb[1], hb[2], hb[3]};
+    lo = (uh8){la[0], la[1], la[2], la[3], lb[0], lb[1], lb[2], lb[3]};
+}
+
+template <int ACT>
+__device__ __forceinline__ float uh_act(float v, float alpha)
+{
+    if (ACT == 1) return fmaxf(v, 0.f);
+    if (ACT == 2) return fmaxf(v, alpha * v);                      // leaky relu, 0 <= alpha <= 1
+    if (ACT == 3) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// packing: [W1 fragments | W2 fragments] as f16, then {1/s1, 1/s2} as fp32.
+// fragment f = (chunk * tiles + tile) * 2 + (0 hi | 1 lo); element (f * 64 + lane) * 8 + i, lane = 16 q + m
+//   W1: value W1[32 chunk + 8 q + i][16 tile + m] * s1
+//   W2: value W2[32 chunk + 16 (i / 4) + 4 q + (i % 4)][16 tile + m] * s2
+// s = power of two with max |w| s in [2^13, 2^14)
+// ------------------------------------------------------------------------------------------
+__device__ float uh_block_scale(const float* __restrict__ w, int n, float* red)
+{
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(w[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = blockDim.x / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+        __syncthreads();
+    }
+    const float mx = red[0];
+    __syncthreads();
+    if (!(mx > 0.f) || !isfinite(mx)) return 1.f;
+    int ex;
+    (void)frexpf(mx, &ex);                                           // mx = f 2^ex, f in [0.5, 1)
+    ex = max(-100, min(100, ex));
+    return ldexpf(1.f, 14 - ex);
+}
+
+__global__ __launch_bounds__(256) void uh_pack_mlp_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
+                                                          _Float16* __restrict__ dst, int C)
+{
+    __shared__ float red[256];
+    const int H = 4 * C;
+    const float s1 = uh_block_scale(w1, C * H, red);
+    const float s2 = uh_block_scale(w2, C * H, red);
+    const int n = C * H;                                             // values per matrix; 2 n halves per matrix
+    for (int e = threadIdx.x; e < 2 * n; e += 256) {
+        const int i = e & 7, lane = (e >> 3) & 63, f = e >> 9;
+        const int hl = f & 1, ct = f >> 1;
+        const int q = lane >> 4, m = lane & 15;
+        {
+            const int T = H / 16, t = ct % T, c = ct / T;
+            const float v = w1[(32 * c + 8 * q + i) * H + 16 * t + m] * s1;
+            const _Float16 hi = (_Float16)v;
+            dst[e] = hl ? (_Float16)(v - (float)hi) : hi;
+        }
+        {
+            const int T = C / 16, t = ct % T, c = ct / T;
+            const float v = w2[(32 * c + 16 * (i >> 2) + 4 * q + (i & 3)) * C + 16 * t + m] * s2;
+            const _Float16 hi = (_Float16)v;
+            dst[2 * n + e] = hl ? (_Float16)(v - (float)hi) : hi;
+        }
+    }
+    if (threadIdx.x == 0) {
+        float* aux = reinterpret_cast<float*>(dst + 4 * n);
+        aux[0] = 1.f / s1;
+        aux[1] = 1.f / s2;
+        aux[2] = 0.f;
+        aux[3] = 0.f;
+    }
+}
+
+extern "C" int64_t bf_op_mlp_h3_pack_bytes(int C)
+{
+    if (C != 32 && C != 64) return -1;
+    return (int64_t)32 * C * C + 16;
+}
+
+extern "C" int bf_op_pack_mlp_h3(const float* w1, const float* w2, void* packed, int C, void* stream)
+{
+    if (!w1 || !w2 || !packed) return BF_EINVAL;
+    if (C != 32 && C != 64) return BF_EUNSUPPORTED;
+    if ((uintptr_t)packed % 16) return BF_EINVAL;
+    hipLaunchKernelGGL(uh_pack_mlp_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w1, w2, (_Float16*)packed, C);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// ------------------------------------------------------------------------------------------
+template <int C, int NP, int ACT, int NT>
+__global__ __launch_bounds__(NT, 512 / NT) void uh_mlp_kernel(const float* __restrict__ in, const float* __restrict__ skip, float* __restrict__ out,
+                                                    const void* __restrict__ packed, const float* __restrict__ mult, int64_t npix,
+                                                    float alpha)
+{
+    constexpr int KC1 = C / 32, T1 = 4 * C / 16, KC2 = 4 * C / 32, T2 = C / 16;
+    constexpr int W1_BYTES = KC1 * T1 * 2 * 1024, W2_BYTES = KC2 * T2 * 2 * 1024;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    {
+        const int4* src = reinterpret_cast<const int4*>(packed);
+        int4* dstv = reinterpret_cast<int4*>(lds);
+        for (int i = threadIdx.x; i < (W1_BYTES + W2_BYTES) / 16; i += NT) dstv[i] = src[i];
+    }
+    const float* aux = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed) + W1_BYTES + W2_BYTES);
+    const float inv1 = aux[0], inv2 = aux[1];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
+    const int64_t wave = (int64_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (NT / 64);
+    const int64_t ngroups = (npix + 16 * NP - 1) / (16 * NP);
+    // per-channel output factor mult / s2 of the lane's 4 channels of every output tile
+    f32x4 m4[T2];
+#pragma unroll
+    for (int t = 0; t < T2; ++t) {
+        m4[t] = (f32x4){inv2, inv2, inv2, inv2};
+        if (mult) m4[t] *= *reinterpret_cast<const f32x4*>(mult + 16 * t + 4 * q);
+    }
+    for (int64_t g = wave; g < ngroups; g += nwaves) {
+        const int64_t p0 = g * 16 * NP;
+        // opaque per iteration: the LDS-resident weights do not depend on g; without this hipcc hoists every fragment
+        // read out of the loop and keeps all of them in registers
+        int wl = lane * 16;
+        asm volatile("" : "+v"(wl));
+        const char* w1l = lds + wl;
+        const char* w2l = lds + W1_BYTES + wl;
+        uh8 xh[KC1][NP], xl[KC1][NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            int64_t p = p0 + 16 * i + n;
+            p = p < npix ? p : npix - 1;
+            const float* src = in + p * C + 8 * q;
+#pragma unroll
+            for (int c = 0; c < KC1; ++c)
+                uh_split8(*reinterpret_cast<const f32x4*>(src + 32 * c), *reinterpret_cast<const f32x4*>(src + 32 * c + 4), xh[c][i],
+                          xl[c][i]);
+        }
+        f32x4 acc2[T2][NP];
+#pragma unroll
+        for (int t = 0; t < T2; ++t)
+#pragma unroll
+            for (int i = 0; i < NP; ++i) acc2[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c2 = 0; c2 < KC2; ++c2) {
+            // ---- GEMM1: hidden tiles 2 c2 and 2 c2 + 1
+            f32x4 h[2][NP];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int i = 0; i < NP; ++i) h[u][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < KC1; ++c) {
+                    const int f = (c * T1 + 2 * c2 + u) * 2;
+                    const uh8 ah = *reinterpret_cast<const uh8*>(w1l + f * 1024);
+                    const uh8 al = *reinterpret_cast<const uh8*>(w1l + (f + 1) * 1024);
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) h[u][i] = UH_MFMA(ah, xh[c][i], h[u][i]);
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) h[u][i] = UH_MFMA(al, xh[c][i], h[u][i]);
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) h[u][i] = UH_MFMA(ah, xl[c][i], h[u][i]);
+                }
+            }
+            // ---- activation + split: the lane's 8 hidden values are its B fragment of chunk c2
+            uh8 bh[NP], bl[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                f32x4 v0 = bf_acc_ready(h[0][i]) * inv1, v1 = bf_acc_ready(h[1][i]) * inv1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v0[r] = uh_act<ACT>(v0[r], alpha);
+                    v1[r] = uh_act<ACT>(v1[r], alpha);
+                }
+                uh_split8(v0, v1, bh[i], bl[i]);
+            }
+            // ---- GEMM2: K chunk c2
+#pragma unroll
+            for (int t = 0; t < T2; ++t) {
+                const int f = (c2 * T2 + t) * 2;
+                const uh8 ah = *reinterpret_cast<const uh8*>(w2l + f * 1024);
+                const uh8 al = *reinterpret_cast<const uh8*>(w2l + (f + 1) * 1024);
+#pragma unroll
+                for (int i = 0; i < NP; ++i) acc2[t][i] = UH_MFMA(ah, bh[i], acc2[t][i]);
+#pragma unroll
+                for (int i = 0; i < NP; ++i) acc2[t][i] = UH_MFMA(al, bh[i], acc2[t][i]);
+#pragma unroll
+                for (int i = 0; i < NP; ++i) acc2[t][i] = UH_MFMA(ah, bl[i], acc2[t][i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int64_t p = p0 + 16 * i + n;
+            if (p >= npix) continue;
+#pragma unroll
+            for (int t = 0; t < T2; ++t) {
+                f32x4 v = bf_acc_ready(acc2[t][i]) * m4[t];
+                const int co = 16 * t + 4 * q;
+                if (skip) v += *reinterpret_cast<const f32x4*>(skip + p * C + co);
+                *reinterpret_cast<f32x4*>(out + p * C + co) = v;
+            }
+        }
+    }
+}
+
+template <int C, int NP, int NT>
+static hipError_t uh_launch(const float* in, const float* skip, float* out, const void* packed, const float* mult, int64_t npix, int act,
+                            float alpha, hipStream_t s)
+{
+    constexpr int LDS = 32 * C * C;
+    const int64_t ngroups = (npix + 16 * NP - 1) / (16 * NP);
+    const int wpb = NT / 64;
+    int64_t grid = (ngroups + wpb - 1) / wpb;
+    const int cap = LDS > 64 * 1024 ? 256 : 256 * 3;             // persistent: every workgroup loads the weights once
+    if (grid > cap) grid = cap;
+    static bool attr_done[4] = {false, false, false, false};
+#define UH_LAUNCH(A)                                                                                                          \
+    {                                                                                                                         \
+        if (!attr_done[A]) {                                                                                                  \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(uh_mlp_kernel<C, NP, A, NT>),                     \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);                              \
+            if (e != hipSuccess) return e;                                                                                    \
+            attr_done[A] = true;                                                                                              \
+        }                                                                                                                     \
+        hipLaunchKernelGGL((uh_mlp_kernel<C, NP, A, NT>), dim3((int)grid), dim3(NT), LDS, s, in, skip, out, packed, mult, npix, alpha); \
+    }
+    switch (act) {
+    case 0: UH_LAUNCH(0) break;
+    case 1: UH_LAUNCH(1) break;
+    case 2: UH_LAUNCH(2) break;
+    case 3: UH_LAUNCH(3) break;
+    default: return hipErrorInvalidValue;
+    }
+#undef UH_LAUNCH
+    return hipGetLastError();
+}
+
+extern "C" int bf_op_convnext_mlp_h3(const float* in, const float* skip, float* out, const void* packed, const float* mult,
+                                     int64_t npix, int C, int act, float alpha, void* stream)
+{
+    if (!in || !out || !packed || npix <= 0) return BF_EINVAL;
+    if (((uintptr_t)in | (uintptr_t)out | (uintptr_t)packed | (uintptr_t)mult | (uintptr_t)skip) % 16) return BF_EINVAL;
+    if (act == 2 && !(alpha >= 0.f && alpha <= 1.f)) return BF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if (C == 32) e = uh_launch<32, 4, 256>(in, skip, out, packed, mult, npix, act, alpha, s);
+    else if (C == 64) e = uh_launch<64, 2, 512>(in, skip, out, packed, mult, npix, act, alpha, s);
+    else return BF_EUNSUPPORTED;
+    if (e == hipErrorInvalidValue) return BF_EINVAL;
+    return e == hipSuccess ? BF_OK : BF_EHIP;
+}

@@ -69,6 +69,27 @@ def convnext_mlp(x: torch.Tensor, skip: Optional[torch.Tensor], w1p: torch.Tenso
     return out
 
 
+def pack_mlp_h3(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """[1,1,C,4C] and [1,1,4C,C] fp32 kernels -> split-f16 fragments of the f16x3 MLP kernel."""
+    C = int(w1.shape[-2])
+    nbytes = int(N.lib().bf_op_mlp_h3_pack_bytes(C))
+    if nbytes < 0:
+        raise NotImplementedError(f"split-f16 MLP: C={C} (32 and 64 are built)")
+    out = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
+    _call("bf_op_pack_mlp_h3", N.ptr(w1.contiguous()), N.ptr(w2.contiguous()), N.ptr(out), C, N.stream_ptr(w1))
+    return out
+
+
+def convnext_mlp_h3(x: torch.Tensor, skip: Optional[torch.Tensor], packed: torch.Tensor, mult: Optional[torch.Tensor],
+                    act: str) -> torch.Tensor:
+    C = x.shape[-1]
+    out = torch.empty_like(x)
+    code, a = _act(act)
+    _call("bf_op_convnext_mlp_h3", N.ptr(x), N.ptr(skip), N.ptr(out), N.ptr(packed), N.ptr(mult), x.numel() // C, C, code, a,
+          N.stream_ptr(x))
+    return out
+
+
 def dwconv_ln(x: torch.Tensor, w: Optional[torch.Tensor], gamma: Optional[torch.Tensor], act: str = "linear",
               eps: float = LN_EPSILON) -> torch.Tensor:
     """depthwise k x k (w [k,k,C,1] or None) -> LayerNorm(center=False) * gamma (or None) -> activation."""
@@ -157,7 +178,7 @@ class UnetLaplacianHydra:
     `trainable_variables` lists (name, shape, kind, offset)."""
 
     multi_output = True           # DenoiserModule keeps output 0
-    auto_exact_fallback = False   # exact fp32 throughout: no reduced-range arithmetic to fall back from
+    auto_exact_fallback = False
 
     class _Desc:
         def __init__(self, cin, cout):
@@ -165,6 +186,11 @@ class UnetLaplacianHydra:
 
     def check_status(self, raise_on_overflow: bool = True) -> bool:
         return True
+
+    def set_option(self, key: str, value: int):
+        if key != "arith" or int(value) not in (0, 1):
+            raise ValueError(f"unknown option {key}={value}")
+        self.arith = int(value)
 
     def __init__(self, config: Dict, device=None, seed: Optional[int] = None):
         bb, dn = config["backbone"], config["denoiser"]
@@ -230,6 +256,9 @@ class UnetLaplacianHydra:
 
         self.desc = self._Desc(self.in_channels, self.out_channels)
         self.device = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        # 1: ConvNext MLPs with 32 / 64 channels on the f16 matrix cores with split-f16 operands (csrc/unet_h3.hip);
+        # 0: every GEMM in exact fp32 (csrc/unet_ops.hip).  Same tests, same bars.
+        self.arith = 1
         self._inventory = self._build_inventory()
         self.n_params = sum(int(np.prod(s)) for _, s, _ in self._inventory)
         self.params = torch.from_numpy(self._initial_values(seed)).to(self.device)
@@ -346,6 +375,13 @@ class UnetLaplacianHydra:
                 P[name] = t.reshape(shape[0], shape[1], shape[2]).contiguous()
             else:
                 P[name] = t.contiguous()
+        for name, shape, kind, off in self.trainable_variables:
+            if name.endswith("/pw1/kernel") and shape[2] in (32, 64):
+                prefix = name[:-len("/pw1/kernel")]
+                n1, n2 = int(np.prod(shape)), int(np.prod(shape))
+                o2 = dict((v[0], v[3]) for v in self.trainable_variables)[f"{prefix}/pw2/kernel"]
+                P[f"{prefix}/mlp_h3"] = pack_mlp_h3(self.params[off:off + n1].clone().view(shape[2], shape[3]),
+                                                   self.params[o2:o2 + n2].clone().view(shape[3], shape[2]))
         if not self.use_laplacian_averaging:
             P["gauss"] = torch.from_numpy(gaussian_kernel((self.gauss_k, self.gauss_k))).to(self.device)
         self._packed = P
@@ -358,6 +394,9 @@ class UnetLaplacianHydra:
 
     def _convnext(self, P, prefix: str, x: torch.Tensor) -> torch.Tensor:
         t = dwconv_ln(x, P[f"{prefix}/dw/kernel"], P.get(f"{prefix}/ln/gamma") if self.use_ln else None)
+        mult = P.get(f"{prefix}/gamma/w") if self.use_gamma else None
+        if self.arith == 1 and f"{prefix}/mlp_h3" in P:
+            return convnext_mlp_h3(t, x, P[f"{prefix}/mlp_h3"], mult, self.activation)
         return convnext_mlp(t, x, P[f"{prefix}/pw1/kernel"], P[f"{prefix}/pw2/kernel"],
                             P.get(f"{prefix}/gamma/w") if self.use_gamma else None, self.activation)
 

@@ -205,6 +205,13 @@ int bf_op_pointwise(const float* in, float* out, const float* wp, const float* m
  * backbone_unet_laplacian.py:351-354): out = skip + mult * (act(in . w1) . w2), w1 [C][4C], w2 [4C][C] packed as above. */
 int bf_op_convnext_mlp(const float* in, const float* skip, float* out, const float* w1p, const float* w2p, const float* mult,
                        int64_t npix, int channels, int act, float alpha, void* stream);
+/* The same operator on the f16 matrix cores with split-f16 operands (hi + lo f16 pairs, three products, fp32
+ * accumulation: ~22 mantissa bits; needs |activation| < 65504): w1 [C][4C], w2 [4C][C] fp32 are packed once into
+ * bf_op_mlp_h3_pack_bytes(C) bytes; C = 32 or 64. */
+int64_t bf_op_mlp_h3_pack_bytes(int channels);
+int bf_op_pack_mlp_h3(const float* w1, const float* w2, void* packed, int channels, void* stream);
+int bf_op_convnext_mlp_h3(const float* in, const float* skip, float* out, const void* packed, const float* mult,
+                          int64_t npix, int channels, int act, float alpha, void* stream);
 /* DepthwiseConv2D k x k (SAME, zero pad; w [k][k][C]; k = 0: none) -> LayerNormalization(center=False, epsilon) * gamma
  * (ln_gamma NULL: none) -> activation   (custom_layers.py:979-988; backbone_unet_laplacian.py:355-360). */
 int bf_op_dwconv_ln(const float* in, float* out, const float* w, const float* ln_gamma, int batch, int height, int width,

@@ -58,6 +58,43 @@ def test_convnext_mlp_fused(C, npix):
     assert_close(host(got), O.conv2d_same(np.maximum(O.conv2d_same(x, w1), 0), w2), what="mlp plain")
 
 
+@pytest.mark.parametrize("C", [32, 64])
+@pytest.mark.parametrize("npix", [1, 17, 64, 129, 777, 5000])
+def test_convnext_mlp_split_f16(C, npix):
+    """the f16x3 kernel (csrc/unet_h3.hip) against the same fp64 reference and the same tolerance as the fp32 kernel."""
+    r = _rng(C + npix + 1)
+    x, skip = r.normal(size=(1, 1, npix, C)) * 1.5, r.normal(size=(1, 1, npix, C))
+    w1, w2 = r.normal(size=(1, 1, C, 4 * C)) / np.sqrt(C), r.normal(size=(1, 1, 4 * C, C)) / np.sqrt(4 * C)
+    mult = r.uniform(0.2, 1.0, C)
+    pk = UL.pack_mlp_h3(dev(w1.reshape(C, 4 * C)), dev(w2.reshape(4 * C, C)))
+    for act in ("leaky_relu_01", "gelu", "linear", "relu"):
+        ref = skip + mult * O.conv2d_same(U.act(O.conv2d_same(x, w1), act), w2)
+        got = UL.convnext_mlp_h3(dev(x), dev(skip), pk, dev(mult), act)
+        assert_close(host(got), ref, what=f"mlp h3 C={C} {act}")
+    got = UL.convnext_mlp_h3(dev(x), None, pk, None, "linear")
+    assert_close(host(got), O.conv2d_same(O.conv2d_same(x, w1), w2), what="mlp h3 plain")
+
+
+def test_convnext_mlp_split_f16_small_integers_exact_and_tiny_weights():
+    r = _rng(77)
+    C = 32
+    x = r.integers(-8, 9, size=(1, 1, 300, C)).astype(np.float64)
+    w1 = r.integers(-3, 4, size=(1, 1, C, 4 * C)).astype(np.float64)
+    w2 = r.integers(-3, 4, size=(1, 1, 4 * C, C)).astype(np.float64)
+    pk = UL.pack_mlp_h3(dev(w1.reshape(C, 4 * C)), dev(w2.reshape(4 * C, C)))
+    got = host(UL.convnext_mlp_h3(dev(x), None, pk, None, "relu"))
+    assert np.array_equal(got, O.conv2d_same(np.maximum(O.conv2d_same(x, w1), 0), w2))
+    # weights far below the f16 normal range (and large inputs): the power-of-two pre-scale keeps their lo parts exact.
+    # (the ACTIVATIONS are not rescaled: an activation below 2^-14 keeps an absolute rounding floor of 2^-25, the
+    # documented domain of the split-f16 arithmetic -- here x w1 stays O(1..100))
+    xs = x * 2048.0
+    w1s, w2s = w1 * 2.0 ** -14 * r.uniform(0.5, 1, w1.shape), w2 * 1e-7 * r.uniform(0.5, 1, w2.shape)
+    pk = UL.pack_mlp_h3(dev(w1s.reshape(C, 4 * C)), dev(w2s.reshape(4 * C, C)))
+    ref = O.conv2d_same(np.maximum(O.conv2d_same(xs, w1s), 0), w2s)
+    got = host(UL.convnext_mlp_h3(dev(xs), None, pk, None, "relu")).astype(np.float64)
+    assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("C", [32, 64, 128])
 @pytest.mark.parametrize("k", [0, 1, 3, 5])
 @pytest.mark.parametrize("shape", [(1, 1, 1), (2, 7, 9), (1, 16, 40)])
@@ -140,7 +177,7 @@ def test_channel_multiplier():
 
 # ---- whole model ---------------------------------------------------------------------------------
 
-def _model(depth=3, width=3, seed=42, **bb):
+def _model(depth=3, width=3, seed=42, arith=1, **bb):
     cfg = U.canonical_config(depth=depth, width=width)
     cfg["model"]["backbone"].update(bb)
     spec = U.UnetLaplacianSpec.from_config(cfg["model"])
@@ -148,6 +185,7 @@ def _model(depth=3, width=3, seed=42, **bb):
     m = bf.model_builder(cfg["model"], device="cuda").hydra
     assert [(v[0], tuple(v[1])) for v in m.trainable_variables] == [(n, tuple(s)) for n, s, _ in spec.tensors()]
     m.set_weights(params)
+    m.set_option("arith", arith)
     return cfg, spec, params, m
 
 
@@ -165,9 +203,10 @@ def _check_u8(got, ref):
     assert d.max() <= 1 and (d > 0).mean() < 0.01, (d.max(), (d > 0).mean())
 
 
+@pytest.mark.parametrize("arith", [1, 0], ids=["f16x3", "f32"])
 @pytest.mark.parametrize("shape", [(1, 64, 64), (2, 32, 96), (1, 128, 128)])
-def test_v5_hydra_all_scales_match_oracle(shape):
-    cfg, spec, params, m = _model()
+def test_v5_hydra_all_scales_match_oracle(shape, arith):
+    cfg, spec, params, m = _model(arith=arith)
     _, noisy = O.synthetic_batch(*shape, seed=shape[1])
     x = noisy.astype(np.float32)
     got, ref = m(x), U.hydra_forward(spec, params, x.astype(np.float64))
@@ -191,9 +230,10 @@ def test_builder_variants_match_oracle(bb):
         _check_f32(g, r)
 
 
+@pytest.mark.parametrize("arith", [1, 0], ids=["f16x3", "f32"])
 @pytest.mark.parametrize("hw", [(64, 64), (40, 50), (17, 100), (128, 128)])
-def test_denoiser_module_u8(hw):
-    cfg, spec, params, m = _model(seed=11)
+def test_denoiser_module_u8(hw, arith):
+    cfg, spec, params, m = _model(seed=11, arith=arith)
     _, noisy = O.synthetic_batch(1, hw[0], hw[1], seed=hw[0] + hw[1])
     got = bf.DenoiserModule(m)(noisy)
     assert got.shape == noisy.shape and got.dtype == np.uint8
