@@ -129,10 +129,14 @@ extern "C" int bf_op_pack_mlp_h3(const float* w1, const float* w2, void* packed,
 }
 
 // ------------------------------------------------------------------------------------------
-template <int C, int NP, int ACT, int NT>
+// PRE = 1: the whole ConvNextBlock with a 1x1 depthwise convolution (the decoder blocks, decoder_kernel_size 1): `in` is
+// the block input x; t = LayerNorm(x * dw) * gamma is formed in registers (the 4 lanes (q, n) of a pixel hold all its
+// channels: two cross-row shuffles per reduction) and never written; skip = x.
+template <int C, int NP, int ACT, int NT, int PRE>
 __global__ __launch_bounds__(NT, 512 / NT) void uh_mlp_kernel(const float* __restrict__ in, const float* __restrict__ skip, float* __restrict__ out,
                                                     const void* __restrict__ packed, const float* __restrict__ mult, int64_t npix,
-                                                    float alpha)
+                                                    float alpha, const float* __restrict__ dw, const float* __restrict__ gamma,
+                                                    float eps)
 {
     constexpr int KC1 = C / 32, T1 = 4 * C / 16, KC2 = 4 * C / 32, T2 = C / 16;
     constexpr int W1_BYTES = KC1 * T1 * 2 * 1024, W2_BYTES = KC2 * T2 * 2 * 1024;
@@ -156,6 +160,16 @@ __global__ __launch_bounds__(NT, 512 / NT) void uh_mlp_kernel(const float* __res
         m4[t] = (f32x4){inv2, inv2, inv2, inv2};
         if (mult) m4[t] *= *reinterpret_cast<const f32x4*>(mult + 16 * t + 4 * q);
     }
+    f32x4 dwv[KC1][2], gmv[KC1][2];
+    if (PRE) {
+#pragma unroll
+        for (int c = 0; c < KC1; ++c)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                dwv[c][u] = *reinterpret_cast<const f32x4*>(dw + 32 * c + 8 * q + 4 * u);
+                gmv[c][u] = gamma ? *reinterpret_cast<const f32x4*>(gamma + 32 * c + 8 * q + 4 * u) : (f32x4){1.f, 1.f, 1.f, 1.f};
+            }
+    }
     for (int64_t g = wave; g < ngroups; g += nwaves) {
         const int64_t p0 = g * 16 * NP;
         // opaque per iteration: the LDS-resident weights do not depend on g; without this hipcc hoists every fragment
@@ -170,10 +184,44 @@ __global__ __launch_bounds__(NT, 512 / NT) void uh_mlp_kernel(const float* __res
             int64_t p = p0 + 16 * i + n;
             p = p < npix ? p : npix - 1;
             const float* src = in + p * C + 8 * q;
+            if (PRE) {
+                f32x4 v[KC1][2];
+                float sum = 0.f;
 #pragma unroll
-            for (int c = 0; c < KC1; ++c)
-                uh_split8(*reinterpret_cast<const f32x4*>(src + 32 * c), *reinterpret_cast<const f32x4*>(src + 32 * c + 4), xh[c][i],
-                          xl[c][i]);
+                for (int c = 0; c < KC1; ++c)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        v[c][u] = *reinterpret_cast<const f32x4*>(src + 32 * c + 4 * u) * dwv[c][u];
+                        sum += v[c][u][0] + v[c][u][1] + v[c][u][2] + v[c][u][3];
+                    }
+                if (gamma) {
+                    sum += __shfl_xor(sum, 16, 64);
+                    sum += __shfl_xor(sum, 32, 64);
+                    const float mean = sum * (1.f / C);
+                    float sq = 0.f;
+#pragma unroll
+                    for (int c = 0; c < KC1; ++c)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            v[c][u] = v[c][u] - mean;
+                            sq += v[c][u][0] * v[c][u][0] + v[c][u][1] * v[c][u][1] + v[c][u][2] * v[c][u][2] + v[c][u][3] * v[c][u][3];
+                        }
+                    sq += __shfl_xor(sq, 16, 64);
+                    sq += __shfl_xor(sq, 32, 64);
+                    const float rs = rsqrtf(sq * (1.f / C) + eps);
+#pragma unroll
+                    for (int c = 0; c < KC1; ++c)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) v[c][u] = v[c][u] * (gmv[c][u] * rs);
+                }
+#pragma unroll
+                for (int c = 0; c < KC1; ++c) uh_split8(v[c][0], v[c][1], xh[c][i], xl[c][i]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < KC1; ++c)
+                    uh_split8(*reinterpret_cast<const f32x4*>(src + 32 * c), *reinterpret_cast<const f32x4*>(src + 32 * c + 4),
+                              xh[c][i], xl[c][i]);
+            }
         }
         f32x4 acc2[T2][NP];
 #pragma unroll
@@ -242,9 +290,9 @@ __global__ __launch_bounds__(NT, 512 / NT) void uh_mlp_kernel(const float* __res
     }
 }
 
-template <int C, int NP, int NT>
+template <int C, int NP, int NT, int PRE>
 static hipError_t uh_launch(const float* in, const float* skip, float* out, const void* packed, const float* mult, int64_t npix, int act,
-                            float alpha, hipStream_t s)
+                            float alpha, const float* dw, const float* gamma, float eps, hipStream_t s)
 {
     constexpr int LDS = 32 * C * C;
     const int64_t ngroups = (npix + 16 * NP - 1) / (16 * NP);
@@ -256,12 +304,13 @@ static hipError_t uh_launch(const float* in, const float* skip, float* out, cons
 #define UH_LAUNCH(A)                                                                                                          \
     {                                                                                                                         \
         if (!attr_done[A]) {                                                                                                  \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(uh_mlp_kernel<C, NP, A, NT>),                     \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(uh_mlp_kernel<C, NP, A, NT, PRE>),                \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS);                              \
             if (e != hipSuccess) return e;                                                                                    \
             attr_done[A] = true;                                                                                              \
         }                                                                                                                     \
-        hipLaunchKernelGGL((uh_mlp_kernel<C, NP, A, NT>), dim3((int)grid), dim3(NT), LDS, s, in, skip, out, packed, mult, npix, alpha); \
+        hipLaunchKernelGGL((uh_mlp_kernel<C, NP, A, NT, PRE>), dim3((int)grid), dim3(NT), LDS, s, in, skip, out, packed, mult, npix,   \
+                           alpha, dw, gamma, eps);                                                                            \
     }
     switch (act) {
     case 0: UH_LAUNCH(0) break;
@@ -282,8 +331,25 @@ extern "C" int bf_op_convnext_mlp_h3(const float* in, const float* skip, float* 
     if (act == 2 && !(alpha >= 0.f && alpha <= 1.f)) return BF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
-    if (C == 32) e = uh_launch<32, 4, 256>(in, skip, out, packed, mult, npix, act, alpha, s);
-    else if (C == 64) e = uh_launch<64, 2, 512>(in, skip, out, packed, mult, npix, act, alpha, s);
+    if (C == 32) e = uh_launch<32, 4, 256, 0>(in, skip, out, packed, mult, npix, act, alpha, nullptr, nullptr, 0.f, s);
+    else if (C == 64) e = uh_launch<64, 2, 512, 0>(in, skip, out, packed, mult, npix, act, alpha, nullptr, nullptr, 0.f, s);
+    else return BF_EUNSUPPORTED;
+    if (e == hipErrorInvalidValue) return BF_EINVAL;
+    return e == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// whole ConvNextBlock with a 1x1 depthwise convolution + the residual Add:
+//   out = x + mult * (act(LayerNorm(x * dw) * gamma . W1) . W2)       dw [C] (DepthwiseConv2D 1x1 kernel), gamma [C] or NULL
+extern "C" int bf_op_convnext_block1_h3(const float* x, float* out, const float* dw, const float* ln_gamma, float eps,
+                                        const void* packed, const float* mult, int64_t npix, int C, int act, float alpha, void* stream)
+{
+    if (!x || !out || !dw || !packed || npix <= 0) return BF_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)packed | (uintptr_t)mult | (uintptr_t)dw | (uintptr_t)ln_gamma) % 16) return BF_EINVAL;
+    if (act == 2 && !(alpha >= 0.f && alpha <= 1.f)) return BF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if (C == 32) e = uh_launch<32, 4, 256, 1>(x, x, out, packed, mult, npix, act, alpha, dw, ln_gamma, eps, s);
+    else if (C == 64) e = uh_launch<64, 2, 512, 1>(x, x, out, packed, mult, npix, act, alpha, dw, ln_gamma, eps, s);
     else return BF_EUNSUPPORTED;
     if (e == hipErrorInvalidValue) return BF_EINVAL;
     return e == hipSuccess ? BF_OK : BF_EHIP;

@@ -90,6 +90,17 @@ def convnext_mlp_h3(x: torch.Tensor, skip: Optional[torch.Tensor], packed: torch
     return out
 
 
+def convnext_block1_h3(x: torch.Tensor, dw: torch.Tensor, gamma: Optional[torch.Tensor], packed: torch.Tensor,
+                       mult: Optional[torch.Tensor], act: str, eps: float = LN_EPSILON) -> torch.Tensor:
+    """x + ConvNextBlock(x) for a block with a 1x1 depthwise convolution (dw [C]), one kernel."""
+    C = x.shape[-1]
+    out = torch.empty_like(x)
+    code, a = _act(act)
+    _call("bf_op_convnext_block1_h3", N.ptr(x), N.ptr(out), N.ptr(dw), N.ptr(gamma), eps, N.ptr(packed), N.ptr(mult),
+          x.numel() // C, C, code, a, N.stream_ptr(x))
+    return out
+
+
 def dwconv_ln(x: torch.Tensor, w: Optional[torch.Tensor], gamma: Optional[torch.Tensor], act: str = "linear",
               eps: float = LN_EPSILON) -> torch.Tensor:
     """depthwise k x k (w [k,k,C,1] or None) -> LayerNorm(center=False) * gamma (or None) -> activation."""
@@ -393,8 +404,12 @@ class UnetLaplacianHydra:
             raise RuntimeError("unet_laplacian inference needs the GPU: there is no CPU execution path")
 
     def _convnext(self, P, prefix: str, x: torch.Tensor) -> torch.Tensor:
-        t = dwconv_ln(x, P[f"{prefix}/dw/kernel"], P.get(f"{prefix}/ln/gamma") if self.use_ln else None)
         mult = P.get(f"{prefix}/gamma/w") if self.use_gamma else None
+        gamma = P.get(f"{prefix}/ln/gamma") if self.use_ln else None
+        dw = P[f"{prefix}/dw/kernel"]
+        if self.arith == 1 and f"{prefix}/mlp_h3" in P and dw.shape[0] == 1:
+            return convnext_block1_h3(x, dw.view(-1), gamma, P[f"{prefix}/mlp_h3"], mult, self.activation)
+        t = dwconv_ln(x, dw, gamma)
         if self.arith == 1 and f"{prefix}/mlp_h3" in P:
             return convnext_mlp_h3(t, x, P[f"{prefix}/mlp_h3"], mult, self.activation)
         return convnext_mlp(t, x, P[f"{prefix}/pw1/kernel"], P[f"{prefix}/pw2/kernel"],

@@ -212,6 +212,10 @@ int64_t bf_op_mlp_h3_pack_bytes(int channels);
 int bf_op_pack_mlp_h3(const float* w1, const float* w2, void* packed, int channels, void* stream);
 int bf_op_convnext_mlp_h3(const float* in, const float* skip, float* out, const void* packed, const float* mult,
                           int64_t npix, int channels, int act, float alpha, void* stream);
+/* A whole ConvNextBlock whose depthwise convolution is 1x1 (decoder_kernel_size 1) plus the residual Add, one kernel:
+ * out = x + mult * (act(LayerNormalization(x * dw) * ln_gamma . w1) . w2); dw [C], ln_gamma [C] or NULL. */
+int bf_op_convnext_block1_h3(const float* x, float* out, const float* dw, const float* ln_gamma, float eps, const void* packed,
+                             const float* mult, int64_t npix, int channels, int act, float alpha, void* stream);
 /* DepthwiseConv2D k x k (SAME, zero pad; w [k][k][C]; k = 0: none) -> LayerNormalization(center=False, epsilon) * gamma
  * (ln_gamma NULL: none) -> activation   (custom_layers.py:979-988; backbone_unet_laplacian.py:355-360). */
 int bf_op_dwconv_ln(const float* in, float* out, const float* w, const float* ln_gamma, int batch, int height, int width,

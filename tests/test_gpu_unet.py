@@ -75,6 +75,24 @@ def test_convnext_mlp_split_f16(C, npix):
     assert_close(host(got), O.conv2d_same(O.conv2d_same(x, w1), w2), what="mlp h3 plain")
 
 
+@pytest.mark.parametrize("C", [32, 64])
+@pytest.mark.parametrize("npix", [1, 100, 2049])
+@pytest.mark.parametrize("use_ln", [True, False])
+def test_convnext_block_with_1x1_depthwise_in_one_kernel(C, npix, use_ln):
+    r = _rng(C + npix + 2)
+    x = r.normal(size=(1, 1, npix, C)) * 2 + 0.3
+    dw, g = r.normal(size=(1, 1, C, 1)), r.uniform(0.5, 1.5, C)
+    w1, w2 = r.normal(size=(1, 1, C, 4 * C)) / np.sqrt(C), r.normal(size=(1, 1, 4 * C, C)) / np.sqrt(4 * C)
+    mult = r.uniform(0.2, 1.0, C)
+    pk = UL.pack_mlp_h3(dev(w1.reshape(C, 4 * C)), dev(w2.reshape(4 * C, C)))
+    t = U.depthwise_same(x, dw)
+    if use_ln:
+        t = U.layer_norm(t, g)
+    ref = x + mult * O.conv2d_same(U.act(O.conv2d_same(t, w1), "leaky_relu_01"), w2)
+    got = UL.convnext_block1_h3(dev(x), dev(dw.reshape(C)), dev(g) if use_ln else None, pk, dev(mult), "leaky_relu_01")
+    assert_close(host(got), ref, rel=5e-5, what="block1 h3")
+
+
 def test_convnext_mlp_split_f16_small_integers_exact_and_tiny_weights():
     r = _rng(77)
     C = 32
