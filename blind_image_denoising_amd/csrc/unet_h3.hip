@@ -170,6 +170,22 @@ __global__ __launch_bounds__(NT, 512 / NT) void uh_mlp_kernel(const float* __res
                 gmv[c][u] = gamma ? *reinterpret_cast<const f32x4*>(gamma + 32 * c + 8 * q + 4 * u) : (f32x4){1.f, 1.f, 1.f, 1.f};
             }
     }
+    // raw input of the NEXT group is requested as soon as the current one has been converted: its latency hides behind
+    // the matrix work of the current group instead of sitting in front of it
+    f32x4 xr[NP][KC1][2];
+    auto load_raw = [&](int64_t gg) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            int64_t p = gg * 16 * NP + 16 * i + n;
+            p = p < npix ? p : npix - 1;                          // tail: clamp the read, predicate the store
+            const float* src = in + p * C + 8 * q;
+#pragma unroll
+            for (int c = 0; c < KC1; ++c)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) xr[i][c][u] = *reinterpret_cast<const f32x4*>(src + 32 * c + 4 * u);
+        }
+    };
+    if (wave < ngroups) load_raw(wave);
     for (int64_t g = wave; g < ngroups; g += nwaves) {
         const int64_t p0 = g * 16 * NP;
         // opaque per iteration: the LDS-resident weights do not depend on g; without this hipcc hoists every fragment
@@ -181,9 +197,6 @@ __global__ __launch_bounds__(NT, 512 / NT) void uh_mlp_kernel(const float* __res
         uh8 xh[KC1][NP], xl[KC1][NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            int64_t p = p0 + 16 * i + n;
-            p = p < npix ? p : npix - 1;
-            const float* src = in + p * C + 8 * q;
             if (PRE) {
                 f32x4 v[KC1][2];
                 float sum = 0.f;
@@ -191,7 +204,7 @@ __global__ __launch_bounds__(NT, 512 / NT) void uh_mlp_kernel(const float* __res
                 for (int c = 0; c < KC1; ++c)
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        v[c][u] = *reinterpret_cast<const f32x4*>(src + 32 * c + 4 * u) * dwv[c][u];
+                        v[c][u] = xr[i][c][u] * dwv[c][u];
                         sum += v[c][u][0] + v[c][u][1] + v[c][u][2] + v[c][u][3];
                     }
                 if (gamma) {
@@ -218,11 +231,22 @@ __global__ __launch_bounds__(NT, 512 / NT) void uh_mlp_kernel(const float* __res
                 for (int c = 0; c < KC1; ++c) uh_split8(v[c][0], v[c][1], xh[c][i], xl[c][i]);
             } else {
 #pragma unroll
-                for (int c = 0; c < KC1; ++c)
-                    uh_split8(*reinterpret_cast<const f32x4*>(src + 32 * c), *reinterpret_cast<const f32x4*>(src + 32 * c + 4),
-                              xh[c][i], xl[c][i]);
+                for (int c = 0; c < KC1; ++c) uh_split8(xr[i][c][0], xr[i][c][1], xh[c][i], xl[c][i]);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + nwaves < ngroups) load_raw(g + nwaves);
+        f32x4 sk[T2][NP];
+        if (skip) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                int64_t p = p0 + 16 * i + n;
+                p = p < npix ? p : npix - 1;
+#pragma unroll
+                for (int t = 0; t < T2; ++t) sk[t][i] = *reinterpret_cast<const f32x4*>(skip + p * C + 16 * t + 4 * q);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 acc2[T2][NP];
 #pragma unroll
         for (int t = 0; t < T2; ++t)
@@ -283,7 +307,7 @@ __global__ __launch_bounds__(NT, 512 / NT) void uh_mlp_kernel(const float* __res
             for (int t = 0; t < T2; ++t) {
                 f32x4 v = bf_acc_ready(acc2[t][i]) * m4[t];
                 const int co = 16 * t + 4 * q;
-                if (skip) v += *reinterpret_cast<const f32x4*>(skip + p * C + co);
+                if (skip) v += sk[t][i];
                 *reinterpret_cast<f32x4*>(out + p * C + co) = v;
             }
         }
