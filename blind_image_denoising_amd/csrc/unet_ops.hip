@@ -436,18 +436,26 @@ __global__ __launch_bounds__(256) void uo_dwconv_ln_rows_kernel(const float* __r
 #pragma unroll
     for (int j = 0; j < K; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int yend = min(y0 + R, H);
+    // the k loads of input row yi + 1 are in flight while row yi is multiplied (rows outside the image load row 0 / H-1
+    // and are masked: the loop body has no divergent memory path)
+    auto load_row = [&](int yi, f32x4 (&v)[K]) {
+        const float* row = in + (img + (int64_t)min(max(yi, 0), H - 1) * W) * C;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) v[kx] = *reinterpret_cast<const f32x4*>(row + xo[kx]);
+    };
+    f32x4 vn[K];
+    load_row(y0 - RAD, vn);
     for (int yi = y0 - RAD; yi < yend + RAD; ++yi) {
-        if (yi >= 0 && yi < H) {
-            const float* row = in + (img + (int64_t)yi * W) * C;
-            f32x4 v[K];
+        f32x4 v[K];
+        const float ym = (yi >= 0 && yi < H) ? 1.f : 0.f;
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) v[kx] = *reinterpret_cast<const f32x4*>(row + xo[kx]) * xm[kx];
-            // input row yi is tap row ky of output row yi - ky + RAD = accumulator ky
+        for (int kx = 0; kx < K; ++kx) v[kx] = vn[kx] * (xm[kx] * ym);
+        load_row(yi + 1, vn);
+        // input row yi is tap row ky of output row yi - ky + RAD = accumulator ky
 #pragma unroll
-            for (int ky = 0; ky < K; ++ky)
+        for (int ky = 0; ky < K; ++ky)
 #pragma unroll
-                for (int kx = 0; kx < K; ++kx) acc[ky] += wk[ky * K + kx] * v[kx];
-        }
+            for (int kx = 0; kx < K; ++kx) acc[ky] += wk[ky * K + kx] * v[kx];
         const int yo = yi - RAD;                       // acc[K-1] is complete
         if (yo >= y0) {
             f32x4 r = acc[K - 1];
@@ -814,6 +822,142 @@ extern "C" int bf_op_head_out(const float* in, const float* w, void* out, int ou
     const int64_t n = (int64_t)B * Ho * Wo;
     hipLaunchKernelGGL(uo_head_out_kernel, dim3(uo_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, in, w, out, out_is_u8, B, H, W, Ho,
                        Wo, hf, cout, denormalize, v_min, v_max);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// ------------------------------------------------------------------------------------------
+// whole denoiser head on one feature map, one kernel (model.py:297-342 + the backbone's output LayerNorm,
+// backbone_unet_laplacian.py:547-551): [LayerNorm(x) * gamma] -> 1x1 C -> 32, activation -> 1x1 32 -> cout (<= 4) ->
+// tanh(2x) * 0.51 -> [denormalise] -> [round, uint8], cropped to [Ho,Wo].  The 32-wide hidden layer stays in the
+// accumulators: lane (q, n) holds hidden channels 16t + 4q + r of pixel n, multiplies them with its rows of the last
+// kernel and the four q-lanes of a pixel are summed with two cross-row shuffles.
+// ------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void uo_head_fused_kernel(const float* __restrict__ in, const float* __restrict__ gamma, float eps,
+                                                               const float* __restrict__ w0p, int act, float alpha,
+                                                               const float* __restrict__ w1, void* __restrict__ out, int out_is_u8,
+                                                               int B, int H, int W, int Ho, int Wo, int cout, int denormalize,
+                                                               float v_min, float v_max)
+{
+    constexpr int KC = CIN / 16, T = 2, NP = 2, HF = 32;
+    const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t npix = (int64_t)B * Ho * Wo;
+    const int64_t ngroups = (npix + 16 * NP - 1) / (16 * NP);
+    // rows 16t + 4q + r of the last kernel [HF][cout]
+    float wl[T][4][4];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) wl[t][r][o] = o < cout ? w1[(16 * t + 4 * q + r) * cout + o] : 0.f;
+    f32x4 gm[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) gm[c] = gamma ? *reinterpret_cast<const f32x4*>(gamma + 16 * c + 4 * q) : (f32x4){1.f, 1.f, 1.f, 1.f};
+    for (int64_t g = wave; g < ngroups; g += nwaves) {
+        const int64_t p0 = g * 16 * NP;
+        const float* wpo = w0p;
+        asm volatile("" : "+s"(wpo));                              // see uo_pointwise_kernel
+        const f32x4* wv = reinterpret_cast<const f32x4*>(wpo) + lane;
+        f32x4 b[NP][KC];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            int64_t p = p0 + 16 * i + n;
+            p = p < npix ? p : npix - 1;
+            const int x = (int)(p % Wo);
+            const int y = (int)((p / Wo) % Ho);
+            const int64_t bi = p / ((int64_t)Wo * Ho);
+            const float* src = in + ((bi * H + y) * W + x) * CIN + 4 * q;
+            float sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                b[i][c] = *reinterpret_cast<const f32x4*>(src + 16 * c);
+                sum += b[i][c][0] + b[i][c][1] + b[i][c][2] + b[i][c][3];
+            }
+            if (gamma) {
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                const float mean = sum * (1.f / CIN);
+                float sq = 0.f;
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    b[i][c] = b[i][c] - mean;
+                    sq += b[i][c][0] * b[i][c][0] + b[i][c][1] * b[i][c][1] + b[i][c][2] * b[i][c][2] + b[i][c][3] * b[i][c][3];
+                }
+                sq += __shfl_xor(sq, 16, 64);
+                sq += __shfl_xor(sq, 32, 64);
+                const float rs = rsqrtf(sq * (1.f / CIN) + eps);
+#pragma unroll
+                for (int c = 0; c < KC; ++c) b[i][c] = b[i][c] * (gm[c] * rs);
+            }
+        }
+        f32x4 acc[T][NP];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int i = 0; i < NP; ++i) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const f32x4 a = wv[(c * T + t) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) acc[t][i] = MFMA4(a[j], b[i][c][j], acc[t][i]);
+            }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const f32x4 hv = bf_acc_ready(acc[t][i]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float hh = uo_act_rt(hv[r], act, alpha);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] += hh * wl[t][r][k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                o[k] += __shfl_xor(o[k], 16, 64);
+                o[k] += __shfl_xor(o[k], 32, 64);
+            }
+            const int64_t p = p0 + 16 * i + n;
+            if (q == 0 && p < npix) {
+                for (int k = 0; k < cout; ++k) {
+                    float r = tanhf(2.f * o[k]) * 0.51f;
+                    if (denormalize) r = (fminf(fmaxf(r, -0.5f), 0.5f) + 0.5f) * (v_max - v_min) + v_min;
+                    if (out_is_u8) reinterpret_cast<unsigned char*>(out)[p * cout + k] = (unsigned char)fminf(fmaxf(rintf(r), 0.f), 255.f);
+                    else reinterpret_cast<float*>(out)[p * cout + k] = r;
+                }
+            }
+        }
+    }
+    (void)HF;
+}
+
+extern "C" int bf_op_head_fused(const float* in, const float* ln_gamma, float eps, const float* w0p, int act, float alpha,
+                                const float* w1, void* out, int out_is_u8, int B, int H, int W, int Ho, int Wo, int cin, int hf,
+                                int cout, int denormalize, float v_min, float v_max, void* stream)
+{
+    if (!in || !w0p || !w1 || !out || B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Ho > H || Wo > W) return BF_EINVAL;
+    if (hf != 32 || cout <= 0 || cout > 4) return BF_EUNSUPPORTED;
+    if (((uintptr_t)in | (uintptr_t)w0p | (uintptr_t)ln_gamma) % 16) return BF_EINVAL;
+    const int64_t npix = (int64_t)B * Ho * Wo;
+    const int grid = uo_grid(npix, 4 * 32, 256 * 8);
+    hipStream_t s = (hipStream_t)stream;
+#define UO_HEAD(CC)                                                                                                            \
+    hipLaunchKernelGGL((uo_head_fused_kernel<CC>), dim3(grid), dim3(256), 0, s, in, ln_gamma, eps, w0p, act, alpha, w1, out,    \
+                       out_is_u8, B, H, W, Ho, Wo, cout, denormalize, v_min, v_max)
+    if (cin == 32) UO_HEAD(32);
+    else if (cin == 64) UO_HEAD(64);
+    else if (cin == 128) UO_HEAD(128);
+    else return BF_EUNSUPPORTED;
+#undef UO_HEAD
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
 

@@ -165,6 +165,18 @@ def head_out(x: torch.Tensor, w: torch.Tensor, Ho: int, Wo: int, as_uint8: bool,
     return out
 
 
+def head_fused(x: torch.Tensor, gamma: Optional[torch.Tensor], w0p: torch.Tensor, act: str, w1: torch.Tensor, Ho: int, Wo: int,
+               as_uint8: bool, denormalize: bool, v_min: float, v_max: float, hf: int = 32, eps: float = LN_EPSILON) -> torch.Tensor:
+    """[LayerNorm * gamma] -> 1x1 C->hf + act -> 1x1 hf->cout -> tanh(2x)*0.51 -> denormalise [-> uint8], one kernel."""
+    B, H, W, C = x.shape
+    cout = int(w1.shape[-1])
+    out = torch.empty((B, Ho, Wo, cout), dtype=torch.uint8 if as_uint8 else torch.float32, device=x.device)
+    code, a = _act(act)
+    _call("bf_op_head_fused", N.ptr(x), N.ptr(gamma), eps, N.ptr(w0p), code, a, N.ptr(w1), N.ptr(out), int(as_uint8), B, H, W,
+          Ho, Wo, C, hf, cout, int(denormalize), v_min, v_max, N.stream_ptr(x))
+    return out
+
+
 def channel_multiplier(w: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(w)
     _call("bf_op_channel_multiplier", N.ptr(w), N.ptr(out), w.numel(), N.stream_ptr(w))
@@ -428,8 +440,10 @@ class UnetLaplacianHydra:
         t = resize_bilinear(t, H, W)
         return pointwise(t, P[f"{prefix}/out/kernel"], C, "linear", mult=P[f"{prefix}/gamma/w"], res=x)
 
-    def backbone(self, x: torch.Tensor, H: int, W: int) -> List[torch.Tensor]:
-        """x: [B,Hs,Ws,cin] image on the value_range scale (zero-padded to [H,W]); returns the per-scale feature maps."""
+    def backbone(self, x: torch.Tensor, H: int, W: int, defer_output_norm: bool = False) -> List[torch.Tensor]:
+        """x: [B,Hs,Ws,cin] image on the value_range scale (zero-padded to [H,W]); returns the per-scale feature maps.
+        defer_output_norm: level 0 is returned BEFORE its output LayerNorm (nothing else in the graph reads that
+        normalised map -- the deeper ones feed the decoder above them -- so the fused head kernel applies it)."""
         P = self._pack()
         step = 2 ** (self.depth - 1)
         if H % step or W % step:
@@ -462,12 +476,20 @@ class UnetLaplacianHydra:
                 f = pointwise(f, P[f"mix{d}/kernel"], self.level_filters(d), a)
             for w in range(self.width):
                 f = self._convnext(P, f"dec{d}_{w}", f)
-            if self.use_output_normalization and self.use_ln:
+            if self.use_output_normalization and self.use_ln and not (defer_output_norm and d == 0):
                 f = dwconv_ln(f, None, P[f"dec{d}/out_ln/gamma"])
             outs[d] = f
         return [outs[d] for d in range(self.depth)]
 
-    def _head(self, P, i: int, f: torch.Tensor, Ho: int, Wo: int, as_uint8: bool) -> torch.Tensor:
+    def _head(self, P, i: int, f: torch.Tensor, Ho: int, Wo: int, as_uint8: bool, deferred_norm: bool = False) -> torch.Tensor:
+        gamma = None
+        if deferred_norm and i == 0 and self.depth > 1 and self.use_output_normalization and self.use_ln:
+            gamma = P[f"dec{i}/out_ln/gamma"]
+        if self.head_filters == 32:
+            return head_fused(f, gamma, P[f"head{i}/conv0/kernel"], self.head_activation, P[f"head{i}/conv1/kernel"], Ho, Wo,
+                              as_uint8, True, self.v_min, self.v_max)
+        if gamma is not None:
+            f = dwconv_ln(f, None, gamma)
         h = pointwise(f, P[f"head{i}/conv0/kernel"], self.head_filters, self.head_activation)
         return head_out(h, P[f"head{i}/conv1/kernel"], Ho, Wo, as_uint8, True, self.v_min, self.v_max)
 
@@ -490,8 +512,8 @@ class UnetLaplacianHydra:
         B, H, W, _ = x.shape
         P = self._pack()
         outs = []
-        for i, f in enumerate(self.backbone(x, H, W)):
-            outs.append(self._head(P, i, f, f.shape[1], f.shape[2], False))
+        for i, f in enumerate(self.backbone(x, H, W, defer_output_norm=True)):
+            outs.append(self._head(P, i, f, f.shape[1], f.shape[2], False, deferred_norm=True))
         if was_numpy:
             torch.cuda.synchronize(self.device)
             return [o.cpu().numpy() for o in outs]
@@ -508,5 +530,5 @@ class UnetLaplacianHydra:
         B, Hs, Ws, _ = image.shape
         H, W = next_power_of_2(Hs), next_power_of_2(Ws)
         P = self._pack()
-        f = self.backbone(image, H, W)[0]
-        return self._head(P, 0, f, Hs, Ws, cast_to_uint8)
+        f = self.backbone(image, H, W, defer_output_norm=True)[0]
+        return self._head(P, 0, f, Hs, Ws, cast_to_uint8, deferred_norm=True)

@@ -241,6 +241,12 @@ int bf_op_first_conv(const void* in, int in_is_u8, float* out, const float* w, i
  * (model.py:321-342, 136-139; module_denoiser.py:62-73). */
 int bf_op_head_out(const float* in, const float* w, void* out, int out_is_u8, int batch, int height, int width, int out_height,
                    int out_width, int head_filters, int cout, int denormalize, float v_min, float v_max, void* stream);
+/* A whole denoiser head in one kernel: [LayerNormalization(in) * ln_gamma (the backbone's output normalisation,
+ * backbone_unet_laplacian.py:547-551; NULL: none)] -> Conv2D 1x1 cin -> 32 (w0p packed by bf_op_pack_pointwise) ->
+ * activation -> Conv2D 1x1 32 -> cout (w1 [32][cout]) -> tanh(2x)*0.51 [-> denormalise][-> round, uint8], cropped. */
+int bf_op_head_fused(const float* in, const float* ln_gamma, float eps, const float* w0p, int act, float alpha, const float* w1,
+                     void* out, int out_is_u8, int batch, int height, int width, int out_height, int out_width, int cin,
+                     int head_filters, int cout, int denormalize, float v_min, float v_max, void* stream);
 /* mult[c] = tanh(relu(1 + w[c])) (ChannelLearnableMultiplier, custom_layers.py:304-306). */
 int bf_op_channel_multiplier(const float* w, float* mult, int n, void* stream);
 

@@ -188,6 +188,23 @@ def test_head_out_f32_u8_and_crop():
     assert got.dtype == np.uint8 and np.abs(got.astype(int) - want).max() <= 1 and (got != want).mean() < 0.01
 
 
+@pytest.mark.parametrize("C", [32, 64, 128])
+@pytest.mark.parametrize("use_ln", [True, False])
+def test_head_fused_layernorm_two_convs_tanh(C, use_ln):
+    r = _rng(C + 12)
+    x = r.normal(size=(2, 9, 11, C)) * 2 + 0.2
+    g = r.uniform(0.5, 1.5, C)
+    w0, w1 = r.normal(size=(1, 1, C, 32)) / np.sqrt(C), r.normal(size=(1, 1, 32, 3)) * 0.3
+    t = U.layer_norm(x, g) if use_ln else x
+    ref = O.layer_denormalize(np.tanh(2 * O.conv2d_same(U.act(O.conv2d_same(t, w0), "leaky_relu_01"), w1)) * 0.51, 0.0, 255.0)
+    w0p = UL.pack_pointwise(dev(w0))
+    got = UL.head_fused(dev(x), dev(g) if use_ln else None, w0p, "leaky_relu_01", dev(w1), 9, 11, False, True, 0.0, 255.0)
+    assert_close(host(got), ref, rel=3e-5 * 255 / max(1.0, np.abs(ref).max()), what="fused head f32")
+    got = host(UL.head_fused(dev(x), dev(g) if use_ln else None, w0p, "leaky_relu_01", dev(w1), 6, 7, True, True, 0.0, 255.0))
+    want = np.clip(np.rint(ref[:, :6, :7]), 0, 255)
+    assert got.dtype == np.uint8 and np.abs(got.astype(int) - want).max() <= 1 and (got != want).mean() < 0.02
+
+
 def test_channel_multiplier():
     w = np.linspace(-2.0, 1.0, 64)
     assert_close(host(UL.channel_multiplier(dev(w))), np.tanh(np.maximum(1 + w, 0)), what="multiplier")
