@@ -545,6 +545,117 @@ __global__ __launch_bounds__(256) void uo_smooth_split_kernel(const float* __res
     }
 }
 
+// Column-walking form with the level's output normalisation fused in front (backbone_unet_laplacian.py:355-386):
+//   y = act(LayerNorm(in) * gamma)  (gamma NULL: y = act(in));  smooth = AveragePooling2D / GaussianFilter k x k of y;
+//   lap = y - smooth;  down = smooth[:, ::2, ::2, :].
+// y is never written: every thread normalises the k pixels of the input row it loads (C/4 lanes per pixel, DPP
+// reductions) and adds them to k rotating accumulators, as uo_dwconv_ln_rows_kernel does.
+template <int C, int K, int R>
+__global__ __launch_bounds__(256) void uo_norm_smooth_split_rows_kernel(const float* __restrict__ in, const float* __restrict__ gamma,
+                                                                        float eps, int act, float alpha, const float* __restrict__ gauss,
+                                                                        float* __restrict__ lap, float* __restrict__ down, int H, int W)
+{
+    constexpr int LPP = C / 4, PPB = 256 / LPP, RAD = K / 2;
+    const int cl = threadIdx.x % LPP, pl = threadIdx.x / LPP;
+    const int c0 = 4 * cl;
+    const int x = blockIdx.x * PPB + pl;
+    const bool xlive = x < W;
+    const int y0 = blockIdx.y * R;
+    const int64_t img = (int64_t)blockIdx.z * H * W;
+    const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+    f32x4 gm = {1.f, 1.f, 1.f, 1.f};
+    if (gamma) gm = *reinterpret_cast<const f32x4*>(gamma + c0);
+    float g[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) g[i] = gauss ? gauss[i] : 1.f;
+    int xo[K];
+    float xm[K];
+    int cntx = 0;
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+        const int xx = x + kx - RAD;
+        const bool ok = xx >= 0 && xx < W;
+        xm[kx] = ok ? 1.f : 0.f;
+        cntx += ok ? 1 : 0;
+        xo[kx] = min(max(xx, 0), W - 1) * C + c0;
+    }
+    f32x4 acc[K], ctr[RAD + 1];
+#pragma unroll
+    for (int j = 0; j < K; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j <= RAD; ++j) ctr[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int yend = min(y0 + R, H);
+    auto load_row = [&](int yi, f32x4 (&v)[K]) {
+        const float* row = in + (img + (int64_t)min(max(yi, 0), H - 1) * W) * C;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) v[kx] = *reinterpret_cast<const f32x4*>(row + xo[kx]);
+    };
+    f32x4 vn[K];
+    load_row(y0 - RAD, vn);
+    for (int yi = y0 - RAD; yi < yend + RAD; ++yi) {
+        f32x4 v[K];
+        const float ym = (yi >= 0 && yi < H) ? 1.f : 0.f;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            f32x4 t = vn[kx];
+            if (gamma) {
+                const float mean = uo_pixel_sum<LPP>(t[0] + t[1] + t[2] + t[3]) * (1.f / C);
+                const f32x4 d = t - mean;
+                const float var = uo_pixel_sum<LPP>(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / C);
+                t = d * (gm * rsqrtf(var + eps));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = uo_act_rt(t[j], act, alpha);
+            v[kx] = t * (xm[kx] * ym);
+        }
+        load_row(yi + 1, vn);
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) acc[ky] += g[ky * K + kx] * v[kx];
+        // centre pixel of output row yi: needed RAD rows later
+#pragma unroll
+        for (int j = RAD; j > 0; --j) ctr[j] = ctr[j - 1];
+        ctr[0] = v[RAD];
+        const int yo = yi - RAD;
+        if (yo >= y0) {
+            f32x4 sm = acc[K - 1];
+            if (!gauss) {
+                const int cnty = min(yo + RAD, H - 1) - max(yo - RAD, 0) + 1;
+                sm = sm / (float)(cntx * cnty);
+            }
+            if (xlive) {
+                *reinterpret_cast<f32x4*>(lap + ((img + (int64_t)yo * W) + x) * C + c0) = ctr[RAD] - sm;
+                if (!((x | yo) & 1))
+                    *reinterpret_cast<f32x4*>(down + (((int64_t)blockIdx.z * OH + (yo >> 1)) * OW + (x >> 1)) * C + c0) = sm;
+            }
+        }
+#pragma unroll
+        for (int j = K - 1; j > 0; --j) acc[j] = acc[j - 1];
+        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+extern "C" int bf_op_norm_smooth_split(const float* in, const float* ln_gamma, float eps, int act, float alpha, const float* gauss,
+                                       float* lap, float* down, int B, int H, int W, int C, int k, void* stream)
+{
+    if (!in || !lap || !down || B <= 0 || H <= 0 || W <= 0) return BF_EINVAL;
+    if (((uintptr_t)in | (uintptr_t)lap | (uintptr_t)down | (uintptr_t)ln_gamma) % 16) return BF_EINVAL;
+    constexpr int RROWS = 16;
+    if (B > 65535 || (H + RROWS - 1) / RROWS > 65535) return BF_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+#define UO_NS(CC, KK)                                                                                                          \
+    if (C == CC && k == KK) {                                                                                                  \
+        constexpr int PPB = 256 / (CC / 4);                                                                                    \
+        hipLaunchKernelGGL((uo_norm_smooth_split_rows_kernel<CC, KK, RROWS>), dim3((W + PPB - 1) / PPB, (H + RROWS - 1) / RROWS, B), \
+                           dim3(256), 0, s, in, ln_gamma, eps, act, alpha, gauss, lap, down, H, W);                            \
+        return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;                                                               \
+    }
+    UO_NS(32, 3) UO_NS(64, 3) UO_NS(128, 3) UO_NS(32, 5) UO_NS(64, 5) UO_NS(128, 5)
+#undef UO_NS
+    return BF_EUNSUPPORTED;
+}
+
 extern "C" int bf_op_smooth_split(const float* in, float* lap, float* down, const float* gauss, int B, int H, int W, int C, int k,
                                   void* stream)
 {

@@ -121,6 +121,18 @@ def smooth_split(x: torch.Tensor, k: int, gauss: Optional[torch.Tensor] = None) 
     return lap, down
 
 
+def norm_smooth_split(x: torch.Tensor, gamma: Optional[torch.Tensor], act: str, k: int, gauss: Optional[torch.Tensor] = None,
+                      eps: float = LN_EPSILON) -> Tuple[torch.Tensor, torch.Tensor]:
+    """y = act(LayerNorm(x) * gamma) -> (y - smooth(y), smooth(y)[:, ::2, ::2, :]) in one kernel."""
+    B, H, W, C = x.shape
+    lap = torch.empty_like(x)
+    down = torch.empty((B, (H + 1) // 2, (W + 1) // 2, C), dtype=torch.float32, device=x.device)
+    code, a = _act(act)
+    _call("bf_op_norm_smooth_split", N.ptr(x), N.ptr(gamma), eps, code, a, N.ptr(gauss), N.ptr(lap), N.ptr(down), B, H, W, C, k,
+          N.stream_ptr(x))
+    return lap, down
+
+
 def upsample_act_add(x: torch.Tensor, other: Optional[torch.Tensor], act: str = "linear") -> torch.Tensor:
     B, H, W, C = x.shape
     out = torch.empty((B, 2 * H, 2 * W, C), dtype=torch.float32, device=x.device)
@@ -456,12 +468,17 @@ class UnetLaplacianHydra:
             for w in range(self.width):
                 f = self._attention(P, f"enc{d}_{w}", f) if self._is_attention(d) else self._convnext(P, f"enc{d}_{w}", f)
             gamma = P[f"enc{d}/out_ln/gamma"] if (self.use_output_normalization and self.use_ln) else None
-            f = dwconv_ln(f, None, gamma, a)
-            nodes[d] = f
             if d != self.depth - 1:
-                lap, down = smooth_split(f, self.gauss_k, None if self.use_laplacian_averaging else P["gauss"])
+                gauss = None if self.use_laplacian_averaging else P["gauss"]
+                if self.gauss_k in (3, 5):       # output LayerNorm + activation + Laplacian split in one kernel
+                    lap, down = norm_smooth_split(f, gamma, a, self.gauss_k, gauss)
+                else:
+                    lap, down = smooth_split(dwconv_ln(f, None, gamma, a), self.gauss_k, gauss)
                 nodes[d] = lap
                 f = pointwise(down, P[f"down{d}/kernel"], self.level_filters(d + 1), a)
+            else:
+                f = dwconv_ln(f, None, gamma, a)
+                nodes[d] = f
         outs = {self.depth - 1: nodes[self.depth - 1]}
         for d in reversed(range(self.depth - 1)):
             low = outs[d + 1]

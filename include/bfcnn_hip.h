@@ -224,6 +224,11 @@ int bf_op_dwconv_ln(const float* in, float* out, const float* w, const float* ln
  * with gauss [k][k], GaussianFilter; lap = in - smooth; down = smooth[:, ::2, ::2, :] (downsampling.py:61). */
 int bf_op_smooth_split(const float* in, float* lap, float* down, const float* gauss, int batch, int height, int width,
                        int channels, int k, void* stream);
+/* The same split with the level's output normalisation in front, one kernel (backbone_unet_laplacian.py:355-386):
+ * y = act(LayerNormalization(in) * ln_gamma) (ln_gamma NULL: y = act(in)) is never written; lap = y - smooth(y),
+ * down = smooth(y)[:, ::2, ::2, :]; k = 3 or 5. */
+int bf_op_norm_smooth_split(const float* in, const float* ln_gamma, float eps, int act, float alpha, const float* gauss,
+                            float* lap, float* down, int batch, int height, int width, int channels, int k, void* stream);
 /* out = other + act(UpSampling2D(2, "bilinear")(in)) (upsampling.py:80-102 + the decoder Add). */
 int bf_op_upsample_act_add(const float* in, const float* other, float* out, int batch, int height, int width, int channels,
                            int act, float alpha, void* stream);

@@ -144,6 +144,25 @@ def test_smooth_split_average_and_gaussian(shape):
     assert_close(host(down), smooth[:, ::2, ::2], what="down gauss")
 
 
+@pytest.mark.parametrize("shape", [(1, 2, 2, 32), (2, 8, 12, 32), (1, 17, 35, 64), (1, 6, 10, 128), (1, 40, 33, 32)])
+@pytest.mark.parametrize("k", [3, 5])
+def test_norm_smooth_split_fused(shape, k):
+    r = _rng(13 + k)
+    x, g = r.normal(size=shape) * 2 + 0.4, r.uniform(0.5, 1.5, shape[-1])
+    for use_ln in (True, False):
+        y = U.act(U.layer_norm(x, g) if use_ln else x, "leaky_relu_01")
+        smooth = O.avg_pool_same(y, (k, k), 1)
+        lap, down = UL.norm_smooth_split(dev(x), dev(g) if use_ln else None, "leaky_relu_01", k)
+        assert_close(host(lap), y - smooth, rel=5e-5, what="lap")
+        assert_close(host(down), smooth[:, ::2, ::2], rel=5e-5, what="down")
+    gk = U.gaussian_kernel_3((k, k))
+    y = U.act(U.layer_norm(x, g), "leaky_relu_01")
+    smooth = U.depthwise_same(y, np.repeat(gk[:, :, None, None], shape[-1], axis=2))
+    lap, down = UL.norm_smooth_split(dev(x), dev(g), "leaky_relu_01", k, dev(gk))
+    assert_close(host(lap), y - smooth, rel=5e-5, what="lap gauss")
+    assert_close(host(down), smooth[:, ::2, ::2], rel=5e-5, what="down gauss")
+
+
 @pytest.mark.parametrize("shape,out", [((1, 128, 128, 32), (16, 16)), ((2, 16, 16, 32), (128, 128)), ((1, 20, 36, 64), (16, 16)),
                                        ((1, 16, 16, 32), (20, 36)), ((1, 4, 4, 128), (16, 16)), ((1, 16, 16, 32), (16, 16))])
 def test_resize_bilinear(shape, out):
