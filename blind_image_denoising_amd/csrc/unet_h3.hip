@@ -44,6 +44,20 @@ __device__ __forceinline__ void uh_split8(const f32x4 a, const f32x4 b, uh8& hi,
     lo = (uh8){la[0], la[1], la[2], la[3], lb[0], lb[1], lb[2], lb[3]};
 }
 
+// sum over the 8 consecutive lanes of a pixel in the depthwise layout (DPP butterfly: quad_perm xor 1, xor 2, half-row mirror)
+template <int CTRL>
+__device__ __forceinline__ float uh_dpp_add(float v)
+{
+    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true);
+    return v + __builtin_bit_cast(float, t);
+}
+__device__ __forceinline__ float uh_pixel_sum8(float v)
+{
+    v = uh_dpp_add<0xB1>(v);
+    v = uh_dpp_add<0x4E>(v);
+    return uh_dpp_add<0x141>(v);
+}
+
 template <int ACT>
 __device__ __forceinline__ float uh_act(float v, float alpha)
 {
@@ -129,6 +143,66 @@ extern "C" int bf_op_pack_mlp_h3(const float* w1, const float* w2, void* packed,
 }
 
 // ------------------------------------------------------------------------------------------
+// the two GEMMs of the MLP on one wave's NP groups of 16 pixels: xh / xl = split B fragments of the input (K chunk c of 32
+// channels), w1l / w2l = the lane's byte address inside the LDS fragment arrays, acc2 = C / 16 output tiles
+template <int C, int NP, int ACT>
+__device__ __forceinline__ void uh_mlp_core(const uh8 (&xh)[C / 32][NP], const uh8 (&xl)[C / 32][NP], const char* w1l, const char* w2l,
+                                            const float inv1, const float alpha, f32x4 (&acc2)[C / 16][NP])
+{
+    constexpr int KC1 = C / 32, T1 = 4 * C / 16, KC2 = 4 * C / 32, T2 = C / 16;
+#pragma unroll
+    for (int t = 0; t < T2; ++t)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) acc2[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c2 = 0; c2 < KC2; ++c2) {
+        // ---- GEMM1: hidden tiles 2 c2 and 2 c2 + 1
+        f32x4 h[2][NP];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) h[u][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < KC1; ++c) {
+                const int f = (c * T1 + 2 * c2 + u) * 2;
+                const uh8 ah = *reinterpret_cast<const uh8*>(w1l + f * 1024);
+                const uh8 al = *reinterpret_cast<const uh8*>(w1l + (f + 1) * 1024);
+#pragma unroll
+                for (int i = 0; i < NP; ++i) h[u][i] = UH_MFMA(ah, xh[c][i], h[u][i]);
+#pragma unroll
+                for (int i = 0; i < NP; ++i) h[u][i] = UH_MFMA(al, xh[c][i], h[u][i]);
+#pragma unroll
+                for (int i = 0; i < NP; ++i) h[u][i] = UH_MFMA(ah, xl[c][i], h[u][i]);
+            }
+        }
+        // ---- activation + split: the lane's 8 hidden values are its B fragment of chunk c2
+        uh8 bh[NP], bl[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            f32x4 v0 = bf_acc_ready(h[0][i]) * inv1, v1 = bf_acc_ready(h[1][i]) * inv1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v0[r] = uh_act<ACT>(v0[r], alpha);
+                v1[r] = uh_act<ACT>(v1[r], alpha);
+            }
+            uh_split8(v0, v1, bh[i], bl[i]);
+        }
+        // ---- GEMM2: K chunk c2
+#pragma unroll
+        for (int t = 0; t < T2; ++t) {
+            const int f = (c2 * T2 + t) * 2;
+            const uh8 ah = *reinterpret_cast<const uh8*>(w2l + f * 1024);
+            const uh8 al = *reinterpret_cast<const uh8*>(w2l + (f + 1) * 1024);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) acc2[t][i] = UH_MFMA(ah, bh[i], acc2[t][i]);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) acc2[t][i] = UH_MFMA(al, bh[i], acc2[t][i]);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) acc2[t][i] = UH_MFMA(ah, bl[i], acc2[t][i]);
+        }
+    }
+}
+
 // PRE = 1: the whole ConvNextBlock with a 1x1 depthwise convolution (the decoder blocks, decoder_kernel_size 1): `in` is
 // the block input x; t = LayerNorm(x * dw) * gamma is formed in registers (the 4 lanes (q, n) of a pixel hold all its
 // channels: two cross-row shuffles per reduction) and never written; skip = x.
@@ -248,57 +322,7 @@ __global__ __launch_bounds__(NT, 512 / NT) void uh_mlp_kernel(const float* __res
         }
         __builtin_amdgcn_sched_barrier(0);
         f32x4 acc2[T2][NP];
-#pragma unroll
-        for (int t = 0; t < T2; ++t)
-#pragma unroll
-            for (int i = 0; i < NP; ++i) acc2[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c2 = 0; c2 < KC2; ++c2) {
-            // ---- GEMM1: hidden tiles 2 c2 and 2 c2 + 1
-            f32x4 h[2][NP];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-#pragma unroll
-                for (int i = 0; i < NP; ++i) h[u][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int c = 0; c < KC1; ++c) {
-                    const int f = (c * T1 + 2 * c2 + u) * 2;
-                    const uh8 ah = *reinterpret_cast<const uh8*>(w1l + f * 1024);
-                    const uh8 al = *reinterpret_cast<const uh8*>(w1l + (f + 1) * 1024);
-#pragma unroll
-                    for (int i = 0; i < NP; ++i) h[u][i] = UH_MFMA(ah, xh[c][i], h[u][i]);
-#pragma unroll
-                    for (int i = 0; i < NP; ++i) h[u][i] = UH_MFMA(al, xh[c][i], h[u][i]);
-#pragma unroll
-                    for (int i = 0; i < NP; ++i) h[u][i] = UH_MFMA(ah, xl[c][i], h[u][i]);
-                }
-            }
-            // ---- activation + split: the lane's 8 hidden values are its B fragment of chunk c2
-            uh8 bh[NP], bl[NP];
-#pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                f32x4 v0 = bf_acc_ready(h[0][i]) * inv1, v1 = bf_acc_ready(h[1][i]) * inv1;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v0[r] = uh_act<ACT>(v0[r], alpha);
-                    v1[r] = uh_act<ACT>(v1[r], alpha);
-                }
-                uh_split8(v0, v1, bh[i], bl[i]);
-            }
-            // ---- GEMM2: K chunk c2
-#pragma unroll
-            for (int t = 0; t < T2; ++t) {
-                const int f = (c2 * T2 + t) * 2;
-                const uh8 ah = *reinterpret_cast<const uh8*>(w2l + f * 1024);
-                const uh8 al = *reinterpret_cast<const uh8*>(w2l + (f + 1) * 1024);
-#pragma unroll
-                for (int i = 0; i < NP; ++i) acc2[t][i] = UH_MFMA(ah, bh[i], acc2[t][i]);
-#pragma unroll
-                for (int i = 0; i < NP; ++i) acc2[t][i] = UH_MFMA(al, bh[i], acc2[t][i]);
-#pragma unroll
-                for (int i = 0; i < NP; ++i) acc2[t][i] = UH_MFMA(ah, bl[i], acc2[t][i]);
-            }
-        }
+        uh_mlp_core<C, NP, ACT>(xh, xl, w1l, w2l, inv1, alpha, acc2);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int64_t p = p0 + 16 * i + n;
@@ -377,4 +401,185 @@ extern "C" int bf_op_convnext_block1_h3(const float* x, float* out, const float*
     else return BF_EUNSUPPORTED;
     if (e == hipErrorInvalidValue) return BF_EINVAL;
     return e == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// ------------------------------------------------------------------------------------------
+// Whole ENCODER ConvNextBlock (k x k depthwise, 32 channels) + residual Add in one kernel:
+//   out = x + mult * (act(LayerNorm(dw_kxk(x)) * gamma . W1) . W2)
+// A wave owns an 8-pixel-wide column strip and walks down it as uo_dwconv_ln_rows_kernel does (4 channels per lane,
+// 8 lanes per pixel, k rotating accumulators, DPP LayerNorm).  Every 8 finished rows (64 pixels) are handed over through a
+// wave-private LDS buffer to the matrix-core layout (lane (q, n): channels 8q..8q+7 of pixel n; a 16-pixel group = 2 rows
+// x 8 columns) and go through the split-f16 MLP; the skip comes from the rows just read (cache hits).  The LayerNorm
+// output and the hidden layer never reach HBM: x is read once (+ halo), out written once.
+// ------------------------------------------------------------------------------------------
+constexpr int UH_ENC_ROWS = 16;        // rows per tile
+constexpr int UH_STG_PITCH = 36;       // floats per staged pixel (32 + 4: the 16 lanes of a fragment read spread over the banks)
+template <int K, int ACT>
+__global__ __launch_bounds__(256, 2) void uh_enc32_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                          const float* __restrict__ dww, const float* __restrict__ gamma, float eps,
+                                                          const void* __restrict__ packed, const float* __restrict__ mult, int B, int H,
+                                                          int W, float alpha)
+{
+    constexpr int C = 32, NP = 4, RAD = K / 2, T2 = 2, RB = 8;
+    constexpr int W_BYTES = 32 * C * C;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    {
+        const int4* src = reinterpret_cast<const int4*>(packed);
+        int4* dstv = reinterpret_cast<int4*>(lds);
+        for (int i = threadIdx.x; i < W_BYTES / 16; i += 256) dstv[i] = src[i];
+    }
+    const float* aux = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed) + W_BYTES);
+    const float inv1 = aux[0], inv2 = aux[1];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, n = lane & 15;            // matrix-core layout
+    const int cl = lane & 7, pl = lane >> 3;           // depthwise layout: channels 4cl..4cl+3 of strip column pl
+    float* stg = reinterpret_cast<float*>(lds + W_BYTES) + wave * (RB * 8 * UH_STG_PITCH);
+    f32x4 m4[T2];
+#pragma unroll
+    for (int t = 0; t < T2; ++t) {
+        m4[t] = (f32x4){inv2, inv2, inv2, inv2};
+        if (mult) m4[t] *= *reinterpret_cast<const f32x4*>(mult + 16 * t + 4 * q);
+    }
+    f32x4 gm = {1.f, 1.f, 1.f, 1.f};
+    if (gamma) gm = *reinterpret_cast<const f32x4*>(gamma + 4 * cl);
+    const int tiles_x = (W + 31) / 32, tiles_y = (H + UH_ENC_ROWS - 1) / UH_ENC_ROWS;
+    const int64_t ntiles = (int64_t)B * tiles_y * tiles_x;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = (int)(tile % tiles_x);
+        const int ty = (int)((tile / tiles_x) % tiles_y);
+        const int64_t img = (tile / ((int64_t)tiles_x * tiles_y)) * H * W;
+        const int x0 = tx * 32 + wave * 8, y0 = ty * UH_ENC_ROWS;
+        if (x0 >= W) continue;                           // wave-uniform; no workgroup barrier inside the tile loop
+        // ---- depthwise column walk state
+        const int xd = x0 + pl;
+        int xo[K];
+        float xm[K];
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            const int xx = xd + kx - RAD;
+            xm[kx] = (xx >= 0 && xx < W) ? 1.f : 0.f;
+            xo[kx] = min(max(xx, 0), W - 1) * C + 4 * cl;
+        }
+        auto load_row = [&](int yi, f32x4 (&v)[K]) {
+            const float* row = x + (img + (int64_t)min(max(yi, 0), H - 1) * W) * C;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) v[kx] = *reinterpret_cast<const f32x4*>(row + xo[kx]);
+        };
+        f32x4 acc[K], vn[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        load_row(y0 - RAD, vn);
+        int yi = y0 - RAD;
+        for (int batch = 0; batch < UH_ENC_ROWS / RB; ++batch) {
+            const int yb = y0 + batch * RB;              // first output row of the batch
+            if (yb >= H) break;
+            {
+                // depthwise weights: reloaded per batch (opaque pointer) so that they are not live across the matrix phase
+                const float* wp = dww;
+                asm volatile("" : "+s"(wp));
+                f32x4 wk[K * K];
+#pragma unroll
+                for (int i = 0; i < K * K; ++i) wk[i] = *reinterpret_cast<const f32x4*>(wp + i * C + 4 * cl);
+                for (; yi < yb + RB + RAD; ++yi) {
+                    f32x4 v[K];
+                    const float ym = (yi >= 0 && yi < H) ? 1.f : 0.f;
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) v[kx] = vn[kx] * (xm[kx] * ym);
+                    load_row(yi + 1, vn);
+#pragma unroll
+                    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < K; ++kx) acc[ky] += wk[ky * K + kx] * v[kx];
+                    const int yo = yi - RAD;
+                    if (yo >= yb) {
+                        f32x4 r = acc[K - 1];
+                        if (gamma) {
+                            const float mean = uh_pixel_sum8(r[0] + r[1] + r[2] + r[3]) * (1.f / C);
+                            const f32x4 d = r - mean;
+                            const float var = uh_pixel_sum8(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / C);
+                            r = d * (gm * rsqrtf(var + eps));
+                        }
+                        *reinterpret_cast<f32x4*>(stg + ((yo - yb) * 8 + pl) * UH_STG_PITCH + 4 * cl) = r;
+                    }
+#pragma unroll
+                    for (int j = K - 1; j > 0; --j) acc[j] = acc[j - 1];
+                    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            // ---- hand-over inside the wave: the staged rows are read by other lanes than wrote them
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            int wl = lane * 16;
+            asm volatile("" : "+v"(wl));
+            const char* w1l = lds + wl;
+            const char* w2l = lds + 16 * C * C + wl;
+            uh8 xh[1][NP], xl[1][NP];
+            f32x4 sk[T2][NP];
+            int64_t pix[NP];
+            bool ok[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int s = 16 * i + n;                 // staged pixel: row 2i + n / 8, column n % 8
+                const float* sp = stg + s * UH_STG_PITCH + 8 * q;
+                uh_split8(*reinterpret_cast<const f32x4*>(sp), *reinterpret_cast<const f32x4*>(sp + 4), xh[0][i], xl[0][i]);
+                const int py = yb + 2 * i + (n >> 3), px = x0 + (n & 7);
+                ok[i] = py < H && px < W;
+                pix[i] = img + (int64_t)min(py, H - 1) * W + min(px, W - 1);
+#pragma unroll
+                for (int t = 0; t < T2; ++t) sk[t][i] = *reinterpret_cast<const f32x4*>(x + pix[i] * C + 16 * t + 4 * q);
+            }
+            f32x4 acc2[T2][NP];
+            uh_mlp_core<C, NP, ACT>(xh, xl, w1l, w2l, inv1, alpha, acc2);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                if (!ok[i]) continue;
+#pragma unroll
+                for (int t = 0; t < T2; ++t)
+                    *reinterpret_cast<f32x4*>(out + pix[i] * C + 16 * t + 4 * q) = bf_acc_ready(acc2[t][i]) * m4[t] + sk[t][i];
+            }
+            // the next batch overwrites the staging buffer
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+extern "C" int bf_op_convnext_block_h3(const float* x, float* out, const float* dw, int k, const float* ln_gamma, float eps,
+                                       const void* packed, const float* mult, int B, int H, int W, int C, int act, float alpha,
+                                       void* stream)
+{
+    if (!x || !out || !dw || !packed || B <= 0 || H <= 0 || W <= 0) return BF_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)packed | (uintptr_t)mult | (uintptr_t)dw | (uintptr_t)ln_gamma) % 16) return BF_EINVAL;
+    if (act == 2 && !(alpha >= 0.f && alpha <= 1.f)) return BF_EINVAL;
+    if (C != 32 || (k != 3 && k != 5) || act < 0 || act > 3) return BF_EUNSUPPORTED;
+    if (x == out) return BF_EINVAL;                      // neighbouring strips read the halo of this one
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int LDS = 32 * 32 * 32 + 4 * 8 * 8 * UH_STG_PITCH * 4;
+    const int64_t ntiles = (int64_t)B * ((H + UH_ENC_ROWS - 1) / UH_ENC_ROWS) * ((W + 31) / 32);
+    const int grid = (int)(ntiles < 512 ? ntiles : 512);
+    static bool attr_done[2][4] = {};
+#define UH_ENC(KK, A)                                                                                                          \
+    {                                                                                                                          \
+        if (!attr_done[KK == 5][A]) {                                                                                          \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(uh_enc32_kernel<KK, A>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    LDS) != hipSuccess)                                                                        \
+                return BF_EHIP;                                                                                                \
+            attr_done[KK == 5][A] = true;                                                                                      \
+        }                                                                                                                      \
+        hipLaunchKernelGGL((uh_enc32_kernel<KK, A>), dim3(grid), dim3(256), LDS, s, x, out, dw, ln_gamma, eps, packed, mult, B, H, W, \
+                           alpha);                                                                                             \
+    }
+#define UH_ENC_K(KK)                                                                                                           \
+    switch (act) {                                                                                                             \
+    case 0: UH_ENC(KK, 0) break;                                                                                               \
+    case 1: UH_ENC(KK, 1) break;                                                                                               \
+    case 2: UH_ENC(KK, 2) break;                                                                                               \
+    default: UH_ENC(KK, 3) break;                                                                                              \
+    }
+    if (k == 5) { UH_ENC_K(5) } else { UH_ENC_K(3) }
+#undef UH_ENC_K
+#undef UH_ENC
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }

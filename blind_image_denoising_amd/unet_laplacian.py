@@ -101,6 +101,17 @@ def convnext_block1_h3(x: torch.Tensor, dw: torch.Tensor, gamma: Optional[torch.
     return out
 
 
+def convnext_block_h3(x: torch.Tensor, dw: torch.Tensor, gamma: Optional[torch.Tensor], packed: torch.Tensor,
+                      mult: Optional[torch.Tensor], act: str, eps: float = LN_EPSILON) -> torch.Tensor:
+    """x + ConvNextBlock(x) for a 32-channel block with a k x k depthwise convolution (dw [k,k,C], k = 3 | 5), one kernel."""
+    B, H, W, C = x.shape
+    out = torch.empty_like(x)
+    code, a = _act(act)
+    _call("bf_op_convnext_block_h3", N.ptr(x), N.ptr(out), N.ptr(dw), int(dw.shape[0]), N.ptr(gamma), eps, N.ptr(packed),
+          N.ptr(mult), B, H, W, C, code, a, N.stream_ptr(x))
+    return out
+
+
 def dwconv_ln(x: torch.Tensor, w: Optional[torch.Tensor], gamma: Optional[torch.Tensor], act: str = "linear",
               eps: float = LN_EPSILON) -> torch.Tensor:
     """depthwise k x k (w [k,k,C,1] or None) -> LayerNorm(center=False) * gamma (or None) -> activation."""
@@ -433,6 +444,8 @@ class UnetLaplacianHydra:
         dw = P[f"{prefix}/dw/kernel"]
         if self.arith == 1 and f"{prefix}/mlp_h3" in P and dw.shape[0] == 1:
             return convnext_block1_h3(x, dw.view(-1), gamma, P[f"{prefix}/mlp_h3"], mult, self.activation)
+        if self.arith == 1 and f"{prefix}/mlp_h3" in P and dw.shape[0] in (3, 5) and x.shape[-1] == 32:
+            return convnext_block_h3(x, dw, gamma, P[f"{prefix}/mlp_h3"], mult, self.activation)
         t = dwconv_ln(x, dw, gamma)
         if self.arith == 1 and f"{prefix}/mlp_h3" in P:
             return convnext_mlp_h3(t, x, P[f"{prefix}/mlp_h3"], mult, self.activation)

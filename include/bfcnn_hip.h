@@ -216,6 +216,12 @@ int bf_op_convnext_mlp_h3(const float* in, const float* skip, float* out, const 
  * out = x + mult * (act(LayerNormalization(x * dw) * ln_gamma . w1) . w2); dw [C], ln_gamma [C] or NULL. */
 int bf_op_convnext_block1_h3(const float* x, float* out, const float* dw, const float* ln_gamma, float eps, const void* packed,
                              const float* mult, int64_t npix, int channels, int act, float alpha, void* stream);
+/* A whole encoder ConvNextBlock (k x k depthwise, k = 3 or 5, 32 channels) plus the residual Add, one kernel
+ * (custom_layers.py:975-1008; backbone_unet_laplacian.py:336-354):
+ * out = x + mult * (act(LayerNormalization(DepthwiseConv2D_kxk(x)) * ln_gamma . w1) . w2); dw [k][k][C]; out != x. */
+int bf_op_convnext_block_h3(const float* x, float* out, const float* dw, int k, const float* ln_gamma, float eps,
+                            const void* packed, const float* mult, int batch, int height, int width, int channels, int act,
+                            float alpha, void* stream);
 /* DepthwiseConv2D k x k (SAME, zero pad; w [k][k][C]; k = 0: none) -> LayerNormalization(center=False, epsilon) * gamma
  * (ln_gamma NULL: none) -> activation   (custom_layers.py:979-988; backbone_unet_laplacian.py:355-360). */
 int bf_op_dwconv_ln(const float* in, float* out, const float* w, const float* ln_gamma, int batch, int height, int width,

@@ -93,6 +93,25 @@ def test_convnext_block_with_1x1_depthwise_in_one_kernel(C, npix, use_ln):
     assert_close(host(got), ref, rel=5e-5, what="block1 h3")
 
 
+@pytest.mark.parametrize("k", [3, 5])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (1, 16, 32), (2, 20, 37), (1, 7, 70), (1, 64, 64), (1, 33, 8)])
+@pytest.mark.parametrize("use_ln", [True, False])
+def test_encoder_convnext_block_in_one_kernel(k, shape, use_ln):
+    C = 32
+    r = _rng(k + shape[1] + shape[2])
+    x = r.normal(size=shape + (C,)) * 2 + 0.3
+    dw, g = r.normal(size=(k, k, C, 1)) * 0.3, r.uniform(0.5, 1.5, C)
+    w1, w2 = r.normal(size=(1, 1, C, 4 * C)) / np.sqrt(C), r.normal(size=(1, 1, 4 * C, C)) / np.sqrt(4 * C)
+    mult = r.uniform(0.2, 1.0, C)
+    pk = UL.pack_mlp_h3(dev(w1.reshape(C, 4 * C)), dev(w2.reshape(4 * C, C)))
+    t = U.depthwise_same(x, dw)
+    if use_ln:
+        t = U.layer_norm(t, g)
+    ref = x + mult * O.conv2d_same(U.act(O.conv2d_same(t, w1), "leaky_relu_01"), w2)
+    got = UL.convnext_block_h3(dev(x), dev(dw.reshape(k, k, C)), dev(g) if use_ln else None, pk, dev(mult), "leaky_relu_01")
+    assert_close(host(got), ref, rel=5e-5, what="encoder block h3")
+
+
 def test_convnext_mlp_split_f16_small_integers_exact_and_tiny_weights():
     r = _rng(77)
     C = 32
