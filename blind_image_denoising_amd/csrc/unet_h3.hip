@@ -379,7 +379,7 @@ extern "C" int bf_op_convnext_mlp_h3(const float* in, const float* skip, float* 
     if (act == 2 && !(alpha >= 0.f && alpha <= 1.f)) return BF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
-    if (C == 32) e = uh_launch<32, 4, 256, 0>(in, skip, out, packed, mult, npix, act, alpha, nullptr, nullptr, 0.f, s);
+    if (C == 32) e = uh_launch<32, 2, 256, 0>(in, skip, out, packed, mult, npix, act, alpha, nullptr, nullptr, 0.f, s);
     else if (C == 64) e = uh_launch<64, 2, 512, 0>(in, skip, out, packed, mult, npix, act, alpha, nullptr, nullptr, 0.f, s);
     else return BF_EUNSUPPORTED;
     if (e == hipErrorInvalidValue) return BF_EINVAL;
@@ -396,7 +396,7 @@ extern "C" int bf_op_convnext_block1_h3(const float* x, float* out, const float*
     if (act == 2 && !(alpha >= 0.f && alpha <= 1.f)) return BF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
-    if (C == 32) e = uh_launch<32, 4, 256, 1>(x, x, out, packed, mult, npix, act, alpha, dw, ln_gamma, eps, s);
+    if (C == 32) e = uh_launch<32, 2, 256, 1>(x, x, out, packed, mult, npix, act, alpha, dw, ln_gamma, eps, s);
     else if (C == 64) e = uh_launch<64, 2, 512, 1>(x, x, out, packed, mult, npix, act, alpha, dw, ln_gamma, eps, s);
     else return BF_EUNSUPPORTED;
     if (e == hipErrorInvalidValue) return BF_EINVAL;

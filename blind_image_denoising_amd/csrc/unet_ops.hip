@@ -747,11 +747,12 @@ extern "C" int bf_op_resize_bilinear(const float* in, float* out, int B, int H, 
 
 // ------------------------------------------------------------------------------------------
 // keras.layers.Attention(use_scale=False, score_mode="dot"): out = softmax(q k^T) v per image; q, k, v [B][T][A],
-// A = 32.  One workgroup = up to 256 queries of one image (one per thread, online softmax); K and V of the image sit in LDS
+// A = 32.  One workgroup = 64 queries of one image (one per thread, online softmax); K and V of the image sit in LDS
 // and every key / value row is an LDS broadcast.  (256 tokens x 32 channels per image: 8 MFLOP, negligible.)
 // ------------------------------------------------------------------------------------------
 constexpr int UO_ATT_A = 32;
-__global__ __launch_bounds__(256) void uo_attention_kernel(const float* __restrict__ q, const float* __restrict__ v,
+constexpr int UO_ATT_THREADS = 64;     // queries per workgroup: 256 tokens x 32 images alone would fill 32 of the 256 CUs
+__global__ __launch_bounds__(UO_ATT_THREADS) void uo_attention_kernel(const float* __restrict__ q, const float* __restrict__ v,
                                                            const float* __restrict__ k, float* __restrict__ out, int T)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -760,12 +761,12 @@ __global__ __launch_bounds__(256) void uo_attention_kernel(const float* __restri
     const int b = blockIdx.y;
     const float* kb = k + (int64_t)b * T * UO_ATT_A;
     const float* vb = v + (int64_t)b * T * UO_ATT_A;
-    for (int i = threadIdx.x; i < T * UO_ATT_A / 4; i += 256) {
+    for (int i = threadIdx.x; i < T * UO_ATT_A / 4; i += UO_ATT_THREADS) {
         reinterpret_cast<f32x4*>(ks)[i] = reinterpret_cast<const f32x4*>(kb)[i];
         reinterpret_cast<f32x4*>(vs)[i] = reinterpret_cast<const f32x4*>(vb)[i];
     }
     __syncthreads();
-    const int row = blockIdx.x * 256 + threadIdx.x;
+    const int row = blockIdx.x * UO_ATT_THREADS + threadIdx.x;
     if (row >= T) return;
     float qr[UO_ATT_A], acc[UO_ATT_A];
     const float* qp = q + ((int64_t)b * T + row) * UO_ATT_A;
@@ -808,7 +809,8 @@ extern "C" int bf_op_attention(const float* q, const float* v, const float* k, f
             return BF_EHIP;
         attr_done = true;
     }
-    hipLaunchKernelGGL(uo_attention_kernel, dim3((T + 255) / 256, B), dim3(256), lds, (hipStream_t)stream, q, v, k, out, T);
+    hipLaunchKernelGGL(uo_attention_kernel, dim3((T + UO_ATT_THREADS - 1) / UO_ATT_THREADS, B), dim3(UO_ATT_THREADS), lds,
+                       (hipStream_t)stream, q, v, k, out, T);
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
 
@@ -816,7 +818,9 @@ extern "C" int bf_op_attention(const float* q, const float* v, const float* k, f
 // first convolution: k x k, Cin (<= 4) -> COUT on the normalised image, SAME zero padding, activation.
 // The source image [B,Hs,Ws,cin] (u8 or f32, 0..255) is virtually zero-padded to [H,W] BEFORE normalisation
 // (pad_to_power_of_2, utilities.py:736-751: padded pixels normalise to -0.5); outside [H,W] the convolution pads with 0.
-// thread = one pixel, all output channels; weights broadcast from LDS.
+// thread = one pixel, all output channels; weights broadcast from LDS.  (A matrix-core form -- K = 75 patch elements
+// gathered per lane with byte loads, 19 fp32 MFMA steps -- measured 1.66 ms against 1.09 ms for this kernel on
+// [32,512,512,3] uint8: the 64-address byte gathers cost more than the MFMAs save.)
 // ------------------------------------------------------------------------------------------
 template <int COUT>
 __global__ __launch_bounds__(256) void uo_first_conv_kernel(const void* __restrict__ in, int in_is_u8, float* __restrict__ out,

@@ -325,6 +325,19 @@ def test_midgrey_fixed_point_and_determinism():
     assert np.array_equal(a, mod(noisy)) and np.array_equal(a[1:2], mod(noisy[1:2]))
 
 
+def test_full_size_config_512_batch_properties_and_256_oracle():
+    """BASELINE.json configs[4] sizes: a 256x256 image against the oracle (the fp64 NumPy oracle needs minutes for 512x512),
+    and at 512x512 the size-independent properties: determinism and batch independence."""
+    cfg, spec, params, m = _model(seed=21)
+    mod = bf.DenoiserModule(m)
+    _, noisy = O.synthetic_batch(1, 256, 256, seed=9)
+    _check_u8(mod(noisy), U.denoiser_module_call(spec, params, noisy))
+    _, big = O.synthetic_batch(3, 512, 512, seed=10)
+    full = mod(big)
+    assert full.shape == big.shape and np.array_equal(full, mod(big))
+    assert np.array_equal(full[2:3], mod(big[2:3]))
+
+
 def test_shape_and_config_errors():
     cfg, spec, params, m = _model(seed=2)
     with pytest.raises(ValueError, match="multiples of 4"):
