@@ -183,6 +183,148 @@ extern "C" int bf_op_pointwise(const float* in, float* out, const float* wp, con
 }
 
 // ------------------------------------------------------------------------------------------
+// Conv2D kh x kw, stride s, padding="same" (TF pad split: extra at the bottom / right), use_bias=False, Cin -> Cout with
+// Cin, Cout in {32, 64, 128}: implicit GEMM over the taps with the 1x1 machinery above (the 2x2 stride-2 "conv2d"
+// downsample, downsampling.py:45-55; the 3x3 convolutions behind upsample_bilinear_conv2d / upsample_nearest_conv2d,
+// upsampling.py:52-72).  wp = the taps' [Cin][Cout] matrices, each packed by bf_op_pack_pointwise, tap-major.
+// ------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int NP, int ACT>
+__global__ __launch_bounds__(256, 2) void uo_conv2d_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                        const float* __restrict__ wp, const float* __restrict__ res, int B, int H,
+                                                        int W, int OH, int OW, int kh, int kw, int stride, int pt, int pl, float alpha)
+{
+    constexpr int KC = CIN / 16, T = COUT / 16;
+    const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t npix = (int64_t)B * OH * OW;
+    const int64_t ngroups = (npix + 16 * NP - 1) / (16 * NP);
+    for (int64_t g = wave; g < ngroups; g += nwaves) {
+        const int64_t p0 = g * 16 * NP;
+        int oy[NP], ox[NP];
+        int64_t ib[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            int64_t p = p0 + 16 * i + n;
+            p = p < npix ? p : npix - 1;
+            ox[i] = (int)(p % OW);
+            oy[i] = (int)((p / OW) % OH);
+            ib[i] = (p / ((int64_t)OW * OH)) * H * W;
+        }
+        f32x4 acc[T][NP];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int i = 0; i < NP; ++i) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int tap = 0; tap < kh * kw; ++tap) {
+            const int ky = tap / kw, kx = tap - ky * kw;
+            const float* wpo = wp + (int64_t)tap * CIN * COUT;
+            asm volatile("" : "+s"(wpo));                          // see uo_pointwise_kernel
+            const f32x4* wv = reinterpret_cast<const f32x4*>(wpo) + lane;
+            const float* src[NP];
+            float ok[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int yy = oy[i] * stride + ky - pt, xx = ox[i] * stride + kx - pl;
+                ok[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? 1.f : 0.f;
+                src[i] = in + (ib[i] + (int64_t)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)) * CIN + 4 * q;
+            }
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                f32x4 b[NP];
+#pragma unroll
+                for (int i = 0; i < NP; ++i) b[i] = *reinterpret_cast<const f32x4*>(src[i] + 16 * c) * ok[i];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const f32x4 a = wv[(c * T + t) * 64];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int i = 0; i < NP; ++i) acc[t][i] = MFMA4(a[j], b[i][j], acc[t][i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int64_t p = p0 + 16 * i + n;
+            if (p >= npix) continue;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                f32x4 v = bf_acc_ready(acc[t][i]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = uo_act<ACT>(v[r], alpha);
+                if (res) v += *reinterpret_cast<const f32x4*>(res + p * COUT + 16 * t + 4 * q);
+                *reinterpret_cast<f32x4*>(out + p * COUT + 16 * t + 4 * q) = v;
+            }
+        }
+    }
+}
+
+extern "C" int bf_op_conv2d(const float* in, float* out, const float* wp, const float* res, int B, int H, int W, int cin, int cout,
+                            int kh, int kw, int stride, int act, float alpha, void* stream)
+{
+    if (!in || !out || !wp || B <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return BF_EINVAL;
+    if (((uintptr_t)in | (uintptr_t)out | (uintptr_t)wp | (uintptr_t)res) % 16) return BF_EINVAL;
+    if (act < 0 || act > 3) return BF_EUNSUPPORTED;
+    const int OH = (H + stride - 1) / stride, OW = (W + stride - 1) / stride;
+    const int th = max((OH - 1) * stride + kh - H, 0), tw = max((OW - 1) * stride + kw - W, 0);
+    const int pt = th / 2, pl = tw / 2;
+    const int64_t npix = (int64_t)B * OH * OW;
+    hipStream_t s = (hipStream_t)stream;
+    bool ok = false;
+#define UO_CV_A(CI, CO, NPP, A)                                                                                                \
+    hipLaunchKernelGGL((uo_conv2d_kernel<CI, CO, NPP, A>), dim3(uo_grid(npix, 4 * 16 * NPP, 256 * 8)), dim3(256), 0, s, in, out, wp, res, B,  \
+                       H, W, OH, OW, kh, kw, stride, pt, pl, alpha)
+#define UO_CV(CI, CO, NPP)                                                                                                     \
+    if (cin == CI && cout == CO) {                                                                                             \
+        ok = true;                                                                                                             \
+        switch (act) {                                                                                                         \
+        case 0: UO_CV_A(CI, CO, NPP, 0); break;                                                                                \
+        case 1: UO_CV_A(CI, CO, NPP, 1); break;                                                                                \
+        case 2: UO_CV_A(CI, CO, NPP, 2); break;                                                                                \
+        default: UO_CV_A(CI, CO, NPP, 3); break;                                                                               \
+        }                                                                                                                      \
+    }
+    UO_CV(32, 32, 4) UO_CV(32, 64, 4) UO_CV(64, 32, 4) UO_CV(64, 64, 4) UO_CV(64, 128, 2) UO_CV(128, 64, 4) UO_CV(128, 128, 2)
+#undef UO_CV
+#undef UO_CV_A
+    if (!ok) return BF_EUNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// MaxPooling2D(pool 2x2, strides 2, padding="same") (downsampling.py:56-58): out-of-image taps are ignored
+__global__ __launch_bounds__(256) void uo_maxpool2_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C)
+{
+    const int Cv = C / 4, OH = (H + 1) / 2, OW = (W + 1) / 2;
+    const int64_t n = (int64_t)B * OH * OW * Cv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % Cv);
+        int64_t t = i / Cv;
+        const int ox = (int)(t % OW); t /= OW;
+        const int oy = (int)(t % OH);
+        const int b = (int)(t / OH);
+        const f32x4* img = reinterpret_cast<const f32x4*>(in) + (int64_t)b * H * W * Cv + c;
+        const int y1 = min(2 * oy + 1, H - 1), x1 = min(2 * ox + 1, W - 1);      // a clamped tap repeats an in-image one
+        const f32x4 v00 = img[((int64_t)2 * oy * W + 2 * ox) * Cv], v01 = img[((int64_t)2 * oy * W + x1) * Cv];
+        const f32x4 v10 = img[((int64_t)y1 * W + 2 * ox) * Cv], v11 = img[((int64_t)y1 * W + x1) * Cv];
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = fmaxf(fmaxf(v00[j], v01[j]), fmaxf(v10[j], v11[j]));
+        reinterpret_cast<f32x4*>(out)[i] = r;
+    }
+}
+
+extern "C" int bf_op_maxpool2(const float* in, float* out, int B, int H, int W, int C, void* stream)
+{
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4) return BF_EINVAL;
+    if (((uintptr_t)in | (uintptr_t)out) % 16) return BF_EINVAL;
+    const int64_t n = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+    hipLaunchKernelGGL(uo_maxpool2_kernel, dim3(uo_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, C);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// ------------------------------------------------------------------------------------------
 // ConvNext MLP in one kernel: out = skip + mult * (act(in . w1) . w2)     in: [npix][C] (LayerNorm output), w1 [C][4C],
 // w2 [4C][C] (both packed by bf_op_pack_pointwise)
 // ------------------------------------------------------------------------------------------
@@ -513,7 +655,7 @@ extern "C" int bf_op_dwconv_ln(const float* in, float* out, const float* w, cons
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void uo_smooth_split_kernel(const float* __restrict__ in, float* __restrict__ lap,
                                                               float* __restrict__ down, const float* __restrict__ gauss, int B, int H,
-                                                              int W, int C, int k)
+                                                              int W, int C, int k, int down_stride)
 {
     const int Cv = C / 4, OH = (H + 1) / 2, OW = (W + 1) / 2, R = k / 2;
     const int64_t n = (int64_t)B * H * W * Cv;
@@ -541,7 +683,8 @@ __global__ __launch_bounds__(256) void uo_smooth_split_kernel(const float* __res
         if (!gauss) acc = acc / (float)cnt;
         const f32x4 ctr = img[((int64_t)y * W + x) * Cv];
         reinterpret_cast<f32x4*>(lap)[i] = ctr - acc;
-        if (!((x | y) & 1)) reinterpret_cast<f32x4*>(down)[(((int64_t)b * OH + (y >> 1)) * OW + (x >> 1)) * Cv + c] = acc;
+        if (down_stride == 1) reinterpret_cast<f32x4*>(down)[i] = acc;
+        else if (!((x | y) & 1)) reinterpret_cast<f32x4*>(down)[(((int64_t)b * OH + (y >> 1)) * OW + (x >> 1)) * Cv + c] = acc;
     }
 }
 
@@ -657,13 +800,14 @@ extern "C" int bf_op_norm_smooth_split(const float* in, const float* ln_gamma, f
 }
 
 extern "C" int bf_op_smooth_split(const float* in, float* lap, float* down, const float* gauss, int B, int H, int W, int C, int k,
-                                  void* stream)
+                                  int down_stride, void* stream)
 {
     if (!in || !lap || !down || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || k <= 0 || !(k & 1)) return BF_EINVAL;
+    if (down_stride != 1 && down_stride != 2) return BF_EINVAL;
     if (((uintptr_t)in | (uintptr_t)lap | (uintptr_t)down) % 16) return BF_EINVAL;
     const int64_t n = (int64_t)B * H * W * (C / 4);
     hipLaunchKernelGGL(uo_smooth_split_kernel, dim3(uo_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, in, lap, down, gauss, B, H, W,
-                       C, k);
+                       C, k, down_stride);
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
 

@@ -123,13 +123,38 @@ def dwconv_ln(x: torch.Tensor, w: Optional[torch.Tensor], gamma: Optional[torch.
     return out
 
 
-def smooth_split(x: torch.Tensor, k: int, gauss: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(x - smooth(x), smooth(x)[:, ::2, ::2, :])."""
+def smooth_split(x: torch.Tensor, k: int, gauss: Optional[torch.Tensor] = None, down_stride: int = 2
+                 ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(x - smooth(x), smooth(x)[:, ::2, ::2, :]) or, with down_stride 1, (x - smooth(x), smooth(x))."""
     B, H, W, C = x.shape
     lap = torch.empty_like(x)
-    down = torch.empty((B, (H + 1) // 2, (W + 1) // 2, C), dtype=torch.float32, device=x.device)
-    _call("bf_op_smooth_split", N.ptr(x), N.ptr(lap), N.ptr(down), N.ptr(gauss), B, H, W, C, k, N.stream_ptr(x))
+    down = torch.empty_like(x) if down_stride == 1 else \
+        torch.empty((B, (H + 1) // 2, (W + 1) // 2, C), dtype=torch.float32, device=x.device)
+    _call("bf_op_smooth_split", N.ptr(x), N.ptr(lap), N.ptr(down), N.ptr(gauss), B, H, W, C, k, down_stride, N.stream_ptr(x))
     return lap, down
+
+
+def pack_conv(w: torch.Tensor) -> torch.Tensor:
+    """[kh,kw,cin,cout] kernel -> tap-major matrix-core operand order."""
+    kh, kw, cin, cout = w.shape
+    return torch.cat([pack_pointwise(w[i, j].contiguous()) for i in range(kh) for j in range(kw)])
+
+
+def conv2d(x: torch.Tensor, wp: torch.Tensor, cout: int, k: int, stride: int = 1, act: str = "linear",
+           res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Conv2D k x k, strides, padding="same", no bias (+ activation, + res)."""
+    B, H, W, cin = x.shape
+    out = torch.empty((B, -(-H // stride), -(-W // stride), cout), dtype=torch.float32, device=x.device)
+    code, a = _act(act)
+    _call("bf_op_conv2d", N.ptr(x), N.ptr(out), N.ptr(wp), N.ptr(res), B, H, W, cin, cout, k, k, stride, code, a, N.stream_ptr(x))
+    return out
+
+
+def maxpool2(x: torch.Tensor) -> torch.Tensor:
+    B, H, W, C = x.shape
+    out = torch.empty((B, (H + 1) // 2, (W + 1) // 2, C), dtype=torch.float32, device=x.device)
+    _call("bf_op_maxpool2", N.ptr(x), N.ptr(out), B, H, W, C, N.stream_ptr(x))
+    return out
 
 
 def norm_smooth_split(x: torch.Tensor, gamma: Optional[torch.Tensor], act: str, k: int, gauss: Optional[torch.Tensor] = None,
@@ -247,8 +272,9 @@ class UnetLaplacianHydra:
             default = True if key in ("use_concat", "multiple_scale_outputs") else False
             if bb.get(key, default) != want:
                 raise NotImplementedError(f"unet_laplacian: {key}={bb.get(key, default)} is outside the built graph")
-        if bb.get("downsample_type", "strides").strip().lower() != "strides":
-            raise NotImplementedError("unet_laplacian: downsample_type must be 'strides'")
+        self.downsample_type = bb.get("downsample_type", "strides").strip().lower()
+        if self.downsample_type not in ("strides", "conv2d", "maxpool"):
+            raise ValueError(f"don't know how to handle [{self.downsample_type}]")          # downsampling.py:73-75
         if dn.get("use_bn", False) or dn.get("use_ln", False) or dn.get("use_bias", False):
             raise NotImplementedError("denoiser head: use_bn / use_ln / use_bias are outside the built graph")
         self.depth = int(bb.get("depth", 5))
@@ -273,8 +299,11 @@ class UnetLaplacianHydra:
         self.activation = (bb.get("activation", "leaky_relu_01") or "leaky_relu_01").strip().lower()
         _act(self.activation)
         self.upsample_type = bb.get("upsample_type", "bilinear").strip().lower()
-        if self.upsample_type not in ("upsample_laplacian_conv2d", "bilinear"):
-            raise NotImplementedError(f"unet_laplacian: upsample_type [{self.upsample_type}]")
+        if self.upsample_type == "conv2d_transpose":
+            raise NotImplementedError("unet_laplacian: upsample_type conv2d_transpose is not built")
+        if self.upsample_type not in ("upsample_laplacian_conv2d", "upsample_bilinear_conv2d", "upsample_nearest_conv2d",
+                                      "bilinear", "nn", "nearest"):
+            raise ValueError(f"don't know how to handle [{self.upsample_type}]")             # upsampling.py:118-120
         self.use_ln = bool(bb.get("use_ln", True))
         self.use_gamma = bool(bb.get("use_gamma", True))
         self.use_laplacian = bool(bb.get("use_laplacian", True))
@@ -346,11 +375,14 @@ class UnetLaplacianHydra:
             if self.use_output_normalization and self.use_ln:
                 out.append((f"enc{d}/out_ln/gamma", (C,), "ln_gamma"))
             if d != self.depth - 1:
-                out.append((f"down{d}/kernel", (1, 1, C, self.level_filters(d + 1)), "conv"))
+                kd = 2 if self.downsample_type == "conv2d" else 1
+                out.append((f"down{d}/kernel", (kd, kd, C, self.level_filters(d + 1)), "conv"))
         for d in reversed(range(self.depth - 1)):
             C = self.level_filters(d)
             if self.upsample_type == "upsample_laplacian_conv2d":
                 out.append((f"up{d}/kernel", (1, 1, self.level_filters(d + 1), C), "conv"))
+            elif self.upsample_type in ("upsample_bilinear_conv2d", "upsample_nearest_conv2d"):
+                out.append((f"up{d}/kernel", (3, 3, self.level_filters(d + 1), C), "conv"))
             if self.use_mix_project:
                 out.append((f"mix{d}/kernel", (1, 1, C, C), "conv"))
             for w in range(self.width):
@@ -415,6 +447,8 @@ class UnetLaplacianHydra:
             t = t.view(shape)
             if kind == "conv" and shape[0] == 1 and shape[2] % 16 == 0 and shape[3] % 16 == 0:
                 P[name] = pack_pointwise(t)
+            elif kind == "conv" and shape[0] > 1 and shape[2] % 16 == 0 and shape[3] % 16 == 0:
+                P[name] = pack_conv(t)
             elif kind == "multiplier":
                 P[name] = channel_multiplier(t)
             elif kind == "depthwise":
@@ -483,12 +517,20 @@ class UnetLaplacianHydra:
             gamma = P[f"enc{d}/out_ln/gamma"] if (self.use_output_normalization and self.use_ln) else None
             if d != self.depth - 1:
                 gauss = None if self.use_laplacian_averaging else P["gauss"]
-                if self.gauss_k in (3, 5):       # output LayerNorm + activation + Laplacian split in one kernel
-                    lap, down = norm_smooth_split(f, gamma, a, self.gauss_k, gauss)
+                Cn = self.level_filters(d + 1)
+                if self.downsample_type == "strides":                     # downsampling.py:60-72
+                    if self.gauss_k in (3, 5):   # output LayerNorm + activation + Laplacian split in one kernel
+                        lap, down = norm_smooth_split(f, gamma, a, self.gauss_k, gauss)
+                    else:
+                        lap, down = smooth_split(dwconv_ln(f, None, gamma, a), self.gauss_k, gauss)
+                    f = pointwise(down, P[f"down{d}/kernel"], Cn, a)
                 else:
-                    lap, down = smooth_split(dwconv_ln(f, None, gamma, a), self.gauss_k, gauss)
+                    lap, smooth = smooth_split(dwconv_ln(f, None, gamma, a), self.gauss_k, gauss, down_stride=1)
+                    if self.downsample_type == "conv2d":                   # 2x2 stride 2 (:45-55)
+                        f = conv2d(smooth, P[f"down{d}/kernel"], Cn, 2, 2, a)
+                    else:                                                   # maxpool + 1x1 (:56-68)
+                        f = pointwise(maxpool2(smooth), P[f"down{d}/kernel"], Cn, a)
                 nodes[d] = lap
-                f = pointwise(down, P[f"down{d}/kernel"], self.level_filters(d + 1), a)
             else:
                 f = dwconv_ln(f, None, gamma, a)
                 nodes[d] = f
@@ -500,8 +542,19 @@ class UnetLaplacianHydra:
                 # upsampling.py:80-90 makes the same exchange itself when the activation is linear)
                 low = pointwise(low, P[f"up{d}/kernel"], self.level_filters(d), "linear")
                 f = upsample_act_add(low, nodes[d], a)
+            elif self.upsample_type in ("upsample_bilinear_conv2d", "upsample_nearest_conv2d"):
+                from .pyramid import upsample_2x                           # UpSampling2D, then Conv2D 3x3 + activation
+                up = upsample_2x(low, bilinear=self.upsample_type == "upsample_bilinear_conv2d")
+                f = conv2d(up, P[f"up{d}/kernel"], self.level_filters(d), 3, 1, a, res=nodes[d])
             else:
-                f = upsample_act_add(low, nodes[d], "linear")
+                if low.shape[-1] != nodes[d].shape[-1]:
+                    raise ValueError(f"Add of [{nodes[d].shape[-1]}] and [{low.shape[-1]}] channels: upsample_type "
+                                     f"[{self.upsample_type}] needs equal filters on both levels")
+                if self.upsample_type == "bilinear":
+                    f = upsample_act_add(low, nodes[d], "linear")
+                else:
+                    from .pyramid import upsample_2x
+                    f = upsample_2x(low, other=nodes[d], bilinear=False)
             if self.use_mix_project:
                 f = pointwise(f, P[f"mix{d}/kernel"], self.level_filters(d), a)
             for w in range(self.width):

@@ -201,6 +201,14 @@ int bf_op_pack_pointwise(const float* w, float* wp, int cin, int cout, void* str
 /* Conv2D 1x1, use_bias=False (utilities.py:196): out = res + mult * act(in . w); mult [cout] / res [npix][cout] may be NULL. */
 int bf_op_pointwise(const float* in, float* out, const float* wp, const float* mult, const float* res, int64_t npix,
                     int cin, int cout, int act, float alpha, void* stream);
+/* Conv2D kh x kw, strides s, padding="same", use_bias=False (utilities.py:196): out = res + act(conv(in)); wp = kh*kw
+ * tap matrices [cin][cout], each packed by bf_op_pack_pointwise, tap-major; cin, cout in {32, 64, 128}.  Serves the
+ * "conv2d" downsample (2x2 stride 2, downsampling.py:45-55) and the 3x3 convolution of upsample_bilinear_conv2d /
+ * upsample_nearest_conv2d (upsampling.py:52-72). */
+int bf_op_conv2d(const float* in, float* out, const float* wp, const float* res, int batch, int height, int width, int cin,
+                 int cout, int kh, int kw, int stride, int act, float alpha, void* stream);
+/* MaxPooling2D(2, 2, padding="same") (downsampling.py:56-58). */
+int bf_op_maxpool2(const float* in, float* out, int batch, int height, int width, int channels, void* stream);
 /* ConvNextBlock conv_2 -> activation -> conv_3 -> ChannelLearnableMultiplier -> Add(skip, .) (custom_layers.py:990-1008;
  * backbone_unet_laplacian.py:351-354): out = skip + mult * (act(in . w1) . w2), w1 [C][4C], w2 [4C][C] packed as above. */
 int bf_op_convnext_mlp(const float* in, const float* skip, float* out, const float* w1p, const float* w2p, const float* mult,
@@ -229,7 +237,7 @@ int bf_op_dwconv_ln(const float* in, float* out, const float* w, const float* ln
 /* Laplacian split between levels (backbone_unet_laplacian.py:366-386): smooth = AveragePooling2D(k, strides 1, same) or,
  * with gauss [k][k], GaussianFilter; lap = in - smooth; down = smooth[:, ::2, ::2, :] (downsampling.py:61). */
 int bf_op_smooth_split(const float* in, float* lap, float* down, const float* gauss, int batch, int height, int width,
-                       int channels, int k, void* stream);
+                       int channels, int k, int down_stride /* 2: the slice above; 1: the whole smooth map */, void* stream);
 /* The same split with the level's output normalisation in front, one kernel (backbone_unet_laplacian.py:355-386):
  * y = act(LayerNormalization(in) * ln_gamma) (ln_gamma NULL: y = act(in)) is never written; lap = y - smooth(y),
  * down = smooth(y)[:, ::2, ::2, :]; k = 3 or 5. */

@@ -82,6 +82,14 @@ def gaussian_kernel_3(kernel_size=(3, 3)) -> np.ndarray:
     return (g / g.sum()).astype(np.float32).astype(np.float64)
 
 
+def max_pool_2x2_same(x: np.ndarray) -> np.ndarray:
+    """keras MaxPooling2D(pool_size 2, strides 2, padding="same") (downsampling.py:56-58): padded taps are ignored."""
+    B, H, W, C = x.shape
+    xp = np.full((B, H + H % 2, W + W % 2, C), -np.inf, dtype=x.dtype)
+    xp[:, :H, :W] = x
+    return np.maximum(np.maximum(xp[:, 0::2, 0::2], xp[:, 1::2, 0::2]), np.maximum(xp[:, 0::2, 1::2], xp[:, 1::2, 1::2]))
+
+
 def resize_bilinear(x: np.ndarray, oh: int, ow: int) -> np.ndarray:
     """tf.image.resize(method=BILINEAR, antialias=False): half-pixel centres, src = (dst + 0.5) * in/out - 0.5,
     lower = max(floor(src), 0), upper = min(ceil(src), in - 1), weight = src - floor(src)
@@ -119,6 +127,8 @@ class UnetLaplacianSpec:
     gaussian_kernel_size: int = 3
     activation: str = "leaky_relu_01"
     upsample_type: str = "upsample_laplacian_conv2d"
+    downsample_type: str = "strides"
+    filters_level_multiplier: float = 2.0
     use_ln: bool = True
     use_gamma: bool = True
     use_laplacian: bool = True
@@ -140,7 +150,7 @@ class UnetLaplacianSpec:
         if bb["type"] != "unet_laplacian":
             raise ValueError(bb["type"])
         unsupported = dict(use_bn=False, use_bias=False, use_concat=False, use_attention_gates=False,
-                           use_complex_base=False, downsample_type="strides", multiple_scale_outputs=True)
+                           use_complex_base=False, multiple_scale_outputs=True)
         for k, v in unsupported.items():
             if bb.get(k, v) != v:
                 raise NotImplementedError(f"{k}={bb[k]} is outside the restated graph")
@@ -150,6 +160,8 @@ class UnetLaplacianSpec:
             in_channels=bb["input_shape"][-1], encoder_kernel_size=bb.get("encoder_kernel_size", 5),
             decoder_kernel_size=bb.get("decoder_kernel_size", 3), gaussian_kernel_size=bb.get("gaussian_kernel_size", 3),
             activation=bb.get("activation", "leaky_relu_01"), upsample_type=bb.get("upsample_type", "bilinear"),
+            downsample_type=bb.get("downsample_type", "strides"),
+            filters_level_multiplier=float(bb.get("filters_level_multiplier", 2.0)),
             use_ln=bb.get("use_ln", True), use_gamma=bb.get("use_gamma", True), use_laplacian=bb.get("use_laplacian", True),
             use_laplacian_averaging=bb.get("use_laplacian_averaging", True), use_mix_project=bb.get("use_mix_project", True),
             use_self_attention=bb.get("use_self_attention", False),
@@ -158,7 +170,7 @@ class UnetLaplacianSpec:
             out_channels=dn.get("output_channels", 3), v_min=float(vr[0]), v_max=float(vr[1]))
 
     def level_filters(self, d: int) -> int:
-        return int(round(self.filters * max(1, 2.0 ** d)))           # backbone_unet_laplacian.py:198-205
+        return int(round(self.filters * max(1, self.filters_level_multiplier ** d)))   # backbone_unet_laplacian.py:198-205
 
     def tensors(self) -> List[Tuple[str, Tuple[int, ...], str]]:
         """(name, shape, kind) of every trainable tensor in graph-construction order; kind in
@@ -190,11 +202,14 @@ class UnetLaplacianSpec:
             if self.use_output_normalization and self.use_ln:
                 out.append((f"enc{d}/out_ln/gamma", (C,), "ln_gamma"))
             if d != self.depth - 1:
-                out.append((f"down{d}/kernel", (1, 1, C, self.level_filters(d + 1)), "conv"))
+                kd = 2 if self.downsample_type == "conv2d" else 1            # downsampling.py:45-72
+                out.append((f"down{d}/kernel", (kd, kd, C, self.level_filters(d + 1)), "conv"))
         for d in reversed(range(self.depth - 1)):
             C = self.level_filters(d)
             if self.upsample_type == "upsample_laplacian_conv2d":
                 out.append((f"up{d}/kernel", (1, 1, self.level_filters(d + 1), C), "conv"))
+            elif self.upsample_type in ("upsample_bilinear_conv2d", "upsample_nearest_conv2d"):
+                out.append((f"up{d}/kernel", (3, 3, self.level_filters(d + 1), C), "conv"))   # upsampling.py:52-72
             if self.use_mix_project:
                 out.append((f"mix{d}/kernel", (1, 1, C, C), "conv"))
             for w in range(self.width):
@@ -305,7 +320,14 @@ def backbone_forward(spec: UnetLaplacianSpec, P: Dict[str, np.ndarray], xn: np.n
                     smooth = depthwise_same(x, np.repeat(g[:, :, None, None], x.shape[-1], axis=2))
                 nodes[d] = x - smooth
                 x = smooth
-            x = act(conv(O.strided_slice_2x(x), P[f"down{d}/kernel"]), a)    # downsampling.py:60-72
+            if spec.downsample_type == "strides":
+                x = act(conv(O.strided_slice_2x(x), P[f"down{d}/kernel"]), a)             # downsampling.py:60-72
+            elif spec.downsample_type == "conv2d":
+                x = act(conv(x, P[f"down{d}/kernel"], stride=2), a)                       # 2x2, strides 2, same (:45-55)
+            elif spec.downsample_type == "maxpool":
+                x = act(conv(max_pool_2x2_same(x), P[f"down{d}/kernel"]), a)              # :56-68
+            else:
+                raise ValueError(spec.downsample_type)
     outs = {spec.depth - 1: nodes[spec.depth - 1]}                       # nodes_output[(depth-1, 1)] (:434)
     for d in reversed(range(spec.depth - 1)):
         low = outs[d + 1]
@@ -314,6 +336,10 @@ def backbone_forward(spec: UnetLaplacianSpec, P: Dict[str, np.ndarray], xn: np.n
                 up = O.upsample_bilinear_2x(conv(low, P[f"up{d}/kernel"]))
             else:                                                        # :91-102
                 up = act(conv(O.upsample_bilinear_2x(low), P[f"up{d}/kernel"]), a)
+        elif spec.upsample_type == "upsample_bilinear_conv2d":              # upsampling.py:52-63
+            up = act(conv(O.upsample_bilinear_2x(low), P[f"up{d}/kernel"]), a)
+        elif spec.upsample_type == "upsample_nearest_conv2d":               # :64-76
+            up = act(conv(O.upsample_nearest_2x(low), P[f"up{d}/kernel"]), a)
         elif spec.upsample_type == "bilinear":
             up = O.upsample_bilinear_2x(low)
         elif spec.upsample_type in ("nn", "nearest"):

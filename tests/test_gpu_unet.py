@@ -243,6 +243,27 @@ def test_head_fused_layernorm_two_convs_tanh(C, use_ln):
     assert got.dtype == np.uint8 and np.abs(got.astype(int) - want).max() <= 1 and (got != want).mean() < 0.02
 
 
+@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 128), (128, 64), (128, 128)])
+@pytest.mark.parametrize("k,stride,shape", [(3, 1, (2, 9, 11)), (2, 2, (1, 10, 14)), (2, 2, (1, 7, 9)), (3, 2, (1, 8, 8)), (5, 1, (1, 6, 6)),
+                                            (1, 1, (1, 5, 5))])
+def test_conv2d_strided_same(cin, cout, k, stride, shape):
+    r = _rng(cin + cout + k)
+    x = r.normal(size=shape + (cin,))
+    w = r.normal(size=(k, k, cin, cout)) / np.sqrt(k * k * cin)
+    ref = O.conv2d_same(x, w, stride=stride)
+    res = r.normal(size=ref.shape)
+    wp = UL.pack_conv(dev(w))
+    assert_close(host(UL.conv2d(dev(x), wp, cout, k, stride)), ref, what="conv2d")
+    assert_close(host(UL.conv2d(dev(x), wp, cout, k, stride, "leaky_relu_01", dev(res))), res + U.act(ref, "leaky_relu_01"),
+                 what="conv2d act res")
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 2, 32), (2, 7, 9, 32), (1, 16, 16, 64)])
+def test_maxpool2_same(shape):
+    x = _rng(14).normal(size=shape)
+    assert np.array_equal(host(UL.maxpool2(dev(x))), U.max_pool_2x2_same(x).astype(np.float32))
+
+
 def test_channel_multiplier():
     w = np.linspace(-2.0, 1.0, 64)
     assert_close(host(UL.channel_multiplier(dev(w))), np.tanh(np.maximum(1 + w, 0)), what="multiplier")
@@ -292,8 +313,13 @@ def test_v5_hydra_all_scales_match_oracle(shape, arith):
                                 dict(use_mix_project=True, width=1), dict(upsample_type="bilinear", filters=32, depth=1),
                                 dict(use_output_normalization=False, use_gamma=False, width=2),
                                 dict(decoder_kernel_size=3, encoder_kernel_size=3, width=1),
-                                dict(use_self_attention=False, width=1)],
-                         ids=["no-attn-d2", "gaussian", "mix-project", "depth1", "no-outnorm-no-gamma", "k3", "convnext-c128"])
+                                dict(use_self_attention=False, width=1),
+                                dict(downsample_type="conv2d", upsample_type="upsample_bilinear_conv2d", width=1),
+                                dict(downsample_type="maxpool", upsample_type="upsample_nearest_conv2d", width=1, depth=2),
+                                dict(downsample_type="conv2d", upsample_type="nearest", filters_level_multiplier=1.0, width=1,
+                                     use_self_attention=False)],
+                         ids=["no-attn-d2", "gaussian", "mix-project", "depth1", "no-outnorm-no-gamma", "k3", "convnext-c128",
+                              "conv2d-down-bilinear-conv-up", "maxpool-down-nearest-conv-up", "nearest-up-flat-filters"])
 def test_builder_variants_match_oracle(bb):
     depth, width = bb.pop("depth", 3), bb.pop("width", 2)
     cfg, spec, params, m = _model(depth=depth, width=width, seed=7, **bb)
