@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256) void uo_smooth_split_kernel(const float* __res
                                                               float* __restrict__ down, const float* __restrict__ gauss, int B, int H,
                                                               int W, int C, int k, int down_stride)
 {
-    const int Cv = C / 4, OH = (H + 1) / 2, OW = (W + 1) / 2, R = k / 2;
+    const int Cv = C / 4, OH = (H + 1) / 2, OW = (W + 1) / 2, R = (k - 1) / 2;    // TF SAME: the extra pad of an even k is after
     const int64_t n = (int64_t)B * H * W * Cv;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % Cv);
@@ -802,7 +802,7 @@ extern "C" int bf_op_norm_smooth_split(const float* in, const float* ln_gamma, f
 extern "C" int bf_op_smooth_split(const float* in, float* lap, float* down, const float* gauss, int B, int H, int W, int C, int k,
                                   int down_stride, void* stream)
 {
-    if (!in || !lap || !down || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || k <= 0 || !(k & 1)) return BF_EINVAL;
+    if (!in || !lap || !down || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || k <= 0) return BF_EINVAL;
     if (down_stride != 1 && down_stride != 2) return BF_EINVAL;
     if (((uintptr_t)in | (uintptr_t)lap | (uintptr_t)down) % 16) return BF_EINVAL;
     const int64_t n = (int64_t)B * H * W * (C / 4);

@@ -151,6 +151,13 @@ def test_dwconv_layernorm(C, k, shape):
 @pytest.mark.parametrize("shape", [(1, 2, 2, 32), (2, 8, 12, 32), (1, 16, 16, 64), (1, 6, 10, 128)])
 def test_smooth_split_average_and_gaussian(shape):
     x = _rng(3).normal(size=shape)
+    for k in (2, 4):                                       # even kernels: TF SAME puts the extra pad after
+        smooth = O.avg_pool_same(x, (k, k), 1)
+        lap, down = UL.smooth_split(dev(x), k)
+        assert_close(host(lap), x - smooth, what="lap avg even")
+        assert_close(host(down), smooth[:, ::2, ::2], what="down avg even")
+        lap, full = UL.smooth_split(dev(x), k, down_stride=1)
+        assert_close(host(full), smooth, what="smooth full")
     smooth = O.avg_pool_same(x, (3, 3), 1)
     lap, down = UL.smooth_split(dev(x), 3)
     assert_close(host(lap), x - smooth, what="lap avg")
@@ -327,6 +334,18 @@ def test_builder_variants_match_oracle(bb):
     x = noisy.astype(np.float32)
     for g, r in zip(m(x), U.hydra_forward(spec, params, x.astype(np.float64))):
         _check_f32(g, r)
+
+
+def test_shipped_v6_config_matches_oracle():
+    """configs/unet_laplacian_v6.json: 2x2 averaging, 5x5 decoder depthwise, nearest + 3x3 conv upsample, 2x2 stride-2 conv
+    downsample."""
+    cfg, spec, params, m = _model(seed=6, gaussian_kernel_size=2, decoder_kernel_size=5, use_laplacian_averaging=True,
+                                  upsample_type="upsample_nearest_conv2d", downsample_type="conv2d")
+    _, noisy = O.synthetic_batch(1, 64, 96, seed=6)
+    x = noisy.astype(np.float32)
+    for g, r in zip(m(x), U.hydra_forward(spec, params, x.astype(np.float64))):
+        _check_f32(g, r)
+    _check_u8(bf.DenoiserModule(m)(noisy), U.denoiser_module_call(spec, params, noisy))
 
 
 @pytest.mark.parametrize("arith", [1, 0], ids=["f16x3", "f32"])
