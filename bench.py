@@ -206,7 +206,8 @@ def unet_bench(args, torch, bf, O, rank, local_rank, world, dist):
         "end_to_end_tflops": tf,
         "roofline": {"bound": "hbm", "kernel": "uh_enc32_kernel (level-0 encoder ConvNext block, 6 of the 13.6 ms graph "
                                                "are this kernel family)", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": blk_bytes,
+                     "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(0, B, S, True, kernel="uh_enc32_kernel"),
+                     "algorithmic_bytes_per_launch": blk_bytes,
                      "launch_us": launch_us,
                      "mfma": {"dtype": "f16 (split hi/lo, 3 products)", "algorithmic_tflops": blk_flop / launch_us / 1e6,
                               "peak_tflops": MFMA_F16_PEAK_TFLOPS}}}
