@@ -962,9 +962,8 @@ extern "C" int bf_op_attention(const float* q, const float* v, const float* k, f
 // first convolution: k x k, Cin (<= 4) -> COUT on the normalised image, SAME zero padding, activation.
 // The source image [B,Hs,Ws,cin] (u8 or f32, 0..255) is virtually zero-padded to [H,W] BEFORE normalisation
 // (pad_to_power_of_2, utilities.py:736-751: padded pixels normalise to -0.5); outside [H,W] the convolution pads with 0.
-// thread = one pixel, all output channels; weights broadcast from LDS.  (A matrix-core form -- K = 75 patch elements
-// gathered per lane with byte loads, 19 fp32 MFMA steps -- measured 1.66 ms against 1.09 ms for this kernel on
-// [32,512,512,3] uint8: the 64-address byte gathers cost more than the MFMAs save.)
+// thread = one pixel, all output channels; weights broadcast from LDS (general k / cin / cout; the 5x5 3 -> 32 case of the
+// unet_laplacian builder goes to uo_first_conv_tile_kernel below).
 // ------------------------------------------------------------------------------------------
 template <int COUT>
 __global__ __launch_bounds__(256) void uo_first_conv_kernel(const void* __restrict__ in, int in_is_u8, float* __restrict__ out,
@@ -1015,6 +1014,77 @@ __global__ __launch_bounds__(256) void uo_first_conv_kernel(const void* __restri
     }
 }
 
+// Matrix-core form for the 5x5, 3 -> 32 case (the one the unet_laplacian builder emits): a workgroup stages the
+// normalised input tile of 8 x 64 output pixels (+ halo 2) in LDS once; K = 75 patch elements (tap-major, channel-minor)
+// padded to 76 = 19 steps of the fp32 16x16x4 MFMA; lane (q, n) gathers element k = 4j + q of pixel n's patch with a
+// 4-byte LDS read, the 19 x 2 weight operands stay in registers.  (Gathering the patch straight from global memory with
+// byte loads was slower than the VALU kernel: 1.66 vs 1.09 ms on [32,512,512,3] uint8.)
+constexpr int UO_FC_TH = 8, UO_FC_TW = 64;
+template <int COUT>
+__global__ __launch_bounds__(256) void uo_first_conv_tile_kernel(const void* __restrict__ in, int in_is_u8, float* __restrict__ out,
+                                                                 const float* __restrict__ w, int Hs, int Ws, int H, int W,
+                                                                 int normalize, float v_min, float v_max, int act, float alpha)
+{
+    constexpr int KS = 5, CIN = 3, KT = KS * KS * CIN, NJ = (KT + 3) / 4, T = COUT / 16, RAD = KS / 2;
+    constexpr int IH = UO_FC_TH + 2 * RAD, IW = UO_FC_TW + 2 * RAD;
+    __shared__ float tile[IH * IW * CIN];
+    const int x0 = blockIdx.x * UO_FC_TW, y0 = blockIdx.y * UO_FC_TH;
+    const int64_t b = blockIdx.z;
+    const float range = v_max - v_min;
+    for (int e = threadIdx.x; e < IH * IW * CIN; e += 256) {
+        const int ci = e % CIN, px = (e / CIN) % IW, py = e / (CIN * IW);
+        const int yy = y0 + py - RAD, xx = x0 + px - RAD;
+        float v = 0.f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {                // inside the (virtually padded) image
+            if (yy < Hs && xx < Ws) {
+                const int64_t o = ((b * Hs + yy) * Ws + xx) * CIN + ci;
+                v = in_is_u8 ? (float)reinterpret_cast<const unsigned char*>(in)[o] : reinterpret_cast<const float*>(in)[o];
+            }
+            if (normalize) v = (fminf(fmaxf(v, v_min), v_max) - v_min) / range - 0.5f;
+        }
+        tile[e] = v;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, n = lane & 15;
+    float a[NJ][T];
+    int koff[NJ];                                      // LDS offset of patch element k = 4j + q relative to the pixel
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int k = 4 * j + q;
+        const bool real = k < KT;
+        const int tap = real ? k / CIN : 0, ci = real ? k - tap * CIN : 0;
+        koff[j] = ((tap / KS) * IW + (tap % KS)) * CIN + ci;
+#pragma unroll
+        for (int t = 0; t < T; ++t) a[j][t] = real ? w[k * COUT + 16 * t + n] : 0.f;
+    }
+    __syncthreads();
+    // 8 rows x 4 column groups of 16 pixels = 32 groups, 8 per wave
+    for (int gi = wave; gi < UO_FC_TH * (UO_FC_TW / 16); gi += 4) {
+        const int ry = gi / (UO_FC_TW / 16), cx = (gi % (UO_FC_TW / 16)) * 16 + n;
+        const float* base = tile + (ry * IW + cx) * CIN;
+        f32x4 acc[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float bv[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bv[j] = base[koff[j]];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[t] = MFMA4(a[j][t], bv[j], acc[t]);
+        const int gy = y0 + ry, gx = x0 + cx;
+        if (gy < H && gx < W) {
+            float* op = out + ((b * H + gy) * (int64_t)W + gx) * COUT + 4 * q;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                f32x4 v = bf_acc_ready(acc[t]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = uo_act_rt(v[r], act, alpha);
+                *reinterpret_cast<f32x4*>(op + 16 * t) = v;
+            }
+        }
+    }
+}
+
 extern "C" int bf_op_first_conv(const void* in, int in_is_u8, float* out, const float* w, int B, int Hs, int Ws, int H, int W, int cin,
                                 int cout, int k, int normalize, float v_min, float v_max, int act, float alpha, void* stream)
 {
@@ -1026,6 +1096,11 @@ extern "C" int bf_op_first_conv(const void* in, int in_is_u8, float* out, const 
     const int64_t npix = (int64_t)B * H * W;
     hipStream_t s = (hipStream_t)stream;
     const int grid = uo_grid(npix, 256);
+    if (cout == 32 && k == 5 && cin == 3 && B <= 65535 && (H + UO_FC_TH - 1) / UO_FC_TH <= 65535) {
+        hipLaunchKernelGGL((uo_first_conv_tile_kernel<32>), dim3((W + UO_FC_TW - 1) / UO_FC_TW, (H + UO_FC_TH - 1) / UO_FC_TH, B),
+                           dim3(256), 0, s, in, in_is_u8, out, w, Hs, Ws, H, W, normalize, v_min, v_max, act, alpha);
+        return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+    }
     if (cout == 32)
         hipLaunchKernelGGL((uo_first_conv_kernel<32>), dim3(grid), dim3(256), lds, s, in, in_is_u8, out, w, B, Hs, Ws, H, W, cin, k,
                            normalize, v_min, v_max, act, alpha);
@@ -1115,26 +1190,45 @@ __global__ __launch_bounds__(256, 2) void uo_head_fused_kernel(const float* __re
     f32x4 gm[KC];
 #pragma unroll
     for (int c = 0; c < KC; ++c) gm[c] = gamma ? *reinterpret_cast<const f32x4*>(gamma + 16 * c + 4 * q) : (f32x4){1.f, 1.f, 1.f, 1.f};
-    for (int64_t g = wave; g < ngroups; g += nwaves) {
-        const int64_t p0 = g * 16 * NP;
-        const float* wpo = w0p;
-        asm volatile("" : "+s"(wpo));                              // see uo_pointwise_kernel
-        const f32x4* wv = reinterpret_cast<const f32x4*>(wpo) + lane;
-        f32x4 b[NP][KC];
+    // the raw pixels of the NEXT group are requested before the current one is normalised and multiplied (CIN <= 64: the
+    // extra registers fit), as in the split-f16 MLP kernel
+    constexpr bool PF = CIN <= 64;
+    f32x4 raw[NP][KC];
+    auto load_raw = [&](int64_t gg) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            int64_t p = p0 + 16 * i + n;
+            int64_t p = gg * 16 * NP + 16 * i + n;
             p = p < npix ? p : npix - 1;
             const int x = (int)(p % Wo);
             const int y = (int)((p / Wo) % Ho);
             const int64_t bi = p / ((int64_t)Wo * Ho);
             const float* src = in + ((bi * H + y) * W + x) * CIN + 4 * q;
+#pragma unroll
+            for (int c = 0; c < KC; ++c) raw[i][c] = *reinterpret_cast<const f32x4*>(src + 16 * c);
+        }
+    };
+    if (PF && wave < ngroups) load_raw(wave);
+    for (int64_t g = wave; g < ngroups; g += nwaves) {
+        const int64_t p0 = g * 16 * NP;
+        const float* wpo = w0p;
+        asm volatile("" : "+s"(wpo));                              // see uo_pointwise_kernel
+        const f32x4* wv = reinterpret_cast<const f32x4*>(wpo) + lane;
+        if (!PF) load_raw(g);
+        f32x4 b[NP][KC];
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+#pragma unroll
+            for (int c = 0; c < KC; ++c) b[i][c] = raw[i][c];
+        if (PF) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + nwaves < ngroups) load_raw(g + nwaves);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
             float sum = 0.f;
 #pragma unroll
-            for (int c = 0; c < KC; ++c) {
-                b[i][c] = *reinterpret_cast<const f32x4*>(src + 16 * c);
-                sum += b[i][c][0] + b[i][c][1] + b[i][c][2] + b[i][c][3];
-            }
+            for (int c = 0; c < KC; ++c) sum += b[i][c][0] + b[i][c][1] + b[i][c][2] + b[i][c][3];
             if (gamma) {
                 sum += __shfl_xor(sum, 16, 64);
                 sum += __shfl_xor(sum, 32, 64);
