@@ -230,6 +230,9 @@ int bf_op_convnext_block1_h3(const float* x, float* out, const float* dw, const 
 int bf_op_convnext_block_h3(const float* x, float* out, const float* dw, int k, const float* ln_gamma, float eps,
                             const void* packed, const float* mult, int batch, int height, int width, int channels, int act,
                             float alpha, void* stream);
+/* A/B switch between kernel variants of one operator (process-wide; tests and tools only): key "enc32":
+ * 1 = wave-specialised encoder block kernel (default), 0 = the single-role one. */
+int bf_op_set_variant(const char* key, int value);
 /* DepthwiseConv2D k x k (SAME, zero pad; w [k][k][C]; k = 0: none) -> LayerNormalization(center=False, epsilon) * gamma
  * (ln_gamma NULL: none) -> activation   (custom_layers.py:979-988; backbone_unet_laplacian.py:355-360). */
 int bf_op_dwconv_ln(const float* in, float* out, const float* w, const float* ln_gamma, int batch, int height, int width,

@@ -93,10 +93,20 @@ def test_convnext_block_with_1x1_depthwise_in_one_kernel(C, npix, use_ln):
     assert_close(host(got), ref, rel=5e-5, what="block1 h3")
 
 
+@pytest.mark.parametrize("variant", [1, 0], ids=["wave-specialised", "single-role"])
 @pytest.mark.parametrize("k", [3, 5])
-@pytest.mark.parametrize("shape", [(1, 1, 1), (1, 16, 32), (2, 20, 37), (1, 7, 70), (1, 64, 64), (1, 33, 8)])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (1, 16, 32), (2, 20, 37), (1, 7, 70), (1, 64, 64), (1, 33, 8), (3, 48, 96)])
 @pytest.mark.parametrize("use_ln", [True, False])
-def test_encoder_convnext_block_in_one_kernel(k, shape, use_ln):
+def test_encoder_convnext_block_in_one_kernel(k, shape, use_ln, variant):
+    from blind_image_denoising_amd import _native as N
+    N.check(N.lib().bf_op_set_variant(b"enc32", variant), None, "bf_op_set_variant")
+    try:
+        _encoder_block_case(k, shape, use_ln)
+    finally:
+        N.lib().bf_op_set_variant(b"enc32", 1)
+
+
+def _encoder_block_case(k, shape, use_ln):
     C = 32
     r = _rng(k + shape[1] + shape[2])
     x = r.normal(size=shape + (C,)) * 2 + 0.3

@@ -10,6 +10,9 @@ w1, w2 = torch.randn((C, 4 * C), device="cuda") / C ** 0.5, torch.randn((4 * C, 
 pk = UL.pack_mlp_h3(w1, w2)
 mult = torch.rand(C, device="cuda")
 f = lambda: UL.convnext_block_h3(x, dw, g, pk, mult, "leaky_relu_01")
+if os.environ.get("ENC_VARIANT"):
+    from blind_image_denoising_amd import _native as N
+    N.lib().bf_op_set_variant(b"enc32", int(os.environ["ENC_VARIANT"]))
 for _ in range(3):
     f()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
