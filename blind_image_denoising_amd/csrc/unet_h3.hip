@@ -26,6 +26,9 @@ typedef _Float16 uh8 __attribute__((ext_vector_type(8)));
 typedef _Float16 uh4 __attribute__((ext_vector_type(4)));
 typedef _Float16 uh2 __attribute__((ext_vector_type(2)));
 #define UH_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#ifndef UH_MLP_VALU_PER_MFMA
+#define UH_MLP_VALU_PER_MFMA 3
+#endif
 
 // v - float(one half of the packed f16 pair hh) in one instruction (v_fma_mix_f32)
 __device__ __forceinline__ float uh_sub_half(const float v, const unsigned hh, const bool high)
@@ -159,10 +162,8 @@ __device__ __forceinline__ void uh_mlp_core(const uh8 (&xh)[C / 32][NP], const u
     for (int t = 0; t < T2; ++t)
 #pragma unroll
         for (int i = 0; i < NP; ++i) acc2[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c2 = 0; c2 < KC2; ++c2) {
-        // ---- GEMM1: hidden tiles 2 c2 and 2 c2 + 1
-        f32x4 h[2][NP];
+    // GEMM1 of hidden tiles 2 c2, 2 c2 + 1 into h
+    auto gemm1 = [&](const int c2, f32x4 (&h)[2][NP]) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
 #pragma unroll
@@ -180,7 +181,9 @@ __device__ __forceinline__ void uh_mlp_core(const uh8 (&xh)[C / 32][NP], const u
                 for (int i = 0; i < NP; ++i) h[u][i] = UH_MFMA(ah, xl[c][i], h[u][i]);
             }
         }
-        // ---- activation + split: the lane's 8 hidden values are its B fragment of chunk c2
+    };
+    // activation + split of chunk c2 (the lane's 8 hidden values are its B fragment), then GEMM2 with K chunk c2
+    auto finish = [&](const int c2, f32x4 (&h)[2][NP]) {
         uh8 bh[NP], bl[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -192,7 +195,6 @@ __device__ __forceinline__ void uh_mlp_core(const uh8 (&xh)[C / 32][NP], const u
             }
             uh_split8(v0, v1, bh[i], bl[i]);
         }
-        // ---- GEMM2: K chunk c2
 #pragma unroll
         for (int t = 0; t < T2; ++t) {
             const int f = (c2 * T2 + t) * 2;
@@ -204,6 +206,26 @@ __device__ __forceinline__ void uh_mlp_core(const uh8 (&xh)[C / 32][NP], const u
             for (int i = 0; i < NP; ++i) acc2[t][i] = UH_MFMA(al, bh[i], acc2[t][i]);
 #pragma unroll
             for (int i = 0; i < NP; ++i) acc2[t][i] = UH_MFMA(ah, bl[i], acc2[t][i]);
+        }
+    };
+    // software pipeline: the matrix instructions of GEMM1 (chunk c2 + 1) are in the instruction stream before the
+    // vector-ALU work of chunk c2 (scale, activation, hi/lo split) that depends on the PREVIOUS GEMM1, and the scheduler is
+    // asked to interleave them (1 MFMA : UH_MLP_VALU_PER_MFMA VALU) so that a wave that is alone on its SIMD (the consumer
+    // waves of uh_enc32s_kernel) keeps both pipes busy
+    f32x4 hA[2][NP], hB[2][NP];
+    gemm1(0, hA);
+#pragma unroll
+    for (int c2 = 0; c2 < KC2; ++c2) {
+        if (c2 + 1 < KC2) {
+            if (c2 & 1) gemm1(c2 + 1, hA);
+            else gemm1(c2 + 1, hB);
+        }
+        if (c2 & 1) finish(c2, hB);
+        else finish(c2, hA);
+#pragma unroll
+        for (int g = 0; g < 6 * KC1 * NP + 3 * T2 * NP; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, UH_MLP_VALU_PER_MFMA, 0);    // VALU
         }
     }
 }
