@@ -187,7 +187,9 @@ __device__ __forceinline__ void uh_mlp_core(const uh8 (&xh)[C / 32][NP], const u
         uh8 bh[NP], bl[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            f32x4 v0 = bf_acc_ready(h[0][i]) * inv1, v1 = bf_acc_ready(h[1][i]) * inv1;
+            // straight-line code from the MFMAs to here: hipcc pads the MFMA -> VALU hazard itself (bf_acc_ready is for reads
+            // behind branches; its volatile s_nop would also pin the schedule)
+            f32x4 v0 = h[0][i] * inv1, v1 = h[1][i] * inv1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 v0[r] = uh_act<ACT>(v0[r], alpha);
