@@ -223,6 +223,63 @@ def unet_bench(args, torch, bf, O, rank, local_rank, world, dist):
     print(json.dumps(rec), flush=True)
 
 
+def latency_bench(args, torch, bf, O, rank, local_rank, world, dist):
+    """configs[0]/[1] territory: single-image latency of DenoiserModule.__call__ (uint8 256x256x3 -> uint8), launched
+    op by op on the stream and as ONE captured HIP graph (the C ABI neither allocates nor synchronises, so the whole call
+    is capturable); resnet 1x6 / 1x18 and unet_laplacian v5 (512x512)."""
+    from oracle import unet_oracle as U
+    dev = f"cuda:{local_rank}"
+    rows = {}
+
+    def measure(name, module, img):
+        x = torch.from_numpy(img).to(dev)
+        for _ in range(5):
+            module(x)
+        torch.cuda.synchronize()
+        n = max(args.steps, 50)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            module(x)
+        torch.cuda.synchronize()
+        t_stream = (time.perf_counter() - t0) / n
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = module(x)
+        for _ in range(5):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            g.replay()
+        torch.cuda.synchronize()
+        t_graph = (time.perf_counter() - t0) / n
+        rows[name] = {"stream_us": t_stream * 1e6, "graph_us": t_graph * 1e6}
+        return out
+
+    for layers in (6, 18):
+        cfg = O.canonical_config(no_layers=layers)
+        spec = O.ResnetSpec.from_config(cfg["model"])
+        params, state = O.init_params(spec, seed=42, nontrivial_bn=True)
+        m = bf.model_builder(cfg["model"], device=dev).hydra
+        m.set_weights(params, state)
+        _, img = O.synthetic_batch(1, 256, 256, sigma=20.0, seed=1234)
+        measure(f"resnet_1x{layers} 1x256x256x3", bf.DenoiserModule(m), img)
+    ucfg = U.canonical_config()
+    um = bf.model_builder(ucfg["model"], device=dev).hydra
+    um.set_weights(U.init_params(U.UnetLaplacianSpec.from_config(ucfg["model"]), seed=42))
+    _, img = O.synthetic_batch(1, 512, 512, sigma=20.0, seed=1234)
+    measure("unet_laplacian_v5 1x512x512x3", bf.DenoiserModule(um), img)
+    if rank == 0:
+        best = rows["resnet_1x18 1x256x256x3"]
+        print(json.dumps({
+            "metric": "single-image latency, DenoiserModule.__call__ (us)", "value": best["graph_us"], "unit": "us",
+            "n_gpus": 1, "steps": max(args.steps, 50), "warmup": 5, "ms_per_step": best["graph_us"] / 1e3,
+            "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f16x2 split (hi+lo, fp32 accumulate)",
+            "data": "synthetic",
+            "config": {"workload": "batch 1 uint8->uint8, launched op by op on the stream vs replayed as one captured HIP graph"},
+            "latency": rows}), flush=True)
+
+
 def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
     """configs[3]: resnet_color_1x18 training step, L1 loss (hinge 0.5), additive-gaussian synthetic batch, global batch =
     --batch x world sharded over the ranks, one sum-all-reduce of the flat fp32 gradient buffer, fused clip + Adam."""
@@ -292,7 +349,7 @@ def main():
     ap.add_argument("--fused-tile", type=int, default=None, help="exact-fp32 fused-block tile geometry variant (A/B only)")
     ap.add_argument("--arith", type=int, default=1, help="1 = split-f16 fused blocks (default), 0 = exact-fp32 fused blocks")
     ap.add_argument("--h3-variant", type=int, default=None, help="split-f16 kernel variant (A/B only)")
-    ap.add_argument("--mode", choices=["inference", "train", "pyramid", "unet"], default="inference",
+    ap.add_argument("--mode", choices=["inference", "train", "pyramid", "unet", "latency"], default="inference",
                     help="train: BASELINE.json configs[3] -- one data-parallel training step per step (L1 loss, "
                          "batch sharded over the ranks, ONE gradient all-reduce, clip + Adam); not the headline metric")
     args = ap.parse_args()
@@ -323,6 +380,8 @@ def main():
         return pyramid_bench(args, torch, bf, O, rank, local_rank, world, dist)
     if args.mode == "unet":
         return unet_bench(args, torch, bf, O, rank, local_rank, world, dist)
+    if args.mode == "latency":
+        return latency_bench(args, torch, bf, O, rank, local_rank, world, dist)
     cfg = O.canonical_config(no_layers=args.layers)
     spec = O.ResnetSpec.from_config(cfg["model"])
     params, state = O.init_params(spec, seed=42, nontrivial_bn=True)
