@@ -68,6 +68,7 @@ SIGNATURES = {
     "bf_noise_augment": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, C.c_uint64, _P]),
     "bf_op_pack_pointwise": (_I, [_P, _P, _I, _I, _P]),
     "bf_op_pointwise": (_I, [_P, _P, _P, _P, _P, C.c_int64, _I, _I, _I, _F, _P]),
+    "bf_op_pointwise_ex": (_I, [_P, _P, _P, _P, _P, _P, C.c_int64, _I, _I, _I, _F, _I, _P]),
     "bf_op_convnext_mlp": (_I, [_P, _P, _P, _P, _P, _P, C.c_int64, _I, _I, _F, _P]),
     "bf_op_mlp_h3_pack_bytes": (C.c_int64, [_I]),
     "bf_op_pack_mlp_h3": (_I, [_P, _P, _P, _I, _P]),

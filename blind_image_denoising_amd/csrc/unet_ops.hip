@@ -74,10 +74,14 @@ extern "C" int bf_op_pack_pointwise(const float* w, float* wp, int cin, int cout
 // 1x1 convolution: out[p][co] = res[p][co] + mult[co] * act(sum_ci in[p][ci] w[ci][co])
 // one wave = NP groups of 16 pixels, all output channels; 4 waves per workgroup
 // ------------------------------------------------------------------------------------------
+// mode 0: out = res + mult * act(acc)                      (1x1 convolution, activation, channel multiplier, residual Add)
+// mode 1: out = act(acc + res)                             (AdditiveAttentionGate: leaky_relu(conv_x(x) + conv_y(y)), custom_layers.py:823)
+// mode 2: out = res * sigmoid(4 * mult * acc) + add        (the gate applied to the encoder feature, :824-832, + the decoder Add)
 template <int CIN, int COUT, int NP, int ACT>
 __global__ __launch_bounds__(256, 2) void uo_pointwise_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                            const float* __restrict__ wp, const float* __restrict__ mult,
-                                                           const float* __restrict__ res, int64_t npix, float alpha)
+                                                           const float* __restrict__ res, int64_t npix, float alpha, int mode,
+                                                           const float* __restrict__ add)
 {
     constexpr int KC = CIN / 16, T = COUT / 16;
     const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
@@ -140,10 +144,22 @@ __global__ __launch_bounds__(256, 2) void uo_pointwise_kernel(const float* __res
             for (int t = 0; t < T; ++t) {
                 f32x4 v = bf_acc_ready(acc[t][i]);
                 const int co = 16 * t + 4 * q;
+                if (mode == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = uo_act<ACT>(v[r], alpha);
-                if (mult) v *= *reinterpret_cast<const f32x4*>(mult + co);
-                if (res) v += *reinterpret_cast<const f32x4*>(res + p * COUT + co);
+                    for (int r = 0; r < 4; ++r) v[r] = uo_act<ACT>(v[r], alpha);
+                    if (mult) v *= *reinterpret_cast<const f32x4*>(mult + co);
+                    if (res) v += *reinterpret_cast<const f32x4*>(res + p * COUT + co);
+                } else if (mode == 1) {
+                    if (res) v += *reinterpret_cast<const f32x4*>(res + p * COUT + co);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = uo_act<ACT>(v[r], alpha);
+                } else {
+                    if (mult) v *= *reinterpret_cast<const f32x4*>(mult + co);
+                    const f32x4 e = *reinterpret_cast<const f32x4*>(res + p * COUT + co);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = e[r] / (1.f + __expf(-4.f * v[r]));
+                    if (add) v += *reinterpret_cast<const f32x4*>(add + p * COUT + co);
+                }
                 *reinterpret_cast<f32x4*>(out + p * COUT + co) = v;
             }
         }
@@ -152,10 +168,10 @@ __global__ __launch_bounds__(256, 2) void uo_pointwise_kernel(const float* __res
 
 template <int CIN, int COUT, int NP>
 static hipError_t uo_launch_pointwise(const float* in, float* out, const float* wp, const float* mult, const float* res, int64_t npix,
-                                      int act, float alpha, hipStream_t s)
+                                      int act, float alpha, int mode, const float* add, hipStream_t s)
 {
     const int grid = uo_grid(npix, 4 * 16 * NP, 256 * 8);
-#define UO_PW(A) hipLaunchKernelGGL((uo_pointwise_kernel<CIN, COUT, NP, A>), dim3(grid), dim3(256), 0, s, in, out, wp, mult, res, npix, alpha)
+#define UO_PW(A) hipLaunchKernelGGL((uo_pointwise_kernel<CIN, COUT, NP, A>), dim3(grid), dim3(256), 0, s, in, out, wp, mult, res, npix, alpha, mode, add)
     switch (act) {
     case 0: UO_PW(0); break;
     case 1: UO_PW(1); break;
@@ -167,19 +183,33 @@ static hipError_t uo_launch_pointwise(const float* in, float* out, const float* 
     return hipGetLastError();
 }
 
+static int uo_pointwise_dispatch(const float* in, float* out, const float* wp, const float* mult, const float* res, int64_t npix,
+                                 int cin, int cout, int act, float alpha, int mode, const float* add, hipStream_t s)
+{
+    hipError_t e = hipErrorInvalidValue;
+#define UO_CASE(CI, CO, NP) if (cin == CI && cout == CO) e = uo_launch_pointwise<CI, CO, NP>(in, out, wp, mult, res, npix, act, alpha, mode, add, s)
+    UO_CASE(32, 32, 4); UO_CASE(32, 64, 4); UO_CASE(32, 128, 4); UO_CASE(64, 32, 4); UO_CASE(64, 64, 4); UO_CASE(64, 128, 4);
+    UO_CASE(128, 32, 4); UO_CASE(128, 64, 4); UO_CASE(128, 128, 4);
+    UO_CASE(128, 256, 2); UO_CASE(256, 128, 4); UO_CASE(256, 32, 4); UO_CASE(32, 256, 2);      // 4-level models (256 channels)
+#undef UO_CASE
+    if (e == hipErrorInvalidValue) return BF_EUNSUPPORTED;
+    return e == hipSuccess ? BF_OK : BF_EHIP;
+}
+
 extern "C" int bf_op_pointwise(const float* in, float* out, const float* wp, const float* mult, const float* res, int64_t npix,
                                int cin, int cout, int act, float alpha, void* stream)
 {
     if (!in || !out || !wp || npix <= 0) return BF_EINVAL;
     if (((uintptr_t)in | (uintptr_t)out | (uintptr_t)wp | (uintptr_t)mult | (uintptr_t)res) % 16) return BF_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipErrorInvalidValue;
-#define UO_CASE(CI, CO, NP) if (cin == CI && cout == CO) e = uo_launch_pointwise<CI, CO, NP>(in, out, wp, mult, res, npix, act, alpha, s)
-    UO_CASE(32, 32, 4); UO_CASE(32, 64, 4); UO_CASE(32, 128, 4); UO_CASE(64, 32, 4); UO_CASE(64, 64, 4); UO_CASE(64, 128, 4);
-    UO_CASE(128, 32, 4); UO_CASE(128, 64, 4); UO_CASE(128, 128, 4);
-#undef UO_CASE
-    if (e == hipErrorInvalidValue) return BF_EUNSUPPORTED;
-    return e == hipSuccess ? BF_OK : BF_EHIP;
+    return uo_pointwise_dispatch(in, out, wp, mult, res, npix, cin, cout, act, alpha, 0, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int bf_op_pointwise_ex(const float* in, float* out, const float* wp, const float* mult, const float* res, const float* add,
+                                  int64_t npix, int cin, int cout, int act, float alpha, int mode, void* stream)
+{
+    if (!in || !out || !wp || npix <= 0 || mode < 0 || mode > 2 || (mode == 2 && !res)) return BF_EINVAL;
+    if (((uintptr_t)in | (uintptr_t)out | (uintptr_t)wp | (uintptr_t)mult | (uintptr_t)res | (uintptr_t)add) % 16) return BF_EINVAL;
+    return uo_pointwise_dispatch(in, out, wp, mult, res, npix, cin, cout, act, alpha, mode, add, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -286,7 +316,7 @@ extern "C" int bf_op_conv2d(const float* in, float* out, const float* wp, const 
         default: UO_CV_A(CI, CO, NPP, 3); break;                                                                               \
         }                                                                                                                      \
     }
-    UO_CV(32, 32, 4) UO_CV(32, 64, 4) UO_CV(64, 32, 4) UO_CV(64, 64, 4) UO_CV(64, 128, 2) UO_CV(128, 64, 4) UO_CV(128, 128, 2)
+    UO_CV(32, 32, 4) UO_CV(32, 64, 4) UO_CV(64, 32, 4) UO_CV(64, 64, 4) UO_CV(64, 128, 2) UO_CV(128, 64, 4) UO_CV(128, 128, 2) UO_CV(256, 128, 2)
 #undef UO_CV
 #undef UO_CV_A
     if (!ok) return BF_EUNSUPPORTED;
@@ -488,6 +518,7 @@ __device__ __forceinline__ float uo_pixel_sum(float v)
     if (LPP >= 8) v = uo_dpp_add<0x141>(v);       // row_half_mirror
     if (LPP >= 16) v = uo_dpp_add<0x140>(v);      // row_mirror
     if (LPP >= 32) v += __shfl_xor(v, 16, 64);
+    if (LPP >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
 
@@ -642,7 +673,7 @@ extern "C" int bf_op_dwconv_ln(const float* in, float* out, const float* w, cons
         ok = true;                                                                                                            \
     }
     UO_DW(32, 0) UO_DW(32, 1) UO_DW(32, 3) UO_DW(32, 5) UO_DW(64, 0) UO_DW(64, 1) UO_DW(64, 3) UO_DW(64, 5)
-    UO_DW(128, 0) UO_DW(128, 1) UO_DW(128, 3) UO_DW(128, 5)
+    UO_DW(128, 0) UO_DW(128, 1) UO_DW(128, 3) UO_DW(128, 5) UO_DW(256, 0)
 #undef UO_DW
     if (!ok) return BF_EUNSUPPORTED;
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
@@ -1309,6 +1340,7 @@ extern "C" int bf_op_head_fused(const float* in, const float* ln_gamma, float ep
     if (cin == 32) UO_HEAD(32);
     else if (cin == 64) UO_HEAD(64);
     else if (cin == 128) UO_HEAD(128);
+    else if (cin == 256) UO_HEAD(256);
     else return BF_EUNSUPPORTED;
 #undef UO_HEAD
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;

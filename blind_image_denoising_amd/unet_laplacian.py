@@ -59,6 +59,17 @@ def pointwise(x: torch.Tensor, wp: torch.Tensor, cout: int, act: str = "linear",
     return out
 
 
+def pointwise_ex(x: torch.Tensor, wp: torch.Tensor, cout: int, mode: int, act: str = "linear", mult: torch.Tensor = None,
+                 res: torch.Tensor = None, add: torch.Tensor = None) -> torch.Tensor:
+    """mode 1: act(x . w + res);  mode 2: res * sigmoid(4 * mult * (x . w)) + add   (AdditiveAttentionGate epilogues)."""
+    cin = x.shape[-1]
+    out = torch.empty(x.shape[:-1] + (cout,), dtype=torch.float32, device=x.device)
+    code, a = _act(act)
+    _call("bf_op_pointwise_ex", N.ptr(x), N.ptr(out), N.ptr(wp), N.ptr(mult), N.ptr(res), N.ptr(add), x.numel() // cin, cin, cout,
+          code, a, mode, N.stream_ptr(x))
+    return out
+
+
 def convnext_mlp(x: torch.Tensor, skip: Optional[torch.Tensor], w1p: torch.Tensor, w2p: torch.Tensor,
                  mult: Optional[torch.Tensor], act: str) -> torch.Tensor:
     C = x.shape[-1]
@@ -266,7 +277,7 @@ class UnetLaplacianHydra:
     def __init__(self, config: Dict, device=None, seed: Optional[int] = None):
         bb, dn = config["backbone"], config["denoiser"]
         self.config = config
-        for key, want in dict(use_bn=False, use_bias=False, use_concat=False, use_attention_gates=False,
+        for key, want in dict(use_bn=False, use_bias=False, use_concat=False,
                               use_complex_base=False, use_value_compressor=False, use_global_pool_information=False,
                               multiple_scale_outputs=True).items():
             default = True if key in ("use_concat", "multiple_scale_outputs") else False
@@ -312,6 +323,7 @@ class UnetLaplacianHydra:
             raise NotImplementedError("unet_laplacian without the Laplacian split")
         self.use_mix_project = bool(bb.get("use_mix_project", True))
         self.use_self_attention = bool(bb.get("use_self_attention", False))
+        self.use_attention_gates = bool(bb.get("use_attention_gates", False))
         self.use_output_normalization = bool(bb.get("use_output_normalization", False))
         # keras 2.13 cannot resolve the string "leaky_relu" ConvolutionalSelfAttention gives its Conv2D layers
         # (custom_layers.py:1272-1282); later keras resolve it to negative_slope 0.2, which is what is built here
@@ -324,8 +336,11 @@ class UnetLaplacianHydra:
         _act(self.head_activation)
         self.out_channels = int(dn.get("output_channels", 3))
         for d in range(self.depth):
-            if self.level_filters(d) not in (32, 64, 128):
-                raise NotImplementedError(f"unet_laplacian: level {d} has {self.level_filters(d)} channels (32/64/128 are built)")
+            C = self.level_filters(d)
+            ok = C in (32, 64, 128) or (C == 256 and d == self.depth - 1 and self.use_self_attention)
+            if not ok:
+                raise NotImplementedError(f"unet_laplacian: level {d} has {C} channels (ConvNext levels: 32/64/128; a 256-channel "
+                                          f"level only as the self-attention bottleneck)")
         if self.head_filters not in (32, 64, 128):
             raise NotImplementedError("denoiser head filters must be 32, 64 or 128")
 
@@ -383,6 +398,15 @@ class UnetLaplacianHydra:
                 out.append((f"up{d}/kernel", (1, 1, self.level_filters(d + 1), C), "conv"))
             elif self.upsample_type in ("upsample_bilinear_conv2d", "upsample_nearest_conv2d"):
                 out.append((f"up{d}/kernel", (3, 3, self.level_filters(d + 1), C), "conv"))
+            if self.use_attention_gates:                    # AdditiveAttentionGate.build order (custom_layers.py:749-790)
+                out.append((f"gate{d}/x/kernel", (1, 1, C, C), "conv"))
+                if self.use_ln:
+                    out.append((f"gate{d}/x_ln/gamma", (C,), "ln_gamma"))
+                out.append((f"gate{d}/y/kernel", (1, 1, C, C), "conv"))
+                if self.use_ln:
+                    out.append((f"gate{d}/y_ln/gamma", (C,), "ln_gamma"))
+                out.append((f"gate{d}/o/kernel", (1, 1, C, C), "conv"))
+                out.append((f"gate{d}/scale/w", (C,), "multiplier"))
             if self.use_mix_project:
                 out.append((f"mix{d}/kernel", (1, 1, C, C), "conv"))
             for w in range(self.width):
@@ -537,24 +561,34 @@ class UnetLaplacianHydra:
         outs = {self.depth - 1: nodes[self.depth - 1]}
         for d in reversed(range(self.depth - 1)):
             low = outs[d + 1]
+            C = self.level_filters(d)
+            skip = None if self.use_attention_gates else nodes[d]       # gated: the Add happens in the gate kernel
             if self.upsample_type == "upsample_laplacian_conv2d":
                 # 1x1 and the bilinear resize are both linear: the 1x1 runs on the low-resolution map (1/4 of the work;
                 # upsampling.py:80-90 makes the same exchange itself when the activation is linear)
-                low = pointwise(low, P[f"up{d}/kernel"], self.level_filters(d), "linear")
-                f = upsample_act_add(low, nodes[d], a)
+                low = pointwise(low, P[f"up{d}/kernel"], C, "linear")
+                f = upsample_act_add(low, skip, a)
             elif self.upsample_type in ("upsample_bilinear_conv2d", "upsample_nearest_conv2d"):
                 from .pyramid import upsample_2x                           # UpSampling2D, then Conv2D 3x3 + activation
                 up = upsample_2x(low, bilinear=self.upsample_type == "upsample_bilinear_conv2d")
-                f = conv2d(up, P[f"up{d}/kernel"], self.level_filters(d), 3, 1, a, res=nodes[d])
+                f = conv2d(up, P[f"up{d}/kernel"], C, 3, 1, a, res=skip)
             else:
                 if low.shape[-1] != nodes[d].shape[-1]:
                     raise ValueError(f"Add of [{nodes[d].shape[-1]}] and [{low.shape[-1]}] channels: upsample_type "
                                      f"[{self.upsample_type}] needs equal filters on both levels")
                 if self.upsample_type == "bilinear":
-                    f = upsample_act_add(low, nodes[d], "linear")
+                    f = upsample_act_add(low, skip, "linear")
                 else:
                     from .pyramid import upsample_2x
-                    f = upsample_2x(low, other=nodes[d], bilinear=False)
+                    f = upsample_2x(low, other=skip, bilinear=False)
+            if self.use_attention_gates:
+                # AdditiveAttentionGate([encoder feature, upsampled]) (backbone_unet_laplacian.py:497-509; custom_layers.py:805-832)
+                # then Add([gated encoder feature, upsampled]): f = enc * sigmoid(4 * scale * conv_o(lrelu(conv_x(LN up) + conv_y(LN enc)))) + up
+                enc, up = nodes[d], f
+                y = pointwise(dwconv_ln(enc, None, P.get(f"gate{d}/y_ln/gamma")) if self.use_ln else enc, P[f"gate{d}/y/kernel"], C)
+                o = pointwise_ex(dwconv_ln(up, None, P.get(f"gate{d}/x_ln/gamma")) if self.use_ln else up, P[f"gate{d}/x/kernel"], C,
+                                 1, "leaky_relu_01", res=y)
+                f = pointwise_ex(o, P[f"gate{d}/o/kernel"], C, 2, mult=P[f"gate{d}/scale/w"], res=enc, add=up)
             if self.use_mix_project:
                 f = pointwise(f, P[f"mix{d}/kernel"], self.level_filters(d), a)
             for w in range(self.width):

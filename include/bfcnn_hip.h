@@ -209,6 +209,10 @@ int bf_op_conv2d(const float* in, float* out, const float* wp, const float* res,
                  int cout, int kh, int kw, int stride, int act, float alpha, void* stream);
 /* MaxPooling2D(2, 2, padding="same") (downsampling.py:56-58). */
 int bf_op_maxpool2(const float* in, float* out, int batch, int height, int width, int channels, void* stream);
+/* The same 1x1 convolution with the epilogues of AdditiveAttentionGate (custom_layers.py:805-832):
+ * mode 0 = bf_op_pointwise;  mode 1: out = act(in . w + res);  mode 2: out = res * sigmoid(4 * mult * (in . w)) + add. */
+int bf_op_pointwise_ex(const float* in, float* out, const float* wp, const float* mult, const float* res, const float* add,
+                       int64_t npix, int cin, int cout, int act, float alpha, int mode, void* stream);
 /* ConvNextBlock conv_2 -> activation -> conv_3 -> ChannelLearnableMultiplier -> Add(skip, .) (custom_layers.py:990-1008;
  * backbone_unet_laplacian.py:351-354): out = skip + mult * (act(in . w1) . w2), w1 [C][4C], w2 [4C][C] packed as above. */
 int bf_op_convnext_mlp(const float* in, const float* skip, float* out, const float* w1p, const float* w2p, const float* mult,

@@ -135,6 +135,7 @@ class UnetLaplacianSpec:
     use_laplacian_averaging: bool = True
     use_mix_project: bool = False
     use_self_attention: bool = True
+    use_attention_gates: bool = False
     use_output_normalization: bool = True
     attention_alpha: float = 0.2
     attention_resolution: Tuple[int, int] = (16, 16)
@@ -149,7 +150,7 @@ class UnetLaplacianSpec:
         bb, dn = model_config["backbone"], model_config["denoiser"]
         if bb["type"] != "unet_laplacian":
             raise ValueError(bb["type"])
-        unsupported = dict(use_bn=False, use_bias=False, use_concat=False, use_attention_gates=False,
+        unsupported = dict(use_bn=False, use_bias=False, use_concat=False,
                            use_complex_base=False, multiple_scale_outputs=True)
         for k, v in unsupported.items():
             if bb.get(k, v) != v:
@@ -165,6 +166,7 @@ class UnetLaplacianSpec:
             use_ln=bb.get("use_ln", True), use_gamma=bb.get("use_gamma", True), use_laplacian=bb.get("use_laplacian", True),
             use_laplacian_averaging=bb.get("use_laplacian_averaging", True), use_mix_project=bb.get("use_mix_project", True),
             use_self_attention=bb.get("use_self_attention", False),
+            use_attention_gates=bb.get("use_attention_gates", False),
             use_output_normalization=bb.get("use_output_normalization", False),
             head_filters=dn.get("filters", 32), head_activation=dn.get("activation", "linear"),
             out_channels=dn.get("output_channels", 3), v_min=float(vr[0]), v_max=float(vr[1]))
@@ -210,6 +212,15 @@ class UnetLaplacianSpec:
                 out.append((f"up{d}/kernel", (1, 1, self.level_filters(d + 1), C), "conv"))
             elif self.upsample_type in ("upsample_bilinear_conv2d", "upsample_nearest_conv2d"):
                 out.append((f"up{d}/kernel", (3, 3, self.level_filters(d + 1), C), "conv"))   # upsampling.py:52-72
+            if self.use_attention_gates:                    # AdditiveAttentionGate.build (custom_layers.py:749-790)
+                out.append((f"gate{d}/x/kernel", (1, 1, C, C), "conv"))
+                if self.use_ln:
+                    out.append((f"gate{d}/x_ln/gamma", (C,), "ln_gamma"))
+                out.append((f"gate{d}/y/kernel", (1, 1, C, C), "conv"))
+                if self.use_ln:
+                    out.append((f"gate{d}/y_ln/gamma", (C,), "ln_gamma"))
+                out.append((f"gate{d}/o/kernel", (1, 1, C, C), "conv"))
+                out.append((f"gate{d}/scale/w", (C,), "multiplier"))
             if self.use_mix_project:
                 out.append((f"mix{d}/kernel", (1, 1, C, C), "conv"))
             for w in range(self.width):
@@ -346,7 +357,13 @@ def backbone_forward(spec: UnetLaplacianSpec, P: Dict[str, np.ndarray], xn: np.n
             up = O.upsample_nearest_2x(low)
         else:
             raise NotImplementedError(spec.upsample_type)
-        x = nodes[d] + up                                                # use_concat False: Add (:514)
+        enc = nodes[d]
+        if spec.use_attention_gates:                                     # :497-509; AdditiveAttentionGate.call (custom_layers.py:805-832)
+            yg = conv(layer_norm(enc, P[f"gate{d}/y_ln/gamma"]) if spec.use_ln else enc, P[f"gate{d}/y/kernel"])
+            xg = conv(layer_norm(up, P[f"gate{d}/x_ln/gamma"]) if spec.use_ln else up, P[f"gate{d}/x/kernel"])
+            o = channel_multiplier(conv(leaky(xg + yg, 0.1), P[f"gate{d}/o/kernel"]), P[f"gate{d}/scale/w"])
+            enc = enc * (1.0 / (1.0 + np.exp(-4.0 * o)))
+        x = enc + up                                                     # use_concat False: Add (:514)
         if spec.use_mix_project:
             x = act(conv(x, P[f"mix{d}/kernel"]), a)
         for w in range(spec.width):

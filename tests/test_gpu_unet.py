@@ -358,6 +358,33 @@ def test_shipped_v6_config_matches_oracle():
     _check_u8(bf.DenoiserModule(m)(noisy), U.denoiser_module_call(spec, params, noisy))
 
 
+@pytest.mark.parametrize("up", ["upsample_nearest_conv2d", "upsample_laplacian_conv2d"], ids=["v3", "v4"])
+def test_shipped_v3_v4_configs_match_oracle(up):
+    """configs/unet_laplacian_v3.json / v4.json: 4 levels (32/64/128/256, self-attention on the 256-channel level) and
+    AdditiveAttentionGate in front of every decoder Add."""
+    cfg, spec, params, m = _model(depth=4, width=3, seed=8, use_attention_gates=True, upsample_type=up)
+    _, noisy = O.synthetic_batch(1, 64, 128, seed=8)
+    x = noisy.astype(np.float32)
+    got, ref = m(x), U.hydra_forward(spec, params, x.astype(np.float64))
+    assert len(got) == 4
+    for g, r in zip(got, ref):
+        _check_f32(g, r)
+    _check_u8(bf.DenoiserModule(m)(noisy), U.denoiser_module_call(spec, params, noisy))
+
+
+def test_pointwise_attention_gate_epilogues():
+    r = _rng(21)
+    C = 64
+    x, res, add = r.normal(size=(1, 1, 333, C)), r.normal(size=(1, 1, 333, C)), r.normal(size=(1, 1, 333, C))
+    w = r.normal(size=(1, 1, C, C)) / np.sqrt(C)
+    mult = r.uniform(0.2, 1.0, C)
+    wp = UL.pack_pointwise(dev(w))
+    acc = O.conv2d_same(x, w)
+    assert_close(host(UL.pointwise_ex(dev(x), wp, C, 1, "leaky_relu_01", res=dev(res))), U.act(acc + res, "leaky_relu_01"), what="mode 1")
+    ref = res / (1.0 + np.exp(-4.0 * mult * acc)) + add
+    assert_close(host(UL.pointwise_ex(dev(x), wp, C, 2, mult=dev(mult), res=dev(res), add=dev(add))), ref, what="mode 2")
+
+
 @pytest.mark.parametrize("arith", [1, 0], ids=["f16x3", "f32"])
 @pytest.mark.parametrize("hw", [(64, 64), (40, 50), (17, 100), (128, 128)])
 def test_denoiser_module_u8(hw, arith):

@@ -106,8 +106,10 @@ def _cfg(**bb):
 @pytest.mark.parametrize("bb", [dict(), dict(depth=2, width=1), dict(use_self_attention=False),
                                 dict(gaussian_kernel_size=2, decoder_kernel_size=5, upsample_type="upsample_nearest_conv2d",
                                      downsample_type="conv2d"),
-                                dict(use_mix_project=True, use_gamma=False, use_output_normalization=False)],
-                         ids=["v5", "small", "no-attention", "v6", "mix-no-gamma"])
+                                dict(use_mix_project=True, use_gamma=False, use_output_normalization=False),
+                                dict(depth=4, use_attention_gates=True, upsample_type="upsample_nearest_conv2d"),
+                                dict(depth=4, use_attention_gates=True)],
+                         ids=["v5", "small", "no-attention", "v6", "mix-no-gamma", "v3", "v4"])
 def test_product_inventory_matches_oracle(bb):
     import blind_image_denoising_amd as bf
     cfg = _cfg(**bb)
@@ -135,7 +137,7 @@ def test_product_rejects_what_the_reference_rejects_and_what_is_not_built():
         bf.model_builder(_cfg(convolutional_self_attention_dropout_rate=1.5), device="cpu")
     with pytest.raises(ValueError, match="only one"):
         bf.model_builder(_cfg(use_soft_orthogonal_regularization=True), device="cpu")
-    for bad in (dict(use_concat=True), dict(use_attention_gates=True), dict(use_bn=True), dict(depth=4),
+    for bad in (dict(use_concat=True), dict(use_bn=True), dict(depth=4, use_self_attention=False), dict(depth=5),
                 dict(upsample_type="conv2d_transpose")):
         with pytest.raises(NotImplementedError):
             bf.model_builder(_cfg(**bad), device="cpu")
