@@ -77,6 +77,7 @@ extern "C" int bf_op_pack_pointwise(const float* w, float* wp, int cin, int cout
 // mode 0: out = res + mult * act(acc)                      (1x1 convolution, activation, channel multiplier, residual Add)
 // mode 1: out = act(acc + res)                             (AdditiveAttentionGate: leaky_relu(conv_x(x) + conv_y(y)), custom_layers.py:823)
 // mode 2: out = res * sigmoid(4 * mult * acc) + add        (the gate applied to the encoder feature, :824-832, + the decoder Add)
+// mode 3: out = act(acc + mult) + res                      (convolution with a folded BatchNorm: mult = per-channel shift)
 template <int CIN, int COUT, int NP, int ACT>
 __global__ __launch_bounds__(256, 2) void uo_pointwise_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                            const float* __restrict__ wp, const float* __restrict__ mult,
@@ -153,6 +154,11 @@ __global__ __launch_bounds__(256, 2) void uo_pointwise_kernel(const float* __res
                     if (res) v += *reinterpret_cast<const f32x4*>(res + p * COUT + co);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = uo_act<ACT>(v[r], alpha);
+                } else if (mode == 3) {
+                    if (mult) v += *reinterpret_cast<const f32x4*>(mult + co);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = uo_act<ACT>(v[r], alpha);
+                    if (res) v += *reinterpret_cast<const f32x4*>(res + p * COUT + co);
                 } else {
                     if (mult) v *= *reinterpret_cast<const f32x4*>(mult + co);
                     const f32x4 e = *reinterpret_cast<const f32x4*>(res + p * COUT + co);
@@ -207,7 +213,7 @@ extern "C" int bf_op_pointwise(const float* in, float* out, const float* wp, con
 extern "C" int bf_op_pointwise_ex(const float* in, float* out, const float* wp, const float* mult, const float* res, const float* add,
                                   int64_t npix, int cin, int cout, int act, float alpha, int mode, void* stream)
 {
-    if (!in || !out || !wp || npix <= 0 || mode < 0 || mode > 2 || (mode == 2 && !res)) return BF_EINVAL;
+    if (!in || !out || !wp || npix <= 0 || mode < 0 || mode > 3 || (mode == 2 && !res)) return BF_EINVAL;
     if (((uintptr_t)in | (uintptr_t)out | (uintptr_t)wp | (uintptr_t)mult | (uintptr_t)res | (uintptr_t)add) % 16) return BF_EINVAL;
     return uo_pointwise_dispatch(in, out, wp, mult, res, npix, cin, cout, act, alpha, mode, add, (hipStream_t)stream);
 }
@@ -220,8 +226,9 @@ extern "C" int bf_op_pointwise_ex(const float* in, float* out, const float* wp, 
 // ------------------------------------------------------------------------------------------
 template <int CIN, int COUT, int NP, int ACT>
 __global__ __launch_bounds__(256, 2) void uo_conv2d_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                        const float* __restrict__ wp, const float* __restrict__ res, int B, int H,
-                                                        int W, int OH, int OW, int kh, int kw, int stride, int pt, int pl, float alpha)
+                                                        const float* __restrict__ wp, const float* __restrict__ res,
+                                                        const float* __restrict__ bias, int B, int H, int W, int OH, int OW, int kh,
+                                                        int kw, int stride, int pt, int pl, float alpha)
 {
     constexpr int KC = CIN / 16, T = COUT / 16;
     const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
@@ -282,6 +289,7 @@ __global__ __launch_bounds__(256, 2) void uo_conv2d_kernel(const float* __restri
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 f32x4 v = bf_acc_ready(acc[t][i]);
+                if (bias) v += *reinterpret_cast<const f32x4*>(bias + 16 * t + 4 * q);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = uo_act<ACT>(v[r], alpha);
                 if (res) v += *reinterpret_cast<const f32x4*>(res + p * COUT + 16 * t + 4 * q);
@@ -291,11 +299,11 @@ __global__ __launch_bounds__(256, 2) void uo_conv2d_kernel(const float* __restri
     }
 }
 
-extern "C" int bf_op_conv2d(const float* in, float* out, const float* wp, const float* res, int B, int H, int W, int cin, int cout,
-                            int kh, int kw, int stride, int act, float alpha, void* stream)
+extern "C" int bf_op_conv2d(const float* in, float* out, const float* wp, const float* res, const float* bias, int B, int H, int W,
+                            int cin, int cout, int kh, int kw, int stride, int act, float alpha, void* stream)
 {
     if (!in || !out || !wp || B <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return BF_EINVAL;
-    if (((uintptr_t)in | (uintptr_t)out | (uintptr_t)wp | (uintptr_t)res) % 16) return BF_EINVAL;
+    if (((uintptr_t)in | (uintptr_t)out | (uintptr_t)wp | (uintptr_t)res | (uintptr_t)bias) % 16) return BF_EINVAL;
     if (act < 0 || act > 3) return BF_EUNSUPPORTED;
     const int OH = (H + stride - 1) / stride, OW = (W + stride - 1) / stride;
     const int th = max((OH - 1) * stride + kh - H, 0), tw = max((OW - 1) * stride + kw - W, 0);
@@ -304,7 +312,7 @@ extern "C" int bf_op_conv2d(const float* in, float* out, const float* wp, const 
     hipStream_t s = (hipStream_t)stream;
     bool ok = false;
 #define UO_CV_A(CI, CO, NPP, A)                                                                                                \
-    hipLaunchKernelGGL((uo_conv2d_kernel<CI, CO, NPP, A>), dim3(uo_grid(npix, 4 * 16 * NPP, 256 * 8)), dim3(256), 0, s, in, out, wp, res, B,  \
+    hipLaunchKernelGGL((uo_conv2d_kernel<CI, CO, NPP, A>), dim3(uo_grid(npix, 4 * 16 * NPP, 256 * 8)), dim3(256), 0, s, in, out, wp, res, bias, B,  \
                        H, W, OH, OW, kh, kw, stride, pt, pl, alpha)
 #define UO_CV(CI, CO, NPP)                                                                                                     \
     if (cin == CI && cout == CO) {                                                                                             \
@@ -320,6 +328,51 @@ extern "C" int bf_op_conv2d(const float* in, float* out, const float* wp, const 
 #undef UO_CV
 #undef UO_CV_A
     if (!ok) return BF_EUNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// DepthwiseConv2D k x k with depth_multiplier m (output channel c * m + j, keras order), SAME zero padding, + per-channel
+// bias (a folded BatchNorm shift) + activation: the depthwise middle convolution of the shipped resnet config
+// (backbone_resnet.py:165-176; block_depthwise).  w [k][k][C][m]; thread = 4 consecutive OUTPUT channels of one pixel.
+__global__ __launch_bounds__(256) void uo_dwconv_mult_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            const float* __restrict__ w, const float* __restrict__ bias, int B, int H,
+                                                            int W, int C, int m, int k, int act, float alpha)
+{
+    const int CO = C * m, Cv = CO / 4, R = (k - 1) / 2;
+    const int64_t n = (int64_t)B * H * W * Cv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int co = (int)(i % Cv) * 4;
+        int64_t t = i / Cv;
+        const int x = (int)(t % W); t /= W;
+        const int y = (int)(t % H);
+        const int64_t b = t / H;
+        f32x4 acc = bias ? *reinterpret_cast<const f32x4*>(bias + co) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ky = 0; ky < k; ++ky) {
+            const int yy = y + ky - R;
+            if (yy < 0 || yy >= H) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int xx = x + kx - R;
+                if (xx < 0 || xx >= W) continue;
+                const float* px = in + ((b * H + yy) * W + xx) * C;
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (ky * k + kx) * CO + co);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += wv[j] * px[(co + j) / m];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = uo_act_rt(acc[j], act, alpha);
+        reinterpret_cast<f32x4*>(out)[i] = acc;
+    }
+}
+
+extern "C" int bf_op_dwconv_mult(const float* in, float* out, const float* w, const float* bias, int B, int H, int W, int C, int m,
+                                 int k, int act, float alpha, void* stream)
+{
+    if (!in || !out || !w || B <= 0 || H <= 0 || W <= 0 || C <= 0 || m <= 0 || k <= 0 || (C * m) % 4) return BF_EINVAL;
+    if (((uintptr_t)out | (uintptr_t)w | (uintptr_t)bias) % 16) return BF_EINVAL;
+    const int64_t n = (int64_t)B * H * W * (C * m / 4);
+    hipLaunchKernelGGL(uo_dwconv_mult_kernel, dim3(uo_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, w, bias, B, H, W, C, m,
+                       k, act, alpha);
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
 

@@ -443,17 +443,35 @@ class _SubModelView:
         return [v for v in self._hydra.trainable_variables if v.name.startswith(self._prefixes)]
 
 
+def _build_hydra(config: Dict, device=None, strict_snapshot: bool = False, seed: Optional[int] = None):
+    """backbone type -> model class: unet_laplacian; the 16-filter 3x3 resnet family (fused engine, trainable); any other
+    resnet the operator library covers (per-position kernels / filters, depthwise multipliers, groups; inference)."""
+    btype = str(config[BACKBONE_STR].get(TYPE_STR, "")).strip().lower()
+    if btype == "unet_laplacian":
+        from .unet_laplacian import UnetLaplacianHydra
+        return UnetLaplacianHydra(config, device=device, seed=seed)
+    try:
+        return HydraModel(config, device=device, strict_snapshot=strict_snapshot, seed=seed)
+    except NotImplementedError as first:
+        if btype != "resnet":
+            raise
+        from .resnet_generic import GenericResnetHydra
+        try:
+            return GenericResnetHydra(config, device=device, seed=seed)
+        except NotImplementedError as second:
+            raise NotImplementedError(f"{first}; generic resnet path: {second}") from None
+
+
 def model_builder(config: Dict, device=None, strict_snapshot: bool = False, seed: Optional[int] = None) -> BuilderResults:
     """bfcnn/model.py:58-162.  `config` is the `model` section ({"backbone":…, "denoiser":…})."""
-    if str(config[BACKBONE_STR].get(TYPE_STR, "")).strip().lower() == "unet_laplacian":
-        from .unet_laplacian import UnetLaplacianHydra
-        hydra = UnetLaplacianHydra(config, device=device, seed=seed)
-        logger.warning(f"Backbone model has [{hydra.depth}] outputs, probably of different scale or depth")
+    hydra = _build_hydra(config, device, strict_snapshot, seed)
+    if not isinstance(hydra, HydraModel):
+        outs = getattr(hydra, "depth", 1) if getattr(hydra, "multi_output", False) else 1
+        logger.warning(f"Backbone model has [{outs}] outputs, probably of different scale or depth")
         return BuilderResults(
             backbone=None, denoiser=None, hydra=hydra, options={},
             normalizer=build_normalize_model(min_value=hydra.v_min, max_value=hydra.v_max),
             denormalizer=build_denormalize_model(min_value=hydra.v_min, max_value=hydra.v_max))
-    hydra = HydraModel(config, device=device, strict_snapshot=strict_snapshot, seed=seed)
     vr = config[BACKBONE_STR].get("value_range", (0, 255))
     logger.warning(f"Backbone model has [1] outputs, probably of different scale or depth")
     return BuilderResults(
@@ -474,11 +492,13 @@ def save_model(hydra: HydraModel, directory: str, pipeline_config: Optional[Dict
     os.makedirs(directory, exist_ok=True)
     cfg = copy.deepcopy(pipeline_config) if pipeline_config else {MODEL_STR: hydra.config}
     cfg.setdefault(MODEL_STR, hydra.config)
-    if getattr(hydra, "multi_output", False):                   # unet_laplacian: flat parameter vector, no state
+    if not isinstance(hydra, HydraModel):                        # unet_laplacian / generic resnet: flat vectors + tensor table
         with open(os.path.join(directory, PIPELINE_FILE_STR), "w") as f:
             json.dump(cfg, f, indent=4)
         tv = hydra.trainable_variables
-        np.savez(os.path.join(directory, WEIGHTS_FILE_STR), params=hydra.get_weights(), state=np.zeros(0, np.float32),
+        w = hydra.get_weights()
+        params, state = w if isinstance(w, tuple) else (w, np.zeros(0, np.float32))
+        np.savez(os.path.join(directory, WEIGHTS_FILE_STR), params=params, state=state,
                  names=np.array([v[0] for v in tv]), offsets=np.array([v[3] for v in tv]))
         return
     cfg["strict_snapshot"] = not bool(hydra.desc.denormalize)
@@ -495,13 +515,14 @@ def load_hydra(directory: str, device=None) -> HydraModel:
     if not os.path.isfile(cfg_path) or not os.path.isfile(w_path):
         raise ValueError(f"model_path [{directory}] does not hold {PIPELINE_FILE_STR} + {WEIGHTS_FILE_STR}")
     cfg = load_config(cfg_path)
-    if str(cfg[MODEL_STR][BACKBONE_STR].get(TYPE_STR, "")).strip().lower() == "unet_laplacian":
-        from .unet_laplacian import UnetLaplacianHydra
-        hydra = UnetLaplacianHydra(cfg[MODEL_STR], device=device)
+    hydra = _build_hydra(cfg[MODEL_STR], device, bool(cfg.get("strict_snapshot", False)))
+    if not isinstance(hydra, HydraModel):
         with np.load(w_path) as z:
-            hydra.set_weights(z["params"])
+            if getattr(hydra, "n_state", 0):
+                hydra.set_weights(z["params"], z["state"])
+            else:
+                hydra.set_weights(z["params"])
         return hydra
-    hydra = HydraModel(cfg[MODEL_STR], device=device, strict_snapshot=bool(cfg.get("strict_snapshot", False)))
     with np.load(w_path) as z:
         hydra.set_weights(z["params"], z["state"])
     return hydra

@@ -1,0 +1,256 @@
+"""Resnet backbones outside the 16-filter 3x3 family (bfcnn/backbone_resnet.py:36-298): per-position kernel sizes and
+filters, depthwise convolutions with a depth multiplier, grouped convolutions -- e.g. the config the reference ships,
+`resnet_color_1x6_bn_32x128x32_1x3x1_..._depthwise` (1x1 32->32, depthwise 3x3 x4, grouped 1x1 128->32).  Inference only, on
+the operator library of csrc/unet_ops.hip: first convolution, 1x1 / k x k matrix-core convolutions with the BatchNorm
+folded (scale into the weights at pack time, shift as the epilogue bias), depthwise-with-multiplier kernel, fused head.
+The 16-filter 3x3 family keeps its own engine (`HydraModel`, fused split-f16 blocks, training)."""
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _native as N
+from . import unet_laplacian as UL
+from .custom_logger import logger
+
+BN_EPSILON = 1e-3          # DEFAULT_BN_EPSILON (bfcnn/constants.py:9)
+
+
+class GenericResnetHydra:
+    multi_output = False
+    auto_exact_fallback = False
+
+    class _Desc:
+        def __init__(self, cin, cout):
+            self.in_channels, self.out_channels = cin, cout
+            self.denormalize = 1
+
+    def __init__(self, config: Dict, device=None, seed: Optional[int] = None):
+        bb, dn = config["backbone"], config["denoiser"]
+        self.config = config
+        for key in ("add_gelu", "add_gates", "add_final_bn", "add_initial_bn", "add_concat_input", "add_gradient_dropout",
+                    "add_channelwise_scaling", "add_learnable_multiplier", "add_mean_sigma_normalization", "use_bias"):
+            if bb.get(key, False):
+                raise NotImplementedError(f"resnet: {key} is outside the built graph")
+        if bb.get("selector_params") is not None or bb.get("base_conv_params") is not None:
+            raise NotImplementedError("resnet: selector_params / base_conv_params are outside the built graph")
+        if dn.get("use_bias", False) or dn.get("use_bn", False) or dn.get("use_ln", False):
+            raise NotImplementedError("denoiser head: use_bias / use_bn / use_ln are outside the built graph")
+        self.filters = int(bb.get("filters", 32))
+        self.kernel_size = int(bb.get("kernel_size", 3))
+        self.no_layers = int(bb["no_layers"])
+        self.block_kernels = list(bb.get("block_kernels", [3, 3]))
+        nb = len(self.block_kernels)
+        if nb <= 0:
+            raise ValueError("len(block_kernels) must be >= 0 ")                     # backbone_resnet.py:110-113
+        if nb > 3:
+            raise ValueError("len(block_kernels) must be <= 3")
+        self.block_filters = list(bb.get("block_filters", [self.filters] * nb))
+        self.block_depthwise = list(bb.get("block_depthwise") or [-1] * nb)
+        self.block_groups = list(bb.get("block_groups") or [1] * nb)
+        act = bb.get("activation", "relu")
+        self.block_activation = list(bb.get("block_activation") or [act] * nb)
+        if not (len(self.block_filters) == len(self.block_depthwise) == len(self.block_groups) == len(self.block_activation) == nb):
+            raise ValueError("len(block_filters) must == len(block_kernels)")         # :116-126
+        self.base_activation = bb.get("base_activation", "linear")
+        self.block_activation[-1] = self.base_activation                              # :178
+        self.use_bn = bool(bb.get("use_bn", True))
+        self.in_channels = int(bb["input_shape"][-1])
+        vr = bb.get("value_range", [0, 255])
+        self.v_min, self.v_max = float(vr[0]), float(vr[1])
+        self.head_filters = int(dn.get("filters", 32))
+        self.head_activation = dn.get("activation", "linear")
+        self.out_channels = int(dn.get("output_channels", 3))
+        for a in self.block_activation + [self.base_activation, self.head_activation]:
+            UL._act(a)
+        # channel bookkeeping + what the operators cover
+        ok_c = (32, 64, 128)
+        cin = self.filters
+        if cin not in ok_c:
+            raise NotImplementedError(f"resnet: filters={cin} (32 / 64 / 128 are built here; 16 has its own engine)")
+        for kk, cf, dm, g in zip(self.block_kernels, self.block_filters, self.block_depthwise, self.block_groups):
+            cout = cin * dm if dm != -1 else cf
+            if cout not in ok_c or (dm == -1 and (cin % g or cf % g)):
+                raise NotImplementedError(f"resnet: a block convolution {cin}->{cout} (groups {g}) is outside the built operators")
+            cin = cout
+        if cin != self.filters:
+            raise ValueError(f"the last block convolution must produce {self.filters} channels for the residual Add (got {cin})")
+        if self.head_filters != 32 or self.kernel_size > 7:
+            raise NotImplementedError("resnet: head filters must be 32 and the base kernel at most 7x7")
+        self.desc = self._Desc(self.in_channels, self.out_channels)
+        self.device = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self._inventory, self._state_inventory = self._build_inventory()
+        self.n_params = sum(int(np.prod(s)) for _, s, _ in self._inventory)
+        self.n_state = sum(int(np.prod(s)) for _, s in self._state_inventory)
+        self.params = torch.from_numpy(self._initial_values(seed)).to(self.device)
+        st = np.concatenate([np.zeros(s, np.float32).ravel() if n.endswith("mean") else np.ones(s, np.float32).ravel()
+                             for n, s in self._state_inventory]) if self._state_inventory else np.zeros(0, np.float32)
+        self.state = torch.from_numpy(st).to(self.device)
+        self._packed = None
+
+    # -- inventory ---------------------------------------------------------------------------
+    def _build_inventory(self):
+        k = self.kernel_size
+        out = [("base/kernel", (k, k, self.in_channels, self.filters), "conv")]
+        state = []
+        for i in range(self.no_layers):
+            cin = self.filters
+            for j, (kk, cf, dm, g) in enumerate(zip(self.block_kernels, self.block_filters, self.block_depthwise, self.block_groups)):
+                if dm != -1:
+                    out.append((f"block{i}/conv{j}/kernel", (kk, kk, cin, dm), "depthwise"))
+                    cout = cin * dm
+                else:
+                    out.append((f"block{i}/conv{j}/kernel", (kk, kk, cin // g, cf), "conv"))
+                    cout = cf
+                if j >= 1 and self.use_bn:              # the first convolution of a block has no BN (backbone_blocks.py:174-179)
+                    out.append((f"block{i}/bn{j}/gamma", (cout,), "bn_gamma"))
+                    state += [(f"block{i}/bn{j}/moving_mean", (cout,)), (f"block{i}/bn{j}/moving_variance", (cout,))]
+                cin = cout
+        out.append(("head/conv0/kernel", (1, 1, self.filters, self.head_filters), "conv"))
+        out.append(("head/conv1/kernel", (1, 1, self.head_filters, self.out_channels), "conv"))
+        return out, state
+
+    @property
+    def trainable_variables(self):
+        o, res = 0, []
+        for name, shape, kind in self._inventory:
+            res.append((name, shape, kind, o))
+            o += int(np.prod(shape))
+        return res
+
+    @property
+    def non_trainable_variables(self):
+        o, res = 0, []
+        for name, shape in self._state_inventory:
+            res.append((name, shape, o))
+            o += int(np.prod(shape))
+        return res
+
+    def count_params(self) -> int:
+        return self.n_params
+
+    def _initial_values(self, seed) -> np.ndarray:
+        from .model import glorot_normal
+        rng = np.random.default_rng(seed)
+        return np.concatenate([np.asarray(np.ones(s) if kind == "bn_gamma" else glorot_normal(s, rng), np.float32).ravel()
+                               for _, s, kind in self._inventory])
+
+    def get_weights(self):
+        return self.params.detach().cpu().numpy(), self.state.detach().cpu().numpy()
+
+    def set_weights(self, params: np.ndarray, state: Optional[np.ndarray] = None):
+        params = np.ascontiguousarray(params, np.float32).ravel()
+        if params.size != self.n_params:
+            raise ValueError(f"expected {self.n_params} parameters, got {params.size}")
+        self.params.copy_(torch.from_numpy(params))
+        if state is not None:
+            state = np.ascontiguousarray(state, np.float32).ravel()
+            if state.size != self.n_state:
+                raise ValueError(f"expected {self.n_state} state values, got {state.size}")
+            self.state.copy_(torch.from_numpy(state))
+        self._packed = None
+
+    def set_option(self, key: str, value: int):
+        raise ValueError(f"unknown option {key}={value}")
+
+    def check_status(self, raise_on_overflow: bool = True) -> bool:
+        return True
+
+    # -- packing (host arithmetic on the weights only: BatchNorm folding, block-diagonal grouped kernels) ----------------
+    def _pack(self):
+        if self._packed is not None:
+            return self._packed
+        w, st = self.get_weights()
+        W = {n: w[o:o + int(np.prod(s))].reshape(s).astype(np.float64) for n, s, _, o in self.trainable_variables}
+        S = {n: st[o:o + int(np.prod(s))].reshape(s).astype(np.float64) for n, s, o in self.non_trainable_variables}
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.device)
+        P = {"base": dev(W["base/kernel"])}
+        for i in range(self.no_layers):
+            cin = self.filters
+            for j, (kk, cf, dm, g) in enumerate(zip(self.block_kernels, self.block_filters, self.block_depthwise, self.block_groups)):
+                k = W[f"block{i}/conv{j}/kernel"]
+                cout = cin * dm if dm != -1 else cf
+                scale, shift = np.ones(cout), None
+                if j >= 1 and self.use_bn:              # inference BN folded: y = gamma (x - mean) / sqrt(var + eps), center=False
+                    base = f"block{i}/bn{j}"
+                    scale = W[base + "/gamma"] / np.sqrt(S[base + "/moving_variance"] + BN_EPSILON)
+                    shift = -scale * S[base + "/moving_mean"]
+                if dm != -1:
+                    kf = (k * scale.reshape(cin, dm)[None, None]).reshape(kk, kk, cin * dm)
+                    P[f"b{i}c{j}"] = ("dw", dev(kf.reshape(kk, kk, cin, dm)), None if shift is None else dev(shift))
+                else:
+                    dense = np.zeros((kk, kk, cin, cf))     # grouped convolution as a block-diagonal dense one
+                    ci_g, co_g = cin // g, cf // g
+                    for gi in range(g):
+                        dense[:, :, gi * ci_g:(gi + 1) * ci_g, gi * co_g:(gi + 1) * co_g] = k[:, :, :, gi * co_g:(gi + 1) * co_g]
+                    dense = dense * scale[None, None, None, :]
+                    packed = UL.pack_pointwise(dev(dense[0, 0])) if kk == 1 else UL.pack_conv(dev(dense))
+                    P[f"b{i}c{j}"] = ("pw" if kk == 1 else "conv", packed, None if shift is None else dev(shift))
+                cin = cout
+        P["head0"] = UL.pack_pointwise(dev(W["head/conv0/kernel"][0, 0]))
+        P["head1"] = dev(W["head/conv1/kernel"])
+        self._packed = P
+        return P
+
+    # -- forward -----------------------------------------------------------------------------
+    def _require_gpu(self):
+        if self.device.type != "cuda":
+            raise RuntimeError("resnet inference needs the GPU: there is no CPU execution path")
+
+    def _features(self, x: torch.Tensor, H: int, W: int) -> torch.Tensor:
+        P = self._pack()
+        f = UL.first_conv(x, P["base"], H, W, self.base_activation, True, self.v_min, self.v_max)
+        nb = len(self.block_kernels)
+        for i in range(self.no_layers):
+            t = f
+            for j in range(nb):
+                kind, wp, shift = P[f"b{i}c{j}"]
+                res = f if j == nb - 1 else None          # Add(block output, block input) (backbone_blocks.py:242)
+                a = self.block_activation[j]
+                if kind == "dw":
+                    t = UL.dwconv_mult(t, wp, shift, a)
+                    if res is not None:
+                        raise NotImplementedError("a depthwise convolution as the last convolution of a block")
+                elif kind == "pw":
+                    cout = self.block_filters[j]
+                    t = UL.pointwise_ex(t, wp, cout, 3, a, mult=shift, res=res)
+                else:
+                    t = UL.conv2d(t, wp, self.block_filters[j], self.block_kernels[j], 1, a, res=res, bias=shift)
+            f = t
+        return f
+
+    def _as_device(self, x):
+        was_numpy = isinstance(x, np.ndarray)
+        if was_numpy:
+            x = torch.from_numpy(np.ascontiguousarray(x))
+        if x.dim() != 4 or x.shape[-1] != self.in_channels:
+            raise ValueError(f"expected [B,H,W,{self.in_channels}], got {tuple(x.shape)}")
+        if x.dtype != torch.uint8:
+            x = x.to(torch.float32)
+        return x.to(self.device).contiguous(), was_numpy
+
+    def __call__(self, x, training: bool = False):
+        if training:
+            raise NotImplementedError("resnet configs outside the 16-filter 3x3 family: only inference is built")
+        self._require_gpu()
+        x, was_numpy = self._as_device(x)
+        B, H, W, _ = x.shape
+        P = self._pack()
+        out = UL.head_fused(self._features(x, H, W), None, P["head0"], self.head_activation, P["head1"], H, W, False, True,
+                            self.v_min, self.v_max)
+        if was_numpy:
+            torch.cuda.synchronize(self.device)
+            return out.cpu().numpy()
+        return out
+
+    def predict(self, x):
+        return self(x)
+
+    def infer_u8(self, image: torch.Tensor) -> torch.Tensor:
+        from .utilities import next_power_of_2
+        self._require_gpu()
+        B, Hs, Ws, _ = image.shape
+        H, W = next_power_of_2(Hs), next_power_of_2(Ws)
+        P = self._pack()
+        return UL.head_fused(self._features(image, H, W), None, P["head0"], self.head_activation, P["head1"], Hs, Ws, True, True,
+                             self.v_min, self.v_max)

@@ -152,12 +152,23 @@ def pack_conv(w: torch.Tensor) -> torch.Tensor:
 
 
 def conv2d(x: torch.Tensor, wp: torch.Tensor, cout: int, k: int, stride: int = 1, act: str = "linear",
-           res: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Conv2D k x k, strides, padding="same", no bias (+ activation, + res)."""
+           res: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Conv2D k x k, strides, padding="same": res + act(conv(x) + bias)."""
     B, H, W, cin = x.shape
     out = torch.empty((B, -(-H // stride), -(-W // stride), cout), dtype=torch.float32, device=x.device)
     code, a = _act(act)
-    _call("bf_op_conv2d", N.ptr(x), N.ptr(out), N.ptr(wp), N.ptr(res), B, H, W, cin, cout, k, k, stride, code, a, N.stream_ptr(x))
+    _call("bf_op_conv2d", N.ptr(x), N.ptr(out), N.ptr(wp), N.ptr(res), N.ptr(bias), B, H, W, cin, cout, k, k, stride, code, a,
+          N.stream_ptr(x))
+    return out
+
+
+def dwconv_mult(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: str = "linear") -> torch.Tensor:
+    """DepthwiseConv2D k x k with depth_multiplier m (w [k,k,C,m]) + bias + activation."""
+    B, H, W, C = x.shape
+    k, m = int(w.shape[0]), int(w.shape[-1])
+    out = torch.empty((B, H, W, C * m), dtype=torch.float32, device=x.device)
+    code, a = _act(act)
+    _call("bf_op_dwconv_mult", N.ptr(x), N.ptr(out), N.ptr(w), N.ptr(bias), B, H, W, C, m, k, code, a, N.stream_ptr(x))
     return out
 
 

@@ -201,16 +201,22 @@ int bf_op_pack_pointwise(const float* w, float* wp, int cin, int cout, void* str
 /* Conv2D 1x1, use_bias=False (utilities.py:196): out = res + mult * act(in . w); mult [cout] / res [npix][cout] may be NULL. */
 int bf_op_pointwise(const float* in, float* out, const float* wp, const float* mult, const float* res, int64_t npix,
                     int cin, int cout, int act, float alpha, void* stream);
-/* Conv2D kh x kw, strides s, padding="same", use_bias=False (utilities.py:196): out = res + act(conv(in)); wp = kh*kw
+/* Conv2D kh x kw, strides s, padding="same" (utilities.py:196): out = res + act(conv(in) + bias), bias [cout] (a folded
+ * BatchNorm shift) / res may be NULL; wp = kh*kw
  * tap matrices [cin][cout], each packed by bf_op_pack_pointwise, tap-major; cin, cout in {32, 64, 128}.  Serves the
  * "conv2d" downsample (2x2 stride 2, downsampling.py:45-55) and the 3x3 convolution of upsample_bilinear_conv2d /
  * upsample_nearest_conv2d (upsampling.py:52-72). */
-int bf_op_conv2d(const float* in, float* out, const float* wp, const float* res, int batch, int height, int width, int cin,
-                 int cout, int kh, int kw, int stride, int act, float alpha, void* stream);
+int bf_op_conv2d(const float* in, float* out, const float* wp, const float* res, const float* bias, int batch, int height,
+                 int width, int cin, int cout, int kh, int kw, int stride, int act, float alpha, void* stream);
+/* DepthwiseConv2D k x k, depth_multiplier m (output channel c*m + j), padding="same", + bias[C*m] (folded BatchNorm shift,
+ * may be NULL) + activation (backbone_resnet.py:165-176, block_depthwise); w [k][k][C][m]. */
+int bf_op_dwconv_mult(const float* in, float* out, const float* w, const float* bias, int batch, int height, int width,
+                      int channels, int multiplier, int k, int act, float alpha, void* stream);
 /* MaxPooling2D(2, 2, padding="same") (downsampling.py:56-58). */
 int bf_op_maxpool2(const float* in, float* out, int batch, int height, int width, int channels, void* stream);
 /* The same 1x1 convolution with the epilogues of AdditiveAttentionGate (custom_layers.py:805-832):
- * mode 0 = bf_op_pointwise;  mode 1: out = act(in . w + res);  mode 2: out = res * sigmoid(4 * mult * (in . w)) + add. */
+ * mode 0 = bf_op_pointwise;  mode 1: out = act(in . w + res);  mode 2: out = res * sigmoid(4 * mult * (in . w)) + add;
+ * mode 3: out = act(in . w + mult) + res (mult = per-channel bias: a convolution with a folded BatchNorm). */
 int bf_op_pointwise_ex(const float* in, float* out, const float* wp, const float* mult, const float* res, const float* add,
                        int64_t npix, int cin, int cout, int act, float alpha, int mode, void* stream);
 /* ConvNextBlock conv_2 -> activation -> conv_3 -> ChannelLearnableMultiplier -> Add(skip, .) (custom_layers.py:990-1008;

@@ -1,0 +1,172 @@
+"""CPU oracle for resnet backbones outside the 16-filter 3x3 family: per-block kernel sizes / filters, depthwise
+convolutions with a depth multiplier and grouped convolutions, as in the one resnet config the reference ships
+(`configs/resnet_color_1x6_bn_32x128x32_1x3x1_128x128_depthwise_l1_relu.json`).  Inference only.
+
+TEST INFRASTRUCTURE ONLY (tests/, smoke, bench cpu_baseline).  NumPy fp64 restatement of
+  bfcnn/backbone_resnet.py:36-298 (builder: conv params per block position, last activation = base_activation),
+  bfcnn/backbone_blocks.py:163-246 (first conv without BN, second / third with BN, Add),
+  bfcnn/utilities.py:132-224 (conv2d_wrapper: conv -> BN -> activation; depth_multiplier => DepthwiseConv2D),
+  bfcnn/model.py:58-162, 251-359 (normalise, head 1x1 -> 1x1 -> tanh(2x)*0.51, denormalise).
+Parity unpinned beyond structure for the same reason as the other oracles (TensorFlow 2.13.1 absent, no golden vectors)."""
+from dataclasses import dataclass
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from . import bfcnn_oracle as O
+
+F64 = np.float64
+BN_EPS = 1e-3
+
+
+def depthwise_mult_same(x: np.ndarray, w: np.ndarray) -> np.ndarray:
+    """keras DepthwiseConv2D(depth_multiplier=m, padding="same"): w [kh,kw,C,m], output channel c*m + j."""
+    B, H, W, C = x.shape
+    kh, kw, _, m = w.shape
+    _, pt, pb = O.same_pads(H, kh, 1)
+    _, pl, pr = O.same_pads(W, kw, 1)
+    xp = np.zeros((B, H + pt + pb, W + pl + pr, C), dtype=x.dtype)
+    xp[:, pt:pt + H, pl:pl + W, :] = x
+    y = np.zeros((B, H, W, C, m), dtype=np.result_type(x.dtype, w.dtype))
+    for i in range(kh):
+        for j in range(kw):
+            y += xp[:, i:i + H, j:j + W, :, None] * w[i, j][None, None, None]
+    return y.reshape(B, H, W, C * m)
+
+
+def grouped_conv_same(x: np.ndarray, w: np.ndarray, groups: int) -> np.ndarray:
+    """keras Conv2D(groups=g): w [kh,kw,cin/g,cout]; group i maps input channels [i cin/g, (i+1) cin/g) to output channels
+    [i cout/g, (i+1) cout/g)."""
+    if groups == 1:
+        return O.conv2d_same(x, w)
+    cin_g, cout_g = w.shape[2], w.shape[3] // groups
+    return np.concatenate([O.conv2d_same(x[..., g * cin_g:(g + 1) * cin_g], w[..., g * cout_g:(g + 1) * cout_g])
+                           for g in range(groups)], axis=-1)
+
+
+@dataclass(frozen=True)
+class GenericResnetSpec:
+    filters: int
+    kernel_size: int
+    no_layers: int
+    block_kernels: Tuple[int, ...]
+    block_filters: Tuple[int, ...]
+    block_depthwise: Tuple[int, ...]
+    block_groups: Tuple[int, ...]
+    block_activation: Tuple[str, ...]
+    base_activation: str = "linear"
+    use_bn: bool = True
+    in_channels: int = 3
+    head_filters: int = 32
+    head_activation: str = "linear"
+    out_channels: int = 3
+    v_min: float = 0.0
+    v_max: float = 255.0
+
+    @staticmethod
+    def from_config(model_config: Dict) -> "GenericResnetSpec":
+        bb, dn = model_config["backbone"], model_config["denoiser"]
+        bk = tuple(bb.get("block_kernels", [3, 3]))
+        act = bb.get("activation", "relu")
+        ba = list(bb.get("block_activation") or [act] * len(bk))
+        base_act = bb.get("base_activation", "linear")
+        ba[-1] = base_act                                            # backbone_resnet.py:178
+        vr = bb.get("value_range", [0, 255])
+        return GenericResnetSpec(
+            filters=bb.get("filters", 32), kernel_size=bb.get("kernel_size", 3), no_layers=bb["no_layers"], block_kernels=bk,
+            block_filters=tuple(bb.get("block_filters", [bb.get("filters", 32)] * len(bk))),
+            block_depthwise=tuple(bb.get("block_depthwise") or [-1] * len(bk)),
+            block_groups=tuple(bb.get("block_groups") or [1] * len(bk)), block_activation=tuple(ba),
+            base_activation=base_act, use_bn=bb.get("use_bn", True), in_channels=bb["input_shape"][-1],
+            head_filters=dn.get("filters", 32), head_activation=dn.get("activation", "linear"),
+            out_channels=dn.get("output_channels", 3), v_min=float(vr[0]), v_max=float(vr[1]))
+
+    def tensors(self) -> List[Tuple[str, Tuple[int, ...], str]]:
+        """(name, shape, kind) in graph-construction order; kind in conv | depthwise | bn_gamma."""
+        k = self.kernel_size
+        out = [("base/kernel", (k, k, self.in_channels, self.filters), "conv")]
+        for i in range(self.no_layers):
+            cin = self.filters
+            for j, (kk, cf, dm, g) in enumerate(zip(self.block_kernels, self.block_filters, self.block_depthwise, self.block_groups)):
+                if dm != -1:
+                    out.append((f"block{i}/conv{j}/kernel", (kk, kk, cin, dm), "depthwise"))
+                    cout = cin * dm
+                else:
+                    out.append((f"block{i}/conv{j}/kernel", (kk, kk, cin // g, cf), "conv"))
+                    cout = cf
+                if j >= 1 and self.use_bn:
+                    out.append((f"block{i}/bn{j}/gamma", (cout,), "bn_gamma"))
+                cin = cout
+        out.append(("head/conv0/kernel", (1, 1, self.filters, self.head_filters), "conv"))
+        out.append(("head/conv1/kernel", (1, 1, self.head_filters, self.out_channels), "conv"))
+        return out
+
+    def state_tensors(self) -> List[Tuple[str, Tuple[int, ...]]]:
+        out = []
+        for name, shape, kind in self.tensors():
+            if kind == "bn_gamma":
+                base = name[:-len("/gamma")]
+                out += [(base + "/moving_mean", shape), (base + "/moving_variance", shape)]
+        return out
+
+
+def init_params(spec: GenericResnetSpec, seed: int = 42) -> Tuple[np.ndarray, np.ndarray]:
+    rng = np.random.default_rng(seed)
+    params = []
+    for name, shape, kind in spec.tensors():
+        if kind == "bn_gamma":
+            params.append(rng.uniform(0.5, 1.5, shape))
+        else:
+            params.append(O.glorot_normal(shape if len(shape) == 4 else shape, rng))
+    state = []
+    for name, shape in spec.state_tensors():
+        state.append(rng.normal(0, 0.1, shape) if name.endswith("mean") else rng.uniform(0.5, 1.5, shape))
+    cat = lambda parts: np.concatenate([np.asarray(p, np.float32).ravel() for p in parts]) if parts else np.zeros(0, np.float32)
+    return cat(params), cat(state)
+
+
+def _views(items, flat, dtype):
+    out, o = {}, 0
+    for item in items:
+        name, shape = item[0], item[1]
+        n = int(np.prod(shape))
+        out[name] = np.asarray(flat[o:o + n]).reshape(shape).astype(dtype)
+        o += n
+    return out
+
+
+def hydra_forward(spec: GenericResnetSpec, params: np.ndarray, state: np.ndarray, x: np.ndarray, dtype=F64) -> np.ndarray:
+    P = _views(spec.tensors(), params, dtype)
+    S = _views(spec.state_tensors(), state, dtype)
+    f = O.activation_fwd(O.conv2d_same(O.layer_normalize(x.astype(dtype), spec.v_min, spec.v_max), P["base/kernel"]),
+                         spec.base_activation)
+    for i in range(spec.no_layers):
+        t = f
+        for j, (dm, g, a) in enumerate(zip(spec.block_depthwise, spec.block_groups, spec.block_activation)):
+            w = P[f"block{i}/conv{j}/kernel"]
+            t = depthwise_mult_same(t, w) if dm != -1 else grouped_conv_same(t, w, g)
+            if j >= 1 and spec.use_bn:                                   # first conv: bn_params=None (backbone_blocks.py:174-179)
+                base = f"block{i}/bn{j}"
+                t = O.bn_infer(t, P[base + "/gamma"], S[base + "/moving_mean"], S[base + "/moving_variance"], BN_EPS)
+            t = O.activation_fwd(t, a)
+        f = t + f
+    h = O.activation_fwd(O.conv2d_same(f, P["head/conv0/kernel"]), spec.head_activation)
+    h = O.conv2d_same(h, P["head/conv1/kernel"])
+    return O.layer_denormalize(np.tanh(2.0 * h) * 0.51, spec.v_min, spec.v_max)
+
+
+def denoiser_module_call(spec: GenericResnetSpec, params, state, image_u8: np.ndarray, cast_to_uint8: bool = True):
+    xp, ph, pw = O.pad_to_power_of_2(image_u8.astype(F64))
+    y = O.remove_padding(hydra_forward(spec, params, state, xp), ph, pw)
+    return np.clip(O.round_half_even(y), 0, 255).astype(np.uint8) if cast_to_uint8 else y
+
+
+def shipped_config() -> Dict:
+    """model section of configs/resnet_color_1x6_bn_32x128x32_1x3x1_128x128_depthwise_l1_relu.json (backbone values as
+    shipped; the denoiser section of that file carries only regulariser / initialiser settings)."""
+    return {"backbone": {"type": "resnet", "filters": 32, "no_layers": 6, "kernel_size": 7, "block_kernels": [1, 3, 1],
+                         "block_filters": [32, 128, 32], "block_depthwise": [-1, 4, -1], "block_regularizer": ["l1", "l1", "l1"],
+                         "block_activation": ["relu", "relu", "linear"], "block_groups": [1, 1, 2], "value_range": [0, 255],
+                         "batchnorm": True, "activation": "relu", "add_final_bn": False, "input_shape": ["?", "?", 3],
+                         "kernel_regularizer": "l1", "kernel_initializer": "glorot_normal"},
+            "denoiser": {"output_channels": 3, "kernel_regularizer": "l1", "kernel_initializer": "glorot_normal"}}

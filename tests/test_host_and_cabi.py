@@ -101,9 +101,12 @@ def test_create_rejects_what_the_reference_rejects():
     bad = json.loads(json.dumps(cfg)); bad["backbone"]["type"] = "efficientnet"
     with pytest.raises(NotImplementedError):
         bf.model_builder(bad, device="cpu")
-    bad = json.loads(json.dumps(cfg)); bad["backbone"]["filters"] = 32; bad["backbone"]["block_filters"] = [32, 32]
+    bad = json.loads(json.dumps(cfg)); bad["backbone"]["filters"] = 48; bad["backbone"]["block_filters"] = [48, 48]
     with pytest.raises(NotImplementedError, match="16"):
         bf.model_builder(bad, device="cpu")
+    # 32 / 64 / 128 filters go to the generic resnet model (operator library, inference only)
+    ok = json.loads(json.dumps(cfg)); ok["backbone"]["filters"] = 32; ok["backbone"]["block_filters"] = [32, 32]
+    assert type(bf.model_builder(ok, device="cpu").hydra).__name__ == "GenericResnetHydra"
     d = N.ResnetDesc()
     h = C.c_void_p()
     assert N.lib().bf_create(C.byref(d), C.byref(h)) == N.BF_EINVAL and not h.value
