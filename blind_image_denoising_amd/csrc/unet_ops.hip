@@ -376,6 +376,118 @@ extern "C" int bf_op_dwconv_mult(const float* in, float* out, const float* w, co
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
 
+// Depthwise k x k with depth multiplier M (+ bias1, act1) followed by a 1x1 convolution HID = CIN * M -> COUT (+ bias2, act2,
+// + res) in ONE kernel: the bottleneck tail of the shipped resnet config (depthwise 3x3 x4 -> BN -> ReLU -> grouped 1x1 ->
+// BN -> Add, backbone_resnet.py:149-178; both BatchNorms folded, the grouped kernel packed block-diagonal).  The HID-wide
+// tensor (4x the block's traffic) never reaches memory: a workgroup stages the CIN-channel input tile of 8 x 32 pixels
+// (+ halo) and the depthwise weights in LDS; lane (q, n) of a wave computes hidden channels 16c + 4q + j of pixel n --
+// exactly the B operand of step j of chunk c of the fp32 16x16x4 MFMA GEMM (weights packed by bf_op_pack_pointwise).
+constexpr int UO_DP_TH = 8, UO_DP_TW = 32;
+template <int CIN, int M, int COUT, int K>
+__global__ __launch_bounds__(256) void uo_dwmult_pw_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          const float* __restrict__ wd, const float* __restrict__ bias1, int act1,
+                                                          float alpha1, const float* __restrict__ wp, const float* __restrict__ bias2,
+                                                          int act2, float alpha2, const float* __restrict__ res, int H, int W)
+{
+    constexpr int HID = CIN * M, KC = HID / 16, T = COUT / 16, RAD = (K - 1) / 2, IH = UO_DP_TH + K - 1, IW = UO_DP_TW + K - 1;
+    static_assert(M == 1 || M == 2 || M == 4, "depth multiplier");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* tile = lds;                                   // [IH][IW][CIN]
+    float* wl = lds + IH * IW * CIN;                     // [K*K][CIN][M]
+    const int x0 = blockIdx.x * UO_DP_TW, y0 = blockIdx.y * UO_DP_TH;
+    const int64_t img = (int64_t)blockIdx.z * H * W;
+    for (int e = threadIdx.x; e < IH * IW * (CIN / 4); e += 256) {
+        const int c4 = e % (CIN / 4), px = (e / (CIN / 4)) % IW, py = e / ((CIN / 4) * IW);
+        const int yy = y0 + py - RAD, xx = x0 + px - RAD;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = *reinterpret_cast<const f32x4*>(in + (img + (int64_t)yy * W + xx) * CIN + 4 * c4);
+        reinterpret_cast<f32x4*>(tile)[e] = v;
+    }
+    for (int e = threadIdx.x; e < K * K * HID; e += 256) wl[e] = wd[e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, n = lane & 15;
+    const f32x4* wv = reinterpret_cast<const f32x4*>(wp) + lane;
+    for (int gi = wave; gi < UO_DP_TH * (UO_DP_TW / 16); gi += 4) {
+        const int ry = gi / (UO_DP_TW / 16), cx = (gi % (UO_DP_TW / 16)) * 16 + n;
+        const float* base = tile + (ry * IW + cx) * CIN;
+        f32x4 acc[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int h0 = 16 * c + 4 * q;               // the lane's 4 hidden channels of this chunk
+            f32x4 hv = bias1 ? *reinterpret_cast<const f32x4*>(bias1 + h0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const float* px = base + (ky * IW + kx) * CIN;
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl + (ky * K + kx) * HID + h0);   // [tap][ic][mi] == [tap][h]
+                    if (M == 4) {
+                        hv += w4 * px[h0 / 4];
+                    } else if (M == 2) {
+                        const float a = px[h0 / 2], b2 = px[h0 / 2 + 1];
+                        hv += w4 * (f32x4){a, a, b2, b2};
+                    } else {
+                        hv += w4 * *reinterpret_cast<const f32x4*>(px + h0);
+                    }
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hv[j] = uo_act_rt(hv[j], act1, alpha1);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const f32x4 a = wv[(c * T + t) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t] = MFMA4(a[j], hv[j], acc[t]);
+            }
+        }
+        const int gy = y0 + ry, gx = x0 + cx;
+        if (gy < H && gx < W) {
+            const int64_t p = img + (int64_t)gy * W + gx;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                f32x4 v = bf_acc_ready(acc[t]);
+                const int co = 16 * t + 4 * q;
+                if (bias2) v += *reinterpret_cast<const f32x4*>(bias2 + co);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = uo_act_rt(v[r], act2, alpha2);
+                if (res) v += *reinterpret_cast<const f32x4*>(res + p * COUT + co);
+                *reinterpret_cast<f32x4*>(out + p * COUT + co) = v;
+            }
+        }
+    }
+}
+
+extern "C" int bf_op_dwmult_pointwise(const float* in, float* out, const float* wd, const float* bias1, int act1, float alpha1,
+                                      const float* wp, const float* bias2, int act2, float alpha2, const float* res, int B, int H,
+                                      int W, int cin, int m, int k, int cout, void* stream)
+{
+    if (!in || !out || !wd || !wp || B <= 0 || H <= 0 || W <= 0) return BF_EINVAL;
+    if (((uintptr_t)in | (uintptr_t)out | (uintptr_t)wp | (uintptr_t)bias1 | (uintptr_t)bias2 | (uintptr_t)res) % 16) return BF_EINVAL;
+    if (B > 65535 || (H + UO_DP_TH - 1) / UO_DP_TH > 65535) return BF_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((W + UO_DP_TW - 1) / UO_DP_TW, (H + UO_DP_TH - 1) / UO_DP_TH, B);
+    bool ok = false;
+#define UO_DP(CI, MM, CO, KK)                                                                                                  \
+    if (cin == CI && m == MM && cout == CO && k == KK) {                                                                       \
+        constexpr int LDSB = ((UO_DP_TH + KK - 1) * (UO_DP_TW + KK - 1) * CI + KK * KK * CI * MM) * 4;                          \
+        static bool attr = false;                                                                                              \
+        if (!attr) {                                                                                                           \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(uo_dwmult_pw_kernel<CI, MM, CO, KK>),                        \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess)                           \
+                return BF_EHIP;                                                                                                \
+            attr = true;                                                                                                       \
+        }                                                                                                                      \
+        hipLaunchKernelGGL((uo_dwmult_pw_kernel<CI, MM, CO, KK>), grid, dim3(256), LDSB, s, in, out, wd, bias1, act1, alpha1, wp,  \
+                           bias2, act2, alpha2, res, H, W);                                                                    \
+        ok = true;                                                                                                             \
+    }
+    UO_DP(32, 4, 32, 3) UO_DP(32, 2, 32, 3) UO_DP(64, 2, 64, 3) UO_DP(32, 4, 64, 3) UO_DP(32, 1, 32, 3) UO_DP(64, 1, 64, 3)
+#undef UO_DP
+    if (!ok) return BF_EUNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
 // MaxPooling2D(pool 2x2, strides 2, padding="same") (downsampling.py:56-58): out-of-image taps are ignored
 __global__ __launch_bounds__(256) void uo_maxpool2_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C)
 {

@@ -201,10 +201,20 @@ class GenericResnetHydra:
         P = self._pack()
         f = UL.first_conv(x, P["base"], H, W, self.base_activation, True, self.v_min, self.v_max)
         nb = len(self.block_kernels)
+        fused = {(32, 4, 32, 3), (32, 2, 32, 3), (64, 2, 64, 3), (32, 4, 64, 3), (32, 1, 32, 3), (64, 1, 64, 3)}   # built instances
         for i in range(self.no_layers):
             t = f
-            for j in range(nb):
+            j = 0
+            while j < nb:
                 kind, wp, shift = P[f"b{i}c{j}"]
+                if kind == "dw" and j + 1 < nb and P[f"b{i}c{j + 1}"][0] == "pw" and \
+                        (t.shape[-1], int(wp.shape[-1]), self.block_filters[j + 1], int(wp.shape[0])) in fused:
+                    # depthwise (+BN, act) and the 1x1 after it (+BN, act, +skip) in one kernel: the wide tensor stays on chip
+                    _, wp2, shift2 = P[f"b{i}c{j + 1}"]
+                    t = UL.dwmult_pointwise(t, wp, shift, self.block_activation[j], wp2, self.block_filters[j + 1], shift2,
+                                            self.block_activation[j + 1], f if j + 1 == nb - 1 else None)
+                    j += 2
+                    continue
                 res = f if j == nb - 1 else None          # Add(block output, block input) (backbone_blocks.py:242)
                 a = self.block_activation[j]
                 if kind == "dw":
@@ -216,6 +226,7 @@ class GenericResnetHydra:
                     t = UL.pointwise_ex(t, wp, cout, 3, a, mult=shift, res=res)
                 else:
                     t = UL.conv2d(t, wp, self.block_filters[j], self.block_kernels[j], 1, a, res=res, bias=shift)
+                j += 1
             f = t
         return f
 

@@ -172,6 +172,18 @@ def dwconv_mult(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], 
     return out
 
 
+def dwmult_pointwise(x: torch.Tensor, wd: torch.Tensor, bias1: Optional[torch.Tensor], act1: str, wp: torch.Tensor, cout: int,
+                     bias2: Optional[torch.Tensor], act2: str, res: Optional[torch.Tensor]) -> torch.Tensor:
+    """res + act2(act1(depthwise_kxk_xm(x) + bias1) . w + bias2), one kernel (wd [k,k,C,m])."""
+    B, H, W, C = x.shape
+    k, m = int(wd.shape[0]), int(wd.shape[-1])
+    out = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device)
+    (c1, a1), (c2, a2) = _act(act1), _act(act2)
+    _call("bf_op_dwmult_pointwise", N.ptr(x), N.ptr(out), N.ptr(wd), N.ptr(bias1), c1, a1, N.ptr(wp), N.ptr(bias2), c2, a2,
+          N.ptr(res), B, H, W, C, m, k, cout, N.stream_ptr(x))
+    return out
+
+
 def maxpool2(x: torch.Tensor) -> torch.Tensor:
     B, H, W, C = x.shape
     out = torch.empty((B, (H + 1) // 2, (W + 1) // 2, C), dtype=torch.float32, device=x.device)

@@ -212,6 +212,12 @@ int bf_op_conv2d(const float* in, float* out, const float* wp, const float* res,
  * may be NULL) + activation (backbone_resnet.py:165-176, block_depthwise); w [k][k][C][m]. */
 int bf_op_dwconv_mult(const float* in, float* out, const float* w, const float* bias, int batch, int height, int width,
                       int channels, int multiplier, int k, int act, float alpha, void* stream);
+/* bf_op_dwconv_mult followed by a 1x1 convolution cin*m -> cout (wp packed by bf_op_pack_pointwise) in one kernel:
+ * out = res + act2(act1(dw(in) + bias1) . w + bias2); the cin*m-wide tensor is never written (the bottleneck tail of the
+ * shipped resnet config: depthwise 3x3 x4 -> BN -> ReLU -> grouped 1x1 -> BN -> Add). */
+int bf_op_dwmult_pointwise(const float* in, float* out, const float* wd, const float* bias1, int act1, float alpha1,
+                           const float* wp, const float* bias2, int act2, float alpha2, const float* res, int batch, int height,
+                           int width, int cin, int multiplier, int k, int cout, void* stream);
 /* MaxPooling2D(2, 2, padding="same") (downsampling.py:56-58). */
 int bf_op_maxpool2(const float* in, float* out, int batch, int height, int width, int channels, void* stream);
 /* The same 1x1 convolution with the epilogues of AdditiveAttentionGate (custom_layers.py:805-832):

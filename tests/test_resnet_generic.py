@@ -68,8 +68,10 @@ def test_shipped_resnet_config_matches_oracle(shape):
                                 dict(filters=64, kernel_size=5, block_kernels=[1, 3, 1], block_filters=[64, 128, 64],
                                      block_depthwise=[-1, 2, -1], block_groups=[2, 1, 4], no_layers=2, use_bn=False),
                                 dict(filters=32, kernel_size=7, block_kernels=[3], block_filters=[32], block_depthwise=[-1],
-                                     block_groups=[1], block_activation=["relu"], no_layers=2)],
-                         ids=["3x3-32", "bottleneck-64-groups-nobn", "single-conv"])
+                                     block_groups=[1], block_activation=["relu"], no_layers=2),
+                                dict(filters=32, kernel_size=3, block_kernels=[1, 5, 1], block_filters=[32, 128, 32],
+                                     block_depthwise=[-1, 4, -1], block_groups=[1, 1, 1], no_layers=2)],
+                         ids=["3x3-32", "bottleneck-64-groups-nobn", "single-conv", "depthwise-5x5-unfused"])
 def test_other_resnet_shapes_match_oracle(bb):
     cfg = G.shipped_config()
     cfg["backbone"].update(bb)
@@ -77,6 +79,25 @@ def test_other_resnet_shapes_match_oracle(bb):
     if "block_activation" not in bb:
         cfg["backbone"]["block_activation"] = ["relu"] * len(bb["block_kernels"])
     _check(cfg, (1, 48, 64), seed=5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,m,cout", [(32, 4, 32), (32, 2, 32), (64, 2, 64), (32, 4, 64), (32, 1, 32), (64, 1, 64)])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (2, 9, 37), (1, 16, 64)])
+def test_fused_depthwise_multiplier_pointwise_kernel(cin, m, cout, shape):
+    from blind_image_denoising_amd import unet_laplacian as UL
+    from helpers import dev, host, assert_close
+    r = np.random.default_rng(cin + m + cout)
+    x = r.normal(size=shape + (cin,))
+    wd, b1 = r.normal(size=(3, 3, cin, m)) * 0.3, r.normal(size=cin * m) * 0.1
+    w, b2 = r.normal(size=(1, 1, cin * m, cout)) / np.sqrt(cin * m), r.normal(size=cout) * 0.1
+    res = r.normal(size=shape + (cout,))
+    hid = np.maximum(G.depthwise_mult_same(x, wd) + b1, 0.0)
+    ref = res + O.activation_fwd(O.conv2d_same(hid, w) + b2, "leaky_relu_01")
+    got = UL.dwmult_pointwise(dev(x), dev(wd), dev(b1), "relu", UL.pack_pointwise(dev(w)), cout, dev(b2), "leaky_relu_01", dev(res))
+    assert_close(host(got), ref, what="dw x m + 1x1 fused")
+    got = UL.dwmult_pointwise(dev(x), dev(wd), None, "linear", UL.pack_pointwise(dev(w)), cout, None, "linear", None)
+    assert_close(host(got), O.conv2d_same(G.depthwise_mult_same(x, wd), w), what="dw x m + 1x1 fused, plain")
 
 
 @pytest.mark.gpu
