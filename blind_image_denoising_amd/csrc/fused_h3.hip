@@ -1445,37 +1445,61 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_h3_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // The fp32 elements of a tile are fetched into registers one tile ahead (NX + ND 16-byte loads per thread) and split /
+    // written to LDS after the matrix work of the previous tile: the global-memory latency of tile t+1 hides behind the
+    // MFMAs of tile t inside the workgroup, instead of relying on the second workgroup of the CU alone.
+    constexpr int NX = (G::IH * G::IW * 4 + 255) / 256, ND = G::TH * G::TW * 4 / 256;
+    f32x4 rx[NX], rd[ND];
+    auto fetch = [&](const int t) {
         int tt = t;
         const int txi = tt % tiles_x; tt /= tiles_x;
         const int tyi = tt % tiles_y;
         const int b = tt / tiles_y;
         const int y0 = tyi * G::TH, x0 = txi * G::TW;
         const size_t img = (size_t)b * H * W * 16;
-        // stage + split: x with a 1-pixel halo (zero outside the image), dy (zero outside the image)
-        for (int e = tid; e < G::IH * G::IW * 4; e += 256) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {                     // x with a 1-pixel halo (zero outside the image)
+            const int e = tid + i * 256;
             const int px = e >> 2, quad = e & 3;
             const int row = px / G::IW, col = px - row * G::IW;
             const int gy = y0 - 1 + row, gx = x0 - 1 + col;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const f32x4*>(x + img + ((size_t)gy * W + gx) * 16 + quad * 4);
-            h4 hi, lo;
-            h3_split(v, hi, lo);
-            *reinterpret_cast<h4*>(xh + px * 32 + quad * 8) = hi;
-            *reinterpret_cast<h4*>(xl + px * 32 + quad * 8) = lo;
+            rx[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (e < G::IH * G::IW * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                rx[i] = *reinterpret_cast<const f32x4*>(x + img + ((size_t)gy * W + gx) * 16 + quad * 4);
         }
-        for (int e = tid; e < G::TH * G::TW * 4; e += 256) {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {                     // dy (zero outside the image)
+            const int e = tid + i * 256;
             const int px = e >> 2, quad = e & 3;
             const int row = px / G::TW, col = px - row * G::TW;
             const int gy = y0 + row, gx = x0 + col;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gy < H && gx < W) v = *reinterpret_cast<const f32x4*>(dy + img + ((size_t)gy * W + gx) * 16 + quad * 4);
+            rd[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (gy < H && gx < W) rd[i] = *reinterpret_cast<const f32x4*>(dy + img + ((size_t)gy * W + gx) * 16 + quad * 4);
+        }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        // split + store the prefetched tile
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = tid + i * 256;
+            if (e < G::IH * G::IW * 4) {
+                h4 hi, lo;
+                h3_split(rx[i], hi, lo);
+                *reinterpret_cast<h4*>(xh + (e >> 2) * 32 + (e & 3) * 8) = hi;
+                *reinterpret_cast<h4*>(xl + (e >> 2) * 32 + (e & 3) * 8) = lo;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int e = tid + i * 256;
             h4 hi, lo;
-            h3_split(v, hi, lo);
-            *reinterpret_cast<h4*>(dh + px * 32 + quad * 8) = hi;
-            *reinterpret_cast<h4*>(dl + px * 32 + quad * 8) = lo;
+            h3_split(rd[i], hi, lo);
+            *reinterpret_cast<h4*>(dh + (e >> 2) * 32 + (e & 3) * 8) = hi;
+            *reinterpret_cast<h4*>(dl + (e >> 2) * 32 + (e & 3) * 8) = lo;
         }
         __syncthreads();
+        if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
         // wave handles rows 4w .. 4w+3 of the tile: four K chunks of 32 pixels
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
