@@ -1237,19 +1237,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h3_kernel(ConvArgs a)
     w[12] = w[0];
     const float inv_s = a.wpack[BF_H3R_WPACK_FLOATS];
 
-    // stage: fp32 NHWC (1-pixel halo, zero outside the image) -> hi / lo planes [4][IH][IW][8 x f16]
-    for (int e = tid; e < G::IH * G::IW * 4; e += 256) {
-        const int px = e >> 2, quad = e & 3;
-        const int row = px / G::IW, col = px - row * G::IW;
-        const int gy = y0 - 1 + row, gx = x0 - 1 + col;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-            v = *reinterpret_cast<const f32x4*>(inb + ((size_t)gy * a.W + gx) * 16 + quad * 4);
-        h4 hi, lo;
-        h3_split(v, hi, lo);
-        char* p = tile + (quad >> 1) * G::PLANE + px * 16 + (quad & 1) * 8;
-        *reinterpret_cast<h4*>(p) = hi;
-        *reinterpret_cast<h4*>(p + 2 * G::PLANE) = lo;
+    // stage: fp32 NHWC (1-pixel halo, zero outside the image) -> hi / lo planes [4][IH][IW][8 x f16].  All the loads of a
+    // thread are issued before the first one is consumed (a rolled load -> split -> store loop pays one memory round trip
+    // per element: hipcc does not pipeline it)
+    {
+        constexpr int NX = (G::IH * G::IW * 4 + 255) / 256;
+        f32x4 rx[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = tid + i * 256;
+            const int px = e >> 2, quad = e & 3;
+            const int row = px / G::IW, col = px - row * G::IW;
+            const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+            rx[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (e < G::IH * G::IW * 4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                rx[i] = *reinterpret_cast<const f32x4*>(inb + ((size_t)gy * a.W + gx) * 16 + quad * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = tid + i * 256;
+            if (e < G::IH * G::IW * 4) {
+                const int px = e >> 2, quad = e & 3;
+                h4 hi, lo;
+                h3_split(rx[i], hi, lo);
+                char* p = tile + (quad >> 1) * G::PLANE + px * 16 + (quad & 1) * 8;
+                *reinterpret_cast<h4*>(p) = hi;
+                *reinterpret_cast<h4*>(p + 2 * G::PLANE) = lo;
+            }
+        }
     }
     __syncthreads();
 
