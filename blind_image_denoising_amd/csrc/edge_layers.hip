@@ -33,19 +33,30 @@ __global__ __launch_bounds__(256) void base_conv_kernel(BaseConvArgs a)
     const int y0 = ty * BC_T, x0 = tx * BC_T;
     if (a.status && blockIdx.x == 0 && threadIdx.x == 0) *a.status = 0;       // first kernel of a forward
     const float range = a.v_max - a.v_min;       // true division: (x - min) / (max - min) - 0.5 is exact for mid-grey
-    for (int n = threadIdx.x; n < IT * IT * CIN; n += 256) {
-        const int ci = n % CIN, px = (n / CIN) % IT, row = n / (CIN * IT);
-        const int gy = y0 - R + row, gx = x0 - R + px;
-        float v = 0.f;                                          // conv zero padding outside H x W
-        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-            float raw = 0.f;                                    // pad_to_power_of_2 band: value 0
-            if (gy < a.Hs && gx < a.Ws) {
+    {
+        // all loads of a thread first, then the stores (a rolled load -> store loop pays one memory round trip per element)
+        constexpr int NE = (IT * IT * CIN + 255) / 256;
+        float raw[NE];
+        bool inimg[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int n = threadIdx.x + i * 256;
+            const int ci = n % CIN, px = (n / CIN) % IT, row = n / (CIN * IT);
+            const int gy = y0 - R + row, gx = x0 - R + px;
+            inimg[i] = n < IT * IT * CIN && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            raw[i] = 0.f;                                       // pad_to_power_of_2 band: value 0
+            if (inimg[i] && gy < a.Hs && gx < a.Ws) {
                 const int64_t si = (((int64_t)b * a.Hs + gy) * a.Ws + gx) * CIN + ci;
-                raw = U8 ? (float)reinterpret_cast<const uint8_t*>(a.in)[si] : reinterpret_cast<const float*>(a.in)[si];
+                raw[i] = U8 ? (float)reinterpret_cast<const uint8_t*>(a.in)[si] : reinterpret_cast<const float*>(a.in)[si];
             }
-            v = (fminf(fmaxf(raw, a.v_min), a.v_max) - a.v_min) / range - 0.5f;
         }
-        tile[n] = v;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int n = threadIdx.x + i * 256;
+            // conv zero padding outside H x W
+            const float v = inimg[i] ? (fminf(fmaxf(raw[i], a.v_min), a.v_max) - a.v_min) / range - 0.5f : 0.f;
+            if (n < IT * IT * CIN) tile[n] = v;
+        }
     }
     __syncthreads();
     const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;

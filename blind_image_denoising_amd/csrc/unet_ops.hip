@@ -396,12 +396,23 @@ __global__ __launch_bounds__(256) void uo_dwmult_pw_kernel(const float* __restri
     float* wl = lds + IH * IW * CIN;                     // [K*K][CIN][M]
     const int x0 = blockIdx.x * UO_DP_TW, y0 = blockIdx.y * UO_DP_TH;
     const int64_t img = (int64_t)blockIdx.z * H * W;
-    for (int e = threadIdx.x; e < IH * IW * (CIN / 4); e += 256) {
-        const int c4 = e % (CIN / 4), px = (e / (CIN / 4)) % IW, py = e / ((CIN / 4) * IW);
-        const int yy = y0 + py - RAD, xx = x0 + px - RAD;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = *reinterpret_cast<const f32x4*>(in + (img + (int64_t)yy * W + xx) * CIN + 4 * c4);
-        reinterpret_cast<f32x4*>(tile)[e] = v;
+    {
+        constexpr int NE = (IH * IW * (CIN / 4) + 255) / 256;      // loads first, stores after (see uo_first_conv_tile_kernel)
+        f32x4 rv[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = threadIdx.x + i * 256;
+            const int c4 = e % (CIN / 4), px = (e / (CIN / 4)) % IW, py = e / ((CIN / 4) * IW);
+            const int yy = y0 + py - RAD, xx = x0 + px - RAD;
+            rv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (e < IH * IW * (CIN / 4) && yy >= 0 && yy < H && xx >= 0 && xx < W)
+                rv[i] = *reinterpret_cast<const f32x4*>(in + (img + (int64_t)yy * W + xx) * CIN + 4 * c4);
+        }
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = threadIdx.x + i * 256;
+            if (e < IH * IW * (CIN / 4)) reinterpret_cast<f32x4*>(tile)[e] = rv[i];
+        }
     }
     for (int e = threadIdx.x; e < K * K * HID; e += 256) wl[e] = wd[e];
     __syncthreads();
@@ -1227,18 +1238,32 @@ __global__ __launch_bounds__(256) void uo_first_conv_tile_kernel(const void* __r
     const int x0 = blockIdx.x * UO_FC_TW, y0 = blockIdx.y * UO_FC_TH;
     const int64_t b = blockIdx.z;
     const float range = v_max - v_min;
-    for (int e = threadIdx.x; e < IH * IW * CIN; e += 256) {
-        const int ci = e % CIN, px = (e / CIN) % IW, py = e / (CIN * IW);
-        const int yy = y0 + py - RAD, xx = x0 + px - RAD;
-        float v = 0.f;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {                // inside the (virtually padded) image
-            if (yy < Hs && xx < Ws) {
+    // all loads of a thread are issued before the first is consumed (a rolled load -> store loop costs one memory round
+    // trip per element)
+    {
+        constexpr int NE = (IH * IW * CIN + 255) / 256;
+        float rv[NE];
+        bool inpad[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = threadIdx.x + i * 256;
+            const int ci = e % CIN, px = (e / CIN) % IW, py = e / (CIN * IW);
+            const int yy = y0 + py - RAD, xx = x0 + px - RAD;
+            inpad[i] = e < IH * IW * CIN && yy >= 0 && yy < H && xx >= 0 && xx < W;      // inside the (virtually padded) image
+            rv[i] = 0.f;
+            if (inpad[i] && yy < Hs && xx < Ws) {
                 const int64_t o = ((b * Hs + yy) * Ws + xx) * CIN + ci;
-                v = in_is_u8 ? (float)reinterpret_cast<const unsigned char*>(in)[o] : reinterpret_cast<const float*>(in)[o];
+                rv[i] = in_is_u8 ? (float)reinterpret_cast<const unsigned char*>(in)[o] : reinterpret_cast<const float*>(in)[o];
             }
-            if (normalize) v = (fminf(fmaxf(v, v_min), v_max) - v_min) / range - 0.5f;
         }
-        tile[e] = v;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = threadIdx.x + i * 256;
+            float v = rv[i];
+            if (inpad[i] && normalize) v = (fminf(fmaxf(v, v_min), v_max) - v_min) / range - 0.5f;
+            if (!inpad[i]) v = 0.f;
+            if (e < IH * IW * CIN) tile[e] = v;
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, n = lane & 15;
     float a[NJ][T];
