@@ -23,7 +23,9 @@ __device__ __forceinline__ f32x4 bf_acc_ready(f32x4 acc)
 // epilogue stages of the 3x3 C16 convolution: [scale+shift] -> [ReLU] -> [mask] -> [+residual]
 // (general form of SURVEY.md 8a "epilogue note"); STATS = per-channel sum / sum-of-squares of
 // the raw convolution output for training-mode batch norm.
-enum { EPI_RELU = 1, EPI_AFFINE = 2, EPI_RES = 4, EPI_MASK = 8, EPI_STATS = 16 };
+// BNBWD = per-channel sum of the FINAL output v and of v * bnc (the two reductions of the next BatchNorm backward,
+// train_ops.hip bn_bwd_reduce_kernel) in the same [grid][32] partial format as STATS.
+enum { EPI_RELU = 1, EPI_AFFINE = 2, EPI_RES = 4, EPI_MASK = 8, EPI_STATS = 16, EPI_BNBWD = 32 };
 
 struct ConvArgs {
     const float* in;      // [B,H,W,16]
@@ -33,7 +35,8 @@ struct ConvArgs {
     const float* shift;   // [16]
     const float* res;     // [B,H,W,16] (EPI_RES)
     const float* mask;    // [B,H,W,16] (EPI_MASK): out = mask > 0 ? out : 0
-    float* stats;         // [grid][32] (EPI_STATS)
+    float* stats;         // [grid][32] (EPI_STATS, EPI_BNBWD)
+    const float* bnc;     // [B,H,W,16] (EPI_BNBWD): raw convolution output c of the BatchNorm whose backward comes next
     int B, H, W;
 };
 

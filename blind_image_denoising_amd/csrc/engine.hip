@@ -740,8 +740,12 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
         float* gblk = grads + h->p_blocks + i * h->p_block_stride;
         float* dC = dA;
         if (d.use_bn) {
-            BF_HIP(bf_launch_bn_bwd_reduce(dA, C(i), partial, npix, bgrid, s), "bn_bwd_reduce");
-            BF_HIP(bf_launch_bn_bwd_finalize(partial, bgrid, count, params + h->p_blocks + i * h->p_block_stride + 4608,
+            // sum dy, sum dy*c: from the data-gradient kernel of the block above when it produced dy (split-f16 path: its
+            // epilogue accumulates them, one pass over dy and c saved), else from the reduction kernel
+            const bool fused_sums = h3t && i < N - 1;
+            if (!fused_sums) BF_HIP(bf_launch_bn_bwd_reduce(dA, C(i), partial, npix, bgrid, s), "bn_bwd_reduce");
+            BF_HIP(bf_launch_bn_bwd_finalize(partial, fused_sums ? conv_grid : bgrid, count,
+                                             params + h->p_blocks + i * h->p_block_stride + 4608,
                                              w + L.bn_meaninv + i * 32, w + L.coef, gblk + 4608, stage1, s), "bn_bwd_finalize");
             BF_HIP(bf_launch_bn_bwd_apply(dA, C(i), w + L.coef, C(i), npix, s), "bn_bwd_apply");
             dC = C(i);
@@ -754,7 +758,12 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
         BF_HIP(conv(ca, d.activation == BF_ACT_RELU ? EPI_MASK : 0), "dgrad2");
         BF_HIP(wgrad(A(i), T(i), gblk), "wgrad1");
         ca.in = T(i); ca.out = dA; ca.wpack = wp + 2 * BF_TRAIN_PACK_STRIDE; ca.mask = nullptr; ca.res = dA;
-        BF_HIP(conv(ca, EPI_RES), "dgrad1");
+        if (h3t && d.use_bn && i > 0) {                   // dA becomes dy of block i-1: its BN-backward sums ride along
+            ca.bnc = C(i - 1); ca.stats = partial;
+            BF_HIP(conv(ca, EPI_RES | EPI_BNBWD), "dgrad1");
+        } else {
+            BF_HIP(conv(ca, EPI_RES), "dgrad1");
+        }
     }
     BF_HIP(bf_launch_base_wgrad(noisy, dA, partial, grads + h->p_base, B, H, W, d.in_channels, d.kernel_size, d.v_min, d.v_max, s),
            "base_wgrad");

@@ -1296,6 +1296,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h3_kernel(ConvArgs a)
                     v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
                 }
                 if (EPI & EPI_RES) v += *reinterpret_cast<const f32x4*>(a.res + idx);
+                if (EPI & EPI_BNBWD) { *s1 += v; *s2 += v * *reinterpret_cast<const f32x4*>(a.bnc + idx); }
                 *reinterpret_cast<f32x4*>(a.out + idx) = v;
             }
         }
@@ -1309,7 +1310,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h3_kernel(ConvArgs a)
     const Epi epi{a, img + ((size_t)(y0 + o0) * a.W + gx) * 16 + q * 4, y0 + o0, gx, q, inv_s, sc, sh, &s1, &s2};
     h3r_rows<G::R, G::IW * 16, 2 * G::PLANE>(tile, b1 + (q >> 1) * 16, b1 + 32 + (q >> 1) * 2 * G::PLANE, w, epi, H3NoHook{});
 
-    if (EPI & EPI_STATS) {
+    if (EPI & (EPI_STATS | EPI_BNBWD)) {
         // reduce over the 16 pixel lanes that share a channel quad, then over the 4 waves (fixed order)
 #pragma unroll
         for (int m = 1; m < 16; m <<= 1) {
@@ -1343,6 +1344,7 @@ hipError_t bf_launch_conv3x3_h3(const ConvArgs& a, int epi, hipStream_t s)
         BF_CASE(EPI_RELU)
         BF_CASE(EPI_STATS)
         BF_CASE(EPI_RES)
+        BF_CASE(EPI_RES | EPI_BNBWD)
         BF_CASE(EPI_MASK)
         default: return hipErrorInvalidValue;
     }
