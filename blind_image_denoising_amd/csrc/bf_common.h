@@ -74,6 +74,13 @@ struct FusedH3Args {
     const void* zeros;    // >= 64 B of zeros, 16-B aligned (source of out-of-image elements)
     void* dump;           // >= 1024 B writable scratch (sink of out-of-image stores)
     unsigned long long* dbg;  // diagnostic builds only (per-wave phase cycle sums), else NULL
+    // last block with the LINEAR denoiser head folded into its epilogue (head_wh != NULL; row-streaming kernel, 3 output
+    // channels): the block output is not written, out3 = [round, u8](denormalise(tanh(2 y . wh) * 0.51)) cropped to [Ho,Wo]
+    const float* head_wh;  // [16][4] premultiplied head_conv0 . head_conv1 (pack_edges_kernel), or NULL
+    void* head_out;        // u8 or f32 [B,Ho,Wo,3]
+    int head_u8, Ho, Wo, denormalize;
+    float v_min, v_max;
+    int* status;           // |= BF_STATUS_F16_RANGE when a block output is not finite
 };
 hipError_t bf_launch_fused_block_h3(const FusedH3Args& a, hipStream_t s);
 void       bf_set_h3_variant(int v);   // 1 (default) row-streaming kernel, 0 group-per-pass kernel (A/B only)

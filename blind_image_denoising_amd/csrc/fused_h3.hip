@@ -716,7 +716,10 @@ __device__ __forceinline__ void h3r_conv1_run(const FusedH3Args& a, const char* 
     h3r_rows<R, Cfg::IW * 16, 2 * Cfg::IN_PLANE>(tin, L.p1, L.s1, w, epi, hook);
 }
 
-template <class Cfg>
+// HEAD = 1: the last block of a network with a linear denoiser head: y . wh (16 x 3, premultiplied), tanh, denormalise,
+// [round, uint8] happen in the conv2 epilogue; the block output is never written and the head kernel (one more pass over
+// the 64 B / pixel activation) disappears.
+template <class Cfg, int HEAD = 0>
 __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args a)
 {
     using Plan = H3RPlan<Cfg>;
@@ -770,6 +773,9 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args
     const float inv_s2 = a.aux[48];                             // BN scale is folded into the row-layout w2
     const float relu_floor = a.act1_relu ? 0.f : -__builtin_inff();
     const f32x4 sh = *reinterpret_cast<const f32x4*>(a.aux + 32 + q * 4);
+    f32x4 whr[4];                                               // HEAD: rows 4q .. 4q+3 of the 16 x 4 head matrix
+#pragma unroll
+    for (int j = 0; j < 4; ++j) whr[j] = HEAD ? *reinterpret_cast<const f32x4*>(a.head_wh + (4 * q + j) * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nxcd = gridDim.x >= 8 ? 8 : 1;
     const int label = blockIdx.x % nxcd, slot = blockIdx.x / nxcd;
@@ -876,6 +882,7 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args
                 enum { EXTRA_MFMA = 1 };
                 const FusedH3Args& a; const char* __restrict__ tin; h8 wres; char* out_row0; size_t rowbytes, lo_g;
                 float inv_s2; f32x4 sh; bool interior; int rr, y_base, x_px, lane; unsigned g;
+                f32x4 wh0, wh1, wh2, wh3; char* head_row0; int q;
                 // residual operand [x_hi | x_lo] of the centre pixel of output row o: requested one row step early
                 __device__ __forceinline__ Pre pre(const int o) const { return *reinterpret_cast<const h8*>(tin + rr + o * Cfg::IW * 16); }
                 // residual on the matrix pipe: acc += (s2 * I) x [x_hi | x_lo] -- exact (power-of-two times f16 in
@@ -884,6 +891,34 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args
                 __device__ __forceinline__ void operator()(const int o, const f32x4 acc) const
                 {
                     const f32x4 v = (H3_ABLATE & 64) ? acc : acc * inv_s2 + sh;
+                    if constexpr (HEAD) {
+                        // the lane's 4 channels times their rows of the head matrix, summed over the 4 lanes of the pixel
+                        f32x4 hsum = wh0 * v.x + wh1 * v.y + wh2 * v.z + wh3 * v.w;
+                        const bool finite = fabsf(v.x) <= 3.0e38f && fabsf(v.y) <= 3.0e38f && fabsf(v.z) <= 3.0e38f && fabsf(v.w) <= 3.0e38f;
+                        if (!finite && a.status) atomicOr(a.status, BF_STATUS_F16_RANGE);      // never on valid activations
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            hsum[k] += __shfl_xor(hsum[k], 16, 64);
+                            hsum[k] += __shfl_xor(hsum[k], 32, 64);
+                        }
+                        // after the reduction the 4 lanes of a pixel hold the same three sums: lane group q writes output
+                        // channel q (q = 3: dump line), ONE store per row and wave, every lane with its own tanh
+                        const float hk = q == 0 ? hsum[0] : (q == 1 ? hsum[1] : hsum[2]);
+                        const bool live = q < 3 && y_base + o < a.Ho && x_px < a.Wo;
+                        // tanh(2h) = 1 - 2 / (exp(4h) + 1): a handful of instructions inside the matrix loop (libm tanhf: ~30)
+                        float r = (1.0f - 2.0f / (__expf(4.0f * hk) + 1.0f)) * 0.51f;
+                        if (a.denormalize) r = (fminf(fmaxf(r, -0.5f), 0.5f) + 0.5f) * (a.v_max - a.v_min) + a.v_min;
+                        if (a.head_u8) {
+                            unsigned char* p = live ? reinterpret_cast<unsigned char*>(head_row0) + (size_t)o * a.Wo * 3 + q
+                                                    : reinterpret_cast<unsigned char*>(a.dump) + lane * 16;
+                            *p = (unsigned char)fminf(fmaxf(rintf(r), 0.f), 255.f);              // rintf = round-half-even
+                        } else {
+                            float* p = live ? reinterpret_cast<float*>(head_row0) + (size_t)o * a.Wo * 3 + q
+                                            : reinterpret_cast<float*>(a.dump) + lane * 4;
+                            *p = r;
+                        }
+                        return;
+                    }
                     const h8 rec = h3_split_record(v);
                     // out-of-image lanes store to a dump line: every wave issues exactly R2 stores per tile
                     char* p = out_row0 + o * rowbytes + g;
@@ -891,12 +926,20 @@ __global__ __launch_bounds__(Cfg::NT, 2) void fused_block_h3r_kernel(FusedH3Args
                     if (H3_ABLATE & 2) { if (v.x == 12345.678f) *reinterpret_cast<h8*>(p) = rec; }   // keeps the work live
                     else *reinterpret_cast<h8*>(p) = rec;
                 }
-            } const epi2{a, tin, w2[12], out_row0, rowbytes, lo_g, inv_s2, sh, interior, L.rr, cur.y0 + o2, cur.x0 + L.px, lane, L.g};
+            };
+            char* head_row0 = nullptr;
+            if constexpr (HEAD) {
+                const size_t bimg = cur.img / img_bytes;             // image index (once per tile)
+                head_row0 = reinterpret_cast<char*>(a.head_out) +
+                            ((bimg * a.Ho + (size_t)(cur.y0 + o2)) * a.Wo + (size_t)(cur.x0 + L.px)) * 3 * (a.head_u8 ? 1 : 4);
+            }
+            const Epi2 epi2{a, tin, w2[12], out_row0, rowbytes, lo_g, inv_s2, sh, interior, L.rr, cur.y0 + o2, cur.x0 + L.px, lane, L.g,
+                            whr[0], whr[1], whr[2], whr[3], head_row0, q};
             h3r_rows<Plan::R2, Cfg::MW * 16, 2 * Cfg::MID_PLANE>(tmid, L.p2, L.s2, w2, epi2, H3NoHook{});
         }
         // next tile's DMA landed <=> at most the R2 stores above are outstanding (see fused_block_h3_kernel)
         H3_STAMP(3);                                             // conv2 + stores
-        __builtin_amdgcn_s_waitcnt(h3_vmcnt((H3_ABLATE & 2) ? 0 : Plan::R2));
+        __builtin_amdgcn_s_waitcnt(h3_vmcnt((H3_ABLATE & 2) ? 0 : Plan::R2));      // HEAD: also one store per row
         H3_STAMP(4);                                             // wait for the next tile's DMA
         h3_barrier();
         H3_STAMP(5);                                             // barrier B
@@ -1618,6 +1661,7 @@ hipError_t bf_launch_fused_block_h3(const FusedH3Args& args, hipStream_t s)
     a.ntiles = a.B * a.tiles_x * a.tiles_y;
     if (g_h3_variant == 0) return launch_h3<Cfg, 0>(fused_block_h3_kernel<Cfg>, a, s);
     a.w1 = a.w1r; a.w2 = a.w2r;                                 // horizontally paired weights
+    if (a.head_wh) return launch_h3<Cfg, 5>(fused_block_h3r_kernel<Cfg, 1>, a, s);
     return launch_h3<Cfg, 1>(fused_block_h3r_kernel<Cfg>, a, s);
 }
 

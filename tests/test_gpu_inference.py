@@ -93,6 +93,21 @@ def test_denoiser_module_u8_shapes_and_values(hw, arith):
     _check_u8(got, O.denoiser_module_call(spec, params, state, noisy))
 
 
+@pytest.mark.parametrize("hw", [(64, 64), (256, 256), (17, 23), (1, 1), (40, 130)])
+@pytest.mark.parametrize("no_layers", [1, 3])
+def test_head_folded_into_the_last_block(hw, no_layers):
+    """option fused_head = 1: the linear head runs in the epilogue of the last split-f16 block (u8 and f32 outputs, ragged
+    sizes with the virtual power-of-two padding, crop)."""
+    cfg, spec, params, state, m = _model(no_layers, seed=13)
+    m.set_option("fused_head", 1)
+    _, noisy = O.synthetic_batch(2, hw[0], hw[1], seed=hw[0] + hw[1])
+    _check_u8(bf.DenoiserModule(m)(noisy), O.denoiser_module_call(spec, params, state, noisy))
+    f = bf.DenoiserModule(m, cast_to_uint8=False)(noisy)
+    _check_f32(f, O.denoiser_module_call(spec, params, state, noisy, cast_to_uint8=False))
+    m.set_option("fused_head", 0)
+    assert np.abs(bf.DenoiserModule(m)(noisy).astype(int) - O.denoiser_module_call(spec, params, state, noisy).astype(int)).max() <= 1
+
+
 def test_denoiser_module_device_tensors_and_float_output():
     cfg, spec, params, state, m = _model(1, seed=9)
     _, noisy = O.synthetic_batch(2, 24, 40, seed=1)
