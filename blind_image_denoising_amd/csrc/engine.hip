@@ -553,7 +553,16 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restr
     if (tid < 198) {
         const int col = tid % 66, stripe = tid / 66;
         double s = 0.0;
-        for (int r = stripe; r < nblk; r += 3) s += (double)partial[(size_t)r * 80 + col];
+        // loads issued eight at a time (a rolled load -> add loop waits out one L2 round trip per row); same add order
+        int r = stripe;
+        for (; r + 21 < nblk; r += 24) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(r + 3 * u) * 80 + col];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (double)v[u];
+        }
+        for (; r < nblk; r += 3) s += (double)partial[(size_t)r * 80 + col];
         part[stripe][col] = s;
     }
     __syncthreads();
@@ -565,7 +574,15 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restr
     double acc = 0.0;
     for (int b = tid; b < B; b += 256) {
         double sq = 0.0;
-        for (int k = 0; k < blocks_per_image; ++k) sq += (double)partial[(size_t)(b * blocks_per_image + k) * 80 + 66];
+        int k = 0;
+        for (; k + 7 < blocks_per_image; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(b * blocks_per_image + k + u) * 80 + 66];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sq += (double)v[u];
+        }
+        for (; k < blocks_per_image; ++k) sq += (double)partial[(size_t)(b * blocks_per_image + k) * 80 + 66];
         acc += sqrt(sq / per_image + 1e-3);
     }
     rm[tid] = acc;
@@ -608,18 +625,31 @@ __global__ __launch_bounds__(1024) void regularizer_kernel(const float* __restri
 {
     __shared__ double red[1024];
     double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    for (int64_t i0 = threadIdx.x; i0 < n; i0 += 4096) {
+        // four parameter / gradient loads in flight per thread; the per-thread add order is unchanged
+        float wv[4], gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + 1024 * u;
+            wv[u] = i < n ? params[i] : 0.f;
+            gv[u] = i < n ? grads[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+        const int64_t i = i0 + 1024 * u;
+        if (i >= n) break;
         int reg;
         if (i < n_base) reg = reg_base;
         else if (i >= p_head0) reg = reg_head;
         else reg = ((i - p_blocks) % p_stride) < 4608 ? reg_block : BF_REG_NONE;
-        const float w = params[i];
+        const float w = wv[u];
         if (reg == BF_REG_L1) {
             acc += 0.01 * fabs((double)w);
-            grads[i] += regularization * 0.01f * (w > 0.f ? 1.f : (w < 0.f ? -1.f : 0.f));
+            grads[i] = gv[u] + regularization * 0.01f * (w > 0.f ? 1.f : (w < 0.f ? -1.f : 0.f));
         } else if (reg == BF_REG_L2) {
             acc += 0.01 * (double)w * (double)w;
-            grads[i] += regularization * 0.02f * w;
+            grads[i] = gv[u] + regularization * 0.02f * w;
+        }
         }
     }
     red[threadIdx.x] = acc;
