@@ -60,8 +60,9 @@ if pretrained_dir.is_dir():
 
 
 def load_model(model_path: str, device=None) -> DenoiserModule:
-    """bfcnn/__init__.py:81-97: a registry name or a model directory (pipeline.json + weights.npz
-    written by `save_model`).  Returns a callable uint8 [B,H,W,C] -> uint8 [B,H,W,C]."""
+    """bfcnn/__init__.py:81-97: a registry name, a model directory (pipeline.json + weights.npz written by
+    `save_model`), or a `.keras` archive of a trained unet_laplacian hydra / the directory holding `model_hydra.keras`
+    (the layout of the reference's bfcnn/pretrained/<name>/).  Returns a callable uint8 [B,H,W,C] -> uint8 [B,H,W,C]."""
     # --- argument checking
     if model_path is None or len(model_path) <= 0:
         raise ValueError("model_path cannot be empty")
@@ -71,6 +72,11 @@ def load_model(model_path: str, device=None) -> DenoiserModule:
     # --- load from any directory
     if not os.path.exists(model_path):
         raise ValueError("model_path [{0}] does not exist".format(model_path))
+    # --- a trained hydra as keras wrote it (bfcnn/export_model.py:106-110), or the directory holding one
+    archive = os.path.join(model_path, "model_hydra.keras") if os.path.isdir(model_path) else str(model_path)
+    if archive.endswith(".keras") and os.path.isfile(archive):
+        from .unet_laplacian import UnetLaplacianHydra
+        return DenoiserModule(UnetLaplacianHydra.from_keras_archive(archive, device=device))
     return DenoiserModule(load_hydra(str(model_path), device=device))
 
 

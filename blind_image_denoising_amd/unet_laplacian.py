@@ -352,6 +352,19 @@ class UnetLaplacianHydra:
         # (custom_layers.py:1272-1282); later keras resolve it to negative_slope 0.2, which is what is built here
         self.attention_alpha = float(bb.get("attention_alpha", 0.2))
         self.attention_resolution = (16, 16)
+        # graph revision of the reference's trained archive (pretrained/unet_laplacian_v5.6, older code than the snapshot
+        # builder; keys of this package, set by keras_import.config_from_archive_graph -- oracle/unet_oracle.py explains them)
+        self.mlp_activation = (bb.get("convnext_activation") or self.activation).strip().lower()
+        _act(self.mlp_activation)
+        self.level_activation = bool(bb.get("encoder_level_activation", True))
+        self.output_norm_at_heads = bool(bb.get("output_normalization_at_heads", False))
+        self.attention_rows = bool(bb.get("attention_full_resolution", False))
+        self.attention_activation = (bb.get("attention_activation") or "").strip().lower()
+        if self.attention_activation in ("leaky_relu", "leakyrelu"):
+            self.attention_activation = ""                       # LeakyReLU(attention_alpha), see above
+        if self.attention_activation:
+            _act(self.attention_activation)
+        self.upsample_linear = bool(bb.get("upsample_linear", False))
         vr = bb.get("value_range", [0, 255])
         self.v_min, self.v_max = float(vr[0]), float(vr[1])
         self.head_filters = int(dn.get("filters", 32))
@@ -377,6 +390,16 @@ class UnetLaplacianHydra:
         self.params = torch.from_numpy(self._initial_values(seed)).to(self.device)
         self._packed = None
 
+    @classmethod
+    def from_keras_archive(cls, path: str, device=None) -> "UnetLaplacianHydra":
+        """hydra with the graph and the trained tensors of a `.keras` archive written by `model.save`
+        (bfcnn/export_model.py:106-110), e.g. the reference's pretrained/unet_laplacian_v5.6/model_hydra.keras."""
+        from . import keras_import
+        config, h5 = keras_import.read_archive(path)
+        model = cls(config, device=device, seed=0)
+        model.set_weights(keras_import.params_from_archive(config, h5, model._inventory))
+        return model
+
     # -- inventory ---------------------------------------------------------------------------
     def level_filters(self, d: int) -> int:
         f = int(round(self.filters * max(1, self.multiplier ** d)))              # backbone_unet_laplacian.py:198-201
@@ -395,6 +418,8 @@ class UnetLaplacianHydra:
                     out.append((f"{prefix}/ln/gamma", (C,), "ln_gamma"))
                 for n in ("key", "query", "value"):
                     out.append((f"{prefix}/{n}/kernel", (1, 1, C, A), "conv"))
+                if self.attention_rows and self.use_ln:
+                    out.append((f"{prefix}/ln1/gamma", (A,), "ln_gamma"))
                 out.append((f"{prefix}/out/kernel", (1, 1, A, C), "conv"))
                 out.append((f"{prefix}/gamma/w", (C,), "multiplier"))
                 return
@@ -410,7 +435,7 @@ class UnetLaplacianHydra:
             C = self.level_filters(d)
             for w in range(self.width):
                 block(f"enc{d}_{w}", C, self.enc_k, self._is_attention(d))
-            if self.use_output_normalization and self.use_ln:
+            if self.use_output_normalization and self.use_ln and (d == self.depth - 1 or not self.output_norm_at_heads):
                 out.append((f"enc{d}/out_ln/gamma", (C,), "ln_gamma"))
             if d != self.depth - 1:
                 kd = 2 if self.downsample_type == "conv2d" else 1
@@ -524,24 +549,34 @@ class UnetLaplacianHydra:
         gamma = P.get(f"{prefix}/ln/gamma") if self.use_ln else None
         dw = P[f"{prefix}/dw/kernel"]
         if self.arith == 1 and f"{prefix}/mlp_h3" in P and dw.shape[0] == 1:
-            return convnext_block1_h3(x, dw.view(-1), gamma, P[f"{prefix}/mlp_h3"], mult, self.activation)
+            return convnext_block1_h3(x, dw.view(-1), gamma, P[f"{prefix}/mlp_h3"], mult, self.mlp_activation)
         if self.arith == 1 and f"{prefix}/mlp_h3" in P and dw.shape[0] in (3, 5) and x.shape[-1] == 32:
-            return convnext_block_h3(x, dw, gamma, P[f"{prefix}/mlp_h3"], mult, self.activation)
+            return convnext_block_h3(x, dw, gamma, P[f"{prefix}/mlp_h3"], mult, self.mlp_activation)
         t = dwconv_ln(x, dw, gamma)
         if self.arith == 1 and f"{prefix}/mlp_h3" in P:
-            return convnext_mlp_h3(t, x, P[f"{prefix}/mlp_h3"], mult, self.activation)
+            return convnext_mlp_h3(t, x, P[f"{prefix}/mlp_h3"], mult, self.mlp_activation)
         return convnext_mlp(t, x, P[f"{prefix}/pw1/kernel"], P[f"{prefix}/pw2/kernel"],
-                            P.get(f"{prefix}/gamma/w") if self.use_gamma else None, self.activation)
+                            P.get(f"{prefix}/gamma/w") if self.use_gamma else None, self.mlp_activation)
 
     def _attention(self, P, prefix: str, x: torch.Tensor) -> torch.Tensor:
         B, H, W, C = x.shape
-        rh, rw = self.attention_resolution
         A = self.filters
+        qkv_act = dict(act=self.attention_activation) if self.attention_activation else \
+            dict(act="leaky_relu", alpha=self.attention_alpha)
+        if self.attention_rows:
+            # archive revision: no resize, one sequence per image row, operands in the order the archive's graph wires them
+            # (scores = query_conv . value_conv^T, output = softmax . key_conv), LayerNorm on the product
+            t = dwconv_ln(x, None, P[f"{prefix}/ln/gamma"]) if self.use_ln else x
+            q, v, k = (pointwise(t, P[f"{prefix}/{n}/kernel"], A, **qkv_act).view(B * H, W, A) for n in ("query", "key", "value"))
+            t = attention(q, v, k).view(B, H, W, A)
+            if self.use_ln:
+                t = dwconv_ln(t, None, P[f"{prefix}/ln1/gamma"])
+            return pointwise(t, P[f"{prefix}/out/kernel"], C, "linear", mult=P[f"{prefix}/gamma/w"], res=x)
+        rh, rw = self.attention_resolution
         t = resize_bilinear(x, rh, rw)
         if self.use_ln:
             t = dwconv_ln(t, None, P[f"{prefix}/ln/gamma"])
-        q, v, k = (pointwise(t, P[f"{prefix}/{n}/kernel"], A, "leaky_relu", alpha=self.attention_alpha).view(B, rh * rw, A)
-                   for n in ("query", "value", "key"))
+        q, v, k = (pointwise(t, P[f"{prefix}/{n}/kernel"], A, **qkv_act).view(B, rh * rw, A) for n in ("query", "value", "key"))
         t = attention(q, v, k).view(B, rh, rw, A)
         t = resize_bilinear(t, H, W)
         return pointwise(t, P[f"{prefix}/out/kernel"], C, "linear", mult=P[f"{prefix}/gamma/w"], res=x)
@@ -561,25 +596,27 @@ class UnetLaplacianHydra:
         for d in range(self.depth):
             for w in range(self.width):
                 f = self._attention(P, f"enc{d}_{w}", f) if self._is_attention(d) else self._convnext(P, f"enc{d}_{w}", f)
-            gamma = P[f"enc{d}/out_ln/gamma"] if (self.use_output_normalization and self.use_ln) else None
+            inline_norm = self.use_output_normalization and self.use_ln and not self.output_norm_at_heads
+            gamma = P[f"enc{d}/out_ln/gamma"] if inline_norm else None
+            la = a if self.level_activation else "linear"
             if d != self.depth - 1:
                 gauss = None if self.use_laplacian_averaging else P["gauss"]
                 Cn = self.level_filters(d + 1)
                 if self.downsample_type == "strides":                     # downsampling.py:60-72
                     if self.gauss_k in (3, 5):   # output LayerNorm + activation + Laplacian split in one kernel
-                        lap, down = norm_smooth_split(f, gamma, a, self.gauss_k, gauss)
+                        lap, down = norm_smooth_split(f, gamma, la, self.gauss_k, gauss)
                     else:
-                        lap, down = smooth_split(dwconv_ln(f, None, gamma, a), self.gauss_k, gauss)
+                        lap, down = smooth_split(self._level_out(f, gamma, la), self.gauss_k, gauss)
                     f = pointwise(down, P[f"down{d}/kernel"], Cn, a)
                 else:
-                    lap, smooth = smooth_split(dwconv_ln(f, None, gamma, a), self.gauss_k, gauss, down_stride=1)
+                    lap, smooth = smooth_split(self._level_out(f, gamma, la), self.gauss_k, gauss, down_stride=1)
                     if self.downsample_type == "conv2d":                   # 2x2 stride 2 (:45-55)
                         f = conv2d(smooth, P[f"down{d}/kernel"], Cn, 2, 2, a)
                     else:                                                   # maxpool + 1x1 (:56-68)
                         f = pointwise(maxpool2(smooth), P[f"down{d}/kernel"], Cn, a)
                 nodes[d] = lap
             else:
-                f = dwconv_ln(f, None, gamma, a)
+                f = self._level_out(f, gamma, la)
                 nodes[d] = f
         outs = {self.depth - 1: nodes[self.depth - 1]}
         for d in reversed(range(self.depth - 1)):
@@ -590,7 +627,7 @@ class UnetLaplacianHydra:
                 # 1x1 and the bilinear resize are both linear: the 1x1 runs on the low-resolution map (1/4 of the work;
                 # upsampling.py:80-90 makes the same exchange itself when the activation is linear)
                 low = pointwise(low, P[f"up{d}/kernel"], C, "linear")
-                f = upsample_act_add(low, skip, a)
+                f = upsample_act_add(low, skip, "linear" if self.upsample_linear else a)
             elif self.upsample_type in ("upsample_bilinear_conv2d", "upsample_nearest_conv2d"):
                 from .pyramid import upsample_2x                           # UpSampling2D, then Conv2D 3x3 + activation
                 up = upsample_2x(low, bilinear=self.upsample_type == "upsample_bilinear_conv2d")
@@ -616,15 +653,28 @@ class UnetLaplacianHydra:
                 f = pointwise(f, P[f"mix{d}/kernel"], self.level_filters(d), a)
             for w in range(self.width):
                 f = self._convnext(P, f"dec{d}_{w}", f)
-            if self.use_output_normalization and self.use_ln and not (defer_output_norm and d == 0):
+            if self.use_output_normalization and self.use_ln and not self.output_norm_at_heads \
+                    and not (defer_output_norm and d == 0):
                 f = dwconv_ln(f, None, P[f"dec{d}/out_ln/gamma"])
             outs[d] = f
+        if self.use_output_normalization and self.use_ln and self.output_norm_at_heads and not defer_output_norm:
+            outs = {d: dwconv_ln(f, None, P[self._out_ln_name(d)]) for d, f in outs.items()}
         return [outs[d] for d in range(self.depth)]
+
+    def _out_ln_name(self, d: int) -> str:
+        return f"enc{d}/out_ln/gamma" if d == self.depth - 1 else f"dec{d}/out_ln/gamma"
+
+    @staticmethod
+    def _level_out(f: torch.Tensor, gamma: Optional[torch.Tensor], act: str) -> torch.Tensor:
+        return f if (gamma is None and act == "linear") else dwconv_ln(f, None, gamma, act)
 
     def _head(self, P, i: int, f: torch.Tensor, Ho: int, Wo: int, as_uint8: bool, deferred_norm: bool = False) -> torch.Tensor:
         gamma = None
-        if deferred_norm and i == 0 and self.depth > 1 and self.use_output_normalization and self.use_ln:
-            gamma = P[f"dec{i}/out_ln/gamma"]
+        if deferred_norm and self.use_output_normalization and self.use_ln:
+            if self.output_norm_at_heads:                      # every scale arrives un-normalised
+                gamma = P[self._out_ln_name(i)]
+            elif i == 0 and self.depth > 1:
+                gamma = P[f"dec{i}/out_ln/gamma"]
         if self.head_filters == 32:
             return head_fused(f, gamma, P[f"head{i}/conv0/kernel"], self.head_activation, P[f"head{i}/conv1/kernel"], Ho, Wo,
                               as_uint8, True, self.v_min, self.v_max)

@@ -139,6 +139,18 @@ class UnetLaplacianSpec:
     use_output_normalization: bool = True
     attention_alpha: float = 0.2
     attention_resolution: Tuple[int, int] = (16, 16)
+    # graph revision of the one trained archive the reference ships (pretrained/unet_laplacian_v5.6/model_hydra.keras,
+    # written by older code than the snapshot builder; structure read from the archive's config.json and from the
+    # operator names inside denoiser_model.tflite next to it): the ConvNext MLP has its own activation, the encoder
+    # levels end without LayerNorm / activation, the output LayerNorms sit only in front of the heads (the decoder
+    # reads the un-normalised maps), attention runs at the deepest level's own resolution (no resize), row by row, with a
+    # second LayerNorm between the attention product and the output convolution
+    mlp_activation: str = ""                  # "" = `activation`
+    level_activation: bool = True
+    output_norm_at_heads: bool = False
+    attention_full: bool = False
+    attention_activation: str = ""            # "" = LeakyReLU(attention_alpha)
+    upsample_linear: bool = False             # upsample_laplacian_conv2d as 1x1 -> bilinear x2 without an activation
     head_filters: int = 32
     head_activation: str = "leaky_relu_01"
     out_channels: int = 3
@@ -168,6 +180,10 @@ class UnetLaplacianSpec:
             use_self_attention=bb.get("use_self_attention", False),
             use_attention_gates=bb.get("use_attention_gates", False),
             use_output_normalization=bb.get("use_output_normalization", False),
+            mlp_activation=bb.get("convnext_activation", ""), level_activation=bb.get("encoder_level_activation", True),
+            output_norm_at_heads=bb.get("output_normalization_at_heads", False),
+            attention_full=bb.get("attention_full_resolution", False), attention_activation=bb.get("attention_activation", ""),
+            upsample_linear=bb.get("upsample_linear", False),
             head_filters=dn.get("filters", 32), head_activation=dn.get("activation", "linear"),
             out_channels=dn.get("output_channels", 3), v_min=float(vr[0]), v_max=float(vr[1]))
 
@@ -186,6 +202,8 @@ class UnetLaplacianSpec:
                     out.append((f"{prefix}/ln/gamma", (C,), "ln_gamma"))
                 for n in ("key", "query", "value"):
                     out.append((f"{prefix}/{n}/kernel", (1, 1, C, A), "conv"))
+                if self.attention_full and self.use_ln:
+                    out.append((f"{prefix}/ln1/gamma", (A,), "ln_gamma"))
                 out.append((f"{prefix}/out/kernel", (1, 1, A, C), "conv"))
                 out.append((f"{prefix}/gamma/w", (C,), "multiplier"))
                 return
@@ -201,7 +219,7 @@ class UnetLaplacianSpec:
             C = self.level_filters(d)
             for w in range(self.width):
                 block(f"enc{d}_{w}", C, self.encoder_kernel_size, self.use_self_attention and d == self.depth - 1)
-            if self.use_output_normalization and self.use_ln:
+            if self.use_output_normalization and self.use_ln and (d == self.depth - 1 or not self.output_norm_at_heads):
                 out.append((f"enc{d}/out_ln/gamma", (C,), "ln_gamma"))
             if d != self.depth - 1:
                 kd = 2 if self.downsample_type == "conv2d" else 1            # downsampling.py:45-72
@@ -290,7 +308,7 @@ def backbone_forward(spec: UnetLaplacianSpec, P: Dict[str, np.ndarray], xn: np.n
         t = depthwise_same(x, P[f"{prefix}/dw/kernel"])                 # conv_1, linear (custom_layers.py:979-988)
         if spec.use_ln:
             t = layer_norm(t, P[f"{prefix}/ln/gamma"])
-        t = act(conv(t, P[f"{prefix}/pw1/kernel"]), a)                  # conv_2 + activation (:991-993)
+        t = act(conv(t, P[f"{prefix}/pw1/kernel"]), spec.mlp_activation or a)   # conv_2 + activation (:991-993)
         t = conv(t, P[f"{prefix}/pw2/kernel"])                          # conv_3, linear (:1000-1002)
         if spec.use_gamma:
             t = channel_multiplier(t, P[f"{prefix}/gamma/w"])
@@ -298,14 +316,25 @@ def backbone_forward(spec: UnetLaplacianSpec, P: Dict[str, np.ndarray], xn: np.n
 
     def attention(prefix, x):
         B, H, W, C = x.shape
-        rh, rw = spec.attention_resolution
-        t = resize_bilinear(x, rh, rw)
+        rh, rw = (H, W) if spec.attention_full else spec.attention_resolution
+        t = x if spec.attention_full else resize_bilinear(x, rh, rw)
         if spec.use_ln:
             t = layer_norm(t, P[f"{prefix}/ln/gamma"])
-        q, v, k = (leaky(conv(t, P[f"{prefix}/{n}/kernel"]), spec.attention_alpha).reshape(B, rh * rw, -1)
-                   for n in ("query", "value", "key"))
+        qkv_act = (lambda z: act(z, spec.attention_activation)) if spec.attention_activation else \
+                  (lambda z: leaky(z, spec.attention_alpha))
+        if spec.attention_full:
+            # the archive's graph (operator list of denoiser_model.tflite): keras Attention fed the rank-4 maps without a
+            # reshape, i.e. one sequence per image ROW (scores [B,H,W,W]), and handed over in the order [query, key, value]
+            # where keras reads [query, value, key]: scores = query_conv . value_conv^T, output = softmax . key_conv
+            q, v, k = (qkv_act(conv(t, P[f"{prefix}/{n}/kernel"])).reshape(B * rh, rw, -1) for n in ("query", "key", "value"))
+        else:
+            q, v, k = (qkv_act(conv(t, P[f"{prefix}/{n}/kernel"])).reshape(B, rh * rw, -1) for n in ("query", "value", "key"))
         t = dot_attention(q, v, k).reshape(B, rh, rw, -1)
-        t = resize_bilinear(t, H, W)
+        if spec.attention_full:
+            if spec.use_ln:
+                t = layer_norm(t, P[f"{prefix}/ln1/gamma"])
+        else:
+            t = resize_bilinear(t, H, W)
         t = conv(t, P[f"{prefix}/out/kernel"])                           # output_activation "linear" (:331)
         return channel_multiplier(t, P[f"{prefix}/gamma/w"])             # use_gamma=True fixed (:326)
 
@@ -317,9 +346,10 @@ def backbone_forward(spec: UnetLaplacianSpec, P: Dict[str, np.ndarray], xn: np.n
                 x = x + attention(f"enc{d}_{w}", x)
             else:
                 x = x + convnext(f"enc{d}_{w}", x)                      # Add (:351-354), StochasticDepth = identity
-        if spec.use_output_normalization and spec.use_ln:
+        if spec.use_output_normalization and spec.use_ln and not spec.output_norm_at_heads:
             x = layer_norm(x, P[f"enc{d}/out_ln/gamma"])                 # keras default epsilon 1e-3 (:359)
-        x = act(x, a)                                                    # :360
+        if spec.level_activation:
+            x = act(x, a)                                                # :360
         nodes[d] = x
         if d != spec.depth - 1:
             if spec.use_laplacian or spec.use_laplacian_averaging:
@@ -343,7 +373,7 @@ def backbone_forward(spec: UnetLaplacianSpec, P: Dict[str, np.ndarray], xn: np.n
     for d in reversed(range(spec.depth - 1)):
         low = outs[d + 1]
         if spec.upsample_type == "upsample_laplacian_conv2d":
-            if a == "linear":                                            # upsampling.py:80-90
+            if a == "linear" or spec.upsample_linear:                    # upsampling.py:80-90
                 up = O.upsample_bilinear_2x(conv(low, P[f"up{d}/kernel"]))
             else:                                                        # :91-102
                 up = act(conv(O.upsample_bilinear_2x(low), P[f"up{d}/kernel"]), a)
@@ -368,9 +398,12 @@ def backbone_forward(spec: UnetLaplacianSpec, P: Dict[str, np.ndarray], xn: np.n
             x = act(conv(x, P[f"mix{d}/kernel"]), a)
         for w in range(spec.width):
             x = x + convnext(f"dec{d}_{w}", x)
-        if spec.use_output_normalization and spec.use_ln:
+        if spec.use_output_normalization and spec.use_ln and not spec.output_norm_at_heads:
             x = layer_norm(x, P[f"dec{d}/out_ln/gamma"])
         outs[d] = x
+    if spec.use_output_normalization and spec.use_ln and spec.output_norm_at_heads:
+        last = spec.depth - 1
+        outs = {d: layer_norm(outs[d], P[f"enc{d}/out_ln/gamma" if d == last else f"dec{d}/out_ln/gamma"]) for d in outs}
     return [outs[d] for d in range(spec.depth)]                          # deepest-last after the double reverse (:569-588)
 
 

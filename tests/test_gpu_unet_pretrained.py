@@ -1,0 +1,66 @@
+"""The reference's trained unet_laplacian_v5.6 network on the HIP path: parity with the oracle on real weights and real
+frames, and the reference's own acceptance test (tests/bfcnn/test_pretrained.py: the denoised frame beats the noisy one
+in PSNR, SSIM and MAE for noise of 10..30 grey levels)."""
+import numpy as np
+import pytest
+
+import blind_image_denoising_amd as bf
+from oracle import unet_oracle as U
+import unet_v56 as V
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def net():
+    z, cfg = V.load()
+    spec = U.UnetLaplacianSpec.from_config(cfg)
+    m = bf.model_builder(cfg, device="cuda").hydra
+    assert [(v[0], tuple(v[1])) for v in m.trainable_variables] == [(n, tuple(s)) for n, s, _ in spec.tensors()]
+    m.set_weights(z["params"])
+    return z, spec, np.asarray(z["params"]), m
+
+
+@pytest.mark.parametrize("arith", [1, 0], ids=["f16x3", "f32"])
+def test_trained_network_matches_oracle(net, arith):
+    z, spec, params, m = net
+    m.set_option("arith", arith)
+    clean = z["kitti"][:1, 32:160, 16:208]                       # 128 x 192: rows and columns differ, no padding
+    noisy = V.corrupt(clean, 20.0, seed=3)
+    got, ref = m(noisy.astype(np.float32)), U.hydra_forward(spec, params, noisy.astype(np.float64))
+    assert len(got) == 3
+    for g, r in zip(got, ref):
+        g = np.asarray(g, np.float64)
+        assert g.shape == r.shape and np.isfinite(g).all()
+        assert np.abs(g - r).mean() / 255.0 <= 1e-4, np.abs(g - r).mean() / 255.0
+    den, want = bf.DenoiserModule(m)(noisy), U.denoiser_module_call(spec, params, noisy)
+    d = np.abs(den.astype(np.int32) - want.astype(np.int32))
+    assert den.dtype == np.uint8 and d.max() <= 1 and (d > 0).mean() < 0.01, (d.max(), (d > 0).mean())
+    m.set_option("arith", 1)
+
+
+def test_trained_network_non_power_of_two_frame(net):
+    """DenoiserModule pads to a power of two (module_denoiser.py:53-56): a 100 x 180 frame runs as 128 x 256."""
+    z, spec, params, m = net
+    noisy = V.corrupt(z["kitti"][1:2, 10:110, 20:200], 15.0, seed=4)
+    den, want = bf.DenoiserModule(m)(noisy), U.denoiser_module_call(spec, params, noisy)
+    d = np.abs(den.astype(np.int32) - want.astype(np.int32))
+    assert den.shape == noisy.shape and d.max() <= 1 and (d > 0).mean() < 0.01
+
+
+@pytest.mark.parametrize("std", [10.0, 15.0, 20.0, 25.0, 30.0])
+def test_reference_acceptance_test_on_the_hip_path(net, std):
+    z, _, _, m = net
+    clean = z["kitti"][:1]
+    noisy = V.corrupt(clean, std, seed=int(std))
+    V.assert_denoised(clean, noisy, bf.DenoiserModule(m)(noisy), f"std {std}")
+
+
+@pytest.mark.parametrize("std", [15.0, 20.0, 25.0, 30.0])
+def test_reference_acceptance_test_second_frame(net, std):
+    """heavily textured crop (foliage): the network's floor error (about 7 grey levels here) is above the noise at
+    std 10, so the inequalities start at 15."""
+    z, _, _, m = net
+    clean = z["kitti"][1:2]
+    noisy = V.corrupt(clean, std, seed=int(std))
+    V.assert_denoised(clean, noisy, bf.DenoiserModule(m)(noisy), f"std {std}")

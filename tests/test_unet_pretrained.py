@@ -1,0 +1,92 @@
+"""Pins of the unet_laplacian oracle by the reference's own artifacts (no TensorFlow needed):
+  * known-answer constants of the network the reference exported to TFLite (tests/golden/unet_v56.npz, "kat/..."):
+    GaussianFilter taps, per-channel int8 scales of conv_3 * ChannelLearnableMultiplier, scales of the attention kernels;
+  * the reference's test of its trained network (tests/bfcnn/test_pretrained.py): the trained tensors of
+    pretrained/unet_laplacian_v5.6 run through the oracle must denoise the KITTI frames that test uses."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import unet_oracle as U
+import unet_v56 as V
+
+
+@pytest.fixture(scope="module")
+def net():
+    z, cfg = V.load()
+    spec = U.UnetLaplacianSpec.from_config(cfg)
+    assert spec.param_count() == z["params"].size == 334976
+    return z, cfg, spec, np.asarray(z["params"])
+
+
+def test_archive_graph_revision(net):
+    _, cfg, spec, _ = net
+    assert (spec.depth, spec.width, spec.filters) == (3, 3, 32)
+    assert spec.mlp_activation == "gelu" and spec.attention_activation == "gelu" and spec.activation == "leaky_relu_01"
+    assert spec.attention_full and spec.output_norm_at_heads and spec.upsample_linear and not spec.level_activation
+    assert not spec.use_laplacian_averaging
+
+
+def test_gaussian_taps_equal_the_exported_constant(net):
+    z = net[0]
+    g = U.gaussian_kernel_3((3, 3)).astype(np.float32)
+    for name, C in (("kat/gauss0", 32), ("kat/gauss1", 64)):
+        k = z[name]
+        assert k.shape == (1, 3, 3, C)
+        assert np.array_equal(k, np.broadcast_to(g[None, :, :, None], k.shape))
+
+
+@pytest.mark.parametrize("block", ["enc0_0", "enc1_1", "dec0_2", "dec1_0"])
+def test_multiplier_function_pinned_by_quantisation_scales(net, block):
+    """the converter folded the multiplier into conv_3 and quantised per output channel: scale = max|w * m| / 127.
+    Only m = tanh(relu(1 + w_mult)) (custom_layers.py:304-306) reproduces the exported scales."""
+    z, _, spec, params = net
+    P = U._views(spec, params, np.float64)
+    w3, wm = P[f"{block}/pw2/kernel"][0, 0], P[f"{block}/gamma/w"]
+    want = z[f"kat/conv3_scales/{block}"]
+    got = np.abs(U.channel_multiplier(w3, wm)).max(axis=0) / 127.0
+    live = want > 1e-7                              # switched-off channels (multiplier 0) carry the converter's floor scale
+    assert live.sum() >= 4
+    np.testing.assert_allclose(got[live], want[live], rtol=2e-6)
+    for other in (np.maximum(1.0 + wm, 0.0), 1.0 + wm, np.ones_like(wm)):
+        alt = np.abs(w3 * other).max(axis=0) / 127.0
+        assert not np.allclose(alt[live], want[live], rtol=1e-3)
+
+
+def test_attention_kernels_pinned_by_quantisation_scales(net):
+    z, _, spec, params = net
+    P = U._views(spec, params, np.float64)
+    for n in ("key", "query", "value"):
+        np.testing.assert_allclose(np.abs(P[f"enc2_0/{n}/kernel"][0, 0]).max(axis=0) / 127.0, z[f"kat/attn_scales/{n}"], rtol=2e-6)
+
+
+@pytest.mark.parametrize("std", [20.0, 30.0])
+def test_trained_network_denoises_through_the_oracle(net, std):
+    z, _, spec, params = net
+    clean = z["kitti"][:1, 64:192, 64:192]
+    noisy = V.corrupt(clean, std, seed=int(std))
+    V.assert_denoised(clean, noisy, U.denoiser_module_call(spec, params, noisy), f"std {std}")
+
+
+def test_multi_scale_outputs_follow_the_image(net):
+    """the half and quarter resolution heads of the trained network reproduce the down-sampled frame (deep supervision
+    targets, utilities.py:625-685): a wrong level wiring shows here first."""
+    z, _, spec, params = net
+    clean = z["kitti"][:1, 64:192, 64:192].astype(np.float64)
+    outs = U.hydra_forward(spec, params, clean)
+    ref = clean
+    for i, o in enumerate(outs):
+        assert o.shape == ref.shape
+        assert np.corrcoef(o.ravel(), ref.ravel())[0, 1] > (0.97, 0.95, 0.85)[i], i
+        ref = 0.25 * (ref[:, 0::2, 0::2] + ref[:, 1::2, 0::2] + ref[:, 0::2, 1::2] + ref[:, 1::2, 1::2])
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/bfcnn/pretrained/unet_laplacian_v5.6/model_hydra.keras"),
+                    reason="the reference archive exists only in the build container")
+def test_importer_reproduces_the_fixture(net):
+    from blind_image_denoising_amd import keras_import
+    _, cfg, spec, params = net
+    config, h5 = keras_import.read_archive("/root/reference/bfcnn/pretrained/unet_laplacian_v5.6/model_hydra.keras")
+    assert config == cfg
+    assert np.array_equal(keras_import.params_from_archive(config, h5, spec.tensors()), params)
