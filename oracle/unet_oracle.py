@@ -10,11 +10,21 @@ A NumPy fp64 restatement of what the reference builds for `configs/unet_laplacia
   bfcnn/upsampling.py:37-116, bfcnn/downsampling.py:37-72, bfcnn/model.py:58-162 (hydra with one head per scale),
   :251-359 (denoiser head), bfcnn/utilities.py:132-224 (conv2d_wrapper: conv -> activation layer).
 
-PARITY UNPINNED beyond structure: the arithmetic lives in tensorflow==2.13.1 / keras 2.13.1 (un-vendored, not
-installable here), the reference ships no golden vectors for this graph, and its one trained file
-(bfcnn/pretrained/unet_laplacian_v5.6) was saved by older code than the snapshot builder.
-The op semantics follow SURVEY.md appendix A; convolutions / resize / attention are cross-checked against
-torch-CPU fp64 in tests/test_unet_oracle.py.
+PINNED BY THE REFERENCE'S OWN ARTIFACTS for the graph revision of its one trained network
+(bfcnn/pretrained/unet_laplacian_v5.6: model_hydra.keras + the same network exported as denoiser_model.tflite), with
+no TensorFlow involved (tests/test_unet_pretrained.py, fixture tests/golden/unet_v56.npz written by
+tests/golden/make_unet_v56_fixture.py):
+  * structure: the operator list of the exported graph (tools/exp/tflite_graph.py) gives the dataflow this file follows
+    for that revision (spec fields mlp_activation .. upsample_linear);
+  * known-answer constants: the GaussianFilter taps, LayerNorm epsilon, head constants, and all 74 weight tensors of the
+    exported graph (float constants exactly, int8 kernels through their per-channel scales max|w|/127, which also fixes
+    ChannelLearnableMultiplier = tanh(relu(1 + w)) because the converter folded it into conv_3);
+  * behaviour: the reference's acceptance test for a trained network (tests/bfcnn/test_pretrained.py: denoised beats
+    noisy in PSNR, SSIM and MAE on its KITTI frames) holds for the oracle and for the HIP path with the real weights.
+What stays UNPINNED: bit-level TensorFlow numerics (no golden activations exist), and the pieces only the snapshot
+builder has (16x16 resized attention, AveragePooling split, in-line output norms, attention gates): those follow
+SURVEY.md appendix A; convolutions / resize / attention are cross-checked against torch-CPU fp64 in
+tests/test_unet_oracle.py.
 
 One deliberate deviation: ConvolutionalSelfAttention hands the STRING "leaky_relu" to keras.layers.Conv2D
 (custom_layers.py:1272-1282 with backbone_unet_laplacian.py:330); Keras 2.13 has no activation of that name

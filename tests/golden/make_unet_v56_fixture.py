@@ -58,14 +58,48 @@ def main():
     for name, (y, x) in (("kitti_0000000000.png", (100, 400)), ("kitti_0000000017.png", (110, 700))):
         im = np.asarray(Image.open(os.path.join(kitti, name)).convert("RGB"))
         crops.append(im[y:y + 256, x:x + 256])
-    tfl = tflite_tensors(os.path.join(arch, "denoiser_model.tflite"))
-    pick = lambda frag: next(v for k, v in tfl.items() if k.split(";")[0].endswith(frag))
-    kat = {"gauss0": pick("unet_laplacian/gaussian_filter/depthwise")[0],
-           "gauss1": pick("unet_laplacian/gaussian_filter_1/depthwise")[0]}
-    for blk, ours in (("encoder_0_0", "enc0_0"), ("encoder_1_1", "enc1_1"), ("decoder_0_2", "dec0_2"), ("decoder_1_0", "dec1_0")):
-        kat[f"conv3_scales/{ours}"] = pick(f"unet_laplacian/{blk}/conv2d_1/Conv2D")[1]
-    for n, frag in (("key", "conv2d"), ("query", "conv2d_1"), ("value", "conv2d_2")):
-        kat[f"attn_scales/{n}"] = pick(f"unet_laplacian/convolutional_self_attention/{frag}/Conv2D")[1]
+    tfl = {k.split(";")[0]: v for k, v in tflite_tensors(os.path.join(arch, "denoiser_model.tflite")).items()}
+    U_ = "hydra/unet_laplacian_backbone/unet_laplacian/"
+
+    def const(name):
+        return tfl[name][0]
+
+    def scales(name):                                   # the kernel is ".../Conv2D", or ".../Conv2D1" next to a zero bias
+        for n in (name, name + "1"):
+            if n in tfl and tfl[n][1] is not None:
+                return tfl[n][1]
+        raise KeyError(name)
+
+    def ln_gamma(layer):
+        return next(v[0] for k, v in tfl.items() if k.startswith(U_ + layer + "/layer_normalization") and k.endswith("mul_4/ReadVariableOp"))
+
+    # every weight the exported graph holds, keyed by OUR tensor name: "f/" float constants, "s/" per-output-channel int8
+    # scales (max|w| / 127 over the kernel the converter saw, i.e. with the multiplier folded in where there is one)
+    kat = {"gauss0": const(U_ + "gaussian_filter/depthwise"), "gauss1": const(U_ + "gaussian_filter_1/depthwise"),
+           "f/base/kernel": const(U_ + "conv2d/Conv2D/ReadVariableOp")}
+    blocks = [(f"enc{d}_{w}", f"encoder_{d}_{w}") for d in range(2) for w in range(3)] + \
+             [(f"dec{d}_{w}", f"decoder_{d}_{w}") for d in range(2) for w in range(3)]
+    for ours, theirs in blocks:
+        dw = U_ + theirs + "/depthwise_conv2d/depthwise"
+        if tfl[dw][0] is not None:
+            kat[f"f/{ours}/dw/kernel"] = const(dw)
+        else:
+            kat[f"s/{ours}/dw/kernel"] = tfl[dw][1]
+        kat[f"f/{ours}/ln/gamma"] = ln_gamma(theirs)
+        kat[f"s/{ours}/pw1/kernel"] = scales(U_ + theirs + "/conv2d/Conv2D")
+        kat[f"s/{ours}/pw2/kernel"] = scales(U_ + theirs + "/conv2d_1/Conv2D")
+    for i in range(3):
+        theirs = "convolutional_self_attention" + ("" if i == 0 else f"_{i}")
+        lns = sorted((k for k in tfl if k.startswith(U_ + theirs + "/layer_normalization") and k.endswith("mul_4/ReadVariableOp")),
+                     key=lambda k: int(k.split("layer_normalization_")[1].split("/")[0]))
+        kat[f"f/enc2_{i}/ln/gamma"], kat[f"f/enc2_{i}/ln1/gamma"] = const(lns[0]), const(lns[1])
+        for n, frag in (("key", "conv2d"), ("query", "conv2d_1"), ("value", "conv2d_2"), ("out", "conv2d_3")):
+            kat[f"s/enc2_{i}/{n}/kernel"] = scales(U_ + theirs + f"/{frag}/Conv2D")
+    for ours, theirs in (("down0", "conv2d_1"), ("down1", "conv2d_2"), ("up1", "conv2d_3"), ("up0", "conv2d_4")):
+        kat[f"s/{ours}/kernel"] = scales(U_ + theirs + "/Conv2D")
+    kat["f/dec0/out_ln/gamma"] = const(U_ + "layer_normalization_18/mul_4/ReadVariableOp")
+    kat["s/head0/conv0/kernel"] = scales("hydra/denoiser_head_0/conv2d_7/Conv2D")
+    kat["f/head0/conv1/kernel"] = const("hydra/denoiser_head_0/conv2d_8/Conv2D")
     assert all(v is not None for v in kat.values()), [k for k, v in kat.items() if v is None]
     out = os.path.join(ROOT, "tests", "golden", "unet_v56.npz")
     np.savez_compressed(out, params=params, config=np.frombuffer(json.dumps(config).encode(), np.uint8),

@@ -37,28 +37,56 @@ def test_gaussian_taps_equal_the_exported_constant(net):
         assert np.array_equal(k, np.broadcast_to(g[None, :, :, None], k.shape))
 
 
-@pytest.mark.parametrize("block", ["enc0_0", "enc1_1", "dec0_2", "dec1_0"])
-def test_multiplier_function_pinned_by_quantisation_scales(net, block):
-    """the converter folded the multiplier into conv_3 and quantised per output channel: scale = max|w * m| / 127.
-    Only m = tanh(relu(1 + w_mult)) (custom_layers.py:304-306) reproduces the exported scales."""
+def _effective_kernel(P, name):
+    """the kernel the converter saw: [..., cout] with the ChannelLearnableMultiplier folded in where one follows."""
+    w = P[name]
+    prefix = name.rsplit("/", 2)[0]
+    if name.endswith("/pw2/kernel") or name.endswith("/out/kernel"):
+        w = U.channel_multiplier(w, P[f"{prefix}/gamma/w"])
+    return w
+
+
+def test_every_exported_weight_matches_the_imported_tensor(net):
+    """float constants and per-output-channel int8 scales (max|w| / 127) of the TFLite graph, which names its tensors after
+    the keras layers of the GRAPH (encoder_0_1/conv2d_1/...), against the tensors the importer placed by the archive's
+    variable ORDER: pins the importer's mapping for all 12 ConvNext blocks, 3 attention blocks, the level projections,
+    the full-resolution head, and -- through the folded kernels -- the multiplier function tanh(relu(1 + w))."""
     z, _, spec, params = net
     P = U._views(spec, params, np.float64)
-    w3, wm = P[f"{block}/pw2/kernel"][0, 0], P[f"{block}/gamma/w"]
-    want = z[f"kat/conv3_scales/{block}"]
-    got = np.abs(U.channel_multiplier(w3, wm)).max(axis=0) / 127.0
-    live = want > 1e-7                              # switched-off channels (multiplier 0) carry the converter's floor scale
-    assert live.sum() >= 4
-    np.testing.assert_allclose(got[live], want[live], rtol=2e-6)
+    seen = 0
+    for key in z.files:
+        if key.startswith("kat/f/"):
+            name, want = key[len("kat/f/"):], z[key]
+            w = P[name]
+            if name.endswith("/dw/kernel"):
+                assert np.array_equal(want[0], w[:, :, :, 0].astype(np.float32)), name
+            elif name == "head0/conv1/kernel":                    # tanh(2 x): the 2 is folded into the kernel, stored OHWI
+                np.testing.assert_allclose(want[:, 0, 0, :], 2.0 * w[0, 0].T, rtol=1e-6, err_msg=name)
+            else:
+                assert np.array_equal(want.reshape(w.shape), w.astype(np.float32)), name
+        elif key.startswith("kat/s/"):
+            name, want = key[len("kat/s/"):], z[key]
+            w = _effective_kernel(P, name)
+            got = (np.abs(w[:, :, :, 0]).max(axis=(0, 1)) if name.endswith("/dw/kernel") else np.abs(w).max(axis=(0, 1, 2))) / 127.0
+            live = want > 1e-7                                    # switched-off channels carry the converter's floor scale
+            assert live.any(), name                               # (dec1_2 keeps 5 of its 64 output channels)
+            np.testing.assert_allclose(got[live], want[live], rtol=3e-6, err_msg=name)
+            assert (got[~live] < 1e-7).all(), name
+        else:
+            continue
+        seen += 1
+    assert seen == 74
+
+
+@pytest.mark.parametrize("block", ["enc0_0", "enc1_1", "dec0_2", "dec1_0"])
+def test_other_multiplier_functions_do_not_fit(net, block):
+    z, _, spec, params = net
+    P = U._views(spec, params, np.float64)
+    w3, wm, want = P[f"{block}/pw2/kernel"][0, 0], P[f"{block}/gamma/w"], z[f"kat/s/{block}/pw2/kernel"]
+    live = want > 1e-7
     for other in (np.maximum(1.0 + wm, 0.0), 1.0 + wm, np.ones_like(wm)):
         alt = np.abs(w3 * other).max(axis=0) / 127.0
         assert not np.allclose(alt[live], want[live], rtol=1e-3)
-
-
-def test_attention_kernels_pinned_by_quantisation_scales(net):
-    z, _, spec, params = net
-    P = U._views(spec, params, np.float64)
-    for n in ("key", "query", "value"):
-        np.testing.assert_allclose(np.abs(P[f"enc2_0/{n}/kernel"][0, 0]).max(axis=0) / 127.0, z[f"kat/attn_scales/{n}"], rtol=2e-6)
 
 
 @pytest.mark.parametrize("std", [20.0, 30.0])
