@@ -140,13 +140,22 @@ def unet_bench(args, torch, bf, O, rank, local_rank, world, dist):
     output 0).  Images are independent: N ranks = N replicas, no collective."""
     from oracle import unet_oracle as U
     B, S = (32 if args.batch == 128 else args.batch), (512 if args.size == 256 else args.size)
-    cfg = U.canonical_config()
+    trained = args.unet_graph == "v5.6"
+    if trained:
+        # the reference's trained network (graph revision and tensors of pretrained/unet_laplacian_v5.6, committed as data
+        # in tests/golden/unet_v56.npz; same size as the v5 graph: 334 976 parameters)
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "unet_v56.npz"))
+        cfg = {"model": json.loads(bytes(z["config"]).decode())}
+        params = np.asarray(z["params"])
+    else:
+        cfg = U.canonical_config()
     spec = U.UnetLaplacianSpec.from_config(cfg["model"])
-    params = U.init_params(spec, seed=42)
+    if not trained:
+        params = U.init_params(spec, seed=42)
     model = bf.model_builder(cfg["model"], device=f"cuda:{local_rank}").hydra
     model.set_weights(params)
     module = bf.DenoiserModule(model)
-    _, base = O.synthetic_batch(4, S, S, sigma=20.0, seed=1234 + rank)
+    clean, base = O.synthetic_batch(4, S, S, sigma=20.0, seed=1234 + rank)
     noisy = torch.from_numpy(np.concatenate([base] * ((B + 3) // 4), axis=0)[:B]).cuda()
 
     def barrier():
@@ -180,7 +189,7 @@ def unet_bench(args, torch, bf, O, rank, local_rank, world, dist):
     P = model._pack()
     x0 = torch.randn((B, S, S, 32), device=f"cuda:{local_rank}")
     blk = lambda: UL.convnext_block_h3(x0, P["enc0_0/dw/kernel"], P["enc0_0/ln/gamma"], P["enc0_0/mlp_h3"], P["enc0_0/gamma/w"],
-                                       model.activation)
+                                       model.mlp_activation)
     for _ in range(3):
         blk()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -199,7 +208,8 @@ def unet_bench(args, torch, bf, O, rank, local_rank, world, dist):
         "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (ConvNext MLPs: f16x2 split hi+lo, fp32 accumulate)", "data": "synthetic",
-        "config": {"workload": f"unet_laplacian v5 graph (depth 3, width 3, filters 32/64/128, attention on the deepest "
+        "config": {"workload": f"unet_laplacian {'v5.6 trained archive graph' if trained else 'v5 graph'} (depth 3, width 3, "
+                               f"filters 32/64/128, attention on the deepest "
                                f"level) inference, batch={B}/GPU {S}x{S}x3 uint8->uint8 (DenoiserModule.__call__)",
                    "batch_per_gpu": B, "parallelism": f"replicas x{world}, no collective"},
         "parity": {"max_abs_lsb": int(diff.max()), "mean_abs_lsb": float(diff.mean()), "checked": "one 64x64 crop vs oracle"},
@@ -211,6 +221,11 @@ def unet_bench(args, torch, bf, O, rank, local_rank, world, dist):
                      "launch_us": launch_us,
                      "mfma": {"dtype": "f16 (split hi/lo, 3 products)", "algorithmic_tflops": blk_flop / launch_us / 1e6,
                               "peak_tflops": MFMA_F16_PEAK_TFLOPS}}}
+    if trained:
+        mae = lambda a, b: float(np.abs(a.astype(np.float64) - b.astype(np.float64)).mean())
+        den = out[:4].cpu().numpy()
+        rec["denoising"] = {"mae_noisy": mae(clean, base), "mae_denoised": mae(clean, den),
+                            "note": "synthetic smooth fields + truncated normal noise, std 20 (SURVEY 8d); trained weights"}
     if not args.no_cpu_baseline:
         import time as _t
         small = base[:1, :256, :256]
@@ -349,6 +364,8 @@ def main():
     ap.add_argument("--fused-tile", type=int, default=None, help="exact-fp32 fused-block tile geometry variant (A/B only)")
     ap.add_argument("--arith", type=int, default=1, help="1 = split-f16 fused blocks (default), 0 = exact-fp32 fused blocks")
     ap.add_argument("--h3-variant", type=int, default=None, help="split-f16 kernel variant (A/B only)")
+    ap.add_argument("--unet-graph", choices=["v5", "v5.6"], default="v5",
+                    help="--mode unet: v5 = snapshot builder graph, random weights; v5.6 = the reference's trained network")
     ap.add_argument("--mode", choices=["inference", "train", "pyramid", "unet", "latency"], default="inference",
                     help="train: BASELINE.json configs[3] -- one data-parallel training step per step (L1 loss, "
                          "batch sharded over the ranks, ONE gradient all-reduce, clip + Adam); not the headline metric")
