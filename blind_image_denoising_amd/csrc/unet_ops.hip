@@ -1109,7 +1109,7 @@ __global__ __launch_bounds__(UO_ATT_THREADS) void uo_attention_kernel(const floa
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* ks = lds;                       // [T][A]
     float* vs = lds + (size_t)T * UO_ATT_A;
-    const int b = blockIdx.y;
+    const int b = blockIdx.x;              // sequences on x: one per image, or one per image ROW (B x H of them)
     const float* kb = k + (int64_t)b * T * UO_ATT_A;
     const float* vb = v + (int64_t)b * T * UO_ATT_A;
     for (int i = threadIdx.x; i < T * UO_ATT_A / 4; i += UO_ATT_THREADS) {
@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(UO_ATT_THREADS) void uo_attention_kernel(const floa
         reinterpret_cast<f32x4*>(vs)[i] = reinterpret_cast<const f32x4*>(vb)[i];
     }
     __syncthreads();
-    const int row = blockIdx.x * UO_ATT_THREADS + threadIdx.x;
+    const int row = blockIdx.y * UO_ATT_THREADS + threadIdx.x;
     if (row >= T) return;
     float qr[UO_ATT_A], acc[UO_ATT_A];
     const float* qp = q + ((int64_t)b * T + row) * UO_ATT_A;
@@ -1160,7 +1160,7 @@ extern "C" int bf_op_attention(const float* q, const float* v, const float* k, f
             return BF_EHIP;
         attr_done = true;
     }
-    hipLaunchKernelGGL(uo_attention_kernel, dim3((T + UO_ATT_THREADS - 1) / UO_ATT_THREADS, B), dim3(UO_ATT_THREADS), lds,
+    hipLaunchKernelGGL(uo_attention_kernel, dim3(B, (T + UO_ATT_THREADS - 1) / UO_ATT_THREADS), dim3(UO_ATT_THREADS), lds,
                        (hipStream_t)stream, q, v, k, out, T);
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }

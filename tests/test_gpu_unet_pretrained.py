@@ -64,3 +64,15 @@ def test_reference_acceptance_test_second_frame(net, std):
     clean = z["kitti"][1:2]
     noisy = V.corrupt(clean, std, seed=int(std))
     V.assert_denoised(clean, noisy, bf.DenoiserModule(m)(noisy), f"std {std}")
+
+
+def test_registry_model_is_the_trained_network(net):
+    """bfcnn.load_denoiser_model(name) / models[name]["denoiser"]() as in tests/bfcnn/test_pretrained.py:26-29."""
+    z, _, _, m = net
+    clean = z["kitti"][:1, :128, :128]
+    noisy = V.corrupt(clean, 25.0, seed=9)
+    module = bf.load_denoiser_model("unet_laplacian_v5.6")
+    den = module(noisy)
+    assert np.array_equal(den, bf.DenoiserModule(m)(noisy))
+    V.assert_denoised(clean, noisy, den, "registry model")
+    assert np.array_equal(bf.models["unet_laplacian_v5.6"]["denoiser"]()(noisy), den)

@@ -118,3 +118,17 @@ def test_importer_reproduces_the_fixture(net):
     config, h5 = keras_import.read_archive("/root/reference/bfcnn/pretrained/unet_laplacian_v5.6/model_hydra.keras")
     assert config == cfg
     assert np.array_equal(keras_import.params_from_archive(config, h5, spec.tensors()), params)
+
+
+def test_registry_offers_the_reference_pretrained_name(net):
+    """bfcnn.models / load_default_denoiser (bfcnn/__init__.py:48-75, 118-122): same key, same dict fields; the packaged
+    tensors are the fixture's."""
+    import blind_image_denoising_amd as bf
+    _, _, _, params = net
+    entry = bf.models["unet_laplacian_v5.6"]
+    assert set(entry) >= {"directory", "denoiser", "configuration", "saved_model_path"}
+    assert os.path.isfile(entry["configuration"]) and callable(entry["denoiser"]) and bf.load_default_denoiser is not None
+    with np.load(os.path.join(entry["saved_model_path"], "weights.npz")) as w:
+        assert np.array_equal(w["params"], params)
+    with pytest.raises(ValueError):
+        bf.load_denoiser_model("no_such_model")
