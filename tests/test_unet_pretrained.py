@@ -132,3 +132,26 @@ def test_registry_offers_the_reference_pretrained_name(net):
         assert np.array_equal(w["params"], params)
     with pytest.raises(ValueError):
         bf.load_denoiser_model("no_such_model")
+
+
+def test_exported_operator_options_match_the_oracle_semantics(net):
+    """what the reference's converter recorded for the operators of the trained graph, against what the oracle computes:
+    exact-erf GELU, LeakyReLU(0.1), bilinear resize with half-pixel centres and no corner alignment, softmax(q k^T) v
+    without a scale, stride-1 SAME convolutions with no fused activation."""
+    import json
+    from oracle import bfcnn_oracle as O
+    z = net[0]
+    opt = json.loads(bytes(z["tflite_options"]).decode())
+    assert opt["GELU"] == [{"approximate": 0.0}]
+    x = np.linspace(-4, 4, 33)
+    from scipy.special import erf
+    np.testing.assert_allclose(U.act(x, "gelu"), 0.5 * x * (1 + erf(x / np.sqrt(2))), rtol=1e-12)
+    assert opt["LEAKY_RELU"] == [{"alpha": 0.1}]
+    np.testing.assert_allclose(U.act(x, "leaky_relu_01"), np.where(x > 0, x, 0.1 * x))
+    assert opt["RESIZE_BILINEAR"] == [{"align_corners": 0.0, "half_pixel_centers": 1.0}]
+    ramp = np.arange(4, dtype=np.float64).reshape(1, 1, 4, 1)            # half-pixel centres: 0, .25, .75, 1.25, ... clamped
+    np.testing.assert_allclose(O.upsample_bilinear_2x(np.repeat(ramp, 2, axis=1))[0, 0, :, 0], [0, 0.25, 0.75, 1.25, 1.75, 2.25, 2.75, 3])
+    assert opt["SOFTMAX"] == [{"beta": 1.0}]
+    assert opt["BATCH_MATMUL"] == [{"adj_x": 0.0, "adj_y": 1.0}, {"adj_x": 0.0, "adj_y": 0.0}]
+    for k in ("CONV_2D", "DEPTHWISE_CONV_2D"):
+        assert opt[k] == [{"padding_valid": 0.0, "stride_w": 1.0, "stride_h": 1.0, "fused_activation": 0.0}]
