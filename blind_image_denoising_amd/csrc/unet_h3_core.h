@@ -1,0 +1,157 @@
+// Shared device code of the split-f16 ConvNext kernels (unet_h3.hip: MLP / decoder block kernels and weight packing;
+// unet_h3_enc.hip: fused encoder block kernels).  Two translation units so that they compile side by side.
+#pragma once
+#include "bf_common.h"
+#include <math.h>
+#include <string.h>
+
+#ifndef UH_ROLE_ABLATE
+#define UH_ROLE_ABLATE 0   // diagnostic builds of uh_enc32s_kernel: 1 consumers idle, 2 producers idle
+#endif
+
+typedef _Float16 uh8 __attribute__((ext_vector_type(8)));
+typedef _Float16 uh4 __attribute__((ext_vector_type(4)));
+typedef _Float16 uh2 __attribute__((ext_vector_type(2)));
+#define UH_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#ifndef UH_MLP_VALU_PER_MFMA
+#define UH_MLP_VALU_PER_MFMA 3
+#endif
+
+// v - float(one half of the packed f16 pair hh) in one instruction (v_fma_mix_f32)
+__device__ __forceinline__ float uh_sub_half(const float v, const unsigned hh, const bool high)
+{
+    float r;
+    if (high) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(v));
+    else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(v));
+    return r;
+}
+
+// 8 fp32 values -> hi / lo f16 fragments
+__device__ __forceinline__ void uh_split8(const f32x4 a, const f32x4 b, uh8& hi, uh8& lo)
+{
+    const uh4 ha = __builtin_convertvector(a, uh4), hb = __builtin_convertvector(b, uh4);
+    const unsigned p0 = __builtin_bit_cast(unsigned, (uh2){ha[0], ha[1]}), p1 = __builtin_bit_cast(unsigned, (uh2){ha[2], ha[3]});
+    const unsigned p2 = __builtin_bit_cast(unsigned, (uh2){hb[0], hb[1]}), p3 = __builtin_bit_cast(unsigned, (uh2){hb[2], hb[3]});
+    const f32x4 da = {uh_sub_half(a[0], p0, false), uh_sub_half(a[1], p0, true), uh_sub_half(a[2], p1, false), uh_sub_half(a[3], p1, true)};
+    const f32x4 db = {uh_sub_half(b[0], p2, false), uh_sub_half(b[1], p2, true), uh_sub_half(b[2], p3, false), uh_sub_half(b[3], p3, true)};
+    const uh4 la = __builtin_convertvector(da, uh4), lb = __builtin_convertvector(db, uh4);
+    hi = (uh8){ha[0], ha[1], ha[2], ha[3], hb[0], hb[1], hb[2], hb[3]};
+    lo = (uh8){la[0], la[1], la[2], la[3], lb[0], lb[1], lb[2], lb[3]};
+}
+
+// sum over the 8 consecutive lanes of a pixel in the depthwise layout (DPP butterfly: quad_perm xor 1, xor 2, half-row mirror)
+template <int CTRL>
+__device__ __forceinline__ float uh_dpp_add(float v)
+{
+    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true);
+    return v + __builtin_bit_cast(float, t);
+}
+__device__ __forceinline__ float uh_pixel_sum8(float v)
+{
+    v = uh_dpp_add<0xB1>(v);
+    v = uh_dpp_add<0x4E>(v);
+    return uh_dpp_add<0x141>(v);
+}
+
+template <int ACT>
+__device__ __forceinline__ float uh_act(float v, float alpha)
+{
+    if (ACT == 1) return fmaxf(v, 0.f);
+    if (ACT == 2) return fmaxf(v, alpha * v);                      // leaky relu, 0 <= alpha <= 1
+    if (ACT == 3) {
+        // exact (erf) GELU = v * Phi(v) without erff's two-branch polynomial (it doubled the time of the MLP kernels):
+        // Phi(|v|) = 1 - h, Phi(-|v|) = h, h = 0.5 (a1 t + .. + a5 t^5) exp(-v^2 / 2), t = 1 / (1 + p |v| / sqrt 2)
+        // (Abramowitz-Stegun 7.1.26).  Max |error| 4.2e-7 over [-12, 12] in fp32, the same as 0.5 v (1 + erff(v / sqrt 2)).
+        const float t = __builtin_amdgcn_rcpf(fmaf(0.231641888f, fabsf(v), 1.f));
+        float poly = fmaf(0.5307027145f, t, -0.7265760135f);
+        poly = fmaf(poly, t, 0.7107068705f);
+        poly = fmaf(poly, t, -0.142248368f);
+        poly = fmaf(poly, t, 0.127414796f) * t;
+        const float h = poly * __builtin_amdgcn_exp2f(v * v * -0.72134752044f);
+        return v * (v >= 0.f ? 1.f - h : h);
+    }
+    return v;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// the two GEMMs of the MLP on one wave's NP groups of 16 pixels: xh / xl = split B fragments of the input (K chunk c of 32
+// channels), w1l / w2l = the lane's byte address inside the LDS fragment arrays, acc2 = C / 16 output tiles
+template <int C, int NP, int ACT>
+__device__ __forceinline__ void uh_mlp_core(const uh8 (&xh)[C / 32][NP], const uh8 (&xl)[C / 32][NP], const char* w1l, const char* w2l,
+                                            const float inv1, const float alpha, f32x4 (&acc2)[C / 16][NP])
+{
+    constexpr int KC1 = C / 32, T1 = 4 * C / 16, KC2 = 4 * C / 32, T2 = C / 16;
+#pragma unroll
+    for (int t = 0; t < T2; ++t)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) acc2[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // GEMM1 of hidden tiles 2 c2, 2 c2 + 1 into h
+    auto gemm1 = [&](const int c2, f32x4 (&h)[2][NP]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) h[u][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < KC1; ++c) {
+                const int f = (c * T1 + 2 * c2 + u) * 2;
+                const uh8 ah = *reinterpret_cast<const uh8*>(w1l + f * 1024);
+                const uh8 al = *reinterpret_cast<const uh8*>(w1l + (f + 1) * 1024);
+#pragma unroll
+                for (int i = 0; i < NP; ++i) h[u][i] = UH_MFMA(ah, xh[c][i], h[u][i]);
+#pragma unroll
+                for (int i = 0; i < NP; ++i) h[u][i] = UH_MFMA(al, xh[c][i], h[u][i]);
+#pragma unroll
+                for (int i = 0; i < NP; ++i) h[u][i] = UH_MFMA(ah, xl[c][i], h[u][i]);
+            }
+        }
+    };
+    // activation + split of chunk c2 (the lane's 8 hidden values are its B fragment), then GEMM2 with K chunk c2
+    auto finish = [&](const int c2, f32x4 (&h)[2][NP]) {
+        uh8 bh[NP], bl[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            // straight-line code from the MFMAs to here: hipcc pads the MFMA -> VALU hazard itself (bf_acc_ready is for reads
+            // behind branches; its volatile s_nop would also pin the schedule)
+            f32x4 v0 = h[0][i] * inv1, v1 = h[1][i] * inv1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v0[r] = uh_act<ACT>(v0[r], alpha);
+                v1[r] = uh_act<ACT>(v1[r], alpha);
+            }
+            uh_split8(v0, v1, bh[i], bl[i]);
+        }
+#pragma unroll
+        for (int t = 0; t < T2; ++t) {
+            const int f = (c2 * T2 + t) * 2;
+            const uh8 ah = *reinterpret_cast<const uh8*>(w2l + f * 1024);
+            const uh8 al = *reinterpret_cast<const uh8*>(w2l + (f + 1) * 1024);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) acc2[t][i] = UH_MFMA(ah, bh[i], acc2[t][i]);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) acc2[t][i] = UH_MFMA(al, bh[i], acc2[t][i]);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) acc2[t][i] = UH_MFMA(ah, bl[i], acc2[t][i]);
+        }
+    };
+    // software pipeline: the matrix instructions of GEMM1 (chunk c2 + 1) are in the instruction stream before the
+    // vector-ALU work of chunk c2 (scale, activation, hi/lo split) that depends on the PREVIOUS GEMM1, and the scheduler is
+    // asked to interleave them (1 MFMA : UH_MLP_VALU_PER_MFMA VALU) so that a wave that is alone on its SIMD (the consumer
+    // waves of uh_enc32s_kernel) keeps both pipes busy
+    f32x4 hA[2][NP], hB[2][NP];
+    gemm1(0, hA);
+#pragma unroll
+    for (int c2 = 0; c2 < KC2; ++c2) {
+        if (c2 + 1 < KC2) {
+            if (c2 & 1) gemm1(c2 + 1, hA);
+            else gemm1(c2 + 1, hB);
+        }
+        if (c2 & 1) finish(c2, hB);
+        else finish(c2, hA);
+#pragma unroll
+        for (int g = 0; g < 6 * KC1 * NP + 3 * T2 * NP; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, UH_MLP_VALU_PER_MFMA, 0);    // VALU
+        }
+    }
+}

@@ -6,7 +6,8 @@ the flat float32 parameter vector in their inventory order.
 The one archive the reference ships (`pretrained/unet_laplacian_v5.6/model_hydra.keras`) was written by older code
 than the snapshot builder; what differs is detected from the archive itself and expressed through config keys of this
 package (not reference keys): `convnext_activation`, `encoder_level_activation`, `output_normalization_at_heads`,
-`attention_full_resolution`, `attention_activation` (see `oracle/unet_oracle.py`, UnetLaplacianSpec)."""
+`attention_full_resolution`, `attention_activation`, `upsample_linear` (DESIGN.md section 7 says what each stands for and
+how the exported TFLite graph next to the archive pins them)."""
 import json
 import re
 import zipfile
@@ -60,7 +61,6 @@ def config_from_archive_graph(graph: Dict) -> Dict:
     base = next(l for l in by_class["Conv2D"] if tuple(l["config"]["kernel_size"]) == (5, 5))["config"]
     leaky = by_class.get("LeakyReLU", [])
     activation = _leaky_name(float(leaky[0]["config"]["alpha"])) if leaky else "linear"
-    graph_names = [l["config"]["name"] for l in layers]
     # encoder level output: snapshot applies LayerNorm + activation before the Laplacian split; the archive's graph feeds
     # the last Add of the level straight into the smoothing filter
     smooth = by_class.get("GaussianFilter", []) or by_class.get("AveragePooling2D", [])
@@ -97,7 +97,6 @@ def config_from_archive_graph(graph: Dict) -> Dict:
     denoiser = {"filters": int(head_convs[0]["filters"]), "use_bn": False, "use_ln": False, "use_bias": False,
                 "activation": _leaky_name(float(head_leaky[0]["alpha"])) if head_leaky else head_convs[0].get("activation", "linear"),
                 "output_channels": int(head_convs[-1]["filters"])}
-    del graph_names
     return {"backbone": backbone, "denoiser": denoiser}
 
 
