@@ -1103,24 +1103,20 @@ extern "C" int bf_op_resize_bilinear(const float* in, float* out, int B, int H, 
 // ------------------------------------------------------------------------------------------
 constexpr int UO_ATT_A = 32;
 constexpr int UO_ATT_THREADS = 64;     // queries per workgroup: 256 tokens x 32 images alone would fill 32 of the 256 CUs
+constexpr int UO_ATT_CHUNK = 512;      // keys / values staged in LDS at a time (128 KB); longer sequences stream through in chunks
 __global__ __launch_bounds__(UO_ATT_THREADS) void uo_attention_kernel(const float* __restrict__ q, const float* __restrict__ v,
-                                                           const float* __restrict__ k, float* __restrict__ out, int T)
+                                                           const float* __restrict__ k, float* __restrict__ out, int T, int chunk)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* ks = lds;                       // [T][A]
-    float* vs = lds + (size_t)T * UO_ATT_A;
+    float* ks = lds;                       // [chunk][A]
+    float* vs = lds + (size_t)chunk * UO_ATT_A;
     const int b = blockIdx.x;              // sequences on x: one per image, or one per image ROW (B x H of them)
     const float* kb = k + (int64_t)b * T * UO_ATT_A;
     const float* vb = v + (int64_t)b * T * UO_ATT_A;
-    for (int i = threadIdx.x; i < T * UO_ATT_A / 4; i += UO_ATT_THREADS) {
-        reinterpret_cast<f32x4*>(ks)[i] = reinterpret_cast<const f32x4*>(kb)[i];
-        reinterpret_cast<f32x4*>(vs)[i] = reinterpret_cast<const f32x4*>(vb)[i];
-    }
-    __syncthreads();
     const int row = blockIdx.y * UO_ATT_THREADS + threadIdx.x;
-    if (row >= T) return;
+    const bool live = row < T;             // idle lanes still help staging and must reach every barrier
     float qr[UO_ATT_A], acc[UO_ATT_A];
-    const float* qp = q + ((int64_t)b * T + row) * UO_ATT_A;
+    const float* qp = q + ((int64_t)b * T + (live ? row : 0)) * UO_ATT_A;
 #pragma unroll
     for (int i = 0; i < UO_ATT_A; i += 4) {
         const f32x4 t = *reinterpret_cast<const f32x4*>(qp + i);
@@ -1128,17 +1124,27 @@ __global__ __launch_bounds__(UO_ATT_THREADS) void uo_attention_kernel(const floa
         acc[i] = acc[i + 1] = acc[i + 2] = acc[i + 3] = 0.f;
     }
     float m = -INFINITY, l = 0.f;
-    for (int j = 0; j < T; ++j) {
-        float s = 0.f;
+    for (int t0 = 0; t0 < T; t0 += chunk) {
+        const int n = min(chunk, T - t0);
+        if (t0) __syncthreads();           // everyone is done with the previous chunk
+        for (int i = threadIdx.x; i < n * UO_ATT_A / 4; i += UO_ATT_THREADS) {
+            reinterpret_cast<f32x4*>(ks)[i] = reinterpret_cast<const f32x4*>(kb + (int64_t)t0 * UO_ATT_A)[i];
+            reinterpret_cast<f32x4*>(vs)[i] = reinterpret_cast<const f32x4*>(vb + (int64_t)t0 * UO_ATT_A)[i];
+        }
+        __syncthreads();
+        for (int j = 0; j < n; ++j) {
+            float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < UO_ATT_A; ++i) s += qr[i] * ks[j * UO_ATT_A + i];
-        const float mn = fmaxf(m, s);
-        const float corr = __expf(m - mn), pj = __expf(s - mn);
-        l = l * corr + pj;
+            for (int i = 0; i < UO_ATT_A; ++i) s += qr[i] * ks[j * UO_ATT_A + i];
+            const float mn = fmaxf(m, s);
+            const float corr = __expf(m - mn), pj = __expf(s - mn);
+            l = l * corr + pj;
 #pragma unroll
-        for (int i = 0; i < UO_ATT_A; ++i) acc[i] = acc[i] * corr + pj * vs[j * UO_ATT_A + i];
-        m = mn;
+            for (int i = 0; i < UO_ATT_A; ++i) acc[i] = acc[i] * corr + pj * vs[j * UO_ATT_A + i];
+            m = mn;
+        }
     }
+    if (!live) return;
     const float inv = 1.f / l;
     float* op = out + ((int64_t)b * T + row) * UO_ATT_A;
 #pragma unroll
@@ -1151,8 +1157,9 @@ extern "C" int bf_op_attention(const float* q, const float* v, const float* k, f
     if (!q || !v || !k || !out || B <= 0 || T <= 0) return BF_EINVAL;
     if (A != UO_ATT_A) return BF_EUNSUPPORTED;
     if (((uintptr_t)q | (uintptr_t)v | (uintptr_t)k | (uintptr_t)out) % 16) return BF_EINVAL;
-    const size_t lds = (size_t)2 * T * UO_ATT_A * sizeof(float);
-    if (lds > 160 * 1024) return BF_EUNSUPPORTED;
+    const int chunk = T < UO_ATT_CHUNK ? T : UO_ATT_CHUNK;
+    const size_t lds = (size_t)2 * chunk * UO_ATT_A * sizeof(float);
+    if ((T + UO_ATT_THREADS - 1) / UO_ATT_THREADS > 65535) return BF_EUNSUPPORTED;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(uo_attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1161,7 +1168,7 @@ extern "C" int bf_op_attention(const float* q, const float* v, const float* k, f
         attr_done = true;
     }
     hipLaunchKernelGGL(uo_attention_kernel, dim3(B, (T + UO_ATT_THREADS - 1) / UO_ATT_THREADS), dim3(UO_ATT_THREADS), lds,
-                       (hipStream_t)stream, q, v, k, out, T);
+                       (hipStream_t)stream, q, v, k, out, T, chunk);
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
 

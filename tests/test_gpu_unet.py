@@ -214,7 +214,7 @@ def test_upsample_act_add():
     assert_close(host(UL.upsample_act_add(dev(x), None)), O.upsample_bilinear_2x(x), what="up")
 
 
-@pytest.mark.parametrize("B,T", [(1, 256), (3, 256), (2, 64)])
+@pytest.mark.parametrize("B,T", [(1, 256), (3, 256), (2, 64), (5, 100), (2, 512), (3, 513), (2, 1100), (300, 33)])
 def test_attention(B, T):
     r = _rng(9)
     q, v, k = (r.normal(size=(B, T, 32)) for _ in range(3))
