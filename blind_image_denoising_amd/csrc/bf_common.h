@@ -141,11 +141,19 @@ struct HeadTrainArgs {
     const float* feat; const float* wh;      // [16,4]
     const float* gt; float* pred;            // [B,H,W,cout]; pred may be NULL
     float* dfeat;                            // [B,H,W,16]
-    float* partial;                          // [grid][64]: M[16][3] (48), sums (abs, hinge-abs, sq per block...)
+    float* partial;                          // [grid][80]: M[16][4] (64), sums: |e|, hinge |e|, relu(e)^2, relu(e, hinge, cutoff^2)^2
+    const float* dextra;                     // [B,H,W,cout] added to dL/dpred (RMSE / SSIM terms, loss_terms.hip) or NULL
     int B, H, W, cout, denormalize;
     float v_min, v_max, hinge, cutoff, dscale; // dscale = mae_multiplier*depth_weight/numel
 };
 hipError_t bf_launch_head_train(const HeadTrainArgs& a, int grid, hipStream_t s);
+// RMSE / SSIM loss terms (loss_terms.hip): additive dL/dpred from the prediction and the head's per-image sums
+hipError_t bf_launch_loss_extra(const float* pred, const float* gt, int B, int H, int W, int C, const float* head_partial,
+                                int blocks_per_image, float hinge, float cutoff, float mse_multiplier, float ssim_multiplier,
+                                float depth_weight, float max_val, float* maps, float* ssim_partial, float* coef, float* scal,
+                                float* dextra, hipStream_t s);
+hipError_t bf_launch_loss_extra_finalize(const float* scal, int B, int H, int W, int C, float mse_multiplier, float ssim_multiplier,
+                                         float depth_weight, float* losses, hipStream_t s);
 int        bf_head_train_grid(int B, int H, int W);
 
 // elementwise / reductions

@@ -321,7 +321,7 @@ hipError_t bf_launch_head(const HeadArgs& a, hipStream_t s)
 // M[c][o] = sum_pix feat[c]*dh1[o]  (dW1 = W0^T M, dW0 = M W1^T), so a thread only carries
 // 16*cout accumulators.  One workgroup handles pixels of ONE image (per-image sum of squares
 // for the rmse metric, loss.py:92-113).  partial row layout (80 floats):
-//   [0,64) M[c*4+o] | 64 sum|e| | 65 sum relu(|e|,hinge,cutoff) | 66 sum e^2 | 67.. unused
+//   [0,64) M[c*4+o] | 64 sum|e| | 65 sum relu(|e|,hinge,cutoff) | 66 sum relu(e,0,255)^2 | 67 sum relu(e,hinge,cutoff^2)^2 | 68.. unused
 // ------------------------------------------------------------------------------------------
 constexpr int HT_BLOCKS_PER_IMAGE_MAX = 64;
 
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadTrainArgs a, int bl
     float M[64];
 #pragma unroll
     for (int i = 0; i < 64; ++i) M[i] = 0.f;
-    float s_abs = 0.f, s_hinge = 0.f, s_sq = 0.f;
+    float s_abs = 0.f, s_hinge = 0.f, s_sq = 0.f, s_sqh = 0.f;
     for (int pi = sub * 256 + threadIdx.x; pi < hw; pi += blocks_per_image * 256) {
         const int64_t pix = (int64_t)b * hw + pi;
         const float4* fp = reinterpret_cast<const float4*>(a.feat + pix * 16);
@@ -367,8 +367,11 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadTrainArgs a, int bl
                 s_hinge += ae > a.hinge ? fminf(ae, a.cutoff) : 0.f;
                 const float ep = e > 0.f ? fminf(e, 255.0f) : 0.f;   // rmse_diff: relu on the signed error
                 s_sq += ep * ep;
+                const float eh = e > a.hinge ? fminf(e, a.cutoff * a.cutoff) : 0.f;   // the RMSE loss term's own thresholds
+                s_sqh += eh * eh;
                 float dpred = 0.f;
                 if (ae > a.hinge && ae < a.cutoff) dpred = (e > 0.f ? -1.f : (e < 0.f ? 1.f : 0.f)) * a.dscale;
+                if (a.dextra) dpred += a.dextra[pix * a.cout + o];
                 dh1[o] = dpred * dpred_dp * (0.51f * 2.0f) * (1.0f - th * th);
             }
         }
@@ -396,9 +399,9 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadTrainArgs a, int bl
         for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
         if (lane == 0) red[wave][i] = v;
     }
-    float sv[3] = {s_abs, s_hinge, s_sq};
+    float sv[4] = {s_abs, s_hinge, s_sq, s_sqh};
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 4; ++i) {
         float v = sv[i];
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadTrainArgs a, int bl
     __syncthreads();
     if (threadIdx.x < 80) {
         const int i = threadIdx.x;
-        a.partial[(size_t)blockIdx.x * 80 + i] = i < 67 ? (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]) : 0.f;
+        a.partial[(size_t)blockIdx.x * 80 + i] = i < 68 ? (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]) : 0.f;
     }
 }
 

@@ -355,7 +355,7 @@ extern "C" int bf_pack_inference(bf_handle h, const float* params, const float* 
 // workspace layout
 // ------------------------------------------------------------------------------------------
 struct TrainLayout {
-    int64_t wpack, wh, bn_scale, bn_meaninv, coef, stage1, partial, acts, total;   // float offsets
+    int64_t wpack, wh, bn_scale, bn_meaninv, coef, stage1, partial, acts, extra, total;   // float offsets
     int64_t act_floats, partial_floats;
 };
 
@@ -382,6 +382,8 @@ static TrainLayout train_layout(bf_handle h, int B, int H, int W)
     o = align_up(o, 64);
     L.act_floats = (int64_t)B * H * W * 16;
     L.acts = o; o += L.act_floats * (3 * (int64_t)N + 2);
+    // RMSE / SSIM loss terms (loss_terms.hip): prediction, extra gradient, three window maps (4 channels at most), partials
+    L.extra = o; o += (int64_t)B * H * W * 4 * 5 + 4096 + align_up(B, 64) + 64;
     L.total = o;
     return L;
 }
@@ -692,8 +694,10 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
         return fail(h, BF_EINVAL, "bf_train_step: NULL argument");
     if (loss->struct_size != (int32_t)sizeof(bf_loss_desc)) return fail(h, BF_EINVAL, "bf_loss_desc struct_size mismatch");
     if (B <= 0 || H <= 0 || W <= 0) return fail(h, BF_EINVAL, "batch/height/width must be positive");
-    if (loss->ssim_multiplier > 0.f) return fail(h, BF_EUNSUPPORTED, "ssim_multiplier > 0: SSIM term is outside the hot path");
-    if (loss->mse_multiplier > 0.f) return fail(h, BF_EUNSUPPORTED, "mse_multiplier > 0: RMSE loss term is outside the hot path");
+    const bool extra_terms = loss->ssim_multiplier > 0.f || loss->mse_multiplier > 0.f;     // use_ssim / use_mse (loss.py:174-179)
+    if (loss->ssim_multiplier > 0.f && (H < 7 || W < 7)) return fail(h, BF_EINVAL, "SSIM needs images of at least 7x7");
+    if (loss->ssim_multiplier > 0.f && !d.denormalize)
+        return fail(h, BF_EUNSUPPORTED, "SSIM term (max_val 255) is built for the denormalised hydra output");
     if (d.head_activation != BF_ACT_LINEAR) return fail(h, BF_EUNSUPPORTED, "training is built for the linear denoiser head");
     if (d.block_convs != 2) return fail(h, BF_EUNSUPPORTED, "training is built for block_kernels [3,3] (got %d convolutions)", d.block_convs);
     if (d.out_channels != d.in_channels) return fail(h, BF_EINVAL, "gt/prediction channel mismatch");
@@ -764,16 +768,38 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     // ---- head forward + loss + head backward ---------------------------------------------------
     const double numel = (double)npix * d.out_channels;
     HeadTrainArgs ta;
-    ta.feat = A(N); ta.wh = w + L.wh; ta.gt = gt; ta.pred = predictions; ta.dfeat = dA; ta.partial = partial;
+    ta.feat = A(N); ta.wh = w + L.wh; ta.gt = gt; ta.pred = predictions; ta.dfeat = dA; ta.partial = partial; ta.dextra = nullptr;
     ta.B = B; ta.H = H; ta.W = W; ta.cout = d.out_channels; ta.denormalize = d.denormalize;
     ta.v_min = d.v_min; ta.v_max = d.v_max; ta.hinge = loss->hinge; ta.cutoff = loss->cutoff;
     ta.dscale = loss->mae_multiplier > 0.f ? (float)((double)loss->mae_multiplier * loss->depth_weight / numel) : 0.f;
     const int hgrid = bf_head_train_grid(B, H, W);
+    float* scal = nullptr;
+    if (extra_terms) {
+        // pass A: prediction + per-image sums; then the additive gradient of the RMSE / SSIM terms; pass B below adds it
+        const int64_t pe = npix * d.out_channels;
+        float* ex = w + L.extra;
+        float* predbuf = predictions ? predictions : ex;
+        float *dextra = ex + pe, *maps = ex + 2 * pe, *ssim_partial = ex + 5 * (int64_t)npix * 4;
+        float* coef = ssim_partial + 4096;
+        scal = coef + align_up(B, 64);
+        ta.pred = predbuf;
+        BF_HIP(bf_launch_head_train(ta, hgrid, s), "head_train (prediction pass)");
+        BF_HIP(bf_launch_loss_extra(predbuf, gt, B, H, W, d.out_channels, partial, hgrid / B, loss->hinge, loss->cutoff,
+                                    loss->mse_multiplier > 0.f ? loss->mse_multiplier : 0.f,
+                                    loss->ssim_multiplier > 0.f ? loss->ssim_multiplier : 0.f, loss->depth_weight, 255.0f, maps,
+                                    ssim_partial, coef, scal, dextra, s), "loss_extra");
+        ta.pred = nullptr;
+        ta.dextra = dextra;
+    }
     BF_HIP(bf_launch_head_train(ta, hgrid, s), "head_train");
     hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, s, partial, hgrid, hgrid / B, B, numel,
                        (double)H * W * d.out_channels, params + h->p_head0, params + h->p_head1, d.head_filters, d.out_channels,
                        grads + h->p_head0, grads + h->p_head1, losses, loss->mae_multiplier, loss->depth_weight);
     BF_HIP(hipGetLastError(), "head_finalize");
+    if (extra_terms)
+        BF_HIP(bf_launch_loss_extra_finalize(scal, B, H, W, d.out_channels, loss->mse_multiplier > 0.f ? loss->mse_multiplier : 0.f,
+                                             loss->ssim_multiplier > 0.f ? loss->ssim_multiplier : 0.f, loss->depth_weight, losses, s),
+               "loss_extra_finalize");
 
     // ---- backward through the blocks -----------------------------------------------------------
     int64_t n4 = npix * 4;

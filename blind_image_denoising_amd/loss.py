@@ -37,6 +37,23 @@ def rmse(original, prediction, **kwargs):
     return rmse_diff(error=(original - prediction), **kwargs)
 
 
+def ssim_mean(original, prediction, max_val: float = 255.0, filter_size: int = 7, filter_sigma: float = 1.5):
+    """tf.reduce_mean(tf.image.ssim(original, prediction, filter_size=7, max_val=255)) as bfcnn/loss.py:219-226 calls it
+    (VALID Gaussian windows, k1 0.01, k2 0.03), for the host-side metric dict; the training step computes the same value
+    and its gradient in csrc/loss_terms.hip."""
+    x, y = original.to(torch.float64).permute(0, 3, 1, 2), prediction.to(torch.float64).permute(0, 3, 1, 2)
+    c = torch.arange(filter_size, dtype=torch.float64, device=x.device) - (filter_size - 1) / 2.0
+    g = -0.5 * c * c / (filter_sigma * filter_sigma)
+    g = torch.softmax((g[None, :] + g[:, None]).reshape(-1), dim=0).reshape(1, 1, filter_size, filter_size)
+    ch = x.shape[1]
+    red = lambda t: torch.nn.functional.conv2d(t, g.repeat(ch, 1, 1, 1), groups=ch)
+    c1, c2 = (0.01 * max_val) ** 2, (0.03 * max_val) ** 2
+    a, b = red(x), red(y)
+    lum = (2.0 * a * b + c1) / (a * a + b * b + c1)
+    cs = (2.0 * red(x * y) - 2.0 * a * b + c2) / (red(x * x + y * y) - a * a - b * b + c2)
+    return (lum * cs).mean().to(torch.float32)
+
+
 def loss_function_builder(config: Dict) -> Dict[str, Callable]:
     """bfcnn/loss.py:152-253.  Returns {"model": model_loss, "denoiser": denoiser_loss}; both
     callables expose `.desc(depth_weight)` = the bf_loss_desc for bf_train_step."""
@@ -66,16 +83,15 @@ def loss_function_builder(config: Dict) -> Dict[str, Callable]:
                 TOTAL_LOSS_STR: regularization_loss * regularization_multiplier}
 
     def denoiser_loss(gt_batch: torch.Tensor, predicted_batch: torch.Tensor) -> Dict[str, torch.Tensor]:
-        if use_ssim:
-            raise NotImplementedError(
-                "ssim_multiplier > 0: the SSIM term is outside the MI355X hot path; set ssim_multiplier to 0")
         mae_actual = mae(gt_batch, predicted_batch, hinge=0.0, cutoff=255.0)
         mse_actual = rmse(gt_batch, predicted_batch, hinge=0.0, cutoff=255.0)
         zero = torch.zeros((), dtype=torch.float32, device=gt_batch.device)
         mae_prediction_loss = mae(gt_batch, predicted_batch, hinge=hinge, cutoff=cutoff) if use_mae else zero
         mse_prediction_loss = rmse(gt_batch, predicted_batch, hinge=hinge, cutoff=cutoff * cutoff) if use_mse else zero
-        return {TOTAL_LOSS_STR: mae_prediction_loss * mae_multiplier + mse_prediction_loss * mse_multiplier,
-                MSE_LOSS_STR: mse_actual, MAE_LOSS_STR: mae_actual, SSIM_LOSS_STR: zero}
+        ssim_loss = 1.0 - ssim_mean(gt_batch, predicted_batch) if use_ssim else zero          # :217-227
+        return {TOTAL_LOSS_STR: mae_prediction_loss * mae_multiplier + mse_prediction_loss * mse_multiplier
+                                + ssim_loss * ssim_multiplier,
+                MSE_LOSS_STR: mse_actual, MAE_LOSS_STR: mae_actual, SSIM_LOSS_STR: ssim_loss}
 
     model_loss.desc = desc
     denoiser_loss.desc = desc

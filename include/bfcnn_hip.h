@@ -76,8 +76,8 @@ typedef struct bf_loss_desc {
     int32_t struct_size;
     float hinge, cutoff;
     float mae_multiplier;
-    float mse_multiplier;     /* must be 0 (RMSE term outside the hot path)                  */
-    float ssim_multiplier;    /* must be 0 (SSIM term outside the hot path)                  */
+    float mse_multiplier;     /* > 0: + rmse(hinge, cutoff^2) * this (loss.py:228-235)       */
+    float ssim_multiplier;    /* > 0: + (1 - mean tf.image.ssim(7x7, max 255)) * this (:219-227) */
     float regularization;
     float depth_weight;
 } bf_loss_desc;
@@ -88,7 +88,7 @@ enum bf_loss_slot {
     BF_LOSS_DENOISER_TOTAL = 1, /* denoiser_loss[total_loss]                                 */
     BF_LOSS_MAE = 2,            /* mae_loss (no hinge)                                       */
     BF_LOSS_MSE = 3,            /* mse_loss = rmse (no hinge)                                */
-    BF_LOSS_SSIM = 4,           /* 0                                                         */
+    BF_LOSS_SSIM = 4,           /* ssim_loss = 1 - mean ssim (0 when the term is off)        */
     BF_LOSS_REGULARIZATION = 5, /* model_loss[regularization_loss]                           */
     BF_LOSS_MODEL_TOTAL = 6,    /* model_loss[total_loss]                                    */
     BF_LOSS_GRAD_NORM = 7,      /* global L2 norm of the last gradient given to bf_adam_step */

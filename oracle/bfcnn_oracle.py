@@ -504,6 +504,60 @@ def rmse_diff(error, hinge=0.0, cutoff=255.0 * 255.0):
     return np.sqrt(d.mean(axis=(1, 2, 3)) + DEFAULT_EPSILON).mean()
 
 
+def ssim_gauss_kernel(size: int = 7, sigma: float = 1.5) -> np.ndarray:
+    """tf.image.ssim's window (_fspecial_gauss): softmax over the 2-D grid of -(x^2 + y^2) / (2 sigma^2)."""
+    c = np.arange(size, dtype=F64) - (size - 1) / 2.0
+    g = -0.5 * c * c / (sigma * sigma)
+    g = g[None, :] + g[:, None]
+    e = np.exp(g - g.max())
+    return e / e.sum()
+
+
+def _valid_window_sum(x, g):
+    """depthwise_conv2d(x, g, strides 1, padding "VALID") for one window g shared by all channels."""
+    k = g.shape[0]
+    H, W = x.shape[1] - k + 1, x.shape[2] - k + 1
+    out = np.zeros((x.shape[0], H, W, x.shape[3]), dtype=x.dtype)
+    for i in range(k):
+        for j in range(k):
+            out += g[i, j] * x[:, i:i + H, j:j + W, :]
+    return out
+
+
+def _valid_window_sum_transposed(m, g, H, W):
+    """adjoint of _valid_window_sum: scatters every window value back over the pixels it covers."""
+    k = g.shape[0]
+    out = np.zeros((m.shape[0], H, W, m.shape[3]), dtype=m.dtype)
+    for i in range(k):
+        for j in range(k):
+            out[:, i:i + m.shape[1], j:j + m.shape[2], :] += g[i, j] * m
+    return out
+
+
+def ssim_mean_and_grad(gt, pred, max_val: float = 255.0, filter_size: int = 7, filter_sigma: float = 1.5,
+                       k1: float = 0.01, k2: float = 0.03):
+    """tf.reduce_mean(tf.image.ssim(img1=gt, img2=pred, filter_size=7, max_val=255)) as bfcnn/loss.py:219-226 calls it
+    (TF 2.13 image_ops_impl: _ssim_per_channel / _ssim_helper, compensation 1.0, VALID windows, mean over windows then
+    channels then batch = one global mean) and its gradient with respect to `pred`."""
+    x, y = np.asarray(pred, F64), np.asarray(gt, F64)          # x: the variable
+    g = ssim_gauss_kernel(filter_size, filter_sigma)
+    c1, c2 = (k1 * max_val) ** 2, (k2 * max_val) ** 2
+    a, b = _valid_window_sum(x, g), _valid_window_sum(y, g)
+    s, q = _valid_window_sum(x * y, g), _valid_window_sum(x * x + y * y, g)
+    nl, dl = 2.0 * a * b + c1, a * a + b * b + c1
+    nc, dc = 2.0 * s - 2.0 * a * b + c2, q - a * a - b * b + c2
+    lum, cs = nl / dl, nc / dc
+    val = (lum * cs).mean()
+    n = lum.size
+    dS_da = cs * (2.0 * b * dl - nl * 2.0 * a) / (dl * dl) + lum * (-2.0 * b * dc + nc * 2.0 * a) / (dc * dc)
+    dS_ds = lum * 2.0 / dc
+    dS_dq = -lum * nc / (dc * dc)
+    H, W = x.shape[1], x.shape[2]
+    grad = (_valid_window_sum_transposed(dS_da, g, H, W) + y * _valid_window_sum_transposed(dS_ds, g, H, W)
+            + 2.0 * x * _valid_window_sum_transposed(dS_dq, g, H, W)) / n
+    return val, grad
+
+
 @dataclass
 class LossSpec:
     """bfcnn/loss.py:162-179 (defaults as the reference: ssim_multiplier defaults to 1.0)."""
@@ -525,15 +579,14 @@ class LossSpec:
 
 def denoiser_loss(ls: LossSpec, gt, pred) -> Dict[str, float]:
     """bfcnn/loss.py:190-247."""
-    if ls.ssim_multiplier > 0.0:
-        raise NotImplementedError("SSIM term is outside the hot path (SURVEY.md 8a row L)")
     err = gt - pred
     mae_actual = mae_diff(err, 0.0, 255.0)
     mse_actual = rmse_diff(err, 0.0, 255.0)   # reference passes cutoff=255.0 here (:205-209)
     mae_pl = mae_diff(err, ls.hinge, ls.cutoff) if ls.mae_multiplier > 0 else 0.0
     mse_pl = rmse_diff(err, ls.hinge, ls.cutoff * ls.cutoff) if ls.mse_multiplier > 0 else 0.0
-    return {"total_loss": mae_pl * ls.mae_multiplier + mse_pl * ls.mse_multiplier,
-            "mse_loss": mse_actual, "mae_loss": mae_actual, "ssim_loss": 0.0}
+    ssim_loss = 1.0 - ssim_mean_and_grad(gt, pred)[0] if ls.ssim_multiplier > 0 else 0.0      # :219-227
+    return {"total_loss": mae_pl * ls.mae_multiplier + mse_pl * ls.mse_multiplier + ssim_loss * ls.ssim_multiplier,
+            "mse_loss": mse_actual, "mae_loss": mae_actual, "ssim_loss": ssim_loss}
 
 
 def _reg_value_grad(w, kind):
@@ -563,8 +616,6 @@ def train_step_single_gpu(spec: ResnetSpec, ls: LossSpec, params, state, gt, noi
     denoiser loss * depth_weight[0] + model loss, gradients w.r.t. every trainable
     variable.  Returns (total_loss, model_loss, [denoiser_loss], predictions, grads_flat,
     new_state_flat)."""
-    if ls.mse_multiplier > 0:
-        raise NotImplementedError("oracle backward restates the L1 term only")
     P = _views(spec, params, dtype)
     pred, new_state, C = hydra_forward(spec, params, state, noisy, training=True, dtype=dtype,
                                        want_cache=True)
@@ -579,6 +630,14 @@ def train_step_single_gpu(spec: ResnetSpec, ls: LossSpec, params, state, gt, noi
     a = np.abs(err)
     dpred = np.where((a > ls.hinge) & (a < ls.cutoff), -np.sign(err), 0.0) \
         * (ls.mae_multiplier * depth_weight / n_el) if ls.mae_multiplier > 0 else np.zeros_like(pred)
+    if ls.mse_multiplier > 0:          # d/dpred of mean_b sqrt(mean(d^2) + eps), d = relu(gt - pred, hinge, cutoff^2)
+        d = keras_relu(err, ls.hinge, ls.cutoff * ls.cutoff)
+        live = (err > ls.hinge) & (err < ls.cutoff * ls.cutoff)
+        per_image = d[0].size
+        rm = np.sqrt((d * d).mean(axis=(1, 2, 3)) + DEFAULT_EPSILON)
+        dpred = dpred - (ls.mse_multiplier * depth_weight / (pred.shape[0] * per_image)) * (d * live) / rm[:, None, None, None]
+    if ls.ssim_multiplier > 0:         # loss term (1 - mean ssim) * multiplier
+        dpred = dpred - (ls.ssim_multiplier * depth_weight) * ssim_mean_and_grad(gt, pred)[1]
     if spec.denormalize:
         p = C["p"]
         dp = dpred * (spec.v_max - spec.v_min) * ((p >= -0.5) & (p <= 0.5))

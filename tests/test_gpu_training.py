@@ -147,11 +147,35 @@ def test_training_forward_updates_moving_stats_and_matches_oracle():
     assert np.abs(t.cpu().numpy() - O.hydra_forward(spec, params, r_state.astype(np.float32), x.astype(np.float64))).max() < 0.02
 
 
-def test_unsupported_loss_terms_raise():
+@pytest.mark.parametrize("loss_over", [{"ssim_multiplier": 1.0}, {"mse_multiplier": 0.5},
+                                       {"ssim_multiplier": 1.0, "mse_multiplier": 0.5, "hinge": 3.5},      # the shipped unet configs
+                                       {"ssim_multiplier": 2.0, "mae_multiplier": 0.0, "mse_multiplier": -1.0}],
+                         ids=["ssim", "rmse", "shipped", "ssim_only"])
+@pytest.mark.parametrize("train_arith", [1, 0], ids=["f16x3", "f32"])
+def test_train_step_with_ssim_and_rmse_terms_matches_oracle(loss_over, train_arith):
+    """total = mae * m1 + rmse(hinge, cutoff^2) * m2 + (1 - mean tf.image.ssim(7x7)) * m3 (bfcnn/loss.py:190-247): the two
+    extra terms of csrc/loss_terms.hip, values and every gradient against the fp64 oracle (whose SSIM gradient is checked
+    against torch autograd in tests/test_oracle_vs_torch.py)."""
+    cfg, spec, ls, params, state, m, fns = _setup(2, loss_over=loss_over)
+    m.set_option("train_arith", train_arith)
+    clean, noisy = O.synthetic_batch(3, 24, 40, seed=11)
+    gt, x = clean.astype(np.float32), noisy.astype(np.float32)
+    total, ml, dl, pred, grads = fns.train_step_single_gpu(torch.from_numpy(gt), torch.from_numpy(x), (0.7,), 0.0, None)
+    r_total, r_ml, r_dl, r_pred, r_grads, r_state = O.train_step_single_gpu(
+        spec, ls, params, state, gt.astype(np.float64), x.astype(np.float64), depth_weight=0.7)
+    assert abs(total.item() - r_total) <= 1e-5 * abs(r_total)
+    for k in ("total_loss", "mae_loss", "mse_loss", "ssim_loss"):
+        assert abs(dl[0][k].item() - r_dl[0][k]) <= 1e-5 * max(abs(r_dl[0][k]), 1e-3), k
+    assert np.abs(pred.cpu().numpy() - r_pred).max() < 0.02
+    # SSIM alone gives a heavy-tailed dL/dprediction (flat windows weigh 1 / (sigma^2 + c2)); through the 22-bit operands
+    # of the split-f16 data-gradient convolutions the first block's kernel gradient lands at 2.4e-4 of its maximum
+    _cmp_grads(spec, grads.cpu().numpy().astype(np.float64), r_grads, rel=5e-4 if train_arith == 1 else 2e-4)
+
+
+def test_loss_term_argument_errors():
     cfg, spec, ls, params, state, m, fns = _setup(1, loss_over={"ssim_multiplier": 1.0})
-    x = torch.zeros((1, 16, 16, 3))
-    with pytest.raises(NotImplementedError, match="SSIM"):
-        fns.train_step_single_gpu(x, x)
+    with pytest.raises(ValueError):                                     # tf.image.ssim needs a 7x7 window
+        fns.train_step_single_gpu(torch.zeros((1, 6, 16, 3)), torch.zeros((1, 6, 16, 3)))
     with pytest.raises(ValueError):
         fns.train_step_single_gpu(torch.zeros((1, 16, 16, 3)), torch.zeros((1, 8, 16, 3)))
 

@@ -210,8 +210,12 @@ def test_loss_builder_contract_and_monitor_values():
     ref = O.denoiser_loss(O.LossSpec.from_config(O.canonical_config()["loss"]), gt, pr)
     for k in ("total_loss", "mae_loss", "mse_loss"):
         assert abs(float(got[k]) - ref[k]) < 1e-9
-    with pytest.raises(NotImplementedError, match="SSIM"):
-        bf.loss_function_builder({})["denoiser"](torch.zeros(1, 4, 4, 3), torch.zeros(1, 4, 4, 3))   # ssim default 1.0
+    full = bf.loss_function_builder({"mse_multiplier": 0.5, "hinge": 3.5})["denoiser"]       # ssim_multiplier defaults to 1.0
+    got = full(torch.from_numpy(gt), torch.from_numpy(pr))
+    ref = O.denoiser_loss(O.LossSpec.from_config({"mse_multiplier": 0.5, "hinge": 3.5}), gt, pr)
+    for k in ("total_loss", "mae_loss", "mse_loss", "ssim_loss"):
+        assert abs(float(got[k]) - ref[k]) < 1e-5 * max(1.0, abs(ref[k])), k
+    assert 0.5 < ref["ssim_loss"] < 1.5                                   # unrelated random images: ssim near 0
 
 
 def test_pyramid_type_parsing():

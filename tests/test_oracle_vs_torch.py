@@ -143,6 +143,70 @@ def test_train_step_grads_match_autograd():
         assert np.abs(mine - g).max() < 1e-10 * max(1.0, np.abs(g).max()), n
 
 
+def _torch_ssim_mean(y, x):
+    """tf.image.ssim(filter_size=7, max_val=255) restated with F.conv2d (NCHW fp64), for autograd."""
+    g = torch.from_numpy(O.ssim_gauss_kernel(7, 1.5))[None, None].repeat(x.shape[1], 1, 1, 1)
+    red = lambda t: F.conv2d(t, g, groups=x.shape[1])
+    c1, c2 = (0.01 * 255.0) ** 2, (0.03 * 255.0) ** 2
+    m0, m1 = red(y), red(x)
+    lum = (2.0 * m0 * m1 + c1) / (m0 * m0 + m1 * m1 + c1)
+    cs = (2.0 * red(x * y) - 2.0 * m0 * m1 + c2) / (red(x * x + y * y) - m0 * m0 - m1 * m1 + c2)
+    return (lum * cs).mean(dim=(2, 3)).mean(dim=1).mean()
+
+
+def test_ssim_window_and_gradient_match_autograd():
+    g = O.ssim_gauss_kernel(7, 1.5)
+    assert abs(g.sum() - 1.0) < 1e-15 and np.allclose(g, g.T) and g[3, 3] == g.max()
+    rng = np.random.default_rng(0)
+    gt = rng.uniform(0, 255, (2, 13, 17, 3))
+    pred = np.clip(gt + rng.normal(0, 25, gt.shape), 0, 255)
+    val, grad = O.ssim_mean_and_grad(gt, pred)
+    x = _nchw(pred).requires_grad_(True)
+    v = _torch_ssim_mean(_nchw(gt), x)
+    v.backward()
+    assert abs(val - float(v.detach())) < 1e-14
+    assert np.abs(grad - _nhwc(x.grad)).max() < 1e-16 + 1e-10 * np.abs(grad).max()
+    same, _ = O.ssim_mean_and_grad(gt, gt)
+    assert abs(same - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize("over", [{"ssim_multiplier": 1.0}, {"mse_multiplier": 0.5},
+                                  {"ssim_multiplier": 1.0, "mse_multiplier": 0.5, "hinge": 3.5}])
+def test_train_step_grads_with_rmse_and_ssim_terms_match_autograd(over):
+    """loss.py:190-247 with all three terms: mae * m1 + rmse(hinge, cutoff^2) * m2 + (1 - mean ssim) * m3."""
+    cfg = O.canonical_config(no_layers=1)
+    cfg["loss"].update(over)
+    spec = O.ResnetSpec.from_config(cfg["model"])
+    ls = O.LossSpec.from_config(cfg["loss"])
+    params, state = O.init_params(spec, seed=5)
+    clean, noisy = O.synthetic_batch(2, 12, 14, seed=3)
+    gt, x = clean.astype(np.float64), noisy.astype(np.float64)
+    total, ml, dl, pred, grads, _ = O.train_step_single_gpu(spec, ls, params, state, gt, x, depth_weight=0.6)
+    P, S = _torch_params(spec, params, state, requires_grad=True)
+    yt, _ = torch_hydra(spec, P, S, _nchw(x), True)
+    err = _nchw(gt) - yt
+    a = err.abs()
+    loss = torch.where(a > ls.hinge, a, torch.zeros_like(a)).clamp(max=ls.cutoff).mean() * ls.mae_multiplier
+    if ls.mse_multiplier > 0:
+        d = torch.where(err > ls.hinge, err, torch.zeros_like(err)).clamp(max=ls.cutoff * ls.cutoff) ** 2
+        loss = loss + torch.sqrt(d.mean(dim=(1, 2, 3)) + O.DEFAULT_EPSILON).mean() * ls.mse_multiplier
+    if ls.ssim_multiplier > 0:
+        loss = loss + (1.0 - _torch_ssim_mean(_nchw(gt), yt)) * ls.ssim_multiplier
+    reg = 0.0
+    for n, _, kind, r in spec.tensors():
+        if kind == "conv":
+            reg = reg + (0.01 * P[n].abs().sum() if r == "l1" else 0.01 * (P[n] ** 2).sum())
+    tot = loss * 0.6 + reg * ls.regularization
+    tot.backward()
+    assert abs(float(tot.detach()) - total) < 1e-10
+    assert abs(float(loss.detach()) - dl[0]["total_loss"]) < 1e-10
+    for n, (o, s) in spec.offsets().items():
+        g = P[n].grad
+        g = g.permute(2, 3, 1, 0).numpy() if len(s) == 4 else g.numpy()
+        mine = grads[o:o + int(np.prod(s))].reshape(s)
+        assert np.abs(mine - g).max() < 1e-10 * max(1.0, np.abs(g).max()), n
+
+
 def test_adam_matches_torch_formula():
     """keras-2.13 Adam differs from torch.optim.Adam only in where epsilon sits
     (alpha*m/(sqrt(v)+eps) vs bias-corrected sqrt(v)); check against a literal
