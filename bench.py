@@ -301,6 +301,8 @@ def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
     B = 32 if args.batch == 128 else args.batch            # per-GPU shard (256 global on 8 GPUs)
     S = args.size
     cfg = O.canonical_config(no_layers=args.layers)
+    if args.loss == "shipped":        # the loss section of the reference's shipped configs (configs/unet_laplacian_v5.json)
+        cfg["loss"].update({"hinge": 3.5, "cutoff": 255.0, "mae_multiplier": 1.0, "mse_multiplier": 0.5, "ssim_multiplier": 1.0})
     spec = O.ResnetSpec.from_config(cfg["model"])
     params, state = O.init_params(spec, seed=42, nontrivial_bn=False)
     model = bf.model_builder(cfg["model"], device=f"cuda:{local_rank}").hydra
@@ -341,7 +343,8 @@ def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
             "metric": "training images/sec (256x256x3), resnet_1x18 data-parallel step", "value": value, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"resnet_color_1x{args.layers}_bn_16x3x3 training step (L1 hinge 0.5, Adam, global clipnorm 1), "
+            "config": {"workload": f"resnet_color_1x{args.layers}_bn_16x3x3 training step ("
+                                   f"{'L1 hinge 3.5 + 0.5 RMSE + SSIM' if args.loss == 'shipped' else 'L1 hinge 0.5'}, Adam, global clipnorm 1), "
                                    f"batch={B}/GPU {S}x{S}x3 float32 corrupted on the device every step, one all-reduce of {model.n_params} fp32 gradients",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
             "last_total_loss": float(total.item()),
@@ -364,6 +367,8 @@ def main():
     ap.add_argument("--fused-tile", type=int, default=None, help="exact-fp32 fused-block tile geometry variant (A/B only)")
     ap.add_argument("--arith", type=int, default=1, help="1 = split-f16 fused blocks (default), 0 = exact-fp32 fused blocks")
     ap.add_argument("--h3-variant", type=int, default=None, help="split-f16 kernel variant (A/B only)")
+    ap.add_argument("--loss", choices=["l1", "shipped"], default="l1",
+                    help="--mode train: l1 = BASELINE configs[3] (L1 only); shipped = L1 + RMSE + SSIM as the reference's configs")
     ap.add_argument("--unet-graph", choices=["v5", "v5.6"], default="v5",
                     help="--mode unet: v5 = snapshot builder graph, random weights; v5.6 = the reference's trained network")
     ap.add_argument("--mode", choices=["inference", "train", "pyramid", "unet", "latency"], default="inference",
