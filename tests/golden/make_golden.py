@@ -25,6 +25,18 @@ from oracle import bfcnn_oracle as O   # noqa: E402
 OUT = pathlib.Path(__file__).resolve().parent
 
 
+FULL_LOSS = {"hinge": 3.5, "cutoff": 255.0, "mae_multiplier": 1.0, "mse_multiplier": 0.5, "ssim_multiplier": 1.0,
+             "regularization": 0.01}
+
+
+def full_loss_step(spec, params, state, clean_t, noisy_t):
+    ls = O.LossSpec.from_config(FULL_LOSS)
+    total, ml, dl, pred, grads, _ = O.train_step_single_gpu(spec, ls, params, state, clean_t.astype(np.float64),
+                                                             noisy_t.astype(np.float64), depth_weight=0.8)
+    np.savez_compressed(OUT / "train_step_full_loss.npz", total=total, denoiser_total=dl[0]["total_loss"],
+                        ssim=dl[0]["ssim_loss"], mae=dl[0]["mae_loss"], mse=dl[0]["mse_loss"], grads=grads)
+
+
 def main():
     # (1) single 3x3 C16 SAME convolution, 5 seeds
     d = {}
@@ -59,6 +71,9 @@ def main():
         OUT / "train_step.npz", clean=clean_t, noisy=noisy_t, total=total, reg=ml["regularization_loss"],
         mae=dl[0]["mae_loss"], mse=dl[0]["mse_loss"], denoiser_total=dl[0]["total_loss"], pred=pred, grads=grads,
         new_state=new_state, params_after=p1, m_after=m1, v_after=v1)
+
+    # (4b) the same step with all three loss terms on, weights as the reference's shipped configs (loss.py:190-247)
+    full_loss_step(spec, params, state, clean_t, noisy_t)
 
     # (5) pyramid / resampling
     rng = np.random.default_rng(5)

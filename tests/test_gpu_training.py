@@ -91,6 +91,23 @@ def test_golden_train_step_and_adam():
     assert np.abs(opt.v.cpu().numpy() - z["v_after"]).max() < 1e-7
 
 
+def test_golden_train_step_with_all_loss_terms():
+    z, t, n = np.load(G / "train_step_full_loss.npz"), np.load(G / "train_step.npz"), np.load(G / "net_2blocks.npz")
+    cfg = O.canonical_config(no_layers=2)
+    cfg["loss"] = {"hinge": 3.5, "cutoff": 255.0, "mae_multiplier": 1.0, "mse_multiplier": 0.5, "ssim_multiplier": 1.0,
+                   "regularization": 0.01}
+    spec = O.ResnetSpec.from_config(cfg["model"])
+    m = bf.model_builder(cfg["model"], device="cuda").hydra
+    m.set_weights(n["params"], n["state"])
+    fns = bf.build_train_functions(m, bf.loss_function_builder(cfg["loss"]))
+    total, ml, dl, pred, grads = fns.train_step_single_gpu(
+        torch.from_numpy(t["clean"].astype(np.float32)), torch.from_numpy(t["noisy"].astype(np.float32)), (0.8,), 0.0, None)
+    assert abs(total.item() - float(z["total"])) <= 1e-5 * float(z["total"])
+    for k, key in (("ssim_loss", "ssim"), ("mae_loss", "mae"), ("mse_loss", "mse"), ("total_loss", "denoiser_total")):
+        assert abs(dl[0][k].item() - float(z[key])) <= 1e-5 * abs(float(z[key])), k
+    _cmp_grads(spec, grads.cpu().numpy().astype(np.float64), z["grads"], rel=3e-4)
+
+
 def test_adam_exact_on_given_gradient():
     """isolates bf_adam_step: feed the oracle's own gradient; with/without clipping; 3 steps."""
     cfg, spec, ls, params, state, m, fns = _setup(1)

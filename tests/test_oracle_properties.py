@@ -38,6 +38,17 @@ def test_oracle_matches_golden_train_step():
     assert np.abs(new_state - z["new_state"]).max() < 1e-12
 
 
+def test_oracle_matches_golden_train_step_with_all_loss_terms():
+    z, t, n = np.load(G / "train_step_full_loss.npz"), np.load(G / "train_step.npz"), np.load(G / "net_2blocks.npz")
+    spec = O.ResnetSpec.from_config(O.canonical_config(no_layers=2)["model"])
+    ls = O.LossSpec.from_config({"hinge": 3.5, "cutoff": 255.0, "mae_multiplier": 1.0, "mse_multiplier": 0.5,
+                                 "ssim_multiplier": 1.0, "regularization": 0.01})
+    total, ml, dl, pred, grads, _ = O.train_step_single_gpu(spec, ls, n["params"], n["state"], t["clean"].astype(np.float64),
+                                                             t["noisy"].astype(np.float64), depth_weight=0.8)
+    assert abs(total - z["total"]) < 1e-12 and abs(dl[0]["ssim_loss"] - z["ssim"]) < 1e-14
+    assert np.abs(grads - z["grads"]).max() < 1e-12
+
+
 def test_param_counts_match_survey():
     """1x6 -> 28,784 trainable parameters, 1x18 -> 84,272."""
     for n, cnt in ((6, 28784), (18, 84272)):
