@@ -1102,54 +1102,80 @@ extern "C" int bf_op_resize_bilinear(const float* in, float* out, int B, int H, 
 // and every key / value row is an LDS broadcast.  (256 tokens x 32 channels per image: 8 MFLOP, negligible.)
 // ------------------------------------------------------------------------------------------
 constexpr int UO_ATT_A = 32;
-constexpr int UO_ATT_THREADS = 64;     // queries per workgroup: 256 tokens x 32 images alone would fill 32 of the 256 CUs
-constexpr int UO_ATT_CHUNK = 512;      // keys / values staged in LDS at a time (128 KB); longer sequences stream through in chunks
-__global__ __launch_bounds__(UO_ATT_THREADS) void uo_attention_kernel(const float* __restrict__ q, const float* __restrict__ v,
-                                                           const float* __restrict__ k, float* __restrict__ out, int T, int chunk)
+constexpr int UO_ATT_WAVES = 4;        // waves per workgroup; a wave owns 16 queries of one sequence
+// softmax(q k^T) v on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products, bitwise an fmaf chain), no LDS:
+// a wave walks the keys of its sequence 16 at a time with the running-max form of the softmax.
+//   S^T tile (16 keys x 16 queries) = K_tile . Q^T, contraction over the 32 channels in the order c = 8 kq + s (step s of 8,
+//     lane group kq): A = lane (key m, kq) holds K[m][8kq .. 8kq+7], B = lane (query n, kq) holds Q[n][8kq .. 8kq+7] - two
+//     16-byte loads each; accumulator: lane (g, n), register r = score of key 4g + r with query n.
+//   O^T (32 channels x 16 queries) += V_tile^T . P^T: those four registers ARE the B operand of step r when the contraction
+//     runs over the keys in the order k(g, r) = 4g + r; A = lane (channel m, g) holds V[4g + r][16 t + m].
+//   A query's 16 scores of a tile sit in 4 registers x 4 lane groups: max / sum = in-lane + two cross-row shuffles.
+__global__ __launch_bounds__(64 * UO_ATT_WAVES) void uo_attention_kernel(const float* __restrict__ q, const float* __restrict__ v,
+                                                                 const float* __restrict__ k, float* __restrict__ out, int T,
+                                                                 int tiles_per_seq, int64_t total_tiles)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* ks = lds;                       // [chunk][A]
-    float* vs = lds + (size_t)chunk * UO_ATT_A;
-    const int b = blockIdx.x;              // sequences on x: one per image, or one per image ROW (B x H of them)
-    const float* kb = k + (int64_t)b * T * UO_ATT_A;
-    const float* vb = v + (int64_t)b * T * UO_ATT_A;
-    const int row = blockIdx.y * UO_ATT_THREADS + threadIdx.x;
-    const bool live = row < T;             // idle lanes still help staging and must reach every barrier
-    float qr[UO_ATT_A], acc[UO_ATT_A];
-    const float* qp = q + ((int64_t)b * T + (live ? row : 0)) * UO_ATT_A;
-#pragma unroll
-    for (int i = 0; i < UO_ATT_A; i += 4) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(qp + i);
-        qr[i] = t[0]; qr[i + 1] = t[1]; qr[i + 2] = t[2]; qr[i + 3] = t[3];
-        acc[i] = acc[i + 1] = acc[i + 2] = acc[i + 3] = 0.f;
+    const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+    const int64_t tile = (int64_t)blockIdx.x * UO_ATT_WAVES + (threadIdx.x >> 6);
+    if (tile >= total_tiles) return;                      // whole waves leave; nothing below synchronises across waves
+    const int64_t b = tile / tiles_per_seq;
+    const int q0 = (int)(tile % tiles_per_seq) * 16;
+    const float* qb = q + b * T * UO_ATT_A;
+    const float* kb = k + b * T * UO_ATT_A;
+    const float* vb = v + b * T * UO_ATT_A;
+    float qf[8];
+    {
+        const float* qp = qb + (int64_t)min(q0 + n, T - 1) * UO_ATT_A + 8 * g;
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(qp), t1 = *reinterpret_cast<const f32x4*>(qp + 4);
+        qf[0] = t0[0]; qf[1] = t0[1]; qf[2] = t0[2]; qf[3] = t0[3]; qf[4] = t1[0]; qf[5] = t1[1]; qf[6] = t1[2]; qf[7] = t1[3];
     }
-    float m = -INFINITY, l = 0.f;
-    for (int t0 = 0; t0 < T; t0 += chunk) {
-        const int n = min(chunk, T - t0);
-        if (t0) __syncthreads();           // everyone is done with the previous chunk
-        for (int i = threadIdx.x; i < n * UO_ATT_A / 4; i += UO_ATT_THREADS) {
-            reinterpret_cast<f32x4*>(ks)[i] = reinterpret_cast<const f32x4*>(kb + (int64_t)t0 * UO_ATT_A)[i];
-            reinterpret_cast<f32x4*>(vs)[i] = reinterpret_cast<const f32x4*>(vb + (int64_t)t0 * UO_ATT_A)[i];
+    f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float mrun = -INFINITY, lrun = 0.f;
+    for (int k0 = 0; k0 < T; k0 += 16) {
+        float kf[8];
+        {
+            const float* kp = kb + (int64_t)min(k0 + n, T - 1) * UO_ATT_A + 8 * g;
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(kp), t1 = *reinterpret_cast<const f32x4*>(kp + 4);
+            kf[0] = t0[0]; kf[1] = t0[1]; kf[2] = t0[2]; kf[3] = t0[3]; kf[4] = t1[0]; kf[5] = t1[1]; kf[6] = t1[2]; kf[7] = t1[3];
         }
-        __syncthreads();
-        for (int j = 0; j < n; ++j) {
-            float s = 0.f;
+        float vf[2][4];
 #pragma unroll
-            for (int i = 0; i < UO_ATT_A; ++i) s += qr[i] * ks[j * UO_ATT_A + i];
-            const float mn = fmaxf(m, s);
-            const float corr = __expf(m - mn), pj = __expf(s - mn);
-            l = l * corr + pj;
+        for (int r = 0; r < 4; ++r) {
+            const float* vp = vb + (int64_t)min(k0 + 4 * g + r, T - 1) * UO_ATT_A + n;
+            vf[0][r] = vp[0]; vf[1][r] = vp[16];
+        }
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < UO_ATT_A; ++i) acc[i] = acc[i] * corr + pj * vs[j * UO_ATT_A + i];
-            m = mn;
+        for (int s2 = 0; s2 < 8; ++s2) sc = MFMA4(kf[s2], qf[s2], sc);
+        sc = bf_acc_ready(sc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (k0 + 4 * g + r >= T) sc[r] = -INFINITY;          // keys past the end of the sequence
+        float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun, mx);                      // finite: every tile holds at least one real key
+        const float corr = __expf(mrun - mnew);
+        f32x4 p;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = __expf(sc[r] - mnew);
+        float ps = (p[0] + p[1]) + (p[2] + p[3]);
+        ps += __shfl_xor(ps, 16, 64);
+        ps += __shfl_xor(ps, 32, 64);
+        lrun = lrun * corr + ps;
+        mrun = mnew;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            o[t] *= corr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[t] = MFMA4(vf[t][r], p[r], o[t]);
         }
     }
-    if (!live) return;
-    const float inv = 1.f / l;
-    float* op = out + ((int64_t)b * T + row) * UO_ATT_A;
+    if (q0 + n >= T) return;
+    const float inv = 1.f / lrun;
+    float* op = out + (b * T + q0 + n) * UO_ATT_A + 4 * g;
 #pragma unroll
-    for (int i = 0; i < UO_ATT_A; i += 4)
-        *reinterpret_cast<f32x4*>(op + i) = (f32x4){acc[i] * inv, acc[i + 1] * inv, acc[i + 2] * inv, acc[i + 3] * inv};
+    for (int t = 0; t < 2; ++t) *reinterpret_cast<f32x4*>(op + 16 * t) = bf_acc_ready(o[t]) * inv;
 }
 
 extern "C" int bf_op_attention(const float* q, const float* v, const float* k, float* out, int B, int T, int A, void* stream)
@@ -1157,18 +1183,12 @@ extern "C" int bf_op_attention(const float* q, const float* v, const float* k, f
     if (!q || !v || !k || !out || B <= 0 || T <= 0) return BF_EINVAL;
     if (A != UO_ATT_A) return BF_EUNSUPPORTED;
     if (((uintptr_t)q | (uintptr_t)v | (uintptr_t)k | (uintptr_t)out) % 16) return BF_EINVAL;
-    const int chunk = T < UO_ATT_CHUNK ? T : UO_ATT_CHUNK;
-    const size_t lds = (size_t)2 * chunk * UO_ATT_A * sizeof(float);
-    if ((T + UO_ATT_THREADS - 1) / UO_ATT_THREADS > 65535) return BF_EUNSUPPORTED;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(uo_attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return BF_EHIP;
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(uo_attention_kernel, dim3(B, (T + UO_ATT_THREADS - 1) / UO_ATT_THREADS), dim3(UO_ATT_THREADS), lds,
-                       (hipStream_t)stream, q, v, k, out, T, chunk);
+    const int tiles = (T + 15) / 16;
+    const int64_t total = (int64_t)B * tiles;
+    const int64_t grid = (total + UO_ATT_WAVES - 1) / UO_ATT_WAVES;
+    if (grid > 0x7fffffff) return BF_EUNSUPPORTED;
+    hipLaunchKernelGGL(uo_attention_kernel, dim3((unsigned)grid), dim3(64 * UO_ATT_WAVES), 0, (hipStream_t)stream, q, v, k, out, T,
+                       tiles, total);
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
 

@@ -270,7 +270,7 @@ int bf_op_resize_bilinear(const float* in, float* out, int batch, int height, in
                           int out_width, void* stream);
 /* keras.layers.Attention(use_scale=False, score_mode="dot") on [query, value, key] (custom_layers.py:1345): [B][T][A], A = 32,
  * out = softmax(q k^T) v per sequence.  batch = number of sequences (images, or image rows for rank-4 inputs: keras then
- * attends along the last-but-one axis only); keys and values pass through LDS 512 tokens at a time, any length. */
+ * attends along the last-but-one axis only); any length (16 queries per wave, keys walked 16 at a time). */
 int bf_op_attention(const float* q, const float* v, const float* k, float* out, int batch, int tokens, int channels, void* stream);
 /* first Conv2D k x k cin(<=4) -> cout on the (optionally) normalised image; the [Hs,Ws] source (u8 or f32) is zero-padded
  * to [H,W] before normalisation as pad_to_power_of_2 does (utilities.py:736-751; model.py:100-102). */
