@@ -7,7 +7,7 @@ out="$here/../lib"
 obj="$out/obj"
 mkdir -p "$out" "$obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-units=(conv3x3_c16 fused_h3 edge_layers train_ops pyramid augment loss_terms unet_ops unet_h3 unet_h3_enc engine)
+units=(conv3x3_c16 fused_h3 edge_layers train_ops pyramid augment loss_terms unet_ops unet_h3 unet_h3_enc unet_h3_first engine)
 pids=()
 for u in "${units[@]}"; do
     "$HIPCC" -O3 --offload-arch=gfx950 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed "$@" \

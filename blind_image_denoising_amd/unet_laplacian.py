@@ -225,13 +225,18 @@ def attention(q: torch.Tensor, v: torch.Tensor, k: torch.Tensor) -> torch.Tensor
     return out
 
 
-def first_conv(x: torch.Tensor, w: torch.Tensor, H: int, W: int, act: str, normalize: bool, v_min: float, v_max: float
-               ) -> torch.Tensor:
-    """x [B,Hs,Ws,cin] uint8 / float32 (0..255 scale), zero-padded to [H,W] before normalisation."""
+def first_conv(x: torch.Tensor, w: torch.Tensor, H: int, W: int, act: str, normalize: bool, v_min: float, v_max: float,
+               arith: int = 0) -> torch.Tensor:
+    """x [B,Hs,Ws,cin] uint8 / float32 (0..255 scale), zero-padded to [H,W] before normalisation.
+    arith 1: split-f16 matrix-core kernel for the 5x5 3 -> 32 shape (csrc/unet_h3_first.hip); 0: exact fp32."""
     B, Hs, Ws, cin = x.shape
     k, cout = int(w.shape[0]), int(w.shape[-1])
     out = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device)
     code, a = _act(act)
+    if arith == 1 and (k, cin, cout) == (5, 3, 32):
+        _call("bf_op_first_conv_h3", N.ptr(x), int(x.dtype == torch.uint8), N.ptr(out), N.ptr(w), B, Hs, Ws, H, W, int(normalize),
+              v_min, v_max, code, a, N.stream_ptr(x))
+        return out
     _call("bf_op_first_conv", N.ptr(x), int(x.dtype == torch.uint8), N.ptr(out), N.ptr(w), B, Hs, Ws, H, W, cin, cout, k,
           int(normalize), v_min, v_max, code, a, N.stream_ptr(x))
     return out
@@ -591,7 +596,7 @@ class UnetLaplacianHydra:
             raise ValueError(f"height and width must be multiples of {step} (the decoder adds x2-upsampled maps to the "
                              f"::2-sliced ones; got {H}x{W})")
         a = self.activation
-        f = first_conv(x, P["base/kernel"], H, W, a, True, self.v_min, self.v_max)
+        f = first_conv(x, P["base/kernel"], H, W, a, True, self.v_min, self.v_max, arith=self.arith)
         nodes = {}
         for d in range(self.depth):
             for w in range(self.width):

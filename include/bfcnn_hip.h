@@ -277,6 +277,10 @@ int bf_op_attention(const float* q, const float* v, const float* k, float* out, 
 int bf_op_first_conv(const void* in, int in_is_u8, float* out, const float* w, int batch, int src_height, int src_width,
                      int height, int width, int cin, int cout, int k, int normalize, float v_min, float v_max, int act,
                      float alpha, void* stream);
+/* The same for the one shape the unet_laplacian builder emits (5 x 5, 3 -> 32) on the f16 matrix cores with split-f16
+ * operands (three products, fp32 accumulation: the arithmetic of bf_op_convnext_mlp_h3). */
+int bf_op_first_conv_h3(const void* in, int in_is_u8, float* out, const float* w, int batch, int src_height, int src_width,
+                        int height, int width, int normalize, float v_min, float v_max, int act, float alpha, void* stream);
 /* last Conv2D 1x1 of a denoiser head + tanh(2x)*0.51 [+ denormalise][+ round, uint8], cropped to [Ho,Wo]
  * (model.py:321-342, 136-139; module_denoiser.py:62-73). */
 int bf_op_head_out(const float* in, const float* w, void* out, int out_is_u8, int batch, int height, int width, int out_height,
