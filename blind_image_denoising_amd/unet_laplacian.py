@@ -339,7 +339,10 @@ class UnetLaplacianHydra:
         _act(self.activation)
         self.upsample_type = bb.get("upsample_type", "bilinear").strip().lower()
         if self.upsample_type == "conv2d_transpose":
-            raise NotImplementedError("unet_laplacian: upsample_type conv2d_transpose is not built")
+            # the builder hands Conv2DTranspose the level's base parameters, strides (1, 1) (backbone_unet_laplacian.py:179-188,
+            # 246-250; upsampling.py:52-59): nothing is upsampled and the decoder's Add cannot be built in the reference either
+            raise NotImplementedError("unet_laplacian: upsample_type conv2d_transpose (stride 1 in the reference builder: the "
+                                      "decoder Add has mismatched shapes there) is not built")
         if self.upsample_type not in ("upsample_laplacian_conv2d", "upsample_bilinear_conv2d", "upsample_nearest_conv2d",
                                       "bilinear", "nn", "nearest"):
             raise ValueError(f"don't know how to handle [{self.upsample_type}]")             # upsampling.py:118-120
