@@ -61,6 +61,7 @@ SIGNATURES = {
     "bf_forward_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _I64, _P]),
     "bf_train_step": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, C.POINTER(LossDesc), _P, _P, _P, _P, _I64, _P]),
     "bf_adam_step": (_I, [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _P, _P, _P]),
+    "bf_adam_step_ex": (_I, [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _P, _I, _P, _F, _P, _P, _P]),
     "bf_avgpool_s2_same": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "bf_avgpool2_valid": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "bf_upsample2x": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P]),

@@ -885,6 +885,80 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// per-tensor clipping (keras clipnorm = tf.clip_by_norm on every gradient tensor, optimizer.py:165-169): one workgroup per
+// tensor sums its squares in a fixed order; factor = c / max(norm, c)
+__global__ __launch_bounds__(256) void tensor_clip_factor_kernel(const float* __restrict__ g, const int64_t* __restrict__ offs,
+                                                                 float grad_scale, float clipnorm, float* __restrict__ factor)
+{
+    __shared__ double red[256];
+    const int64_t a = offs[blockIdx.x], b = offs[blockIdx.x + 1];
+    double acc = 0.0;
+    for (int64_t i = a + threadIdx.x; i < b; i += 256) {
+        const double x = (double)g[i] * grad_scale;
+        acc += x * x;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) factor[blockIdx.x] = clipnorm / fmaxf((float)sqrt(red[0]), clipnorm);
+}
+
+__global__ __launch_bounds__(256) void adam_tensor_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, const int64_t* __restrict__ offs,
+                                                          const float* __restrict__ factor, float clipvalue, float alpha, float beta_1,
+                                                          float beta_2, float epsilon, float grad_scale)
+{
+    const int64_t a = offs[blockIdx.x], b = offs[blockIdx.x + 1];
+    const float f = grad_scale * (factor ? factor[blockIdx.x] : 1.f);
+    for (int64_t i = a + threadIdx.x; i < b; i += 256) {
+        float gi = g[i] * f;
+        if (clipvalue > 0.f) gi = fminf(fmaxf(gi, -clipvalue), clipvalue);
+        const float mi = m[i] + (gi - m[i]) * (1.0f - beta_1);
+        const float vi = v[i] + (gi * gi - v[i]) * (1.0f - beta_2);
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - (mi * alpha) / (sqrtf(vi) + epsilon);
+    }
+}
+
+// bf_adam_step with keras' other two clipping modes.  Precedence as keras 2.13 (_clip_gradients): clipnorm (per tensor), else
+// global_clipnorm, else clipvalue.  tensor_offsets = device int64[n_tensors + 1] (offsets of the trainable tensors in the flat
+// vector, last = n_params), tensor_scratch = device float[n_tensors]; both only read when clipnorm or clipvalue is on.
+extern "C" int bf_adam_step_ex(bf_handle h, float* params, const float* grads, float* m, float* v, int64_t iterations, float lr,
+                               float beta_1, float beta_2, float epsilon, float global_clipnorm, float clipnorm, float clipvalue,
+                               const int64_t* tensor_offsets, int n_tensors, float* tensor_scratch, float grad_scale, float* losses,
+                               float* scratch, void* stream)
+{
+    if (!h) return BF_EINVAL;
+    const bool local = clipnorm > 0.f, by_value = !local && !(global_clipnorm > 0.f) && clipvalue > 0.f;
+    if (!local && !by_value)
+        return bf_adam_step(h, params, grads, m, v, iterations, lr, beta_1, beta_2, epsilon, global_clipnorm, grad_scale, losses,
+                            scratch, stream);
+    if (!params || !grads || !m || !v || !scratch || !tensor_offsets || n_tensors <= 0 || (local && !tensor_scratch))
+        return fail(h, BF_EINVAL, "bf_adam_step_ex: NULL argument");
+    if (iterations < 0) return fail(h, BF_EINVAL, "iterations must be >= 0");
+    hipStream_t s = (hipStream_t)stream;
+    if (losses) {
+        hipLaunchKernelGGL(grad_norm_kernel, dim3(1), dim3(1024), 0, s, grads, h->n_params, grad_scale, scratch, losses);
+        BF_HIP(hipGetLastError(), "grad_norm");
+    }
+    if (local) {
+        hipLaunchKernelGGL(tensor_clip_factor_kernel, dim3(n_tensors), dim3(256), 0, s, grads, tensor_offsets, grad_scale, clipnorm,
+                           tensor_scratch);
+        BF_HIP(hipGetLastError(), "tensor_clip_factor");
+    }
+    const double t = (double)iterations + 1.0;
+    const double alpha = (double)lr * sqrt(1.0 - pow((double)beta_2, t)) / (1.0 - pow((double)beta_1, t));
+    hipLaunchKernelGGL(adam_tensor_kernel, dim3(n_tensors), dim3(256), 0, s, params, grads, m, v, tensor_offsets,
+                       local ? tensor_scratch : (const float*)nullptr, by_value ? clipvalue : 0.f, (float)alpha, beta_1, beta_2, epsilon,
+                       grad_scale);
+    BF_HIP(hipGetLastError(), "adam_tensor");
+    return BF_OK;
+}
+
 extern "C" int bf_adam_step(bf_handle h, float* params, const float* grads, float* m, float* v, int64_t iterations, float lr,
                             float beta_1, float beta_2, float epsilon, float global_clipnorm, float grad_scale, float* losses,
                             float* scratch, void* stream)

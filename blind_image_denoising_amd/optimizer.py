@@ -107,13 +107,13 @@ class Adam:
                  clipvalue=None, clipnorm=None, global_clipnorm=None):
         if amsgrad:
             raise NotImplementedError("amsgrad is outside the hot path")
-        if clipvalue is not None or clipnorm is not None:
-            raise NotImplementedError("only gradient_clipping_by_norm (global_clipnorm) is on the hot path")
+        if clipnorm is not None and global_clipnorm is not None:            # keras 2.13 optimizer.__init__
+            raise ValueError("At most one of `clipnorm` and `global_clipnorm` can be set")
         self.learning_rate = learning_rate
         self.beta_1, self.beta_2, self.epsilon = beta_1, beta_2, epsilon
-        self.global_clipnorm = global_clipnorm
+        self.global_clipnorm, self.clipnorm, self.clipvalue = global_clipnorm, clipnorm, clipvalue
         self.iterations = 0
-        self.m = self.v = self._scratch = None
+        self.m = self.v = self._scratch = self._offsets = self._tensor_scratch = None
 
     def lr(self) -> float:
         lr = self.learning_rate
@@ -124,6 +124,10 @@ class Adam:
             self.m = torch.zeros_like(model.params)
             self.v = torch.zeros_like(model.params)
             self._scratch = torch.zeros(4, dtype=torch.float32, device=model.params.device)
+            # offsets of the trainable tensors in the flat vector: per-tensor clipping (clipnorm / clipvalue) walks them
+            offs = sorted(int(i[1]) for i in model._infos) + [int(model.n_params)]
+            self._offsets = torch.tensor(offs, dtype=torch.int64, device=model.params.device)
+            self._tensor_scratch = torch.zeros(len(offs), dtype=torch.float32, device=model.params.device)
 
     def apply_gradients(self, grads: torch.Tensor, model, grad_scale: float = 1.0, losses: Optional[torch.Tensor] = None):
         """grads: flat tensor laid out like model.params (what train_step_single_gpu returns)."""
@@ -132,10 +136,19 @@ class Adam:
             raise ValueError("gradient / variable size mismatch")
         self._slots(model)
         clip = float(self.global_clipnorm) if self.global_clipnorm else 0.0
-        N.check(N.lib().bf_adam_step(model._h, N.ptr(model.params), N.ptr(grads), N.ptr(self.m), N.ptr(self.v),
-                                     int(self.iterations), self.lr(), self.beta_1, self.beta_2, self.epsilon, clip,
-                                     float(grad_scale), N.ptr(losses), N.ptr(self._scratch), N.stream_ptr(grads)),
-                model._h, "bf_adam_step")
+        local = float(self.clipnorm) if self.clipnorm else 0.0
+        value = float(self.clipvalue) if self.clipvalue else 0.0
+        if local > 0.0 or value > 0.0:      # keras precedence: clipnorm, else global_clipnorm, else clipvalue (in the library)
+            N.check(N.lib().bf_adam_step_ex(model._h, N.ptr(model.params), N.ptr(grads), N.ptr(self.m), N.ptr(self.v),
+                                            int(self.iterations), self.lr(), self.beta_1, self.beta_2, self.epsilon, clip, local,
+                                            value, N.ptr(self._offsets), int(self._offsets.numel() - 1),
+                                            N.ptr(self._tensor_scratch), float(grad_scale), N.ptr(losses), N.ptr(self._scratch),
+                                            N.stream_ptr(grads)), model._h, "bf_adam_step_ex")
+        else:
+            N.check(N.lib().bf_adam_step(model._h, N.ptr(model.params), N.ptr(grads), N.ptr(self.m), N.ptr(self.v),
+                                         int(self.iterations), self.lr(), self.beta_1, self.beta_2, self.epsilon, clip,
+                                         float(grad_scale), N.ptr(losses), N.ptr(self._scratch), N.stream_ptr(grads)),
+                    model._h, "bf_adam_step")
         self.iterations += 1
         model.mark_dirty()
 

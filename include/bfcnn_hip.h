@@ -164,6 +164,15 @@ int bf_adam_step(bf_handle h, float* params, const float* grads, float* m, float
                  int64_t iterations, float lr, float beta_1, float beta_2, float epsilon,
                  float global_clipnorm, float grad_scale, float* losses, float* scratch, void* stream);
 
+/* The same with keras' other two clipping modes (optimizer.py:165-169): clipnorm = tf.clip_by_norm on every gradient tensor,
+ * clipvalue = clip_by_value; precedence as keras 2.13: clipnorm, else global_clipnorm, else clipvalue (<= 0 disables each).
+ * tensor_offsets = device int64[n_tensors + 1]: offsets of the trainable tensors in the flat vector, last = parameter
+ * count (bf_tensor_info order); tensor_scratch = device float[n_tensors]. */
+int bf_adam_step_ex(bf_handle h, float* params, const float* grads, float* m, float* v,
+                    int64_t iterations, float lr, float beta_1, float beta_2, float epsilon,
+                    float global_clipnorm, float clipnorm, float clipvalue, const int64_t* tensor_offsets, int n_tensors,
+                    float* tensor_scratch, float grad_scale, float* losses, float* scratch, void* stream);
+
 /* ---- pyramid / resampling (bfcnn/pyramid.py, upsampling.py, downsampling.py) ---------- */
 
 /* AveragePooling2D(pool_size=(kh,kw), strides=2, padding="same") (pyramid.py:266-270,374-378). */

@@ -690,11 +690,23 @@ def clip_by_global_norm(g: np.ndarray, clip: Optional[float]) -> Tuple[np.ndarra
 
 
 def adam_step(params, grads, m, v, iterations: int, lr: float, beta_1=0.9, beta_2=0.999,
-              epsilon=1e-7, global_clipnorm: Optional[float] = None):
+              epsilon=1e-7, global_clipnorm: Optional[float] = None, clipnorm: Optional[float] = None,
+              clipvalue: Optional[float] = None, tensor_offsets=None):
     """keras.optimizers.Adam.update_step (Keras 2.13): t = iterations+1,
     alpha = lr*sqrt(1-b2^t)/(1-b1^t); m += (g-m)(1-b1); v += (g^2-v)(1-b2);
-    w -= alpha*m/(sqrt(v)+eps).  global_clipnorm applied first (optimizer.py:165-206)."""
-    g, _ = clip_by_global_norm(grads.astype(F64), global_clipnorm)
+    w -= alpha*m/(sqrt(v)+eps).  Gradient clipping first (optimizer.py:165-206), with keras' precedence
+    (_clip_gradients): clipnorm = tf.clip_by_norm per tensor (needs `tensor_offsets`, the starts of the tensors in the
+    flat vector + its length), else global_clipnorm, else clipvalue."""
+    g = grads.astype(F64)
+    if clipnorm and clipnorm > 0:
+        g = g.copy()
+        for a, b in zip(tensor_offsets[:-1], tensor_offsets[1:]):
+            nrm = math.sqrt(float((g[a:b] ** 2).sum()))
+            g[a:b] *= clipnorm / max(nrm, clipnorm)
+    elif global_clipnorm and global_clipnorm > 0:
+        g, _ = clip_by_global_norm(g, global_clipnorm)
+    elif clipvalue and clipvalue > 0:
+        g = np.clip(g, -clipvalue, clipvalue)
     t = iterations + 1
     alpha = lr * math.sqrt(1.0 - beta_2 ** t) / (1.0 - beta_1 ** t)
     m = m + (g - m) * (1.0 - beta_1)

@@ -121,6 +121,30 @@ def test_adam_exact_on_given_gradient():
         assert np.abs(m.params.cpu().numpy() - p).max() < 2e-6, it
 
 
+@pytest.mark.parametrize("mode", ["clipnorm", "clipvalue", "clipnorm_wins_over_clipvalue"])
+def test_adam_per_tensor_clipping_modes(mode):
+    """keras' other clipping modes (bfcnn/optimizer.py:165-169, the shipped unet configs use gradient_clipping_by_norm_local):
+    clipnorm = tf.clip_by_norm on every gradient tensor, clipvalue = clip_by_value; precedence as keras 2.13."""
+    cfg, spec, ls, params, state, m, fns = _setup(2)
+    ocfg = {"type": "ADAM", "schedule": cfg["train"]["optimizer"]["schedule"]}
+    kw = {}
+    if mode != "clipvalue":
+        ocfg["gradient_clipping_by_norm_local"] = kw["clipnorm"] = 0.05
+    if mode != "clipnorm":
+        ocfg["gradient_clipping_by_value"] = kw["clipvalue"] = 0.002
+    opt, sched = bf.optimizer_builder(ocfg)
+    offs = sorted(o for o, _ in spec.offsets().values()) + [params.size]
+    rng = np.random.default_rng(1)
+    p, mm, vv = params.astype(np.float64), np.zeros(params.size), np.zeros(params.size)
+    for it in range(3):
+        g = (rng.standard_normal(params.size) * (0.01 if it != 1 else 1e-4)).astype(np.float32)     # step 1 stays under the norm
+        opt.apply_gradients(torch.from_numpy(g).cuda(), m)
+        p, mm, vv = O.adam_step(p, g.astype(np.float64), mm, vv, it, sched(it), tensor_offsets=offs, **kw)
+        assert np.abs(m.params.cpu().numpy() - p).max() < 2e-6, it
+    with pytest.raises(ValueError):
+        bf.optimizer_builder(dict(ocfg, gradient_clipping_by_norm=1.0, gradient_clipping_by_norm_local=1.0))
+
+
 def test_loss_curve_tracks_oracle_over_steps():
     """10 optimiser steps on a tiny problem: the fp32 engine stays on the fp64 oracle's curve."""
     cfg, spec, ls, params, state, m, fns = _setup(2, seed=3)

@@ -197,6 +197,11 @@ def test_optimizer_builder_contract():
         bf.optimizer_builder({"type": "sgd", "schedule": cfg["schedule"]})
     with pytest.raises(NotImplementedError):
         bf.optimizer_builder({"schedule": cfg["schedule"]})          # default RMSprop: outside the hot path
+    # the optimizer section of the reference's shipped unet configs: per-tensor clipnorm + cosine restarts
+    opt, sched = bf.optimizer_builder({"type": "ADAM", "gradient_clipping_by_norm_local": 1.0, "schedule": {
+        "type": "cosine_decay_restarts", "config": {"t_mul": 1.1, "epsilon": 1e-5, "decay_rate": 0.9, "decay_steps": 40000,
+                                                    "learning_rate": 0.001}}})
+    assert (opt.clipnorm, opt.global_clipnorm, opt.clipvalue) == (1.0, None, None) and abs(opt.lr() - 1e-3) < 1e-9
 
 
 def test_loss_builder_contract_and_monitor_values():
