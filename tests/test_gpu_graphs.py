@@ -47,3 +47,36 @@ def test_unet_laplacian_denoiser_module_in_a_hip_graph():
     _, a = O.synthetic_batch(1, 64, 64, seed=1)
     _, b = O.synthetic_batch(1, 64, 64, seed=2)
     _capture_and_check(bf.DenoiserModule(m), a, b)
+
+
+def test_trained_unet_from_the_registry_in_a_hip_graph():
+    """the packaged trained network (row attention, GELU MLPs, Gaussian split): same capture, real frames."""
+    import unet_v56 as V
+    z, _ = V.load()
+    a = V.corrupt(z["kitti"][:1, :64, :128], 20.0, seed=1)
+    b = V.corrupt(z["kitti"][1:2, 64:128, :128], 20.0, seed=2)
+    _capture_and_check(bf.load_denoiser_model("unet_laplacian_v5.6"), a, b)
+
+
+def test_train_step_with_all_loss_terms_in_a_hip_graph():
+    """bf_train_step with the RMSE and SSIM terms on (two head passes + csrc/loss_terms.hip) captures and replays bitwise."""
+    cfg = O.canonical_config(no_layers=2)
+    cfg["loss"].update({"hinge": 3.5, "mse_multiplier": 0.5, "ssim_multiplier": 1.0})
+    spec = O.ResnetSpec.from_config(cfg["model"])
+    params, state = O.init_params(spec, seed=6)
+    m = bf.model_builder(cfg["model"], device="cuda").hydra
+    m.set_weights(params, state)
+    fns = bf.build_train_functions(m, bf.loss_function_builder(cfg["loss"]))
+    clean, noisy = O.synthetic_batch(2, 32, 32, seed=3)
+    gt, x = torch.from_numpy(clean.astype(np.float32)).cuda(), torch.from_numpy(noisy.astype(np.float32)).cuda()
+    ref = fns.train_step_single_gpu(gt, x)
+    m.set_weights(params, state)                       # the step updated the BN moving statistics
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fns.train_step_single_gpu(gt, x)
+    m.set_weights(params, state)
+    g.replay()
+    torch.cuda.synchronize()
+    assert out[0].item() == ref[0].item()
+    assert torch.equal(out[4], ref[4])
