@@ -87,6 +87,7 @@ SIGNATURES = {
     "bf_op_upsample_act_add": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "bf_op_resize_bilinear": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "bf_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "bf_op_attention_ld": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "bf_op_first_conv": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _F, _P]),
     "bf_op_first_conv_h3": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _I, _F, _P]),
     "bf_op_head_out": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]),

@@ -196,6 +196,7 @@ static int uo_pointwise_dispatch(const float* in, float* out, const float* wp, c
 #define UO_CASE(CI, CO, NP) if (cin == CI && cout == CO) e = uo_launch_pointwise<CI, CO, NP>(in, out, wp, mult, res, npix, act, alpha, mode, add, s)
     UO_CASE(32, 32, 4); UO_CASE(32, 64, 4); UO_CASE(32, 128, 2); UO_CASE(64, 32, 4); UO_CASE(64, 64, 4); UO_CASE(64, 128, 4);
     UO_CASE(128, 32, 4); UO_CASE(128, 64, 4); UO_CASE(128, 128, 4);
+    UO_CASE(128, 96, 2);                                   // query | key | value of one attention block in one pass
     UO_CASE(128, 256, 2); UO_CASE(256, 128, 4); UO_CASE(256, 32, 4); UO_CASE(32, 256, 2);      // 4-level models (256 channels)
 #undef UO_CASE
     if (e == hipErrorInvalidValue) return BF_EUNSUPPORTED;
@@ -1114,19 +1115,19 @@ constexpr int UO_ATT_WAVES = 4;        // waves per workgroup; a wave owns 16 qu
 //   A query's 16 scores of a tile sit in 4 registers x 4 lane groups: max / sum = in-lane + two cross-row shuffles.
 __global__ __launch_bounds__(64 * UO_ATT_WAVES) void uo_attention_kernel(const float* __restrict__ q, const float* __restrict__ v,
                                                                  const float* __restrict__ k, float* __restrict__ out, int T,
-                                                                 int tiles_per_seq, int64_t total_tiles)
+                                                                 int tiles_per_seq, int64_t total_tiles, int ld)
 {
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int64_t tile = (int64_t)blockIdx.x * UO_ATT_WAVES + (threadIdx.x >> 6);
     if (tile >= total_tiles) return;                      // whole waves leave; nothing below synchronises across waves
     const int64_t b = tile / tiles_per_seq;
     const int q0 = (int)(tile % tiles_per_seq) * 16;
-    const float* qb = q + b * T * UO_ATT_A;
-    const float* kb = k + b * T * UO_ATT_A;
-    const float* vb = v + b * T * UO_ATT_A;
+    const float* qb = q + b * T * ld;                       // ld: row pitch of q / k / v in floats (32, or 96 when the three
+    const float* kb = k + b * T * ld;                       // projections come interleaved out of one 1x1 convolution)
+    const float* vb = v + b * T * ld;
     float qf[8];
     {
-        const float* qp = qb + (int64_t)min(q0 + n, T - 1) * UO_ATT_A + 8 * g;
+        const float* qp = qb + (int64_t)min(q0 + n, T - 1) * ld + 8 * g;
         const f32x4 t0 = *reinterpret_cast<const f32x4*>(qp), t1 = *reinterpret_cast<const f32x4*>(qp + 4);
         qf[0] = t0[0]; qf[1] = t0[1]; qf[2] = t0[2]; qf[3] = t0[3]; qf[4] = t1[0]; qf[5] = t1[1]; qf[6] = t1[2]; qf[7] = t1[3];
     }
@@ -1135,14 +1136,14 @@ __global__ __launch_bounds__(64 * UO_ATT_WAVES) void uo_attention_kernel(const f
     for (int k0 = 0; k0 < T; k0 += 16) {
         float kf[8];
         {
-            const float* kp = kb + (int64_t)min(k0 + n, T - 1) * UO_ATT_A + 8 * g;
+            const float* kp = kb + (int64_t)min(k0 + n, T - 1) * ld + 8 * g;
             const f32x4 t0 = *reinterpret_cast<const f32x4*>(kp), t1 = *reinterpret_cast<const f32x4*>(kp + 4);
             kf[0] = t0[0]; kf[1] = t0[1]; kf[2] = t0[2]; kf[3] = t0[3]; kf[4] = t1[0]; kf[5] = t1[1]; kf[6] = t1[2]; kf[7] = t1[3];
         }
         float vf[2][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float* vp = vb + (int64_t)min(k0 + 4 * g + r, T - 1) * UO_ATT_A + n;
+            const float* vp = vb + (int64_t)min(k0 + 4 * g + r, T - 1) * ld + n;
             vf[0][r] = vp[0]; vf[1][r] = vp[16];
         }
         f32x4 sc = {0.f, 0.f, 0.f, 0.f};
@@ -1179,9 +1180,10 @@ __global__ __launch_bounds__(64 * UO_ATT_WAVES) void uo_attention_kernel(const f
     for (int t = 0; t < 2; ++t) *reinterpret_cast<f32x4*>(op + 16 * t) = bf_acc_ready(o[t]) * inv;
 }
 
-extern "C" int bf_op_attention(const float* q, const float* v, const float* k, float* out, int B, int T, int A, void* stream)
+extern "C" int bf_op_attention_ld(const float* q, const float* v, const float* k, float* out, int B, int T, int A, int ld,
+                                  void* stream)
 {
-    if (!q || !v || !k || !out || B <= 0 || T <= 0) return BF_EINVAL;
+    if (!q || !v || !k || !out || B <= 0 || T <= 0 || ld < A || ld % 4) return BF_EINVAL;
     if (A != UO_ATT_A) return BF_EUNSUPPORTED;
     if (((uintptr_t)q | (uintptr_t)v | (uintptr_t)k | (uintptr_t)out) % 16) return BF_EINVAL;
     const int tiles = (T + 15) / 16;
@@ -1189,8 +1191,13 @@ extern "C" int bf_op_attention(const float* q, const float* v, const float* k, f
     const int64_t grid = (total + UO_ATT_WAVES - 1) / UO_ATT_WAVES;
     if (grid > 0x7fffffff) return BF_EUNSUPPORTED;
     hipLaunchKernelGGL(uo_attention_kernel, dim3((unsigned)grid), dim3(64 * UO_ATT_WAVES), 0, (hipStream_t)stream, q, v, k, out, T,
-                       tiles, total);
+                       tiles, total, ld);
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+extern "C" int bf_op_attention(const float* q, const float* v, const float* k, float* out, int B, int T, int A, void* stream)
+{
+    return bf_op_attention_ld(q, v, k, out, B, T, A, A, stream);
 }
 
 // ------------------------------------------------------------------------------------------

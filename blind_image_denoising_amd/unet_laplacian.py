@@ -225,6 +225,17 @@ def attention(q: torch.Tensor, v: torch.Tensor, k: torch.Tensor) -> torch.Tensor
     return out
 
 
+def attention_interleaved(qvk: torch.Tensor, A: int) -> torch.Tensor:
+    """qvk [B,T,3A] = query | value | key side by side (one 1x1 convolution wrote all three) -> softmax(q k^T) v, [B,T,A]."""
+    B, T, ld = qvk.shape
+    out = torch.empty((B, T, A), dtype=torch.float32, device=qvk.device)
+    if not qvk.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    at = lambda floats: N.C.c_void_p(qvk.data_ptr() + 4 * floats)
+    _call("bf_op_attention_ld", at(0), at(A), at(2 * A), N.ptr(out), B, T, A, ld, N.stream_ptr(qvk))
+    return out
+
+
 def first_conv(x: torch.Tensor, w: torch.Tensor, H: int, W: int, act: str, normalize: bool, v_min: float, v_max: float,
                arith: int = 0) -> torch.Tensor:
     """x [B,Hs,Ws,cin] uint8 / float32 (0..255 scale), zero-padded to [H,W] before normalisation.
@@ -542,6 +553,17 @@ class UnetLaplacianHydra:
                 o2 = dict((v[0], v[3]) for v in self.trainable_variables)[f"{prefix}/pw2/kernel"]
                 P[f"{prefix}/mlp_h3"] = pack_mlp_h3(self.params[off:off + n1].clone().view(shape[2], shape[3]),
                                                    self.params[o2:o2 + n2].clone().view(shape[3], shape[2]))
+        if self.attention_rows and self.filters == 32:
+            # query | "value" operand | "key" operand side by side = query_conv | key_conv | value_conv (the archive's wiring)
+            tv = {v[0]: v for v in self.trainable_variables}
+            for name, (_, shape, _, off) in list(tv.items()):
+                if name.endswith("/query/kernel") and shape[2] == 128:
+                    prefix = name[:-len("/query/kernel")]
+                    mats = []
+                    for nm in ("query", "key", "value"):
+                        o = tv[f"{prefix}/{nm}/kernel"][3]
+                        mats.append(self.params[o:o + shape[2] * shape[3]].view(shape[2], shape[3]))
+                    P[f"{prefix}/qvk"] = pack_pointwise(torch.cat(mats, dim=1).contiguous().view(1, 1, shape[2], 3 * shape[3]))
         if not self.use_laplacian_averaging:
             P["gauss"] = torch.from_numpy(gaussian_kernel((self.gauss_k, self.gauss_k))).to(self.device)
         self._packed = P
@@ -575,8 +597,11 @@ class UnetLaplacianHydra:
             # archive revision: no resize, one sequence per image row, operands in the order the archive's graph wires them
             # (scores = query_conv . value_conv^T, output = softmax . key_conv), LayerNorm on the product
             t = dwconv_ln(x, None, P[f"{prefix}/ln/gamma"]) if self.use_ln else x
-            q, v, k = (pointwise(t, P[f"{prefix}/{n}/kernel"], A, **qkv_act).view(B * H, W, A) for n in ("query", "key", "value"))
-            t = attention(q, v, k).view(B, H, W, A)
+            if f"{prefix}/qvk" in P:                           # the three projections in one pass over t
+                t = attention_interleaved(pointwise(t, P[f"{prefix}/qvk"], 3 * A, **qkv_act).view(B * H, W, 3 * A), A).view(B, H, W, A)
+            else:
+                q, v, k = (pointwise(t, P[f"{prefix}/{n}/kernel"], A, **qkv_act).view(B * H, W, A) for n in ("query", "key", "value"))
+                t = attention(q, v, k).view(B, H, W, A)
             if self.use_ln:
                 t = dwconv_ln(t, None, P[f"{prefix}/ln1/gamma"])
             return pointwise(t, P[f"{prefix}/out/kernel"], C, "linear", mult=P[f"{prefix}/gamma/w"], res=x)

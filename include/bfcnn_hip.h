@@ -281,6 +281,10 @@ int bf_op_resize_bilinear(const float* in, float* out, int batch, int height, in
  * out = softmax(q k^T) v per sequence.  batch = number of sequences (images, or image rows for rank-4 inputs: keras then
  * attends along the last-but-one axis only); any length (16 queries per wave, keys walked 16 at a time). */
 int bf_op_attention(const float* q, const float* v, const float* k, float* out, int batch, int tokens, int channels, void* stream);
+/* The same with q / v / k rows `ld` floats apart (ld >= channels, a multiple of 4): the three projections written side by
+ * side by ONE 1x1 convolution with 3 * channels outputs (q = base, the others at base + channels, base + 2 * channels). */
+int bf_op_attention_ld(const float* q, const float* v, const float* k, float* out, int batch, int tokens, int channels, int ld,
+                       void* stream);
 /* first Conv2D k x k cin(<=4) -> cout on the (optionally) normalised image; the [Hs,Ws] source (u8 or f32) is zero-padded
  * to [H,W] before normalisation as pad_to_power_of_2 does (utilities.py:736-751; model.py:100-102). */
 int bf_op_first_conv(const void* in, int in_is_u8, float* out, const float* w, int batch, int src_height, int src_width,
