@@ -357,8 +357,8 @@ def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)      # >= 100 timed iterations after >= 20 warm-up ones
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=128, help="images per GPU")
     ap.add_argument("--layers", type=int, default=18)
     ap.add_argument("--size", type=int, default=256)
