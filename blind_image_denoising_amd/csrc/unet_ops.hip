@@ -194,7 +194,7 @@ static int uo_pointwise_dispatch(const float* in, float* out, const float* wp, c
 {
     hipError_t e = hipErrorInvalidValue;
 #define UO_CASE(CI, CO, NP) if (cin == CI && cout == CO) e = uo_launch_pointwise<CI, CO, NP>(in, out, wp, mult, res, npix, act, alpha, mode, add, s)
-    UO_CASE(32, 32, 4); UO_CASE(32, 64, 4); UO_CASE(32, 128, 2); UO_CASE(64, 32, 4); UO_CASE(64, 64, 4); UO_CASE(64, 128, 4);
+    UO_CASE(32, 32, 4); UO_CASE(32, 64, 2); UO_CASE(32, 128, 2); UO_CASE(64, 32, 2); UO_CASE(64, 64, 4); UO_CASE(64, 128, 4);
     UO_CASE(128, 32, 4); UO_CASE(128, 64, 4); UO_CASE(128, 128, 4);
     UO_CASE(128, 96, 2);                                   // query | key | value of one attention block in one pass
     UO_CASE(128, 256, 2); UO_CASE(256, 128, 4); UO_CASE(256, 32, 4); UO_CASE(32, 256, 2);      // 4-level models (256 channels)
