@@ -354,6 +354,21 @@ def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
         dist.destroy_process_group()
 
 
+def self_launch(n):
+    import socket
+    import subprocess
+    with socket.socket() as sk:                       # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes needs it on this driver)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env)
+    raise SystemExit(proc.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -376,6 +391,12 @@ def main():
                          "batch sharded over the ranks, ONE gradient all-reduce, clip + Adam); not the headline metric")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` by itself: THIS process never touches a GPU (no torch import, no HIP call); it starts
+        # one rank per GPU through torch.distributed.run as a child, relays the child's output (rank 0 prints the JSON
+        # line) and exits with its code.
+        return self_launch(args.gpus)
+
     import torch
     import blind_image_denoising_amd as bf
     from blind_image_denoising_amd import _native as N
@@ -385,16 +406,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU (or run bench.py by itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU execution path")
+    # BF_BENCH_REHEARSE=1: the N ranks share the visible GPU(s) and rendezvous over gloo -- exercises the launch / barrier /
+    # max-over-ranks path on a one-GPU box; the line it prints says "rehearsal" and is not a measurement
+    rehearse = os.environ.get("BF_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     if args.mode == "train":
         return train_bench(args, torch, bf, O, rank, local_rank, world, dist)

@@ -17,6 +17,26 @@ __device__ __forceinline__ f32x4 bf_acc_ready(f32x4 acc)
     return acc;
 }
 
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device).  A process-wide "done" flag per kernel would
+// leave the second device of a process without the attribute (launch failure there), and is not thread-safe.
+#include <mutex>
+#include <unordered_set>
+inline hipError_t bf_set_max_lds(const void* kernel, int bytes)
+{
+    static std::mutex mu;
+    static std::unordered_set<uint64_t> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t key = (uint64_t)(uintptr_t)kernel * 131u + (uint64_t)(dev + 1);
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count(key)) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.insert(key);
+    return e;
+}
+
 #define BF_C 16             // feature channels of the MFMA path (filters == 16)
 #define BF_WPACK_FLOATS (36 * 64)   // one 3x3 16->16 kernel as MFMA A-operand register images
 
@@ -69,7 +89,9 @@ struct FusedH3Args {
     const void* w2r;
     const float* aux;     // [0..15] 1/s1, [16..31] scale/s2 (group kernel), [32..47] shift, [48..63] 1/s2r (row kernel)
     int B, H, W;
-    int tiles_x, tiles_y, ntiles;
+    int tiles_x, tiles_y, ntiles;   // filled in by the launcher
+    int rows_per_tile;    // full-row streaming kernel (fused_h3v.hip): rows per band, filled in by the launcher
+    int variant;          // kernel selection: < 0 = library default (bf_set_h3_variant), else as bf_set_option("h3_variant")
     int act1_relu;
     const void* zeros;    // >= 64 B of zeros, 16-B aligned (source of out-of-image elements)
     void* dump;           // >= 1024 B writable scratch (sink of out-of-image stores)
@@ -83,7 +105,11 @@ struct FusedH3Args {
     int* status;           // |= BF_STATUS_F16_RANGE when a block output is not finite
 };
 hipError_t bf_launch_fused_block_h3(const FusedH3Args& a, hipStream_t s);
-void       bf_set_h3_variant(int v);   // 1 (default) row-streaming kernel, 0 group-per-pass kernel (A/B only)
+// library default of FusedH3Args::variant (handle-less debug entries): 4 = full-row streaming kernel where it applies
+// (W <= 256), 1 = row-streaming tile kernel, 0 / 2 / 3 = earlier tile kernels (A/B only)
+void       bf_set_h3_variant(int v);
+hipError_t bf_launch_fused_block_h3v(const FusedH3Args& a, hipStream_t s);      // fused_h3v.hip
+bool       bf_fused_block_h3v_supports(int H, int W);
 hipError_t bf_launch_pack_h3(const float* params, const float* state, int64_t p_blocks, int64_t p_stride, float* dst,
                              int64_t d_stride, int layers, int use_bn, float eps, const float* ext_scale,
                              const float* ext_shift, hipStream_t s);

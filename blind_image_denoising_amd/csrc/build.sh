@@ -3,13 +3,21 @@
 # parallel (device code never crosses a unit: no -fgpu-rdc) and linked into one shared library.
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-out="$here/../lib"
-obj="$out/obj"
+# BF_BUILD_OUT / BF_BUILD_NAME: another directory / file name for the result (tools/ablate.sh builds timing variants with
+# extra -D flags passed as arguments; the unit list below is the only one)
+out="${BF_BUILD_OUT:-$here/../lib}"
+name="${BF_BUILD_NAME:-libbfcnn_hip.so}"
+obj="$out/obj${BF_BUILD_NAME:+_${BF_BUILD_NAME%.so}}"
 mkdir -p "$out" "$obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-units=(conv3x3_c16 fused_h3 edge_layers train_ops pyramid augment loss_terms unet_ops unet_h3 unet_h3_enc unet_h3_first engine)
+units=(conv3x3_c16 fused_h3 fused_h3v edge_layers train_ops pyramid augment loss_terms unet_ops unet_h3 unet_h3_enc unet_h3_first engine)
+# incremental: a unit is recompiled when its source, any header or the flag set is newer than / differs from its object
+flags_sig="$*"
+[ -f "$obj/.flags" ] && [ "$(cat "$obj/.flags")" = "$flags_sig" ] || { rm -f "$obj"/*.o; printf '%s' "$flags_sig" > "$obj/.flags"; }
+newest_hdr="$(ls -t "$here"/*.h "$here/../../include/bfcnn_hip.h" "${BASH_SOURCE[0]}" | head -1)"
 pids=()
 for u in "${units[@]}"; do
+    if [ -f "$obj/$u.o" ] && [ "$obj/$u.o" -nt "$here/$u.hip" ] && [ "$obj/$u.o" -nt "$newest_hdr" ]; then continue; fi
     "$HIPCC" -O3 --offload-arch=gfx950 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed "$@" \
         -c "$here/$u.hip" -o "$obj/$u.o" &
     pids+=($!)
@@ -19,5 +27,5 @@ for p in "${pids[@]}"; do wait "$p" || fail=1; done
 [ "$fail" -eq 0 ] || { echo "compilation failed" >&2; exit 1; }
 objs=()
 for u in "${units[@]}"; do objs+=("$obj/$u.o"); done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$out/libbfcnn_hip.so"
-echo "built $out/libbfcnn_hip.so"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$out/$name"
+echo "built $out/$name"

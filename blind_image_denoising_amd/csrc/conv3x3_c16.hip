@@ -706,12 +706,9 @@ static hipError_t launch_fused_dma(FusedBlockArgs a, int wgs_per_cu, hipStream_t
     a.tiles_x = (a.W + Cfg::TW - 1) / Cfg::TW;
     a.tiles_y = (a.H + Cfg::TH - 1) / Cfg::TH;
     a.ntiles = a.B * a.tiles_x * a.tiles_y;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_block_dma_kernel<Cfg>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, FusedDmaCfg<Cfg>::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_done = true;
+    {
+        const hipError_t ea = bf_set_max_lds(reinterpret_cast<const void*>(fused_block_dma_kernel<Cfg>), FusedDmaCfg<Cfg>::LDS_BYTES);      // once per device
+        if (ea != hipSuccess) return ea;
     }
     const int resident = 256 * wgs_per_cu;
     int grid = a.ntiles < resident ? a.ntiles : resident;
@@ -998,12 +995,9 @@ static hipError_t launch_fused_v4(FusedBlockArgs a, int wgs_per_cu, hipStream_t 
     a.tiles_x = (a.W + Cfg::TW - 1) / Cfg::TW;
     a.tiles_y = (a.H + Cfg::TH - 1) / Cfg::TH;
     a.ntiles = a.B * a.tiles_x * a.tiles_y;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_block_v4_kernel<Cfg>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, V4<Cfg>::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_done = true;
+    {
+        const hipError_t ea = bf_set_max_lds(reinterpret_cast<const void*>(fused_block_v4_kernel<Cfg>), V4<Cfg>::LDS_BYTES);      // once per device
+        if (ea != hipSuccess) return ea;
     }
     const int resident = 256 * wgs_per_cu;
     int grid = a.ntiles < resident ? a.ntiles : resident;
@@ -1025,12 +1019,9 @@ static hipError_t launch_fused(FusedBlockArgs a, int wgs_per_cu, hipStream_t s)
     a.tiles_x = (a.W + Cfg::TW - 1) / Cfg::TW;
     a.tiles_y = (a.H + Cfg::TH - 1) / Cfg::TH;
     a.ntiles = a.B * a.tiles_x * a.tiles_y;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_block_kernel<Cfg>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_done = true;
+    {
+        const hipError_t ea = bf_set_max_lds(reinterpret_cast<const void*>(fused_block_kernel<Cfg>), Cfg::LDS_BYTES);      // once per device
+        if (ea != hipSuccess) return ea;
     }
     const int resident = 256 * wgs_per_cu;
     int grid = a.ntiles < resident ? a.ntiles : resident;
@@ -1142,12 +1133,9 @@ hipError_t bf_launch_wgrad3x3_c16(const float* x, const float* dy, float* partia
     const int ntiles = B * tiles_x * tiles_y;
     const int grid = bf_wgrad_grid(B, H, W);
     constexpr int lds_bytes = (WG_IH * WG_IW + WG_TH * WG_TW) * 16 * 4;   // 71,936
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_c16_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return e;
-        attr_done = true;
+    {
+        const hipError_t ea = bf_set_max_lds(reinterpret_cast<const void*>(wgrad3x3_c16_kernel), lds_bytes);      // once per device
+        if (ea != hipSuccess) return ea;
     }
     hipLaunchKernelGGL(wgrad3x3_c16_kernel, dim3(grid), dim3(256), lds_bytes, s, x, dy, partial, B, H, W,
                        tiles_x, tiles_y, ntiles);

@@ -26,7 +26,7 @@ struct bf_engine {
     int fused_head = 0;      // 1: split-f16 path, linear head, 3 output channels: head folded into the last block's epilogue
                              // (measured 5.49 vs 5.51 ms per batch of 128: the longer epilogue of the last block costs what the
                              // head kernel saves, so it stays an option)
-    int h3_variant = 1;
+    int h3_variant = -1;            // split-f16 block kernel: < 0 = library default (bf_set_h3_variant), else that variant
     // arithmetic of the fused inference blocks: 1 = split-f16 on the f16 matrix cores (fused_h3.hip, needs
     // |activation| < 65504), 0 = exact fp32 on the f32 matrix cores (conv3x3_c16.hip)
     int arith = 1;
@@ -189,7 +189,7 @@ extern "C" int bf_set_option(bf_handle h, const char* key, int value)
     if (!h || !key) return BF_EINVAL;
     if (!strcmp(key, "fused_blocks")) { h->fused_blocks = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "fused_tile")) { bf_set_fused_tile(value); return BF_OK; }
-    if (!strcmp(key, "h3_variant")) { bf_set_h3_variant(value); h->h3_variant = value < 0 ? 1 : value; return BF_OK; }
+    if (!strcmp(key, "h3_variant")) { h->h3_variant = value; return BF_OK; }      // per handle; < 0 = library default
     if (!strcmp(key, "fused_head")) { h->fused_head = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_arith")) { h->train_arith = value < 0 ? 1 : (value ? 1 : 0); return BF_OK; }
     if (!strcmp(key, "arith")) { h->arith = value < 0 ? 1 : (value ? 1 : 0); return BF_OK; }
@@ -425,7 +425,8 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
     BF_HIP(bf_launch_base_conv(ba, s), "base_conv");
 
     int cur = 0;
-    const bool head_in_block = h3 && h->fused_head && h->h3_variant == 1 && d.head_activation == BF_ACT_LINEAR && d.out_channels == 3;
+    // the head epilogue exists in the row-streaming tile kernel only: asking for it selects that kernel for the last block
+    const bool head_in_block = h3 && h->fused_head && d.head_activation == BF_ACT_LINEAR && d.out_channels == 3;
     const int64_t tslot = h->n_timed % BF_TIMING_RING;
     if (h->timing) BF_HIP(hipEventRecord(h->ev[2 * tslot], s), "hipEventRecord");
     for (int i = 0; i < d.no_layers; ++i) {
@@ -456,11 +457,12 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
             fa.in = buf[cur]; fa.out = buf[cur ^ 1];
             fa.w1 = b3; fa.w2 = b3 + BF_H3_WPACK_FLOATS; fa.aux = b3 + 2 * BF_H3_WPACK_FLOATS;
             fa.w1r = fa.aux + 64; fa.w2r = fa.aux + 64 + BF_H3R_WPACK_FLOATS;
-            fa.B = B; fa.H = H; fa.W = W; fa.tiles_x = fa.tiles_y = fa.ntiles = 0;
+            fa.B = B; fa.H = H; fa.W = W; fa.tiles_x = fa.tiles_y = fa.ntiles = 0; fa.rows_per_tile = 0; fa.variant = h->h3_variant;
             fa.act1_relu = d.activation == BF_ACT_RELU; fa.zeros = pk + h->k_zero; fa.dump = (char*)status + 1024; fa.dbg = nullptr;
             fa.head_wh = nullptr; fa.head_out = nullptr; fa.head_u8 = 0; fa.Ho = fa.Wo = 0; fa.denormalize = 0;
             fa.v_min = fa.v_max = 0.f; fa.status = nullptr;
             if (head_in_block && i == d.no_layers - 1) {          // last block: linear head in its epilogue, no head kernel
+                fa.variant = 1;
                 fa.head_wh = pk + h->k_wh; fa.head_out = out; fa.head_u8 = out_is_u8; fa.Ho = Hs; fa.Wo = Ws;
                 fa.denormalize = d.denormalize; fa.v_min = d.v_min; fa.v_max = d.v_max; fa.status = status;
             }
@@ -1048,12 +1050,18 @@ extern "C" int bf_debug_fused_block_h3(const float* in, const float* w1_hwio, co
     FusedH3Args fa;
     fa.in = xa; fa.out = ya; fa.w1 = pk; fa.w2 = pk + BF_H3_WPACK_FLOATS; fa.aux = pk + 2 * BF_H3_WPACK_FLOATS;
     fa.w1r = fa.aux + 64; fa.w2r = fa.aux + 64 + BF_H3R_WPACK_FLOATS;
-    fa.B = B; fa.H = H; fa.W = W; fa.tiles_x = fa.tiles_y = fa.ntiles = 0; fa.act1_relu = act1_relu;
+    fa.B = B; fa.H = H; fa.W = W; fa.tiles_x = fa.tiles_y = fa.ntiles = 0; fa.rows_per_tile = 0; fa.variant = -1; fa.act1_relu = act1_relu;
     fa.zeros = zeros; fa.dump = dump; fa.dbg = g_fused_dbg;
     fa.head_wh = nullptr; fa.head_out = nullptr; fa.head_u8 = 0; fa.Ho = fa.Wo = 0; fa.denormalize = 0; fa.v_min = fa.v_max = 0.f;
     fa.status = nullptr;
     if (bf_launch_fused_block_h3(fa, s) != hipSuccess) return BF_EHIP;
     return bf_launch_h3_to_f32(ya, out, B, H, W, s) == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+extern "C" int bf_debug_set_h3_variant(int variant)
+{
+    bf_set_h3_variant(variant);
+    return BF_OK;
 }
 
 // single split-f16 3x3 convolution on fp32 NHWC (the training convolution); scratch = 4 * BF_H3_TRAIN_PACK floats + 2304

@@ -31,32 +31,7 @@
 // Barriers are bare s_barrier with lgkmcnt(0) only (hipcc puts vmcnt(0) in front of every __syncthreads it
 // can see, which would drain the DMA).
 #include "bf_common.h"
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-
-#define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
-
-// timing-only ablations of fused_block_h3r_kernel (tools/ablate.sh; results are WRONG when any is set):
-// 1 = no next-tile DMA, 2 = no global stores, 4 = no conv2 MFMA work, 8 = no conv1 MFMA work, 16 = no barriers,
-// 64 = no epilogue arithmetic (raw accumulator bits are stored)
-// 32 = s_memtime stamps per phase (diagnostic build; per-wave sums go to args.dbg, tools/stamp_h3.py)
-#ifndef H3_ABLATE
-#define H3_ABLATE 0
-#endif
-#if H3_ABLATE & 32
-#define H3_STAMP(k)                                                                                      \
-    do {                                                                                                 \
-        unsigned long long now_;                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                               \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");                      \
-        __builtin_amdgcn_sched_barrier(0);                                                               \
-        stamp_sum[k] += now_ - stamp_prev;                                                               \
-        stamp_prev = now_;                                                                               \
-    } while (0)
-#else
-#define H3_STAMP(k) do { } while (0)
-#endif
+#include "h3_core.h"
 
 template <int TH_, int TW_, int NW_>
 struct H3Cfg {
@@ -107,78 +82,6 @@ template <class Cfg>
 __device__ __forceinline__ bool h3_interior(const FusedH3Args& a, const H3Tile& t)
 {
     return t.y0 >= 2 && t.y0 + Cfg::TH + 2 <= a.H && t.x0 >= 2 && t.x0 + Cfg::TW + 2 <= a.W;
-}
-
-// s_waitcnt immediates (gfx9 encoding: vmcnt [3:0] + [15:14], expcnt [6:4], lgkmcnt [11:8]).  The waits go through
-// the builtin, not inline asm, so that hipcc's own waitcnt bookkeeping sees them: with an asm wait in the prologue
-// it believed the weight / scale loads issued before the tile loop were still pending at the loop header and put a
-// vmcnt(0) in front of the first MFMA of conv1 AND conv2 of every tile -- which drained the tile DMA right after
-// it had been issued (385 us per launch instead of the numbers in DESIGN.md).
-constexpr int h3_vmcnt(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
-constexpr int H3_LGKMCNT0 = 0xC07F;
-
-// workgroup barrier that publishes LDS writes but leaves vector-memory operations (the tile DMA) in flight
-// (s_barrier stays inline asm: hipcc puts "s_waitcnt vmcnt(0) lgkmcnt(0)" in front of every barrier it can see)
-__device__ __forceinline__ void h3_barrier()
-{
-    __builtin_amdgcn_s_waitcnt(H3_LGKMCNT0);
-#if H3_ABLATE & 16
-    asm volatile("" ::: "memory");
-#else
-    asm volatile("s_barrier" ::: "memory");
-#endif
-}
-
-// v - float(one half of the packed f16 pair hh) in ONE instruction (hipcc never selects v_fma_mix_f32 for this)
-__device__ __forceinline__ float h3_sub_half(const float v, const unsigned hh, const bool high)
-{
-    float r;
-    if (high) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(v));
-    else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(v));
-    return r;
-}
-
-// hi = f16(v) (round-to-nearest-even), lo = f16(v - hi): 2 x v_cvt_pk + 4 x v_fma_mix + 2 x v_cvt_pk
-__device__ __forceinline__ void h3_split(const f32x4 v, h4& hi, h4& lo)
-{
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-#if H3_ABLATE & 64
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    hi = __builtin_bit_cast(h4, (f32x2){v[0], v[1]});           // timing only: no conversion VALU at all
-    lo = __builtin_bit_cast(h4, (f32x2){v[2], v[3]});
-    return;
-#endif
-    hi = __builtin_convertvector(v, h4);
-    const unsigned a = __builtin_bit_cast(unsigned, (h2){hi[0], hi[1]}), b = __builtin_bit_cast(unsigned, (h2){hi[2], hi[3]});
-    const f32x4 d = {h3_sub_half(v[0], a, false), h3_sub_half(v[1], a, true), h3_sub_half(v[2], b, false), h3_sub_half(v[3], b, true)};
-    lo = __builtin_convertvector(d, h4);
-}
-
-// NOTE on `interior` shortcuts in the conv2 epilogues: `if (!interior && out_of_image) p = dump` made hipcc branch over the
-// select on the uniform `interior`, and on the taken path its hazard recognizer left ONE wait state between the last
-// MFMA of a row and the v_pk_fma that reads the accumulator: stale .zw halves on interior tiles of the wave-specialised
-// kernel (caught by the parity tests).  The out-of-image select is therefore unconditional (per-lane condition, no branch).
-//
-// hi / lo of the lane's four channels, then a row exchange (v_permlane16_swap_b32: result 0 = [a.row0, b.row0, a.row2,
-// b.row2], result 1 = [a.row1, b.row1, a.row3, b.row3], rows = 16-lane groups = q) so that every lane ends up with ONE
-// 16-byte record of EIGHT channels: q = 0 -> hi(c0..7), q = 1 -> lo(c0..7), q = 2 -> hi(c8..15), q = 3 -> lo(c8..15) of its
-// pixel, i.e. plane (q >> 1) + 2 * (q & 1).  One 16-byte store (ds_write_b128 / global dwordx4) per group instead of
-// two 8-byte ones: half the LDS-write and vector-memory instructions of the epilogues.  Needs EXEC all ones.
-__device__ __forceinline__ h8 h3_split_record(const f32x4 v)
-{
-    typedef unsigned u2 __attribute__((ext_vector_type(2)));
-    typedef unsigned u4 __attribute__((ext_vector_type(4)));
-    h4 hi, lo;
-    h3_split(v, hi, lo);
-    u2 H = __builtin_bit_cast(u2, hi), L = __builtin_bit_cast(u2, lo);
-    // inline asm with explicit wait states on both sides: with the builtin, hipcc 7.2 issued the swap in the slot right
-    // after the v_cvt_pk that produces its operand (and the store right after the swap) in the tightest code paths and
-    // the wave-specialised kernel then stored stale halves on interior tiles (parity tests) -- a data hazard of this
-    // new gfx950 instruction the compiler does not pad
-    unsigned h0 = H[0], l0 = L[0], h1 = H[1], l1 = L[1];
-    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
-                 : "+v"(h0), "+v"(l0), "+v"(h1), "+v"(l1));
-    return __builtin_bit_cast(h8, (u4){h0, h1, l0, l1});
 }
 
 // NG groups x 14 MFMAs.  va / vb / vc: per-group LDS byte address of the lane's 16-byte record of tap (0,0)
@@ -1598,12 +1501,9 @@ hipError_t bf_launch_wgrad3x3_h3(const float* x, const float* dy, float* partial
     const int tiles_x = (W + G::TW - 1) / G::TW, tiles_y = (H + G::TH - 1) / G::TH;
     const int ntiles = B * tiles_x * tiles_y;
     const int grid = bf_wgrad_grid(B, H, W);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_h3_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_done = true;
+    {
+        const hipError_t ea = bf_set_max_lds(reinterpret_cast<const void*>(wgrad3x3_h3_kernel), G::LDS_BYTES);      // once per device
+        if (ea != hipSuccess) return ea;
     }
     hipLaunchKernelGGL(wgrad3x3_h3_kernel, dim3(grid), dim3(256), G::LDS_BYTES, s, x, dy, partial, B, H, W, tiles_x, tiles_y, ntiles);
     hipError_t e = hipGetLastError();
@@ -1614,18 +1514,16 @@ hipError_t bf_launch_wgrad3x3_h3(const float* x, const float* dy, float* partial
 using H3Default = H3Cfg<16, 32, 8>;
 using H3Small = H3Cfg<16, 16, 4>;
 
-static int g_h3_variant = 1;      // 1 (default): row-streaming kernel ; 0: group-per-pass kernel
-void bf_set_h3_variant(int v) { g_h3_variant = v < 0 ? 1 : v; }
+#define BF_H3_DEFAULT_VARIANT 1
+static int g_h3_variant = BF_H3_DEFAULT_VARIANT;      // default of FusedH3Args::variant < 0 (debug entries without a handle)
+void bf_set_h3_variant(int v) { g_h3_variant = v < 0 ? BF_H3_DEFAULT_VARIANT : v; }
 
-template <class Cfg, int VARIANT>      // VARIANT keeps one attr_done per kernel (both kernels have the same function type)
+template <class Cfg, int VARIANT>
 static hipError_t launch_h3(void (*kernel)(FusedH3Args), const FusedH3Args& a, hipStream_t s)
 {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           Cfg::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_done = true;
+    {
+        const hipError_t ea = bf_set_max_lds(reinterpret_cast<const void*>(kernel), Cfg::LDS_BYTES);      // once per device
+        if (ea != hipSuccess) return ea;
     }
     const int resident = 256 * Cfg::WG_PER_CU;                  // persistent: every workgroup resident at once
     int grid = a.ntiles < resident ? a.ntiles : resident;
@@ -1639,7 +1537,10 @@ hipError_t bf_launch_fused_block_h3(const FusedH3Args& args, hipStream_t s)
     FusedH3Args a = args;
     if (!a.zeros || !a.dump) return hipErrorInvalidValue;
     if ((int64_t)a.H * a.W * 64 >= ((int64_t)1 << 32)) return hipErrorInvalidValue;      // 32-bit in-image offsets
-    if (g_h3_variant == 2) {                                    // two 4-wave workgroups per CU on 16x16 tiles
+    const int variant = a.variant < 0 ? g_h3_variant : a.variant;
+    // full-row streaming kernel: images up to 256 columns, no head epilogue (the tile kernel below takes the rest)
+    if (variant == 4 && !a.head_wh && bf_fused_block_h3v_supports(a.H, a.W)) return bf_launch_fused_block_h3v(a, s);
+    if (variant == 2) {                                    // two 4-wave workgroups per CU on 16x16 tiles
         using Cfg = H3Small;
         a.tiles_x = (a.W + Cfg::TW - 1) / Cfg::TW;
         a.tiles_y = (a.H + Cfg::TH - 1) / Cfg::TH;
@@ -1647,7 +1548,7 @@ hipError_t bf_launch_fused_block_h3(const FusedH3Args& args, hipStream_t s)
         a.w1 = a.w1r; a.w2 = a.w2r;
         return launch_h3<Cfg, 2>(fused_block_h3r_kernel<Cfg>, a, s);
     }
-    if (g_h3_variant == 3) {                                    // wave-specialised: conv1 waves / conv2 waves, 14x32 tiles
+    if (variant == 3) {                                    // wave-specialised: conv1 waves / conv2 waves, 14x32 tiles
         using Cfg = H3Spec;
         a.tiles_x = (a.W + Cfg::TW - 1) / Cfg::TW;
         a.tiles_y = (a.H + Cfg::TH - 1) / Cfg::TH;
@@ -1659,7 +1560,7 @@ hipError_t bf_launch_fused_block_h3(const FusedH3Args& args, hipStream_t s)
     a.tiles_x = (a.W + Cfg::TW - 1) / Cfg::TW;
     a.tiles_y = (a.H + Cfg::TH - 1) / Cfg::TH;
     a.ntiles = a.B * a.tiles_x * a.tiles_y;
-    if (g_h3_variant == 0) return launch_h3<Cfg, 0>(fused_block_h3_kernel<Cfg>, a, s);
+    if (variant == 0) return launch_h3<Cfg, 0>(fused_block_h3_kernel<Cfg>, a, s);
     a.w1 = a.w1r; a.w2 = a.w2r;                                 // horizontally paired weights
     if (a.head_wh) return launch_h3<Cfg, 5>(fused_block_h3r_kernel<Cfg, 1>, a, s);
     return launch_h3<Cfg, 1>(fused_block_h3r_kernel<Cfg>, a, s);

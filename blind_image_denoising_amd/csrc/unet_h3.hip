@@ -237,14 +237,11 @@ static hipError_t uh_launch(const float* in, const float* skip, float* out, cons
     int64_t grid = (ngroups + wpb - 1) / wpb;
     const int cap = LDS > 64 * 1024 ? 256 : 256 * 3;             // persistent: every workgroup loads the weights once
     if (grid > cap) grid = cap;
-    static bool attr_done[4] = {false, false, false, false};
 #define UH_LAUNCH(A)                                                                                                          \
     {                                                                                                                         \
-        if (!attr_done[A]) {                                                                                                  \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(uh_mlp_kernel<C, NP, A, NT, PRE>),                \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);                              \
+        {                                                                                                                     \
+            const hipError_t e = bf_set_max_lds(reinterpret_cast<const void*>(uh_mlp_kernel<C, NP, A, NT, PRE>), LDS);         \
             if (e != hipSuccess) return e;                                                                                    \
-            attr_done[A] = true;                                                                                              \
         }                                                                                                                     \
         hipLaunchKernelGGL((uh_mlp_kernel<C, NP, A, NT, PRE>), dim3((int)grid), dim3(NT), LDS, s, in, skip, out, packed, mult, npix,   \
                            alpha, dw, gamma, eps);                                                                            \

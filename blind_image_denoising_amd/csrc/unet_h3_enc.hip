@@ -374,15 +374,9 @@ extern "C" int bf_op_convnext_block_h3(const float* x, float* out, const float* 
     if (g_uh_enc_variant == 1) {
         constexpr int LDS_S = 32 * 32 * 32 + 2 * 4 * 8 * 8 * UH_STG_PITCH * 4 + 4 * 2 * UH_ROWBUF_F4 * 16;
         const int grid_s = (int)(ntiles < 256 ? ntiles : 256);
-        static bool attr_s[2][4] = {};
 #define UH_ENCS(KK, A)                                                                                                         \
     {                                                                                                                          \
-        if (!attr_s[KK == 5][A]) {                                                                                             \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(uh_enc32s_kernel<KK, A>),                                    \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_S) != hipSuccess)                           \
-                return BF_EHIP;                                                                                                \
-            attr_s[KK == 5][A] = true;                                                                                         \
-        }                                                                                                                      \
+        if (bf_set_max_lds(reinterpret_cast<const void*>(uh_enc32s_kernel<KK, A>), LDS_S) != hipSuccess) return BF_EHIP;  /* once per device */ \
         hipLaunchKernelGGL((uh_enc32s_kernel<KK, A>), dim3(grid_s), dim3(512), LDS_S, s, x, out, dw, ln_gamma, eps, packed, mult, B, H,  \
                            W, alpha);                                                                                          \
     }
@@ -400,15 +394,9 @@ extern "C" int bf_op_convnext_block_h3(const float* x, float* out, const float* 
     }
     constexpr int LDS = 32 * 32 * 32 + 4 * 8 * 8 * UH_STG_PITCH * 4;
     const int grid = (int)(ntiles < 512 ? ntiles : 512);
-    static bool attr_done[2][4] = {};
 #define UH_ENC(KK, A)                                                                                                          \
     {                                                                                                                          \
-        if (!attr_done[KK == 5][A]) {                                                                                          \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(uh_enc32_kernel<KK, A>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    LDS) != hipSuccess)                                                                        \
-                return BF_EHIP;                                                                                                \
-            attr_done[KK == 5][A] = true;                                                                                      \
-        }                                                                                                                      \
+        if (bf_set_max_lds(reinterpret_cast<const void*>(uh_enc32_kernel<KK, A>), LDS) != hipSuccess) return BF_EHIP;      /* once per device */ \
         hipLaunchKernelGGL((uh_enc32_kernel<KK, A>), dim3(grid), dim3(256), LDS, s, x, out, dw, ln_gamma, eps, packed, mult, B, H, W, \
                            alpha);                                                                                             \
     }

@@ -483,13 +483,7 @@ extern "C" int bf_op_dwmult_pointwise(const float* in, float* out, const float* 
 #define UO_DP(CI, MM, CO, KK)                                                                                                  \
     if (cin == CI && m == MM && cout == CO && k == KK) {                                                                       \
         constexpr int LDSB = ((UO_DP_TH + KK - 1) * (UO_DP_TW + KK - 1) * CI + KK * KK * CI * MM) * 4;                          \
-        static bool attr = false;                                                                                              \
-        if (!attr) {                                                                                                           \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(uo_dwmult_pw_kernel<CI, MM, CO, KK>),                        \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess)                           \
-                return BF_EHIP;                                                                                                \
-            attr = true;                                                                                                       \
-        }                                                                                                                      \
+        if (bf_set_max_lds(reinterpret_cast<const void*>(uo_dwmult_pw_kernel<CI, MM, CO, KK>), LDSB) != hipSuccess) return BF_EHIP;      \
         hipLaunchKernelGGL((uo_dwmult_pw_kernel<CI, MM, CO, KK>), grid, dim3(256), LDSB, s, in, out, wd, bias1, act1, alpha1, wp,  \
                            bias2, act2, alpha2, res, H, W);                                                                    \
         ok = true;                                                                                                             \

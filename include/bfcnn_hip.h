@@ -348,6 +348,9 @@ int64_t bf_debug_fused_block_h3_scratch_floats(int batch, int height, int width)
 int bf_debug_fused_block_h3(const float* in, const float* w1_hwio, const float* w2_hwio, const float* scale,
                             const float* shift, float* out, float* scratch,
                             int batch, int height, int width, int act1_relu, void* stream);
+/* kernel the handle-less entry above launches (a handle's own choice is bf_set_option "h3_variant"): 4 full-row streaming
+   (falls back to 1 beyond 256 columns), 1 row-streaming tiles, 0 / 2 / 3 earlier tile kernels; < 0 = library default */
+int bf_debug_set_h3_variant(int variant);
 int64_t bf_debug_conv3x3_h3_scratch_floats(void);
 int bf_debug_conv3x3_h3(const float* in, const float* w_hwio, float* out, const float* res, const float* mask, float* stats,
                         float* scratch, int batch, int height, int width, int epi, int transpose_flip, void* stream);

@@ -161,14 +161,12 @@ def test_fused_block_many_tiles_persistent_schedule(fused_tile):
 
 
 # ---- split-f16 ("f16x3") fused block: same oracle, same bar as the exact-fp32 kernels ---------------------
-@pytest.fixture(params=[1, 0, 2, 3], ids=["rows", "groups", "rows16x16", "specialised"], autouse=False)
+@pytest.fixture(params=[4, 1, 0, 2, 3], ids=["fullrow", "rows", "groups", "rows16x16", "specialised"], autouse=False)
 def h3_variant(request):
-    """both split-f16 kernels (row-streaming = default, group-per-pass) must pass the same parity tests."""
-    import blind_image_denoising_amd as bf
-    m = bf.model_builder(O.canonical_config(no_layers=0)["model"], device="cuda").hydra
-    m.set_option("h3_variant", request.param)
+    """every split-f16 kernel (full-row streaming, row-streaming tiles, group-per-pass, ...) must pass the same parity tests."""
+    N.lib().bf_debug_set_h3_variant(request.param)
     yield request.param
-    m.set_option("h3_variant", -1)
+    N.lib().bf_debug_set_h3_variant(-1)
 
 
 @pytest.mark.parametrize("shape", SHAPES + [(1, 16, 32), (2, 32, 64), (1, 17, 33), (4, 70, 40), (1, 2, 2), (3, 48, 100)])
