@@ -382,6 +382,7 @@ def main():
     ap.add_argument("--fused-tile", type=int, default=None, help="exact-fp32 fused-block tile geometry variant (A/B only)")
     ap.add_argument("--arith", type=int, default=1, help="1 = split-f16 fused blocks (default), 0 = exact-fp32 fused blocks")
     ap.add_argument("--h3-variant", type=int, default=None, help="split-f16 kernel variant (A/B only)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT", help="bf_set_option on the model (A/B only)")
     ap.add_argument("--loss", choices=["l1", "shipped"], default="l1",
                     help="--mode train: l1 = BASELINE configs[3] (L1 only); shipped = L1 + RMSE + SSIM as the reference's configs")
     ap.add_argument("--unet-graph", choices=["v5", "v5.6"], default="v5",
@@ -444,6 +445,9 @@ def main():
     if args.h3_variant is not None:
         model.set_option("h3_variant", args.h3_variant)
     model.set_option("arith", args.arith)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        model.set_option(k, int(v))
     h3 = bool(args.arith) and not args.unfused
     model.set_option("timing", 1)
     module = bf.DenoiserModule(model)
@@ -493,7 +497,9 @@ def main():
         avg_launch_s = block_ms / 1e3 / max(launches, 1)
         achieved = per_launch_flop / avg_launch_s / 1e12
         if h3:
-            kernel = "fused_block_h3r_kernel" if args.h3_variant in (None, 1) else "fused_block_h3_kernel"
+            kernel = {None: "fused_block_h3v_kernel", 4: "fused_block_h3v_kernel", 1: "fused_block_h3r_kernel"}.get(args.h3_variant, "fused_block_h3_kernel")
+            if S > 256 and kernel == "fused_block_h3v_kernel":
+                kernel = "fused_block_h3r_kernel"          # the full-row kernel covers images up to 256 columns
             gbs = per_launch_bytes / avg_launch_s / 1e9
             roofline = {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(args.layers, B, S, True, kernel),

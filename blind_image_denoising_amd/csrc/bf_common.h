@@ -91,6 +91,7 @@ struct FusedH3Args {
     int B, H, W;
     int tiles_x, tiles_y, ntiles;   // filled in by the launcher
     int rows_per_tile;    // full-row streaming kernel (fused_h3v.hip): rows per band, filled in by the launcher
+    int reverse_tiles;    // full-row streaming kernel: walk the bands last to first (see forward_common)
     int variant;          // kernel selection: < 0 = library default (bf_set_h3_variant), else as bf_set_option("h3_variant")
     int act1_relu;
     const void* zeros;    // >= 64 B of zeros, 16-B aligned (source of out-of-image elements)

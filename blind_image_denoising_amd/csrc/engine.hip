@@ -26,6 +26,7 @@ struct bf_engine {
     int fused_head = 0;      // 1: split-f16 path, linear head, 3 output channels: head folded into the last block's epilogue
                              // (measured 5.49 vs 5.51 ms per batch of 128: the longer epilogue of the last block costs what the
                              // head kernel saves, so it stays an option)
+    int h3_zigzag = 1;              // alternate the band order of consecutive split-f16 blocks (Infinity Cache reuse)
     int h3_variant = -1;            // split-f16 block kernel: < 0 = library default (bf_set_h3_variant), else that variant
     // arithmetic of the fused inference blocks: 1 = split-f16 on the f16 matrix cores (fused_h3.hip, needs
     // |activation| < 65504), 0 = exact fp32 on the f32 matrix cores (conv3x3_c16.hip)
@@ -190,6 +191,7 @@ extern "C" int bf_set_option(bf_handle h, const char* key, int value)
     if (!strcmp(key, "fused_blocks")) { h->fused_blocks = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "fused_tile")) { bf_set_fused_tile(value); return BF_OK; }
     if (!strcmp(key, "h3_variant")) { h->h3_variant = value; return BF_OK; }      // per handle; < 0 = library default
+    if (!strcmp(key, "h3_zigzag")) { h->h3_zigzag = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "fused_head")) { h->fused_head = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_arith")) { h->train_arith = value < 0 ? 1 : (value ? 1 : 0); return BF_OK; }
     if (!strcmp(key, "arith")) { h->arith = value < 0 ? 1 : (value ? 1 : 0); return BF_OK; }
@@ -458,6 +460,9 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
             fa.w1 = b3; fa.w2 = b3 + BF_H3_WPACK_FLOATS; fa.aux = b3 + 2 * BF_H3_WPACK_FLOATS;
             fa.w1r = fa.aux + 64; fa.w2r = fa.aux + 64 + BF_H3R_WPACK_FLOATS;
             fa.B = B; fa.H = H; fa.W = W; fa.tiles_x = fa.tiles_y = fa.ntiles = 0; fa.rows_per_tile = 0; fa.variant = h->h3_variant;
+            // consecutive blocks walk the batch in opposite directions: a block starts on the bands the previous one wrote
+            // last, which are the ones still in the 256 MB Infinity Cache
+            fa.reverse_tiles = h->h3_zigzag ? (i & 1) : 0;
             fa.act1_relu = d.activation == BF_ACT_RELU; fa.zeros = pk + h->k_zero; fa.dump = (char*)status + 1024; fa.dbg = nullptr;
             fa.head_wh = nullptr; fa.head_out = nullptr; fa.head_u8 = 0; fa.Ho = fa.Wo = 0; fa.denormalize = 0;
             fa.v_min = fa.v_max = 0.f; fa.status = nullptr;
@@ -1050,7 +1055,7 @@ extern "C" int bf_debug_fused_block_h3(const float* in, const float* w1_hwio, co
     FusedH3Args fa;
     fa.in = xa; fa.out = ya; fa.w1 = pk; fa.w2 = pk + BF_H3_WPACK_FLOATS; fa.aux = pk + 2 * BF_H3_WPACK_FLOATS;
     fa.w1r = fa.aux + 64; fa.w2r = fa.aux + 64 + BF_H3R_WPACK_FLOATS;
-    fa.B = B; fa.H = H; fa.W = W; fa.tiles_x = fa.tiles_y = fa.ntiles = 0; fa.rows_per_tile = 0; fa.variant = -1; fa.act1_relu = act1_relu;
+    fa.B = B; fa.H = H; fa.W = W; fa.tiles_x = fa.tiles_y = fa.ntiles = 0; fa.rows_per_tile = 0; fa.variant = -1; fa.reverse_tiles = 0; fa.act1_relu = act1_relu;
     fa.zeros = zeros; fa.dump = dump; fa.dbg = g_fused_dbg;
     fa.head_wh = nullptr; fa.head_out = nullptr; fa.head_u8 = 0; fa.Ho = fa.Wo = 0; fa.denormalize = 0; fa.v_min = fa.v_max = 0.f;
     fa.status = nullptr;

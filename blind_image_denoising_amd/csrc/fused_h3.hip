@@ -1514,7 +1514,7 @@ hipError_t bf_launch_wgrad3x3_h3(const float* x, const float* dy, float* partial
 using H3Default = H3Cfg<16, 32, 8>;
 using H3Small = H3Cfg<16, 16, 4>;
 
-#define BF_H3_DEFAULT_VARIANT 1
+#define BF_H3_DEFAULT_VARIANT 4      // full-row streaming kernel (fused_h3v.hip) up to 256 columns, row-streaming tiles beyond
 static int g_h3_variant = BF_H3_DEFAULT_VARIANT;      // default of FusedH3Args::variant < 0 (debug entries without a handle)
 void bf_set_h3_variant(int v) { g_h3_variant = v < 0 ? BF_H3_DEFAULT_VARIANT : v; }
 
@@ -1537,7 +1537,9 @@ hipError_t bf_launch_fused_block_h3(const FusedH3Args& args, hipStream_t s)
     FusedH3Args a = args;
     if (!a.zeros || !a.dump) return hipErrorInvalidValue;
     if ((int64_t)a.H * a.W * 64 >= ((int64_t)1 << 32)) return hipErrorInvalidValue;      // 32-bit in-image offsets
-    const int variant = a.variant < 0 ? g_h3_variant : a.variant;
+    int variant = a.variant < 0 ? g_h3_variant : a.variant;
+    if (variant & 256) a.reverse_tiles = 1;                      // tests: the bottom-up walk of the full-row streaming kernel
+    variant &= 255;
     // full-row streaming kernel: images up to 256 columns, no head epilogue (the tile kernel below takes the rest)
     if (variant == 4 && !a.head_wh && bf_fused_block_h3v_supports(a.H, a.W)) return bf_launch_fused_block_h3v(a, s);
     if (variant == 2) {                                    // two 4-wave workgroups per CU on 16x16 tiles

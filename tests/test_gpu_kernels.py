@@ -161,7 +161,7 @@ def test_fused_block_many_tiles_persistent_schedule(fused_tile):
 
 
 # ---- split-f16 ("f16x3") fused block: same oracle, same bar as the exact-fp32 kernels ---------------------
-@pytest.fixture(params=[4, 1, 0, 2, 3], ids=["fullrow", "rows", "groups", "rows16x16", "specialised"], autouse=False)
+@pytest.fixture(params=[4, 260, 1, 0, 2, 3], ids=["fullrow", "fullrow_up", "rows", "groups", "rows16x16", "specialised"], autouse=False)
 def h3_variant(request):
     """every split-f16 kernel (full-row streaming, row-streaming tiles, group-per-pass, ...) must pass the same parity tests."""
     N.lib().bf_debug_set_h3_variant(request.param)
