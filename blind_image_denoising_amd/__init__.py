@@ -21,7 +21,9 @@ from .model import (BuilderResults, HydraModel, model_builder, describe_resnet, 
 from .module_denoiser import DenoiserModule
 from .loss import loss_function_builder
 from .optimizer import optimizer_builder, schedule_builder, deep_supervision_schedule_builder
-from .train_loop import (train_loop, build_train_functions, DataParallelTrainer, shard_batch, allreduce_gradients)
+from .train_loop import (train_loop, build_train_functions, DataParallelTrainer, NativeCommunicator, shard_batch,
+                         allreduce_gradients)
+from .checkpoint import Checkpoint, CheckpointManager
 from .pyramid import (build_pyramid_model, build_inverse_pyramid_model, multiscales_generator_fn)
 from .dataset import dataset_builder, PrepareData, noise_augment
 

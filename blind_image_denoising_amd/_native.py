@@ -59,6 +59,7 @@ SIGNATURES = {
     "bf_pack_inference": (_I, [_P, _P, _P, _P, _P]),
     "bf_forward_u8": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _I64, _P]),
     "bf_forward_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _I64, _P]),
+    "bf_forward_u8_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _I64, _P]),
     "bf_train_step": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, C.POINTER(LossDesc), _P, _P, _P, _P, _I64, _P]),
     "bf_adam_step": (_I, [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _P, _P, _P]),
     "bf_adam_step_ex": (_I, [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _P, _I, _P, _F, _P, _P, _P]),
@@ -90,8 +91,16 @@ SIGNATURES = {
     "bf_op_attention_ld": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "bf_op_first_conv": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _F, _P]),
     "bf_op_first_conv_h3": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _I, _F, _P]),
-    "bf_op_head_out": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
-    "bf_op_head_fused": (_I, [_P, _P, _F, _P, _I, _F, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
+    "bf_op_head_out": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P]),
+    "bf_op_head_fused": (_I, [_P, _P, _F, _P, _I, _F, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P]),
+    "bf_op_fill32": (_I, [_P, _I, _I64, _P]),
+    "bf_op_axpy": (_I, [_P, _P, _F, _I, _I64, _P]),
+    "bf_op_conv2d_transpose": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "bf_comm_unique_id": (_I, [C.c_char_p]),
+    "bf_comm_init_rank": (_I, [C.POINTER(_P), _I, _I, C.c_char_p]),
+    "bf_comm_destroy": (_I, [_P]),
+    "bf_allreduce_grads": (_I, [_P, _P, _I64, _P, _P]),
+    "bf_comm_last_error": (C.c_char_p, []),
     "bf_op_channel_multiplier": (_I, [_P, _P, _I, _P]),
     "bf_set_option": (_I, [_P, C.c_char_p, _I]),
     "bf_get_timing": (_I, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
@@ -115,6 +124,41 @@ BF_STATUS_F16_RANGE = 1
 _lib = None
 
 
+class StreamArg(C.c_void_p):
+    """hipStream_t argument that remembers which device it belongs to (see _device_guard)."""
+    _bf_device = None
+
+
+def _device_guard(fn):
+    """A HIP launch goes to the CURRENT device of the calling thread, whatever memory its pointers name; a stream of
+    another device is an error, and the null stream silently means "the current device".  Every launching entry point
+    takes the stream `stream_ptr(tensor)` made from one of its tensors: the wrapper runs the call with that tensor's
+    device current (a no-op in the usual one-process-per-GPU setting)."""
+    def call(*args):
+        for a in args:
+            dev = getattr(a, "_bf_device", None)
+            if dev is not None:
+                import torch
+                if torch.cuda.current_device() != dev:
+                    with torch.cuda.device(dev):
+                        return fn(*args)
+                break
+        return fn(*args)
+    call.raw = fn
+    call.__name__ = getattr(fn, "__name__", "bf_call")
+    return call
+
+
+class _Library:
+    """namespace of the guarded entry points (attribute access as on the ctypes.CDLL it wraps)."""
+
+    def __init__(self, handle):
+        self._handle = handle
+
+    def __getattr__(self, name):          # symbols outside SIGNATURES (tools/: debug hooks): the raw ctypes function
+        return getattr(self._handle, name)
+
+
 def lib():
     """The loaded library; raises (never falls back) when it is missing."""
     global _lib
@@ -124,13 +168,15 @@ def lib():
                 f"{LIB_PATH} is missing: the gfx950 HIP library has not been built "
                 f"(run blind_image_denoising_amd/csrc/build.sh). There is no CPU fallback.")
         handle = C.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
+        wrapped = _Library(handle)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)   # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+            setattr(wrapped, name, _device_guard(fn))
         if handle.bf_abi_version() != 1:
             raise ImportError("libbfcnn_hip.so ABI version mismatch")
-        _lib = handle
+        _lib = wrapped
     return _lib
 
 
@@ -163,8 +209,13 @@ def ptr(t):
 
 
 def stream_ptr(t=None):
-    """hipStream_t of torch's current stream on the tensor's device."""
+    """hipStream_t of torch's current stream on the tensor's device (and, for the call it is passed to, the device
+    that call runs on: _device_guard)."""
     import torch
     if t is not None and t.is_cuda:
-        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        dev = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    else:
+        dev = torch.cuda.current_device()
+    s = StreamArg(torch.cuda.current_stream(dev).cuda_stream)
+    s._bf_device = dev
+    return s

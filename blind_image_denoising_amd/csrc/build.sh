@@ -10,7 +10,7 @@ name="${BF_BUILD_NAME:-libbfcnn_hip.so}"
 obj="$out/obj${BF_BUILD_NAME:+_${BF_BUILD_NAME%.so}}"
 mkdir -p "$out" "$obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-units=(conv3x3_c16 fused_h3 fused_h3v edge_layers train_ops pyramid augment loss_terms unet_ops unet_h3 unet_h3_enc unet_h3_first engine)
+units=(conv3x3_c16 fused_h3 fused_h3v edge_layers train_ops pyramid augment loss_terms unet_ops unet_h3 unet_h3_enc unet_h3_first collective engine)
 # incremental: a unit is recompiled when its source, any header or the flag set is newer than / differs from its object
 flags_sig="$*"
 [ -f "$obj/.flags" ] && [ "$(cat "$obj/.flags")" = "$flags_sig" ] || { rm -f "$obj"/*.o; printf '%s' "$flags_sig" > "$obj/.flags"; }
@@ -27,5 +27,5 @@ for p in "${pids[@]}"; do wait "$p" || fail=1; done
 [ "$fail" -eq 0 ] || { echo "compilation failed" >&2; exit 1; }
 objs=()
 for u in "${units[@]}"; do objs+=("$obj/$u.o"); done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$out/$name"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -ldl -o "$out/$name"
 echo "built $out/$name"

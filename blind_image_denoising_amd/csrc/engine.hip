@@ -533,6 +533,17 @@ extern "C" int bf_forward_u8(bf_handle h, const void* packed, const uint8_t* in,
                           (hipStream_t)stream);
 }
 
+// DenoiserModule(cast_to_uint8=False): the same chain as bf_forward_u8 without the final round + cast
+extern "C" int bf_forward_u8_f32(bf_handle h, const void* packed, const uint8_t* in, float* out, int B, int H, int W, void* ws,
+                                 int64_t ws_bytes, void* stream)
+{
+    if (!h) return BF_EINVAL;
+    int rc = check_dims(h, packed, in, out, B, H, W);
+    if (rc) return rc;
+    return forward_common(h, (const float*)packed, in, 1, out, 0, B, H, W, pow2_target(H), pow2_target(W), ws, ws_bytes,
+                          (hipStream_t)stream);
+}
+
 extern "C" int bf_forward_f32(bf_handle h, const void* packed, const float* in, float* out, int B, int H, int W, void* ws,
                               int64_t ws_bytes, void* stream)
 {

@@ -53,6 +53,22 @@ hipError_t bf_launch_zero(float* p, int64_t n, hipStream_t s)
     return hipGetLastError();
 }
 
+// y += a * x (gradient accumulation over gpu_batches_per_step micro-batches, bfcnn/train_loop.py:296-310); a = 0 with
+// overwrite: y = x
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, int overwrite, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = overwrite ? x[i] : fmaf(a, x[i], y[i]);
+}
+
+extern "C" int bf_op_axpy(float* y, const float* x, float a, int overwrite, int64_t n, void* stream)
+{
+    if (!y || !x || n <= 0) return BF_EINVAL;
+    int64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(axpy_kernel, dim3((int)(g < 1024 ? g : 1024)), dim3(256), 0, (hipStream_t)stream, y, x, a, overwrite, n);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
 // ------------------------------------------------------------------------------------------
 // training-mode BatchNormalization(scale=True, center=False, momentum, epsilon)
 // (bfcnn/backbone_resnet.py:129-135; keras fused semantics):

@@ -1370,7 +1370,7 @@ extern "C" int bf_op_first_conv(const void* in, int in_is_u8, float* out, const 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void uo_head_out_kernel(const float* __restrict__ in, const float* __restrict__ w, void* __restrict__ out,
                                                           int out_is_u8, int B, int H, int W, int Ho, int Wo, int hf, int cout,
-                                                          int denormalize, float v_min, float v_max)
+                                                          int denormalize, float v_min, float v_max, int* __restrict__ status)
 {
     __shared__ float wl[4 * 256];
     for (int i = threadIdx.x; i < hf * cout; i += 256) wl[i] = w[i];
@@ -1389,6 +1389,8 @@ __global__ __launch_bounds__(256) void uo_head_out_kernel(const float* __restric
                 for (int o = 0; o < cout; ++o) acc[o] += v[j] * wl[(c + j) * cout + o];
         }
         for (int o = 0; o < cout; ++o) {
+            // an inf / NaN anywhere upstream (f16 range left inside a split-f16 kernel) reaches this sum; tanh would hide it
+            if (status && !(fabsf(acc[o]) <= 3.0e38f)) atomicOr(status, BF_STATUS_F16_RANGE);
             float r = tanhf(2.f * acc[o]) * 0.51f;
             if (denormalize) r = (fminf(fmaxf(r, -0.5f), 0.5f) + 0.5f) * (v_max - v_min) + v_min;
             if (out_is_u8) reinterpret_cast<unsigned char*>(out)[i * cout + o] = (unsigned char)fminf(fmaxf(rintf(r), 0.f), 255.f);
@@ -1398,14 +1400,14 @@ __global__ __launch_bounds__(256) void uo_head_out_kernel(const float* __restric
 }
 
 extern "C" int bf_op_head_out(const float* in, const float* w, void* out, int out_is_u8, int B, int H, int W, int Ho, int Wo, int hf,
-                              int cout, int denormalize, float v_min, float v_max, void* stream)
+                              int cout, int denormalize, float v_min, float v_max, int* status, void* stream)
 {
     if (!in || !w || !out || B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Ho > H || Wo > W) return BF_EINVAL;
     if (hf <= 0 || hf % 4 || hf > 256 || cout <= 0 || cout > 4) return BF_EUNSUPPORTED;
     if ((uintptr_t)in % 16) return BF_EINVAL;
     const int64_t n = (int64_t)B * Ho * Wo;
     hipLaunchKernelGGL(uo_head_out_kernel, dim3(uo_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, in, w, out, out_is_u8, B, H, W, Ho,
-                       Wo, hf, cout, denormalize, v_min, v_max);
+                       Wo, hf, cout, denormalize, v_min, v_max, status);
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
 
@@ -1421,7 +1423,7 @@ __global__ __launch_bounds__(256, 2) void uo_head_fused_kernel(const float* __re
                                                                const float* __restrict__ w0p, int act, float alpha,
                                                                const float* __restrict__ w1, void* __restrict__ out, int out_is_u8,
                                                                int B, int H, int W, int Ho, int Wo, int cout, int denormalize,
-                                                               float v_min, float v_max)
+                                                               float v_min, float v_max, int* __restrict__ status)
 {
     constexpr int KC = CIN / 16, T = 2, NP = 2, HF = 32;
     const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
@@ -1534,6 +1536,8 @@ __global__ __launch_bounds__(256, 2) void uo_head_fused_kernel(const float* __re
             // the resnet head uses (fused_h3.hip): absolute error ~1e-7, 1e-5 of an output grey level.
             const int64_t p = p0 + 16 * i + n;
             const float ok = q == 0 ? o[0] : (q == 1 ? o[1] : (q == 2 ? o[2] : o[3]));
+            // an inf / NaN anywhere upstream (f16 range left inside a split-f16 kernel) reaches this sum; tanh would hide it
+            if (status && !(fabsf(ok) <= 3.0e38f)) atomicOr(status, BF_STATUS_F16_RANGE);
             float r = (1.0f - 2.0f / (__expf(4.0f * ok) + 1.0f)) * 0.51f;
             if (denormalize) r = (fminf(fmaxf(r, -0.5f), 0.5f) + 0.5f) * (v_max - v_min) + v_min;
             if (q < cout && p < npix) {
@@ -1547,7 +1551,7 @@ __global__ __launch_bounds__(256, 2) void uo_head_fused_kernel(const float* __re
 
 extern "C" int bf_op_head_fused(const float* in, const float* ln_gamma, float eps, const float* w0p, int act, float alpha,
                                 const float* w1, void* out, int out_is_u8, int B, int H, int W, int Ho, int Wo, int cin, int hf,
-                                int cout, int denormalize, float v_min, float v_max, void* stream)
+                                int cout, int denormalize, float v_min, float v_max, int* status, void* stream)
 {
     if (!in || !w0p || !w1 || !out || B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Ho > H || Wo > W) return BF_EINVAL;
     if (hf != 32 || cout <= 0 || cout > 4) return BF_EUNSUPPORTED;
@@ -1557,13 +1561,77 @@ extern "C" int bf_op_head_fused(const float* in, const float* ln_gamma, float ep
     hipStream_t s = (hipStream_t)stream;
 #define UO_HEAD(CC)                                                                                                            \
     hipLaunchKernelGGL((uo_head_fused_kernel<CC>), dim3(grid), dim3(256), 0, s, in, ln_gamma, eps, w0p, act, alpha, w1, out,    \
-                       out_is_u8, B, H, W, Ho, Wo, cout, denormalize, v_min, v_max)
+                       out_is_u8, B, H, W, Ho, Wo, cout, denormalize, v_min, v_max, status)
     if (cin == 32) UO_HEAD(32);
     else if (cin == 64) UO_HEAD(64);
     else if (cin == 128) UO_HEAD(128);
     else if (cin == 256) UO_HEAD(256);
     else return BF_EUNSUPPORTED;
 #undef UO_HEAD
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// ------------------------------------------------------------------------------------------
+// Conv2DTranspose k x k, stride s, padding "same", no bias (upsample_type "conv2d_transpose", bfcnn/upsampling.py:37-48;
+// utilities.py:200-202): out [B, H*s, W*s, cout], kernel [k, k, cout, cin] (keras layout).  It is the transpose of the
+// stride-s SAME convolution that maps [H*s, W*s] to [H, W] (pad_before = max(k - s, 0) / 2):
+//   out[y, x, co] = sum over (iy, i), (ix, j) with iy*s + i - pb = y, ix*s + j - pb = x of in[iy, ix, :] . K[i, j, co, :]
+// One thread per output element; an upsampling primitive of configurations nobody ships, not a hot kernel.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void uo_conv2d_transpose_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                                  float* __restrict__ out, int B, int H, int W, int cin, int cout,
+                                                                  int k, int s, int act, float alpha)
+{
+    const int Ho = H * s, Wo = W * s, pb = (k > s ? k - s : 0) / 2;
+    const int64_t n = (int64_t)B * Ho * Wo * cout;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int co = (int)(e % cout);
+        int64_t p = e / cout;
+        const int x = (int)(p % Wo);
+        p /= Wo;
+        const int y = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        float acc = 0.f;
+        for (int i = 0; i < k; ++i) {
+            const int ty = y + pb - i;
+            if (ty < 0 || ty % s) continue;
+            const int iy = ty / s;
+            if (iy >= H) continue;
+            for (int j = 0; j < k; ++j) {
+                const int tx = x + pb - j;
+                if (tx < 0 || tx % s) continue;
+                const int ix = tx / s;
+                if (ix >= W) continue;
+                const float* src = in + (((int64_t)b * H + iy) * W + ix) * cin;
+                const float* kw = w + ((int64_t)(i * k + j) * cout + co) * cin;
+                for (int c = 0; c < cin; ++c) acc = fmaf(src[c], kw[c], acc);
+            }
+        }
+        out[e] = uo_act_rt(acc, act, alpha);
+    }
+}
+
+extern "C" int bf_op_conv2d_transpose(const float* in, const float* w, float* out, int B, int H, int W, int cin, int cout, int k,
+                                      int stride, int act, float alpha, void* stream)
+{
+    if (!in || !w || !out || B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return BF_EINVAL;
+    if (k <= 0 || k > 16 || stride <= 0 || stride > 8) return BF_EUNSUPPORTED;
+    const int64_t n = (int64_t)B * H * stride * W * stride * cout;
+    hipLaunchKernelGGL(uo_conv2d_transpose_kernel, dim3(uo_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, in, w, out, B, H, W, cin,
+                       cout, k, stride, act, alpha);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// 32-bit fill on the stream (status words, accumulators): the host library allocates, the engine initialises
+__global__ void uo_fill32_kernel(int* __restrict__ p, int value, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = value;
+}
+
+extern "C" int bf_op_fill32(void* p, int value, int64_t n, void* stream)
+{
+    if (!p || n <= 0) return BF_EINVAL;
+    hipLaunchKernelGGL(uo_fill32_kernel, dim3(uo_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, (int*)p, value, n);
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
 

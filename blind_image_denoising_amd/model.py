@@ -298,7 +298,11 @@ class HydraModel:
         return self._packed
 
     def set_option(self, key: str, value: int):
-        N.check(self._lib.bf_set_option(self._h, key.encode(), int(value)), self._h)
+        if self.device.type == "cuda":
+            with torch.cuda.device(self.device):       # ("timing" creates its events: on THIS model's device)
+                N.check(self._lib.bf_set_option(self._h, key.encode(), int(value)), self._h)
+        else:
+            N.check(self._lib.bf_set_option(self._h, key.encode(), int(value)), self._h)
 
     # ---- execution -----------------------------------------------------------------------
     def _as_device(self, x, dtype):
@@ -341,6 +345,14 @@ class HydraModel:
     # False: raise FloatingPointError instead.
     auto_exact_fallback = True
 
+    def status_tensor(self) -> Optional[torch.Tensor]:
+        """int32 view of the status word of the last inference forward (device memory, workspace tail), or None."""
+        ws = self._workspace
+        if ws is None:
+            return None
+        off = (ws.numel() - N.BF_STATUS_BYTES) // 4 * 4
+        return ws[off:off + 4].view(torch.int32)
+
     def check_status(self, raise_on_overflow: bool = True) -> bool:
         """Reads the status word of the last inference forward (synchronises the stream).  Returns True when it is
         clean; when an activation left the f16 range inside the split-f16 blocks -- the result is then not trustworthy
@@ -362,13 +374,14 @@ class HydraModel:
     def predict(self, x):
         return self(x, training=False)
 
-    def infer_u8(self, image: torch.Tensor) -> torch.Tensor:
-        """the fused DenoiserModule path: uint8 in -> uint8 out on device."""
+    def infer_u8(self, image: torch.Tensor, cast_to_uint8: bool = True) -> torch.Tensor:
+        """the fused DenoiserModule path: uint8 in -> uint8 out on device (cast_to_uint8=False: float32 out, not rounded)."""
         self._require_gpu()
         B, H, W, _ = image.shape
-        out = torch.empty((B, H, W, self.desc.out_channels), dtype=torch.uint8, device=self.device)
+        out = torch.empty((B, H, W, self.desc.out_channels), dtype=torch.uint8 if cast_to_uint8 else torch.float32, device=self.device)
         ws = self.workspace(N.BF_MODE_INFERENCE, B, H, W)
-        N.check(self._lib.bf_forward_u8(self._h, N.ptr(self.packed()), N.ptr(image), N.ptr(out), B, H, W,
+        fn = self._lib.bf_forward_u8 if cast_to_uint8 else self._lib.bf_forward_u8_f32
+        N.check(fn(self._h, N.ptr(self.packed()), N.ptr(image), N.ptr(out), B, H, W,
                                         N.ptr(ws), ws.numel(), N.stream_ptr(image)), self._h, "bf_forward_u8")
         return out
 

@@ -3,7 +3,33 @@ import numpy as np
 import torch
 
 from .constants import DENOISER_STR
-from .utilities import next_power_of_2
+
+
+class _DeferredStatus:
+    """The f16-range status word of a call that handed back DEVICE tensors: copied to pinned host memory behind that call
+    (stream-ordered, nothing synchronises) and looked at when the next call starts or when the caller asks.  Host-array
+    calls do not need it: they synchronise anyway and check at once."""
+
+    def __init__(self):
+        self.host, self.event = None, None
+
+    def post(self, status_dev: torch.Tensor):
+        if self.host is None:
+            self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.host.copy_(status_dev, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(status_dev.device))
+
+    def poll(self, wait: bool = False) -> int:
+        """status of the posted call if it is known (0 when nothing is pending or the copy has not finished yet)."""
+        if self.event is None:
+            return 0
+        if wait:
+            self.event.synchronize()
+        elif not self.event.query():
+            return 0
+        self.event = None
+        return int(self.host[0])
 
 
 class DenoiserModule:
@@ -21,10 +47,28 @@ class DenoiserModule:
         self.name = DENOISER_STR
         self._cast_to_uint8 = cast_to_uint8
         self._model_hydra = model_hydra
+        self._deferred = _DeferredStatus()
 
     @property
     def model_hydra(self):
         return self._model_hydra
+
+    def check_status(self, wait: bool = True) -> bool:
+        """f16-range status of the last call that returned device tensors (waits for it by default).  On a hit: with
+        `auto_exact_fallback` the model is switched to the exact-fp32 kernels for every later call and False comes back
+        (the tensor that call returned is NOT trustworthy); without it FloatingPointError is raised."""
+        from . import _native as N
+        hydra = self._model_hydra
+        if not (self._deferred.poll(wait) & N.BF_STATUS_F16_RANGE):
+            return True
+        if not getattr(hydra, "auto_exact_fallback", False):
+            raise FloatingPointError("an activation left the f16 range inside the split-f16 kernels during the previous "
+                                     "call: its output is not trustworthy; use set_option('arith', 0)")
+        from .custom_logger import logger
+        logger.warning("an activation left the f16 range inside the split-f16 kernels during the previous call (its output "
+                       "is not trustworthy): switching this model to the exact-fp32 kernels")
+        hydra.set_option("arith", 0)
+        return False
 
     def __call__(self, image):
         """image: uint8 tensor of rank 4 (the input_signature of module_denoiser.py:43-45)."""
@@ -43,22 +87,19 @@ class DenoiserModule:
             out = torch.empty((0,) + tuple(image.shape[1:3]) + (hydra.desc.out_channels,), dtype=torch.uint8)
             return out.numpy() if was_numpy else out
         hydra._require_gpu()
+        self.check_status(wait=False)          # the previous device-tensor call, if its status has arrived by now
         image = image.to(hydra.device).contiguous()
-        if getattr(hydra, "multi_output", False):
-            # several outputs (one per scale): the module keeps the first, full-resolution one (module_denoiser.py:62-65)
-            out = hydra.infer_u8(image, self._cast_to_uint8)
-        elif self._cast_to_uint8:
-            out = hydra.infer_u8(image)
-        else:
-            # float output: explicit pad -> hydra -> crop (no rounding)
-            B, H, W, C = image.shape
-            Hp, Wp = next_power_of_2(H), next_power_of_2(W)
-            x = torch.zeros((B, Hp, Wp, C), dtype=torch.float32, device=hydra.device)
-            x[:, :H, :W, :] = image.to(torch.float32)
-            out = hydra(x, training=False)[:, :H, :W, :].contiguous()
+        # one C-ABI call: cast, virtual power-of-two padding, hydra, crop and (cast_to_uint8) round + cast all run in the
+        # engine; a multi-output hydra keeps its first, full-resolution output (module_denoiser.py:62-65)
+        out = hydra.infer_u8(image, self._cast_to_uint8)
         if was_numpy and not hydra.check_status(raise_on_overflow=not hydra.auto_exact_fallback):
             # host arrays are handed back (the stream is synchronised anyway) and an activation left the f16 range:
             # switch this model to the exact-fp32 kernels for good and repeat the call
             hydra.set_option("arith", 0)
             return self(image.cpu().numpy())
-        return out.cpu().numpy() if was_numpy else out
+        if was_numpy:
+            return out.cpu().numpy()
+        st = hydra.status_tensor() if hasattr(hydra, "status_tensor") else None
+        if st is not None:
+            self._deferred.post(st)            # no synchronisation: looked at by the next call / check_status()
+        return out

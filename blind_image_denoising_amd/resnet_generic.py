@@ -257,11 +257,11 @@ class GenericResnetHydra:
     def predict(self, x):
         return self(x)
 
-    def infer_u8(self, image: torch.Tensor) -> torch.Tensor:
+    def infer_u8(self, image: torch.Tensor, cast_to_uint8: bool = True) -> torch.Tensor:
         from .utilities import next_power_of_2
         self._require_gpu()
         B, Hs, Ws, _ = image.shape
         H, W = next_power_of_2(Hs), next_power_of_2(Ws)
         P = self._pack()
-        return UL.head_fused(self._features(image, H, W), None, P["head0"], self.head_activation, P["head1"], Hs, Ws, True, True,
+        return UL.head_fused(self._features(image, H, W), None, P["head0"], self.head_activation, P["head1"], Hs, Ws, bool(cast_to_uint8), True,
                              self.v_min, self.v_max)

@@ -93,14 +93,55 @@ def allreduce_gradients(grads: torch.Tensor, group=None, async_op: bool = False)
     return dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
-class DataParallelTrainer:
-    """train_step_single_gpu + all-reduce + apply_grads for one rank of an N-GPU job."""
+class NativeCommunicator:
+    """The gradient exchange through the C ABI (bf_comm_* / bf_allreduce_grads: RCCL bound inside libbfcnn_hip.so), for a
+    host that does not want PyTorch on the data path.  The 128-byte rendezvous id travels over whatever channel the host has;
+    here torch.distributed's (already initialised) process group carries it once."""
 
-    def __init__(self, model: HydraModel, loss_fn_map, optimizer, group=None):
+    def __init__(self, device, group=None):
+        import ctypes as C
+        import torch.distributed as dist
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        lib = N.lib()
+        box = [None]
+        if self.rank == 0:
+            buf = C.create_string_buffer(128)
+            N.check(lib.bf_comm_unique_id(buf), None, "bf_comm_unique_id")
+            box[0] = buf.raw
+        dist.broadcast_object_list(box, src=0, group=group)
+        comm = C.c_void_p()
+        with torch.cuda.device(device):
+            rc = lib.bf_comm_init_rank(C.byref(comm), self.world, self.rank, box[0])
+        if rc != N.BF_OK:
+            raise RuntimeError(f"bf_comm_init_rank: {lib.bf_comm_last_error().decode()}")
+        self._comm, self._lib = comm, lib
+
+    def allreduce(self, grads: torch.Tensor):
+        rc = self._lib.bf_allreduce_grads(None, N.ptr(grads), grads.numel(), self._comm, N.stream_ptr(grads))
+        if rc != N.BF_OK:
+            raise RuntimeError(f"bf_allreduce_grads: {self._lib.bf_comm_last_error().decode()}")
+
+    def close(self):
+        if self._comm:
+            self._lib.bf_comm_destroy(self._comm)
+            self._comm = None
+
+
+class DataParallelTrainer:
+    """train_step_single_gpu + all-reduce + apply_grads for one rank of an N-GPU job.
+
+    The step has ONE collective, on one flat buffer whose consumer (the global-norm clip of Adam) needs all of it: the
+    all-reduce cannot overlap with the optimizer kernels themselves.  What it does overlap with is the work that does not
+    depend on it: `step(..., overlap=fn)` runs `fn()` -- typically the on-device corruption of the NEXT batch
+    (PrepareData / bf_noise_augment) -- between the launch of the all-reduce (asynchronous, on RCCL's stream) and the point
+    where the compute stream waits for it."""
+
+    def __init__(self, model: HydraModel, loss_fn_map, optimizer, group=None, native_collective: bool = False):
         import torch.distributed as dist
         self.model, self.optimizer, self.group = model, optimizer, group
         self.fns = build_train_functions(model, loss_fn_map)
         self.world_size = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.comm = NativeCommunicator(model.device, group) if (native_collective and self.world_size > 1) else None
 
     def broadcast_parameters(self, src: int = 0):
         import torch.distributed as dist
@@ -109,13 +150,23 @@ class DataParallelTrainer:
             dist.broadcast(self.model.state, src=src, group=self.group)
             self.model.mark_dirty()
 
-    def step(self, gt_shard: torch.Tensor, noisy_shard: torch.Tensor, depth_weight: float = 1.0):
+    def step(self, gt_shard: torch.Tensor, noisy_shard: torch.Tensor, depth_weight: float = 1.0, overlap: Optional[Callable] = None):
         total, model_loss, denoiser_loss, predictions, grads = self.fns.train_step_single_gpu(
             gt_shard, noisy_shard, (depth_weight,), 0.0, None)
-        work = allreduce_gradients(grads, self.group, async_op=True)
-        if work is not None:
-            work.wait()          # stream-ordered on RCCL: no host block, the Adam kernels queue behind it
+        side = None
+        if self.comm is not None:
+            self.comm.allreduce(grads)      # stream-ordered on the compute stream (RCCL kernel); `overlap` queues behind it
+            if overlap is not None:
+                side = overlap()
+        else:
+            work = allreduce_gradients(grads, self.group, async_op=True)
+            if overlap is not None:
+                side = overlap()            # runs on the compute stream while RCCL's stream carries the all-reduce
+            if work is not None:
+                work.wait()                 # stream-ordered on RCCL: no host block, the Adam kernels queue behind it
         self.fns.apply_grads(self.optimizer, grads, None, grad_scale=1.0 / self.world_size)
+        if overlap is not None:
+            return total, model_loss, denoiser_loss, predictions, side
         return total, model_loss, denoiser_loss, predictions
 
 
@@ -124,13 +175,19 @@ class DataParallelTrainer:
 def train_loop(pipeline_config_path, model_dir: str, dataset: Iterable = None, weights_dir: str = None,
                device=None, max_steps: Optional[int] = None):
     """Outer loop of bfcnn/train_loop.py:40-601 reduced to what surrounds the hot path: config ->
-    loss / optimizer / model builders -> epochs over `dataset` (an iterable yielding
-    (input_image_batch, noisy_image_batch) float tensors in value range) with gradient
-    accumulation over `gpu_batches_per_step` micro-batches -> model directory per epoch.
-    The tf.data pipeline, TensorBoard summaries and TF checkpoints are out of scope."""
+    loss / optimizer / model builders -> checkpoint manager (restore the latest checkpoint of `model_dir` if there is one:
+    weights, BN statistics, Adam slots, step, epoch -- train_loop.py:158-181) -> epochs over `dataset` (an iterable
+    yielding (input_image_batch, noisy_image_batch) float tensors in value range) with gradient accumulation over
+    `gpu_batches_per_step` micro-batches, a checkpoint every `checkpoint_every` steps and at the end of every epoch
+    (train_loop.py:563-566, 597) -> model directory per epoch.
+    The tf.data pipeline, TensorBoard summaries and TF's checkpoint format are out of scope."""
+    from .checkpoint import Checkpoint, CheckpointManager
     config = load_config(pipeline_config_path)
     train_config = config["train"]
-    epochs = train_config["epochs"]
+    epochs = int(train_config["epochs"])
+    total_steps = int(train_config.get("total_steps", -1))                 # train_loop.py:103
+    checkpoint_every = int(train_config.get("checkpoint_every", -1))       # train_loop.py:107-108
+    checkpoints_to_keep = int(train_config.get("checkpoints_to_keep", 3))  # train_loop.py:105-106
     gpu_batches_per_step = int(train_config.get("gpu_batches_per_step", 1))
     if gpu_batches_per_step <= 0:
         raise ValueError("gpu_batches_per_step must be > 0")               # train_loop.py:114-115
@@ -138,32 +195,41 @@ def train_loop(pipeline_config_path, model_dir: str, dataset: Iterable = None, w
         raise ValueError("dataset must be an iterable of (input_image_batch, noisy_image_batch)")
     loss_fn_map = loss_function_builder(config=config["loss"])
     optimizer, lr_schedule = optimizer_builder(config=train_config["optimizer"])
-    if weights_dir:
+    model = model_builder(config[MODEL_STR], device=device).hydra
+    ckpt = Checkpoint(model=model, optimizer=optimizer)
+    manager = CheckpointManager(checkpoint=ckpt, directory=model_dir, max_to_keep=checkpoints_to_keep)
+    if not manager.restore_latest() and weights_dir:
         from .model import load_hydra
-        model = load_hydra(weights_dir, device=device)
-    else:
-        model = model_builder(config[MODEL_STR], device=device).hydra
+        logger.info(f"loading weights from [{weights_dir}]")               # train_loop.py:183-210
+        w = load_hydra(weights_dir, device=device).get_weights()
+        model.set_weights(*w) if isinstance(w, tuple) else model.set_weights(w)
     fns = build_train_functions(model, loss_fn_map)
-    accumulated = torch.zeros(model.n_params, dtype=torch.float32, device=model.device)
-    step, history = 0, []
-    for epoch in range(int(epochs)):
+    accumulated = torch.empty(model.n_params, dtype=torch.float32, device=model.device)
+    history = []
+    finished = 0 < total_steps <= ckpt.step          # a restored run may already be complete
+    while not finished and ckpt.epoch < epochs:
         counter = 0
         t0 = time.time()
         for input_image_batch, noisy_image_batch in dataset:
             total, _, denoiser_loss, _, grads = fns.train_step_single_gpu(input_image_batch, noisy_image_batch, (1.0,), 0.0, None)
-            accumulated.add_(grads)
+            # accumulated (+)= grads on the engine's stream (first micro-batch of a step: overwrite)
+            N.check(N.lib().bf_op_axpy(N.ptr(accumulated), N.ptr(grads), 1.0, int(counter == 0), accumulated.numel(),
+                                       N.stream_ptr(accumulated)), None, "bf_op_axpy")
             counter += 1
             if counter >= gpu_batches_per_step:
                 fns.apply_grads(optimizer, accumulated, None, grad_scale=1.0 / counter)
-                accumulated.zero_()
                 counter = 0
-                step += 1
                 history.append(float(total.item()))
-                if max_steps is not None and step >= max_steps:
+                if checkpoint_every > 0 and ckpt.step > 0 and ckpt.step % checkpoint_every == 0:
+                    manager.save()
+                ckpt.step += 1
+                if (0 < total_steps <= ckpt.step) or (max_steps is not None and len(history) >= max_steps):
+                    finished = True
                     break
-        logger.info(f"epoch {epoch}: step {step}, {time.time() - t0:.1f}s")
-        save_model(model, os.path.join(model_dir, f"epoch_{epoch}"), config)
-        if max_steps is not None and step >= max_steps:
-            break
+        logger.info(f"end of epoch [{ckpt.epoch}], step {ckpt.step}, took [{time.time() - t0:.1f}] seconds")
+        save_model(model, os.path.join(model_dir, f"epoch_{ckpt.epoch}"), config)
+        if not finished:
+            ckpt.epoch += 1
+        manager.save()
     save_model(model, os.path.join(model_dir, "final"), config)
     return model, history

@@ -211,6 +211,19 @@ def upsample_act_add(x: torch.Tensor, other: Optional[torch.Tensor], act: str = 
     return out
 
 
+def conv2d_transpose(x: torch.Tensor, w: torch.Tensor, stride: int = 2, act: str = "linear") -> torch.Tensor:
+    """Conv2DTranspose(k, strides s, padding "same", use_bias=False): upsample_type "conv2d_transpose"
+    (bfcnn/upsampling.py:37-48); w [k,k,cout,cin] as keras stores it."""
+    B, H, W, cin = x.shape
+    k, cout = int(w.shape[0]), int(w.shape[2])
+    if w.shape[1] != k or w.shape[3] != cin:
+        raise ValueError(f"kernel {tuple(w.shape)} does not fit {cin} input channels")
+    out = torch.empty((B, H * stride, W * stride, cout), dtype=torch.float32, device=x.device)
+    code, a = _act(act)
+    _call("bf_op_conv2d_transpose", N.ptr(x), N.ptr(w), N.ptr(out), B, H, W, cin, cout, k, int(stride), code, a, N.stream_ptr(x))
+    return out
+
+
 def resize_bilinear(x: torch.Tensor, oh: int, ow: int) -> torch.Tensor:
     B, H, W, C = x.shape
     out = torch.empty((B, oh, ow, C), dtype=torch.float32, device=x.device)
@@ -254,24 +267,25 @@ def first_conv(x: torch.Tensor, w: torch.Tensor, H: int, W: int, act: str, norma
 
 
 def head_out(x: torch.Tensor, w: torch.Tensor, Ho: int, Wo: int, as_uint8: bool, denormalize: bool, v_min: float,
-             v_max: float) -> torch.Tensor:
+             v_max: float, status: Optional[torch.Tensor] = None) -> torch.Tensor:
     B, H, W, hf = x.shape
     cout = int(w.shape[-1])
     out = torch.empty((B, Ho, Wo, cout), dtype=torch.uint8 if as_uint8 else torch.float32, device=x.device)
     _call("bf_op_head_out", N.ptr(x), N.ptr(w), N.ptr(out), int(as_uint8), B, H, W, Ho, Wo, hf, cout, int(denormalize),
-          v_min, v_max, N.stream_ptr(x))
+          v_min, v_max, N.ptr(status), N.stream_ptr(x))
     return out
 
 
 def head_fused(x: torch.Tensor, gamma: Optional[torch.Tensor], w0p: torch.Tensor, act: str, w1: torch.Tensor, Ho: int, Wo: int,
-               as_uint8: bool, denormalize: bool, v_min: float, v_max: float, hf: int = 32, eps: float = LN_EPSILON) -> torch.Tensor:
+               as_uint8: bool, denormalize: bool, v_min: float, v_max: float, hf: int = 32, eps: float = LN_EPSILON,
+               status: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[LayerNorm * gamma] -> 1x1 C->hf + act -> 1x1 hf->cout -> tanh(2x)*0.51 -> denormalise [-> uint8], one kernel."""
     B, H, W, C = x.shape
     cout = int(w1.shape[-1])
     out = torch.empty((B, Ho, Wo, cout), dtype=torch.uint8 if as_uint8 else torch.float32, device=x.device)
     code, a = _act(act)
     _call("bf_op_head_fused", N.ptr(x), N.ptr(gamma), eps, N.ptr(w0p), code, a, N.ptr(w1), N.ptr(out), int(as_uint8), B, H, W,
-          Ho, Wo, C, hf, cout, int(denormalize), v_min, v_max, N.stream_ptr(x))
+          Ho, Wo, C, hf, cout, int(denormalize), v_min, v_max, N.ptr(status), N.stream_ptr(x))
     return out
 
 
@@ -299,14 +313,33 @@ class UnetLaplacianHydra:
     `trainable_variables` lists (name, shape, kind, offset)."""
 
     multi_output = True           # DenoiserModule keeps output 0
-    auto_exact_fallback = False
+    # True: when host arrays are handed back and the status word reports a non-finite value in front of a head's tanh (an
+    # activation left the f16 range inside a split-f16 operator), switch to the exact-fp32 operators and repeat the call
+    auto_exact_fallback = True
 
     class _Desc:
         def __init__(self, cin, cout):
             self.in_channels, self.out_channels = cin, cout
 
+    def _status(self) -> torch.Tensor:
+        """int32 status word on the device, cleared (bf_op_fill32) at the start of a forward, OR-ed by the head kernels."""
+        if getattr(self, "_status_word", None) is None:
+            self._status_word = torch.empty(1, dtype=torch.int32, device=self.device)
+        _call("bf_op_fill32", N.ptr(self._status_word), 0, 1, N.stream_ptr(self._status_word))
+        return self._status_word
+
+    def status_tensor(self) -> Optional[torch.Tensor]:
+        return getattr(self, "_status_word", None)
+
     def check_status(self, raise_on_overflow: bool = True) -> bool:
-        return True
+        """synchronises and reads the status word of the last forward (see HydraModel.check_status)."""
+        st = self.status_tensor()
+        if st is None or not (int(st.item()) & N.BF_STATUS_F16_RANGE):
+            return True
+        if raise_on_overflow:
+            raise FloatingPointError("an activation left the f16 range inside the split-f16 operators; "
+                                     "call set_option('arith', 0) to run the exact-fp32 operators")
+        return False
 
     def set_option(self, key: str, value: int):
         if key != "arith" or int(value) not in (0, 1):
@@ -701,7 +734,8 @@ class UnetLaplacianHydra:
     def _level_out(f: torch.Tensor, gamma: Optional[torch.Tensor], act: str) -> torch.Tensor:
         return f if (gamma is None and act == "linear") else dwconv_ln(f, None, gamma, act)
 
-    def _head(self, P, i: int, f: torch.Tensor, Ho: int, Wo: int, as_uint8: bool, deferred_norm: bool = False) -> torch.Tensor:
+    def _head(self, P, i: int, f: torch.Tensor, Ho: int, Wo: int, as_uint8: bool, deferred_norm: bool = False,
+              status: Optional[torch.Tensor] = None) -> torch.Tensor:
         gamma = None
         if deferred_norm and self.use_output_normalization and self.use_ln:
             if self.output_norm_at_heads:                      # every scale arrives un-normalised
@@ -710,11 +744,11 @@ class UnetLaplacianHydra:
                 gamma = P[f"dec{i}/out_ln/gamma"]
         if self.head_filters == 32:
             return head_fused(f, gamma, P[f"head{i}/conv0/kernel"], self.head_activation, P[f"head{i}/conv1/kernel"], Ho, Wo,
-                              as_uint8, True, self.v_min, self.v_max)
+                              as_uint8, True, self.v_min, self.v_max, status=status)
         if gamma is not None:
             f = dwconv_ln(f, None, gamma)
         h = pointwise(f, P[f"head{i}/conv0/kernel"], self.head_filters, self.head_activation)
-        return head_out(h, P[f"head{i}/conv1/kernel"], Ho, Wo, as_uint8, True, self.v_min, self.v_max)
+        return head_out(h, P[f"head{i}/conv1/kernel"], Ho, Wo, as_uint8, True, self.v_min, self.v_max, status=status)
 
     def _as_device(self, x):
         was_numpy = isinstance(x, np.ndarray)
@@ -735,10 +769,14 @@ class UnetLaplacianHydra:
         B, H, W, _ = x.shape
         P = self._pack()
         outs = []
+        status = self._status()
         for i, f in enumerate(self.backbone(x, H, W, defer_output_norm=True)):
-            outs.append(self._head(P, i, f, f.shape[1], f.shape[2], False, deferred_norm=True))
+            outs.append(self._head(P, i, f, f.shape[1], f.shape[2], False, deferred_norm=True, status=status))
         if was_numpy:
             torch.cuda.synchronize(self.device)
+            if not self.check_status(raise_on_overflow=not (self.auto_exact_fallback and self.arith != 0)):
+                self.set_option("arith", 0)
+                return self(x.cpu().numpy())
             return [o.cpu().numpy() for o in outs]
         return outs
 
@@ -753,5 +791,6 @@ class UnetLaplacianHydra:
         B, Hs, Ws, _ = image.shape
         H, W = next_power_of_2(Hs), next_power_of_2(Ws)
         P = self._pack()
+        status = self._status()
         f = self.backbone(image, H, W, defer_output_norm=True)[0]
-        return self._head(P, 0, f, Hs, Ws, cast_to_uint8, deferred_norm=True)
+        return self._head(P, 0, f, Hs, Ws, cast_to_uint8, deferred_norm=True, status=status)

@@ -137,6 +137,11 @@ int bf_pack_inference(bf_handle h, const float* params, const float* state, void
 int bf_forward_u8(bf_handle h, const void* packed, const uint8_t* in, uint8_t* out,
                   int batch, int height, int width, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* DenoiserModule(cast_to_uint8=False).__call__ (bfcnn/module_denoiser.py:66-75 without the cast branch): the same chain,
+ * float32 [B,H,W,Cout] out, not rounded. */
+int bf_forward_u8_f32(bf_handle h, const void* packed, const uint8_t* in, float* out,
+                      int batch, int height, int width, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* hydra(x, training=False) (bfcnn/model.py:91-151; test_step train_loop.py:253-257):
  * float32 [B,H,W,C] in value_range -> float32 [B,H,W,Cout].  No power-of-two padding. */
 int bf_forward_f32(bf_handle h, const void* packed, const float* in, float* out,
@@ -297,15 +302,38 @@ int bf_op_first_conv_h3(const void* in, int in_is_u8, float* out, const float* w
 /* last Conv2D 1x1 of a denoiser head + tanh(2x)*0.51 [+ denormalise][+ round, uint8], cropped to [Ho,Wo]
  * (model.py:321-342, 136-139; module_denoiser.py:62-73). */
 int bf_op_head_out(const float* in, const float* w, void* out, int out_is_u8, int batch, int height, int width, int out_height,
-                   int out_width, int head_filters, int cout, int denormalize, float v_min, float v_max, void* stream);
+                   int out_width, int head_filters, int cout, int denormalize, float v_min, float v_max, int* status, void* stream);
 /* A whole denoiser head in one kernel: [LayerNormalization(in) * ln_gamma (the backbone's output normalisation,
  * backbone_unet_laplacian.py:547-551; NULL: none)] -> Conv2D 1x1 cin -> 32 (w0p packed by bf_op_pack_pointwise) ->
  * activation -> Conv2D 1x1 32 -> cout (w1 [32][cout]) -> tanh(2x)*0.51 [-> denormalise][-> round, uint8], cropped. */
 int bf_op_head_fused(const float* in, const float* ln_gamma, float eps, const float* w0p, int act, float alpha, const float* w1,
                      void* out, int out_is_u8, int batch, int height, int width, int out_height, int out_width, int cin,
-                     int head_filters, int cout, int denormalize, float v_min, float v_max, void* stream);
+                     int head_filters, int cout, int denormalize, float v_min, float v_max, int* status, void* stream);
+/* status (both heads above; may be NULL): int32 on the device, |= BF_STATUS_F16_RANGE when the value in front of the tanh is
+ * not finite -- an activation left the f16 range inside a split-f16 operator upstream; clear it with bf_op_fill32. */
+int bf_op_fill32(void* p, int value, int64_t n, void* stream);
+/* Conv2DTranspose k x k, stride s, padding "same", no bias (upsample_type "conv2d_transpose": bfcnn/upsampling.py:37-48,
+ * utilities.py:200-202): in [B,H,W,cin] -> out [B,H*s,W*s,cout]; w [k,k,cout,cin] (keras kernel layout); act as
+ * bf_op_pointwise. */
+int bf_op_conv2d_transpose(const float* in, const float* w, float* out, int batch, int height, int width, int cin, int cout,
+                           int k, int stride, int act, float alpha, void* stream);
 /* mult[c] = tanh(relu(1 + w[c])) (ChannelLearnableMultiplier, custom_layers.py:304-306). */
 int bf_op_channel_multiplier(const float* w, float* mult, int n, void* stream);
+
+/* ---- data-parallel exchange (the reference is single-device, bfcnn/train_loop.py:259-321) -----------------
+ * ONE sum-all-reduce of the flat fp32 gradient buffer over RCCL per training step; every rank then runs the identical
+ * bf_adam_step with grad_scale = 1 / world.  RCCL is bound at run time: BF_EUNSUPPORTED when librccl is not installed.
+ *   rank 0: bf_comm_unique_id(id) -> id to every rank over any host channel -> each rank, with ITS GPU current:
+ *   bf_comm_init_rank(&comm, world, rank, id) -> per step bf_allreduce_grads(h, grads, n, comm, stream) -> bf_comm_destroy.
+ * `comm` is an ncclComm_t; one the host already owns (e.g. from its own ncclCommInitRank) is accepted as well. */
+int bf_comm_unique_id(char id_out[128]);
+int bf_comm_init_rank(void** comm_out, int world, int rank, const char id[128]);
+int bf_comm_destroy(void* comm);
+int bf_allreduce_grads(bf_handle h, float* grads, int64_t n, void* comm, void* stream);
+const char* bf_comm_last_error(void);
+
+/* y += a * x over n floats (overwrite != 0: y = x): gradient accumulation over micro-batches (bfcnn/train_loop.py:296-310). */
+int bf_op_axpy(float* y, const float* x, float a, int overwrite, int64_t n, void* stream);
 
 /* ---- options and diagnostics (not part of the drop-in surface; used by tests/) ------------- */
 

@@ -55,6 +55,22 @@ def act(x, name: str):
     return O.activation_fwd(x, name)
 
 
+def conv2d_transpose_same(x: np.ndarray, w: np.ndarray, stride: int) -> np.ndarray:
+    """keras Conv2DTranspose(kernel_size k, strides s, padding="same", use_bias=False) (upsample_type "conv2d_transpose",
+    bfcnn/upsampling.py:37-48 -> utilities.py:200-202); x [B,H,W,cin], w [k,k,cout,cin] (keras kernel layout), out
+    [B,H*s,W*s,cout].  The transpose of the stride-s SAME convolution from [H*s,W*s] to [H,W]: every input pixel scatters
+    its k x k patch to out[iy*s + i - pb, ix*s + j - pb], pb = max(k - s, 0) // 2 (that convolution's leading pad)."""
+    B, H, W, cin = x.shape
+    k, s = w.shape[0], int(stride)
+    cout = w.shape[2]
+    pb = max(k - s, 0) // 2
+    full = np.zeros((B, (H - 1) * s + k + s, (W - 1) * s + k + s, cout), dtype=x.dtype)
+    for i in range(k):
+        for j in range(k):
+            full[:, i:i + (H - 1) * s + 1:s, j:j + (W - 1) * s + 1:s, :] += np.einsum("bhwc,oc->bhwo", x, w[i, j])
+    return full[:, pb:pb + H * s, pb:pb + W * s, :]
+
+
 def depthwise_same(x: np.ndarray, w: np.ndarray) -> np.ndarray:
     """keras DepthwiseConv2D(depth_multiplier=1, padding="same", use_bias=False); w [kh,kw,C,1]
     (custom_layers.py:936; zero padding, cross-correlation)."""

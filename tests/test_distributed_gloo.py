@@ -71,3 +71,86 @@ def test_shard_batch_partitions_the_batch():
 def test_allreduce_is_a_noop_without_a_process_group():
     g = torch.ones(5)
     assert allreduce_gradients(g) is None and torch.all(g == 1)
+
+
+# ---- DataParallelTrainer itself with world > 1 ---------------------------------------------------------------------
+class _OracleModel:
+    """the surface DataParallelTrainer touches (params / state / mark_dirty / device), weights on the CPU"""
+    def __init__(self, params, state):
+        self.params, self.state = torch.from_numpy(params.copy()), torch.from_numpy(state.copy())
+        self.device, self.n_params = torch.device("cpu"), params.size
+        self.dirty = 0
+
+    def mark_dirty(self):
+        self.dirty += 1
+
+
+def _trainer_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from blind_image_denoising_amd.train_loop import DataParallelTrainer, TrainFunctions
+        cfg = O.canonical_config(no_layers=1)
+        spec, ls = O.ResnetSpec.from_config(cfg["model"]), O.LossSpec.from_config(cfg["loss"])
+        params, state = O.init_params(spec, seed=40 + rank)                  # replicas start DIFFERENT: broadcast must fix it
+        model = _OracleModel(params.astype(np.float64), state.astype(np.float64))
+        trainer = DataParallelTrainer.__new__(DataParallelTrainer)
+        trainer.model, trainer.optimizer, trainer.group, trainer.world_size, trainer.comm = model, None, None, world, None
+        log = []
+
+        def train_step_single_gpu(gt, x, dw, pct, tv):                       # per-rank compute: the fp64 oracle
+            total, ml, dl, pred, grads, new_state = O.train_step_single_gpu(spec, ls, model.params.numpy(), model.state.numpy(),
+                                                                            gt.numpy(), x.numpy())
+            model.state = torch.from_numpy(new_state)
+            log.append("compute")
+            return torch.tensor(total), ml, [dl], torch.from_numpy(pred), torch.from_numpy(grads.copy())
+
+        slots = {"m": np.zeros(params.size), "v": np.zeros(params.size), "it": 0}
+
+        def apply_grads(opt, grads, tv=None, grad_scale=1.0):
+            log.append("apply")
+            p1, slots["m"], slots["v"] = O.adam_step(model.params.numpy(), grads.numpy() * grad_scale, slots["m"], slots["v"],
+                                                     slots["it"], 1e-3, global_clipnorm=1.0)
+            slots["it"] += 1
+            model.params = torch.from_numpy(p1)
+
+        trainer.fns = TrainFunctions(None, None, train_step_single_gpu, apply_grads)
+        trainer.broadcast_parameters()
+        assert model.dirty == 1
+        clean, noisy = O.synthetic_batch(4, 16, 16, seed=5)
+        gt = shard_batch(torch.from_numpy(clean.astype(np.float64)), rank, world)
+        x = shard_batch(torch.from_numpy(noisy.astype(np.float64)), rank, world)
+        for _ in range(2):
+            out = trainer.step(gt, x, overlap=lambda: log.append("overlap") or "next batch")
+            assert out[4] == "next batch"                                     # the hook's result comes back
+        assert log == ["compute", "overlap", "apply"] * 2                     # hook between the collective and the update
+        np.save(os.path.join(out_dir, f"trainer_rank{rank}.npy"), model.params.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_data_parallel_trainer_world_two(tmp_path):
+    """DataParallelTrainer.broadcast_parameters / step with two ranks: rank 0's weights win, the all-reduce sits between
+    the local step and the update, the overlap hook runs in between, grad_scale is 1 / world, replicas stay identical and
+    equal the one-process emulation of the same two shards."""
+    world = 2
+    mp.spawn(_trainer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    p = [np.load(tmp_path / f"trainer_rank{i}.npy") for i in range(world)]
+    assert np.array_equal(p[0], p[1])
+    cfg = O.canonical_config(no_layers=1)
+    spec, ls = O.ResnetSpec.from_config(cfg["model"]), O.LossSpec.from_config(cfg["loss"])
+    params, state = O.init_params(spec, seed=40)
+    params, states = params.astype(np.float64), [state.astype(np.float64)] * 2
+    clean, noisy = O.synthetic_batch(4, 16, 16, seed=5)
+    m, v = np.zeros(params.size), np.zeros(params.size)
+    for it in range(2):
+        g = 0
+        for r in range(2):
+            sl = slice(2 * r, 2 * r + 2)
+            _, _, _, _, gr, states[r] = O.train_step_single_gpu(spec, ls, params, states[r], clean[sl].astype(np.float64),
+                                                                noisy[sl].astype(np.float64))
+            g = g + gr
+        params, m, v = O.adam_step(params, g * 0.5, m, v, it, 1e-3, global_clipnorm=1.0)
+    assert np.abs(p[0] - params).max() <= 1e-12

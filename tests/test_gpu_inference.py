@@ -223,3 +223,24 @@ def test_errors_surface_as_python_exceptions():
     x = torch.zeros((1, 8, 8, 3), dtype=torch.float32, device="cuda")
     rc = N.lib().bf_forward_f32(m._h, N.ptr(m.packed()), N.ptr(x), N.ptr(x), 1, 8, 8, N.ptr(ws), 16, None)
     assert rc == N.BF_EWORKSPACE and "workspace too small" in N.last_error(m._h)
+
+
+@pytest.mark.gpu
+def test_model_on_a_device_that_is_not_the_current_one():
+    """a model built with device='cuda:1' while cuda:0 is current must launch on GPU 1 (HIP launches go to the
+    current device of the calling thread; _native._device_guard selects the device of the stream argument)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    import blind_image_denoising_amd as bf
+    torch.cuda.set_device(0)
+    cfg = O.canonical_config(no_layers=2)
+    spec = O.ResnetSpec.from_config(cfg["model"])
+    params, state = O.init_params(spec, seed=3, nontrivial_bn=True)
+    model = bf.model_builder(cfg["model"], device="cuda:1").hydra
+    model.set_weights(params, state)
+    _, noisy = O.synthetic_batch(2, 32, 32, seed=5)
+    out = bf.DenoiserModule(model)(torch.from_numpy(noisy).to("cuda:1"))
+    assert out.device.index == 1 and torch.cuda.current_device() == 0
+    ref = O.denoiser_module_call(spec, params, state, noisy)
+    assert np.abs(out.cpu().numpy().astype(np.int32) - ref.astype(np.int32)).max() <= 1

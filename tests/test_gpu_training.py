@@ -230,3 +230,146 @@ def test_train_loop_runs_and_saves(tmp_path):
     assert len(hist) == 2 and all(np.isfinite(hist))
     mod = bf.load_model(str(tmp_path / "final"))
     assert mod(noisy).shape == noisy.shape
+
+
+# ---- BASELINE configs[3]: resnet 1x18 training step, 32 images of 256x256 per GPU ------------------------------------
+
+@pytest.mark.parametrize("train_arith", [1, 0], ids=["f16x3", "f32"])
+def test_config4_network_on_a_reduced_crop_matches_oracle(train_arith):
+    """the 18-block network of configs[3] itself (not a 1-3 block stand-in) on a crop the fp64 oracle finishes in seconds
+    (2 x 48 x 48): loss, every gradient tensor of all 18 blocks, BN moving statistics."""
+    cfg, spec, ls, params, state, m, fns = _setup(18)
+    m.set_option("train_arith", train_arith)
+    clean, noisy = O.synthetic_batch(2, 48, 48, seed=21)
+    gt, x = clean.astype(np.float32), noisy.astype(np.float32)
+    total, ml, dl, pred, grads = fns.train_step_single_gpu(torch.from_numpy(gt), torch.from_numpy(x), (1.0,), 0.0, None)
+    r_total, r_ml, r_dl, r_pred, r_grads, r_state = O.train_step_single_gpu(
+        spec, ls, params, state, gt.astype(np.float64), x.astype(np.float64))
+    assert abs(total.item() - r_total) <= 1e-5 * abs(r_total)
+    assert abs(dl[0]["mae_loss"].item() - r_dl[0]["mae_loss"]) <= 1e-5 * abs(r_dl[0]["mae_loss"])
+    # 37 layers deep: the bar of the shallow tests (2e-4 of a tensor's largest gradient) with the depth's headroom
+    _cmp_grads(spec, grads.cpu().numpy().astype(np.float64), r_grads, rel=6e-4)
+    assert np.abs(m.state.cpu().numpy() - r_state).max() < 1e-5
+
+
+def test_config4_full_shape_properties():
+    """configs[3] at its real per-GPU shape (1x18, 32 x 256 x 256): properties that need no oracle at this size.
+    (i) bitwise reproducible; (ii) finite; (iii) a batch that repeats 2 images 16 times has the batch statistics, the
+    loss and the gradients of those 2 images alone (mean losses, BatchNorm over N,H,W) -- the B = 2 run of the same
+    kernels is compared, itself pinned by the oracle tests above; (iv) the exact-fp32 arithmetic agrees with the
+    split-f16 one at this depth and size; (v) one Adam step moves every tensor and keeps it finite."""
+    cfg, spec, ls, params, state, m, fns = _setup(18)
+    clean2, noisy2 = O.synthetic_batch(2, 256, 256, seed=31)
+    gt2, x2 = torch.from_numpy(clean2.astype(np.float32)), torch.from_numpy(noisy2.astype(np.float32))
+    gt32, x32 = gt2.repeat(16, 1, 1, 1), x2.repeat(16, 1, 1, 1)
+
+    def run(gt, x, arith=1):
+        m.set_weights(params, state)
+        m.set_option("train_arith", arith)
+        total, ml, dl, pred, grads = fns.train_step_single_gpu(gt, x, (1.0,), 0.0, None)
+        return float(total.item()), grads.cpu().numpy().copy(), m.state.cpu().numpy().copy(), pred
+
+    t_a, g_a, s_a, pred = run(gt32, x32)
+    t_b, g_b, s_b, _ = run(gt32, x32)
+    assert t_a == t_b and np.array_equal(g_a, g_b) and np.array_equal(s_a, s_b)                 # (i)
+    assert np.isfinite(g_a).all() and np.isfinite(s_a).all() and tuple(pred.shape) == (32, 256, 256, 3)   # (ii)
+    t_2, g_2, s_2, _ = run(gt2, x2)                                                               # (iii)
+    assert abs(t_a - t_2) <= 1e-5 * abs(t_2)
+    _cmp_grads(spec, g_a.astype(np.float64), g_2.astype(np.float64), rel=2e-4)
+    # moving variance: Bessel factor n / (n - 1) differs between n = 2*65536 and n = 32*65536 by 7e-6 relative
+    assert np.abs(s_a - s_2).max() < 1e-4
+    t_x, g_x, s_x, _ = run(gt32, x32, arith=0)                                                    # (iv)
+    assert abs(t_a - t_x) <= 1e-5 * abs(t_x)
+    _cmp_grads(spec, g_a.astype(np.float64), g_x.astype(np.float64), rel=6e-4)
+    m.set_weights(params, state)                                                                   # (v)
+    m.set_option("train_arith", 1)
+    opt, _ = bf.optimizer_builder(cfg["train"]["optimizer"])
+    total, ml, dl, pred, grads = fns.train_step_single_gpu(gt32, x32, (1.0,), 0.0, None)
+    fns.apply_grads(opt, grads, None)
+    after = m.params.cpu().numpy()
+    assert np.isfinite(after).all()
+    for name, (o, s) in spec.offsets().items():
+        n = int(np.prod(s))
+        assert np.abs(after[o:o + n] - params[o:o + n]).max() > 0, f"{name} did not move"
+
+
+def test_native_collective_single_rank():
+    """bf_comm_* / bf_allreduce_grads (RCCL bound inside the library) with a world of one: the rendezvous, the
+    communicator and the in-place all-reduce run on this GPU and leave the buffer as it was."""
+    import ctypes as C
+    L = N.lib()
+    uid = C.create_string_buffer(128)
+    N.check(L.bf_comm_unique_id(uid), None, "bf_comm_unique_id")
+    comm = C.c_void_p()
+    rc = L.bf_comm_init_rank(C.byref(comm), 1, 0, uid.raw)
+    assert rc == N.BF_OK, L.bf_comm_last_error()
+    g = torch.arange(84272, dtype=torch.float32, device="cuda") * 0.25
+    ref = g.clone()
+    rc = L.bf_allreduce_grads(None, N.ptr(g), g.numel(), comm, N.stream_ptr(g))
+    assert rc == N.BF_OK, L.bf_comm_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(g, ref)
+    assert L.bf_comm_destroy(comm) == N.BF_OK
+    assert L.bf_allreduce_grads(None, N.ptr(g), g.numel(), None, N.stream_ptr(g)) == N.BF_EINVAL
+
+
+def _dp_rank(rank, world, port, native, out_dir):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    cfg = O.canonical_config(no_layers=2)
+    spec = O.ResnetSpec.from_config(cfg["model"])
+    params, state = O.init_params(spec, seed=3 + rank, nontrivial_bn=True)      # different on purpose: broadcast must fix it
+    model = bf.model_builder(cfg["model"], device=f"cuda:{rank}").hydra
+    model.set_weights(params, state)
+    opt, _ = bf.optimizer_builder(cfg["train"]["optimizer"])
+    trainer = bf.DataParallelTrainer(model, bf.loss_function_builder(cfg["loss"]), opt, native_collective=native)
+    trainer.broadcast_parameters()
+    clean, noisy = O.synthetic_batch(4, 32, 32, seed=9)
+    gt = bf.shard_batch(torch.from_numpy(clean.astype(np.float32)), rank, world).cuda()
+    x = bf.shard_batch(torch.from_numpy(noisy.astype(np.float32)), rank, world).cuda()
+    hook_ran = []
+    for _ in range(2):
+        trainer.step(gt, x, overlap=lambda: hook_ran.append(1))
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, f"params_{int(native)}_{rank}.npy"), model.params.cpu().numpy())
+    assert len(hook_ran) == 2
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("native", [False, True], ids=["torch_distributed", "c_abi_rccl"])
+def test_data_parallel_trainer_two_gpus(native, tmp_path):
+    """DataParallelTrainer with world 2 on two GPUs over RCCL: replicas identical after two steps and equal to the
+    one-process emulation (both shards on one GPU, gradients summed, grad_scale 1/2)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_dp_rank, args=(2, port, native, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = (np.load(tmp_path / f"params_{int(native)}_{r}.npy") for r in (0, 1))
+    assert np.array_equal(p0, p1)
+    cfg = O.canonical_config(no_layers=2)
+    spec = O.ResnetSpec.from_config(cfg["model"])
+    params, state = O.init_params(spec, seed=3, nontrivial_bn=True)
+    clean, noisy = O.synthetic_batch(4, 32, 32, seed=9)
+    reps = []
+    for r in range(2):
+        mdl = bf.model_builder(cfg["model"], device="cuda").hydra
+        mdl.set_weights(params, state)
+        reps.append((mdl, bf.build_train_functions(mdl, bf.loss_function_builder(cfg["loss"])), bf.optimizer_builder(cfg["train"]["optimizer"])[0]))
+    for _ in range(2):
+        gs = []
+        for r, (mdl, fns, opt) in enumerate(reps):
+            gt = torch.from_numpy(clean[2 * r:2 * r + 2].astype(np.float32))
+            x = torch.from_numpy(noisy[2 * r:2 * r + 2].astype(np.float32))
+            gs.append(fns.train_step_single_gpu(gt, x)[4].clone())
+        summed = gs[0] + gs[1]
+        for mdl, fns, opt in reps:
+            fns.apply_grads(opt, summed.clone(), None, grad_scale=0.5)
+    assert np.abs(reps[0][0].params.cpu().numpy() - p0).max() <= 1e-7

@@ -455,3 +455,19 @@ def test_save_and_load_model_roundtrip(tmp_path):
     mod = bf.load_model(str(tmp_path / "unet"))
     _, noisy = O.synthetic_batch(1, 32, 32, seed=4)
     assert np.array_equal(mod(noisy), bf.DenoiserModule(m)(noisy))
+
+
+@pytest.mark.parametrize("k,s,shape", [(2, 2, (2, 9, 7, 5, 8)), (3, 2, (1, 16, 16, 32, 32)), (4, 2, (2, 5, 6, 3, 4)),
+                                       (5, 2, (1, 8, 12, 16, 8)), (3, 1, (1, 7, 9, 4, 4)), (3, 3, (1, 6, 5, 2, 3))])
+def test_conv2d_transpose_matches_oracle(k, s, shape):
+    """upsample_type "conv2d_transpose" (bfcnn/upsampling.py:37-48): Conv2DTranspose padding same."""
+    from blind_image_denoising_amd import unet_laplacian as UL
+    B, H, W, cin, cout = shape
+    rng = np.random.default_rng(k + 7 * s)
+    x = rng.standard_normal((B, H, W, cin)).astype(np.float32)
+    w = (rng.standard_normal((k, k, cout, cin)) * 0.2).astype(np.float32)
+    for act in ("linear", "leaky_relu_01"):
+        got = UL.conv2d_transpose(torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda(), s, act).cpu().numpy()
+        ref = U.act(U.conv2d_transpose_same(x.astype(np.float64), w.astype(np.float64), s), act)
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())

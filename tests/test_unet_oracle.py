@@ -150,3 +150,26 @@ def test_product_has_no_cpu_execution_path():
         m(np.zeros((1, 32, 32, 3), np.float32))
     with pytest.raises(NotImplementedError):
         m(np.zeros((1, 32, 32, 3), np.float32), training=True)
+
+
+@pytest.mark.parametrize("k,s", [(2, 2), (3, 2), (4, 2), (5, 2), (3, 1), (3, 3)])
+def test_conv2d_transpose_same_against_torch(k, s):
+    """Conv2DTranspose padding="same": torch's full transposed convolution cropped at the leading pad of the forward
+    SAME convolution (and, independently, the adjoint identity <conv(y), x> == <y, conv_transpose(x)>)."""
+    import torch
+    rng = np.random.default_rng(k * 10 + s)
+    x = rng.standard_normal((2, 5, 6, 3))
+    w = rng.standard_normal((k, k, 4, 3))                                # [k,k,cout,cin]
+    got = U.conv2d_transpose_same(x, w, s)
+    assert got.shape == (2, 5 * s, 6 * s, 4)
+    full = torch.nn.functional.conv_transpose2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(w).permute(3, 2, 0, 1),
+                                                stride=s).permute(0, 2, 3, 1).numpy()
+    pb = max(k - s, 0) // 2
+    want = np.zeros_like(got)
+    crop = full[:, pb:pb + 5 * s, pb:pb + 6 * s, :]
+    want[:, :crop.shape[1], :crop.shape[2], :] = crop
+    assert np.abs(got - want).max() < 1e-12
+    # adjoint of the stride-s SAME convolution with kernel [k,k,cout(big),cin(small)] read as HWIO of the forward conv
+    y = rng.standard_normal(got.shape)
+    fwd = O.conv2d_same(y, w, stride=s)                                    # [k,k,4,3] as HWIO: 4 -> 3 channels, big -> small
+    assert abs((fwd * x).sum() - (y * got).sum()) < 1e-9 * max(1.0, abs((y * got).sum()))

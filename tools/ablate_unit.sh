@@ -16,7 +16,7 @@ for v in "$@"; do
     (
         /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed \
             "-D${macro}=${v}" -c "$src/$unit.hip" -o "$out/${unit}_${macro}${v}.o"
-        /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "${others[@]}" "$out/${unit}_${macro}${v}.o" \
+        /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "${others[@]}" "$out/${unit}_${macro}${v}.o" -ldl \
             -o "$out/libbfcnn_hip_${macro}${v}.so"
     ) &
     pids+=($!)
