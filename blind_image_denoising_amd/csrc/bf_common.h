@@ -172,6 +172,8 @@ struct HeadTrainArgs {
     const float* dextra;                     // [B,H,W,cout] added to dL/dpred (RMSE / SSIM terms, loss_terms.hip) or NULL
     int B, H, W, cout, denormalize;
     float v_min, v_max, hinge, cutoff, dscale; // dscale = mae_multiplier*depth_weight/numel
+    float dfeat_scale;                         // power of two on the dfeat output only (gradient scaling of the split-f16
+                                               // backward, engine.hip bf_train_step); the head's own gradients (M) are not scaled
 };
 hipError_t bf_launch_head_train(const HeadTrainArgs& a, int grid, hipStream_t s);
 // RMSE / SSIM loss terms (loss_terms.hip): additive dL/dpred from the prediction and the head's per-image sums

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadTrainArgs a, int bl
                 d = fmaf(dh1[o], whs[c * 4 + o], d);
                 M[c * 4 + o] = fmaf(f[c], dh1[o], M[c * 4 + o]);
             }
-            df[c] = d;
+            df[c] = d * a.dfeat_scale;
         }
         float4* dp = reinterpret_cast<float4*>(a.dfeat + pix * 16);
 #pragma unroll

@@ -697,6 +697,11 @@ __global__ void premultiply_head_kernel(const float* __restrict__ w0, const floa
     }
 }
 
+__global__ void scale_range_kernel(float* __restrict__ p, int64_t n, float f)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] *= f;
+}
+
 __global__ void fill_identity_affine_kernel(float* scale_shift)
 {
     if (threadIdx.x < 16) { scale_shift[threadIdx.x] = 1.f; scale_shift[16 + threadIdx.x] = 0.f; }
@@ -790,6 +795,23 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     ta.B = B; ta.H = H; ta.W = W; ta.cout = d.out_channels; ta.denormalize = d.denormalize;
     ta.v_min = d.v_min; ta.v_max = d.v_max; ta.hinge = loss->hinge; ta.cutoff = loss->cutoff;
     ta.dscale = loss->mae_multiplier > 0.f ? (float)((double)loss->mae_multiplier * loss->depth_weight / numel) : 0.f;
+    // Gradient scaling of the split-f16 backward.  dL/dprediction is O(1 / numel): 5e-8 at 32 x 256 x 256 x 3.  The data-
+    // and weight-gradient kernels split every dy into two f16 numbers while they stage it; below 2^-14 the split keeps an
+    // ABSOLUTE floor of 2^-25, so unscaled gradients lost most of their bits -- the larger the batch the more (bf_train_step
+    // against itself on a batch that repeats two images: weight gradients 0.3 % off at 32 x 64 x 64, 12 % at 32 x 256 x 256;
+    // tools/exp/train_batch_rep.py).  The head hands the blocks dfeat * S, S the power of two next to numel / (multiplier *
+    // depth_weight); every backward operator is linear in dy, and the block / base gradients are multiplied by 1 / S (exact)
+    // before the regularisers are added.  The exact-fp32 arithmetic runs with S = 1 as before.
+    float grad_unscale = 1.0f;
+    ta.dfeat_scale = 1.0f;
+    if (h3t) {
+        const double per = (loss->mae_multiplier > 0.f ? (double)loss->mae_multiplier : 1.0) * (loss->depth_weight > 0.f ? loss->depth_weight : 1.0) / numel;
+        int ex = 0;
+        (void)frexp(1.0 / per, &ex);
+        ex = ex - 1 < 0 ? 0 : (ex - 1 > 40 ? 40 : ex - 1);
+        ta.dfeat_scale = ldexpf(1.0f, ex);
+        grad_unscale = ldexpf(1.0f, -ex);
+    }
     const int hgrid = bf_head_train_grid(B, H, W);
     float* scal = nullptr;
     if (extra_terms) {
@@ -854,6 +876,11 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     }
     BF_HIP(bf_launch_base_wgrad(noisy, dA, partial, grads + h->p_base, B, H, W, d.in_channels, d.kernel_size, d.v_min, d.v_max, s),
            "base_wgrad");
+    if (grad_unscale != 1.0f) {
+        // base + block gradients (everything in front of the head's tensors) back to the loss's own scale
+        hipLaunchKernelGGL(scale_range_kernel, dim3(64), dim3(256), 0, s, grads, h->p_head0, grad_unscale);
+        BF_HIP(hipGetLastError(), "grad_unscale");
+    }
     hipLaunchKernelGGL(regularizer_kernel, dim3(1), dim3(1024), 0, s, params, grads, h->n_params, h->n_base, h->p_blocks,
                        h->p_block_stride, h->p_head0, d.reg_base, d.reg_block, d.reg_head, loss->regularization, losses);
     BF_HIP(hipGetLastError(), "regularizer");

@@ -15,13 +15,17 @@ pytestmark = pytest.mark.gpu
 G = pathlib.Path(__file__).resolve().parent / "golden"
 
 
-def _setup(no_layers, seed=42, loss_over=None):
+def _setup(no_layers, seed=42, loss_over=None, head_scale=1.0):
     cfg = O.canonical_config(no_layers=no_layers)
     if loss_over:
         cfg["loss"].update(loss_over)
     spec = O.ResnetSpec.from_config(cfg["model"])
     ls = O.LossSpec.from_config(cfg["loss"])
     params, state = O.init_params(spec, seed=seed, nontrivial_bn=True)
+    if head_scale != 1.0:
+        for name, (o, s) in spec.offsets().items():
+            if name.startswith("head"):
+                params[o:o + int(np.prod(s))] *= head_scale
     m = bf.model_builder(cfg["model"], device="cuda").hydra
     m.set_weights(params, state)
     fns = bf.build_train_functions(m, bf.loss_function_builder(cfg["loss"]))
@@ -237,8 +241,13 @@ def test_train_loop_runs_and_saves(tmp_path):
 @pytest.mark.parametrize("train_arith", [1, 0], ids=["f16x3", "f32"])
 def test_config4_network_on_a_reduced_crop_matches_oracle(train_arith):
     """the 18-block network of configs[3] itself (not a 1-3 block stand-in) on a crop the fp64 oracle finishes in seconds
-    (2 x 48 x 48): loss, every gradient tensor of all 18 blocks, BN moving statistics."""
-    cfg, spec, ls, params, state, m, fns = _setup(18)
+    (2 x 48 x 48): loss, every gradient tensor of all 18 blocks, BN moving statistics.
+
+    The head kernels are scaled by 0.1: a freshly initialised 18-block network drives tanh(2x) * 0.51 past the +-0.5 clip of
+    the denormaliser on 75 % of the pixels, the clip's derivative is discontinuous there, and a gradient comparison would
+    then measure on which side of a discontinuity fp32 rounding lands (fp64 oracle alone: weights perturbed by 1e-6
+    relative move the gradients by up to 3e-2 with the clip active, 3e-4 without; tools/exp/train_depth_err.py)."""
+    cfg, spec, ls, params, state, m, fns = _setup(18, head_scale=0.1)
     m.set_option("train_arith", train_arith)
     clean, noisy = O.synthetic_batch(2, 48, 48, seed=21)
     gt, x = clean.astype(np.float32), noisy.astype(np.float32)
@@ -257,8 +266,9 @@ def test_config4_full_shape_properties():
     (i) bitwise reproducible; (ii) finite; (iii) a batch that repeats 2 images 16 times has the batch statistics, the
     loss and the gradients of those 2 images alone (mean losses, BatchNorm over N,H,W) -- the B = 2 run of the same
     kernels is compared, itself pinned by the oracle tests above; (iv) the exact-fp32 arithmetic agrees with the
-    split-f16 one at this depth and size; (v) one Adam step moves every tensor and keeps it finite."""
-    cfg, spec, ls, params, state, m, fns = _setup(18)
+    split-f16 one at this depth and size; (v) one Adam step moves every tensor and keeps it finite.
+    (Head kernels scaled by 0.1 as in the crop test: no pixel sits on the denormaliser's clip.)"""
+    cfg, spec, ls, params, state, m, fns = _setup(18, head_scale=0.1)
     clean2, noisy2 = O.synthetic_batch(2, 256, 256, seed=31)
     gt2, x2 = torch.from_numpy(clean2.astype(np.float32)), torch.from_numpy(noisy2.astype(np.float32))
     gt32, x32 = gt2.repeat(16, 1, 1, 1), x2.repeat(16, 1, 1, 1)
