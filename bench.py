@@ -48,7 +48,7 @@ def gflop_per_image(no_layers, h, w, k=3, cin=3, hf=32, cout=3):
     return per_px * h * w / 1e9
 
 
-def cpu_baseline(spec, params, state, noisy_u8, budget_s=12.0):
+def cpu_baseline_port(spec, params, state, noisy_u8, budget_s=10.0):
     """the oracle's C port on the host cores: bounded sample, ~budget_s of CPU work."""
     from oracle import port
     h = port.lib(rebuild=True)                       # -march=native on THIS box
@@ -63,6 +63,65 @@ def cpu_baseline(spec, params, state, noisy_u8, budget_s=12.0):
     return {"value": n / dt, "unit": "images/s", "cores": int(h.bfcnn_port_max_threads()), "kind": "port",
             "sample": f"{n} images of the same 1x18 256x256x3 uint8 workload, oracle/bfcnn_port.c fp32 OpenMP "
                       f"(CPU restatement, not TensorFlow)"}
+
+
+def cpu_baseline_torch(spec, params, state, noisy_u8, budget_s=10.0, nthreads=None):
+    """the same graph on PyTorch-CPU (oneDNN convolutions, channels_last, all host cores; SURVEY 8d leg ii): the
+    restatement's tensors loaded into torch.nn.functional calls -- a second CPU implementation, not TensorFlow."""
+    import torch
+    import torch.nn.functional as F
+    if nthreads is None:            # the cores this process may run on (a GPU box hands out a share of its 256)
+        nthreads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(int(nthreads))
+    off = spec.offsets()
+    P = lambda name: torch.from_numpy(np.asarray(params[off[name][0]:off[name][0] + int(np.prod(off[name][1]))], np.float32).reshape(off[name][1]))
+    conv_w = lambda name: P(name).permute(3, 2, 0, 1).contiguous(memory_format=torch.channels_last)       # HWIO -> OIHW
+    base = conv_w("base/kernel")
+    blocks = []
+    for i in range(spec.no_layers):
+        g = P(f"block{i}/bn1/gamma")
+        mean = torch.from_numpy(np.asarray(state[i * 32:i * 32 + 16], np.float32))
+        var = torch.from_numpy(np.asarray(state[i * 32 + 16:i * 32 + 32], np.float32))
+        sc = g / torch.sqrt(var + spec.bn_eps)
+        blocks.append((conv_w(f"block{i}/conv0/kernel"), conv_w(f"block{i}/conv1/kernel"), sc.view(1, -1, 1, 1), (-sc * mean).view(1, -1, 1, 1)))
+    h0, h1 = conv_w("head/conv0/kernel"), conv_w("head/conv1/kernel")
+
+    def forward(u8):
+        x = torch.from_numpy(u8).permute(0, 3, 1, 2).float().contiguous(memory_format=torch.channels_last)
+        x = torch.clamp(x, spec.v_min, spec.v_max) / (spec.v_max - spec.v_min) - 0.5
+        x = F.conv2d(x, base, padding=base.shape[-1] // 2)
+        for w0, w1, sc, sh in blocks:
+            t = F.relu(F.conv2d(x, w0, padding=1))
+            x = x + F.conv2d(t, w1, padding=1) * sc + sh
+        y = torch.tanh(2.0 * F.conv2d(F.conv2d(x, h0), h1)) * 0.51
+        y = (torch.clamp(y, -0.5, 0.5) + 0.5) * (spec.v_max - spec.v_min) + spec.v_min
+        return torch.round(y).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous().numpy()
+
+    with torch.no_grad():
+        forward(noisy_u8[:1])
+        t0 = time.perf_counter()
+        out1 = forward(noisy_u8[:1])
+        one = time.perf_counter() - t0
+        n = int(max(2, min(noisy_u8.shape[0], 16, budget_s / max(one, 1e-3))))
+        t0 = time.perf_counter()
+        forward(noisy_u8[:n])
+        dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "images/s", "cores": nthreads, "kind": "port",
+            "sample": f"{n} images of the same workload in one batch, torch-CPU {torch.__version__} conv2d (oneDNN, channels_last, "
+                      f"{nthreads} threads) with the restatement's tensors"}, out1
+
+
+def cpu_baseline(spec, params, state, noisy_u8):
+    """both CPU legs of SURVEY 8d; the faster one is the reported baseline, the other rides along."""
+    a = cpu_baseline_port(spec, params, state, noisy_u8)
+    try:
+        b, _ = cpu_baseline_torch(spec, params, state, noisy_u8, nthreads=a["cores"])      # same core count as the C port's OpenMP team
+    except Exception as e:                                # torch-CPU leg is a bonus: never fail the bench on it
+        b = {"value": 0.0, "unit": "images/s", "cores": 0, "kind": "port", "sample": f"torch-CPU leg failed: {e}"}
+    best, other = (a, b) if a["value"] >= b["value"] else (b, a)
+    best = dict(best)
+    best["other_leg"] = other
+    return best
 
 
 def pmc_traffic(layers, batch, size, fused, kernel=None):
@@ -322,13 +381,17 @@ def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the corruption of batch k+1 is issued between the launch of step k's gradient all-reduce and the point where the
+    # compute stream waits for it (DataParallelTrainer.step(overlap=...)): the one piece of a step that does not depend on
+    # the reduced gradients
     total = None
+    batch = prep(clean_dev)
     for _ in range(max(args.warmup, 1)):
-        total = trainer.step(*prep(clean_dev))[0]
+        total, _, _, _, batch = trainer.step(*batch, overlap=lambda: prep(clean_dev))
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        total = trainer.step(*prep(clean_dev))[0]
+        total, _, _, _, batch = trainer.step(*batch, overlap=lambda: prep(clean_dev))
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -339,16 +402,53 @@ def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
         # algorithmic FLOPs per image: fwd + dgrad + wgrad of every 3x3 16->16 conv, fwd + wgrad of the base conv, head fwd + bwd
         per_px = 3 * args.layers * FLOP_PER_PX_BLOCK + 2 * 2 * 9 * 3 * 16 + 3 * 2 * (16 * 32 + 32 * 3)
         value = B * world * args.steps / elapsed
-        print(json.dumps({
+        # dominant kernel (36 of the ~240 launches of a step, ~18 % of its time): the split-f16 weight gradient; reads x and
+        # dy once (2 * 64 B per pixel).  Timed live with events on the launch stream through the C ABI's single-kernel entry.
+        from blind_image_denoising_amd import _native as N
+        L = N.lib()
+        xw = torch.randn((B, S, S, 16), device="cuda")
+        dyw = torch.randn((B, S, S, 16), device="cuda") * 0.1
+        dw = torch.empty(2304, device="cuda")
+        part = torch.empty(int(L.bf_debug_wgrad_partial_floats(B, S, S)), device="cuda")
+        wg = lambda: N.check(L.bf_debug_wgrad3x3_h3(N.ptr(xw), N.ptr(dyw), N.ptr(part), N.ptr(dw), B, S, S, N.stream_ptr(xw)), None, "wgrad")
+        for _ in range(3):
+            wg()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        nl = 20
+        e0.record()
+        for _ in range(nl):
+            wg()
+        e1.record()
+        torch.cuda.synchronize()
+        launch_us = e0.elapsed_time(e1) * 1e3 / nl            # wgrad kernel + its 7 us partial reduction
+        wbytes = B * S * S * 16 * 4 * 2
+        gbs = wbytes / launch_us / 1e3
+        rec = {
             "metric": "training images/sec (256x256x3), resnet_1x18 data-parallel step", "value": value, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (convolutions: f16x2 split hi+lo, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": f"resnet_color_1x{args.layers}_bn_16x3x3 training step ("
                                    f"{'L1 hinge 3.5 + 0.5 RMSE + SSIM' if args.loss == 'shipped' else 'L1 hinge 0.5'}, Adam, global clipnorm 1), "
                                    f"batch={B}/GPU {S}x{S}x3 float32 corrupted on the device every step, one all-reduce of {model.n_params} fp32 gradients",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
             "last_total_loss": float(total.item()),
-            "end_to_end_tflops": value / world * per_px * S * S / 1e12}), flush=True)
+            "end_to_end_tflops": value / world * per_px * S * S / 1e12,
+            "roofline": {"bound": "hbm", "kernel": "wgrad3x3_h3_kernel (+ reduce_partials_kernel)", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": wbytes,
+                         "launch_us": launch_us, "launches_per_step": 2 * args.layers}}
+        if world == 1 and not args.no_cpu_baseline:
+            # the oracle's training step (fp64 NumPy restatement) on ONE image of the same shape
+            cfg1 = O.canonical_config(no_layers=args.layers)
+            ls = O.LossSpec.from_config(cfg["loss"])
+            c1, n1 = O.synthetic_batch(1, S, S, sigma=20.0, seed=99)
+            t0 = time.perf_counter()
+            O.train_step_single_gpu(spec, ls, params, state, c1.astype(np.float64), n1.astype(np.float64))
+            dt = time.perf_counter() - t0
+            rec["cpu_baseline"] = {"value": 1.0 / dt, "unit": "images/s", "cores": 1, "kind": "port",
+                                   "sample": f"one {S}x{S} image through oracle/bfcnn_oracle.py train_step_single_gpu (fp64 NumPy "
+                                             f"restatement of forward + loss + backward, BLAS threads as NumPy picks them; not TensorFlow)"}
+        print(json.dumps(rec), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -369,6 +469,44 @@ def self_launch(n):
     raise SystemExit(proc.returncode)
 
 
+def sub_record(model, module, noisy, noisy_host, spec, params, state, O, N, torch, arith, steps, warmup, S):
+    """one more timed loop of the default workload on `model` with another arithmetic / batch (rank 0, N = 1)."""
+    B = int(noisy.shape[0])
+    model.set_option("arith", arith)
+    model.set_option("timing", 1)
+    for _ in range(warmup):
+        out = module(noisy)
+    torch.cuda.synchronize()
+    model.set_option("timing", 1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = module(noisy)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms, ln = C.c_float(), C.c_int()
+    N.check(N.lib().bf_get_timing(model._h, C.byref(ms), C.byref(ln)), model._h)
+    launch_s = float(ms.value) / 1e3 / max(int(ln.value), 1)
+    ref = O.denoiser_module_call(spec, params, state, noisy_host[:1])
+    diff = np.abs(out[:1].cpu().numpy().astype(np.int32) - ref.astype(np.int32))
+    px = B * S * S
+    rec = {"value": B * steps / elapsed, "unit": "images/s", "batch_per_gpu": B, "steps": steps, "warmup": warmup,
+           "ms_per_step": elapsed / steps * 1e3, "parity": {"mae_vs_oracle_lsb": float(diff.mean()), "max_abs_lsb": int(diff.max())}}
+    if arith == 0:
+        tf = px * FLOP_PER_PX_BLOCK / launch_s / 1e12
+        rec.update({"dtype": "f32", "arithmetic": "exact fp32 MFMA",
+                    "roofline": {"bound": "mfma", "kernel": "fused_block_v4_kernel", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS, "launch_us": launch_s * 1e6, "traffic": None}})
+    else:
+        gbs = px * BYTES_PER_PX_BLOCK / launch_s / 1e9
+        rec.update({"dtype": "f16x2 split (hi+lo, fp32 accumulate)", "arithmetic": "split-f16 MFMA (f16x3), fp32 accumulate",
+                    "roofline": {"bound": "hbm", "kernel": "fused_block_h3v_kernel" if S <= 256 else "fused_block_h3r_kernel",
+                                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                 "launch_us": launch_s * 1e6, "traffic": None,
+                                 "mfma_algorithmic_tflops": px * FLOP_PER_PX_BLOCK / launch_s / 1e12}})
+    model.set_option("arith", 1)
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -378,6 +516,7 @@ def main():
     ap.add_argument("--layers", type=int, default=18)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sub-records", action="store_true", help="default mode: skip the fp32_exact / batch64 sub-records")
     ap.add_argument("--unfused", action="store_true", help="one kernel per convolution (A/B only)")
     ap.add_argument("--fused-tile", type=int, default=None, help="exact-fp32 fused-block tile geometry variant (A/B only)")
     ap.add_argument("--arith", type=int, default=1, help="1 = split-f16 fused blocks (default), 0 = exact-fp32 fused blocks")
@@ -534,6 +673,14 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(spec, params, state, noisy_host)
+        if world == 1 and not args.no_sub_records and h3 and args.h3_variant is None:
+            # the same workload on the other arithmetic / at the north star's batch, timed by this very run (fewer steps):
+            #   fp32_exact : --arith 0, exact fp32 on the f32 matrix cores (fused_block_v4_kernel), vs the 157.3 TF fp32 MFMA peak
+            #   batch64    : default arithmetic at batch 64 (BASELINE.json north_star: "1x18 resnet 3x3 conv stack at batch 64")
+            result["fp32_exact"] = sub_record(model, module, noisy, noisy_host, spec, params, state, O, N, torch, arith=0,
+                                              steps=max(args.steps // 4, 10), warmup=max(args.warmup // 4, 3), S=S)
+            result["batch64"] = sub_record(model, module, noisy[:64].contiguous(), noisy_host[:64], spec, params, state, O, N, torch,
+                                           arith=1, steps=max(args.steps // 2, 10), warmup=max(args.warmup // 2, 3), S=S)
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

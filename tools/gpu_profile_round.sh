@@ -1,0 +1,33 @@
+#!/bin/bash
+# One GPU-box session that produces the files of profiles/ for a round: for every bench mode the JSON line of a plain run
+# and the rocprofv3 --kernel-trace --stats summary of the SAME command; the kernel-stats CSV is picked by CONTENT (it must
+# name the mode's dominant kernel), never by pid or directory order.  Usage: bash tools/gpu_profile_round.sh r02 [modes...]
+set -uo pipefail
+tag="${1:-rXX}"; shift || true
+modes=("$@"); [ ${#modes[@]} -gt 0 ] || modes=(inference train unet unet56 pyramid)
+repo="$PWD"
+out="$repo/gpurun_out/profiles_$tag"
+mkdir -p "$out"
+export TMPDIR=/tmp
+declare -A ARGS=( [inference]="" [train]="--mode train" [unet]="--mode unet" [unet56]="--mode unet --unet-graph v5.6" [pyramid]="--mode pyramid" )
+declare -A KERNEL=( [inference]="fused_block_h3v_kernel" [train]="wgrad3x3_h3_kernel" [unet]="uh_enc32s_kernel" [unet56]="uh_enc32s_kernel" [pyramid]="avgpool" )
+rc_all=0
+for m in "${modes[@]}"; do
+    a="${ARGS[$m]}"
+    echo "== $m: bench"
+    timeout -k 10 400 python bench.py $a --steps 30 --warmup 5 > "$out/${tag}_${m}_bench.json" 2> "$out/${tag}_${m}_bench.err" || { echo "bench $m failed"; tail -n 5 "$out/${tag}_${m}_bench.err"; rc_all=1; continue; }
+    tail -c 600 "$out/${tag}_${m}_bench.json"; echo
+    echo "== $m: rocprofv3 --kernel-trace --stats"
+    rm -rf "$out/prof_$m"
+    ( cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_$m" -- \
+        python "$repo/bench.py" $a --steps 10 --warmup 3 --no-cpu-baseline --no-sub-records > "$out/${tag}_${m}_profiled_bench.json" 2> "$out/prof_$m.err" ) || { echo "profile $m failed"; tail -n 5 "$out/prof_$m.err"; rc_all=1; continue; }
+    picked=""
+    while IFS= read -r f; do
+        if grep -q "${KERNEL[$m]}" "$f"; then picked="$f"; break; fi
+    done < <(find "$out/prof_$m" -name "*kernel_stats.csv" | sort)
+    if [ -z "$picked" ]; then echo "no kernel_stats.csv names ${KERNEL[$m]}"; rc_all=1; continue; fi
+    cp "$picked" "$out/${tag}_${m}_kernel_stats.csv"
+    head -n 6 "$out/${tag}_${m}_kernel_stats.csv" | cut -c1-160
+    rm -rf "$out/prof_$m"
+done
+exit $rc_all
