@@ -677,8 +677,11 @@ def main():
             # the same workload on the other arithmetic / at the north star's batch, timed by this very run (fewer steps):
             #   fp32_exact : --arith 0, exact fp32 on the f32 matrix cores (fused_block_v4_kernel), vs the 157.3 TF fp32 MFMA peak
             #   batch64    : default arithmetic at batch 64 (BASELINE.json north_star: "1x18 resnet 3x3 conv stack at batch 64")
+            #   fp32_exact_batch64 : the exact-fp32 kernel at that batch (the north star's ">= 60 % MFMA roofline" reading)
             result["fp32_exact"] = sub_record(model, module, noisy, noisy_host, spec, params, state, O, N, torch, arith=0,
                                               steps=max(args.steps // 4, 10), warmup=max(args.warmup // 4, 3), S=S)
+            result["fp32_exact_batch64"] = sub_record(model, module, noisy[:64].contiguous(), noisy_host[:64], spec, params, state, O, N,
+                                                      torch, arith=0, steps=max(args.steps // 4, 10), warmup=max(args.warmup // 4, 3), S=S)
             result["batch64"] = sub_record(model, module, noisy[:64].contiguous(), noisy_host[:64], spec, params, state, O, N, torch,
                                            arith=1, steps=max(args.steps // 2, 10), warmup=max(args.warmup // 2, 3), S=S)
         print(json.dumps(result), flush=True)

@@ -120,7 +120,10 @@ hipError_t bf_launch_pack_h3(const float* params, const float* state, int64_t p_
 #define BF_TRAIN_PACK_STRIDE BF_H3_TRAIN_PACK_FLOATS           // per-convolution slot of the training pack area (>= BF_WPACK_FLOATS)
 hipError_t bf_launch_conv3x3_h3(const ConvArgs& a, int epi, hipStream_t s);
 hipError_t bf_launch_wgrad3x3_h3(const float* x, const float* dy, float* partial, float* dw, int B, int H, int W, hipStream_t s);
-hipError_t bf_launch_pack_h3_train(const float* params, int64_t p_blocks, int64_t p_stride, float* dst, int layers, hipStream_t s);
+// nconv convolutions per block (forward + data-gradient pack each); unit: floats from one convolution kernel of a block to the
+// next behind the first (2320 with BatchNorm gammas in between, else 2304)
+hipError_t bf_launch_pack_h3_train(const float* params, int64_t p_blocks, int64_t p_stride, float* dst, int layers, int nconv,
+                                   int unit, hipStream_t s);
 hipError_t bf_launch_h3_from_f32(const float* x, void* y, int B, int H, int W, hipStream_t s);
 hipError_t bf_launch_h3_to_f32(const void* y, float* x, int B, int H, int W, hipStream_t s);
 
@@ -192,6 +195,8 @@ hipError_t bf_launch_bn_finalize(const float* partial, int nblk, double count, c
                                  hipStream_t s);
 hipError_t bf_launch_affine_add(const float* x, const float* c, const float* scale, const float* shift,
                                 float* y, int64_t npix, hipStream_t s);   // y = x + scale*c + shift
+hipError_t bf_launch_affine_act(const float* c, const float* scale, const float* shift, float* y, int relu, int64_t npix,
+                                hipStream_t s);                           // y = [relu](scale*c + shift)
 hipError_t bf_launch_bn_bwd_reduce(const float* dy, const float* c, float* partial, int64_t npix, int grid, hipStream_t s);
 hipError_t bf_launch_bn_bwd_finalize(const float* partial, int nblk, double count, const float* gamma,
                                      const float* mean_inv, float* coef /*[48]: k1,k2,k3*/, float* dgamma,

@@ -244,14 +244,16 @@ static int pow2_target(int n)
 
 // ---- tiny pack kernels ---------------------------------------------------------------------
 __global__ void pack_all_convs_kernel(const float* __restrict__ params, int64_t p_blocks, int64_t p_stride, float* __restrict__ dst,
-                                      int64_t d_stride, int with_dgrad)
+                                      int64_t d_stride, int with_dgrad, int nconv, int unit)
 {
-    // blockIdx.x = layer * (with_dgrad ? 4 : 2) + which ; which: 0 w1 fwd, 1 w2 fwd, 2 w1 dgrad, 3 w2 dgrad
-    const int per = with_dgrad ? 4 : 2;
+    // blockIdx.x = layer * (with_dgrad ? 2 : 1) * nconv + which ; which < nconv: forward pack of convolution `which`, else the
+    // data-gradient pack of convolution which - nconv (convolution j of a block at j * 2304, + (j - 1) * 16 behind gammas)
+    const int per = (with_dgrad ? 2 : 1) * nconv;
     const int layer = blockIdx.x / per, which = blockIdx.x % per;
-    const float* w = params + p_blocks + layer * p_stride + (which & 1) * 2304;
+    const int cj = which % nconv;
+    const float* w = params + p_blocks + layer * p_stride + (cj == 0 ? 0 : 2304 + (int64_t)(cj - 1) * unit);
     float* o = dst + layer * d_stride + which * (with_dgrad ? (int64_t)BF_TRAIN_PACK_STRIDE : (int64_t)BF_WPACK_FLOATS);
-    const int tf = which >> 1;
+    const int tf = which / nconv;
     for (int idx = threadIdx.x; idx < BF_WPACK_FLOATS; idx += blockDim.x) {
         const int i = idx >> 6, l = idx & 63;
         const int tap = i >> 2, kk = i & 3;
@@ -339,7 +341,7 @@ extern "C" int bf_pack_inference(bf_handle h, const float* params, const float* 
         BF_HIP(hipGetLastError(), "pack_generic_blocks");
     } else if (d.no_layers > 0) {
         hipLaunchKernelGGL(pack_all_convs_kernel, dim3(d.no_layers * 2), dim3(256), 0, s, params, h->p_blocks, h->p_block_stride,
-                           pk + h->k_blocks, h->k_block_stride, 0);
+                           pk + h->k_blocks, h->k_block_stride, 0, 2, 2320);
         BF_HIP(hipGetLastError(), "pack_all_convs");
         hipLaunchKernelGGL(fold_bn_kernel, dim3((d.no_layers * 16 + 255) / 256), dim3(256), 0, s, params, state, h->p_blocks,
                            h->p_block_stride, pk, h->k_blocks, h->k_block_stride, d.no_layers, d.use_bn, d.bn_eps);
@@ -368,10 +370,11 @@ static TrainLayout train_layout(bf_handle h, int B, int H, int W)
     TrainLayout L;
     const int N = h->d.no_layers;
     int64_t o = 0;
-    L.wpack = o; o += (int64_t)N * 4 * BF_TRAIN_PACK_STRIDE;
+    const int nb = h->d.block_convs;                       // convolutions per block: forward + data-gradient pack each
+    L.wpack = o; o += (int64_t)N * 2 * nb * BF_TRAIN_PACK_STRIDE;
     L.wh = o; o += 64;
-    L.bn_scale = o; o += (int64_t)N * 32 + 32;
-    L.bn_meaninv = o; o += (int64_t)N * 32 + 32;
+    L.bn_scale = o; o += (int64_t)N * (nb > 1 ? nb - 1 : 1) * 32 + 32;
+    L.bn_meaninv = o; o += (int64_t)N * (nb > 1 ? nb - 1 : 1) * 32 + 32;
     L.coef = o; o += 64;
     L.stage1 = o; o += 64 * 32 * 2;            // doubles
     int64_t pf = (int64_t)bf_conv3x3_c16_grid(B, H, W) * 32;
@@ -383,7 +386,8 @@ static TrainLayout train_layout(bf_handle h, int B, int H, int W)
     L.partial = o; o += L.partial_floats + 256;     // +256: reduced head sums / scratch
     o = align_up(o, 64);
     L.act_floats = (int64_t)B * H * W * 16;
-    L.acts = o; o += L.act_floats * (3 * (int64_t)N + 2);
+    // A_0..A_N, per block and convolution j >= 1 its input T_j and its raw output C_j, dA
+    L.acts = o; o += L.act_floats * ((int64_t)N * (2 * (nb - 1) + 1) + 2);
     // RMSE / SSIM loss terms (loss_terms.hip): prediction, extra gradient, three window maps (4 channels at most), partials
     L.extra = o; o += (int64_t)B * H * W * 4 * 5 + 4096 + align_up(B, 64) + 64;
     L.total = o;
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restr
 __global__ __launch_bounds__(1024) void regularizer_kernel(const float* __restrict__ params, float* __restrict__ grads, int64_t n,
                                                            int64_t n_base, int64_t p_blocks, int64_t p_stride, int64_t p_head0,
                                                            int reg_base, int reg_block, int reg_head, float regularization,
-                                                           float* __restrict__ losses)
+                                                           float* __restrict__ losses, int unit)
 {
     __shared__ double red[1024];
     double acc = 0.0;
@@ -661,7 +665,10 @@ __global__ __launch_bounds__(1024) void regularizer_kernel(const float* __restri
         int reg;
         if (i < n_base) reg = reg_base;
         else if (i >= p_head0) reg = reg_head;
-        else reg = ((i - p_blocks) % p_stride) < 4608 ? reg_block : BF_REG_NONE;
+        else {      // block: conv0 [2304], then per further convolution its kernel [2304] and (with BatchNorm) its gamma [16]
+            const int64_t r = (i - p_blocks) % p_stride;
+            reg = (r < 2304 || ((r - 2304) % unit) < 2304) ? reg_block : BF_REG_NONE;
+        }
         const float w = wv[u];
         if (reg == BF_REG_L1) {
             acc += 0.01 * fabs((double)w);
@@ -722,7 +729,7 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     if (loss->ssim_multiplier > 0.f && !d.denormalize)
         return fail(h, BF_EUNSUPPORTED, "SSIM term (max_val 255) is built for the denormalised hydra output");
     if (d.head_activation != BF_ACT_LINEAR) return fail(h, BF_EUNSUPPORTED, "training is built for the linear denoiser head");
-    if (d.block_convs != 2) return fail(h, BF_EUNSUPPORTED, "training is built for block_kernels [3,3] (got %d convolutions)", d.block_convs);
+    if (d.block_convs < 1 || d.block_convs > 3) return fail(h, BF_EUNSUPPORTED, "training is built for blocks of 1 to 3 convolutions (got %d)", d.block_convs);
     if (d.out_channels != d.in_channels) return fail(h, BF_EINVAL, "gt/prediction channel mismatch");
     const TrainLayout L = train_layout(h, B, H, W);
     if (!ws || (uintptr_t)ws % 16) return fail(h, BF_EWORKSPACE, "workspace must be a 16-byte aligned device buffer");
@@ -731,24 +738,29 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     hipStream_t s = (hipStream_t)stream;
     float* w = (float*)ws;
     const int N = d.no_layers;
+    const int nb = d.block_convs;                   // block: conv_0 [+ act] , conv_j + BN [+ act] (j >= 1), last one linear, + skip
+    const int unit = d.use_bn ? 2320 : 2304;        // floats from convolution kernel j >= 1 of a block to the next (gamma in between)
     const int64_t npix = (int64_t)B * H * W;
     const double count = (double)npix;
     float* partial = w + L.partial;
     double* stage1 = reinterpret_cast<double*>(w + L.stage1);     // (offset is a multiple of 2 floats: 8-byte aligned)
     auto ACT = [&](int64_t i) { return w + L.acts + i * L.act_floats; };
-    // buffer map: A_i = ACT(i) (i = 0..N) ; T_i = ACT(N+1+i) ; C_i = ACT(2N+1+i) ; dA = ACT(3N+1)
+    // buffer map: A_i = ACT(i) (i = 0..N: block inputs / outputs) ; T(i,j) = input of convolution j >= 1 of block i (the
+    // activated output of convolution j-1) ; C(i,j) = raw output of convolution j >= 1 (in front of its BatchNorm) ; dA
     auto A = [&](int i) { return ACT(i); };
-    auto T = [&](int i) { return ACT(N + 1 + i); };
-    auto C = [&](int i) { return ACT(2 * (int64_t)N + 1 + i); };
-    float* dA = ACT(3 * (int64_t)N + 1);
+    auto T = [&](int i, int j) { return ACT(N + 1 + (int64_t)i * (nb - 1) + (j - 1)); };
+    auto C = [&](int i, int j) { return ACT(N + 1 + (int64_t)N * (nb - 1) + (int64_t)i * (nb - 1) + (j - 1)); };
+    float* dA = ACT(N + 1 + 2 * (int64_t)N * (nb - 1));
+    auto conv_off = [&](int j) { return j == 0 ? (int64_t)0 : 2304 + (int64_t)(j - 1) * unit; };     // inside a block's parameters
+    auto bn_idx = [&](int i, int j) { return (int64_t)i * (nb - 1) + (j - 1); };                       // BatchNorm of convolution j >= 1
 
     const int h3t = h->train_arith == 1;
     if (N > 0) {
         if (h3t) {
-            BF_HIP(bf_launch_pack_h3_train(params, h->p_blocks, h->p_block_stride, w + L.wpack, N, s), "pack_h3_train");
+            BF_HIP(bf_launch_pack_h3_train(params, h->p_blocks, h->p_block_stride, w + L.wpack, N, nb, unit, s), "pack_h3_train");
         } else {
-            hipLaunchKernelGGL(pack_all_convs_kernel, dim3(N * 4), dim3(256), 0, s, params, h->p_blocks, h->p_block_stride,
-                               w + L.wpack, (int64_t)4 * BF_TRAIN_PACK_STRIDE, 1);
+            hipLaunchKernelGGL(pack_all_convs_kernel, dim3(N * 2 * nb), dim3(256), 0, s, params, h->p_blocks, h->p_block_stride,
+                               w + L.wpack, (int64_t)2 * nb * BF_TRAIN_PACK_STRIDE, 1, nb, unit);
             BF_HIP(hipGetLastError(), "pack_all_convs");
         }
     }
@@ -767,25 +779,34 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     ba.act_relu = 0; ba.v_min = d.v_min; ba.v_max = d.v_max; ba.out_split = 0; ba.status = nullptr;
     BF_HIP(bf_launch_base_conv(ba, s), "base_conv");
     const int conv_grid = bf_conv3x3_c16_grid(B, H, W);
+    const bool relu = d.activation == BF_ACT_RELU;
     for (int i = 0; i < N; ++i) {
-        const float* wp = w + L.wpack + (int64_t)i * 4 * BF_TRAIN_PACK_STRIDE;
-        float* scale = w + L.bn_scale + i * 32;
-        ConvArgs ca;
-        memset(&ca, 0, sizeof(ca));
-        ca.B = B; ca.H = H; ca.W = W;
-        ca.in = A(i); ca.out = T(i); ca.wpack = wp;
-        BF_HIP(conv(ca, d.activation == BF_ACT_RELU ? EPI_RELU : 0), "conv1");
-        ca.in = T(i); ca.out = C(i); ca.wpack = wp + BF_TRAIN_PACK_STRIDE; ca.stats = partial;
-        BF_HIP(conv(ca, d.use_bn ? EPI_STATS : 0), "conv2");
-        if (d.use_bn) {
-            BF_HIP(bf_launch_bn_finalize(partial, conv_grid, count, params + h->p_blocks + i * h->p_block_stride + 4608,
-                                         state + i * 32, state + i * 32 + 16, d.bn_eps, d.bn_momentum, scale, scale + 16,
-                                         w + L.bn_meaninv + i * 32, stage1, s), "bn_finalize");
-        } else {
-            hipLaunchKernelGGL(fill_identity_affine_kernel, dim3(1), dim3(64), 0, s, scale);
-            BF_HIP(hipGetLastError(), "identity_affine");
+        const float* wp = w + L.wpack + (int64_t)i * 2 * nb * BF_TRAIN_PACK_STRIDE;        // forward packs 0..nb-1, then data-gradient packs
+        for (int j = 0; j < nb; ++j) {
+            const bool last = j == nb - 1, bn = j >= 1 && d.use_bn;
+            ConvArgs ca;
+            memset(&ca, 0, sizeof(ca));
+            ca.B = B; ca.H = H; ca.W = W;
+            ca.in = j == 0 ? A(i) : T(i, j); ca.wpack = wp + (int64_t)j * BF_TRAIN_PACK_STRIDE;
+            if (bn) {
+                // conv -> BatchNorm (batch statistics ride in the convolution's epilogue) -> [activation | + skip]
+                float* scale = w + L.bn_scale + bn_idx(i, j) * 32;
+                ca.out = C(i, j); ca.stats = partial;
+                BF_HIP(conv(ca, EPI_STATS), "conv + statistics");
+                BF_HIP(bf_launch_bn_finalize(partial, conv_grid, count, params + h->p_blocks + i * h->p_block_stride + conv_off(j) + 2304,
+                                             state + bn_idx(i, j) * 32, state + bn_idx(i, j) * 32 + 16, d.bn_eps, d.bn_momentum, scale,
+                                             scale + 16, w + L.bn_meaninv + bn_idx(i, j) * 32, stage1, s), "bn_finalize");
+                if (last) BF_HIP(bf_launch_affine_add(A(i), C(i, j), scale, scale + 16, A(i + 1), npix, s), "affine_add");
+                else BF_HIP(bf_launch_affine_act(C(i, j), scale, scale + 16, T(i, j + 1), relu, npix, s), "affine_act");
+            } else if (last) {
+                // no BatchNorm on the block's last convolution (one-convolution block, or use_bn off): linear, + skip
+                ca.out = A(i + 1); ca.res = A(i);
+                BF_HIP(conv(ca, EPI_RES), "conv + skip");
+            } else {
+                ca.out = T(i, j + 1);
+                BF_HIP(conv(ca, relu ? EPI_RELU : 0), "conv + activation");
+            }
         }
-        BF_HIP(bf_launch_affine_add(A(i), C(i), scale, scale + 16, A(i + 1), npix, s), "affine_add");
     }
 
     // ---- head forward + loss + head backward ---------------------------------------------------
@@ -842,36 +863,48 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
                "loss_extra_finalize");
 
     // ---- backward through the blocks -----------------------------------------------------------
+    // g = dL/d(block output) arrives in dA.  Per convolution j = nb-1 .. 0: [BatchNorm backward: g -> dc, dgamma] ; weight
+    // gradient from (input of conv j, dc) ; data gradient through conv j -- for j >= 1 written over T(i,j) with the ReLU mask
+    // of the activation that produced T(i,j), for j = 0 added to dA (the skip).
     int64_t n4 = npix * 4;
     int bgrid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
     for (int i = N - 1; i >= 0; --i) {
-        const float* wp = w + L.wpack + (int64_t)i * 4 * BF_TRAIN_PACK_STRIDE;
+        const float* wp = w + L.wpack + (int64_t)i * 2 * nb * BF_TRAIN_PACK_STRIDE;
         float* gblk = grads + h->p_blocks + i * h->p_block_stride;
-        float* dC = dA;
-        if (d.use_bn) {
-            // sum dy, sum dy*c: from the data-gradient kernel of the block above when it produced dy (split-f16 path: its
-            // epilogue accumulates them, one pass over dy and c saved), else from the reduction kernel
-            const bool fused_sums = h3t && i < N - 1;
-            if (!fused_sums) BF_HIP(bf_launch_bn_bwd_reduce(dA, C(i), partial, npix, bgrid, s), "bn_bwd_reduce");
-            BF_HIP(bf_launch_bn_bwd_finalize(partial, fused_sums ? conv_grid : bgrid, count,
-                                             params + h->p_blocks + i * h->p_block_stride + 4608,
-                                             w + L.bn_meaninv + i * 32, w + L.coef, gblk + 4608, stage1, s), "bn_bwd_finalize");
-            BF_HIP(bf_launch_bn_bwd_apply(dA, C(i), w + L.coef, C(i), npix, s), "bn_bwd_apply");
-            dC = C(i);
-        }
-        BF_HIP(wgrad(T(i), dC, gblk + 2304), "wgrad2");
-        ConvArgs ca;
-        memset(&ca, 0, sizeof(ca));
-        ca.B = B; ca.H = H; ca.W = W;
-        ca.in = dC; ca.out = T(i); ca.wpack = wp + 3 * BF_TRAIN_PACK_STRIDE; ca.mask = T(i);
-        BF_HIP(conv(ca, d.activation == BF_ACT_RELU ? EPI_MASK : 0), "dgrad2");
-        BF_HIP(wgrad(A(i), T(i), gblk), "wgrad1");
-        ca.in = T(i); ca.out = dA; ca.wpack = wp + 2 * BF_TRAIN_PACK_STRIDE; ca.mask = nullptr; ca.res = dA;
-        if (h3t && d.use_bn && i > 0) {                   // dA becomes dy of block i-1: its BN-backward sums ride along
-            ca.bnc = C(i - 1); ca.stats = partial;
-            BF_HIP(conv(ca, EPI_RES | EPI_BNBWD), "dgrad1");
-        } else {
-            BF_HIP(conv(ca, EPI_RES), "dgrad1");
+        const float* g = dA;
+        for (int j = nb - 1; j >= 0; --j) {
+            const bool last = j == nb - 1, bn = j >= 1 && d.use_bn;
+            const float* dy = g;
+            if (bn) {
+                // sum dy, sum dy*c: for the block's last BatchNorm they come from the data-gradient kernel of the block above
+                // when it produced dA (split-f16 path: its epilogue accumulates them), else from the reduction kernel
+                const bool fused_sums = h3t && last && i < N - 1;
+                if (!fused_sums) BF_HIP(bf_launch_bn_bwd_reduce(g, C(i, j), partial, npix, bgrid, s), "bn_bwd_reduce");
+                BF_HIP(bf_launch_bn_bwd_finalize(partial, fused_sums ? conv_grid : bgrid, count,
+                                                 params + h->p_blocks + i * h->p_block_stride + conv_off(j) + 2304,
+                                                 w + L.bn_meaninv + bn_idx(i, j) * 32, w + L.coef, gblk + conv_off(j) + 2304, stage1, s),
+                       "bn_bwd_finalize");
+                BF_HIP(bf_launch_bn_bwd_apply(g, C(i, j), w + L.coef, C(i, j), npix, s), "bn_bwd_apply");
+                dy = C(i, j);
+            }
+            BF_HIP(wgrad(j == 0 ? A(i) : T(i, j), dy, gblk + conv_off(j)), "wgrad");
+            ConvArgs ca;
+            memset(&ca, 0, sizeof(ca));
+            ca.B = B; ca.H = H; ca.W = W;
+            ca.in = dy; ca.wpack = wp + (int64_t)(nb + j) * BF_TRAIN_PACK_STRIDE;
+            if (j > 0) {
+                ca.out = T(i, j); ca.mask = T(i, j);
+                BF_HIP(conv(ca, relu ? EPI_MASK : 0), "dgrad");
+                g = T(i, j);
+            } else {
+                ca.out = dA; ca.res = dA;
+                if (h3t && d.use_bn && nb >= 2 && i > 0) {       // dA becomes dy of block i-1's last BatchNorm: its sums ride along
+                    ca.bnc = C(i - 1, nb - 1); ca.stats = partial;
+                    BF_HIP(conv(ca, EPI_RES | EPI_BNBWD), "dgrad + skip");
+                } else {
+                    BF_HIP(conv(ca, EPI_RES), "dgrad + skip");
+                }
+            }
         }
     }
     BF_HIP(bf_launch_base_wgrad(noisy, dA, partial, grads + h->p_base, B, H, W, d.in_channels, d.kernel_size, d.v_min, d.v_max, s),
@@ -882,7 +915,8 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
         BF_HIP(hipGetLastError(), "grad_unscale");
     }
     hipLaunchKernelGGL(regularizer_kernel, dim3(1), dim3(1024), 0, s, params, grads, h->n_params, h->n_base, h->p_blocks,
-                       h->p_block_stride, h->p_head0, d.reg_base, d.reg_block, d.reg_head, loss->regularization, losses);
+                       h->p_block_stride, h->p_head0, d.reg_base, d.reg_block, d.reg_head, loss->regularization, losses,
+                       d.use_bn ? 2320 : 2304);
     BF_HIP(hipGetLastError(), "regularizer");
     return BF_OK;
 }
@@ -1116,7 +1150,7 @@ extern "C" int bf_debug_conv3x3_h3(const float* in, const float* w_hwio, float* 
     float* params = scratch + 4 * BF_H3_TRAIN_PACK_FLOATS;        // [w 2304][unused 2304][gamma 16]: one "layer"
     if (hipMemcpyAsync(params, w_hwio, 2304 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;
     if (hipMemcpyAsync(params + 2304, w_hwio, 2304 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;
-    if (bf_launch_pack_h3_train(params, 0, 4608 + 16, scratch, 1, s) != hipSuccess) return BF_EHIP;
+    if (bf_launch_pack_h3_train(params, 0, 4608 + 16, scratch, 1, 2, 2320, s) != hipSuccess) return BF_EHIP;
     ConvArgs ca;
     memset(&ca, 0, sizeof(ca));
     ca.in = in; ca.out = out; ca.wpack = scratch + (transpose_flip ? 2 : 0) * BF_H3_TRAIN_PACK_FLOATS;

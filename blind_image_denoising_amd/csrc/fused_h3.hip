@@ -1302,13 +1302,17 @@ hipError_t bf_launch_conv3x3_h3(const ConvArgs& a, int epi, hipStream_t s)
 // 3 w2 data gradient (W'[tap][ci][co] = W[8-tap][co][ci]); row layout of the fused kernels without BN folding or
 // identity; dst = [12 x 64 x 16 B][1/s broadcast x 64 floats]
 __global__ __launch_bounds__(256) void pack_h3_train_kernel(const float* __restrict__ params, int64_t p_blocks, int64_t p_stride,
-                                                            float* __restrict__ dst, int64_t d_stride)
+                                                            float* __restrict__ dst, int64_t d_stride, int nconv, int unit)
 {
+    // blockIdx.x = layer * 2 * nconv + which ; which < nconv: forward pack of convolution `which`, else the data-gradient pack
+    // of convolution which - nconv.  Convolution j of a block sits at j * 2304 (+ (j - 1) * 16 behind the gammas: unit = 2320)
     __shared__ float red[256];
     __shared__ float s_scale;
-    const int layer = blockIdx.x >> 2, which = blockIdx.x & 3;
-    const float* w = params + p_blocks + layer * p_stride + (which & 1) * 2304;
-    const int tf = which >> 1;
+    const int per = 2 * nconv;
+    const int layer = blockIdx.x / per, which = blockIdx.x % per;
+    const int cj = which % nconv;
+    const float* w = params + p_blocks + layer * p_stride + (cj == 0 ? 0 : 2304 + (int64_t)(cj - 1) * unit);
+    const int tf = which / nconv;
     float m = 0.f;
     for (int i = threadIdx.x; i < 2304; i += 256) m = fmaxf(m, fabsf(w[i]));
     red[threadIdx.x] = m;
@@ -1330,7 +1334,7 @@ __global__ __launch_bounds__(256) void pack_h3_train_kernel(const float* __restr
     }
     __syncthreads();
     const float sr = s_scale;
-    float* out = dst + (layer * 4 + which) * d_stride;
+    float* out = dst + ((int64_t)layer * per + which) * d_stride;
     _Float16* orow = reinterpret_cast<_Float16*>(out);
     for (int idx = threadIdx.x; idx < 12 * 64 * 8; idx += 256) {
         const int i = idx >> 9, l = (idx >> 3) & 63, j = idx & 7;
@@ -1351,11 +1355,12 @@ __global__ __launch_bounds__(256) void pack_h3_train_kernel(const float* __restr
     if (threadIdx.x < 64) out[BF_H3R_WPACK_FLOATS + threadIdx.x] = 1.0f / sr;
 }
 
-hipError_t bf_launch_pack_h3_train(const float* params, int64_t p_blocks, int64_t p_stride, float* dst, int layers, hipStream_t s)
+hipError_t bf_launch_pack_h3_train(const float* params, int64_t p_blocks, int64_t p_stride, float* dst, int layers, int nconv,
+                                   int unit, hipStream_t s)
 {
     if (layers <= 0) return hipSuccess;
-    hipLaunchKernelGGL(pack_h3_train_kernel, dim3(layers * 4), dim3(256), 0, s, params, p_blocks, p_stride, dst,
-                       (int64_t)BF_H3_TRAIN_PACK_FLOATS);
+    hipLaunchKernelGGL(pack_h3_train_kernel, dim3(layers * 2 * nconv), dim3(256), 0, s, params, p_blocks, p_stride, dst,
+                       (int64_t)BF_H3_TRAIN_PACK_FLOATS, nconv, unit);
     return hipGetLastError();
 }
 

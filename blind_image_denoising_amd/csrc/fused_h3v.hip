@@ -36,6 +36,11 @@
 #ifndef H3V_PRIO_B
 #define H3V_PRIO_B 1
 #endif
+// experiment: priority flip in the middle of a step (0 = static priorities).  1 / 2: conv1 waves high in the first / second half
+// of their step, low in the other; 3 / 4: the same for the conv2 waves
+#ifndef H3V_PRIO_MODE
+#define H3V_PRIO_MODE 0
+#endif
 
 struct H3VGeom {
     static constexpr int WMAX = 256;                   // columns a workgroup covers (whole image rows)
@@ -265,6 +270,10 @@ struct H3VRoleA {
         for (int g = 0; g < Gm::G; ++g) {
             H3VFrag nx;
             if (g + 1 < Gm::G) nx = load(ib, g + 1);
+            if (H3V_PRIO_MODE == 1 && g == 0) __builtin_amdgcn_s_setprio(2);
+            if (H3V_PRIO_MODE == 1 && g == 2) __builtin_amdgcn_s_setprio(0);
+            if (H3V_PRIO_MODE == 2 && g == 0) __builtin_amdgcn_s_setprio(0);
+            if (H3V_PRIO_MODE == 2 && g == 2) __builtin_amdgcn_s_setprio(2);
             __builtin_amdgcn_sched_barrier(0);
             f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
             if (g > 0) {
@@ -370,6 +379,10 @@ struct H3VRoleB {
                 nx = load(mslot, g + 1);
                 xn = load_res(xb, g + 1);
             }
+            if (H3V_PRIO_MODE == 3 && g == 0) __builtin_amdgcn_s_setprio(2);
+            if (H3V_PRIO_MODE == 3 && g == 2) __builtin_amdgcn_s_setprio(0);
+            if (H3V_PRIO_MODE == 4 && g == 0) __builtin_amdgcn_s_setprio(0);
+            if (H3V_PRIO_MODE == 4 && g == 2) __builtin_amdgcn_s_setprio(2);
             __builtin_amdgcn_sched_barrier(0);
             f32x4 c0;
             if (g > 0) {

@@ -174,6 +174,31 @@ hipError_t bf_launch_affine_add(const float* x, const float* c, const float* sca
     return hipGetLastError();
 }
 
+// y = [relu](scale*c + shift): BatchNorm apply + activation of a block's middle convolution (backbone_blocks.py:191-196)
+__global__ __launch_bounds__(256) void affine_act_kernel(const float4* __restrict__ c, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float4* __restrict__ y, int relu, int64_t n4)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int q = (int)(i & 3) * 4;
+        const float4 cv = c[i];
+        float4 o;
+        o.x = fmaf(scale[q], cv.x, shift[q]);
+        o.y = fmaf(scale[q + 1], cv.y, shift[q + 1]);
+        o.z = fmaf(scale[q + 2], cv.z, shift[q + 2]);
+        o.w = fmaf(scale[q + 3], cv.w, shift[q + 3]);
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        y[i] = o;
+    }
+}
+
+hipError_t bf_launch_affine_act(const float* c, const float* scale, const float* shift, float* y, int relu, int64_t npix,
+                                hipStream_t s)
+{
+    const int64_t n4 = npix * 4;
+    hipLaunchKernelGGL(affine_act_kernel, dim3(stream_grid(n4)), dim3(256), 0, s, (const float4*)c, scale, shift, (float4*)y, relu, n4);
+    return hipGetLastError();
+}
+
 // BN backward, pass 1: partial[blk][32] = (sum dy[16], sum dy*c[16]) over the block's pixels.
 // (sum dy*xhat follows in the finalize: xhat = (c-mean)*inv.)
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4* __restrict__ dy, const float4* __restrict__ c,

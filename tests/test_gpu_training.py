@@ -383,3 +383,40 @@ def test_data_parallel_trainer_two_gpus(native, tmp_path):
         for mdl, fns, opt in reps:
             fns.apply_grads(opt, summed.clone(), None, grad_scale=0.5)
     assert np.abs(reps[0][0].params.cpu().numpy() - p0).max() <= 1e-7
+
+
+# ---- blocks of one and three convolutions (backbone_resnet.py:111-113, backbone_blocks.py:174-246) -------------------
+
+@pytest.mark.parametrize("train_arith", [1, 0], ids=["f16x3", "f32"])
+@pytest.mark.parametrize("use_bn", [True, False], ids=["bn", "nobn"])
+@pytest.mark.parametrize("nb,no_layers,shape", [(1, 2, (2, 24, 32)), (3, 1, (2, 16, 32)), (3, 3, (3, 33, 47)), (2, 2, (2, 24, 32))])
+def test_train_step_block_variants_match_oracle(nb, no_layers, shape, use_bn, train_arith):
+    """block_kernels of length 1, 2 and 3: first convolution without BatchNorm, BatchNorm on the second and third, the
+    activation on every convolution but the last, skip Add -- training forward (batch statistics, moving statistics of
+    every BatchNorm), loss and every gradient against the oracle."""
+    cfg = O.canonical_config(no_layers=no_layers)
+    cfg["model"]["backbone"].update(block_kernels=[3] * nb, block_filters=[16] * nb, use_bn=use_bn)
+    spec = O.ResnetSpec.from_config(cfg["model"])
+    ls = O.LossSpec.from_config(cfg["loss"])
+    params, state = O.init_params(spec, seed=nb * 10 + no_layers, nontrivial_bn=True)
+    m = bf.model_builder(cfg["model"], device="cuda").hydra
+    m.set_weights(params, state)
+    m.set_option("train_arith", train_arith)
+    fns = bf.build_train_functions(m, bf.loss_function_builder(cfg["loss"]))
+    clean, noisy = O.synthetic_batch(*shape, seed=7 + nb)
+    gt, x = clean.astype(np.float32), noisy.astype(np.float32)
+    total, ml, dl, pred, grads = fns.train_step_single_gpu(torch.from_numpy(gt), torch.from_numpy(x), (1.0,), 0.0, None)
+    r_total, r_ml, r_dl, r_pred, r_grads, r_state = O.train_step_single_gpu(
+        spec, ls, params, state, gt.astype(np.float64), x.astype(np.float64))
+    assert abs(total.item() - r_total) <= 1e-5 * abs(r_total)
+    assert abs(ml["regularization_loss"].item() - r_ml["regularization_loss"]) <= 1e-5 * r_ml["regularization_loss"]
+    assert np.abs(pred.cpu().numpy() - r_pred).max() < 0.02
+    _cmp_grads(spec, grads.cpu().numpy().astype(np.float64), r_grads)
+    if state.size:
+        assert np.abs(m.state.cpu().numpy() - r_state).max() < 1e-5
+    # and one optimizer step on top (per-tensor layout of the flat vector differs per variant)
+    opt, _ = bf.optimizer_builder(cfg["train"]["optimizer"])
+    fns.apply_grads(opt, grads, None)
+    p1, _, _ = O.adam_step(params.astype(np.float64), r_grads, np.zeros(params.size), np.zeros(params.size), 0,
+                           opt.lr() if opt.iterations == 0 else 1e-3, global_clipnorm=1.0)
+    assert np.abs(m.params.cpu().numpy() - p1).max() < 5e-6
