@@ -96,6 +96,27 @@ SIGNATURES = {
     "bf_op_fill32": (_I, [_P, _I, _I64, _P]),
     "bf_op_axpy": (_I, [_P, _P, _F, _I, _I64, _P]),
     "bf_op_conv2d_transpose": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "bf_op_adam_step": (_I, [_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _F, _F, _P, _I, _P, _F, _P, _P, _P]),
+    "bf_op_act_bwd": (_I, [_P, _P, _P, _I64, _I, _F, _I, _P]),
+    "bf_op_matmul_wgrad": (_I, [_P, _P, _P, _I64, _I, _I, _P, _I64, _P]),
+    "bf_op_dwconv_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _I64, _P]),
+    "bf_op_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _I64, _I, _F, _P, _I64, _P]),
+    "bf_op_scale_add": (_I, [_P, _P, _P, _P, _P, _I, _I64, _I, _P]),
+    "bf_op_scale_add_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _I64, _P]),
+    "bf_op_multiplier_bwd": (_I, [_P, _P, _P, _I, _P]),
+    "bf_op_smooth_split_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "bf_op_upsample2x_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "bf_op_conv2d_wgrad": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _I64, _P]),
+    "bf_op_head_out_bwd": (_I, [_P, _P, _P, _P, _P, _I64, _I, _I, _I, _F, _F, _P, _I64, _P]),
+    "bf_op_denoiser_loss_scratch_floats": (_I64, [_I, _I, _I, _I]),
+    "bf_op_denoiser_loss": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(LossDesc), _P, _P, _P, _I64, _P]),
+    "bf_op_attention_train": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "bf_op_attention_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "bf_op_resize_bilinear_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "bf_op_reg_elementwise": (_I, [_P, _P, _I64, _I, _F, _F, _P, _P]),
+    "bf_op_reg_soft_orthonormal": (_I, [_P, _P, _I, _I, _F, _F, _F, _F, _P, _P, _P]),
+    "bf_op_flip_hw": (_I, [_P, _P, _I, _I, _P]),
+    "bf_op_transpose2d": (_I, [_P, _P, _I, _I, _P]),
     "bf_comm_unique_id": (_I, [C.c_char_p]),
     "bf_comm_init_rank": (_I, [C.POINTER(_P), _I, _I, C.c_char_p]),
     "bf_comm_destroy": (_I, [_P]),

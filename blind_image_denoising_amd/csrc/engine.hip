@@ -1006,22 +1006,41 @@ __global__ __launch_bounds__(256) void adam_tensor_kernel(float* __restrict__ p,
 // bf_adam_step with keras' other two clipping modes.  Precedence as keras 2.13 (_clip_gradients): clipnorm (per tensor), else
 // global_clipnorm, else clipvalue.  tensor_offsets = device int64[n_tensors + 1] (offsets of the trainable tensors in the flat
 // vector, last = n_params), tensor_scratch = device float[n_tensors]; both only read when clipnorm or clipvalue is on.
-extern "C" int bf_adam_step_ex(bf_handle h, float* params, const float* grads, float* m, float* v, int64_t iterations, float lr,
-                               float beta_1, float beta_2, float epsilon, float global_clipnorm, float clipnorm, float clipvalue,
-                               const int64_t* tensor_offsets, int n_tensors, float* tensor_scratch, float grad_scale, float* losses,
-                               float* scratch, void* stream)
+static int adam_core(bf_handle h, int64_t n, float* params, const float* grads, float* m, float* v, int64_t iterations, float lr,
+                     float beta_1, float beta_2, float epsilon, float global_clipnorm, float grad_scale, float* losses, float* scratch,
+                     void* stream)
 {
-    if (!h) return BF_EINVAL;
+    if (!params || !grads || !m || !v || !scratch || n <= 0) return fail(h, BF_EINVAL, "bf_adam_step: NULL argument");
+    if (iterations < 0) return fail(h, BF_EINVAL, "iterations must be >= 0");
+    hipStream_t s = (hipStream_t)stream;
+    if (global_clipnorm > 0.f || losses) {
+        hipLaunchKernelGGL(grad_norm_kernel, dim3(1), dim3(1024), 0, s, grads, n, grad_scale, scratch, losses);
+        BF_HIP(hipGetLastError(), "grad_norm");
+    }
+    const double t = (double)iterations + 1.0;
+    const double alpha = (double)lr * sqrt(1.0 - pow((double)beta_2, t)) / (1.0 - pow((double)beta_1, t));
+    const int grid = (int)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, s, params, grads, m, v, n, (float)alpha, beta_1, beta_2, epsilon,
+                       global_clipnorm, grad_scale, scratch);
+    BF_HIP(hipGetLastError(), "adam");
+    return BF_OK;
+}
+
+static int adam_ex_core(bf_handle h, int64_t n, float* params, const float* grads, float* m, float* v, int64_t iterations, float lr,
+                        float beta_1, float beta_2, float epsilon, float global_clipnorm, float clipnorm, float clipvalue,
+                        const int64_t* tensor_offsets, int n_tensors, float* tensor_scratch, float grad_scale, float* losses,
+                        float* scratch, void* stream)
+{
     const bool local = clipnorm > 0.f, by_value = !local && !(global_clipnorm > 0.f) && clipvalue > 0.f;
     if (!local && !by_value)
-        return bf_adam_step(h, params, grads, m, v, iterations, lr, beta_1, beta_2, epsilon, global_clipnorm, grad_scale, losses,
-                            scratch, stream);
+        return adam_core(h, n, params, grads, m, v, iterations, lr, beta_1, beta_2, epsilon, global_clipnorm, grad_scale, losses, scratch,
+                         stream);
     if (!params || !grads || !m || !v || !scratch || !tensor_offsets || n_tensors <= 0 || (local && !tensor_scratch))
         return fail(h, BF_EINVAL, "bf_adam_step_ex: NULL argument");
     if (iterations < 0) return fail(h, BF_EINVAL, "iterations must be >= 0");
     hipStream_t s = (hipStream_t)stream;
     if (losses) {
-        hipLaunchKernelGGL(grad_norm_kernel, dim3(1), dim3(1024), 0, s, grads, h->n_params, grad_scale, scratch, losses);
+        hipLaunchKernelGGL(grad_norm_kernel, dim3(1), dim3(1024), 0, s, grads, n, grad_scale, scratch, losses);
         BF_HIP(hipGetLastError(), "grad_norm");
     }
     if (local) {
@@ -1038,26 +1057,34 @@ extern "C" int bf_adam_step_ex(bf_handle h, float* params, const float* grads, f
     return BF_OK;
 }
 
+extern "C" int bf_adam_step_ex(bf_handle h, float* params, const float* grads, float* m, float* v, int64_t iterations, float lr,
+                               float beta_1, float beta_2, float epsilon, float global_clipnorm, float clipnorm, float clipvalue,
+                               const int64_t* tensor_offsets, int n_tensors, float* tensor_scratch, float grad_scale, float* losses,
+                               float* scratch, void* stream)
+{
+    if (!h) return BF_EINVAL;
+    return adam_ex_core(h, h->n_params, params, grads, m, v, iterations, lr, beta_1, beta_2, epsilon, global_clipnorm, clipnorm, clipvalue,
+                        tensor_offsets, n_tensors, tensor_scratch, grad_scale, losses, scratch, stream);
+}
+
 extern "C" int bf_adam_step(bf_handle h, float* params, const float* grads, float* m, float* v, int64_t iterations, float lr,
                             float beta_1, float beta_2, float epsilon, float global_clipnorm, float grad_scale, float* losses,
                             float* scratch, void* stream)
 {
     if (!h) return BF_EINVAL;
-    if (!params || !grads || !m || !v || !scratch) return fail(h, BF_EINVAL, "bf_adam_step: NULL argument");
-    if (iterations < 0) return fail(h, BF_EINVAL, "iterations must be >= 0");
-    hipStream_t s = (hipStream_t)stream;
-    const int64_t n = h->n_params;
-    if (global_clipnorm > 0.f || losses) {
-        hipLaunchKernelGGL(grad_norm_kernel, dim3(1), dim3(1024), 0, s, grads, n, grad_scale, scratch, losses);
-        BF_HIP(hipGetLastError(), "grad_norm");
-    }
-    const double t = (double)iterations + 1.0;
-    const double alpha = (double)lr * sqrt(1.0 - pow((double)beta_2, t)) / (1.0 - pow((double)beta_1, t));
-    const int grid = (int)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
-    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, s, params, grads, m, v, n, (float)alpha, beta_1, beta_2, epsilon,
-                       global_clipnorm, grad_scale, scratch);
-    BF_HIP(hipGetLastError(), "adam");
-    return BF_OK;
+    return adam_core(h, h->n_params, params, grads, m, v, iterations, lr, beta_1, beta_2, epsilon, global_clipnorm, grad_scale, losses,
+                     scratch, stream);
+}
+
+// the same update for a flat parameter vector that no bf_handle describes (models assembled from the operator library:
+// unet_laplacian); n = number of parameters, everything else as bf_adam_step_ex
+extern "C" int bf_op_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, int64_t iterations, float lr, float beta_1,
+                               float beta_2, float epsilon, float global_clipnorm, float clipnorm, float clipvalue,
+                               const int64_t* tensor_offsets, int n_tensors, float* tensor_scratch, float grad_scale, float* losses,
+                               float* scratch, void* stream)
+{
+    return adam_ex_core(nullptr, n, params, grads, m, v, iterations, lr, beta_1, beta_2, epsilon, global_clipnorm, clipnorm, clipvalue,
+                        tensor_offsets, n_tensors, tensor_scratch, grad_scale, losses, scratch, stream);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -198,6 +198,7 @@ static int uo_pointwise_dispatch(const float* in, float* out, const float* wp, c
     UO_CASE(128, 32, 4); UO_CASE(128, 64, 4); UO_CASE(128, 128, 4);
     UO_CASE(128, 96, 2);                                   // query | key | value of one attention block in one pass
     UO_CASE(128, 256, 2); UO_CASE(256, 128, 4); UO_CASE(256, 32, 4); UO_CASE(32, 256, 2);      // 4-level models (256 channels)
+    UO_CASE(64, 256, 2); UO_CASE(256, 64, 4);              // the 64-channel ConvNext MLP as two convolutions (training: unet_train.py)
 #undef UO_CASE
     if (e == hipErrorInvalidValue) return BF_EUNSUPPORTED;
     return e == hipSuccess ? BF_OK : BF_EHIP;

@@ -125,7 +125,9 @@ class Adam:
             self.v = torch.zeros_like(model.params)
             self._scratch = torch.zeros(4, dtype=torch.float32, device=model.params.device)
             # offsets of the trainable tensors in the flat vector: per-tensor clipping (clipnorm / clipvalue) walks them
-            offs = sorted(int(i[1]) for i in model._infos) + [int(model.n_params)]
+            infos = getattr(model, "_infos", None)                    # engine models: (name, offset, ...) ; operator-library
+            starts = [int(i[1]) for i in infos] if infos is not None else [int(v[3]) for v in model.trainable_variables]
+            offs = sorted(starts) + [int(model.n_params)]
             self._offsets = torch.tensor(offs, dtype=torch.int64, device=model.params.device)
             self._tensor_scratch = torch.zeros(len(offs), dtype=torch.float32, device=model.params.device)
 
@@ -138,7 +140,14 @@ class Adam:
         clip = float(self.global_clipnorm) if self.global_clipnorm else 0.0
         local = float(self.clipnorm) if self.clipnorm else 0.0
         value = float(self.clipvalue) if self.clipvalue else 0.0
-        if local > 0.0 or value > 0.0:      # keras precedence: clipnorm, else global_clipnorm, else clipvalue (in the library)
+        if getattr(model, "_h", None) is None:
+            # a model assembled from the operator library (unet_laplacian): the same kernels on its flat vector
+            N.check(N.lib().bf_op_adam_step(N.ptr(model.params), N.ptr(grads), N.ptr(self.m), N.ptr(self.v), int(model.n_params),
+                                            int(self.iterations), self.lr(), self.beta_1, self.beta_2, self.epsilon, clip, local, value,
+                                            N.ptr(self._offsets), int(self._offsets.numel() - 1), N.ptr(self._tensor_scratch),
+                                            float(grad_scale), N.ptr(losses), N.ptr(self._scratch), N.stream_ptr(grads)), None,
+                    "bf_op_adam_step")
+        elif local > 0.0 or value > 0.0:      # keras precedence: clipnorm, else global_clipnorm, else clipvalue (in the library)
             N.check(N.lib().bf_adam_step_ex(model._h, N.ptr(model.params), N.ptr(grads), N.ptr(self.m), N.ptr(self.v),
                                             int(self.iterations), self.lr(), self.beta_1, self.beta_2, self.epsilon, clip, local,
                                             value, N.ptr(self._offsets), int(self._offsets.numel() - 1),

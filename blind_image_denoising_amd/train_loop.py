@@ -33,6 +33,8 @@ def build_train_functions(model: HydraModel, loss_fn_map: Dict[str, Callable]) -
     Losses come back as 0-d views of one device buffer (no host synchronisation); call
     `.item()` when a Python float is wanted."""
     denoiser_loss_fn = loss_fn_map[DENOISER_LOSS_FN_STR]
+    if getattr(model, "multi_output", False):
+        return _build_multi_output_train_functions(model, denoiser_loss_fn)
     state = {"grads": None, "losses": None}
 
     def _buffers():
@@ -69,6 +71,72 @@ def build_train_functions(model: HydraModel, loss_fn_map: Dict[str, Callable]) -
     def apply_grads(internal_optimizer, internal_gradients, internal_trainable_variables=None, grad_scale: float = 1.0):
         """bfcnn/train_loop.py:314-321."""
         internal_optimizer.apply_gradients(internal_gradients, model, grad_scale=grad_scale, losses=state["losses"])
+
+    return TrainFunctions(train_step, test_step, train_step_single_gpu, apply_grads)
+
+
+def _build_multi_output_train_functions(model, denoiser_loss_fn, seed: int = 0) -> TrainFunctions:
+    """the same four closures for a multi-output hydra (unet_laplacian): one denoiser loss per output scale against the
+    ground-truth pyramid, times its depth weight (bfcnn/train_loop.py:273-294), through unet_train.UnetTrainGraph.
+
+    Training-mode randomness (StochasticDepth on the blocks' branches, dropout on the attention weights:
+    backbone_unet_laplacian.py:176-177, 333, 351-352) is drawn here per step from a NumPy generator and handed to the graph as
+    explicit scale tensors; `train_step_single_gpu.randomness = False` switches it off (deterministic steps for parity tests)."""
+    import numpy as np
+    from .unet_train import UnetTrainGraph
+    d = denoiser_loss_fn.desc(1.0)
+    loss_config = {"hinge": d.hinge, "cutoff": d.cutoff, "mae_multiplier": d.mae_multiplier, "mse_multiplier": d.mse_multiplier,
+                   "ssim_multiplier": d.ssim_multiplier, "regularization": d.regularization}
+    graph = UnetTrainGraph(model, loss_config)
+    bb = model.config["backbone"]
+    depth_drop = [float(r) for r in np.linspace(0.0, max(0.0, float(bb.get("depth_drop_rate", 0.0))), model.width)]
+    attn_drop = float(bb.get("convolutional_self_attention_dropout_rate", 0.0))
+    rng = np.random.default_rng(seed)
+    state = {"grads": None}
+
+    def train_step(n):
+        raise NotImplementedError("hydra(n, training=True) on its own is not built for unet_laplacian; use train_step_single_gpu")
+
+    def test_step(n):
+        """bfcnn/train_loop.py:253-257: the first (full-resolution) output"""
+        return model(n, training=False)[0]
+
+    def _randomness(B):
+        ds, at = {}, {}
+        if not train_step_single_gpu.randomness:
+            return ds, at
+        blocks = [f"enc{dl}_{w}" for dl in range(model.depth) for w in range(model.width)] + \
+                 [f"dec{dl}_{w}" for dl in range(model.depth - 1) for w in range(model.width)]
+        for prefix in blocks:
+            rate = depth_drop[int(prefix.rsplit("_", 1)[1])]
+            if rate > 0.0:            # StochasticDepth: the branch of a whole sample is dropped, kept ones scaled by 1 / (1 - rate)
+                keep = (rng.uniform(size=B) >= rate).astype(np.float32) / np.float32(1.0 - rate)
+                ds[prefix] = torch.from_numpy(keep).to(model.device)
+            if attn_drop > 0.0 and prefix.startswith(f"enc{model.depth - 1}_") and model._is_attention(model.depth - 1):
+                T = model.attention_resolution[0] * model.attention_resolution[1]
+                keep = (rng.uniform(size=(B, T, T)) >= attn_drop).astype(np.float32) / np.float32(1.0 - attn_drop)
+                at[prefix] = torch.from_numpy(keep).to(model.device)
+        return ds, at
+
+    def train_step_single_gpu(p_input_image_batch, p_noisy_image_batch, p_depth_weight=None, p_percentage_done=0.0,
+                              p_trainable_variables=None):
+        if state["grads"] is None or state["grads"].device != model.params.device:
+            state["grads"] = torch.zeros(model.n_params, dtype=torch.float32, device=model.device)
+        grads = state["grads"]
+        dw = [1.0] * model.depth if p_depth_weight is None else [float(v) for v in p_depth_weight]
+        if len(dw) < model.depth:
+            raise ValueError(f"{model.depth} output scales need {model.depth} depth weights, got {len(dw)}")
+        ds, at = _randomness(int(p_noisy_image_batch.shape[0]))
+        preds, scale_losses, totals = graph.step(p_input_image_batch, p_noisy_image_batch, dw, grads, ds, at)
+        model_loss = {REGULARIZATION_LOSS_STR: totals[1], TOTAL_LOSS_STR: totals[2]}
+        all_denoiser_loss = [{TOTAL_LOSS_STR: sl[N.BF_LOSS_DENOISER_TOTAL], MSE_LOSS_STR: sl[N.BF_LOSS_MSE], MAE_LOSS_STR: sl[N.BF_LOSS_MAE],
+                              SSIM_LOSS_STR: sl[N.BF_LOSS_SSIM]} for sl in scale_losses]
+        return totals[0], model_loss, all_denoiser_loss, preds, grads
+
+    train_step_single_gpu.randomness = True
+
+    def apply_grads(internal_optimizer, internal_gradients, internal_trainable_variables=None, grad_scale: float = 1.0):
+        internal_optimizer.apply_gradients(internal_gradients, model, grad_scale=grad_scale, losses=None)
 
     return TrainFunctions(train_step, test_step, train_step_single_gpu, apply_grads)
 

@@ -547,6 +547,10 @@ class UnetLaplacianHydra:
             parts.append(np.asarray(a, np.float32).ravel())
         return np.concatenate(parts)
 
+    def mark_dirty(self):
+        """the flat parameter vector changed in place (optimizer step): drop the packed operands"""
+        self._packed = None
+
     def get_weights(self) -> np.ndarray:
         return self.params.detach().cpu().numpy()
 
@@ -763,7 +767,8 @@ class UnetLaplacianHydra:
     def __call__(self, x, training: bool = False):
         """float32 (or uint8) [B,H,W,3] on the 0..255 scale -> list of float32 outputs, full resolution first."""
         if training:
-            raise NotImplementedError("unet_laplacian: only inference is built")
+            raise NotImplementedError("unet_laplacian: hydra(x, training=True) on its own is not built; the training step "
+                                      "(forward + losses + gradients) is build_train_functions(...).train_step_single_gpu")
         self._require_gpu()
         x, was_numpy = self._as_device(x)
         B, H, W, _ = x.shape

@@ -320,6 +320,68 @@ int bf_op_conv2d_transpose(const float* in, const float* w, float* out, int batc
 /* mult[c] = tanh(relu(1 + w[c])) (ChannelLearnableMultiplier, custom_layers.py:304-306). */
 int bf_op_channel_multiplier(const float* w, float* mult, int n, void* stream);
 
+/* bf_adam_step_ex for a flat parameter vector no handle describes (models assembled from bf_op_*: unet_laplacian) */
+int bf_op_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, int64_t iterations, float lr, float beta_1,
+                    float beta_2, float epsilon, float global_clipnorm, float clipnorm, float clipvalue,
+                    const int64_t* tensor_offsets, int n_tensors, float* tensor_scratch, float grad_scale, float* losses,
+                    float* scratch, void* stream);
+
+/* ---- backward primitives of the operator library (train_prims.hip) --------------------------------------------------------
+ * What `unet_laplacian` training needs beyond the forward operators (bfcnn/train_loop.py:259-312 with the multi-output hydra;
+ * tf.GradientTape does this in the reference): exact fp32, NHWC, reductions through caller-supplied scratch (fixed order).
+ * act codes as bf_op_pointwise (0 linear, 1 relu, 2 leaky relu(alpha), 3 exact-erf gelu). */
+/* dx = dy * act'(.) ; ref = the activation's input, or (ref_is_output, relu / leaky relu only) its output */
+int bf_op_act_bwd(const float* ref, const float* dy, float* dx, int64_t n, int act, float alpha, int ref_is_output, void* stream);
+/* 1x1 convolution weight gradient dW[cin][cout] = sum_p x[p][cin] dy[p][cout]; scratch >= cin*cout floats (more = more splits) */
+int bf_op_matmul_wgrad(const float* x, const float* dy, float* dw, int64_t npix, int cin, int cout, float* scratch,
+                       int64_t scratch_floats, void* stream);
+/* DepthwiseConv2D k x k (same) weight gradient dw[k][k][C]; scratch >= k*k*C floats */
+int bf_op_dwconv_wgrad(const float* x, const float* dy, float* dw, int batch, int height, int width, int channels, int k,
+                       float* scratch, int64_t scratch_floats, void* stream);
+/* LayerNormalization(center=False) backward: dx and dgamma from the layer's input x; scratch >= C floats */
+int bf_op_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, int64_t npix, int channels,
+                        float eps, float* scratch, int64_t scratch_floats, void* stream);
+/* out = res + t * m[c] * s[b] (ChannelLearnableMultiplier value m, StochasticDepth sample scale s, skip Add; each optional) */
+int bf_op_scale_add(const float* res, const float* t, const float* m, const float* sample_scale, float* out, int batch, int64_t hw,
+                    int channels, void* stream);
+int bf_op_scale_add_bwd(const float* t, const float* m, const float* sample_scale, const float* dy, float* dt, float* dm, int batch,
+                        int64_t hw, int channels, float* scratch, int64_t scratch_floats, void* stream);
+/* ChannelLearnableMultiplier m = tanh(relu(1 + w)) (custom_layers.py:304-306): dw from dm */
+int bf_op_multiplier_bwd(const float* w, const float* dm, float* dw, int n, void* stream);
+/* adjoint of bf_op_smooth_split (gauss NULL: AveragePooling2D with the in-bounds divisor): dx from (dlap, ddown) */
+int bf_op_smooth_split_bwd(const float* dlap, const float* ddown, const float* gauss, float* dx, int batch, int height, int width,
+                           int channels, int k, void* stream);
+/* adjoint of UpSampling2D(2, bilinear | nearest): dx [B,H,W,C] from dy [B,2H,2W,C] */
+int bf_op_upsample2x_bwd(const float* dy, float* dx, int batch, int height, int width, int channels, int bilinear, void* stream);
+/* k x k convolution (same, stride 1) weight gradient for the first convolution; x = the raw image, normalised as the forward does */
+int bf_op_conv2d_wgrad(const void* x, int x_is_u8, const float* dy, float* dw, int batch, int height, int width, int cin, int cout,
+                       int k, int normalize, float v_min, float v_max, float* scratch, int64_t scratch_floats, void* stream);
+/* last stage of a denoiser head backward (model.py:321-342): h [npix,hf] activated hidden layer, w1 [hf,cout], dL/dpred ->
+ * dh, dw1 (tanh(2x)*0.51, clip, denormalise differentiated) */
+int bf_op_head_out_bwd(const float* h, const float* w1, const float* dpred, float* dh, float* dw1, int64_t npix, int head_filters,
+                       int cout, int denormalize, float v_min, float v_max, float* scratch, int64_t scratch_floats, void* stream);
+/* denoiser_loss of ONE output scale (loss.py:190-247) and d(total * depth_weight)/dpred; losses[BF_LOSS_COUNT] */
+int64_t bf_op_denoiser_loss_scratch_floats(int batch, int height, int width, int channels);
+int bf_op_denoiser_loss(const float* pred, const float* gt, int batch, int height, int width, int channels, const bf_loss_desc* loss,
+                        float* dpred, float* losses, float* scratch, int64_t scratch_floats, void* stream);
+/* dot-product attention for training: out = (softmax(q k^T) * pscale) v with P = softmax kept ([B,T,T]; pscale = dropout
+ * keep-mask / keep-probability or NULL), and its backward (dS_scratch [B,T,T]) */
+int bf_op_attention_train(const float* q, const float* v, const float* k, const float* pscale, float* out, float* P, int batch,
+                          int tokens, int channels, void* stream);
+int bf_op_attention_bwd(const float* q, const float* v, const float* k, const float* pscale, const float* P, const float* dout,
+                        float* dq, float* dv, float* dk, float* dS_scratch, int batch, int tokens, int channels, void* stream);
+/* adjoint of bf_op_resize_bilinear; scratch: B*H*out_width*C floats */
+int bf_op_resize_bilinear_bwd(const float* dy, float* dx, int batch, int height, int width, int channels, int out_height,
+                              int out_width, float* scratch, void* stream);
+/* regularisers: value[0] += term, grad += grad_scale * d(term)/dw.  kind BF_REG_L1 / BF_REG_L2 with coefficient coef;
+ * SoftOrthonormalConstraintRegularizer (regularizers.py:283-338) on a 1x1 kernel [cin][cout], scratch 2*cout*cout floats */
+int bf_op_reg_elementwise(const float* w, float* grad, int64_t n, int kind, float coef, float grad_scale, float* value, void* stream);
+int bf_op_reg_soft_orthonormal(const float* w, float* grad, int cin, int cout, float lambda, float l1, float l2, float grad_scale,
+                               float* value, float* scratch, void* stream);
+/* weight re-layouts for the data gradients: spatial flip of [k][k][inner]; transpose of [a][b] */
+int bf_op_flip_hw(const float* w, float* out, int k, int inner, void* stream);
+int bf_op_transpose2d(const float* w, float* out, int a, int b, void* stream);
+
 /* ---- data-parallel exchange (the reference is single-device, bfcnn/train_loop.py:259-321) -----------------
  * ONE sum-all-reduce of the flat fp32 gradient buffer over RCCL per training step; every rank then runs the identical
  * bf_adam_step with grad_scale = 1 / world.  RCCL is bound at run time: BF_EUNSUPPORTED when librccl is not installed.

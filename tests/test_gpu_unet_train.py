@@ -1,0 +1,277 @@
+"""unet_laplacian training on the GPU (blind_image_denoising_amd/unet_train.py + csrc/train_prims.hip) against the
+torch-autograd gradient oracle (oracle/unet_torch.py, itself pinned to the NumPy restatement in tests/test_unet_train_oracle.py).
+Bars: losses 1e-5 relative, predictions 0.02 grey levels, every gradient tensor 5e-4 of its largest entry (exact fp32 kernels
+against fp64; sums over up to 1e5 pixels)."""
+import numpy as np
+import pytest
+import torch
+
+import blind_image_denoising_amd as bf
+from blind_image_denoising_amd import _native as N
+from blind_image_denoising_amd import unet_laplacian as UL
+from blind_image_denoising_amd.unet_train import UnetTrainGraph
+from oracle import bfcnn_oracle as O
+from oracle import unet_oracle as U
+from oracle import unet_torch as T
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- primitives against torch --------------------------------------------------------------------------------------------
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+
+
+def _scratch(n=1 << 22):
+    return torch.empty(n, dtype=torch.float32, device="cuda")
+
+
+def _close(got, ref, rel=2e-5, what=""):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err, scale = np.abs(got - ref).max(), max(1e-6, np.abs(ref).max())
+    assert err <= rel * scale, f"{what}: {err:.3e} vs {scale:.3e}"
+
+
+@pytest.mark.parametrize("npix,cin,cout", [(1000, 32, 128), (5000, 128, 32), (77, 16, 48), (20000, 64, 64)])
+def test_matmul_wgrad(npix, cin, cout):
+    rng = np.random.default_rng(0)
+    x, dy = rng.standard_normal((npix, cin)), rng.standard_normal((npix, cout))
+    dw, s = torch.empty((cin, cout), device="cuda"), _scratch()
+    xd, dyd = _t(x), _t(dy)                       # (named: a temporary would be freed -- and reused -- before the launch)
+    N.check(N.lib().bf_op_matmul_wgrad(N.ptr(xd), N.ptr(dyd), N.ptr(dw), npix, cin, cout, N.ptr(s), s.numel(), None))
+    _close(dw.cpu(), x.T @ dy, what="matmul_wgrad")
+
+
+@pytest.mark.parametrize("k,shape", [(5, (2, 17, 23, 32)), (1, (1, 8, 8, 64)), (3, (3, 20, 12, 128))])
+def test_depthwise_and_layernorm_backward(k, shape):
+    rng = np.random.default_rng(k)
+    B, H, W, Cc = shape
+    x = torch.tensor(rng.standard_normal(shape), dtype=torch.float64, requires_grad=True)
+    w = torch.tensor(rng.standard_normal((k, k, Cc, 1)), dtype=torch.float64, requires_grad=True)
+    g = torch.tensor(rng.uniform(0.5, 1.5, Cc), dtype=torch.float64, requires_grad=True)
+    dy = rng.standard_normal(shape)
+    t1 = T._depthwise(x, w)
+    y = T._layer_norm(t1, g)
+    (y * torch.from_numpy(dy)).sum().backward()
+    s = _scratch()
+    t1d, dyd, gd = _t(t1.detach().numpy()), _t(dy), _t(g.detach().numpy())
+    dx1 = torch.empty_like(t1d)
+    dg = torch.empty(Cc, device="cuda")
+    N.check(N.lib().bf_op_layernorm_bwd(N.ptr(t1d), N.ptr(gd), N.ptr(dyd), N.ptr(dx1), N.ptr(dg), B * H * W, Cc, 1e-3, N.ptr(s), s.numel(), None))
+    _close(dg.cpu(), g.grad, what="dgamma")
+    dw = torch.empty(k * k * Cc, device="cuda")
+    xd = _t(x.detach().numpy())
+    N.check(N.lib().bf_op_dwconv_wgrad(N.ptr(xd), N.ptr(dx1), N.ptr(dw), B, H, W, Cc, k, N.ptr(s), s.numel(), None))
+    _close(dw.cpu().view(k, k, Cc, 1), w.grad, rel=5e-5, what="dw")
+    wf = torch.empty(k * k * Cc, device="cuda")
+    wd = _t(w.detach().numpy())
+    N.check(N.lib().bf_op_flip_hw(N.ptr(wd), N.ptr(wf), k, Cc, None))
+    dx = UL.dwconv_mult(dx1, wf.view(k, k, Cc, 1), None)
+    _close(dx.cpu(), x.grad, rel=5e-5, what="dx")
+
+
+def test_split_upsample_resize_adjoints():
+    """<A x, y> == <x, A^T y> for the three resamplers, and the averaging split against autograd."""
+    rng = np.random.default_rng(3)
+    B, H, W, Cc = 2, 12, 10, 8
+    x = torch.tensor(rng.standard_normal((B, H, W, Cc)), dtype=torch.float64, requires_grad=True)
+    for gauss in (None, U.gaussian_kernel_3((3, 3))):
+        x.grad = None
+        if gauss is None:
+            sm = T._avg_pool_same(x, 3)
+        else:
+            sm = T._depthwise(x, torch.from_numpy(gauss)[:, :, None, None].repeat(1, 1, Cc, 1))
+        lapv, down = x - sm, sm[:, ::2, ::2, :]
+        dl, dd = rng.standard_normal(lapv.shape), rng.standard_normal(down.shape)
+        ((lapv * torch.from_numpy(dl)).sum() + (down * torch.from_numpy(dd)).sum()).backward()
+        dx = torch.empty((B, H, W, Cc), device="cuda")
+        gd = None if gauss is None else _t(gauss)
+        dld, ddd = _t(dl), _t(dd)
+        N.check(N.lib().bf_op_smooth_split_bwd(N.ptr(dld), N.ptr(ddd), N.ptr(gd), N.ptr(dx), B, H, W, Cc, 3, None))
+        _close(dx.cpu(), x.grad, what="smooth_split_bwd")
+    for bilinear in (1, 0):
+        x.grad = None
+        up = T._up2(x) if bilinear else x.repeat_interleave(2, 1).repeat_interleave(2, 2)
+        dy = rng.standard_normal(up.shape)
+        (up * torch.from_numpy(dy)).sum().backward()
+        dx = torch.empty((B, H, W, Cc), device="cuda")
+        dyd = _t(dy)
+        N.check(N.lib().bf_op_upsample2x_bwd(N.ptr(dyd), N.ptr(dx), B, H, W, Cc, bilinear, None))
+        _close(dx.cpu(), x.grad, what="upsample2x_bwd")
+    for oh, ow in ((16, 16), (5, 7), (24, 20)):
+        x.grad = None
+        r = T._resize(x, oh, ow)
+        dy = rng.standard_normal(r.shape)
+        (r * torch.from_numpy(dy)).sum().backward()
+        dx = torch.empty((B, H, W, Cc), device="cuda")
+        s = _scratch()
+        dyd = _t(dy)
+        N.check(N.lib().bf_op_resize_bilinear_bwd(N.ptr(dyd), N.ptr(dx), B, H, W, Cc, oh, ow, N.ptr(s), None))
+        _close(dx.cpu(), x.grad, what=f"resize_bwd {oh}x{ow}")
+
+
+def test_attention_train_and_backward():
+    rng = np.random.default_rng(4)
+    B, Tn, A = 2, 64, 32
+    q, v, k = (torch.tensor(rng.standard_normal((B, Tn, A)) * 0.5, dtype=torch.float64, requires_grad=True) for _ in range(3))
+    ps = (rng.uniform(size=(B, Tn, Tn)) > 0.25) / 0.75
+    p = torch.softmax(q @ k.transpose(1, 2), dim=-1) * torch.from_numpy(ps)
+    out = p @ v
+    do = rng.standard_normal(out.shape)
+    (out * torch.from_numpy(do)).sum().backward()
+    qd, vd, kd, psd = _t(q.detach().numpy()), _t(v.detach().numpy()), _t(k.detach().numpy()), _t(ps)
+    o, P = torch.empty((B, Tn, A), device="cuda"), torch.empty((B, Tn, Tn), device="cuda")
+    N.check(N.lib().bf_op_attention_train(N.ptr(qd), N.ptr(vd), N.ptr(kd), N.ptr(psd), N.ptr(o), N.ptr(P), B, Tn, A, None))
+    _close(o.cpu(), out.detach(), what="attention fwd")
+    dq, dv, dk = (torch.empty((B, Tn, A), device="cuda") for _ in range(3))
+    dS = torch.empty((B, Tn, Tn), device="cuda")
+    dod = _t(do)
+    N.check(N.lib().bf_op_attention_bwd(N.ptr(qd), N.ptr(vd), N.ptr(kd), N.ptr(psd), N.ptr(P), N.ptr(dod), N.ptr(dq), N.ptr(dv), N.ptr(dk),
+                                        N.ptr(dS), B, Tn, A, None))
+    _close(dq.cpu(), q.grad, rel=5e-5, what="dq")
+    _close(dv.cpu(), v.grad, rel=5e-5, what="dv")
+    _close(dk.cpu(), k.grad, rel=5e-5, what="dk")
+
+
+def test_regularisers():
+    rng = np.random.default_rng(5)
+    w = torch.tensor(rng.standard_normal((1, 1, 24, 40)) * 0.2, dtype=torch.float64, requires_grad=True)
+    T.soft_orthonormal(w).backward()
+    wd = _t(w.detach().numpy())
+    grad, val, s = torch.zeros(24 * 40, device="cuda"), torch.zeros(1, device="cuda"), _scratch(2 * 40 * 40)
+    N.check(N.lib().bf_op_reg_soft_orthonormal(N.ptr(wd), N.ptr(grad), 24, 40, 0.01, 0.0, 1e-4, 0.5, N.ptr(val), N.ptr(s), None))
+    _close(grad.cpu().view(1, 1, 24, 40), 0.5 * w.grad, what="soft orthonormal grad")
+    assert abs(val.item() - float(T.soft_orthonormal(w.detach()))) <= 1e-5 * val.item()
+    grad.zero_()
+    N.check(N.lib().bf_op_reg_elementwise(N.ptr(wd), N.ptr(grad), 960, N.BF_REG_L2, 0.01, 2.0, N.ptr(val), None))
+    _close(grad.cpu().view(1, 1, 24, 40), 2.0 * 0.02 * w.detach(), what="l2 grad")
+
+
+# ---- the whole training step ------------------------------------------------------------------------------------------------
+
+def _setup(depth, width, filters, S, B=2, seed=11):
+    cfg = U.canonical_config(depth=depth, width=width, filters=filters)
+    spec = U.UnetLaplacianSpec.from_config(cfg["model"])
+    params = U.init_params(spec, seed=seed)
+    model = bf.model_builder(cfg["model"], device="cuda").hydra
+    model.set_weights(params)
+    clean, noisy = O.synthetic_batch(B, S, S, seed=seed + 1)
+    return cfg, spec, params, model, clean, noisy
+
+
+def _check_step(spec, params, model, clean, noisy, loss_cfg, dw, depth_scale=None, attn_scale=None):
+    ls = O.LossSpec.from_config(loss_cfg)
+    r_total, r_ml, r_dls, r_preds, r_grads = T.train_step(spec, ls, params, clean.astype(np.float64), noisy.astype(np.float64), dw,
+                                                          depth_scale, attn_scale)
+    graph = UnetTrainGraph(model, loss_cfg)
+    grads = torch.zeros(model.n_params, dtype=torch.float32, device="cuda")
+    dsc = {k: _t(v) for k, v in (depth_scale or {}).items()}
+    asc = {k: _t(v) for k, v in (attn_scale or {}).items()}
+    preds, scale_losses, total = graph.step(torch.from_numpy(clean.astype(np.float32)), torch.from_numpy(noisy.astype(np.float32)), dw,
+                                            grads, dsc, asc)
+    torch.cuda.synchronize()
+    for p, r in zip(preds, r_preds):
+        assert np.abs(p.cpu().numpy() - r).max() < 0.02
+    for i, sl in enumerate(scale_losses):
+        sl = sl.cpu().numpy()
+        assert abs(sl[N.BF_LOSS_DENOISER_TOTAL] - r_dls[i]["total_loss"]) <= 1e-5 * abs(r_dls[i]["total_loss"]), i
+        assert abs(sl[N.BF_LOSS_MAE] - r_dls[i]["mae_loss"]) <= 1e-5 * abs(r_dls[i]["mae_loss"]), i
+    tt = total.cpu().numpy()
+    assert abs(tt[1] - r_ml["regularization_loss"]) <= 1e-5 * r_ml["regularization_loss"]
+    assert abs(tt[0] - r_total) <= 1e-5 * abs(r_total)
+    g = grads.cpu().numpy().astype(np.float64)
+    worst = []
+    for name, (o, s) in spec.offsets().items():
+        n = int(np.prod(s))
+        scale = max(np.abs(r_grads[o:o + n]).max(), 1e-7)
+        worst.append((np.abs(g[o:o + n] - r_grads[o:o + n]).max() / scale, name))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 5e-4, worst[:5]
+
+
+LOSS_V5 = {"hinge": 3.5, "cutoff": 255.0, "mae_multiplier": 1.0, "mse_multiplier": 0.5, "ssim_multiplier": 1.0, "regularization": 0.01}
+
+
+@pytest.mark.parametrize("depth,width,filters,S", [(2, 1, 32, 32), (3, 2, 32, 64)])
+def test_train_step_matches_the_gradient_oracle(depth, width, filters, S):
+    cfg, spec, params, model, clean, noisy = _setup(depth, width, filters, S)
+    _check_step(spec, params, model, clean, noisy, LOSS_V5, [1.0, 0.6, 0.3][:depth])
+
+
+def test_train_step_with_stochastic_depth_and_attention_dropout():
+    """training-mode randomness as explicit inputs: per-sample StochasticDepth scales (0 or 1 / (1 - rate)) and the attention's
+    dropout keep-mask / keep-probability"""
+    cfg, spec, params, model, clean, noisy = _setup(2, 2, 32, 32, B=3)
+    rng = np.random.default_rng(2)
+    ds = {"enc0_1": np.array([2.0, 0.0, 2.0]), "dec0_1": np.array([0.0, 2.0, 2.0]), "enc1_1": np.array([2.0, 2.0, 0.0])}
+    at = {"enc1_0": (rng.uniform(size=(3, 256, 256)) > 0.25) / 0.75}
+    _check_step(spec, params, model, clean, noisy, {"hinge": 0.5, "cutoff": 255.0, "mae_multiplier": 1.0, "mse_multiplier": 0.0,
+                                                     "ssim_multiplier": 0.0, "regularization": 0.01}, [1.0, 0.5], ds, at)
+
+
+def test_shipped_v5_config_trains_through_the_public_api():
+    """configs/unet_laplacian_v5.json (depth 3, width 3, 32/64/128 filters, attention, soft-orthonormal regularisation, L1 hinge 3.5 +
+    0.5 RMSE + SSIM, Adam with per-tensor clipnorm 1): build_train_functions -> train_step_single_gpu -> apply_grads, against
+    the gradient oracle and the oracle's Adam on its gradient."""
+    # the model / loss / optimizer sections of bfcnn/configs/unet_laplacian_v5.json, restated
+    cfg = {"model": U.canonical_config(depth=3, width=3, filters=32)["model"], "loss": dict(LOSS_V5),
+           "train": {"optimizer": {"type": "ADAM", "gradient_clipping_by_norm_local": 1.0,
+                                   "schedule": {"type": "cosine_decay_restarts",
+                                                "config": {"t_mul": 1.1, "epsilon": 0.00001, "decay_rate": 0.9, "decay_steps": 40000,
+                                                           "learning_rate": 0.001}}}}}
+    spec = U.UnetLaplacianSpec.from_config(cfg["model"])
+    params = U.init_params(spec, seed=5)
+    model = bf.model_builder(cfg["model"], device="cuda").hydra
+    assert [v[0] for v in model.trainable_variables] == [t[0] for t in spec.tensors()]
+    model.set_weights(params)
+    fns = bf.build_train_functions(model, bf.loss_function_builder(cfg["loss"]))
+    fns.train_step_single_gpu.randomness = False
+    clean, noisy = O.synthetic_batch(2, 64, 64, seed=6)
+    dw = [1.0, 0.5, 0.25]
+    total, ml, dls, preds, grads = fns.train_step_single_gpu(torch.from_numpy(clean.astype(np.float32)),
+                                                             torch.from_numpy(noisy.astype(np.float32)), dw, 0.0, None)
+    ls = O.LossSpec.from_config(cfg["loss"])
+    r_total, r_ml, r_dls, r_preds, r_grads = T.train_step(spec, ls, params, clean.astype(np.float64), noisy.astype(np.float64), dw)
+    assert len(preds) == 3 and [tuple(p.shape) for p in preds] == [(2, 64, 64, 3), (2, 32, 32, 3), (2, 16, 16, 3)]
+    assert abs(total.item() - r_total) <= 1e-5 * abs(r_total)
+    assert abs(ml["total_loss"].item() - r_ml["total_loss"]) <= 1e-5 * r_ml["total_loss"]
+    for i in range(3):
+        for k in ("total_loss", "mae_loss", "mse_loss", "ssim_loss"):
+            assert abs(dls[i][k].item() - r_dls[i][k]) <= 2e-5 * max(abs(r_dls[i][k]), 1e-3), (i, k)
+    g = grads.cpu().numpy().astype(np.float64)
+    offs = spec.offsets()
+    # bar 3e-3 here (5e-4 in the smaller graphs above): through 9 + 9 + 6 blocks the hinge (3.5) and clip discontinuities make
+    # the fp64 oracle's own base-kernel gradient move by 7e-4 under a 1e-6 relative perturbation of the weights, which is the
+    # size of accumulated fp32 rounding; the GPU result sits at 7e-4
+    for name, (o, s) in offs.items():
+        n = int(np.prod(s))
+        assert np.abs(g[o:o + n] - r_grads[o:o + n]).max() <= 3e-3 * max(np.abs(r_grads[o:o + n]).max(), 1e-7), name
+    opt, _ = bf.optimizer_builder(cfg["train"]["optimizer"])
+    assert opt.clipnorm == 1.0
+    fns.apply_grads(opt, grads, None)
+    starts = sorted(o for o, _ in offs.values()) + [params.size]
+    # (the oracle's Adam on the GPU's own gradient: a first Adam step is lr * g / |g|, so entries whose gradient is within
+    # rounding of zero would flip by 2e-3 between two correct gradients)
+    p1, _, _ = O.adam_step(params.astype(np.float64), g, np.zeros(params.size), np.zeros(params.size), 0, opt.learning_rate(0),
+                           clipnorm=1.0, tensor_offsets=starts)
+    assert np.abs(model.params.cpu().numpy() - p1).max() < 2e-6
+    # the updated weights are what inference sees next
+    out = bf.DenoiserModule(model)(torch.from_numpy(noisy).cuda())
+    assert out.shape == noisy.shape and out.dtype == torch.uint8
+
+
+def test_training_randomness_is_drawn_per_step():
+    cfg = U.canonical_config(depth=2, width=2, filters=32)
+    model = bf.model_builder(cfg["model"], device="cuda").hydra
+    fns = bf.build_train_functions(model, bf.loss_function_builder({"hinge": 0.5, "ssim_multiplier": 0.0, "regularization": 0.01}))
+    clean, noisy = O.synthetic_batch(4, 32, 32, seed=8)
+    gt, x = torch.from_numpy(clean.astype(np.float32)), torch.from_numpy(noisy.astype(np.float32))
+    a = fns.train_step_single_gpu(gt, x, [1.0, 0.5])[4].clone()
+    b = fns.train_step_single_gpu(gt, x, [1.0, 0.5])[4].clone()
+    assert not torch.equal(a, b)                      # StochasticDepth / attention dropout masks differ between steps
+    fns.train_step_single_gpu.randomness = False
+    c = fns.train_step_single_gpu(gt, x, [1.0, 0.5])[4].clone()
+    d = fns.train_step_single_gpu(gt, x, [1.0, 0.5])[4].clone()
+    assert torch.equal(c, d) and torch.isfinite(c).all()
