@@ -366,6 +366,9 @@ def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
     params, state = O.init_params(spec, seed=42, nontrivial_bn=False)
     model = bf.model_builder(cfg["model"], device=f"cuda:{local_rank}").hydra
     model.set_weights(params, state)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        model.set_option(k, int(v))
     opt, _ = bf.optimizer_builder(cfg["train"]["optimizer"])
     trainer = bf.DataParallelTrainer(model, bf.loss_function_builder(cfg["loss"]), opt)
     trainer.broadcast_parameters()

@@ -58,6 +58,7 @@ struct ConvArgs {
     float* stats;         // [grid][32] (EPI_STATS, EPI_BNBWD)
     const float* bnc;     // [B,H,W,16] (EPI_BNBWD): raw convolution output c of the BatchNorm whose backward comes next
     int B, H, W;
+    int reverse;          // conv3x3_h3_kernel: tiles from the last to the first (Infinity Cache reuse across launches)
 };
 
 struct FusedBlockArgs {
@@ -120,6 +121,24 @@ hipError_t bf_launch_pack_h3(const float* params, const float* state, int64_t p_
 #define BF_TRAIN_PACK_STRIDE BF_H3_TRAIN_PACK_FLOATS           // per-convolution slot of the training pack area (>= BF_WPACK_FLOATS)
 hipError_t bf_launch_conv3x3_h3(const ConvArgs& a, int epi, hipStream_t s);
 hipError_t bf_launch_wgrad3x3_h3(const float* x, const float* dy, float* partial, float* dw, int B, int H, int W, hipStream_t s);
+
+// weight gradient + data gradient (+ the BatchNorm backward in front of them) of one convolution in one kernel (train_bwd_h3.hip)
+struct BwdH3Args {
+    const float* x;        // [B,H,W,16] input of the convolution (and, with EPI_MASK, the ReLU mask: x > 0)
+    const float* g;        // gradient at the convolution's output -- or, with coef, at its BatchNorm's output
+    const float* c;        // raw convolution output = BatchNorm input (coef != nullptr)
+    const float* coef;     // [48] k1 | k2 | k3 of bn_bwd_finalize: dc = k1 g + k2 c + k3 ; nullptr: g is used as it is
+    const float* wpack;    // data-gradient pack (pack_h3_train)
+    float* out;            // data gradient; may alias res, must not alias x / g / c
+    const float* res;      // EPI_RES
+    const float* bnc;      // EPI_BNBWD: input of the BatchNorm whose backward comes next (sums of out, out * bnc -> stats)
+    float* wpartial;       // [grid][2304]
+    float* stats;          // [grid][32]
+    int B, H, W, reverse;  // reverse: walk the tiles from the last to the first (Infinity Cache reuse across launches)
+    int tiles_x, tiles_y, ntiles;               // filled in by the launcher
+};
+int        bf_bwd3x3_h3_grid(int B, int H, int W);
+hipError_t bf_launch_bwd3x3_h3(const BwdH3Args& a, int epi, float* dw, hipStream_t s);
 // nconv convolutions per block (forward + data-gradient pack each); unit: floats from one convolution kernel of a block to the
 // next behind the first (2320 with BatchNorm gammas in between, else 2304)
 hipError_t bf_launch_pack_h3_train(const float* params, int64_t p_blocks, int64_t p_stride, float* dst, int layers, int nconv,

@@ -34,6 +34,8 @@ struct bf_engine {
     // arithmetic of the training convolutions (forward + data gradient): 1 = split-f16 on the f16 matrix cores (default),
     // 0 = exact fp32 on the f32 matrix cores; the weight gradients follow the same switch
     int train_arith = 1;
+    int train_zigzag = 1;           // split-f16 training: consecutive kernels walk their tiles in opposite directions
+    int train_fused_bwd = 1;        // split-f16 training: weight + data gradient (+ BatchNorm backward) of a convolution in one kernel
     // optional HIP-event bracket around the residual-block launches of a forward (bench.py roofline)
     int timing = 0;
     // ring of event pairs: one pair per timed forward since the option was (re)set, BF_TIMING_RING forwards at most
@@ -193,6 +195,8 @@ extern "C" int bf_set_option(bf_handle h, const char* key, int value)
     if (!strcmp(key, "h3_variant")) { h->h3_variant = value; return BF_OK; }      // per handle; < 0 = library default
     if (!strcmp(key, "h3_zigzag")) { h->h3_zigzag = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "fused_head")) { h->fused_head = value ? 1 : 0; return BF_OK; }
+    if (!strcmp(key, "train_zigzag")) { h->train_zigzag = value ? 1 : 0; return BF_OK; }
+    if (!strcmp(key, "train_fused_bwd")) { h->train_fused_bwd = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_arith")) { h->train_arith = value < 0 ? 1 : (value ? 1 : 0); return BF_OK; }
     if (!strcmp(key, "arith")) { h->arith = value < 0 ? 1 : (value ? 1 : 0); return BF_OK; }
     if (!strcmp(key, "timing")) {
@@ -380,14 +384,16 @@ static TrainLayout train_layout(bf_handle h, int B, int H, int W)
     int64_t pf = (int64_t)bf_conv3x3_c16_grid(B, H, W) * 32;
     pf = max64(pf, 4096 * 32);
     pf = max64(pf, (int64_t)bf_wgrad_grid(B, H, W) * 2304);
+    pf = max64(pf, (int64_t)bf_bwd3x3_h3_grid(B, H, W) * (2304 + 32));
     pf = max64(pf, (int64_t)bf_base_wgrad_grid(B, H, W) * h->n_base);
     pf = max64(pf, (int64_t)bf_head_train_grid(B, H, W) * 80);
     L.partial_floats = align_up(pf, 64);
     L.partial = o; o += L.partial_floats + 256;     // +256: reduced head sums / scratch
     o = align_up(o, 64);
     L.act_floats = (int64_t)B * H * W * 16;
-    // A_0..A_N, per block and convolution j >= 1 its input T_j and its raw output C_j, dA
-    L.acts = o; o += L.act_floats * ((int64_t)N * (2 * (nb - 1) + 1) + 2);
+    // A_0..A_N, per block and convolution j >= 1 its input T_j and its raw output C_j, dA + two more gradient buffers (the
+    // fused backward kernel reads its operands with a halo, so it never writes over one of them)
+    L.acts = o; o += L.act_floats * ((int64_t)N * (2 * (nb - 1) + 1) + 4);
     // RMSE / SSIM loss terms (loss_terms.hip): prediction, extra gradient, three window maps (4 channels at most), partials
     L.extra = o; o += (int64_t)B * H * W * 4 * 5 + 4096 + align_up(B, 64) + 64;
     L.total = o;
@@ -764,7 +770,14 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
             BF_HIP(hipGetLastError(), "pack_all_convs");
         }
     }
-    auto conv = [&](const ConvArgs& ca, int epi) { return h3t ? bf_launch_conv3x3_h3(ca, epi, s) : bf_launch_conv3x3_c16(ca, epi, s); };
+    // every tile kernel of the step reads what the one before it wrote: alternate the walking direction (train_zigzag)
+    int launch_no = 0;
+    auto next_reverse = [&]() { return h->train_zigzag ? (launch_no++ & 1) : 0; };
+    auto conv = [&](ConvArgs& ca, int epi) {
+        if (!h3t) return bf_launch_conv3x3_c16(ca, epi, s);
+        ca.reverse = next_reverse();
+        return bf_launch_conv3x3_h3(ca, epi, s);
+    };
     auto wgrad = [&](const float* xx, const float* dyy, float* dw) {
         return h3t ? bf_launch_wgrad3x3_h3(xx, dyy, partial, dw, B, H, W, s) : bf_launch_wgrad3x3_c16(xx, dyy, partial, dw, B, H, W, s);
     };
@@ -868,6 +881,11 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     // of the activation that produced T(i,j), for j = 0 added to dA (the skip).
     int64_t n4 = npix * 4;
     int bgrid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    const bool fused_bwd = h3t && h->train_fused_bwd;
+    // gradient buffers: dA (the head's output) and two spares; the fused kernel ping-pongs between them
+    float* const gbuf[3] = {dA, ACT(N + 2 + 2 * (int64_t)N * (nb - 1)), ACT(N + 3 + 2 * (int64_t)N * (nb - 1))};
+    const int bwd_grid = bf_bwd3x3_h3_grid(B, H, W);
+    float* bwd_stats = partial + (int64_t)bwd_grid * 2304;
     for (int i = N - 1; i >= 0; --i) {
         const float* wp = w + L.wpack + (int64_t)i * 2 * nb * BF_TRAIN_PACK_STRIDE;
         float* gblk = grads + h->p_blocks + i * h->p_block_stride;
@@ -880,12 +898,43 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
                 // when it produced dA (split-f16 path: its epilogue accumulates them), else from the reduction kernel
                 const bool fused_sums = h3t && last && i < N - 1;
                 if (!fused_sums) BF_HIP(bf_launch_bn_bwd_reduce(g, C(i, j), partial, npix, bgrid, s), "bn_bwd_reduce");
-                BF_HIP(bf_launch_bn_bwd_finalize(partial, fused_sums ? conv_grid : bgrid, count,
+                BF_HIP(bf_launch_bn_bwd_finalize(fused_sums && fused_bwd ? bwd_stats : partial,
+                                                 fused_sums ? (fused_bwd ? bwd_grid : conv_grid) : bgrid, count,
                                                  params + h->p_blocks + i * h->p_block_stride + conv_off(j) + 2304,
                                                  w + L.bn_meaninv + bn_idx(i, j) * 32, w + L.coef, gblk + conv_off(j) + 2304, stage1, s),
                        "bn_bwd_finalize");
-                BF_HIP(bf_launch_bn_bwd_apply(g, C(i, j), w + L.coef, C(i, j), npix, s), "bn_bwd_apply");
-                dy = C(i, j);
+                if (!fused_bwd) {
+                    BF_HIP(bf_launch_bn_bwd_apply(g, C(i, j), w + L.coef, C(i, j), npix, s), "bn_bwd_apply");
+                    dy = C(i, j);
+                }
+            }
+            if (fused_bwd) {
+                // one kernel: [dc = k1 g + k2 c + k3] ; dw = x^T dc ; dx = dgrad(dc) [* mask | + skip]
+                BwdH3Args fa;
+                memset(&fa, 0, sizeof(fa));
+                fa.B = B; fa.H = H; fa.W = W;
+                fa.x = j == 0 ? A(i) : T(i, j);
+                fa.g = g;
+                if (bn) { fa.c = C(i, j); fa.coef = w + L.coef; }
+                fa.wpack = wp + (int64_t)(nb + j) * BF_TRAIN_PACK_STRIDE;
+                fa.wpartial = partial; fa.stats = bwd_stats; fa.reverse = next_reverse();
+                float* out = nullptr;
+                for (int k = 0; k < 3 && !out; ++k)
+                    if (gbuf[k] != g && gbuf[k] != dA) out = gbuf[k];
+                int epi;
+                if (j > 0) {
+                    epi = relu ? EPI_MASK : 0;
+                } else {
+                    fa.res = dA;
+                    if (g != dA) out = dA;                          // in place over the skip gradient (read at the same element only)
+                    epi = EPI_RES;
+                    if (d.use_bn && nb >= 2 && i > 0) { fa.bnc = C(i - 1, nb - 1); epi |= EPI_BNBWD; }
+                }
+                fa.out = out;
+                BF_HIP(bf_launch_bwd3x3_h3(fa, epi, gblk + conv_off(j), s), "bwd3x3_h3");
+                g = out;
+                if (j == 0) dA = out;                               // (one-convolution block: another buffer than before)
+                continue;
             }
             BF_HIP(wgrad(j == 0 ? A(i) : T(i, j), dy, gblk + conv_off(j)), "wgrad");
             ConvArgs ca;
@@ -1097,6 +1146,7 @@ extern "C" int bf_debug_conv3x3(const float* in, const float* w_hwio, float* out
     hipStream_t s = (hipStream_t)stream;
     if (bf_launch_pack_conv(w_hwio, wpack_scratch, transpose_flip, s) != hipSuccess) return BF_EHIP;
     ConvArgs ca;
+    memset(&ca, 0, sizeof(ca));
     ca.in = in; ca.out = out; ca.wpack = wpack_scratch; ca.scale = scale; ca.shift = shift; ca.res = res; ca.mask = mask;
     ca.stats = stats; ca.B = B; ca.H = H; ca.W = W;
     return bf_launch_conv3x3_c16(ca, epi, s) == hipSuccess ? BF_OK : BF_EHIP;

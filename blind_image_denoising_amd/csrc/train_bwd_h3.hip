@@ -1,0 +1,279 @@
+// Backward of one 3x3 16->16 convolution of a residual block in ONE kernel (split-f16 arithmetic, fp32 NHWC tensors):
+//
+//     dw[tap][ci][co] = sum_px x[px + tap][ci] * g[px][co]                    (weight gradient, wgrad3x3_h3_kernel's work)
+//     dx[px][ci]      = sum_tap sum_co g[px - tap][co] * w[tap][ci][co]       (data gradient, conv3x3_h3_kernel's work)
+//
+// and, when the convolution is followed by a BatchNorm, that BatchNorm's backward on the way in:
+// g = k1[c] * dy + k2[c] * conv_out + k3[c] (bn_bwd_apply_kernel's work) formed while the tile is staged.
+//
+// Why one kernel: the training step is HBM-bound (every kernel of it runs at ~5 TB/s).  As three kernels the
+// gradient g is written once and read twice, dy and conv_out are read once more, x twice: 8 tensor passes for the second
+// convolution of a block, 6 for the first.  Here every operand is read once and dx written once: 4 and 5 passes.
+// (bfcnn/train_loop.py:273-294 is what this computes a part of: tape.gradient through backbone_blocks.py:174-246.)
+//
+// Tile = 16 x 32 pixels + 1-pixel halo for x and g, split into hi / lo f16 planes [4][18][34][8 x f16] while staged (the
+// layout of conv3x3_h3_kernel), one image for x, one for g.  The weight gradient reads both images with the transposing
+// ds_read_b64_tr_b16 (pixel index along K; every lane supplies the address of its own 8-byte chunk, so the planar layout
+// serves as well as a pixel-major one), the data gradient streams rows of the g image exactly as conv3x3_h3_kernel does.
+// Persistent workgroups (<= 512) walk the tiles; weight-gradient accumulators and BatchNorm sums stay in registers across
+// tiles and leave as per-workgroup partials (fixed summation order: bitwise reproducible).
+#include "h3_rows.h"
+
+typedef __fp16 tb_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+struct BwdH3Geom {
+    static constexpr int TH = 16, TW = 32, IH = TH + 2, IW = TW + 2, R = 8;
+    // plane stride = 128 mod 256: the transposed reads of a half-wave touch planes 0 and 1 of 8 neighbouring pixels
+    static constexpr int PLANE = ((IH * IW * 16 + 255) / 256) * 256 + 128 - 256;       // 9856 >= 9792
+    static constexpr int IMG = 4 * PLANE;
+    static constexpr int LDS_BYTES = 2 * IMG;                                          // 78,848: two workgroups per CU
+    static_assert(PLANE >= IH * IW * 16 && PLANE % 256 == 128, "plane stride");
+    static_assert(4 * 9 * 256 * 4 <= LDS_BYTES, "weight-gradient reduction reuses the images");
+};
+
+__device__ __forceinline__ h8 tb_tr_operand(const char* img, const int addr)
+{
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const tb_fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) tb_fp16x4*)(img + addr));
+    const tb_fp16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) tb_fp16x4*)(img + addr + 16 * 16));
+    const u2 ua = __builtin_bit_cast(u2, a), ub = __builtin_bit_cast(u2, b);
+    return __builtin_bit_cast(h8, (u4){ua[0], ua[1], ub[0], ub[1]});
+}
+
+template <int EPI>
+struct BwdH3Epi {
+    struct Pre {};
+    enum { EXTRA_MFMA = 0 };
+    const BwdH3Args& a; float inv_s;
+    // per tile (set_tile); the BatchNorm sums live here across tiles (a pointer to kernel locals put them in scratch memory)
+    mutable size_t base; mutable int gy0, gx;
+    mutable f32x4 s1, s2;
+    __device__ __forceinline__ void set_tile(const size_t base_, const int gy0_, const int gx_) const { base = base_; gy0 = gy0_; gx = gx_; }
+    __device__ __forceinline__ Pre pre(const int) const { return Pre{}; }
+    __device__ __forceinline__ f32x4 finish(const int, const f32x4 v, const Pre&) const { return v; }
+    __device__ __forceinline__ void operator()(const int o, const f32x4 av) const
+    {
+        if (gy0 + o < a.H && gx < a.W) {
+            const size_t idx = base + (size_t)o * a.W * 16;
+            f32x4 v = av * inv_s;
+            if (EPI & EPI_MASK) {
+                const f32x4 m = *reinterpret_cast<const f32x4*>(a.x + idx);      // the activated input IS the mask
+                v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+                v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+            }
+            if (EPI & EPI_RES) v += *reinterpret_cast<const f32x4*>(a.res + idx);
+            if (EPI & EPI_BNBWD) { s1 += v; s2 += v * *reinterpret_cast<const f32x4*>(a.bnc + idx); }
+            *reinterpret_cast<f32x4*>(a.out + idx) = v;
+        }
+    }
+};
+
+template <bool BNAPPLY, int EPI>
+__global__ __launch_bounds__(256, 2) void bwd3x3_h3_kernel(BwdH3Args a)
+{
+    using G = BwdH3Geom;
+    extern __shared__ __attribute__((aligned(16))) char tb_lds[];
+    char* xs = tb_lds;
+    char* gs = tb_lds + G::IMG;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+
+    const float inv_s = a.wpack[BF_H3R_WPACK_FLOATS];
+
+    // BatchNorm-backward coefficients of this thread's channel quad (tid & 3 is the quad of every element it stages)
+    f32x4 k1 = {1.f, 1.f, 1.f, 1.f}, k2 = {0.f, 0.f, 0.f, 0.f}, k3 = {0.f, 0.f, 0.f, 0.f};
+    if (BNAPPLY) {
+        k1 = *reinterpret_cast<const f32x4*>(a.coef + (tid & 3) * 4);
+        k2 = *reinterpret_cast<const f32x4*>(a.coef + 16 + (tid & 3) * 4);
+        k3 = *reinterpret_cast<const f32x4*>(a.coef + 32 + (tid & 3) * 4);
+    }
+
+    // transposed-read address of this lane inside a 32-pixel row chunk: pixel 4g + q', channels 4j .. 4j+3 (j = lane & 3)
+    const int tr_off = ((lane & 3) >> 1) * G::PLANE + (4 * (lane >> 4) + ((lane & 15) >> 2)) * 16 + (lane & 1) * 8;
+    f32x4 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const BwdH3Epi<EPI> epi{a, inv_s, 0, 0, 0, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+
+    const int strip = wave & 1, half = wave >> 1;
+    const int px_l = strip * 16 + n;                              // column inside the tile
+    const int o0 = half * G::R;                                   // first output row of this wave
+    const int b1 = (q & 1) * G::PLANE + (o0 * G::IW + px_l) * 16;
+
+    constexpr int NX = (G::IH * G::IW * 4 + 255) / 256;
+    // Tiles are dealt round-robin (tile = workgroup + k * grid): at any moment the grid covers one contiguous window of the
+    // tensors (every HBM channel busy; a contiguous RUN of tiles per workgroup put all workgroups on the same channels and
+    // was 10 % slower), x-neighbours sit on neighbouring workgroups and, with eight tiles per image row, y-neighbours on the
+    // same XCD.  a.reverse walks the window from the end of the tensors to the start: the caller alternates it from launch to
+    // launch, so that a kernel starts on the part of its input the previous kernel wrote last (still in the Infinity Cache).
+    for (int t0 = blockIdx.x; t0 < a.ntiles; t0 += gridDim.x) {
+        const int t = a.reverse ? a.ntiles - 1 - t0 : t0;
+        int tt = t;
+        const int txi = tt % a.tiles_x; tt /= a.tiles_x;
+        const int tyi = tt % a.tiles_y;
+        const int b = tt / a.tiles_y;
+        const int y0 = tyi * G::TH, x0 = txi * G::TW;
+        const size_t img = (size_t)b * a.H * a.W * 16;
+
+        // ---- stage x and g (1-pixel halo, zero outside the image): all loads of a thread first, then split + store ----
+        {
+            f32x4 rx[NX], rg[NX], rc[BNAPPLY ? NX : 1];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int e = tid + i * 256;
+                const int px = e >> 2, quad = e & 3;
+                const int row = px / G::IW, col = px - row * G::IW;
+                const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+                rx[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                rg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (BNAPPLY) rc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (e < G::IH * G::IW * 4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                    const size_t idx = img + ((size_t)gy * a.W + gx) * 16 + quad * 4;
+                    rx[i] = *reinterpret_cast<const f32x4*>(a.x + idx);
+                    rg[i] = *reinterpret_cast<const f32x4*>(a.g + idx);
+                    if (BNAPPLY) rc[i] = *reinterpret_cast<const f32x4*>(a.c + idx);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int e = tid + i * 256;
+                if (e < G::IH * G::IW * 4) {
+                    const int px = e >> 2, quad = e & 3;
+                    const int off = (quad >> 1) * G::PLANE + px * 16 + (quad & 1) * 8;
+                    h4 hi, lo;
+                    h3_split(rx[i], hi, lo);
+                    *reinterpret_cast<h4*>(xs + off) = hi;
+                    *reinterpret_cast<h4*>(xs + off + 2 * G::PLANE) = lo;
+                    f32x4 gv = rg[i];
+                    if (BNAPPLY) {
+                        // dc = k1 dy + k2 c + k3 inside the image, 0 outside (SAME padding of the data gradient)
+                        const int row = px / G::IW, col = px - row * G::IW;
+                        const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+                        const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) gv[k] = in ? fmaf(k1[k], rg[i][k], fmaf(k2[k], rc[i][k], k3[k])) : 0.f;
+                    }
+                    h3_split(gv, hi, lo);
+                    *reinterpret_cast<h4*>(gs + off) = hi;
+                    *reinterpret_cast<h4*>(gs + off + 2 * G::PLANE) = lo;
+                }
+            }
+        }
+        __syncthreads();
+
+        // data-gradient weights: 12 A-operand images (pack_h3_train_kernel, transposed + flipped pack).  Fetched per tile (L2
+        // hits, in flight behind the weight-gradient MFMAs) rather than once per kernel: 52 registers that would otherwise be
+        // live through the staging phase, whose 30 outstanding 16-byte loads per thread then spill (41 VGPRs measured).
+        h8 w[13];
+        {
+            int opaque = 0;
+            asm volatile("" : "+s"(opaque));                    // keeps hipcc from hoisting the loads out of the tile loop
+            const h8* wp = reinterpret_cast<const h8*>(a.wpack + opaque) + lane;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) w[i] = wp[i * 64];
+            w[12] = w[0];
+        }
+
+        // ---- weight gradient: wave handles rows 4w .. 4w+3 of the tile, one K chunk of 32 pixels per row ----
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = 4 * wave + rr;
+            const int gaddr = ((r + 1) * G::IW + 1) * 16 + tr_off;
+            const h8 bh = tb_tr_operand(gs, gaddr);
+            const h8 bl = tb_tr_operand(gs + 2 * G::PLANE, gaddr);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ax = ((r + tap / 3) * G::IW + tap % 3) * 16 + tr_off;
+                const h8 ah = tb_tr_operand(xs, ax);
+                const h8 al = tb_tr_operand(xs + 2 * G::PLANE, ax);
+                acc[tap] = MFMA_H(ah, bh, acc[tap]);
+                acc[tap] = MFMA_H(al, bh, acc[tap]);
+                acc[tap] = MFMA_H(ah, bl, acc[tap]);
+            }
+        }
+
+        // ---- data gradient: 8 rows of one 16-column strip per wave, streamed from the g image ----
+        {
+            const int gx = x0 + px_l;
+            epi.set_tile(img + ((size_t)(y0 + o0) * a.W + gx) * 16 + q * 4, y0 + o0, gx);
+            h3r_rows<G::R, G::IW * 16, 2 * G::PLANE>(gs, b1 + (q >> 1) * 16, b1 + 32 + (q >> 1) * 2 * G::PLANE, w, epi, H3NoHook{});
+        }
+        __syncthreads();                       // images free for the next tile
+    }
+
+    // ---- per-workgroup partials: weight gradient [9][16][16] (D[ci = 4q + j][co = p] per lane), BatchNorm sums [32] ----
+    float* red = reinterpret_cast<float*>(tb_lds);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const f32x4 v = bf_acc_ready(acc[tap]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[(wave * 9 + tap) * 256 + (4 * q + j) * 16 + n] = v[j];
+    }
+    __syncthreads();
+    for (int i = tid; i < 2304; i += 256)
+        a.wpartial[(size_t)blockIdx.x * 2304 + i] = (red[i] + red[2304 + i]) + (red[2 * 2304 + i] + red[3 * 2304 + i]);
+    if (EPI & EPI_BNBWD) {
+        f32x4 s1 = epi.s1, s2 = epi.s2;
+        // over the 16 pixel lanes that share a channel quad, then over the 4 waves (fixed order)
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s1[c] += __shfl_xor(s1[c], m);
+                s2[c] += __shfl_xor(s2[c], m);
+            }
+        }
+        __syncthreads();
+        if (n == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                red[wave * 32 + q * 4 + c] = s1[c];
+                red[wave * 32 + 16 + q * 4 + c] = s2[c];
+            }
+        }
+        __syncthreads();
+        if (tid < 32)
+            a.stats[(size_t)blockIdx.x * 32 + tid] = (red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid]);
+    }
+}
+
+int bf_bwd3x3_h3_grid(int B, int H, int W)
+{
+    using G = BwdH3Geom;
+    const int64_t ntiles = (int64_t)B * ((H + G::TH - 1) / G::TH) * ((W + G::TW - 1) / G::TW);
+    return (int)(ntiles < 512 ? ntiles : 512);
+}
+
+// a.wpartial: [grid][2304] floats, a.stats: [grid][32]; dw <- sum of the partials (fixed order).  epi: 0, EPI_MASK, EPI_RES
+// or EPI_RES | EPI_BNBWD; a.coef != nullptr selects the BatchNorm-backward staging (a.c = the BatchNorm's input).
+// a.out must not alias a.x, a.g or a.c (all three are read with a halo); it may alias a.res.
+hipError_t bf_launch_bwd3x3_h3(const BwdH3Args& a0, int epi, float* dw, hipStream_t s)
+{
+    using G = BwdH3Geom;
+    BwdH3Args a = a0;
+    a.tiles_x = (a.W + G::TW - 1) / G::TW;
+    a.tiles_y = (a.H + G::TH - 1) / G::TH;
+    a.ntiles = a.B * a.tiles_x * a.tiles_y;
+    if (a.out == a.x || a.out == a.g || (a.coef && a.out == a.c)) return hipErrorInvalidValue;
+    const int grid = bf_bwd3x3_h3_grid(a.B, a.H, a.W);
+    const bool bn = a.coef != nullptr;
+#define BF_CASE(BN, E)                                                                                                    \
+    if (bn == BN && epi == (E)) {                                                                                        \
+        const hipError_t ea = bf_set_max_lds(reinterpret_cast<const void*>(bwd3x3_h3_kernel<BN, E>), G::LDS_BYTES);       \
+        if (ea != hipSuccess) return ea;                                                                                 \
+        hipLaunchKernelGGL((bwd3x3_h3_kernel<BN, E>), dim3(grid), dim3(256), G::LDS_BYTES, s, a);                         \
+    } else
+    BF_CASE(true, EPI_MASK)
+    BF_CASE(true, 0)
+    BF_CASE(false, EPI_MASK)
+    BF_CASE(false, 0)
+    BF_CASE(false, EPI_RES)
+    BF_CASE(false, EPI_RES | EPI_BNBWD)
+    return hipErrorInvalidValue;
+#undef BF_CASE
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return bf_launch_reduce_partials(a.wpartial, grid, 2304, dw, 1.0f, s);
+}
