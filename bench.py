@@ -405,15 +405,27 @@ def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
         # algorithmic FLOPs per image: fwd + dgrad + wgrad of every 3x3 16->16 conv, fwd + wgrad of the base conv, head fwd + bwd
         per_px = 3 * args.layers * FLOP_PER_PX_BLOCK + 2 * 2 * 9 * 3 * 16 + 3 * 2 * (16 * 32 + 32 * 3)
         value = B * world * args.steps / elapsed
-        # dominant kernel (36 of the ~240 launches of a step, ~18 % of its time): the split-f16 weight gradient; reads x and
-        # dy once (2 * 64 B per pixel).  Timed live with events on the launch stream through the C ABI's single-kernel entry.
+        # dominant kernel (18 of the ~150 launches of a step, ~26 % of its time; its sibling for a block's first convolution
+        # takes as long): the fused backward of a block's second convolution -- BatchNorm-backward apply on load, weight
+        # gradient, masked data gradient.  Algorithmic bytes: dy, conv_out and x read once, dx written once (4 * 64 B per pixel).
+        # Timed live with events on the launch stream through the C ABI's single-kernel entry.
         from blind_image_denoising_amd import _native as N
         L = N.lib()
-        xw = torch.randn((B, S, S, 16), device="cuda")
-        dyw = torch.randn((B, S, S, 16), device="cuda") * 0.1
+        xw = torch.relu(torch.randn((B, S, S, 16), device="cuda"))
+        gw = torch.randn((B, S, S, 16), device="cuda") * 0.1
+        cw = torch.randn((B, S, S, 16), device="cuda")
+        coef = torch.cat([torch.ones(16), torch.full((16,), 0.1), torch.full((16,), 0.01)]).cuda()
+        wk = torch.randn((3, 3, 16, 16), device="cuda") * 0.1
+        dxw = torch.empty_like(xw)
         dw = torch.empty(2304, device="cuda")
-        part = torch.empty(int(L.bf_debug_wgrad_partial_floats(B, S, S)), device="cuda")
-        wg = lambda: N.check(L.bf_debug_wgrad3x3_h3(N.ptr(xw), N.ptr(dyw), N.ptr(part), N.ptr(dw), B, S, S, N.stream_ptr(xw)), None, "wgrad")
+        scr = torch.empty(int(L.bf_debug_bwd3x3_h3_scratch_floats(B, S, S)), device="cuda")
+        calls = [0]
+
+        def wg():
+            N.check(L.bf_debug_bwd3x3_h3(N.ptr(xw), N.ptr(gw), N.ptr(cw), N.ptr(coef), N.ptr(wk), N.ptr(dxw), None, None, N.ptr(dw),
+                                         None, N.ptr(scr), B, S, S, N.EPI_MASK, calls[0] & 1, 1 if calls[0] == 0 else 0,
+                                         N.stream_ptr(xw)), None, "bwd3x3_h3")
+            calls[0] += 1
         for _ in range(3):
             wg()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -423,8 +435,8 @@ def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
             wg()
         e1.record()
         torch.cuda.synchronize()
-        launch_us = e0.elapsed_time(e1) * 1e3 / nl            # wgrad kernel + its 7 us partial reduction
-        wbytes = B * S * S * 16 * 4 * 2
+        launch_us = e0.elapsed_time(e1) * 1e3 / nl            # the kernel + the 7 us reduction of its weight-gradient partials
+        wbytes = B * S * S * 16 * 4 * 4
         gbs = wbytes / launch_us / 1e3
         rec = {
             "metric": "training images/sec (256x256x3), resnet_1x18 data-parallel step", "value": value, "unit": "images/s",
@@ -437,9 +449,9 @@ def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
             "last_total_loss": float(total.item()),
             "end_to_end_tflops": value / world * per_px * S * S / 1e12,
-            "roofline": {"bound": "hbm", "kernel": "wgrad3x3_h3_kernel (+ reduce_partials_kernel)", "achieved": gbs, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "bwd3x3_h3_kernel<true, 8> (+ reduce_partials_kernel)", "achieved": gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": wbytes,
-                         "launch_us": launch_us, "launches_per_step": 2 * args.layers}}
+                         "launch_us": launch_us, "launches_per_step": args.layers}}
         if world == 1 and not args.no_cpu_baseline:
             # the oracle's training step (fp64 NumPy restatement) on ONE image of the same shape
             cfg1 = O.canonical_config(no_layers=args.layers)

@@ -20,7 +20,7 @@ BF_MODE_INFERENCE, BF_MODE_TRAIN = 0, 1
 BF_LOSS_COUNT = 8
 (BF_LOSS_TOTAL, BF_LOSS_DENOISER_TOTAL, BF_LOSS_MAE, BF_LOSS_MSE, BF_LOSS_SSIM,
  BF_LOSS_REGULARIZATION, BF_LOSS_MODEL_TOTAL, BF_LOSS_GRAD_NORM) = range(8)
-EPI_RELU, EPI_AFFINE, EPI_RES, EPI_MASK, EPI_STATS = 1, 2, 4, 8, 16
+EPI_RELU, EPI_AFFINE, EPI_RES, EPI_MASK, EPI_STATS, EPI_BNBWD = 1, 2, 4, 8, 16, 32
 
 
 class ResnetDesc(C.Structure):
@@ -136,6 +136,10 @@ SIGNATURES = {
     "bf_debug_wgrad_partial_floats": (_I64, [_I, _I, _I]),
     "bf_debug_wgrad3x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "bf_debug_wgrad3x3_h3": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "bf_debug_conv3x3_h3_pre": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "bf_debug_bwd3x3_h3_scratch_floats": (_I64, [_I, _I, _I]),
+    "bf_debug_bwd3x3_h3_grid": (_I, [_I, _I, _I]),
+    "bf_debug_bwd3x3_h3": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "bf_debug_mfma_probe": (_I, [_P, _P, _P, _P]),
 }
 

@@ -59,6 +59,9 @@ struct ConvArgs {
     const float* bnc;     // [B,H,W,16] (EPI_BNBWD): raw convolution output c of the BatchNorm whose backward comes next
     int B, H, W;
     int reverse;          // conv3x3_h3_kernel: tiles from the last to the first (Infinity Cache reuse across launches)
+    // conv3x3_h3_kernel, "affine + add on load" (pre_c != nullptr): the convolution's input is y = in + pre_scale * pre_c +
+    // pre_shift (the BatchNorm apply + skip Add of the block in front), formed while the tile is staged and written to pre_out
+    const float* pre_c; const float* pre_scale; const float* pre_shift; float* pre_out;
 };
 
 struct FusedBlockArgs {

@@ -35,6 +35,7 @@ struct bf_engine {
     // 0 = exact fp32 on the f32 matrix cores; the weight gradients follow the same switch
     int train_arith = 1;
     int train_zigzag = 1;           // split-f16 training: consecutive kernels walk their tiles in opposite directions
+    int train_fused_fwd = 1;        // split-f16 training: BatchNorm apply + skip Add of block i formed while block i+1's first convolution stages its tile
     int train_fused_bwd = 1;        // split-f16 training: weight + data gradient (+ BatchNorm backward) of a convolution in one kernel
     // optional HIP-event bracket around the residual-block launches of a forward (bench.py roofline)
     int timing = 0;
@@ -196,6 +197,7 @@ extern "C" int bf_set_option(bf_handle h, const char* key, int value)
     if (!strcmp(key, "h3_zigzag")) { h->h3_zigzag = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "fused_head")) { h->fused_head = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_zigzag")) { h->train_zigzag = value ? 1 : 0; return BF_OK; }
+    if (!strcmp(key, "train_fused_fwd")) { h->train_fused_fwd = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_fused_bwd")) { h->train_fused_bwd = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_arith")) { h->train_arith = value < 0 ? 1 : (value ? 1 : 0); return BF_OK; }
     if (!strcmp(key, "arith")) { h->arith = value < 0 ? 1 : (value ? 1 : 0); return BF_OK; }
@@ -793,6 +795,7 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     BF_HIP(bf_launch_base_conv(ba, s), "base_conv");
     const int conv_grid = bf_conv3x3_c16_grid(B, H, W);
     const bool relu = d.activation == BF_ACT_RELU;
+    bool pending_affine = false;
     for (int i = 0; i < N; ++i) {
         const float* wp = w + L.wpack + (int64_t)i * 2 * nb * BF_TRAIN_PACK_STRIDE;        // forward packs 0..nb-1, then data-gradient packs
         for (int j = 0; j < nb; ++j) {
@@ -801,6 +804,12 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
             memset(&ca, 0, sizeof(ca));
             ca.B = B; ca.H = H; ca.W = W;
             ca.in = j == 0 ? A(i) : T(i, j); ca.wpack = wp + (int64_t)j * BF_TRAIN_PACK_STRIDE;
+            if (j == 0 && pending_affine) {
+                // A(i) = A(i-1) + scale * C(i-1, last) + shift has not been formed yet: this convolution does it on load
+                ca.in = A(i - 1); ca.pre_c = C(i - 1, nb - 1); ca.pre_out = A(i);
+                ca.pre_scale = w + L.bn_scale + bn_idx(i - 1, nb - 1) * 32; ca.pre_shift = ca.pre_scale + 16;
+                pending_affine = false;
+            }
             if (bn) {
                 // conv -> BatchNorm (batch statistics ride in the convolution's epilogue) -> [activation | + skip]
                 float* scale = w + L.bn_scale + bn_idx(i, j) * 32;
@@ -809,7 +818,8 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
                 BF_HIP(bf_launch_bn_finalize(partial, conv_grid, count, params + h->p_blocks + i * h->p_block_stride + conv_off(j) + 2304,
                                              state + bn_idx(i, j) * 32, state + bn_idx(i, j) * 32 + 16, d.bn_eps, d.bn_momentum, scale,
                                              scale + 16, w + L.bn_meaninv + bn_idx(i, j) * 32, stage1, s), "bn_finalize");
-                if (last) BF_HIP(bf_launch_affine_add(A(i), C(i, j), scale, scale + 16, A(i + 1), npix, s), "affine_add");
+                if (last && h3t && h->train_fused_fwd && i + 1 < N && nb >= 2) pending_affine = true;      // block i+1's conv_0 forms A(i+1)
+                else if (last) BF_HIP(bf_launch_affine_add(A(i), C(i, j), scale, scale + 16, A(i + 1), npix, s), "affine_add");
                 else BF_HIP(bf_launch_affine_act(C(i, j), scale, scale + 16, T(i, j + 1), relu, npix, s), "affine_act");
             } else if (last) {
                 // no BatchNorm on the block's last convolution (one-convolution block, or use_bn off): linear, + skip
@@ -1233,6 +1243,55 @@ extern "C" int bf_debug_conv3x3_h3(const float* in, const float* w_hwio, float* 
     ca.in = in; ca.out = out; ca.wpack = scratch + (transpose_flip ? 2 : 0) * BF_H3_TRAIN_PACK_FLOATS;
     ca.res = res; ca.mask = mask; ca.stats = stats; ca.B = B; ca.H = H; ca.W = W;
     return bf_launch_conv3x3_h3(ca, epi, s) == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// conv3x3_h3 with "affine + add on load": y = in + pre_scale * pre_c + pre_shift -> pre_out ; out = [relu] conv(y)
+extern "C" int bf_debug_conv3x3_h3_pre(const float* in, const float* pre_c, const float* pre_scale, const float* pre_shift,
+                                       float* pre_out, const float* w_hwio, float* out, float* scratch, int B, int H, int W, int relu,
+                                       int reverse, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    float* params = scratch + 4 * BF_H3_TRAIN_PACK_FLOATS;
+    if (hipMemcpyAsync(params, w_hwio, 2304 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;
+    if (hipMemcpyAsync(params + 2304, w_hwio, 2304 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;
+    if (bf_launch_pack_h3_train(params, 0, 4608 + 16, scratch, 1, 2, 2320, s) != hipSuccess) return BF_EHIP;
+    ConvArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.in = in; ca.out = out; ca.wpack = scratch; ca.B = B; ca.H = H; ca.W = W; ca.reverse = reverse;
+    ca.pre_c = pre_c; ca.pre_scale = pre_scale; ca.pre_shift = pre_shift; ca.pre_out = pre_out;
+    return bf_launch_conv3x3_h3(ca, relu ? EPI_RELU : 0, s) == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// the fused backward kernel of one convolution (train_bwd_h3.hip): dw = x^T g', dx = dgrad(g') [* (x > 0) | + res], with
+// g' = k1 g + k2 c + k3 when coef is given; stats (EPI_BNBWD): [grid][32] partials of (sum dx, sum dx * bnc).
+// scratch: bf_debug_bwd3x3_h3_scratch_floats(B, H, W) floats
+extern "C" int64_t bf_debug_bwd3x3_h3_scratch_floats(int B, int H, int W)
+{
+    return bf_debug_conv3x3_h3_scratch_floats() + (int64_t)bf_bwd3x3_h3_grid(B, H, W) * (2304 + 32);
+}
+extern "C" int bf_debug_bwd3x3_h3_grid(int B, int H, int W) { return bf_bwd3x3_h3_grid(B, H, W); }
+extern "C" int bf_debug_bwd3x3_h3(const float* x, const float* g, const float* c, const float* coef, const float* w_hwio, float* out,
+                                  const float* res, const float* bnc, float* dw, float* stats, float* scratch, int B, int H, int W,
+                                  int epi, int reverse, int repack, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (repack) {
+        float* params = scratch + 4 * BF_H3_TRAIN_PACK_FLOATS;
+        if (hipMemcpyAsync(params, w_hwio, 2304 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;
+        if (hipMemcpyAsync(params + 2304, w_hwio, 2304 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;
+        if (bf_launch_pack_h3_train(params, 0, 4608 + 16, scratch, 1, 2, 2320, s) != hipSuccess) return BF_EHIP;
+    }
+    float* partial = scratch + bf_debug_conv3x3_h3_scratch_floats();
+    BwdH3Args a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.g = g; a.c = c; a.coef = coef; a.wpack = scratch + 2 * BF_H3_TRAIN_PACK_FLOATS; a.out = out; a.res = res; a.bnc = bnc;
+    a.wpartial = partial; a.stats = partial + (int64_t)bf_bwd3x3_h3_grid(B, H, W) * 2304;
+    a.B = B; a.H = H; a.W = W; a.reverse = reverse;
+    if (bf_launch_bwd3x3_h3(a, epi, dw, s) != hipSuccess) return BF_EHIP;
+    if (stats && (epi & EPI_BNBWD) &&
+        hipMemcpyAsync(stats, a.stats, (size_t)bf_bwd3x3_h3_grid(B, H, W) * 32 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return BF_EHIP;
+    return BF_OK;
 }
 
 extern "C" int64_t bf_debug_wgrad_partial_floats(int B, int H, int W) { return (int64_t)bf_wgrad_grid(B, H, W) * 2304; }

@@ -1020,7 +1020,7 @@ struct ConvH3Geom {
     static constexpr int LDS_BYTES = 4 * PLANE;
 };
 
-template <int EPI>
+template <int EPI, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_h3_kernel(ConvArgs a)
 {
     using G = ConvH3Geom;
@@ -1035,7 +1035,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h3_kernel(ConvArgs a)
     const int b = t / tiles_y;
     const int y0 = ty * G::TH, x0 = tx * G::TW;
     const size_t img = (size_t)b * a.H * a.W * 16;
-    const float* inb = a.in + img;
 
     // weights: 12 A-operand images + 1/s (pack_h3_train_kernel)
     h8 w[13];
@@ -1049,7 +1048,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h3_kernel(ConvArgs a)
     // per element: hipcc does not pipeline it)
     {
         constexpr int NX = (G::IH * G::IW * 4 + 255) / 256;
-        f32x4 rx[NX];
+        f32x4 rx[NX], rc[PRE ? NX : 1];
+        f32x4 psc = {0.f, 0.f, 0.f, 0.f}, psh = {0.f, 0.f, 0.f, 0.f};
+        if (PRE) {                              // tid & 3 is the channel quad of every element this thread stages
+            psc = *reinterpret_cast<const f32x4*>(a.pre_scale + (tid & 3) * 4);
+            psh = *reinterpret_cast<const f32x4*>(a.pre_shift + (tid & 3) * 4);
+        }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int e = tid + i * 256;
@@ -1057,16 +1061,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h3_kernel(ConvArgs a)
             const int row = px / G::IW, col = px - row * G::IW;
             const int gy = y0 - 1 + row, gx = x0 - 1 + col;
             rx[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (e < G::IH * G::IW * 4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                rx[i] = *reinterpret_cast<const f32x4*>(inb + ((size_t)gy * a.W + gx) * 16 + quad * 4);
+            if (PRE) rc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (e < G::IH * G::IW * 4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                const size_t idx = img + ((size_t)gy * a.W + gx) * 16 + quad * 4;
+                rx[i] = *reinterpret_cast<const f32x4*>(a.in + idx);
+                if (PRE) rc[i] = *reinterpret_cast<const f32x4*>(a.pre_c + idx);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int e = tid + i * 256;
             if (e < G::IH * G::IW * 4) {
                 const int px = e >> 2, quad = e & 3;
+                f32x4 v = rx[i];
+                if (PRE) {
+                    // y = x + (scale * c + shift) as affine_add_kernel rounds it; 0 outside the image (SAME padding); the tile's
+                    // own pixels (not the halo, which the neighbours own) go back to HBM: the block input the backward pass needs
+                    const int row = px / G::IW, col = px - row * G::IW;
+                    const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+                    const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = in ? rx[i][k] + fmaf(psc[k], rc[i][k], psh[k]) : 0.f;
+                    if (in && row >= 1 && row <= G::TH && col >= 1 && col <= G::TW)
+                        *reinterpret_cast<f32x4*>(a.pre_out + img + ((size_t)gy * a.W + gx) * 16 + quad * 4) = v;
+                }
                 h4 hi, lo;
-                h3_split(rx[i], hi, lo);
+                h3_split(v, hi, lo);
                 char* p = tile + (quad >> 1) * G::PLANE + px * 16 + (quad & 1) * 8;
                 *reinterpret_cast<h4*>(p) = hi;
                 *reinterpret_cast<h4*>(p + 2 * G::PLANE) = lo;
@@ -1145,6 +1165,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h3_kernel(ConvArgs a)
 hipError_t bf_launch_conv3x3_h3(const ConvArgs& a, int epi, hipStream_t s)
 {
     const dim3 grid(bf_conv3x3_c16_grid(a.B, a.H, a.W)), block(256);
+    if (a.pre_c) {
+        // affine + add on load: in front of a block's first convolution only ([activation] epilogue)
+        if (!a.pre_scale || !a.pre_shift || !a.pre_out || a.pre_out == a.in || a.pre_out == a.pre_c) return hipErrorInvalidValue;
+        if (epi == EPI_RELU) hipLaunchKernelGGL((conv3x3_h3_kernel<EPI_RELU, true>), grid, block, 0, s, a);
+        else if (epi == 0) hipLaunchKernelGGL((conv3x3_h3_kernel<0, true>), grid, block, 0, s, a);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
 #define BF_CASE(E) case E: hipLaunchKernelGGL(conv3x3_h3_kernel<E>, grid, block, 0, s, a); break;
     switch (epi) {
         BF_CASE(0)

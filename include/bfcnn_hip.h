@@ -410,7 +410,10 @@ int bf_op_axpy(float* y, const float* x, float a, int overwrite, int64_t n, void
  *   fp32 accumulation) on the f16 matrix cores, ~fp32 accuracy, needs |activation| < 65504;
  *   0: exact fp32 on the f32 matrix cores.  Training and the unfused path are always exact fp32.
  * "train_arith" = 1 (default): the training convolutions (forward, data gradient, weight gradient) run split-f16 on the
- *   f16 matrix cores; 0: exact fp32.
+ *   f16 matrix cores; 0: exact fp32.  With it (all default 1, A/B only): "train_fused_bwd" = weight gradient, data gradient
+ *   and the BatchNorm-backward apply of a convolution in one kernel; "train_fused_fwd" = a block's BatchNorm apply + skip Add
+ *   formed by the next block's first convolution while it stages its tile; "train_zigzag" = consecutive tile kernels walk the
+ *   tensors in opposite directions (Infinity Cache reuse).
  * "fused_head" = 1: with split-f16 blocks, a linear denoiser head and 3 output channels, the head (premultiplied 16 x 3
  *   matrix, tanh, denormalise, rounding) runs in the epilogue of the last block: no head kernel, the last block output is
  *   never written; 0 (default): separate head kernel (the two measure within 0.5 % of each other).
@@ -449,6 +452,19 @@ int bf_debug_wgrad3x3(const float* x, const float* dy, float* partial, float* dw
                       int batch, int height, int width, void* stream);
 int bf_debug_wgrad3x3_h3(const float* x, const float* dy, float* partial, float* dw,
                          int batch, int height, int width, void* stream);
+/* split-f16 training kernels of bf_train_step, one at a time (tests, bench.py's live roofline):
+   conv3x3_h3 with the BatchNorm apply + skip Add of the block in front formed on load (y = in + pre_scale * pre_c + pre_shift
+   -> pre_out; out = [relu] conv(y)); and the fused backward of one convolution: dw = x^T g', dx = dgrad(g') [* (x > 0) with
+   epi 8 | + res with epi 4 | + sums of dx and dx * bnc with epi 4 + 32], g' = coef[0:16] * g + coef[16:32] * c + coef[32:48]
+   when coef is not NULL (the BatchNorm backward of bfcnn/backbone_blocks.py:214-240's BatchNormalization). */
+int bf_debug_conv3x3_h3_pre(const float* in, const float* pre_c, const float* pre_scale, const float* pre_shift, float* pre_out,
+                            const float* w_hwio, float* out, float* scratch, int batch, int height, int width, int relu,
+                            int reverse, void* stream);
+int64_t bf_debug_bwd3x3_h3_scratch_floats(int batch, int height, int width);
+int bf_debug_bwd3x3_h3_grid(int batch, int height, int width);
+int bf_debug_bwd3x3_h3(const float* x, const float* g, const float* c, const float* coef, const float* w_hwio, float* out,
+                       const float* res, const float* bnc, float* dw, float* stats, float* scratch, int batch, int height,
+                       int width, int epi, int reverse, int repack, void* stream);
 int bf_debug_mfma_probe(const float* a, const float* b, float* d, void* stream);
 
 #ifdef __cplusplus

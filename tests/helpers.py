@@ -106,3 +106,39 @@ def wgrad_gpu(x, dy, h3=False):
     rc = fn(N.ptr(xd), N.ptr(dd), N.ptr(partial), N.ptr(dw), B, H, W, N.stream_ptr(xd))
     assert rc == 0, rc
     return host(dw)
+
+
+def conv3x3_h3_pre_gpu(x, c, scale, shift, w, relu=1, reverse=0):
+    """conv3x3_h3 with the affine + add formed on load: returns (y = x + scale * c + shift, [relu] conv(y))."""
+    L = N.lib()
+    B, H, W, _ = x.shape
+    xd, cd, sd, hd, wd = dev(x), dev(c), dev(scale), dev(shift), dev(w)
+    y = torch.full((B, H, W, 16), float("nan"), dtype=torch.float32, device="cuda")
+    out = torch.full((B, H, W, 16), float("nan"), dtype=torch.float32, device="cuda")
+    scratch = torch.full((int(L.bf_debug_conv3x3_h3_scratch_floats()),), float("nan"), dtype=torch.float32, device="cuda")
+    rc = L.bf_debug_conv3x3_h3_pre(N.ptr(xd), N.ptr(cd), N.ptr(sd), N.ptr(hd), N.ptr(y), N.ptr(wd), N.ptr(out), N.ptr(scratch),
+                                   B, H, W, relu, reverse, N.stream_ptr(xd))
+    assert rc == 0, rc
+    return host(y), host(out)
+
+
+def bwd3x3_h3_gpu(x, g, w, epi, c=None, coef=None, res=None, bnc=None, reverse=0):
+    """the fused backward kernel of one convolution: returns (dx, dw[, stats [grid, 32]])."""
+    L = N.lib()
+    B, H, W, _ = x.shape
+    xd, gd, wd = dev(x), dev(g), dev(w)
+    cd = dev(c) if c is not None else None
+    kd = dev(coef) if coef is not None else None
+    rd = dev(res) if res is not None else None
+    bd = dev(bnc) if bnc is not None else None
+    out = torch.full((B, H, W, 16), float("nan"), dtype=torch.float32, device="cuda")
+    dw = torch.full((3, 3, 16, 16), float("nan"), dtype=torch.float32, device="cuda")
+    grid = L.bf_debug_bwd3x3_h3_grid(B, H, W)
+    stats = torch.full((grid * 32,), float("nan"), dtype=torch.float32, device="cuda") if epi & N.EPI_BNBWD else None
+    scratch = torch.full((int(L.bf_debug_bwd3x3_h3_scratch_floats(B, H, W)),), float("nan"), dtype=torch.float32, device="cuda")
+    rc = L.bf_debug_bwd3x3_h3(N.ptr(xd), N.ptr(gd), N.ptr(cd), N.ptr(kd), N.ptr(wd), N.ptr(out), N.ptr(rd), N.ptr(bd), N.ptr(dw),
+                              N.ptr(stats), N.ptr(scratch), B, H, W, epi, reverse, 1, N.stream_ptr(xd))
+    assert rc == 0, rc
+    if stats is not None:
+        return host(out), host(dw), host(stats).reshape(grid, 32)
+    return host(out), host(dw)

@@ -6,7 +6,7 @@ import torch
 
 from oracle import bfcnn_oracle as O
 from blind_image_denoising_amd import _native as N
-from helpers import assert_close, conv3x3_gpu, conv3x3_h3_gpu, dev, fused_block_gpu, fused_block_h3_gpu, host, wgrad_gpu
+from helpers import bwd3x3_h3_gpu, conv3x3_h3_pre_gpu, assert_close, conv3x3_gpu, conv3x3_h3_gpu, dev, fused_block_gpu, fused_block_h3_gpu, host, wgrad_gpu
 
 pytestmark = pytest.mark.gpu
 
@@ -234,6 +234,77 @@ def test_wgrad3x3(shape, h3):
     x, dy = _rand((B, H, W, 16), 23), _rand((B, H, W, 16), 24)
     ref = O.conv2d_same_grad_kernel(x.astype(np.float64), dy.astype(np.float64), 3, 3)
     assert_close(wgrad_gpu(x, dy, h3), ref, rel=3e-6 * np.sqrt(B * H * W), what=f"wgrad {shape}")
+
+
+# ---- the fused training kernels of the split-f16 step (train_bwd_h3.hip, conv3x3_h3_kernel<.., PRE>) ---------------------
+BWD_SHAPES = SHAPES + [(24, 128, 160)]          # the last one: more tiles (1200) than persistent workgroups (512)
+
+
+@pytest.mark.parametrize("shape", BWD_SHAPES)
+@pytest.mark.parametrize("reverse", [0, 1])
+def test_bwd3x3_h3_second_convolution(shape, reverse):
+    """BatchNorm-backward apply on load + weight gradient + masked data gradient (a block's convolution j >= 1)."""
+    B, H, W = shape
+    x = np.maximum(_rand((B, H, W, 16), 40), 0)                       # activated input: also the mask
+    g, c = _rand((B, H, W, 16), 41), _rand((B, H, W, 16), 42)
+    w = _rand((3, 3, 16, 16), 43) * 0.1
+    coef = np.concatenate([1 + 0.3 * _rand(16, 44), 0.2 * _rand(16, 45), 0.1 * _rand(16, 46)]).astype(np.float32)
+    gp = coef[:16].astype(np.float64) * g + coef[16:32].astype(np.float64) * c + coef[32:].astype(np.float64)
+    ref_dw = O.conv2d_same_grad_kernel(x.astype(np.float64), gp, 3, 3)
+    ref_dx = O.conv2d_same_grad_input(gp, w.astype(np.float64)) * (x > 0)
+    dx, dw = bwd3x3_h3_gpu(x, g, w, N.EPI_MASK, c=c, coef=coef, reverse=reverse)
+    assert_close(dx, ref_dx, what=f"dx {shape}")
+    assert_close(dw, ref_dw, rel=3e-6 * np.sqrt(B * H * W), what=f"dw {shape}")
+    dx0, dw0 = bwd3x3_h3_gpu(x, gp.astype(np.float32), w, 0, reverse=reverse)           # no BatchNorm, linear activation
+    assert_close(dx0, O.conv2d_same_grad_input(gp, w.astype(np.float64)), what=f"dx plain {shape}")
+    assert_close(dw0, ref_dw, rel=3e-6 * np.sqrt(B * H * W), what=f"dw plain {shape}")
+
+
+@pytest.mark.parametrize("shape", BWD_SHAPES)
+def test_bwd3x3_h3_first_convolution(shape):
+    """weight gradient + data gradient + skip gradient, and the sums the BatchNorm backward of the block in front needs."""
+    B, H, W = shape
+    x, g = _rand((B, H, W, 16), 50), _rand((B, H, W, 16), 51)
+    res, bnc = _rand((B, H, W, 16), 52), _rand((B, H, W, 16), 53)
+    w = _rand((3, 3, 16, 16), 54) * 0.1
+    g64 = g.astype(np.float64)
+    ref_dx = O.conv2d_same_grad_input(g64, w.astype(np.float64)) + res
+    ref_dw = O.conv2d_same_grad_kernel(x.astype(np.float64), g64, 3, 3)
+    dx, dw, stats = bwd3x3_h3_gpu(x, g, w, N.EPI_RES | N.EPI_BNBWD, res=res, bnc=bnc)
+    assert_close(dx, ref_dx, what=f"dx {shape}")
+    assert_close(dw, ref_dw, rel=3e-6 * np.sqrt(B * H * W), what=f"dw {shape}")
+    tot = stats.astype(np.float64).sum(axis=0)
+    assert_close(tot[:16], ref_dx.sum(axis=(0, 1, 2)), rel=1e-5 * np.sqrt(ref_dx.size), what="sum dx")
+    assert_close(tot[16:], (ref_dx * bnc).sum(axis=(0, 1, 2)), rel=1e-5 * np.sqrt(ref_dx.size), what="sum dx * c")
+    dx1, dw1 = bwd3x3_h3_gpu(x, g, w, N.EPI_RES, res=res)
+    assert np.array_equal(dx1, dx) and np.array_equal(dw1, dw)
+
+
+def test_bwd3x3_h3_exact_on_integers_and_deterministic():
+    rng = np.random.default_rng(55)
+    x = rng.integers(0, 4, (3, 40, 70, 16)).astype(np.float32)
+    g = rng.integers(-3, 4, (3, 40, 70, 16)).astype(np.float32)
+    w = rng.integers(-3, 4, (3, 3, 16, 16)).astype(np.float32)
+    dx, dw = bwd3x3_h3_gpu(x, g, w, N.EPI_MASK)
+    assert np.array_equal(dw, O.conv2d_same_grad_kernel(x.astype(np.float64), g.astype(np.float64), 3, 3))
+    assert np.array_equal(dx, O.conv2d_same_grad_input(g.astype(np.float64), w.astype(np.float64)) * (x > 0))
+    xr, gr, wr = np.maximum(_rand((3, 40, 70, 16), 56), 0), _rand((3, 40, 70, 16), 57), _rand((3, 3, 16, 16), 58)
+    a, b = bwd3x3_h3_gpu(xr, gr, wr, N.EPI_MASK), bwd3x3_h3_gpu(xr, gr, wr, N.EPI_MASK)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])          # fixed-order reductions
+
+
+@pytest.mark.parametrize("shape", SHAPES + [(4, 70, 40)])
+@pytest.mark.parametrize("relu", [1, 0])
+def test_conv3x3_h3_affine_add_on_load(shape, relu):
+    B, H, W = shape
+    x, c = _rand((B, H, W, 16), 60), _rand((B, H, W, 16), 61)
+    sc, sh = (1 + 0.3 * _rand(16, 62)).astype(np.float32), _rand(16, 63)
+    w = _rand((3, 3, 16, 16), 64) * 0.1
+    y, out = conv3x3_h3_pre_gpu(x, c, sc, sh, w, relu=relu, reverse=shape[0] & 1)
+    y_ref = x + (sc * c + sh)                                     # fp32, the rounding of affine_add_kernel up to the fma
+    assert np.abs(y - y_ref).max() <= 4e-7 * np.abs(y_ref).max()
+    ref = O.conv2d_same(y.astype(np.float64), w.astype(np.float64))
+    assert_close(out, np.maximum(ref, 0) if relu else ref, what=f"conv of the formed input {shape}")
 
 
 @pytest.mark.parametrize("h3", [False, True], ids=["f32", "f16x3"])
