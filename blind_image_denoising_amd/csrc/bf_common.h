@@ -142,6 +142,8 @@ struct BwdH3Args {
 };
 int        bf_bwd3x3_h3_grid(int B, int H, int W);
 hipError_t bf_launch_bwd3x3_h3(const BwdH3Args& a, int epi, float* dw, hipStream_t s);
+hipError_t bf_launch_reduce_wgrad_slots(const float* slots, int64_t slot_floats, int nblk, float* out, int64_t p_stride, int layers,
+                                        int nconv, int unit, hipStream_t s);
 // nconv convolutions per block (forward + data-gradient pack each); unit: floats from one convolution kernel of a block to the
 // next behind the first (2320 with BatchNorm gammas in between, else 2304)
 hipError_t bf_launch_pack_h3_train(const float* params, int64_t p_blocks, int64_t p_stride, float* dst, int layers, int nconv,

@@ -365,8 +365,8 @@ extern "C" int bf_pack_inference(bf_handle h, const float* params, const float* 
 // workspace layout
 // ------------------------------------------------------------------------------------------
 struct TrainLayout {
-    int64_t wpack, wh, bn_scale, bn_meaninv, coef, stage1, partial, acts, extra, total;   // float offsets
-    int64_t act_floats, partial_floats;
+    int64_t wpack, wh, bn_scale, bn_meaninv, coef, stage1, partial, wslots, acts, extra, total;   // float offsets
+    int64_t act_floats, partial_floats, wslot_floats;
 };
 
 static int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
@@ -391,6 +391,9 @@ static TrainLayout train_layout(bf_handle h, int B, int H, int W)
     pf = max64(pf, (int64_t)bf_head_train_grid(B, H, W) * 80);
     L.partial_floats = align_up(pf, 64);
     L.partial = o; o += L.partial_floats + 256;     // +256: reduced head sums / scratch
+    // one weight-gradient partial slot per block convolution (fused backward kernel): summed by ONE launch at the end of the step
+    L.wslot_floats = (int64_t)bf_bwd3x3_h3_grid(B, H, W) * 2304;
+    L.wslots = o; o += L.wslot_floats * N * nb;
     o = align_up(o, 64);
     L.act_floats = (int64_t)B * H * W * 16;
     // A_0..A_N, per block and convolution j >= 1 its input T_j and its raw output C_j, dA + two more gradient buffers (the
@@ -927,7 +930,7 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
                 fa.g = g;
                 if (bn) { fa.c = C(i, j); fa.coef = w + L.coef; }
                 fa.wpack = wp + (int64_t)(nb + j) * BF_TRAIN_PACK_STRIDE;
-                fa.wpartial = partial; fa.stats = bwd_stats; fa.reverse = next_reverse();
+                fa.wpartial = w + L.wslots + ((int64_t)i * nb + j) * L.wslot_floats; fa.stats = bwd_stats; fa.reverse = next_reverse();
                 float* out = nullptr;
                 for (int k = 0; k < 3 && !out; ++k)
                     if (gbuf[k] != g && gbuf[k] != dA) out = gbuf[k];
@@ -941,7 +944,7 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
                     if (d.use_bn && nb >= 2 && i > 0) { fa.bnc = C(i - 1, nb - 1); epi |= EPI_BNBWD; }
                 }
                 fa.out = out;
-                BF_HIP(bf_launch_bwd3x3_h3(fa, epi, gblk + conv_off(j), s), "bwd3x3_h3");
+                BF_HIP(bf_launch_bwd3x3_h3(fa, epi, nullptr, s), "bwd3x3_h3");
                 g = out;
                 if (j == 0) dA = out;                               // (one-convolution block: another buffer than before)
                 continue;
@@ -966,6 +969,9 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
             }
         }
     }
+    if (fused_bwd && N > 0)
+        BF_HIP(bf_launch_reduce_wgrad_slots(w + L.wslots, L.wslot_floats, bwd_grid, grads + h->p_blocks, h->p_block_stride, N, nb, unit, s),
+               "reduce_wgrad_slots");
     BF_HIP(bf_launch_base_wgrad(noisy, dA, partial, grads + h->p_base, B, H, W, d.in_channels, d.kernel_size, d.v_min, d.v_max, s),
            "base_wgrad");
     if (grad_unscale != 1.0f) {

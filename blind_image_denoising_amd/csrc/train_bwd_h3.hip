@@ -46,6 +46,7 @@ struct BwdH3Epi {
     struct Pre {};
     enum { EXTRA_MFMA = 0 };
     const BwdH3Args& a; float inv_s;
+    const char* mask_lds;           // this lane's 4 channels of output row 0 of its strip in the x image (hi plane)
     // per tile (set_tile); the BatchNorm sums live here across tiles (a pointer to kernel locals put them in scratch memory)
     mutable size_t base; mutable int gy0, gx;
     mutable f32x4 s1, s2;
@@ -58,9 +59,11 @@ struct BwdH3Epi {
             const size_t idx = base + (size_t)o * a.W * 16;
             f32x4 v = av * inv_s;
             if (EPI & EPI_MASK) {
-                const f32x4 m = *reinterpret_cast<const f32x4*>(a.x + idx);      // the activated input IS the mask
-                v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
-                v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                // the activated input IS the mask, and its hi half sits in LDS: x > 0 <=> hi > 0 (the staging keeps x >= 2^-24)
+                // (a second global read of the tile missed L2 more often than not: 117 KB per tile, 64 tiles in flight per XCD)
+                const h4 mh = *reinterpret_cast<const h4*>(mask_lds + o * (BwdH3Geom::IW * 16));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = (float)mh[k] > 0.f ? v[k] : 0.f;
             }
             if (EPI & EPI_RES) v += *reinterpret_cast<const f32x4*>(a.res + idx);
             if (EPI & EPI_BNBWD) { s1 += v; s2 += v * *reinterpret_cast<const f32x4*>(a.bnc + idx); }
@@ -95,12 +98,13 @@ __global__ __launch_bounds__(256, 2) void bwd3x3_h3_kernel(BwdH3Args a)
     f32x4 acc[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const BwdH3Epi<EPI> epi{a, inv_s, 0, 0, 0, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 
     const int strip = wave & 1, half = wave >> 1;
     const int px_l = strip * 16 + n;                              // column inside the tile
     const int o0 = half * G::R;                                   // first output row of this wave
     const int b1 = (q & 1) * G::PLANE + (o0 * G::IW + px_l) * 16;
+    const BwdH3Epi<EPI> epi{a, inv_s, xs + (q >> 1) * G::PLANE + ((o0 + 1) * G::IW + px_l + 1) * 16 + (q & 1) * 8, 0, 0, 0,
+                            {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 
     constexpr int NX = (G::IH * G::IW * 4 + 255) / 256;
     // Tiles are dealt round-robin (tile = workgroup + k * grid): at any moment the grid covers one contiguous window of the
@@ -143,7 +147,15 @@ __global__ __launch_bounds__(256, 2) void bwd3x3_h3_kernel(BwdH3Args a)
                     const int px = e >> 2, quad = e & 3;
                     const int off = (quad >> 1) * G::PLANE + px * 16 + (quad & 1) * 8;
                     h4 hi, lo;
-                    h3_split(rx[i], hi, lo);
+                    f32x4 xv = rx[i];
+                    if (EPI & EPI_MASK) {
+                        // the epilogue takes the ReLU mask from this image (x > 0 <=> hi > 0): a positive activation below the
+                        // smallest f16 (2^-24) must not vanish in the split -- it is raised to 2^-24 (one element in 8 million of
+                        // a normal sample; the absolute error stays inside the split's own 2^-25 .. 2^-24 floor)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) xv[k] = xv[k] > 0.f ? fmaxf(xv[k], 0x1p-24f) : xv[k];
+                    }
+                    h3_split(xv, hi, lo);
                     *reinterpret_cast<h4*>(xs + off) = hi;
                     *reinterpret_cast<h4*>(xs + off + 2 * G::PLANE) = lo;
                     f32x4 gv = rg[i];
@@ -246,7 +258,7 @@ int bf_bwd3x3_h3_grid(int B, int H, int W)
     return (int)(ntiles < 512 ? ntiles : 512);
 }
 
-// a.wpartial: [grid][2304] floats, a.stats: [grid][32]; dw <- sum of the partials (fixed order).  epi: 0, EPI_MASK, EPI_RES
+// a.wpartial: [grid][2304] floats, a.stats: [grid][32]; dw <- sum of the partials (fixed order; skipped when dw is nullptr).  epi: 0, EPI_MASK, EPI_RES
 // or EPI_RES | EPI_BNBWD; a.coef != nullptr selects the BatchNorm-backward staging (a.c = the BatchNorm's input).
 // a.out must not alias a.x, a.g or a.c (all three are read with a halo); it may alias a.res.
 hipError_t bf_launch_bwd3x3_h3(const BwdH3Args& a0, int epi, float* dw, hipStream_t s)
@@ -275,5 +287,5 @@ hipError_t bf_launch_bwd3x3_h3(const BwdH3Args& a0, int epi, float* dw, hipStrea
 #undef BF_CASE
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return bf_launch_reduce_partials(a.wpartial, grid, 2304, dw, 1.0f, s);
+    return dw ? bf_launch_reduce_partials(a.wpartial, grid, 2304, dw, 1.0f, s) : hipSuccess;      // nullptr: the caller sums a.wpartial later
 }

@@ -41,6 +41,41 @@ hipError_t bf_launch_reduce_partials(const float* partial, int nblk, int width, 
     return hipGetLastError();
 }
 
+// the weight-gradient partials of ALL convolutions of the blocks in one launch (blockIdx.y = block * nconv + j): slot k holds
+// [nblk][2304]; its sum goes to out + block * p_stride + (j == 0 ? 0 : 2304 + (j - 1) * unit).  Same summation order as above.
+__global__ __launch_bounds__(1024) void reduce_wgrad_slots_kernel(const float* __restrict__ slots, int64_t slot_floats, int nblk,
+                                                                  float* __restrict__ out, int64_t p_stride, int nconv, int unit)
+{
+    __shared__ float red[16][64];
+    const int col = threadIdx.x & 63, stripe = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + col;
+    const int blk = blockIdx.y / nconv, j = blockIdx.y % nconv;
+    const float* partial = slots + (int64_t)blockIdx.y * slot_floats;
+    float s0 = 0.f, s1 = 0.f;
+    int r = stripe;
+    for (; r + 16 < nblk; r += 32) {
+        s0 += partial[(size_t)r * 2304 + i];
+        s1 += partial[(size_t)(r + 16) * 2304 + i];
+    }
+    if (r < nblk) s0 += partial[(size_t)r * 2304 + i];
+    red[stripe][col] = s0 + s1;
+    __syncthreads();
+    if (stripe == 0) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += red[k][col];
+        out[(int64_t)blk * p_stride + (j == 0 ? 0 : 2304 + (int64_t)(j - 1) * unit) + i] = a;
+    }
+}
+
+hipError_t bf_launch_reduce_wgrad_slots(const float* slots, int64_t slot_floats, int nblk, float* out, int64_t p_stride, int layers,
+                                        int nconv, int unit, hipStream_t s)
+{
+    hipLaunchKernelGGL(reduce_wgrad_slots_kernel, dim3(2304 / 64, layers * nconv), dim3(1024), 0, s, slots, slot_floats, nblk, out,
+                       p_stride, nconv, unit);
+    return hipGetLastError();
+}
+
 __global__ void zero_kernel(float* p, int64_t n)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.f;
