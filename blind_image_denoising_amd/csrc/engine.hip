@@ -677,8 +677,9 @@ __global__ __launch_bounds__(1024) void regularizer_kernel(const float* __restri
         if (i < n_base) reg = reg_base;
         else if (i >= p_head0) reg = reg_head;
         else {      // block: conv0 [2304], then per further convolution its kernel [2304] and (with BatchNorm) its gamma [16]
-            const int64_t r = (i - p_blocks) % p_stride;
-            reg = (r < 2304 || ((r - 2304) % unit) < 2304) ? reg_block : BF_REG_NONE;
+            // (32-bit: a 64-bit remainder is ~60 instructions and this single workgroup walks every parameter)
+            const unsigned r = (unsigned)(i - p_blocks) % (unsigned)p_stride;
+            reg = (r < 2304u || ((r - 2304u) % (unsigned)unit) < 2304u) ? reg_block : BF_REG_NONE;
         }
         const float w = wv[u];
         if (reg == BF_REG_L1) {
