@@ -115,6 +115,16 @@ SIGNATURES = {
     "bf_op_resize_bilinear_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "bf_op_reg_elementwise": (_I, [_P, _P, _I64, _I, _F, _F, _P, _P]),
     "bf_op_reg_soft_orthonormal": (_I, [_P, _P, _I, _I, _F, _F, _F, _F, _P, _P, _P]),
+    "bf_op_bn_train_scratch_floats": (_I64, [_I]),
+    "bf_op_bn_train_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I, _F, _F, _I, _F, _P, _I64, _P]),
+    "bf_op_bn_train_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I, _P, _I64, _P]),
+    "bf_op_gate_save_floats": (_I64, [_I, _I, _I]),
+    "bf_op_gate_scratch_floats": (_I64, [_I, _I]),
+    "bf_op_gate_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I64, _I, _I, _P, _I64, _P]),
+    "bf_op_gate_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _I, _P, _I64, _P]),
+    "bf_op_channel_repeat": (_I, [_P, _P, _I64, _I, _I, _P]),
+    "bf_op_channel_group_sum": (_I, [_P, _P, _I64, _I, _I, _P]),
+    "bf_op_group_kernel": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "bf_op_flip_hw": (_I, [_P, _P, _I, _I, _P]),
     "bf_op_transpose2d": (_I, [_P, _P, _I, _I, _P]),
     "bf_comm_unique_id": (_I, [C.c_char_p]),

@@ -1,0 +1,351 @@
+// Training-mode operators of the resnet builder outside the 16-filter 3x3 engine (bfcnn/backbone_resnet.py:36-298,
+// backbone_blocks.py:163-246): BatchNormalization with batch statistics (forward + backward) for any channel count that
+// divides 256, the squeeze-style channel gate of `add_gates` (backbone_blocks.py:199-208: mean over the image -> Dense relu ->
+// Dense hard_sigmoid -> Multiply) forward + backward, and the layout helpers that let depthwise-with-multiplier and grouped
+// convolutions reuse the plain operators (channel repeat / group sum, block-diagonal expand / extract).
+// Exact fp32 tensors, fp64 statistics, fixed summation order (bitwise reproducible), stream-ordered, no allocation.
+// Written for correctness: these networks' training is a parity row (tests/test_gpu_resnet_generic_train.py), not a benchmark.
+#include "bf_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int CS_GRID = 128;          // row chunks per sample (or per tensor) of the column sums
+
+// partial[(s * gridDim.x + blockIdx.x) * 2C + {c, C + c}] = sum over the chunk's rows of a[r][c] and a[r][c] * b[r][c]
+// rows of sample s = blockIdx.y: [s * rows, (s + 1) * rows)
+__global__ __launch_bounds__(256) void tg_colsum2_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t rows, int C,
+                                                         double* __restrict__ partial)
+{
+    __shared__ double r1[256], r2[256];
+    const int tid = threadIdx.x, c = tid % C, rr = tid / C, R = 256 / C;
+    const int64_t base = (int64_t)blockIdx.y * rows;
+    const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < rows ? lo + per : rows;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t r = lo + rr; r < hi; r += R) {
+        const double av = a[(base + r) * C + c], bv = b[(base + r) * C + c];
+        s1 += av;
+        s2 += av * bv;
+    }
+    r1[tid] = s1; r2[tid] = s2;
+    __syncthreads();
+    if (tid < C) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int k = 0; k < R; ++k) { t1 += r1[k * C + tid]; t2 += r2[k * C + tid]; }
+        double* p = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C;
+        p[tid] = t1;
+        p[C + tid] = t2;
+    }
+}
+
+// BatchNorm forward finalisation (keras BatchNormalization(center=False), training=True; fused-kernel moving variance)
+__global__ __launch_bounds__(256) void tg_bn_fwd_finalize_kernel(const double* __restrict__ partial, int nblk, double count, int C,
+                                                                const float* __restrict__ gamma, float eps, float momentum,
+                                                                float* moving_mean, float* moving_var, float* save, float* coef)
+{
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nblk; ++k) { s1 += partial[(int64_t)k * 2 * C + c]; s2 += partial[(int64_t)k * 2 * C + C + c]; }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double inv = 1.0 / sqrt(var + (double)eps), g = gamma[c];
+    save[c] = (float)mean;
+    save[C + c] = (float)inv;
+    coef[c] = (float)(g * inv);                    // y = coef[c] * x + coef[C + c]
+    coef[C + c] = (float)(-g * inv * mean);
+    if (moving_mean) {
+        const double unbiased = var * (count / (count > 1.0 ? count - 1.0 : 1.0));
+        moving_mean[c] = (float)((double)moving_mean[c] * momentum + mean * (1.0 - (double)momentum));
+        moving_var[c] = (float)((double)moving_var[c] * momentum + unbiased * (1.0 - (double)momentum));
+    }
+}
+
+// dgamma = sum dy * xhat ; dx = k1 dy + k2 x + k3 (train_ops.hip bn_bwd_finalize_kernel, any C)
+__global__ __launch_bounds__(256) void tg_bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblk, double count, int C,
+                                                                const float* __restrict__ gamma, const float* __restrict__ save,
+                                                                float* coef, float* dgamma)
+{
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    double sdy = 0.0, sdyx = 0.0;
+    for (int k = 0; k < nblk; ++k) { sdy += partial[(int64_t)k * 2 * C + c]; sdyx += partial[(int64_t)k * 2 * C + C + c]; }
+    const double mean = save[c], inv = save[C + c], g = gamma[c];
+    const double sdyh = (sdyx - mean * sdy) * inv;            // sum dy * xhat
+    dgamma[c] = (float)sdyh;
+    const double mdy = sdy / count, mdyh = sdyh / count;
+    coef[c] = (float)(g * inv);
+    coef[C + c] = (float)(-g * inv * inv * mdyh);
+    coef[2 * C + c] = (float)(-g * inv * mdy + g * inv * inv * mean * mdyh);
+}
+
+__device__ __forceinline__ float tg_act(float v, int act, float alpha)
+{
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return v > 0.f ? v : alpha * v;
+    return v;
+}
+
+// out = act(k1[c] * a + k2[c] * b + k3[c])   (b, k2, k3 optional)
+__global__ __launch_bounds__(256) void tg_lincomb_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         const float* __restrict__ k1, const float* __restrict__ k2,
+                                                         const float* __restrict__ k3, float* __restrict__ out, int64_t n, int C, int act,
+                                                         float alpha)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        float v = k1[c] * a[i];
+        if (b) v = fmaf(k2[c], b[i], v);
+        if (k3) v += k3[c];
+        out[i] = tg_act(v, act, alpha);
+    }
+}
+
+// ---- channel gate (backbone_blocks.py:199-208) -------------------------------------------------------------------------
+// one workgroup per sample: m = mean over the image ; h = relu(m W0) ; g = hard_sigmoid(h W1) = clip(0.2 p + 0.5, 0, 1)
+// save: [B][C] mean | [B][C8] h (post relu) | [B][C] p (pre hard_sigmoid) | [B][C] g
+__global__ __launch_bounds__(256) void tg_gate_dense_kernel(const double* __restrict__ partial, int nblk, double hw, int C, int C8,
+                                                            const float* __restrict__ w0, const float* __restrict__ w1, int B,
+                                                            float* __restrict__ save)
+{
+    __shared__ float m[256], h[64];
+    const int b = blockIdx.x, t = threadIdx.x;
+    float* s_mean = save + (int64_t)b * C;
+    float* s_h = save + (int64_t)B * C + (int64_t)b * C8;
+    float* s_p = save + (int64_t)B * (C + C8) + (int64_t)b * C;
+    float* s_g = save + (int64_t)B * (2 * C + C8) + (int64_t)b * C;
+    if (t < C) {
+        double s = 0.0;
+        for (int k = 0; k < nblk; ++k) s += partial[((int64_t)b * nblk + k) * 2 * C + t];
+        m[t] = (float)(s / hw);
+        s_mean[t] = m[t];
+    }
+    __syncthreads();
+    if (t < C8) {
+        float a = 0.f;
+        for (int c = 0; c < C; ++c) a = fmaf(m[c], w0[c * C8 + t], a);
+        h[t] = fmaxf(a, 0.f);
+        s_h[t] = h[t];
+    }
+    __syncthreads();
+    if (t < C) {
+        float p = 0.f;
+        for (int j = 0; j < C8; ++j) p = fmaf(h[j], w1[j * C + t], p);
+        s_p[t] = p;
+        s_g[t] = fminf(fmaxf(0.2f * p + 0.5f, 0.f), 1.f);
+    }
+}
+
+// out = x * g[b][c] (+ res)
+__global__ __launch_bounds__(256) void tg_gate_mul_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                          const float* __restrict__ add_bc, float add_scale,
+                                                          const float* __restrict__ res, float* __restrict__ out, int64_t hwC, int C,
+                                                          int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / hwC;
+        const int c = (int)(i % C);
+        float v = x[i] * g[b * C + c];
+        if (add_bc) v = fmaf(add_bc[b * C + c], add_scale, v);
+        if (res) v += res[i];
+        out[i] = v;
+    }
+}
+
+// single workgroup, samples in order (fixed summation order): dg[b][c] = sum_hw dy * x (from the partials) ->
+// dp = dg * 0.2 [|p| < 2.5] ; dW1 += h^T dp ; dh = dp W1^T * [h > 0] ; dW0 += m^T dh ; dmean[b] = dh W0^T
+__global__ __launch_bounds__(256) void tg_gate_dense_bwd_kernel(const double* __restrict__ partial, int nblk, int C, int C8, int B,
+                                                                const float* __restrict__ w0, const float* __restrict__ w1,
+                                                                const float* __restrict__ save, float* __restrict__ dw0,
+                                                                float* __restrict__ dw1, float* __restrict__ dmean)
+{
+    __shared__ float dp[256], dh[64], m[256], h[64];
+    const int t = threadIdx.x;
+    // accumulators: thread t owns dw1[:, t] (t < C) and dw0[t, :] (t < C)
+    float a1[32], a0[32];                      // C8 <= 32
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { a1[j] = 0.f; a0[j] = 0.f; }
+    for (int b = 0; b < B; ++b) {
+        const float* s_mean = save + (int64_t)b * C;
+        const float* s_h = save + (int64_t)B * C + (int64_t)b * C8;
+        const float* s_p = save + (int64_t)B * (C + C8) + (int64_t)b * C;
+        if (t < C) {
+            double s = 0.0;
+            for (int k = 0; k < nblk; ++k) s += partial[((int64_t)b * nblk + k) * 2 * C + C + t];
+            const float p = s_p[t];
+            dp[t] = (p > -2.5f && p < 2.5f) ? 0.2f * (float)s : 0.f;
+            m[t] = s_mean[t];
+        }
+        if (t < C8) h[t] = s_h[t];
+        __syncthreads();
+        if (t < C8) {
+            float a = 0.f;
+            for (int c = 0; c < C; ++c) a = fmaf(dp[c], w1[t * C + c], a);
+            dh[t] = h[t] > 0.f ? a : 0.f;
+        }
+        __syncthreads();
+        if (t < C) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j)
+                if (j < C8) { a1[j] = fmaf(h[j], dp[t], a1[j]); a0[j] = fmaf(m[t], dh[j], a0[j]); }
+            float d = 0.f;
+            for (int j = 0; j < C8; ++j) d = fmaf(dh[j], w0[t * C8 + j], d);
+            dmean[(int64_t)b * C + t] = d;
+        }
+        __syncthreads();
+    }
+    if (t < C) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+            if (j < C8) { dw1[j * C + t] = a1[j]; dw0[t * C8 + j] = a0[j]; }
+    }
+}
+
+// out[r][c * m + j] = x[r][c]
+__global__ __launch_bounds__(256) void tg_repeat_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n_out, int C, int m)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_out; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / (C * m);
+        const int cm = (int)(i % (C * m));
+        out[i] = x[r * C + cm / m];
+    }
+}
+
+// out[r][c] = sum_j x[r][c * m + j]
+__global__ __launch_bounds__(256) void tg_group_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n_out, int C, int m)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_out; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / C;
+        const int c = (int)(i % C);
+        float s = 0.f;
+        for (int j = 0; j < m; ++j) s += x[(r * C + c) * m + j];
+        out[i] = s;
+    }
+}
+
+// keras Conv2D(groups = g) kernel [cin / g][cout] <-> block-diagonal dense [cin][cout]
+__global__ __launch_bounds__(256) void tg_group_expand_kernel(const float* __restrict__ w, float* __restrict__ dense, int cin, int cout, int g,
+                                                              int extract)
+{
+    const int ci_g = cin / g, co_g = cout / g;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < cin * cout; i += gridDim.x * 256) {
+        const int ci = i / cout, co = i % cout;
+        const bool on = ci / ci_g == co / co_g;
+        if (extract) {
+            if (on) const_cast<float*>(w)[(ci % ci_g) * cout + co] = dense[i];
+        } else {
+            dense[i] = on ? w[(ci % ci_g) * cout + co] : 0.f;
+        }
+    }
+}
+
+inline int tg_grid(int64_t n)
+{
+    const int64_t g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g < 4096 ? g : 4096));
+}
+
+inline bool tg_ok_c(int C) { return C > 0 && C <= 256 && 256 % C == 0; }
+
+}  // namespace
+
+extern "C" int64_t bf_op_bn_train_scratch_floats(int channels) { return (int64_t)CS_GRID * 2 * channels * 2 + 3 * channels + 64; }
+
+extern "C" int bf_op_bn_train_fwd(const float* x, const float* gamma, float* y, float* save, float* moving_mean, float* moving_var,
+                                  int64_t npix, int C, float eps, float momentum, int act, float alpha, float* scratch,
+                                  int64_t scratch_floats, void* stream)
+{
+    if (!x || !gamma || !y || !save || !scratch || npix <= 0) return BF_EINVAL;
+    if (!tg_ok_c(C)) return BF_EUNSUPPORTED;
+    if (scratch_floats < bf_op_bn_train_scratch_floats(C) || (uintptr_t)scratch % 8) return BF_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    double* partial = reinterpret_cast<double*>(scratch);
+    float* coef = scratch + (int64_t)CS_GRID * 2 * C * 2;
+    hipLaunchKernelGGL(tg_colsum2_kernel, dim3(CS_GRID, 1), dim3(256), 0, s, x, x, npix, C, partial);
+    hipLaunchKernelGGL(tg_bn_fwd_finalize_kernel, dim3(1), dim3(256), 0, s, partial, CS_GRID, (double)npix, C, gamma, eps, momentum,
+                       moving_mean, moving_var, save, coef);
+    hipLaunchKernelGGL(tg_lincomb_kernel, dim3(tg_grid(npix * C)), dim3(256), 0, s, x, (const float*)nullptr, coef, (const float*)nullptr,
+                       coef + C, y, npix * C, C, act, alpha);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+extern "C" int bf_op_bn_train_bwd(const float* x, const float* gamma, const float* save, const float* dy, float* dx, float* dgamma,
+                                  int64_t npix, int C, float* scratch, int64_t scratch_floats, void* stream)
+{
+    if (!x || !gamma || !save || !dy || !dx || !dgamma || !scratch || npix <= 0) return BF_EINVAL;
+    if (!tg_ok_c(C)) return BF_EUNSUPPORTED;
+    if (scratch_floats < bf_op_bn_train_scratch_floats(C) || (uintptr_t)scratch % 8) return BF_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    double* partial = reinterpret_cast<double*>(scratch);
+    float* coef = scratch + (int64_t)CS_GRID * 2 * C * 2;
+    hipLaunchKernelGGL(tg_colsum2_kernel, dim3(CS_GRID, 1), dim3(256), 0, s, dy, x, npix, C, partial);
+    hipLaunchKernelGGL(tg_bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, s, partial, CS_GRID, (double)npix, C, gamma, save, coef, dgamma);
+    hipLaunchKernelGGL(tg_lincomb_kernel, dim3(tg_grid(npix * C)), dim3(256), 0, s, dy, x, coef, coef + C, coef + 2 * C, dx, npix * C, C, 0,
+                       0.f);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+extern "C" int64_t bf_op_gate_save_floats(int batch, int channels, int squeeze) { return (int64_t)batch * (3 * channels + squeeze); }
+extern "C" int64_t bf_op_gate_scratch_floats(int batch, int channels)
+{
+    return (int64_t)batch * CS_GRID * 2 * channels * 2 + (int64_t)batch * channels + 64;
+}
+
+extern "C" int bf_op_gate_fwd(const float* x, const float* w0, const float* w1, const float* res, float* out, float* save, int B,
+                              int64_t hw, int C, int C8, float* scratch, int64_t scratch_floats, void* stream)
+{
+    if (!x || !w0 || !w1 || !out || !save || !scratch || B <= 0 || hw <= 0) return BF_EINVAL;
+    if (!tg_ok_c(C) || C8 <= 0 || C8 > 32) return BF_EUNSUPPORTED;
+    if (scratch_floats < bf_op_gate_scratch_floats(B, C) || (uintptr_t)scratch % 8) return BF_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    double* partial = reinterpret_cast<double*>(scratch);
+    hipLaunchKernelGGL(tg_colsum2_kernel, dim3(CS_GRID, B), dim3(256), 0, s, x, x, hw, C, partial);
+    hipLaunchKernelGGL(tg_gate_dense_kernel, dim3(B), dim3(256), 0, s, partial, CS_GRID, (double)hw, C, C8, w0, w1, B, save);
+    const float* g = save + (int64_t)B * (2 * C + C8);
+    hipLaunchKernelGGL(tg_gate_mul_kernel, dim3(tg_grid((int64_t)B * hw * C)), dim3(256), 0, s, x, g, (const float*)nullptr, 0.f, res, out,
+                       hw * C, C, (int64_t)B * hw * C);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// dy: gradient at the gate's output (x * g); dx: gradient at x through both uses (the multiply and the mean)
+extern "C" int bf_op_gate_bwd(const float* x, const float* w0, const float* w1, const float* save, const float* dy, float* dx, float* dw0,
+                              float* dw1, int B, int64_t hw, int C, int C8, float* scratch, int64_t scratch_floats, void* stream)
+{
+    if (!x || !w0 || !w1 || !save || !dy || !dx || !dw0 || !dw1 || !scratch || B <= 0 || hw <= 0) return BF_EINVAL;
+    if (!tg_ok_c(C) || C8 <= 0 || C8 > 32) return BF_EUNSUPPORTED;
+    if (scratch_floats < bf_op_gate_scratch_floats(B, C) || (uintptr_t)scratch % 8) return BF_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    double* partial = reinterpret_cast<double*>(scratch);
+    float* dmean = scratch + (int64_t)B * CS_GRID * 2 * C * 2;
+    hipLaunchKernelGGL(tg_colsum2_kernel, dim3(CS_GRID, B), dim3(256), 0, s, dy, x, hw, C, partial);
+    hipLaunchKernelGGL(tg_gate_dense_bwd_kernel, dim3(1), dim3(256), 0, s, partial, CS_GRID, C, C8, B, w0, w1, save, dw0, dw1, dmean);
+    const float* g = save + (int64_t)B * (2 * C + C8);
+    hipLaunchKernelGGL(tg_gate_mul_kernel, dim3(tg_grid((int64_t)B * hw * C)), dim3(256), 0, s, dy, g, dmean, (float)(1.0 / (double)hw),
+                       (const float*)nullptr, dx, hw * C, C, (int64_t)B * hw * C);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+extern "C" int bf_op_channel_repeat(const float* x, float* out, int64_t npix, int C, int m, void* stream)
+{
+    if (!x || !out || npix <= 0 || C <= 0 || m <= 0) return BF_EINVAL;
+    hipLaunchKernelGGL(tg_repeat_kernel, dim3(tg_grid(npix * C * m)), dim3(256), 0, (hipStream_t)stream, x, out, npix * C * m, C, m);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+extern "C" int bf_op_channel_group_sum(const float* x, float* out, int64_t npix, int C, int m, void* stream)
+{
+    if (!x || !out || npix <= 0 || C <= 0 || m <= 0) return BF_EINVAL;
+    hipLaunchKernelGGL(tg_group_sum_kernel, dim3(tg_grid(npix * C)), dim3(256), 0, (hipStream_t)stream, x, out, npix * C, C, m);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// extract = 0: dense[cin][cout] <- block-diagonal expansion of w[cin / groups][cout]; extract = 1: w <- the diagonal blocks of dense
+extern "C" int bf_op_group_kernel(float* w, float* dense, int cin, int cout, int groups, int extract, void* stream)
+{
+    if (!w || !dense || cin <= 0 || cout <= 0 || groups <= 0 || cin % groups || cout % groups) return BF_EINVAL;
+    hipLaunchKernelGGL(tg_group_expand_kernel, dim3(tg_grid((int64_t)cin * cout)), dim3(256), 0, (hipStream_t)stream, w, dense, cin, cout,
+                       groups, extract);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}

@@ -1,6 +1,7 @@
 """Resnet backbones outside the 16-filter 3x3 family (bfcnn/backbone_resnet.py:36-298): per-position kernel sizes and
 filters, depthwise convolutions with a depth multiplier, grouped convolutions -- e.g. the config the reference ships,
-`resnet_color_1x6_bn_32x128x32_1x3x1_..._depthwise` (1x1 32->32, depthwise 3x3 x4, grouped 1x1 128->32).  Inference only, on
+`resnet_color_1x6_bn_32x128x32_1x3x1_..._depthwise` (1x1 32->32, depthwise 3x3 x4, grouped 1x1 128->32), and the channel gate
+of `add_gates` (backbone_blocks.py:199-208).  This file is inference (training: resnet_generic_train.py), on
 the operator library of csrc/unet_ops.hip: first convolution, 1x1 / k x k matrix-core convolutions with the BatchNorm
 folded (scale into the weights at pack time, shift as the epilogue bias), depthwise-with-multiplier kernel, fused head.
 The 16-filter 3x3 family keeps its own engine (`HydraModel`, fused split-f16 blocks, training)."""
@@ -16,6 +17,18 @@ from .custom_logger import logger
 BN_EPSILON = 1e-3          # DEFAULT_BN_EPSILON (bfcnn/constants.py:9)
 
 
+def channel_gate(x: torch.Tensor, w0: torch.Tensor, w1: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """the `add_gates` gate (backbone_blocks.py:199-208): x * hard_sigmoid(relu(mean_hw(x) @ w0) @ w1) [+ res]"""
+    B, H, W, Cc = x.shape
+    L = N.lib()
+    out = torch.empty_like(x)
+    save = torch.empty(int(L.bf_op_gate_save_floats(B, Cc, int(w0.shape[1]))), dtype=torch.float32, device=x.device)
+    scratch = torch.empty(int(L.bf_op_gate_scratch_floats(B, Cc)) + 2, dtype=torch.float32, device=x.device)
+    N.check(L.bf_op_gate_fwd(N.ptr(x), N.ptr(w0), N.ptr(w1), N.ptr(res), N.ptr(out), N.ptr(save), B, H * W, Cc, int(w0.shape[1]),
+                             N.ptr(scratch), scratch.numel(), N.stream_ptr(x)), None, "bf_op_gate_fwd")
+    return out
+
+
 class GenericResnetHydra:
     multi_output = False
     auto_exact_fallback = False
@@ -28,7 +41,7 @@ class GenericResnetHydra:
     def __init__(self, config: Dict, device=None, seed: Optional[int] = None):
         bb, dn = config["backbone"], config["denoiser"]
         self.config = config
-        for key in ("add_gelu", "add_gates", "add_final_bn", "add_initial_bn", "add_concat_input", "add_gradient_dropout",
+        for key in ("add_gelu", "add_final_bn", "add_initial_bn", "add_concat_input", "add_gradient_dropout",
                     "add_channelwise_scaling", "add_learnable_multiplier", "add_mean_sigma_normalization", "use_bias"):
             if bb.get(key, False):
                 raise NotImplementedError(f"resnet: {key} is outside the built graph")
@@ -55,6 +68,9 @@ class GenericResnetHydra:
         self.base_activation = bb.get("base_activation", "linear")
         self.block_activation[-1] = self.base_activation                              # :178
         self.use_bn = bool(bb.get("use_bn", True))
+        self.add_gates = bool(bb.get("add_gates", False))
+        if self.add_gates and nb < 2:
+            raise ValueError("don't know what to do here")                           # backbone_blocks.py:131-141 (gate_no_filters)
         self.in_channels = int(bb["input_shape"][-1])
         vr = bb.get("value_range", [0, 255])
         self.v_min, self.v_max = float(vr[0]), float(vr[1])
@@ -105,6 +121,10 @@ class GenericResnetHydra:
                 if j >= 1 and self.use_bn:              # the first convolution of a block has no BN (backbone_blocks.py:174-179)
                     out.append((f"block{i}/bn{j}/gamma", (cout,), "bn_gamma"))
                     state += [(f"block{i}/bn{j}/moving_mean", (cout,)), (f"block{i}/bn{j}/moving_variance", (cout,))]
+                if j == 1 and self.add_gates:           # two bias-free Dense layers, created right behind the second convolution
+                    c8 = max(int(cout / 8), 2)
+                    out.append((f"block{i}/gate/dense0/kernel", (cout, c8), "dense"))
+                    out.append((f"block{i}/gate/dense1/kernel", (c8, cout), "dense"))
                 cin = cout
         out.append(("head/conv0/kernel", (1, 1, self.filters, self.head_filters), "conv"))
         out.append(("head/conv1/kernel", (1, 1, self.head_filters, self.out_channels), "conv"))
@@ -132,8 +152,9 @@ class GenericResnetHydra:
     def _initial_values(self, seed) -> np.ndarray:
         from .model import glorot_normal
         rng = np.random.default_rng(seed)
-        return np.concatenate([np.asarray(np.ones(s) if kind == "bn_gamma" else glorot_normal(s, rng), np.float32).ravel()
-                               for _, s, kind in self._inventory])
+        init = lambda s, kind: np.ones(s) if kind == "bn_gamma" else \
+            (glorot_normal((1, 1) + tuple(s), rng).reshape(s) if kind == "dense" else glorot_normal(s, rng))
+        return np.concatenate([np.asarray(init(s, kind), np.float32).ravel() for _, s, kind in self._inventory])
 
     def get_weights(self):
         return self.params.detach().cpu().numpy(), self.state.detach().cpu().numpy()
@@ -148,6 +169,10 @@ class GenericResnetHydra:
             if state.size != self.n_state:
                 raise ValueError(f"expected {self.n_state} state values, got {state.size}")
             self.state.copy_(torch.from_numpy(state))
+        self._packed = None
+
+    def mark_dirty(self):
+        """parameters or moving statistics changed in place (optimizer / training step): drop the folded operands"""
         self._packed = None
 
     def set_option(self, key: str, value: int):
@@ -186,6 +211,8 @@ class GenericResnetHydra:
                     dense = dense * scale[None, None, None, :]
                     packed = UL.pack_pointwise(dev(dense[0, 0])) if kk == 1 else UL.pack_conv(dev(dense))
                     P[f"b{i}c{j}"] = ("pw" if kk == 1 else "conv", packed, None if shift is None else dev(shift))
+                if j == 1 and self.add_gates:
+                    P[f"b{i}gate"] = (dev(W[f"block{i}/gate/dense0/kernel"]), dev(W[f"block{i}/gate/dense1/kernel"]))
                 cin = cout
         P["head0"] = UL.pack_pointwise(dev(W["head/conv0/kernel"][0, 0]))
         P["head1"] = dev(W["head/conv1/kernel"])
@@ -207,7 +234,8 @@ class GenericResnetHydra:
             j = 0
             while j < nb:
                 kind, wp, shift = P[f"b{i}c{j}"]
-                if kind == "dw" and j + 1 < nb and P[f"b{i}c{j + 1}"][0] == "pw" and \
+                gate_here = self.add_gates and j == 1
+                if kind == "dw" and not gate_here and j + 1 < nb and P[f"b{i}c{j + 1}"][0] == "pw" and \
                         (t.shape[-1], int(wp.shape[-1]), self.block_filters[j + 1], int(wp.shape[0])) in fused:
                     # depthwise (+BN, act) and the 1x1 after it (+BN, act, +skip) in one kernel: the wide tensor stays on chip
                     _, wp2, shift2 = P[f"b{i}c{j + 1}"]
@@ -215,17 +243,19 @@ class GenericResnetHydra:
                                             self.block_activation[j + 1], f if j + 1 == nb - 1 else None)
                     j += 2
                     continue
-                res = f if j == nb - 1 else None          # Add(block output, block input) (backbone_blocks.py:242)
+                res = f if j == nb - 1 and not gate_here else None          # Add(block output, block input) (backbone_blocks.py:242)
                 a = self.block_activation[j]
                 if kind == "dw":
                     t = UL.dwconv_mult(t, wp, shift, a)
-                    if res is not None:
+                    if j == nb - 1 and not gate_here:
                         raise NotImplementedError("a depthwise convolution as the last convolution of a block")
                 elif kind == "pw":
                     cout = self.block_filters[j]
                     t = UL.pointwise_ex(t, wp, cout, 3, a, mult=shift, res=res)
                 else:
                     t = UL.conv2d(t, wp, self.block_filters[j], self.block_kernels[j], 1, a, res=res, bias=shift)
+                if gate_here:                                # x * hard_sigmoid(relu(mean(x) W0) W1) [+ skip when the block ends here]
+                    t = channel_gate(t, *P[f"b{i}gate"], res=f if j == nb - 1 else None)
                 j += 1
             f = t
         return f
@@ -242,7 +272,7 @@ class GenericResnetHydra:
 
     def __call__(self, x, training: bool = False):
         if training:
-            raise NotImplementedError("resnet configs outside the 16-filter 3x3 family: only inference is built")
+            raise NotImplementedError("hydra(x, training=True) on its own is not built here; use train_loop's train_step_single_gpu")
         self._require_gpu()
         x, was_numpy = self._as_device(x)
         B, H, W, _ = x.shape

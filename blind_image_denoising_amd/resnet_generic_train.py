@@ -1,0 +1,296 @@
+"""
+Training of the resnet backbones outside the 16-filter 3x3 engine (`GenericResnetHydra`: the shipped bottleneck / depthwise
+config `resnet_color_1x6_bn_32x128x32_1x3x1_..._depthwise`, per-position kernels / filters / groups, `add_gates`):
+bfcnn/train_loop.py:259-312 -- training-mode forward (BatchNormalization on batch statistics, moving statistics updated),
+denoiser loss, the builder's regularisers, and the gradient of the total for every trainable tensor -- as an explicit
+forward / backward walk of the graph of bfcnn/backbone_resnet.py:36-298 + backbone_blocks.py:163-246 over the operator
+library's C-ABI entry points (forward operators of unet_ops.hip, backward primitives of train_prims.hip, BatchNorm / gate /
+layout operators of train_generic.hip).  PyTorch holds the tensors; it computes nothing.
+
+Exact fp32.  Gradients are compared with the torch-autograd oracle (oracle/resnet_generic_torch.py) in
+tests/test_gpu_resnet_generic_train.py.
+"""
+import ctypes as C
+from typing import Dict
+
+import numpy as np
+import torch
+
+from . import _native as N
+from . import unet_laplacian as UL
+from .resnet_generic import BN_EPSILON, GenericResnetHydra
+from .unet_train import _Ops, _call
+
+BN_MOMENTUM = 0.995                # DEFAULT_BN_MOMENTUM (bfcnn/constants.py:10)
+REG_COEF = 0.01                    # keras "l1" / "l2" string regularisers
+
+
+class GenericResnetTrainGraph:
+    """train_step_single_gpu for a GenericResnetHydra: `step(gt, noisy, grads)` returns (prediction, loss slots, totals[3]) and
+    fills `grads` (flat, laid out like model.params); model.state (moving statistics) is updated in place."""
+
+    def __init__(self, model: GenericResnetHydra, loss_config: Dict):
+        self.m = model
+        self.loss_config = dict(loss_config)
+        self.off = {name: (off, shape, kind) for name, shape, kind, off in model.trainable_variables}
+        self.soff = {name: (off, shape) for name, shape, off in model.non_trainable_variables}
+        for j, (kk, g) in enumerate(zip(model.block_kernels, model.block_groups)):
+            if g != 1 and kk != 1:
+                raise NotImplementedError("training: grouped convolutions are built for 1x1 kernels")
+        self.ops = None
+        self.totals = None
+
+    # ---- parameters / state ------------------------------------------------------------------------------------------------
+    def W(self, name) -> torch.Tensor:
+        off, shape, _ = self.off[name]
+        n = int(np.prod(shape))
+        t = self.m.params[off:off + n]
+        if off % 4:
+            t = t.clone()
+        return t.view(shape)
+
+    def G(self, name, grads) -> torch.Tensor:
+        off, shape, _ = self.off[name]
+        n = int(np.prod(shape))
+        if off % 4:
+            buf = torch.empty(n, dtype=torch.float32, device=grads.device)
+            self._unaligned.append((buf, off, n))
+            return buf
+        return grads[off:off + n]
+
+    def _grad_view(self, name, grads):
+        off, shape, _ = self.off[name]
+        for buf, o, nn in self._unaligned:
+            if o == off:
+                return buf
+        return grads[off:off + int(np.prod(shape))]
+
+    def S(self, name) -> torch.Tensor:
+        off, shape = self.soff[name]
+        return self.m.state[off:off + int(np.prod(shape))]
+
+    def regularizer(self, name: str, kind: str):
+        """backbone_resnet.py:128-176, backbone_blocks.py:146-160, model.py:297-342"""
+        bb, dn = self.m.config["backbone"], self.m.config["denoiser"]
+        if kind == "bn_gamma":
+            return None
+        if name.startswith("base/"):
+            return bb.get("kernel_regularizer", "l1")
+        if name.startswith("head/"):
+            return dn.get("kernel_regularizer", "l2")
+        if "/gate/" in name:
+            return "l2"
+        j = int(name.split("/")[1][4:])
+        br = bb.get("block_regularizer") or [bb.get("kernel_regularizer", "l1")] * len(self.m.block_kernels)
+        return br[j]
+
+    # ---- one training step -------------------------------------------------------------------------------------------------
+    def step(self, gt: torch.Tensor, noisy: torch.Tensor, grads: torch.Tensor, depth_weight: float = 1.0):
+        m = self.m
+        dev = m.device
+        gt = gt.to(device=dev, dtype=torch.float32).contiguous()
+        noisy = noisy.to(device=dev).contiguous()
+        if noisy.dtype != torch.uint8:
+            noisy = noisy.to(torch.float32)
+        B, H, Wd, _ = noisy.shape
+        npix = B * H * Wd
+        L = N.lib()
+        cmax = max([m.filters] + [c for c in self._channels()])
+        need = max(8 * 1024 * 1024, int(L.bf_op_denoiser_loss_scratch_floats(B, H, Wd, m.out_channels)) + 1024, npix * 4,
+                   int(L.bf_op_gate_scratch_floats(B, cmax)) + 64, int(L.bf_op_bn_train_scratch_floats(cmax)) + 64)
+        if self.ops is None or self.ops.scratch.numel() < need:
+            self.ops = _Ops(dev, need)
+        ops = self.ops
+        self._unaligned = []
+        nb = len(m.block_kernels)
+        f32 = dict(dtype=torch.float32, device=dev)
+
+        def pack(w2d):
+            return UL.pack_pointwise(w2d.contiguous())
+
+        def conv_op(name, x, j):
+            """convolution j of a block (no normalisation / activation): returns (y, backward closure dy -> dx)"""
+            kk, cf, dm, g = m.block_kernels[j], m.block_filters[j], m.block_depthwise[j], m.block_groups[j]
+            cin = x.shape[-1]
+            w = self.W(name)
+            if dm != -1:
+                # DepthwiseConv2D(depth_multiplier = dm) = plain depthwise convolution of the channel-repeated tensor
+                y = UL.dwconv_mult(x, w, None)
+
+                def bwd(dy):
+                    Bc, Hc, Wc, _ = x.shape
+                    xr = x
+                    if dm != 1:
+                        xr = torch.empty((Bc, Hc, Wc, cin * dm), **f32)
+                        _call("bf_op_channel_repeat", N.ptr(x), N.ptr(xr), Bc * Hc * Wc, cin, dm, N.stream_ptr(x))
+                    ops.dwconv_wgrad(xr, dy, self.G(name, grads), kk)                  # [k,k,C*dm] == [k,k,C,dm] in memory
+                    wf = torch.empty_like(w)
+                    _call("bf_op_flip_hw", N.ptr(w), N.ptr(wf), kk, cin * dm, N.stream_ptr(w))
+                    dxr = UL.dwconv_mult(dy, wf.view(kk, kk, cin * dm, 1), None)
+                    if dm == 1:
+                        return dxr
+                    dx = torch.empty_like(x)
+                    _call("bf_op_channel_group_sum", N.ptr(dxr), N.ptr(dx), Bc * Hc * Wc, cin, dm, N.stream_ptr(dxr))
+                    return dx
+                return y, bwd
+            if kk == 1:
+                dense = w.view(cin // g, cf)
+                if g != 1:
+                    dense = torch.empty((cin, cf), **f32)
+                    _call("bf_op_group_kernel", N.ptr(w), N.ptr(dense), cin, cf, g, 0, N.stream_ptr(w))
+                y = UL.pointwise(x, pack(dense), cf)
+
+                def bwd(dy):
+                    gw = self.G(name, grads)
+                    if g == 1:
+                        ops.matmul_wgrad(x, dy, gw)
+                    else:
+                        dd = torch.empty((cin, cf), **f32)
+                        ops.matmul_wgrad(x, dy, dd)
+                        _call("bf_op_group_kernel", N.ptr(gw), N.ptr(dd), cin, cf, g, 1, N.stream_ptr(dd))
+                    return UL.pointwise(dy, pack(ops.transpose(dense)), cin)
+                return y, bwd
+            # k x k dense convolution
+            y = UL.conv2d(x, UL.pack_conv(w.contiguous()), cf, kk, 1, "linear")
+
+            def bwd(dy):
+                Bc, Hc, Wc, _ = x.shape
+                sp, sn = ops._s()
+                _call("bf_op_conv2d_wgrad", N.ptr(x), 0, N.ptr(dy), N.ptr(self.G(name, grads)), Bc, Hc, Wc, cin, cf, kk, 0, 0.0, 0.0,
+                      sp, sn, N.stream_ptr(dy))
+                # data gradient = convolution with the taps flipped and every tap transposed
+                wf = torch.empty_like(w)
+                _call("bf_op_flip_hw", N.ptr(w), N.ptr(wf), kk, cin * cf, N.stream_ptr(w))
+                wt = torch.empty((kk, kk, cf, cin), **f32)
+                for t_ in range(kk * kk):
+                    _call("bf_op_transpose2d", N.ptr(wf.view(kk * kk, cin, cf)[t_]), N.ptr(wt.view(kk * kk, cf, cin)[t_]), cin, cf,
+                          N.stream_ptr(wf))
+                return UL.conv2d(dy, UL.pack_conv(wt), cin, kk, 1, "linear")
+            return y, bwd
+
+        # -- forward -------------------------------------------------------------------------------------------------------------
+        wb = self.W("base/kernel")
+        f = UL.first_conv(noisy, wb, H, Wd, m.base_activation, True, m.v_min, m.v_max, arith=0)
+        f0 = f
+        chain = []                                   # per block: closure d(block output) -> d(block input)
+        for i in range(m.no_layers):
+            t = f
+            steps = []
+            for j in range(nb):
+                c, b_conv = conv_op(f"block{i}/conv{j}/kernel", t, j)
+                a = m.block_activation[j]
+                code, alpha = UL._act(a)
+                Cc = c.shape[-1]
+                if j >= 1 and m.use_bn:
+                    gamma = self.W(f"block{i}/bn{j}/gamma")
+                    save = torch.empty(2 * Cc, **f32)
+                    y = torch.empty_like(c)
+                    sp, sn = ops._s()
+                    _call("bf_op_bn_train_fwd", N.ptr(c), N.ptr(gamma), N.ptr(y), N.ptr(save), N.ptr(self.S(f"block{i}/bn{j}/moving_mean")),
+                          N.ptr(self.S(f"block{i}/bn{j}/moving_variance")), c.numel() // Cc, Cc, BN_EPSILON, BN_MOMENTUM, code, alpha,
+                          sp, sn, N.stream_ptr(c))
+
+                    def b_norm(dy, c=c, y=y, gamma=gamma, save=save, a=a, Cc=Cc, name=f"block{i}/bn{j}/gamma"):
+                        dpre = ops.act_bwd(y, dy, a)
+                        dx = torch.empty_like(c)
+                        sp, sn = ops._s()
+                        _call("bf_op_bn_train_bwd", N.ptr(c), N.ptr(gamma), N.ptr(save), N.ptr(dpre), N.ptr(dx), N.ptr(self.G(name, grads)),
+                              c.numel() // Cc, Cc, sp, sn, N.stream_ptr(c))
+                        return dx
+                else:
+                    y = c if code == 0 else UL.dwconv_ln(c, None, None, a)
+
+                    def b_norm(dy, y=y, a=a):
+                        return ops.act_bwd(y, dy, a)
+                steps.append((b_conv, b_norm))
+                t = y
+                if j == 1 and m.add_gates:
+                    w0, w1 = self.W(f"block{i}/gate/dense0/kernel"), self.W(f"block{i}/gate/dense1/kernel")
+                    C8 = w0.shape[1]
+                    gsave = torch.empty(int(L.bf_op_gate_save_floats(B, Cc, C8)), **f32)
+                    gout = torch.empty_like(t)
+                    sp, sn = ops._s()
+                    _call("bf_op_gate_fwd", N.ptr(t), N.ptr(w0), N.ptr(w1), None, N.ptr(gout), N.ptr(gsave), B, H * Wd, Cc, C8, sp, sn,
+                          N.stream_ptr(t))
+
+                    def b_gate(dy, t=t, w0=w0, w1=w1, gsave=gsave, Cc=Cc, C8=C8, i=i):
+                        dx = torch.empty_like(t)
+                        sp, sn = ops._s()
+                        _call("bf_op_gate_bwd", N.ptr(t), N.ptr(w0), N.ptr(w1), N.ptr(gsave), N.ptr(dy), N.ptr(dx),
+                              N.ptr(self.G(f"block{i}/gate/dense0/kernel", grads)), N.ptr(self.G(f"block{i}/gate/dense1/kernel", grads)),
+                              B, H * Wd, Cc, C8, sp, sn, N.stream_ptr(t))
+                        return dx
+                    steps.append((None, b_gate))
+                    t = gout
+            f = ops.add(f, t)                                         # Add()([x, previous_layer]) (backbone_blocks.py:242)
+
+            def b_block(dout, steps=steps):
+                g = dout
+                for b_conv, b_norm in reversed(steps):
+                    g = b_norm(g)
+                    if b_conv is not None:
+                        g = b_conv(g)
+                return ops.add(dout, g)
+            chain.append(b_block)
+
+        # -- head + loss ---------------------------------------------------------------------------------------------------------
+        ld = N.LossDesc()
+        ld.struct_size = C.sizeof(N.LossDesc)
+        lc = self.loss_config
+        ld.hinge, ld.cutoff = float(lc.get("hinge", 0.0)), float(lc.get("cutoff", 255.0))
+        ld.mae_multiplier, ld.mse_multiplier = float(lc.get("mae_multiplier", 1.0)), float(lc.get("mse_multiplier", 0.0))
+        ld.ssim_multiplier, ld.regularization = float(lc.get("ssim_multiplier", 0.0)), float(lc.get("regularization", 1.0))
+        ld.depth_weight = float(depth_weight)
+        Cf = m.filters
+        w0 = self.W("head/conv0/kernel").view(Cf, m.head_filters)
+        w1 = self.W("head/conv1/kernel").view(m.head_filters, m.out_channels).contiguous()
+        h0 = UL.pointwise(f, pack(w0), m.head_filters, m.head_activation)
+        pred = UL.head_out(h0, w1, H, Wd, False, True, m.v_min, m.v_max)
+        losses = torch.zeros(N.BF_LOSS_COUNT, **f32)
+        dpred = torch.empty_like(pred)
+        total = torch.zeros(3, **f32)                                # [0] total loss, [1] regularisation value, [2] [1] * regularization
+        sp, sn = ops._s()
+        _call("bf_op_denoiser_loss", N.ptr(pred), N.ptr(gt), B, H, Wd, m.out_channels, C.byref(ld), N.ptr(dpred), N.ptr(losses), sp, sn,
+              N.stream_ptr(pred))
+        _call("bf_op_axpy", N.ptr(total), N.ptr(losses[N.BF_LOSS_TOTAL:N.BF_LOSS_TOTAL + 1]), 1.0, 0, 1, N.stream_ptr(total))
+        dh0 = torch.empty_like(h0)
+        sp, sn = ops._s()
+        _call("bf_op_head_out_bwd", N.ptr(h0), N.ptr(w1), N.ptr(dpred), N.ptr(dh0), N.ptr(self.G("head/conv1/kernel", grads)), npix,
+              m.head_filters, m.out_channels, 1, m.v_min, m.v_max, sp, sn, N.stream_ptr(h0))
+        dh0p = ops.act_bwd(h0, dh0, m.head_activation)
+        ops.matmul_wgrad(f, dh0p, self.G("head/conv0/kernel", grads))
+        g = UL.pointwise(dh0p, pack(ops.transpose(w0)), Cf)
+
+        # -- backward ------------------------------------------------------------------------------------------------------------
+        for b_block in reversed(chain):
+            g = b_block(g)
+        dpre = ops.act_bwd(f0, g, m.base_activation)
+        sp, sn = ops._s()
+        _call("bf_op_conv2d_wgrad", N.ptr(noisy), int(noisy.dtype == torch.uint8), N.ptr(dpre), N.ptr(self.G("base/kernel", grads)),
+              B, H, Wd, m.in_channels, m.filters, m.kernel_size, 1, m.v_min, m.v_max, sp, sn, N.stream_ptr(dpre))
+
+        # -- regularisers: value into total[1], gradients added times `regularization` ------------------------------------------
+        reg = float(ld.regularization)
+        for name, shape, kind, off in m.trainable_variables:
+            rk = self.regularizer(name, kind)
+            if rk in (None, "none"):
+                continue
+            if rk not in ("l1", "l2"):
+                raise NotImplementedError(f"regularizer {rk}")
+            w = self.W(name)
+            _call("bf_op_reg_elementwise", N.ptr(w), N.ptr(self._grad_view(name, grads)), int(np.prod(shape)),
+                  N.BF_REG_L1 if rk == "l1" else N.BF_REG_L2, REG_COEF, reg, N.ptr(total[1:2]), N.stream_ptr(w))
+        for buf, off, n in self._unaligned:
+            grads[off:off + n].copy_(buf)
+        _call("bf_op_axpy", N.ptr(total[2:3]), N.ptr(total[1:2]), reg, 0, 1, N.stream_ptr(total))
+        _call("bf_op_axpy", N.ptr(total), N.ptr(total[2:3]), 1.0, 0, 1, N.stream_ptr(total))
+        m.mark_dirty()                                               # the folded inference weights no longer match the state
+        self.totals = total
+        return pred, losses, total
+
+    def _channels(self):
+        m = self.m
+        cin = m.filters
+        for cf, dm in zip(m.block_filters, m.block_depthwise):
+            cin = cin * dm if dm != -1 else cf
+            yield cin

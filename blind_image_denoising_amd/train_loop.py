@@ -35,6 +35,8 @@ def build_train_functions(model: HydraModel, loss_fn_map: Dict[str, Callable]) -
     denoiser_loss_fn = loss_fn_map[DENOISER_LOSS_FN_STR]
     if getattr(model, "multi_output", False):
         return _build_multi_output_train_functions(model, denoiser_loss_fn)
+    if type(model).__name__ == "GenericResnetHydra":
+        return _build_generic_resnet_train_functions(model, denoiser_loss_fn)
     state = {"grads": None, "losses": None}
 
     def _buffers():
@@ -71,6 +73,40 @@ def build_train_functions(model: HydraModel, loss_fn_map: Dict[str, Callable]) -
     def apply_grads(internal_optimizer, internal_gradients, internal_trainable_variables=None, grad_scale: float = 1.0):
         """bfcnn/train_loop.py:314-321."""
         internal_optimizer.apply_gradients(internal_gradients, model, grad_scale=grad_scale, losses=state["losses"])
+
+    return TrainFunctions(train_step, test_step, train_step_single_gpu, apply_grads)
+
+
+def _build_generic_resnet_train_functions(model, denoiser_loss_fn) -> TrainFunctions:
+    """the four closures for the resnet configs outside the 16-filter 3x3 engine (GenericResnetHydra), through
+    resnet_generic_train.GenericResnetTrainGraph (explicit forward / backward over the operator library)."""
+    from .resnet_generic_train import GenericResnetTrainGraph
+    d = denoiser_loss_fn.desc(1.0)
+    loss_config = {"hinge": d.hinge, "cutoff": d.cutoff, "mae_multiplier": d.mae_multiplier, "mse_multiplier": d.mse_multiplier,
+                   "ssim_multiplier": d.ssim_multiplier, "regularization": d.regularization}
+    graph = GenericResnetTrainGraph(model, loss_config)
+    state = {"grads": None}
+
+    def train_step(n):
+        raise NotImplementedError("hydra(n, training=True) on its own is not built for this model; use train_step_single_gpu")
+
+    def test_step(n):
+        return model(n, training=False)
+
+    def train_step_single_gpu(p_input_image_batch, p_noisy_image_batch, p_depth_weight=(1.0,), p_percentage_done=0.0,
+                              p_trainable_variables=None):
+        if state["grads"] is None or state["grads"].device != model.params.device:
+            state["grads"] = torch.zeros(model.n_params, dtype=torch.float32, device=model.device)
+        grads = state["grads"]
+        dw = p_depth_weight[0] if hasattr(p_depth_weight, "__len__") else p_depth_weight
+        pred, sl, totals = graph.step(p_input_image_batch, p_noisy_image_batch, grads, float(dw))
+        model_loss = {REGULARIZATION_LOSS_STR: totals[1], TOTAL_LOSS_STR: totals[2]}
+        denoiser_loss = {TOTAL_LOSS_STR: sl[N.BF_LOSS_DENOISER_TOTAL], MSE_LOSS_STR: sl[N.BF_LOSS_MSE], MAE_LOSS_STR: sl[N.BF_LOSS_MAE],
+                         SSIM_LOSS_STR: sl[N.BF_LOSS_SSIM]}
+        return totals[0], model_loss, [denoiser_loss], pred, grads
+
+    def apply_grads(internal_optimizer, internal_gradients, internal_trainable_variables=None, grad_scale: float = 1.0):
+        internal_optimizer.apply_gradients(internal_gradients, model, grad_scale=grad_scale, losses=None)
 
     return TrainFunctions(train_step, test_step, train_step_single_gpu, apply_grads)
 

@@ -379,6 +379,32 @@ int bf_op_reg_elementwise(const float* w, float* grad, int64_t n, int kind, floa
 int bf_op_reg_soft_orthonormal(const float* w, float* grad, int cin, int cout, float lambda, float l1, float l2, float grad_scale,
                                float* value, float* scratch, void* stream);
 /* weight re-layouts for the data gradients: spatial flip of [k][k][inner]; transpose of [a][b] */
+/* ---- training-mode operators of the resnet builder outside the 16-filter 3x3 engine (csrc/train_generic.hip) ----
+   BatchNormalization(center=False) with batch statistics, bfcnn/utilities.py:204-206 under training=True: y = act(gamma (x - mean)
+   / sqrt(var + eps)); save [2C] = mean | 1 / sqrt(var + eps) for the backward; moving statistics (may be NULL) updated with
+   `momentum` and the Bessel-corrected variance (fused-kernel semantics).  channels must divide 256.  Backward: dx, dgamma from dy
+   (the gradient at the BatchNorm's output, in front of the activation). */
+int64_t bf_op_bn_train_scratch_floats(int channels);
+int bf_op_bn_train_fwd(const float* x, const float* gamma, float* y, float* save, float* moving_mean, float* moving_var, int64_t npix,
+                       int channels, float eps, float momentum, int act, float alpha, float* scratch, int64_t scratch_floats,
+                       void* stream);
+int bf_op_bn_train_bwd(const float* x, const float* gamma, const float* save, const float* dy, float* dx, float* dgamma, int64_t npix,
+                       int channels, float* scratch, int64_t scratch_floats, void* stream);
+/* channel gate of add_gates (bfcnn/backbone_blocks.py:199-208): g = hard_sigmoid(relu(mean_hw(x) W0) W1), out = x * g [+ res];
+   w0 [C][C8], w1 [C8][C] (keras Dense kernels, no bias), C8 <= 32; save: bf_op_gate_save_floats floats kept for the backward.
+   Backward: dy = gradient at x * g; dx = gradient at x through the multiply AND the mean; dw0 / dw1 overwritten. */
+int64_t bf_op_gate_save_floats(int batch, int channels, int squeeze);
+int64_t bf_op_gate_scratch_floats(int batch, int channels);
+int bf_op_gate_fwd(const float* x, const float* w0, const float* w1, const float* res, float* out, float* save, int batch, int64_t hw,
+                   int channels, int squeeze, float* scratch, int64_t scratch_floats, void* stream);
+int bf_op_gate_bwd(const float* x, const float* w0, const float* w1, const float* save, const float* dy, float* dx, float* dw0,
+                   float* dw1, int batch, int64_t hw, int channels, int squeeze, float* scratch, int64_t scratch_floats, void* stream);
+/* layout helpers: out[r][c * m + j] = x[r][c] (a DepthwiseConv2D with depth_multiplier m is a plain depthwise convolution of the
+   repeated tensor) and its adjoint out[r][c] = sum_j x[r][c * m + j]; keras Conv2D(groups) kernel [cin / groups][cout] to / from the
+   block-diagonal dense [cin][cout] (extract = 1 writes w from dense) */
+int bf_op_channel_repeat(const float* x, float* out, int64_t npix, int channels, int m, void* stream);
+int bf_op_channel_group_sum(const float* x, float* out, int64_t npix, int channels, int m, void* stream);
+int bf_op_group_kernel(float* w, float* dense, int cin, int cout, int groups, int extract, void* stream);
 int bf_op_flip_hw(const float* w, float* out, int k, int inner, void* stream);
 int bf_op_transpose2d(const float* w, float* out, int a, int b, void* stream);
 

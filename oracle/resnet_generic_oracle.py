@@ -1,6 +1,8 @@
 """CPU oracle for resnet backbones outside the 16-filter 3x3 family: per-block kernel sizes / filters, depthwise
 convolutions with a depth multiplier and grouped convolutions, as in the one resnet config the reference ships
-(`configs/resnet_color_1x6_bn_32x128x32_1x3x1_128x128_depthwise_l1_relu.json`).  Inference only.
+(`configs/resnet_color_1x6_bn_32x128x32_1x3x1_128x128_depthwise_l1_relu.json`), and the channel gate of `add_gates`
+(backbone_blocks.py:199-208).  This file is the inference forward; the training step (batch-statistics BatchNorm, loss,
+regularisers, gradients by autograd) is oracle/resnet_generic_torch.py, whose forward is pinned against this one.
 
 TEST INFRASTRUCTURE ONLY (tests/, smoke, bench cpu_baseline).  NumPy fp64 restatement of
   bfcnn/backbone_resnet.py:36-298 (builder: conv params per block position, last activation = base_activation),
@@ -44,6 +46,18 @@ def grouped_conv_same(x: np.ndarray, w: np.ndarray, groups: int) -> np.ndarray:
                            for g in range(groups)], axis=-1)
 
 
+def hard_sigmoid(x):
+    """keras 2.13 hard_sigmoid: 0 below -2.5, 1 above 2.5, 0.2 x + 0.5 in between"""
+    return np.clip(0.2 * x + 0.5, 0.0, 1.0)
+
+
+def gate(x: np.ndarray, w0: np.ndarray, w1: np.ndarray) -> np.ndarray:
+    """backbone_blocks.py:199-208: y = mean over H, W -> Dense(relu, no bias) -> Dense(hard_sigmoid, no bias); x * y"""
+    y = np.maximum(x.mean(axis=(1, 2)) @ w0, 0.0)
+    y = hard_sigmoid(y @ w1)
+    return x * y[:, None, None, :]
+
+
 @dataclass(frozen=True)
 class GenericResnetSpec:
     filters: int
@@ -62,6 +76,10 @@ class GenericResnetSpec:
     out_channels: int = 3
     v_min: float = 0.0
     v_max: float = 255.0
+    add_gates: bool = False
+    kernel_regularizer: str = "l1"
+    block_regularizer: Tuple[str, ...] = ()
+    head_regularizer: str = "l2"
 
     @staticmethod
     def from_config(model_config: Dict) -> "GenericResnetSpec":
@@ -79,7 +97,16 @@ class GenericResnetSpec:
             block_groups=tuple(bb.get("block_groups") or [1] * len(bk)), block_activation=tuple(ba),
             base_activation=base_act, use_bn=bb.get("use_bn", True), in_channels=bb["input_shape"][-1],
             head_filters=dn.get("filters", 32), head_activation=dn.get("activation", "linear"),
-            out_channels=dn.get("output_channels", 3), v_min=float(vr[0]), v_max=float(vr[1]))
+            out_channels=dn.get("output_channels", 3), v_min=float(vr[0]), v_max=float(vr[1]),
+            add_gates=bool(bb.get("add_gates", False)), kernel_regularizer=bb.get("kernel_regularizer", "l1"),
+            block_regularizer=tuple(bb.get("block_regularizer") or [bb.get("kernel_regularizer", "l1")] * len(bk)),
+            head_regularizer=dn.get("kernel_regularizer", "l2"))
+
+    def gate_channels(self) -> int:
+        """backbone_blocks.py:131-141: the second convolution's filters, or filters x depth_multiplier for a depthwise one"""
+        if len(self.block_kernels) < 2:
+            raise ValueError("add_gates needs a second convolution (gate_no_filters)")
+        return self.block_filters[1] if self.block_depthwise[1] == -1 else self.block_filters[0] * self.block_depthwise[1]
 
     def tensors(self) -> List[Tuple[str, Tuple[int, ...], str]]:
         """(name, shape, kind) in graph-construction order; kind in conv | depthwise | bn_gamma."""
@@ -96,6 +123,10 @@ class GenericResnetSpec:
                     cout = cf
                 if j >= 1 and self.use_bn:
                     out.append((f"block{i}/bn{j}/gamma", (cout,), "bn_gamma"))
+                if j == 1 and self.add_gates:                      # created right after the second convolution (:199-208)
+                    gc = self.gate_channels()
+                    out.append((f"block{i}/gate/dense0/kernel", (gc, max(int(gc / 8), 2)), "dense"))
+                    out.append((f"block{i}/gate/dense1/kernel", (max(int(gc / 8), 2), gc), "dense"))
                 cin = cout
         out.append(("head/conv0/kernel", (1, 1, self.filters, self.head_filters), "conv"))
         out.append(("head/conv1/kernel", (1, 1, self.head_filters, self.out_channels), "conv"))
@@ -117,7 +148,7 @@ def init_params(spec: GenericResnetSpec, seed: int = 42) -> Tuple[np.ndarray, np
         if kind == "bn_gamma":
             params.append(rng.uniform(0.5, 1.5, shape))
         else:
-            params.append(O.glorot_normal(shape if len(shape) == 4 else shape, rng))
+            params.append(O.glorot_normal(shape, rng) if len(shape) == 4 else O.glorot_normal((1, 1) + tuple(shape), rng).reshape(shape))
     state = []
     for name, shape in spec.state_tensors():
         state.append(rng.normal(0, 0.1, shape) if name.endswith("mean") else rng.uniform(0.5, 1.5, shape))
@@ -149,6 +180,8 @@ def hydra_forward(spec: GenericResnetSpec, params: np.ndarray, state: np.ndarray
                 base = f"block{i}/bn{j}"
                 t = O.bn_infer(t, P[base + "/gamma"], S[base + "/moving_mean"], S[base + "/moving_variance"], BN_EPS)
             t = O.activation_fwd(t, a)
+            if j == 1 and spec.add_gates:
+                t = gate(t, P[f"block{i}/gate/dense0/kernel"], P[f"block{i}/gate/dense1/kernel"])
         f = t + f
     h = O.activation_fwd(O.conv2d_same(f, P["head/conv0/kernel"]), spec.head_activation)
     h = O.conv2d_same(h, P["head/conv1/kernel"])

@@ -1,0 +1,159 @@
+"""Gradient oracle for training resnet backbones outside the 16-filter 3x3 family (the shipped bottleneck / depthwise config, the
+`add_gates` channel gate): the forward of oracle/resnet_generic_oracle.py restated with torch-CPU fp64 tensor ops, so that
+autograd supplies d(total loss)/d(every trainable tensor).
+
+TEST INFRASTRUCTURE ONLY (tests/, never the product path).  The inference-mode forward here is checked against the NumPy
+restatement (tests/test_resnet_generic_train_oracle.py), which pins it; what it adds is the training side:
+  * bfcnn/train_loop.py:259-312 -- hydra(noisy, training=True), denoiser loss * depth weight + regularization * sum(model.losses);
+  * keras BatchNormalization(center=False) under training=True (bfcnn/utilities.py:204-206): batch mean / biased variance,
+    moving statistics updated with DEFAULT_BN_MOMENTUM, the Bessel-corrected variance into the moving variance (fused kernel);
+  * the regularisers the builder attaches (backbone_resnet.py:128-176): `kernel_regularizer` on the base convolution,
+    `block_regularizer[j]` on block convolution j (kernel_regularizer / depthwise_regularizer), "l2" on the two gate Dense
+    kernels (backbone_blocks.py:146-160), the denoiser section's `kernel_regularizer` on the head, nothing on BatchNorm gammas;
+    keras strings: "l1" = 0.01 sum |w|, "l2" = 0.01 sum w^2.
+"""
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import bfcnn_oracle as O
+from . import resnet_generic_oracle as R
+from . import unet_torch as T
+
+DT = torch.float64
+
+
+def _nchw(x):
+    return x.permute(0, 3, 1, 2)
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1)
+
+
+def _act(x, name):
+    name = (name or "linear").lower()
+    if name == "linear":
+        return x
+    if name == "relu":
+        return torch.relu(x)
+    if name.startswith("leaky_relu"):
+        return F.leaky_relu(x, 0.3)
+    raise ValueError(name)
+
+
+def conv_same(x, w, groups=1):
+    """x [B,H,W,Cin], keras kernel [kh,kw,Cin/groups,Cout]"""
+    kh, kw = w.shape[0], w.shape[1]
+    return _nhwc(F.conv2d(_nchw(x), w.permute(3, 2, 0, 1), padding=(kh // 2, kw // 2), groups=groups))
+
+
+def depthwise_mult_same(x, w):
+    """keras DepthwiseConv2D kernel [kh,kw,C,m], output channel c * m + j"""
+    kh, kw, C, m = w.shape
+    wt = w.permute(2, 3, 0, 1).reshape(C * m, 1, kh, kw)
+    return _nhwc(F.conv2d(_nchw(x), wt, padding=(kh // 2, kw // 2), groups=C))
+
+
+def views(spec: R.GenericResnetSpec, flat) -> Dict[str, torch.Tensor]:
+    out, o = {}, 0
+    for name, shape, _ in spec.tensors():
+        n = int(np.prod(shape))
+        out[name] = flat[o:o + n].reshape(shape)
+        o += n
+    return out
+
+
+def state_views(spec, flat):
+    out, o = {}, 0
+    for name, shape in spec.state_tensors():
+        n = int(np.prod(shape))
+        out[name] = flat[o:o + n].reshape(shape)
+        o += n
+    return out
+
+
+def hydra(spec: R.GenericResnetSpec, P, S, x, training: bool):
+    """returns (prediction, new state dict)"""
+    new_state = dict(S)
+    xn = (torch.clamp(x, spec.v_min, spec.v_max) - spec.v_min) / (spec.v_max - spec.v_min) - 0.5
+    f = _act(conv_same(xn, P["base/kernel"]), spec.base_activation)
+    for i in range(spec.no_layers):
+        t = f
+        for j, (dm, g, a) in enumerate(zip(spec.block_depthwise, spec.block_groups, spec.block_activation)):
+            w = P[f"block{i}/conv{j}/kernel"]
+            t = depthwise_mult_same(t, w) if dm != -1 else conv_same(t, w, g)
+            if j >= 1 and spec.use_bn:
+                base = f"block{i}/bn{j}"
+                gamma = P[base + "/gamma"]
+                if training:
+                    n = t.shape[0] * t.shape[1] * t.shape[2]
+                    mu = t.mean(dim=(0, 1, 2))
+                    var = ((t - mu) ** 2).mean(dim=(0, 1, 2))
+                    t = gamma * (t - mu) / torch.sqrt(var + R.BN_EPS)
+                    mom = O.DEFAULT_BN_MOMENTUM
+                    new_state[base + "/moving_mean"] = (S[base + "/moving_mean"] * mom + mu * (1 - mom)).detach()
+                    new_state[base + "/moving_variance"] = (S[base + "/moving_variance"] * mom + var * (n / max(n - 1, 1)) * (1 - mom)).detach()
+                else:
+                    t = gamma * (t - S[base + "/moving_mean"]) / torch.sqrt(S[base + "/moving_variance"] + R.BN_EPS)
+            t = _act(t, a)
+            if j == 1 and spec.add_gates:
+                y = torch.relu(t.mean(dim=(1, 2)) @ P[f"block{i}/gate/dense0/kernel"])
+                y = torch.clamp(0.2 * (y @ P[f"block{i}/gate/dense1/kernel"]) + 0.5, 0.0, 1.0)
+                t = t * y[:, None, None, :]
+        f = t + f
+    h = _act(conv_same(f, P["head/conv0/kernel"]), spec.head_activation)
+    h = conv_same(h, P["head/conv1/kernel"])
+    p = torch.tanh(2.0 * h) * 0.51
+    return (torch.clamp(p, -0.5, 0.5) + 0.5) * (spec.v_max - spec.v_min) + spec.v_min, new_state
+
+
+def regularizer_kind(spec: R.GenericResnetSpec, name: str, kind: str):
+    if kind == "bn_gamma":
+        return None
+    if name.startswith("base/"):
+        return spec.kernel_regularizer
+    if name.startswith("head/"):
+        return spec.head_regularizer
+    if "/gate/" in name:
+        return "l2"
+    j = int(name.split("/")[1][4:])
+    return spec.block_regularizer[j] if spec.block_regularizer else spec.kernel_regularizer
+
+
+def regularization(spec, P):
+    total = torch.zeros((), dtype=DT)
+    for name, _, kind in spec.tensors():
+        rk = regularizer_kind(spec, name, kind)
+        if rk == "l1":
+            total = total + 0.01 * P[name].abs().sum()
+        elif rk == "l2":
+            total = total + 0.01 * (P[name] ** 2).sum()
+        elif rk not in (None, "none"):
+            raise ValueError(rk)
+    return total
+
+
+def train_step(spec: R.GenericResnetSpec, ls: O.LossSpec, params: np.ndarray, state: np.ndarray, gt: np.ndarray, noisy: np.ndarray,
+               depth_weight: float = 1.0):
+    """train_step_single_gpu (bfcnn/train_loop.py:259-312): returns (total, model-loss dict, denoiser-loss dict, prediction,
+    flat gradient, new flat state)."""
+    flat = torch.tensor(np.asarray(params, np.float64), dtype=DT, requires_grad=True)
+    P = views(spec, flat)
+    S = state_views(spec, torch.tensor(np.asarray(state, np.float64), dtype=DT))
+    pred, new_state = hydra(spec, P, S, torch.from_numpy(noisy.astype(np.float64)), True)
+    dl = T.denoiser_loss(ls, torch.from_numpy(gt.astype(np.float64)), pred)
+    reg = regularization(spec, P)
+    total = dl["total_loss"] * depth_weight + reg * ls.regularization
+    total.backward()
+    st = np.concatenate([new_state[n].numpy().ravel() for n, _ in spec.state_tensors()]) if spec.state_tensors() else np.zeros(0)
+    ml = {"regularization_loss": float(reg.detach()), "total_loss": float(reg.detach() * ls.regularization)}
+    return float(total.detach()), ml, {k: float(v.detach()) for k, v in dl.items()}, pred.detach().numpy(), flat.grad.numpy().copy(), st
+
+
+def infer(spec, params, state, x):
+    P = views(spec, torch.tensor(np.asarray(params, np.float64), dtype=DT))
+    S = state_views(spec, torch.tensor(np.asarray(state, np.float64), dtype=DT))
+    return hydra(spec, P, S, torch.from_numpy(np.asarray(x, np.float64)), False)[0].numpy()

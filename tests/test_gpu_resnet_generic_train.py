@@ -1,0 +1,159 @@
+"""GPU parity of the training step of the resnet configs outside the 16-filter 3x3 engine (blind_image_denoising_amd/
+resnet_generic_train.py over csrc/train_generic.hip + train_prims.hip) against the torch-autograd oracle
+(oracle/resnet_generic_torch.py): the config the reference ships (1x1 -> depthwise 3x3 x4 + BN -> grouped 1x1 + BN, Add), the
+same with `add_gates`, a two-convolution 3x3 block and a k x k block -- losses, every gradient tensor, the moving statistics
+and one Adam step through the public train_loop API.
+Bars: losses 1e-5 relative, moving statistics 1e-5, every gradient tensor 5e-4 of its largest entry (exact fp32 kernels)."""
+import numpy as np
+import pytest
+import torch
+
+import blind_image_denoising_amd as bf
+from blind_image_denoising_amd import _native as N
+from oracle import bfcnn_oracle as O
+from oracle import resnet_generic_oracle as R
+from oracle import resnet_generic_torch as T
+
+pytestmark = pytest.mark.gpu
+
+
+def _ptr(t):
+    return N.ptr(t)
+
+
+@pytest.mark.parametrize("C,act", [(32, "relu"), (128, "linear"), (64, "relu")])
+def test_bn_train_forward_and_backward(C, act):
+    r = np.random.default_rng(C)
+    x = (r.normal(size=(3, 9, 11, C)) * r.uniform(0.5, 2.0, C) + r.normal(size=C)).astype(np.float32)
+    gamma = r.uniform(0.5, 1.5, C).astype(np.float32)
+    mm, mv = r.normal(size=C).astype(np.float32), r.uniform(0.5, 1.5, C).astype(np.float32)
+    dy = r.normal(size=x.shape).astype(np.float32)
+    xt = torch.tensor(x.astype(np.float64), requires_grad=True)
+    gt_ = torch.tensor(gamma.astype(np.float64), requires_grad=True)
+    mu, var = xt.mean(dim=(0, 1, 2)), ((xt - xt.mean(dim=(0, 1, 2))) ** 2).mean(dim=(0, 1, 2))
+    y = gt_ * (xt - mu) / torch.sqrt(var + 1e-3)
+    y = torch.relu(y) if act == "relu" else y
+    (y * torch.from_numpy(dy.astype(np.float64))).sum().backward()
+    L = N.lib()
+    xd, gd, dd = (torch.from_numpy(a).cuda() for a in (x, gamma, dy))
+    mmd, mvd = torch.from_numpy(mm).cuda(), torch.from_numpy(mv).cuda()
+    yd, save = torch.empty_like(xd), torch.empty(2 * C, device="cuda")
+    scr = torch.empty(int(L.bf_op_bn_train_scratch_floats(C)) + 2, device="cuda")
+    npix = x.size // C
+    N.check(L.bf_op_bn_train_fwd(_ptr(xd), _ptr(gd), _ptr(yd), _ptr(save), _ptr(mmd), _ptr(mvd), npix, C, 1e-3, 0.995,
+                                 1 if act == "relu" else 0, 0.0, _ptr(scr), scr.numel(), N.stream_ptr(xd)), None, "bn fwd")
+    assert np.abs(yd.cpu().numpy() - y.detach().numpy()).max() <= 2e-5 * np.abs(y.detach().numpy()).max()
+    n = npix
+    assert np.abs(mmd.cpu().numpy() - (mm * 0.995 + mu.detach().numpy() * 0.005)).max() <= 1e-6
+    assert np.abs(mvd.cpu().numpy() - (mv * 0.995 + var.detach().numpy() * n / (n - 1) * 0.005)).max() <= 1e-6
+    # backward: the operator takes the gradient in front of the activation
+    dpre = dy * (y.detach().numpy() > 0) if act == "relu" else dy
+    dpd = torch.from_numpy(dpre.astype(np.float32)).cuda()
+    dxd, dgd = torch.empty_like(xd), torch.empty(C, device="cuda")
+    N.check(L.bf_op_bn_train_bwd(_ptr(xd), _ptr(gd), _ptr(save), _ptr(dpd), _ptr(dxd), _ptr(dgd), npix, C, _ptr(scr), scr.numel(),
+                                 N.stream_ptr(xd)), None, "bn bwd")
+    assert np.abs(dxd.cpu().numpy() - xt.grad.numpy()).max() <= 5e-5 * np.abs(xt.grad.numpy()).max()
+    assert np.abs(dgd.cpu().numpy() - gt_.grad.numpy()).max() <= 5e-5 * np.abs(gt_.grad.numpy()).max()
+
+
+@pytest.mark.parametrize("C,res", [(32, True), (128, False)])
+def test_gate_forward_and_backward(C, res):
+    r = np.random.default_rng(C + 1)
+    B, H, W, C8 = 3, 10, 7, max(C // 8, 2)
+    x = r.normal(size=(B, H, W, C)).astype(np.float32) + 0.5
+    w0 = (r.normal(size=(C, C8)) * 0.5).astype(np.float32)
+    w1 = (r.normal(size=(C8, C)) * 3.0).astype(np.float32)        # wide: the linear part and the saturations of hard_sigmoid
+    rs = r.normal(size=x.shape).astype(np.float32)
+    dy = r.normal(size=x.shape).astype(np.float32)
+    xt, w0t, w1t = (torch.tensor(a.astype(np.float64), requires_grad=True) for a in (x, w0, w1))
+    g = torch.clamp(0.2 * (torch.relu(xt.mean(dim=(1, 2)) @ w0t) @ w1t) + 0.5, 0.0, 1.0)
+    out = xt * g[:, None, None, :] + (torch.from_numpy(rs.astype(np.float64)) if res else 0.0)
+    (out * torch.from_numpy(dy.astype(np.float64))).sum().backward()
+    L = N.lib()
+    xd, w0d, w1d, rd, dd = (torch.from_numpy(a).cuda() for a in (x, w0, w1, rs, dy))
+    od = torch.empty_like(xd)
+    save = torch.empty(int(L.bf_op_gate_save_floats(B, C, C8)), device="cuda")
+    scr = torch.empty(int(L.bf_op_gate_scratch_floats(B, C)) + 2, device="cuda")
+    N.check(L.bf_op_gate_fwd(_ptr(xd), _ptr(w0d), _ptr(w1d), _ptr(rd) if res else None, _ptr(od), _ptr(save), B, H * W, C, C8, _ptr(scr),
+                             scr.numel(), N.stream_ptr(xd)), None, "gate fwd")
+    assert np.abs(od.cpu().numpy() - out.detach().numpy()).max() <= 2e-5 * np.abs(out.detach().numpy()).max()
+    dxd, dw0d, dw1d = torch.empty_like(xd), torch.empty_like(w0d), torch.empty_like(w1d)
+    N.check(L.bf_op_gate_bwd(_ptr(xd), _ptr(w0d), _ptr(w1d), _ptr(save), _ptr(dd), _ptr(dxd), _ptr(dw0d), _ptr(dw1d), B, H * W, C, C8,
+                             _ptr(scr), scr.numel(), N.stream_ptr(xd)), None, "gate bwd")
+    for got, ref, what in ((dxd, xt.grad, "dx"), (dw0d, w0t.grad, "dw0"), (dw1d, w1t.grad, "dw1")):
+        assert np.abs(got.cpu().numpy() - ref.numpy()).max() <= 5e-5 * max(np.abs(ref.numpy()).max(), 1e-6), what
+
+
+LOSS = {"hinge": 0.5, "cutoff": 255.0, "mae_multiplier": 1.0, "mse_multiplier": 0.5, "ssim_multiplier": 1.0, "regularization": 0.01}
+
+CONFIGS = {
+    "shipped-bottleneck": dict(no_layers=2),
+    "shipped-bottleneck-gates": dict(no_layers=2, add_gates=True),
+    "two-conv-3x3-gates": dict(filters=32, kernel_size=3, block_kernels=[3, 3], block_filters=[32, 32], block_depthwise=[-1, -1],
+                               block_groups=[1, 1], block_activation=["relu", "relu"], block_regularizer=["l1", "l2"], no_layers=2,
+                               add_gates=True),
+    "bottleneck-64-groups-nobn": dict(filters=64, kernel_size=5, block_kernels=[1, 3, 1], block_filters=[64, 128, 64],
+                                      block_depthwise=[-1, 2, -1], block_groups=[2, 1, 4], block_activation=["relu", "relu", "linear"],
+                                      block_regularizer=["l1", "l1", "l1"], no_layers=1, use_bn=False),
+}
+
+
+def _setup(name, shape, seed):
+    cfg = R.shipped_config()
+    cfg["backbone"].update(CONFIGS[name])
+    spec = R.GenericResnetSpec.from_config(cfg)
+    params, state = R.init_params(spec, seed=seed)
+    clean, noisy = O.synthetic_batch(*shape, seed=seed)
+    return cfg, spec, params, state, clean, noisy
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_train_step_matches_the_gradient_oracle(name):
+    cfg, spec, params, state, clean, noisy = _setup(name, (2, 24, 32), 21)
+    ls = O.LossSpec.from_config(LOSS)
+    r_total, r_ml, r_dl, r_pred, r_grads, r_state = T.train_step(spec, ls, params, state, clean, noisy)
+    model = bf.model_builder(cfg, device="cuda").hydra
+    model.set_weights(params, state)
+    fns = bf.build_train_functions(model, bf.loss_function_builder(LOSS))
+    total, ml, dls, pred, grads = fns.train_step_single_gpu(torch.from_numpy(clean.astype(np.float32)), torch.from_numpy(noisy.astype(np.float32)))
+    torch.cuda.synchronize()
+    assert abs(total.item() - r_total) <= 1e-5 * abs(r_total)
+    assert abs(ml["total_loss"].item() - r_ml["total_loss"]) <= 1e-5 * r_ml["total_loss"]
+    for k in ("total_loss", "mae_loss", "mse_loss", "ssim_loss"):
+        assert abs(dls[0][k].item() - r_dl[k]) <= 2e-5 * max(abs(r_dl[k]), 1e-3), k
+    assert np.abs(pred.cpu().numpy() - r_pred).max() <= 0.02
+    g = grads.cpu().numpy().astype(np.float64)
+    worst = []
+    for n, shape, kind, off in model.trainable_variables:
+        sz = int(np.prod(shape))
+        a, b = g[off:off + sz], r_grads[off:off + sz]
+        worst.append((np.abs(a - b).max() / max(np.abs(b).max(), 1e-7), n))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 5e-4, worst[:5]
+    if spec.state_tensors():
+        assert np.abs(model.state.cpu().numpy() - r_state).max() <= 1e-5 * max(1.0, np.abs(r_state).max())
+    # the trained model still runs inference with the NEW moving statistics (folded weights refreshed)
+    out = np.asarray(model(noisy.astype(np.float32)), np.float64)
+    ref = R.hydra_forward(spec, params, model.state.cpu().numpy(), noisy.astype(np.float64))
+    assert np.abs(out - ref).mean() / 255.0 <= 1e-4
+
+
+def test_shipped_config_trains_through_the_public_api():
+    cfg, spec, params, state, clean, noisy = _setup("shipped-bottleneck-gates", (2, 32, 32), 5)
+    model = bf.model_builder(cfg, device="cuda").hydra
+    model.set_weights(params, state)
+    fns = bf.build_train_functions(model, bf.loss_function_builder(LOSS))
+    opt, _ = bf.optimizer_builder({"type": "Adam", "schedule": {"type": "exponential_decay", "config": {"decay_rate": 0.9, "decay_steps": 100, "learning_rate": 1e-3}},
+                                   "gradient_clipping_by_norm": 1.0})
+    losses = []
+    gt, x = torch.from_numpy(clean.astype(np.float32)), torch.from_numpy(noisy.astype(np.float32))
+    for _ in range(8):
+        total, _, _, _, grads = fns.train_step_single_gpu(gt, x)
+        fns.apply_grads(opt, grads, None)
+        losses.append(total.item())
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]                   # eight Adam steps on one batch reduce its loss
+    a = fns.train_step_single_gpu(gt, x)[4].clone()
+    st = model.state.clone()
+    model.state.copy_(st)                                                          # (moving statistics advance every step)
+    b = fns.train_step_single_gpu(gt, x)[4]
+    assert torch.equal(a, b)                                                       # fixed-order reductions: bitwise reproducible

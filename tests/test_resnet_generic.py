@@ -35,9 +35,13 @@ def test_shipped_config_inventory_and_host_logic():
     bad = G.shipped_config(); bad["backbone"]["block_filters"] = [32, 128, 64]     # residual Add needs `filters` channels
     with pytest.raises(ValueError, match="residual Add"):
         bf.model_builder(bad, device="cpu")
-    bad = G.shipped_config(); bad["backbone"]["add_gates"] = True
+    bad = G.shipped_config(); bad["backbone"]["add_gelu"] = True
     with pytest.raises(NotImplementedError):
         bf.model_builder(bad, device="cpu")
+    gated = G.shipped_config(); gated["backbone"]["add_gates"] = True
+    mg, sg = bf.model_builder(gated, device="cpu", seed=0).hydra, G.GenericResnetSpec.from_config(gated)
+    assert [(v[0], tuple(v[1]), v[2]) for v in mg.trainable_variables] == [(n, tuple(s), k) for n, s, k in sg.tensors()]
+    assert mg.count_params() == m.count_params() + 6 * 2 * 128 * 16
 
 
 def _check(cfg, shape, seed):
@@ -79,6 +83,19 @@ def test_other_resnet_shapes_match_oracle(bb):
     if "block_activation" not in bb:
         cfg["backbone"]["block_activation"] = ["relu"] * len(bb["block_kernels"])
     _check(cfg, (1, 48, 64), seed=5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bb", [dict(), dict(filters=32, kernel_size=3, block_kernels=[3, 3], block_filters=[32, 32], block_depthwise=[-1, -1],
+                                             block_groups=[1, 1], block_activation=["relu", "relu"], block_regularizer=["l1", "l1"], no_layers=2)],
+                         ids=["shipped-bottleneck", "two-conv"])
+def test_add_gates_matches_oracle(bb):
+    """the channel gate of backbone_blocks.py:199-208 (mean -> Dense relu -> Dense hard_sigmoid -> Multiply) behind the second
+    convolution: in front of the third one, or in front of the Add when the block ends there"""
+    cfg = G.shipped_config()
+    cfg["backbone"].update(bb)
+    cfg["backbone"]["add_gates"] = True
+    _check(cfg, (2, 40, 48), seed=11)
 
 
 @pytest.mark.gpu
