@@ -2,8 +2,8 @@
 
 Inside a training step the loss is computed by the fused head kernel (bf_train_step); the
 callables returned here carry the same configuration (`.desc` -> bf_loss_desc) and also evaluate
-the same quantities on arbitrary tensors for monitoring / evaluation, using torch elementwise
-ops on whatever device the tensors live on (not part of the timed hot path)."""
+the same quantities on arbitrary GPU batches for monitoring / evaluation through the C ABI
+(bf_op_denoiser_loss: the same kernels, csrc/loss_terms.hip)."""
 import ctypes as C
 from typing import Callable, Dict
 
@@ -14,44 +14,23 @@ from .constants import *
 from .custom_logger import logger
 
 
-def mae_diff(error: torch.Tensor, hinge: float = 0.0, cutoff: float = 255.0) -> torch.Tensor:
-    """bfcnn/loss.py:40-65: keras relu(|e|, threshold=hinge, max_value=cutoff), global mean."""
-    a = error.abs()
-    d = torch.where(a > hinge, a, torch.zeros_like(a)).clamp(max=cutoff)
-    return d.mean(dim=(1, 2, 3)).mean()
-
-
-def mae(original, prediction, **kwargs):
-    """bfcnn/loss.py:71-86."""
-    return mae_diff(error=(original - prediction), **kwargs)
-
-
-def rmse_diff(error: torch.Tensor, hinge: float = 0.0, cutoff: float = 255.0 * 255.0) -> torch.Tensor:
-    """bfcnn/loss.py:92-113 (relu on the signed error, sqrt(mean + DEFAULT_EPSILON))."""
-    d = torch.where(error > hinge, error, torch.zeros_like(error)).clamp(max=cutoff) ** 2
-    return torch.sqrt(d.mean(dim=(1, 2, 3)) + DEFAULT_EPSILON).mean()
-
-
-def rmse(original, prediction, **kwargs):
-    """bfcnn/loss.py:119-134."""
-    return rmse_diff(error=(original - prediction), **kwargs)
-
-
-def ssim_mean(original, prediction, max_val: float = 255.0, filter_size: int = 7, filter_sigma: float = 1.5):
-    """tf.reduce_mean(tf.image.ssim(original, prediction, filter_size=7, max_val=255)) as bfcnn/loss.py:219-226 calls it
-    (VALID Gaussian windows, k1 0.01, k2 0.03), for the host-side metric dict; the training step computes the same value
-    and its gradient in csrc/loss_terms.hip."""
-    x, y = original.to(torch.float64).permute(0, 3, 1, 2), prediction.to(torch.float64).permute(0, 3, 1, 2)
-    c = torch.arange(filter_size, dtype=torch.float64, device=x.device) - (filter_size - 1) / 2.0
-    g = -0.5 * c * c / (filter_sigma * filter_sigma)
-    g = torch.softmax((g[None, :] + g[:, None]).reshape(-1), dim=0).reshape(1, 1, filter_size, filter_size)
-    ch = x.shape[1]
-    red = lambda t: torch.nn.functional.conv2d(t, g.repeat(ch, 1, 1, 1), groups=ch)
-    c1, c2 = (0.01 * max_val) ** 2, (0.03 * max_val) ** 2
-    a, b = red(x), red(y)
-    lum = (2.0 * a * b + c1) / (a * a + b * b + c1)
-    cs = (2.0 * red(x * y) - 2.0 * a * b + c2) / (red(x * x + y * y) - a * a - b * b + c2)
-    return (lum * cs).mean().to(torch.float32)
+def _denoiser_loss_slots(gt_batch: torch.Tensor, predicted_batch: torch.Tensor, desc: "N.LossDesc") -> torch.Tensor:
+    """the loss slots of one output scale through the C ABI (bf_op_denoiser_loss: the kernels of csrc/loss_terms.hip that the
+    training step itself uses); both tensors on the GPU.  There is no CPU execution path."""
+    if gt_batch.device.type != "cuda" or predicted_batch.device.type != "cuda":
+        raise RuntimeError("denoiser_loss needs its tensors on the GPU: there is no CPU execution path")
+    if gt_batch.shape != predicted_batch.shape or gt_batch.dim() != 4:
+        raise ValueError(f"expected two [B,H,W,C] batches of one shape, got {tuple(gt_batch.shape)} and {tuple(predicted_batch.shape)}")
+    gt = gt_batch.to(torch.float32).contiguous()
+    pr = predicted_batch.to(device=gt.device, dtype=torch.float32).contiguous()
+    B, H, W, Cc = gt.shape
+    lib = N.lib()
+    losses = torch.zeros(N.BF_LOSS_COUNT, dtype=torch.float32, device=gt.device)
+    dpred = torch.empty_like(pr)
+    scratch = torch.empty(int(lib.bf_op_denoiser_loss_scratch_floats(B, H, W, Cc)) + 64, dtype=torch.float32, device=gt.device)
+    N.check(lib.bf_op_denoiser_loss(N.ptr(pr), N.ptr(gt), B, H, W, Cc, C.byref(desc), N.ptr(dpred), N.ptr(losses), N.ptr(scratch),
+                                    scratch.numel(), N.stream_ptr(gt)), None, "bf_op_denoiser_loss")
+    return losses
 
 
 def loss_function_builder(config: Dict) -> Dict[str, Callable]:
@@ -83,15 +62,10 @@ def loss_function_builder(config: Dict) -> Dict[str, Callable]:
                 TOTAL_LOSS_STR: regularization_loss * regularization_multiplier}
 
     def denoiser_loss(gt_batch: torch.Tensor, predicted_batch: torch.Tensor) -> Dict[str, torch.Tensor]:
-        mae_actual = mae(gt_batch, predicted_batch, hinge=0.0, cutoff=255.0)
-        mse_actual = rmse(gt_batch, predicted_batch, hinge=0.0, cutoff=255.0)
-        zero = torch.zeros((), dtype=torch.float32, device=gt_batch.device)
-        mae_prediction_loss = mae(gt_batch, predicted_batch, hinge=hinge, cutoff=cutoff) if use_mae else zero
-        mse_prediction_loss = rmse(gt_batch, predicted_batch, hinge=hinge, cutoff=cutoff * cutoff) if use_mse else zero
-        ssim_loss = 1.0 - ssim_mean(gt_batch, predicted_batch) if use_ssim else zero          # :217-227
-        return {TOTAL_LOSS_STR: mae_prediction_loss * mae_multiplier + mse_prediction_loss * mse_multiplier
-                                + ssim_loss * ssim_multiplier,
-                MSE_LOSS_STR: mse_actual, MAE_LOSS_STR: mae_actual, SSIM_LOSS_STR: ssim_loss}
+        """bfcnn/loss.py:190-247 on arbitrary batches (monitoring / evaluation): 0-d views of one device buffer"""
+        sl = _denoiser_loss_slots(gt_batch, predicted_batch, desc(1.0))
+        return {TOTAL_LOSS_STR: sl[N.BF_LOSS_DENOISER_TOTAL], MSE_LOSS_STR: sl[N.BF_LOSS_MSE], MAE_LOSS_STR: sl[N.BF_LOSS_MAE],
+                SSIM_LOSS_STR: sl[N.BF_LOSS_SSIM]}
 
     model_loss.desc = desc
     denoiser_loss.desc = desc

@@ -420,3 +420,14 @@ def test_train_step_block_variants_match_oracle(nb, no_layers, shape, use_bn, tr
     p1, _, _ = O.adam_step(params.astype(np.float64), r_grads, np.zeros(params.size), np.zeros(params.size), 0,
                            opt.lr() if opt.iterations == 0 else 1e-3, global_clipnorm=1.0)
     assert np.abs(m.params.cpu().numpy() - p1).max() < 5e-6
+
+
+def test_monitoring_losses_match_oracle_through_the_c_abi():
+    """loss_function_builder(...)["denoiser"](gt, prediction) (bfcnn/loss.py:190-247) on arbitrary GPU batches: the HIP loss kernels."""
+    rng = np.random.default_rng(0)
+    gt, pr = rng.uniform(0, 255, (2, 24, 20, 3)), rng.uniform(0, 255, (2, 24, 20, 3))
+    for cfg in (O.canonical_config()["loss"], {"mse_multiplier": 0.5, "hinge": 3.5}):        # ssim_multiplier defaults to 1.0
+        got = bf.loss_function_builder(cfg)["denoiser"](torch.from_numpy(gt.astype(np.float32)).cuda(), torch.from_numpy(pr.astype(np.float32)).cuda())
+        ref = O.denoiser_loss(O.LossSpec.from_config(cfg), gt, pr)
+        for k in ("total_loss", "mae_loss", "mse_loss", "ssim_loss"):
+            assert abs(float(got[k]) - ref[k]) <= 2e-5 * max(1.0, abs(ref[k])), (k, float(got[k]), ref[k])
