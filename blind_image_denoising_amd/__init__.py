@@ -24,6 +24,7 @@ from .optimizer import optimizer_builder, schedule_builder, deep_supervision_sch
 from .train_loop import (train_loop, build_train_functions, DataParallelTrainer, NativeCommunicator, shard_batch,
                          allreduce_gradients)
 from .checkpoint import Checkpoint, CheckpointManager
+from .resnet_generic import squeeze_and_excite_block, selector_block
 from .pyramid import (build_pyramid_model, build_inverse_pyramid_model, multiscales_generator_fn)
 from .dataset import dataset_builder, PrepareData, noise_augment
 

@@ -122,6 +122,11 @@ SIGNATURES = {
     "bf_op_gate_scratch_floats": (_I64, [_I, _I]),
     "bf_op_gate_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I64, _I, _I, _P, _I64, _P]),
     "bf_op_gate_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _I, _P, _I64, _P]),
+    "bf_op_channel_gate_save_floats": (_I64, [_I, _I, _I, _I]),
+    "bf_op_channel_gate_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _I, _I, _I, _F, _I, _P, _I64, _P]),
+    "bf_op_dense2": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, _F, _I, _P]),
+    "bf_op_selector_mix": (_I, [_P, _P, _P, _P, _I64, _I, _P]),
+    "bf_op_avgpool_same": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "bf_op_channel_repeat": (_I, [_P, _P, _I64, _I, _I, _P]),
     "bf_op_channel_group_sum": (_I, [_P, _P, _I64, _I, _I, _P]),
     "bf_op_group_kernel": (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -103,54 +103,105 @@ __global__ __launch_bounds__(256) void tg_lincomb_kernel(const float* __restrict
     }
 }
 
-// ---- channel gate (backbone_blocks.py:199-208) -------------------------------------------------------------------------
-// one workgroup per sample: m = mean over the image ; h = relu(m W0) ; g = hard_sigmoid(h W1) = clip(0.2 p + 0.5, 0, 1)
-// save: [B][C] mean | [B][C8] h (post relu) | [B][C] p (pre hard_sigmoid) | [B][C] g
-__global__ __launch_bounds__(256) void tg_gate_dense_kernel(const double* __restrict__ partial, int nblk, double hw, int C, int C8,
-                                                            const float* __restrict__ w0, const float* __restrict__ w1, int B,
-                                                            float* __restrict__ save)
+// ---- channel gate (backbone_blocks.py:199-208) and its relatives ----------------------------------------------------------
+// one workgroup per sample: m = mean over the image of the selector tensor (Cs channels) ; h = act0(m W0 + b0) ;
+// p = h W1 + b1 ; g = F(p).  act0: 1 relu, 2 leaky relu (alpha0).  F (mode): 0 hard_sigmoid(p) = clip(0.2 p + 0.5, 0, 1) (the gate;
+// squeeze_and_excite_block's hard version), 1 sigmoid(p) (squeeze_and_excite_block), 2 hard_sigmoid(2.5 - relu(p)) (its
+// learn_to_turn_off form; selector_block GLOBAL / HARD), 3 sigmoid(2.5 - relu(p)) (selector_block GLOBAL / SOFT).
+// save: [B][Cs] mean | [B][C8] h | [B][C] p | [B][C] g
+__device__ __forceinline__ float tg_gate_final(float p, int mode)
+{
+    if (mode == 4) return fmaxf(p, 0.f);                       // plain relu (the selector's LOCAL map, in front of its up-sampling)
+    if (mode >= 2) p = 2.5f - fmaxf(p, 0.f);
+    if (mode == 1 || mode == 3) return 1.f / (1.f + expf(-p));
+    return fminf(fmaxf(0.2f * p + 0.5f, 0.f), 1.f);
+}
+
+__global__ __launch_bounds__(256) void tg_gate_dense_kernel(const double* __restrict__ partial, int nblk, double hw, int Cs, int C, int C8,
+                                                            const float* __restrict__ w0, const float* __restrict__ b0,
+                                                            const float* __restrict__ w1, const float* __restrict__ b1, int act0,
+                                                            float alpha0, int mode, int B, float* __restrict__ save,
+                                                            const float* __restrict__ direct, float* __restrict__ gout)
 {
     __shared__ float m[256], h[64];
     const int b = blockIdx.x, t = threadIdx.x;
-    float* s_mean = save + (int64_t)b * C;
-    float* s_h = save + (int64_t)B * C + (int64_t)b * C8;
-    float* s_p = save + (int64_t)B * (C + C8) + (int64_t)b * C;
-    float* s_g = save + (int64_t)B * (2 * C + C8) + (int64_t)b * C;
-    if (t < C) {
-        double s = 0.0;
-        for (int k = 0; k < nblk; ++k) s += partial[((int64_t)b * nblk + k) * 2 * C + t];
-        m[t] = (float)(s / hw);
-        s_mean[t] = m[t];
+    float* s_mean = save + (int64_t)b * Cs;
+    float* s_h = save + (int64_t)B * Cs + (int64_t)b * C8;
+    float* s_p = save + (int64_t)B * (Cs + C8) + (int64_t)b * C;
+    float* s_g = save + (int64_t)B * (Cs + C8 + C) + (int64_t)b * C;
+    if (t < Cs) {
+        if (direct) {
+            m[t] = direct[(int64_t)b * Cs + t];
+        } else {
+            double s = 0.0;
+            for (int k = 0; k < nblk; ++k) s += partial[((int64_t)b * nblk + k) * 2 * Cs + t];
+            m[t] = (float)(s / hw);
+        }
+        if (save) s_mean[t] = m[t];
     }
     __syncthreads();
     if (t < C8) {
-        float a = 0.f;
-        for (int c = 0; c < C; ++c) a = fmaf(m[c], w0[c * C8 + t], a);
-        h[t] = fmaxf(a, 0.f);
-        s_h[t] = h[t];
+        float a = b0 ? b0[t] : 0.f;
+        for (int c = 0; c < Cs; ++c) a = fmaf(m[c], w0[c * C8 + t], a);
+        h[t] = act0 == 2 ? (a > 0.f ? a : alpha0 * a) : fmaxf(a, 0.f);
+        if (save) s_h[t] = h[t];
     }
     __syncthreads();
     if (t < C) {
-        float p = 0.f;
+        float p = b1 ? b1[t] : 0.f;
         for (int j = 0; j < C8; ++j) p = fmaf(h[j], w1[j * C + t], p);
-        s_p[t] = p;
-        s_g[t] = fminf(fmaxf(0.2f * p + 0.5f, 0.f), 1.f);
+        const float gv = tg_gate_final(p, mode);
+        if (save) { s_p[t] = p; s_g[t] = gv; }
+        if (gout) gout[(int64_t)b * C + t] = gv;
     }
 }
 
-// out = x * g[b][c] (+ res)
+// out = x * g[b][c] [+ x2 * (1 - g[b][c])] [+ add_bc[b][c] * add_scale] [+ res]
 __global__ __launch_bounds__(256) void tg_gate_mul_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                          const float* __restrict__ add_bc, float add_scale,
+                                                          const float* __restrict__ x2, const float* __restrict__ add_bc, float add_scale,
                                                           const float* __restrict__ res, float* __restrict__ out, int64_t hwC, int C,
                                                           int64_t n)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int64_t b = i / hwC;
         const int c = (int)(i % C);
-        float v = x[i] * g[b * C + c];
+        const float gv = g[b * C + c];
+        float v = x[i] * gv;
+        if (x2) v = fmaf(x2[i], 1.f - gv, v);
         if (add_bc) v = fmaf(add_bc[b * C + c], add_scale, v);
         if (res) v += res[i];
         out[i] = v;
+    }
+}
+
+// selector_block with a per-pixel selector map u >= 0 (custom_layers_selector.py:316-330): s = F(2.5 - u), out = x1 s + x2 (1 - s)
+__global__ __launch_bounds__(256) void tg_selector_mix_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                              const float* __restrict__ u, float* __restrict__ out, int64_t n, int soft)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float p = 2.5f - u[i];
+        const float sv = soft ? 1.f / (1.f + expf(-p)) : fminf(fmaxf(0.2f * p + 0.5f, 0.f), 1.f);
+        out[i] = fmaf(x1[i], sv, x2[i] * (1.f - sv));
+    }
+}
+
+// AveragePooling2D(pool, strides, padding="same"), any pool / stride: the divisor is the number of taps inside the image
+__global__ __launch_bounds__(256) void tg_avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C,
+                                                         int ph, int pw, int sh, int sw, int OH, int OW, int pt, int pl)
+{
+    const int64_t n = (int64_t)B * OH * OW * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int ox = (int)(t % OW); t /= OW;
+        const int oy = (int)(t % OH);
+        const int b = (int)(t / OH);
+        const int y0 = max(oy * sh - pt, 0), y1 = min(oy * sh - pt + ph, H);
+        const int x0 = max(ox * sw - pl, 0), x1 = min(ox * sw - pl + pw, W);
+        float a = 0.f;
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) a += in[(((int64_t)b * H + y) * W + x) * C + c];
+        out[i] = a / (float)((y1 - y0) * (x1 - x0));
     }
 }
 
@@ -288,24 +339,70 @@ extern "C" int bf_op_bn_train_bwd(const float* x, const float* gamma, const floa
 }
 
 extern "C" int64_t bf_op_gate_save_floats(int batch, int channels, int squeeze) { return (int64_t)batch * (3 * channels + squeeze); }
+extern "C" int64_t bf_op_channel_gate_save_floats(int batch, int sel_channels, int channels, int squeeze)
+{
+    return (int64_t)batch * (sel_channels + squeeze + 2 * channels);
+}
 extern "C" int64_t bf_op_gate_scratch_floats(int batch, int channels)
 {
     return (int64_t)batch * CS_GRID * 2 * channels * 2 + (int64_t)batch * channels + 64;
 }
 
+extern "C" int bf_op_channel_gate_ex(const float* sel, const float* x, const float* x2, const float* res, float* out, const float* w0,
+                                     const float* b0, const float* w1, const float* b1, float* save, int B, int64_t hw, int Cs, int C,
+                                     int C8, int act0, float alpha0, int mode, float* scratch, int64_t scratch_floats, void* stream)
+{
+    if (!sel || !x || !w0 || !w1 || !out || !save || !scratch || B <= 0 || hw <= 0) return BF_EINVAL;
+    if (!tg_ok_c(Cs) || C <= 0 || C > 256 || C8 <= 0 || C8 > 64 || (act0 != 1 && act0 != 2) || mode < 0 || mode > 3) return BF_EUNSUPPORTED;
+    if (scratch_floats < bf_op_gate_scratch_floats(B, Cs) || (uintptr_t)scratch % 8) return BF_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    double* partial = reinterpret_cast<double*>(scratch);
+    hipLaunchKernelGGL(tg_colsum2_kernel, dim3(CS_GRID, B), dim3(256), 0, s, sel, sel, hw, Cs, partial);
+    hipLaunchKernelGGL(tg_gate_dense_kernel, dim3(B), dim3(256), 0, s, partial, CS_GRID, (double)hw, Cs, C, C8, w0, b0, w1, b1, act0, alpha0,
+                       mode, B, save, (const float*)nullptr, (float*)nullptr);
+    const float* g = save + (int64_t)B * (Cs + C8 + C);
+    hipLaunchKernelGGL(tg_gate_mul_kernel, dim3(tg_grid((int64_t)B * hw * C)), dim3(256), 0, s, x, g, x2, (const float*)nullptr, 0.f, res, out,
+                       hw * C, C, (int64_t)B * hw * C);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
 extern "C" int bf_op_gate_fwd(const float* x, const float* w0, const float* w1, const float* res, float* out, float* save, int B,
                               int64_t hw, int C, int C8, float* scratch, int64_t scratch_floats, void* stream)
 {
-    if (!x || !w0 || !w1 || !out || !save || !scratch || B <= 0 || hw <= 0) return BF_EINVAL;
-    if (!tg_ok_c(C) || C8 <= 0 || C8 > 32) return BF_EUNSUPPORTED;
-    if (scratch_floats < bf_op_gate_scratch_floats(B, C) || (uintptr_t)scratch % 8) return BF_EWORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    double* partial = reinterpret_cast<double*>(scratch);
-    hipLaunchKernelGGL(tg_colsum2_kernel, dim3(CS_GRID, B), dim3(256), 0, s, x, x, hw, C, partial);
-    hipLaunchKernelGGL(tg_gate_dense_kernel, dim3(B), dim3(256), 0, s, partial, CS_GRID, (double)hw, C, C8, w0, w1, B, save);
-    const float* g = save + (int64_t)B * (2 * C + C8);
-    hipLaunchKernelGGL(tg_gate_mul_kernel, dim3(tg_grid((int64_t)B * hw * C)), dim3(256), 0, s, x, g, (const float*)nullptr, 0.f, res, out,
-                       hw * C, C, (int64_t)B * hw * C);
+    if (C8 > 32) return BF_EUNSUPPORTED;                  // (the backward keeps C8 accumulators per thread)
+    return bf_op_channel_gate_ex(x, x, nullptr, res, out, w0, nullptr, w1, nullptr, save, B, hw, C, C, C8, 1, 0.f, 0, scratch, scratch_floats,
+                                 stream);
+}
+
+// out[r] = F(act0(in[r] W0 + b0) W1 + b1) for every row r of in [n][Cs]: two small dense layers (the selector's LOCAL 1x1
+// convolutions on the pooled map; F as in bf_op_channel_gate_ex, plus mode 4 = relu)
+extern "C" int bf_op_dense2(const float* in, const float* w0, const float* b0, const float* w1, const float* b1, float* out, int64_t n,
+                            int Cs, int C, int C8, int act0, float alpha0, int mode, void* stream)
+{
+    if (!in || !w0 || !w1 || !out || n <= 0 || n > 0x7fffffff) return BF_EINVAL;
+    if (Cs <= 0 || Cs > 256 || C <= 0 || C > 256 || C8 <= 0 || C8 > 64 || (act0 != 1 && act0 != 2) || mode < 0 || mode > 4) return BF_EUNSUPPORTED;
+    hipLaunchKernelGGL(tg_gate_dense_kernel, dim3((int)n), dim3(256), 0, (hipStream_t)stream, (const double*)nullptr, 0, 1.0, Cs, C, C8, w0, b0,
+                       w1, b1, act0, alpha0, mode, (int)n, (float*)nullptr, in, out);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+extern "C" int bf_op_selector_mix(const float* x1, const float* x2, const float* u, float* out, int64_t n, int soft, void* stream)
+{
+    if (!x1 || !x2 || !u || !out || n <= 0) return BF_EINVAL;
+    hipLaunchKernelGGL(tg_selector_mix_kernel, dim3(tg_grid(n)), dim3(256), 0, (hipStream_t)stream, x1, x2, u, out, n, soft);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+extern "C" int bf_op_avgpool_same(const float* in, float* out, int B, int H, int W, int C, int pool_h, int pool_w, int stride_h,
+                                  int stride_w, void* stream)
+{
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || pool_h <= 0 || pool_w <= 0 || stride_h <= 0 || stride_w <= 0) return BF_EINVAL;
+    const int OH = (H + stride_h - 1) / stride_h, OW = (W + stride_w - 1) / stride_w;
+    int th = (OH - 1) * stride_h + pool_h - H, tw = (OW - 1) * stride_w + pool_w - W;
+    if (th < 0) th = 0;
+    if (tw < 0) tw = 0;
+    hipLaunchKernelGGL(tg_avgpool_kernel, dim3(tg_grid((int64_t)B * OH * OW * C)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, C,
+                       pool_h, pool_w, stride_h, stride_w, OH, OW, th / 2, tw / 2);
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
 
@@ -322,8 +419,8 @@ extern "C" int bf_op_gate_bwd(const float* x, const float* w0, const float* w1, 
     hipLaunchKernelGGL(tg_colsum2_kernel, dim3(CS_GRID, B), dim3(256), 0, s, dy, x, hw, C, partial);
     hipLaunchKernelGGL(tg_gate_dense_bwd_kernel, dim3(1), dim3(256), 0, s, partial, CS_GRID, C, C8, B, w0, w1, save, dw0, dw1, dmean);
     const float* g = save + (int64_t)B * (2 * C + C8);
-    hipLaunchKernelGGL(tg_gate_mul_kernel, dim3(tg_grid((int64_t)B * hw * C)), dim3(256), 0, s, dy, g, dmean, (float)(1.0 / (double)hw),
-                       (const float*)nullptr, dx, hw * C, C, (int64_t)B * hw * C);
+    hipLaunchKernelGGL(tg_gate_mul_kernel, dim3(tg_grid((int64_t)B * hw * C)), dim3(256), 0, s, dy, g, (const float*)nullptr, dmean,
+                       (float)(1.0 / (double)hw), (const float*)nullptr, dx, hw * C, C, (int64_t)B * hw * C);
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
 

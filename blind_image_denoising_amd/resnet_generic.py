@@ -29,6 +29,57 @@ def channel_gate(x: torch.Tensor, w0: torch.Tensor, w1: torch.Tensor, res: Optio
     return out
 
 
+def _gate_ex(sel, x, x2, res, w0, b0, w1, b1, act0, alpha0, mode):
+    B, H, W, Cc = x.shape
+    Cs, C8 = sel.shape[-1], int(w0.shape[1])
+    L = N.lib()
+    out = torch.empty_like(x)
+    save = torch.empty(int(L.bf_op_channel_gate_save_floats(B, Cs, Cc, C8)), dtype=torch.float32, device=x.device)
+    scratch = torch.empty(int(L.bf_op_gate_scratch_floats(B, Cs)) + 2, dtype=torch.float32, device=x.device)
+    N.check(L.bf_op_channel_gate_ex(N.ptr(sel), N.ptr(x), N.ptr(x2), N.ptr(res), N.ptr(out), N.ptr(w0), N.ptr(b0), N.ptr(w1), N.ptr(b1),
+                                    N.ptr(save), B, H * W, Cs, Cc, C8, act0, float(alpha0), mode, N.ptr(scratch), scratch.numel(),
+                                    N.stream_ptr(x)), None, "bf_op_channel_gate_ex")
+    return out
+
+
+def squeeze_and_excite_block(x: torch.Tensor, w0: torch.Tensor, b0: Optional[torch.Tensor], w1: torch.Tensor, b1: Optional[torch.Tensor],
+                             hard_sigmoid_version: bool = False, learn_to_turn_off: bool = False) -> torch.Tensor:
+    """bfcnn/backbone_blocks.py:251-313 on a [B,H,W,C] device tensor: GlobalAvgPool -> 1x1 conv (w0 [C, Cs], + b0) -> LeakyReLU(0.1) ->
+    1x1 conv (w1 [Cs, C], + b1) -> sigmoid | hard_sigmoid | hard_sigmoid(2.5 - relu(.)); x * gate.  (No builder of the snapshot
+    calls it; it is offered as the operator it is.)"""
+    mode = (2 if learn_to_turn_off else 0) if hard_sigmoid_version else 1
+    return _gate_ex(x, x, None, None, w0, b0, w1, b1, 2, 0.1, mode)
+
+
+SELECTOR_GLOBAL_LEAKY = 0.2      # Dense(activation="leaky_relu"): unresolvable in Keras 2.13, slope 0.2 from Keras 2.15 on
+
+
+def selector_block(x1: torch.Tensor, x2: torch.Tensor, sel: torch.Tensor, w0: torch.Tensor, w1: torch.Tensor, scale_type: str = "local",
+                   activation_type: str = "hard", pool=(32, 32), stride=(8, 8), compress: Optional[int] = None) -> torch.Tensor:
+    """selector_block (bfcnn/custom_layers_selector.py:81-330), scale types LOCAL and GLOBAL: x1 * s + x2 * (1 - s) with
+    s = hard_sigmoid | sigmoid (2.5 - u), u >= 0 computed from the selector layer."""
+    soft = activation_type == "soft"
+    if scale_type == "global":
+        return _gate_ex(sel, x1, x2, None, w0, None, w1, None, 2, SELECTOR_GLOBAL_LEAKY, 3 if soft else 2)
+    B, H, W, Cs = sel.shape
+    if H % stride[0] or W % stride[1]:
+        raise ValueError(f"selector_block LOCAL: the image ({H}x{W}) must be a multiple of the strides {stride} (UpSampling2D restores it)")
+    L = N.lib()
+    OH, OW = H // stride[0], W // stride[1]
+    pooled = torch.empty((B, OH, OW, Cs), dtype=torch.float32, device=sel.device)
+    N.check(L.bf_op_avgpool_same(N.ptr(sel), N.ptr(pooled), B, H, W, Cs, pool[0], pool[1], stride[0], stride[1], N.stream_ptr(sel)), None,
+            "bf_op_avgpool_same")
+    Ct = x1.shape[-1]
+    u = torch.empty((B, OH, OW, Ct), dtype=torch.float32, device=sel.device)
+    N.check(L.bf_op_dense2(N.ptr(pooled), N.ptr(w0), None, N.ptr(w1), None, N.ptr(u), B * OH * OW, Cs, Ct, int(w0.shape[1]), 2, 0.3, 4,
+                           N.stream_ptr(sel)), None, "bf_op_dense2")
+    up = UL.resize_bilinear(u, H, W)                                        # UpSampling2D(strides, bilinear): half-pixel centres
+    out = torch.empty_like(x1)
+    N.check(L.bf_op_selector_mix(N.ptr(x1), N.ptr(x2), N.ptr(up), N.ptr(out), x1.numel(), int(soft), N.stream_ptr(x1)), None,
+            "bf_op_selector_mix")
+    return out
+
+
 class GenericResnetHydra:
     multi_output = False
     auto_exact_fallback = False
@@ -45,8 +96,24 @@ class GenericResnetHydra:
                     "add_channelwise_scaling", "add_learnable_multiplier", "add_mean_sigma_normalization", "use_bias"):
             if bb.get(key, False):
                 raise NotImplementedError(f"resnet: {key} is outside the built graph")
-        if bb.get("selector_params") is not None or bb.get("base_conv_params") is not None:
-            raise NotImplementedError("resnet: selector_params / base_conv_params are outside the built graph")
+        if bb.get("base_conv_params") is not None:
+            raise NotImplementedError("resnet: base_conv_params is outside the built graph")
+        self.selector = None
+        sp = bb.get("selector_params")
+        if sp is not None:
+            # selector_block (custom_layers_selector.py:81-330) in place of the skip Add (backbone_blocks.py:227-239)
+            for key in ("use_lowpass", "use_highpass", "use_conv1x1_selector", "use_local_normalization", "use_global_normalization"):
+                if sp.get(key, False):
+                    raise NotImplementedError(f"selector_block: {key} is outside the built graph")
+            st, at = str(sp.get("scale_type", "local")).strip().lower(), str(sp.get("activation_type", "hard")).strip().lower()
+            if st not in ("local", "global"):
+                raise NotImplementedError(f"selector_block: scale_type {st} (local and global are built)")
+            if at not in ("hard", "soft"):
+                raise KeyError(at.upper())
+            pool = tuple(int(v) for v in sp.get("pool_size", (32, 32)))
+            stride = tuple(int(v) for v in sp.get("strides_size", (pool[0] / 4, pool[1] / 4)))
+            self.selector = dict(scale_type=st, activation_type=at, pool=pool, stride=stride,
+                                 compress=max(1, int(round(int(bb.get("filters", 32)) * sp.get("filters_compress_ratio", 0.25)))))
         if dn.get("use_bias", False) or dn.get("use_bn", False) or dn.get("use_ln", False):
             raise NotImplementedError("denoiser head: use_bias / use_bn / use_ln are outside the built graph")
         self.filters = int(bb.get("filters", 32))
@@ -126,6 +193,15 @@ class GenericResnetHydra:
                     out.append((f"block{i}/gate/dense0/kernel", (cout, c8), "dense"))
                     out.append((f"block{i}/gate/dense1/kernel", (c8, cout), "dense"))
                 cin = cout
+            if self.selector:
+                cs = self.block_filters[0] if self.block_depthwise[0] == -1 else self.filters * self.block_depthwise[0]
+                cc = self.selector["compress"]
+                if self.selector["scale_type"] == "local":
+                    out.append((f"block{i}/selector/conv0/kernel", (1, 1, cs, cc), "conv"))
+                    out.append((f"block{i}/selector/conv1/kernel", (1, 1, cc, self.filters), "conv"))
+                else:
+                    out.append((f"block{i}/selector/dense0/kernel", (cs, cc), "dense"))
+                    out.append((f"block{i}/selector/dense1/kernel", (cc, self.filters), "dense"))
         out.append(("head/conv0/kernel", (1, 1, self.filters, self.head_filters), "conv"))
         out.append(("head/conv1/kernel", (1, 1, self.head_filters, self.out_channels), "conv"))
         return out, state
@@ -214,6 +290,10 @@ class GenericResnetHydra:
                 if j == 1 and self.add_gates:
                     P[f"b{i}gate"] = (dev(W[f"block{i}/gate/dense0/kernel"]), dev(W[f"block{i}/gate/dense1/kernel"]))
                 cin = cout
+            if self.selector:
+                kind = "conv" if self.selector["scale_type"] == "local" else "dense"
+                w0, w1 = W[f"block{i}/selector/{kind}0/kernel"], W[f"block{i}/selector/{kind}1/kernel"]
+                P[f"b{i}sel"] = (dev(w0.reshape(w0.shape[-2], w0.shape[-1])), dev(w1.reshape(w1.shape[-2], w1.shape[-1])))
         P["head0"] = UL.pack_pointwise(dev(W["head/conv0/kernel"][0, 0]))
         P["head1"] = dev(W["head/conv1/kernel"])
         self._packed = P
@@ -231,6 +311,7 @@ class GenericResnetHydra:
         fused = {(32, 4, 32, 3), (32, 2, 32, 3), (64, 2, 64, 3), (32, 4, 64, 3), (32, 1, 32, 3), (64, 1, 64, 3)}   # built instances
         for i in range(self.no_layers):
             t = f
+            first = None
             j = 0
             while j < nb:
                 kind, wp, shift = P[f"b{i}c{j}"]
@@ -240,14 +321,14 @@ class GenericResnetHydra:
                     # depthwise (+BN, act) and the 1x1 after it (+BN, act, +skip) in one kernel: the wide tensor stays on chip
                     _, wp2, shift2 = P[f"b{i}c{j + 1}"]
                     t = UL.dwmult_pointwise(t, wp, shift, self.block_activation[j], wp2, self.block_filters[j + 1], shift2,
-                                            self.block_activation[j + 1], f if j + 1 == nb - 1 else None)
+                                            self.block_activation[j + 1], f if j + 1 == nb - 1 and not self.selector else None)
                     j += 2
                     continue
-                res = f if j == nb - 1 and not gate_here else None          # Add(block output, block input) (backbone_blocks.py:242)
+                res = f if j == nb - 1 and not gate_here and not self.selector else None   # Add(block output, block input) (:242)
                 a = self.block_activation[j]
                 if kind == "dw":
                     t = UL.dwconv_mult(t, wp, shift, a)
-                    if j == nb - 1 and not gate_here:
+                    if j == nb - 1 and not gate_here and not self.selector:
                         raise NotImplementedError("a depthwise convolution as the last convolution of a block")
                 elif kind == "pw":
                     cout = self.block_filters[j]
@@ -255,9 +336,11 @@ class GenericResnetHydra:
                 else:
                     t = UL.conv2d(t, wp, self.block_filters[j], self.block_kernels[j], 1, a, res=res, bias=shift)
                 if gate_here:                                # x * hard_sigmoid(relu(mean(x) W0) W1) [+ skip when the block ends here]
-                    t = channel_gate(t, *P[f"b{i}gate"], res=f if j == nb - 1 else None)
+                    t = channel_gate(t, *P[f"b{i}gate"], res=f if j == nb - 1 and not self.selector else None)
+                if j == 0:
+                    first = t                                # x_1st_conv: the selector layer (backbone_blocks.py:229-231)
                 j += 1
-            f = t
+            f = selector_block(f, t, first, *P[f"b{i}sel"], **self.selector) if self.selector else t
         return f
 
     def _as_device(self, x):

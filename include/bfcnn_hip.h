@@ -399,6 +399,25 @@ int bf_op_gate_fwd(const float* x, const float* w0, const float* w1, const float
                    int channels, int squeeze, float* scratch, int64_t scratch_floats, void* stream);
 int bf_op_gate_bwd(const float* x, const float* w0, const float* w1, const float* save, const float* dy, float* dx, float* dw0,
                    float* dw1, int batch, int64_t hw, int channels, int squeeze, float* scratch, int64_t scratch_floats, void* stream);
+/* the gate's relatives on the same kernels.  m = mean_hw(sel) [B, sel_channels]; h = act0(m W0 + b0) (act0 1 relu, 2 leaky relu
+   with alpha0; biases may be NULL); p = h W1 + b1; g = F(p) with mode 0 hard_sigmoid(p), 1 sigmoid(p), 2 hard_sigmoid(2.5 - relu(p)),
+   3 sigmoid(2.5 - relu(p)); out = x g [+ x2 (1 - g)] [+ res].
+     squeeze_and_excite_block (bfcnn/backbone_blocks.py:251-313): sel = x, act0 2 / alpha0 0.1, mode 1 (default), 0 (hard_sigmoid_version),
+       2 (+ learn_to_turn_off);  selector_block, scale_type GLOBAL (custom_layers_selector.py:268-283, 316-330): sel = the selector
+       layer, x = input_1, x2 = input_2, mode 2 (HARD) / 3 (SOFT).
+   bf_op_selector_mix: the per-pixel form of the same mix for scale_type LOCAL (u >= 0 the up-sampled selector map):
+     s = F(2.5 - u), out = x1 s + x2 (1 - s).  bf_op_avgpool_same: AveragePooling2D(pool, strides, padding "same"), any sizes,
+     divisor = taps inside the image (custom_layers_selector.py:196-201). */
+int64_t bf_op_channel_gate_save_floats(int batch, int sel_channels, int channels, int squeeze);
+int bf_op_channel_gate_ex(const float* sel, const float* x, const float* x2, const float* res, float* out, const float* w0,
+                          const float* b0, const float* w1, const float* b1, float* save, int batch, int64_t hw, int sel_channels,
+                          int channels, int squeeze, int act0, float alpha0, int mode, float* scratch, int64_t scratch_floats,
+                          void* stream);
+int bf_op_dense2(const float* in, const float* w0, const float* b0, const float* w1, const float* b1, float* out, int64_t n,
+                 int in_channels, int channels, int squeeze, int act0, float alpha0, int mode, void* stream);   /* rows of [n][in_channels]; mode 4 = relu */
+int bf_op_selector_mix(const float* x1, const float* x2, const float* u, float* out, int64_t n, int soft, void* stream);
+int bf_op_avgpool_same(const float* in, float* out, int batch, int height, int width, int channels, int pool_h, int pool_w,
+                       int stride_h, int stride_w, void* stream);
 /* layout helpers: out[r][c * m + j] = x[r][c] (a DepthwiseConv2D with depth_multiplier m is a plain depthwise convolution of the
    repeated tensor) and its adjoint out[r][c] = sum_j x[r][c * m + j]; keras Conv2D(groups) kernel [cin / groups][cout] to / from the
    block-diagonal dense [cin][cout] (extract = 1 writes w from dense) */

@@ -58,6 +58,63 @@ def gate(x: np.ndarray, w0: np.ndarray, w1: np.ndarray) -> np.ndarray:
     return x * y[:, None, None, :]
 
 
+def avgpool_same(x: np.ndarray, pool: Tuple[int, int], stride: Tuple[int, int]) -> np.ndarray:
+    """keras AveragePooling2D(pool, strides, padding="same"): TF SAME padding, divisor = taps inside the image"""
+    B, H, W, C = x.shape
+    OH, OW = -(-H // stride[0]), -(-W // stride[1])
+    pt = max((OH - 1) * stride[0] + pool[0] - H, 0) // 2
+    pl = max((OW - 1) * stride[1] + pool[1] - W, 0) // 2
+    out = np.zeros((B, OH, OW, C), dtype=x.dtype)
+    for oy in range(OH):
+        y0, y1 = max(oy * stride[0] - pt, 0), min(oy * stride[0] - pt + pool[0], H)
+        for ox in range(OW):
+            x0, x1 = max(ox * stride[1] - pl, 0), min(ox * stride[1] - pl + pool[1], W)
+            out[:, oy, ox] = x[:, y0:y1, x0:x1].mean(axis=(1, 2))
+    return out
+
+
+def squeeze_and_excite_block(x, w0, b0, w1, b1, hard_sigmoid_version=False, learn_to_turn_off=False):
+    """backbone_blocks.py:251-313: GlobalAvgPool -> 1x1 conv (+bias) -> LeakyReLU(0.1) -> 1x1 conv (+bias) -> sigmoid, or
+    [2.5 - relu] -> hard_sigmoid; x * gate.  w0 [C, Cs], w1 [Cs, C]; biases may be None (use_bias=False)."""
+    m = x.mean(axis=(1, 2))
+    h = m @ w0 + (0.0 if b0 is None else b0)
+    h = np.where(h > 0, h, 0.1 * h)
+    p = h @ w1 + (0.0 if b1 is None else b1)
+    if hard_sigmoid_version:
+        if learn_to_turn_off:
+            p = 2.5 - np.maximum(p, 0.0)
+        g = hard_sigmoid(p)
+    else:
+        g = 1.0 / (1.0 + np.exp(-p))
+    return x * g[:, None, None, :]
+
+
+SELECTOR_GLOBAL_LEAKY = 0.2      # Dense(activation="leaky_relu") does not resolve in Keras 2.13; Keras >= 2.15 gives slope 0.2
+
+
+def selector_block(x1, x2, sel, w0, w1, scale_type="local", activation_type="hard", pool_size=(32, 32), strides_size=None):
+    """custom_layers_selector.py:81-330, scale types LOCAL (the default) and GLOBAL, no optional pre-filters:
+    LOCAL: AveragePooling2D(pool, strides = pool / 4, same) -> 1x1 conv leaky_relu (0.3, activation_wrapper) -> 1x1 conv relu ->
+    UpSampling2D(strides, bilinear); GLOBAL: mean -> Dense leaky_relu -> Dense relu; then s = F(2.5 - x), x1 s + x2 (1 - s)."""
+    from . import unet_oracle as U
+    strides_size = strides_size or (pool_size[0] // 4, pool_size[1] // 4)
+    if scale_type.lower() == "local":
+        u = avgpool_same(sel, pool_size, strides_size)
+        u = u @ w0.reshape(w0.shape[-2], w0.shape[-1])
+        u = np.where(u > 0, u, 0.3 * u)
+        u = np.maximum(u @ w1.reshape(w1.shape[-2], w1.shape[-1]), 0.0)
+        u = U.resize_bilinear(u, u.shape[1] * strides_size[0], u.shape[2] * strides_size[1])
+    elif scale_type.lower() == "global":
+        u = sel.mean(axis=(1, 2)) @ w0
+        u = np.where(u > 0, u, SELECTOR_GLOBAL_LEAKY * u)
+        u = np.maximum(u @ w1, 0.0)[:, None, None, :]
+    else:
+        raise ValueError(scale_type)
+    p = 2.5 - u
+    s = hard_sigmoid(p) if activation_type.lower() == "hard" else 1.0 / (1.0 + np.exp(-p))
+    return x1 * s + x2 * (1.0 - s)
+
+
 @dataclass(frozen=True)
 class GenericResnetSpec:
     filters: int
@@ -80,6 +137,7 @@ class GenericResnetSpec:
     kernel_regularizer: str = "l1"
     block_regularizer: Tuple[str, ...] = ()
     head_regularizer: str = "l2"
+    selector: Tuple = ()                  # () or (scale_type, activation_type, compress channels, pool, stride)
 
     @staticmethod
     def from_config(model_config: Dict) -> "GenericResnetSpec":
@@ -100,7 +158,19 @@ class GenericResnetSpec:
             out_channels=dn.get("output_channels", 3), v_min=float(vr[0]), v_max=float(vr[1]),
             add_gates=bool(bb.get("add_gates", False)), kernel_regularizer=bb.get("kernel_regularizer", "l1"),
             block_regularizer=tuple(bb.get("block_regularizer") or [bb.get("kernel_regularizer", "l1")] * len(bk)),
-            head_regularizer=dn.get("kernel_regularizer", "l2"))
+            head_regularizer=dn.get("kernel_regularizer", "l2"),
+            selector=GenericResnetSpec._selector(bb))
+
+    @staticmethod
+    def _selector(bb) -> Tuple:
+        sp = bb.get("selector_params")
+        if sp is None:
+            return ()
+        pool = tuple(int(v) for v in sp.get("pool_size", (32, 32)))
+        stride = tuple(int(v) for v in sp.get("strides_size", (pool[0] / 4, pool[1] / 4)))
+        filters = bb.get("filters", 32)
+        return (str(sp.get("scale_type", "local")).lower(), str(sp.get("activation_type", "hard")).lower(),
+                max(1, int(round(filters * sp.get("filters_compress_ratio", 0.25)))), pool, stride)
 
     def gate_channels(self) -> int:
         """backbone_blocks.py:131-141: the second convolution's filters, or filters x depth_multiplier for a depthwise one"""
@@ -128,6 +198,14 @@ class GenericResnetSpec:
                     out.append((f"block{i}/gate/dense0/kernel", (gc, max(int(gc / 8), 2)), "dense"))
                     out.append((f"block{i}/gate/dense1/kernel", (max(int(gc / 8), 2), gc), "dense"))
                 cin = cout
+            if self.selector:                                      # the selector's two layers close the block (backbone_blocks.py:227-239)
+                cs, cc = self.block_filters[0] if self.block_depthwise[0] == -1 else self.filters * self.block_depthwise[0], self.selector[2]
+                if self.selector[0] == "local":
+                    out.append((f"block{i}/selector/conv0/kernel", (1, 1, cs, cc), "conv"))
+                    out.append((f"block{i}/selector/conv1/kernel", (1, 1, cc, self.filters), "conv"))
+                else:
+                    out.append((f"block{i}/selector/dense0/kernel", (cs, cc), "dense"))
+                    out.append((f"block{i}/selector/dense1/kernel", (cc, self.filters), "dense"))
         out.append(("head/conv0/kernel", (1, 1, self.filters, self.head_filters), "conv"))
         out.append(("head/conv1/kernel", (1, 1, self.head_filters, self.out_channels), "conv"))
         return out
@@ -180,9 +258,16 @@ def hydra_forward(spec: GenericResnetSpec, params: np.ndarray, state: np.ndarray
                 base = f"block{i}/bn{j}"
                 t = O.bn_infer(t, P[base + "/gamma"], S[base + "/moving_mean"], S[base + "/moving_variance"], BN_EPS)
             t = O.activation_fwd(t, a)
+            if j == 0:
+                first = t                                                # x_1st_conv: the selector layer
             if j == 1 and spec.add_gates:
                 t = gate(t, P[f"block{i}/gate/dense0/kernel"], P[f"block{i}/gate/dense1/kernel"])
-        f = t + f
+        if spec.selector:
+            kind = "conv" if spec.selector[0] == "local" else "dense"
+            f = selector_block(f, t, first, P[f"block{i}/selector/{kind}0/kernel"], P[f"block{i}/selector/{kind}1/kernel"],
+                               spec.selector[0], spec.selector[1], spec.selector[3], spec.selector[4])
+        else:
+            f = t + f
     h = O.activation_fwd(O.conv2d_same(f, P["head/conv0/kernel"]), spec.head_activation)
     h = O.conv2d_same(h, P["head/conv1/kernel"])
     return O.layer_denormalize(np.tanh(2.0 * h) * 0.51, spec.v_min, spec.v_max)

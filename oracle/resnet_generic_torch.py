@@ -77,6 +77,8 @@ def state_views(spec, flat):
 
 def hydra(spec: R.GenericResnetSpec, P, S, x, training: bool):
     """returns (prediction, new state dict)"""
+    if spec.selector:
+        raise NotImplementedError("the gradient oracle does not restate selector_block (inference only in the product as well)")
     new_state = dict(S)
     xn = (torch.clamp(x, spec.v_min, spec.v_max) - spec.v_min) / (spec.v_max - spec.v_min) - 0.5
     f = _act(conv_same(xn, P["base/kernel"]), spec.base_activation)

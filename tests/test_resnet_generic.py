@@ -98,6 +98,49 @@ def test_add_gates_matches_oracle(bb):
     _check(cfg, (2, 40, 48), seed=11)
 
 
+def test_oracle_avgpool_and_squeeze_excite_match_torch():
+    r = np.random.default_rng(4)
+    x = r.normal(size=(2, 32, 24, 5))
+    ref = F.avg_pool2d(torch.from_numpy(x).permute(0, 3, 1, 2), kernel_size=8, stride=2, padding=3, count_include_pad=False)
+    got = G.avgpool_same(x, (8, 8), (2, 2))                                   # SAME: total pad 6 = 3 + 3 here
+    assert np.abs(got - ref.permute(0, 2, 3, 1).numpy()).max() < 1e-12
+    w0, b0, w1, b1 = r.normal(size=(5, 2)), r.normal(size=2), r.normal(size=(2, 5)), r.normal(size=5)
+    xt = torch.from_numpy(x)
+    h = F.leaky_relu(xt.mean(dim=(1, 2)) @ torch.from_numpy(w0) + torch.from_numpy(b0), 0.1)
+    p = h @ torch.from_numpy(w1) + torch.from_numpy(b1)
+    assert np.abs(G.squeeze_and_excite_block(x, w0, b0, w1, b1) - (xt * torch.sigmoid(p)[:, None, None, :]).numpy()).max() < 1e-12
+    hs = torch.clamp(0.2 * (2.5 - torch.relu(p)) + 0.5, 0, 1)
+    assert np.abs(G.squeeze_and_excite_block(x, w0, b0, w1, b1, True, True) - (xt * hs[:, None, None, :]).numpy()).max() < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sp", [dict(scale_type="local", pool_size=(16, 16)), dict(scale_type="local", activation_type="soft", pool_size=(8, 8), strides_size=(4, 4)),
+                                dict(scale_type="global"), dict(scale_type="global", activation_type="soft", filters_compress_ratio=0.5)],
+                         ids=["local-hard", "local-soft", "global-hard", "global-soft"])
+def test_selector_block_matches_oracle(sp):
+    """selector_params: selector_block (custom_layers_selector.py:81-330) mixes the block's input and output in place of the Add"""
+    cfg = G.shipped_config()
+    cfg["backbone"].update(no_layers=2, selector_params=sp)
+    _check(cfg, (2, 32, 48), seed=13)
+    cfg["backbone"]["add_gates"] = True
+    _check(cfg, (1, 32, 32), seed=14)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C", [32, 128])
+@pytest.mark.parametrize("hard,off", [(False, False), (True, False), (True, True)])
+def test_squeeze_and_excite_block_matches_oracle(C, hard, off):
+    from helpers import dev, host, assert_close
+    r = np.random.default_rng(C)
+    Cs = max(1, int(round(C * 0.25)))
+    x = r.normal(size=(3, 9, 14, C)) + 0.3
+    w0, b0, w1, b1 = r.normal(size=(C, Cs)) * 0.4, r.normal(size=Cs) * 0.2, r.normal(size=(Cs, C)), r.normal(size=C) * 0.5
+    got = bf.squeeze_and_excite_block(dev(x), dev(w0), dev(b0), dev(w1), dev(b1), hard, off)
+    assert_close(host(got), G.squeeze_and_excite_block(x, w0, b0, w1, b1, hard, off), what="squeeze and excite")
+    got = bf.squeeze_and_excite_block(dev(x), dev(w0), None, dev(w1), None, hard, off)
+    assert_close(host(got), G.squeeze_and_excite_block(x, w0, None, w1, None, hard, off), what="squeeze and excite, no bias")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("cin,m,cout", [(32, 4, 32), (32, 2, 32), (64, 2, 64), (32, 4, 64), (32, 1, 32), (64, 1, 64)])
 @pytest.mark.parametrize("shape", [(1, 1, 1), (2, 9, 37), (1, 16, 64)])
