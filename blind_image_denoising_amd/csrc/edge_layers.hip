@@ -135,21 +135,26 @@ __global__ __launch_bounds__(512) void base_wgrad_kernel(const float* __restrict
                                                          float* __restrict__ partial, int B, int H, int W,
                                                          float v_min, float v_max, int tiles_x, int tiles_y, int ntiles)
 {
+    // thread = (row slice s = tid / 32 of the 16-row tile, tap-channel combination j = tid % 32 [+ 32 i]); it keeps the 16
+    // output-channel accumulators of its combinations: per pixel ONE read of x and four 16-byte reads of dy (the same address
+    // for the 32 lanes of a slice: a broadcast) feed 16 FMAs.  The first form (one thread per output, two LDS reads per FMA)
+    // was LDS-bound: 155 us at 32 x 256 x 256.
     constexpr int R = K / 2, IH = BW_TH + 2 * R, IW = BW_TW + 2 * R;
-    constexpr int NOUT = K * K * CIN * 16, PER = (NOUT + 511) / 512;
+    constexpr int NCOMB = K * K * CIN, PERC = (NCOMB + 31) / 32, NOUT = NCOMB * 16;
+    static_assert(BW_TH == 16, "one row slice per 32 threads");
     __shared__ float tx_[IH * IW * CIN];
     __shared__ __attribute__((aligned(16))) float td[BW_TH * BW_TW * 16];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, slice = tid >> 5, j0 = tid & 31;
     const float range = v_max - v_min;
-    float acc[PER];
-    int xoff[PER], co[PER];
+    f32x4 acc[PERC][4];
+    int xoff[PERC];
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        acc[i] = 0.f;
-        int o = tid + i * 512;
-        if (o >= NOUT) o = 0;
-        co[i] = o & 15;
-        const int ci = (o >> 4) % CIN, tap = (o >> 4) / CIN;
+    for (int i = 0; i < PERC; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int jj = j0 + 32 * i;
+        if (jj >= NCOMB) jj = 0;
+        const int ci = jj % CIN, tap = jj / CIN;
         xoff[i] = ((tap / K) * IW + (tap % K)) * CIN + ci;
     }
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -177,18 +182,35 @@ __global__ __launch_bounds__(512) void base_wgrad_kernel(const float* __restrict
             *reinterpret_cast<float4*>(td + n * 4) = v;
         }
         __syncthreads();
-        for (int r = 0; r < BW_TH; ++r)
-            for (int c = 0; c < BW_TW; ++c) {
-                const int pb = (r * IW + c) * CIN, db = (r * BW_TW + c) * 16;
+        for (int c = 0; c < BW_TW; ++c) {
+            const int pb = (slice * IW + c) * CIN, db = (slice * BW_TW + c) * 16;
+            f32x4 d[4];
 #pragma unroll
-                for (int i = 0; i < PER; ++i) acc[i] = fmaf(tx_[pb + xoff[i]], td[db + co[i]], acc[i]);
+            for (int q = 0; q < 4; ++q) d[q] = *reinterpret_cast<const f32x4*>(td + db + 4 * q);
+#pragma unroll
+            for (int i = 0; i < PERC; ++i) {
+                const float xv = tx_[pb + xoff[i]];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[i][q] += d[q] * xv;
             }
+        }
         __syncthreads();
     }
+    // 16 row slices -> one partial per workgroup (fixed order), through the dy tile's LDS ([16 slices][<= 32 * 16] per round)
+    float* red = td;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int o = tid + i * 512;
-        if (o < NOUT) partial[(size_t)blockIdx.x * NOUT + o] = acc[i];
+    for (int i = 0; i < PERC; ++i) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(red + (slice * 32 + j0) * 16 + 4 * q) = acc[i][q];
+        __syncthreads();
+        const int jj = (tid >> 4) + 32 * i, co = tid & 15;            // 512 threads = 32 combinations x 16 channels
+        if (jj < NCOMB) {
+            float a = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < 16; ++sl) a += red[(sl * 32 + (tid >> 4)) * 16 + co];
+            partial[(size_t)blockIdx.x * NOUT + jj * 16 + co] = a;
+        }
     }
 }
 
@@ -329,7 +351,9 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadTrainArgs a, int bl
 {
     __shared__ float whs[64];
     __shared__ float red[4][80];
+    __shared__ float pre_s[32];
     if (threadIdx.x < 64) whs[threadIdx.x] = a.wh[threadIdx.x];
+    if (a.pre_c && threadIdx.x < 32) pre_s[threadIdx.x] = threadIdx.x < 16 ? a.pre_scale[threadIdx.x] : a.pre_shift[threadIdx.x - 16];
     __syncthreads();
     const int b = blockIdx.x / blocks_per_image, sub = blockIdx.x % blocks_per_image;
     const int hw = a.H * a.W;
@@ -345,6 +369,17 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadTrainArgs a, int bl
         for (int i = 0; i < 4; ++i) {
             const float4 v = fp[i];
             f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
+        }
+        if (a.pre_c) {                         // x + (scale * c + shift), rounded as affine_add_kernel rounds it
+            const float4* cp = reinterpret_cast<const float4*>(a.pre_c + pix * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 c = cp[i];
+                f[4 * i] += fmaf(pre_s[4 * i], c.x, pre_s[16 + 4 * i]);
+                f[4 * i + 1] += fmaf(pre_s[4 * i + 1], c.y, pre_s[16 + 4 * i + 1]);
+                f[4 * i + 2] += fmaf(pre_s[4 * i + 2], c.z, pre_s[16 + 4 * i + 2]);
+                f[4 * i + 3] += fmaf(pre_s[4 * i + 3], c.w, pre_s[16 + 4 * i + 3]);
+            }
         }
         float dh1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

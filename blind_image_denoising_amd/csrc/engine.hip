@@ -573,41 +573,44 @@ extern "C" int bf_forward_f32(bf_handle h, const void* packed, const float* in, 
 // ------------------------------------------------------------------------------------------
 // reduces the head partials and writes the head gradients + the data-term losses
 //   partial rows: [0,64) M | 64 sum|e| | 65 hinge sum | 66 per-block sum e^2 (blocks of one image are contiguous)
-__global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restrict__ partial, int nblk, int blocks_per_image, int B,
-                                                            double numel, double per_image, const float* __restrict__ w0,
-                                                            const float* __restrict__ w1, int hf, int co, float* __restrict__ g0,
-                                                            float* __restrict__ g1, float* __restrict__ losses,
-                                                            float mae_multiplier, float depth_weight)
+__global__ __launch_bounds__(1024) void head_finalize_kernel(const float* __restrict__ partial, int nblk, int blocks_per_image, int B,
+                                                             double numel, double per_image, const float* __restrict__ w0,
+                                                             const float* __restrict__ w1, int hf, int co, float* __restrict__ g0,
+                                                             float* __restrict__ g1, float* __restrict__ losses,
+                                                             float mae_multiplier, float depth_weight)
 {
+    constexpr int NS = 15;                     // 66 columns x 15 row stripes = 990 threads
     __shared__ double M[64];
     __shared__ double sums[2];
-    __shared__ double rm[256];
-    __shared__ double part[3][66];
+    __shared__ double rm[1024];
+    __shared__ double part[NS][66];
     const int tid = threadIdx.x;
-    // 66 columns x 3 row stripes (one thread per column walked all B*64 rows alone: 540 us per step), fixed order
-    if (tid < 198) {
+    // (one thread per column walked all B*64 rows alone: 540 us per step; 3 stripes on 198 threads: 61 us), fixed order
+    if (tid < 66 * NS) {
         const int col = tid % 66, stripe = tid / 66;
         double s = 0.0;
         // loads issued eight at a time (a rolled load -> add loop waits out one L2 round trip per row); same add order
         int r = stripe;
-        for (; r + 21 < nblk; r += 24) {
+        for (; r + 7 * NS < nblk; r += 8 * NS) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(r + 3 * u) * 80 + col];
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(r + NS * u) * 80 + col];
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += (double)v[u];
         }
-        for (; r < nblk; r += 3) s += (double)partial[(size_t)r * 80 + col];
+        for (; r < nblk; r += NS) s += (double)partial[(size_t)r * 80 + col];
         part[stripe][col] = s;
     }
     __syncthreads();
     if (tid < 66) {
-        const double s = (part[0][tid] + part[1][tid]) + part[2][tid];
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) s += part[k][tid];
         if (tid < 64) M[tid] = s; else sums[tid - 64] = s;
     }
     // rmse: mean over images of sqrt(mean_sq + DEFAULT_EPSILON)   (loss.py:92-113, constants.py:7)
     double acc = 0.0;
-    for (int b = tid; b < B; b += 256) {
+    for (int b = tid; b < B; b += 1024) {
         double sq = 0.0;
         int k = 0;
         for (; k + 7 < blocks_per_image; k += 8) {
@@ -622,18 +625,18 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restr
     }
     rm[tid] = acc;
     __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
+    for (int st = 512; st > 0; st >>= 1) {
         if (tid < st) rm[tid] += rm[tid + st];
         __syncthreads();
     }
     // dW0[c][j] = sum_o M[c][o] * W1[j][o] ; dW1[j][o] = sum_c W0[c][j] * M[c][o]
-    for (int i = tid; i < 16 * hf; i += 256) {
+    for (int i = tid; i < 16 * hf; i += 1024) {
         const int c = i / hf, j = i % hf;
         double s = 0.0;
         for (int o = 0; o < co; ++o) s += M[c * 4 + o] * (double)w1[j * co + o];
         g0[i] = (float)s;
     }
-    for (int i = tid; i < hf * co; i += 256) {
+    for (int i = tid; i < hf * co; i += 1024) {
         const int j = i / co, o = i % co;
         double s = 0.0;
         for (int c = 0; c < 16; ++c) s += (double)w0[c * hf + j] * M[c * 4 + o];
@@ -651,44 +654,31 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restr
 }
 
 // regularisers (keras "l1" -> 0.01*sum|w|, "l2" -> 0.01*sum w^2; bfcnn/loss.py:181-187):
-// adds d(reg*regularization)/dw to grads and finishes the loss slots.  Single workgroup,
-// fixed order.
+// adds d(reg*regularization)/dw to grads; per-workgroup fp64 partial sums (fixed order), finished by
+// regularizer_finalize_kernel.  (One workgroup walking all 84 k parameters alone took 50 us of a step.)
+constexpr int REG_GRID = 64;
 __global__ __launch_bounds__(1024) void regularizer_kernel(const float* __restrict__ params, float* __restrict__ grads, int64_t n,
                                                            int64_t n_base, int64_t p_blocks, int64_t p_stride, int64_t p_head0,
                                                            int reg_base, int reg_block, int reg_head, float regularization,
-                                                           float* __restrict__ losses, int unit)
+                                                           double* __restrict__ wg_sums, int unit)
 {
     __shared__ double red[1024];
     double acc = 0.0;
-    for (int64_t i0 = threadIdx.x; i0 < n; i0 += 4096) {
-        // four parameter / gradient loads in flight per thread; the per-thread add order is unchanged
-        float wv[4], gv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t i = i0 + 1024 * u;
-            wv[u] = i < n ? params[i] : 0.f;
-            gv[u] = i < n ? grads[i] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-        const int64_t i = i0 + 1024 * u;
-        if (i >= n) break;
+    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (int64_t)REG_GRID * 1024) {
         int reg;
         if (i < n_base) reg = reg_base;
         else if (i >= p_head0) reg = reg_head;
         else {      // block: conv0 [2304], then per further convolution its kernel [2304] and (with BatchNorm) its gamma [16]
-            // (32-bit: a 64-bit remainder is ~60 instructions and this single workgroup walks every parameter)
             const unsigned r = (unsigned)(i - p_blocks) % (unsigned)p_stride;
             reg = (r < 2304u || ((r - 2304u) % (unsigned)unit) < 2304u) ? reg_block : BF_REG_NONE;
         }
-        const float w = wv[u];
+        const float w = params[i];
         if (reg == BF_REG_L1) {
             acc += 0.01 * fabs((double)w);
-            grads[i] = gv[u] + regularization * 0.01f * (w > 0.f ? 1.f : (w < 0.f ? -1.f : 0.f));
+            grads[i] = grads[i] + regularization * 0.01f * (w > 0.f ? 1.f : (w < 0.f ? -1.f : 0.f));
         } else if (reg == BF_REG_L2) {
             acc += 0.01 * (double)w * (double)w;
-            grads[i] = gv[u] + regularization * 0.02f * w;
-        }
+            grads[i] = grads[i] + regularization * 0.02f * w;
         }
     }
     red[threadIdx.x] = acc;
@@ -697,10 +687,17 @@ __global__ __launch_bounds__(1024) void regularizer_kernel(const float* __restri
         if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
         __syncthreads();
     }
+    if (threadIdx.x == 0) wg_sums[blockIdx.x] = red[0];
+}
+
+__global__ void regularizer_finalize_kernel(const double* __restrict__ wg_sums, float regularization, float* __restrict__ losses)
+{
     if (threadIdx.x == 0) {
-        losses[BF_LOSS_REGULARIZATION] = (float)red[0];
-        losses[BF_LOSS_MODEL_TOTAL] = (float)(red[0] * regularization);
-        losses[BF_LOSS_TOTAL] = losses[BF_LOSS_TOTAL] + (float)(red[0] * regularization);
+        double r = 0.0;
+        for (int k = 0; k < REG_GRID; ++k) r += wg_sums[k];
+        losses[BF_LOSS_REGULARIZATION] = (float)r;
+        losses[BF_LOSS_MODEL_TOTAL] = (float)(r * regularization);
+        losses[BF_LOSS_TOTAL] = losses[BF_LOSS_TOTAL] + (float)(r * regularization);
         losses[BF_LOSS_GRAD_NORM] = 0.f;
     }
 }
@@ -822,7 +819,7 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
                 BF_HIP(bf_launch_bn_finalize(partial, conv_grid, count, params + h->p_blocks + i * h->p_block_stride + conv_off(j) + 2304,
                                              state + bn_idx(i, j) * 32, state + bn_idx(i, j) * 32 + 16, d.bn_eps, d.bn_momentum, scale,
                                              scale + 16, w + L.bn_meaninv + bn_idx(i, j) * 32, stage1, s), "bn_finalize");
-                if (last && h3t && h->train_fused_fwd && i + 1 < N && nb >= 2) pending_affine = true;      // block i+1's conv_0 forms A(i+1)
+                if (last && h3t && h->train_fused_fwd && nb >= 2) pending_affine = true;      // block i+1's conv_0 (or the head) forms A(i+1)
                 else if (last) BF_HIP(bf_launch_affine_add(A(i), C(i, j), scale, scale + 16, A(i + 1), npix, s), "affine_add");
                 else BF_HIP(bf_launch_affine_act(C(i, j), scale, scale + 16, T(i, j + 1), relu, npix, s), "affine_act");
             } else if (last) {
@@ -839,7 +836,13 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     // ---- head forward + loss + head backward ---------------------------------------------------
     const double numel = (double)npix * d.out_channels;
     HeadTrainArgs ta;
-    ta.feat = A(N); ta.wh = w + L.wh; ta.gt = gt; ta.pred = predictions; ta.dfeat = dA; ta.partial = partial; ta.dextra = nullptr;
+    ta.pre_c = nullptr; ta.pre_scale = nullptr; ta.pre_shift = nullptr;
+    ta.feat = A(N); ta.wh = w + L.wh;
+    if (pending_affine) {                          // the last block's BatchNorm apply + skip Add: formed by the head on load
+        ta.feat = A(N - 1); ta.pre_c = C(N - 1, nb - 1);
+        ta.pre_scale = w + L.bn_scale + bn_idx(N - 1, nb - 1) * 32; ta.pre_shift = ta.pre_scale + 16;
+    }
+    ta.gt = gt; ta.pred = predictions; ta.dfeat = dA; ta.partial = partial; ta.dextra = nullptr;
     ta.B = B; ta.H = H; ta.W = W; ta.cout = d.out_channels; ta.denormalize = d.denormalize;
     ta.v_min = d.v_min; ta.v_max = d.v_max; ta.hinge = loss->hinge; ta.cutoff = loss->cutoff;
     ta.dscale = loss->mae_multiplier > 0.f ? (float)((double)loss->mae_multiplier * loss->depth_weight / numel) : 0.f;
@@ -880,7 +883,7 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
         ta.dextra = dextra;
     }
     BF_HIP(bf_launch_head_train(ta, hgrid, s), "head_train");
-    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, s, partial, hgrid, hgrid / B, B, numel,
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(1024), 0, s, partial, hgrid, hgrid / B, B, numel,
                        (double)H * W * d.out_channels, params + h->p_head0, params + h->p_head1, d.head_filters, d.out_channels,
                        grads + h->p_head0, grads + h->p_head1, losses, loss->mae_multiplier, loss->depth_weight);
     BF_HIP(hipGetLastError(), "head_finalize");
@@ -980,9 +983,10 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
         hipLaunchKernelGGL(scale_range_kernel, dim3(64), dim3(256), 0, s, grads, h->p_head0, grad_unscale);
         BF_HIP(hipGetLastError(), "grad_unscale");
     }
-    hipLaunchKernelGGL(regularizer_kernel, dim3(1), dim3(1024), 0, s, params, grads, h->n_params, h->n_base, h->p_blocks,
-                       h->p_block_stride, h->p_head0, d.reg_base, d.reg_block, d.reg_head, loss->regularization, losses,
+    hipLaunchKernelGGL(regularizer_kernel, dim3(REG_GRID), dim3(1024), 0, s, params, grads, h->n_params, h->n_base, h->p_blocks,
+                       h->p_block_stride, h->p_head0, d.reg_base, d.reg_block, d.reg_head, loss->regularization, stage1,
                        d.use_bn ? 2320 : 2304);
+    hipLaunchKernelGGL(regularizer_finalize_kernel, dim3(1), dim3(64), 0, s, stage1, loss->regularization, losses);
     BF_HIP(hipGetLastError(), "regularizer");
     return BF_OK;
 }
