@@ -514,7 +514,7 @@ def sub_record(model, module, noisy, noisy_host, spec, params, state, O, N, torc
     else:
         gbs = px * BYTES_PER_PX_BLOCK / launch_s / 1e9
         rec.update({"dtype": "f16x2 split (hi+lo, fp32 accumulate)", "arithmetic": "split-f16 MFMA (f16x3), fp32 accumulate",
-                    "roofline": {"bound": "hbm", "kernel": "fused_block_h3v_kernel" if S <= 256 else "fused_block_h3r_kernel",
+                    "roofline": {"bound": "hbm", "kernel": "fused_block_h3v_kernel" if S <= 256 and B * S >= 3072 else "fused_block_h3r_kernel",
                                  "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                  "launch_us": launch_s * 1e6, "traffic": None,
                                  "mfma_algorithmic_tflops": px * FLOP_PER_PX_BLOCK / launch_s / 1e12}})
@@ -652,8 +652,8 @@ def main():
         achieved = per_launch_flop / avg_launch_s / 1e12
         if h3:
             kernel = {None: "fused_block_h3v_kernel", 4: "fused_block_h3v_kernel", 1: "fused_block_h3r_kernel"}.get(args.h3_variant, "fused_block_h3_kernel")
-            if S > 256 and kernel == "fused_block_h3v_kernel":
-                kernel = "fused_block_h3r_kernel"          # the full-row kernel covers images up to 256 columns
+            if kernel == "fused_block_h3v_kernel" and (S > 256 or (args.h3_variant is None and B * S < 3072)):
+                kernel = "fused_block_h3r_kernel"          # the full-row kernel: images up to 256 columns, batches of >= 3072 rows
             gbs = per_launch_bytes / avg_launch_s / 1e9
             roofline = {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(args.layers, B, S, True, kernel),

@@ -1408,9 +1408,16 @@ hipError_t bf_launch_wgrad3x3_h3(const float* x, const float* dy, float* partial
 using H3Default = H3Cfg<16, 32, 8>;
 using H3Small = H3Cfg<16, 16, 4>;
 
-#define BF_H3_DEFAULT_VARIANT 4      // full-row streaming kernel (fused_h3v.hip) up to 256 columns, row-streaming tiles beyond
-static int g_h3_variant = BF_H3_DEFAULT_VARIANT;      // default of FusedH3Args::variant < 0 (debug entries without a handle)
-void bf_set_h3_variant(int v) { g_h3_variant = v < 0 ? BF_H3_DEFAULT_VARIANT : v; }
+// Default kernel (variant < 0 everywhere): the full-row streaming kernel (4, fused_h3v.hip) for images up to 256 columns when
+// the batch holds enough rows to amortise a band's ~10-step fill (B * H >= 3072: from ~12 rows per workgroup on; measured at
+// 256 x 256: batch 8 0.46 ms (tiles) vs 0.49, batch 16 0.78 vs 0.75, batch 128 5.5 vs 4.5), the row-streaming tile kernel (1)
+// otherwise -- a single 256 x 256 image takes 162 us through the 18 blocks on tiles, 367 us on one-row bands.
+static int g_h3_variant = -1;                         // override of the default for debug entries without a handle (tests, A/B)
+void bf_set_h3_variant(int v) { g_h3_variant = v < 0 ? -1 : v; }
+static int h3_default_variant(const FusedH3Args& a)
+{
+    return (!a.head_wh && bf_fused_block_h3v_supports(a.H, a.W) && (int64_t)a.B * a.H >= 3072) ? 4 : 1;
+}
 
 template <class Cfg, int VARIANT>
 static hipError_t launch_h3(void (*kernel)(FusedH3Args), const FusedH3Args& a, hipStream_t s)
@@ -1431,7 +1438,7 @@ hipError_t bf_launch_fused_block_h3(const FusedH3Args& args, hipStream_t s)
     FusedH3Args a = args;
     if (!a.zeros || !a.dump) return hipErrorInvalidValue;
     if ((int64_t)a.H * a.W * 64 >= ((int64_t)1 << 32)) return hipErrorInvalidValue;      // 32-bit in-image offsets
-    int variant = a.variant < 0 ? g_h3_variant : a.variant;
+    int variant = a.variant >= 0 ? a.variant : (g_h3_variant >= 0 ? g_h3_variant : h3_default_variant(a));
     if (variant & 256) a.reverse_tiles = 1;                      // tests: the bottom-up walk of the full-row streaming kernel
     variant &= 255;
     // full-row streaming kernel: images up to 256 columns, no head epilogue (the tile kernel below takes the rest)
