@@ -273,9 +273,9 @@ def unet_bench(args, torch, bf, O, rank, local_rank, world, dist):
                    "batch_per_gpu": B, "parallelism": f"replicas x{world}, no collective"},
         "parity": {"max_abs_lsb": int(diff.max()), "mean_abs_lsb": float(diff.mean()), "checked": "one 64x64 crop vs oracle"},
         "end_to_end_tflops": tf,
-        "roofline": {"bound": "hbm", "kernel": "uh_enc32s_kernel (level-0 encoder ConvNext block: 2.8 of the 12 ms graph "
+        "roofline": {"bound": "hbm", "kernel": "uh_enc32u_kernel (level-0 encoder ConvNext block: 2.8 of the 12 ms graph "
                                                "are this kernel)", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(0, B, S, True, kernel="uh_enc32s_kernel"),
+                     "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(0, B, S, True, kernel="uh_enc32u_kernel"),
                      "algorithmic_bytes_per_launch": blk_bytes,
                      "launch_us": launch_us,
                      "mfma": {"dtype": "f16 (split hi/lo, 3 products)", "algorithmic_tflops": blk_flop / launch_us / 1e6,

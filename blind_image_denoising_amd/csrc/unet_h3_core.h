@@ -6,16 +6,29 @@
 #include <string.h>
 
 #ifndef UH_ROLE_ABLATE
-#define UH_ROLE_ABLATE 0   // diagnostic builds of uh_enc32s_kernel: 1 consumers idle, 2 producers idle
+#define UH_ROLE_ABLATE 0   // diagnostic builds of uh_enc32s / uh_enc32u_kernel (timing only, results wrong): 1 consumers idle, 2 producers
+                           // idle; consumers: 4 no skip loads / output stores, 8 no scale / activation / split of the hidden layer,
+                           // 16 no MFMAs (the operand reads stay)
 #endif
 
 typedef _Float16 uh8 __attribute__((ext_vector_type(8)));
 typedef _Float16 uh4 __attribute__((ext_vector_type(4)));
 typedef _Float16 uh2 __attribute__((ext_vector_type(2)));
-#define UH_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define UH_MFMA_REAL(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define UH_MFMA(a, b, c) uh_mfma_maybe((a), (b), (c))
 #ifndef UH_MLP_VALU_PER_MFMA
 #define UH_MLP_VALU_PER_MFMA 3
 #endif
+
+__device__ __forceinline__ f32x4 uh_mfma_maybe(const uh8 a, const uh8 b, f32x4 c)
+{
+#if UH_ROLE_ABLATE & 16
+    c[0] += (float)a[0] + (float)b[0];
+    return c;
+#else
+    return UH_MFMA_REAL(a, b, c);
+#endif
+}
 
 // v - float(one half of the packed f16 pair hh) in one instruction (v_fma_mix_f32)
 __device__ __forceinline__ float uh_sub_half(const float v, const unsigned hh, const bool high)
@@ -113,6 +126,10 @@ __device__ __forceinline__ void uh_mlp_core(const uh8 (&xh)[C / 32][NP], const u
         for (int i = 0; i < NP; ++i) {
             // straight-line code from the MFMAs to here: hipcc pads the MFMA -> VALU hazard itself (bf_acc_ready is for reads
             // behind branches; its volatile s_nop would also pin the schedule)
+#if UH_ROLE_ABLATE & 8
+            bh[i] = __builtin_bit_cast(uh8, h[0][i]);
+            bl[i] = __builtin_bit_cast(uh8, h[1][i]);
+#else
             f32x4 v0 = h[0][i] * inv1, v1 = h[1][i] * inv1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -120,6 +137,7 @@ __device__ __forceinline__ void uh_mlp_core(const uh8 (&xh)[C / 32][NP], const u
                 v1[r] = uh_act<ACT>(v1[r], alpha);
             }
             uh_split8(v0, v1, bh[i], bl[i]);
+#endif
         }
 #pragma unroll
         for (int t = 0; t < T2; ++t) {

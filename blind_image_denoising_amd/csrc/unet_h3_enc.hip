@@ -1,6 +1,7 @@
 // Fused ENCODER ConvNext block kernels of the unet_laplacian backbone (split-f16 MLP of unet_h3.hip behind a k x k
 // depthwise convolution + LayerNorm); see unet_h3.hip for the arithmetic and the fragment layouts.
 #include "unet_h3_core.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------
 // Whole ENCODER ConvNextBlock (k x k depthwise, 32 channels) + residual Add in one kernel:
@@ -335,13 +336,14 @@ __global__ __launch_bounds__(512, 1) void uh_enc32s_kernel(const float* __restri
                     ok[i] = py < H && px < W;
                     pix[i] = img + (int64_t)min(py, H - 1) * W + min(px, W - 1);
 #pragma unroll
-                    for (int t = 0; t < T2; ++t) sk[t][i] = *reinterpret_cast<const f32x4*>(x + pix[i] * C + 16 * t + 4 * q);
+                    for (int t = 0; t < T2; ++t)
+                        sk[t][i] = (UH_ROLE_ABLATE & 4) ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(x + pix[i] * C + 16 * t + 4 * q);
                 }
                 f32x4 acc2[T2][NP];
                 uh_mlp_core<C, NP, ACT>(xh, xl, w1l, w2l, inv1, alpha, acc2);
 #pragma unroll
                 for (int i = 0; i < NP; ++i) {
-                    if (!ok[i]) continue;
+                    if (!ok[i] || ((UH_ROLE_ABLATE & 4) && acc2[0][i][0] != 12345.678f)) continue;
 #pragma unroll
                     for (int t = 0; t < T2; ++t)
                         *reinterpret_cast<f32x4*>(out + pix[i] * C + 16 * t + 4 * q) = bf_acc_ready(acc2[t][i]) * m4[t] + sk[t][i];
@@ -353,10 +355,182 @@ __global__ __launch_bounds__(512, 1) void uh_enc32s_kernel(const float* __restri
     }
 }
 
-static int g_uh_enc_variant = 1;     // 1 wave-specialised (default), 0 one kind of wave (A/B, tests)
+// uh_enc32s_kernel with the producer's row walk fully unrolled per tile (see the comment in the producer branch)
+template <int K, int ACT>
+__global__ __launch_bounds__(512, 1) void uh_enc32u_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                           const float* __restrict__ dww, const float* __restrict__ gamma, float eps,
+                                                           const void* __restrict__ packed, const float* __restrict__ mult, int B, int H,
+                                                           int W, float alpha)
+{
+    constexpr int C = 32, NP = 4, RAD = K / 2, T2 = 2, RB = 8;
+    constexpr int W_BYTES = 32 * C * C, STG_FLOATS = RB * 8 * UH_STG_PITCH;       // one strip of one batch
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    {
+        const int4* src = reinterpret_cast<const int4*>(packed);
+        int4* dstv = reinterpret_cast<int4*>(lds);
+        for (int i = threadIdx.x; i < W_BYTES / 16; i += 512) dstv[i] = src[i];
+    }
+    const float* aux = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed) + W_BYTES);
+    const float inv1 = aux[0], inv2 = aux[1];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool producer = wave < 4;
+    const int strip = wave & 3;
+    float* stg_base = reinterpret_cast<float*>(lds + W_BYTES) + strip * STG_FLOATS;     // + (step & 1) * 4 * STG_FLOATS
+    const int tiles_x = (W + 31) / 32, tiles_y = (H + UH_ENC_ROWS - 1) / UH_ENC_ROWS;
+    const int64_t ntiles = (int64_t)B * tiles_y * tiles_x;
+    const int64_t my_tiles = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const int64_t nsteps = 2 * my_tiles;                   // batches of RB rows; UH_ENC_ROWS / RB = 2 per tile
+    static_assert(UH_ENC_ROWS == 2 * RB, "two batches per tile");
+
+    // The two roles are two separate loops (wave-uniform branch) with the same number of barrier arrivals per wave: as one
+    // loop hipcc kept the producers' 100 weight registers AND the consumers' matrix state live together (spills).
+    if (producer) {
+        // ---- depthwise layout: channels 4cl..4cl+3 of strip column pl.  The 16 + 2 RAD input rows of a tile are FULLY
+        // UNROLLED: the ring slot of a row (R % PD), the accumulator of an output row (o % K) and which (row, ky) pairs
+        // exist at the tile's top / bottom are compile-time facts -- no register rotation (16 moves per row in
+        // uh_enc32s_kernel), no arithmetic for the output rows a halo row does not reach (-20 % of the FMAs), no row-mask
+        // multiplies, and no loads for rows past the tile's last one (4 of 24 issued there).
+        const int cl = lane & 7, pl = lane >> 3;
+        constexpr int PD = 4, ROWF4 = (8 + 2 * RAD) * 8, HALVES = 2 * (ROWF4 - 64), NROWS = UH_ENC_ROWS + 2 * RAD;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        struct RowRegs { f32x4 a; f32x2 b; };
+        f32x4 wk[K * K], gm = {1.f, 1.f, 1.f, 1.f}, acc[K];
+        RowRegs ring[PD];
+        const int h1 = lane & (HALVES - 1);
+        f32x4* rowbuf = reinterpret_cast<f32x4*>(lds + W_BYTES + 2 * 4 * STG_FLOATS * 4) + strip * (2 * UH_ROWBUF_F4);
+#pragma unroll
+        for (int i = 0; i < K * K; ++i) wk[i] = *reinterpret_cast<const f32x4*>(dww + i * C + 4 * cl);
+        if (gamma) gm = *reinterpret_cast<const f32x4*>(gamma + 4 * cl);
+        for (int64_t ti = 0; ti < my_tiles; ++ti) {
+            const int64_t tile = blockIdx.x + ti * gridDim.x;
+            const int tx = (int)(tile % tiles_x);
+            const int ty = (int)((tile / tiles_x) % tiles_y);
+            const int64_t pimg = (tile / ((int64_t)tiles_x * tiles_y)) * H * W;
+            const int x0 = tx * 32 + strip * 8, py0 = ty * UH_ENC_ROWS;
+            const bool plive = x0 < W && !(UH_ROLE_ABLATE & 2);
+            const int xg0 = x0 - RAD + (lane >> 3), xg1 = x0 - RAD + 8 + (h1 >> 4);
+            const float gm0 = (xg0 >= 0 && xg0 < W) ? 1.f : 0.f, gm1 = (xg1 >= 0 && xg1 < W) ? 1.f : 0.f;
+            const int go0 = min(max(xg0, 0), W - 1) * C + 4 * cl, go1 = min(max(xg1, 0), W - 1) * C + 2 * (h1 & 15);
+            auto issue = [&](int yy, RowRegs& r) {
+                const float* row = x + (pimg + (int64_t)min(max(yy, 0), H - 1) * W) * C;
+                r.a = *reinterpret_cast<const f32x4*>(row + go0);
+                r.b = *reinterpret_cast<const f32x2*>(row + go1);
+            };
+            float* stg0 = stg_base + ((2 * ti) & 1) * 4 * STG_FLOATS;           // == stg_base: two batches per tile
+            float* stg1 = stg_base + ((2 * ti + 1) & 1) * 4 * STG_FLOATS;
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (plive) {
+#pragma unroll
+                for (int d = 0; d < PD; ++d) issue(py0 - RAD + d, ring[d]);
+            }
+            auto rows = [&](auto lo_c, auto hi_c, float* stg, const int out0) {
+                constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+#pragma unroll
+                for (int R = LO; R < HI; ++R) {
+                    RowRegs& slot = ring[R % PD];
+                    f32x4* rb = rowbuf + (R & 1) * UH_ROWBUF_F4;
+                    rb[lane] = slot.a * gm0;
+                    if (lane < HALVES) reinterpret_cast<f32x2*>(rb + 64)[lane] = slot.b * gm1;
+                    if (R + PD < NROWS) issue(py0 - RAD + R + PD, slot);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const int yi = py0 - RAD + R;
+                    if (yi >= 0 && yi < H) {                   // wave-uniform: a row outside the image contributes nothing
+                        f32x4 v[K];
+#pragma unroll
+                        for (int kx = 0; kx < K; ++kx) v[kx] = rb[(pl + kx) * 8 + cl];
+#pragma unroll
+                        for (int ky = 0; ky < K; ++ky) {
+                            const int o = R - ky;              // output row (of the tile) this input row feeds through tap row ky
+                            if (o >= 0 && o < UH_ENC_ROWS) {
+#pragma unroll
+                                for (int kx = 0; kx < K; ++kx) acc[o % K] += wk[ky * K + kx] * v[kx];
+                            }
+                        }
+                    }
+                    if (R >= K - 1) {
+                        const int o = R - (K - 1);
+                        f32x4 r = acc[o % K];
+                        acc[o % K] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (gamma) {
+                            const float mean = uh_pixel_sum8(r[0] + r[1] + r[2] + r[3]) * (1.f / C);
+                            const f32x4 d = r - mean;
+                            const float var = uh_pixel_sum8(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / C);
+                            r = d * (gm * rsqrtf(var + eps));
+                        }
+                        *reinterpret_cast<f32x4*>(stg + ((o - out0) * 8 + pl) * UH_STG_PITCH + 4 * cl) = r;
+                    }
+                }
+            };
+            if (plive && py0 < H) rows(std::integral_constant<int, 0>{}, std::integral_constant<int, RB + 2 * RAD>{}, stg0, 0);
+            uh_step_barrier();
+            if (plive && py0 + RB < H) rows(std::integral_constant<int, RB + 2 * RAD>{}, std::integral_constant<int, NROWS>{}, stg1, RB);
+            uh_step_barrier();
+        }
+        uh_step_barrier();                                   // the consumers' last step
+    } else {
+        // ---- matrix-core layout
+        const int q = lane >> 4, n = lane & 15;
+        f32x4 m4[T2];
+#pragma unroll
+        for (int t = 0; t < T2; ++t) {
+            m4[t] = (f32x4){inv2, inv2, inv2, inv2};
+            if (mult) m4[t] *= *reinterpret_cast<const f32x4*>(mult + 16 * t + 4 * q);
+        }
+        for (int64_t step = 0; step <= nsteps; ++step) {
+            if (step >= 1) {
+            const int64_t cs = step - 1;                    // the batch the producers finished in the previous step
+            const int batch = (int)(cs & 1);
+            const float* stg = stg_base + (cs & 1) * 4 * STG_FLOATS;
+            const int64_t tile = blockIdx.x + (cs >> 1) * gridDim.x;
+            const int tx = (int)(tile % tiles_x);
+            const int ty = (int)((tile / tiles_x) % tiles_y);
+            const int64_t img = (tile / ((int64_t)tiles_x * tiles_y)) * H * W;
+            const int x0 = tx * 32 + strip * 8, yb = ty * UH_ENC_ROWS + batch * RB;
+            if (x0 < W && yb < H && !(UH_ROLE_ABLATE & 1)) {
+                int wl = lane * 16;
+                asm volatile("" : "+v"(wl));
+                const char* w1l = lds + wl;
+                const char* w2l = lds + 16 * C * C + wl;
+                uh8 xh[1][NP], xl[1][NP];
+                f32x4 sk[T2][NP];
+                int64_t pix[NP];
+                bool ok[NP];
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    const int s = 16 * i + n;             // staged pixel: row 2i + n / 8, column n % 8
+                    const float* sp = stg + s * UH_STG_PITCH + 8 * q;
+                    uh_split8(*reinterpret_cast<const f32x4*>(sp), *reinterpret_cast<const f32x4*>(sp + 4), xh[0][i], xl[0][i]);
+                    const int py = yb + 2 * i + (n >> 3), px = x0 + (n & 7);
+                    ok[i] = py < H && px < W;
+                    pix[i] = img + (int64_t)min(py, H - 1) * W + min(px, W - 1);
+#pragma unroll
+                    for (int t = 0; t < T2; ++t)
+                        sk[t][i] = (UH_ROLE_ABLATE & 4) ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(x + pix[i] * C + 16 * t + 4 * q);
+                }
+                f32x4 acc2[T2][NP];
+                uh_mlp_core<C, NP, ACT>(xh, xl, w1l, w2l, inv1, alpha, acc2);
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    if (!ok[i] || ((UH_ROLE_ABLATE & 4) && acc2[0][i][0] != 12345.678f)) continue;
+#pragma unroll
+                    for (int t = 0; t < T2; ++t)
+                        *reinterpret_cast<f32x4*>(out + pix[i] * C + 16 * t + 4 * q) = bf_acc_ready(acc2[t][i]) * m4[t] + sk[t][i];
+                }
+            }
+            }
+            uh_step_barrier();
+        }
+    }
+}
+
+static int g_uh_enc_variant = 2;     // 2 wave-specialised, unrolled producer (default), 1 wave-specialised, 0 one kind of wave (A/B, tests)
 extern "C" int bf_op_set_variant(const char* key, int value)
 {
-    if (key && !strcmp(key, "enc32")) { g_uh_enc_variant = value ? 1 : 0; return BF_OK; }
+    if (key && !strcmp(key, "enc32")) { g_uh_enc_variant = value < 0 ? 2 : (value > 2 ? 2 : value); return BF_OK; }
     return BF_EINVAL;
 }
 
@@ -371,14 +545,20 @@ extern "C" int bf_op_convnext_block_h3(const float* x, float* out, const float* 
     if (x == out) return BF_EINVAL;                      // neighbouring strips read the halo of this one
     hipStream_t s = (hipStream_t)stream;
     const int64_t ntiles = (int64_t)B * ((H + UH_ENC_ROWS - 1) / UH_ENC_ROWS) * ((W + 31) / 32);
-    if (g_uh_enc_variant == 1) {
+    if (g_uh_enc_variant >= 1) {
         constexpr int LDS_S = 32 * 32 * 32 + 2 * 4 * 8 * 8 * UH_STG_PITCH * 4 + 4 * 2 * UH_ROWBUF_F4 * 16;
         const int grid_s = (int)(ntiles < 256 ? ntiles : 256);
 #define UH_ENCS(KK, A)                                                                                                         \
     {                                                                                                                          \
-        if (bf_set_max_lds(reinterpret_cast<const void*>(uh_enc32s_kernel<KK, A>), LDS_S) != hipSuccess) return BF_EHIP;  /* once per device */ \
-        hipLaunchKernelGGL((uh_enc32s_kernel<KK, A>), dim3(grid_s), dim3(512), LDS_S, s, x, out, dw, ln_gamma, eps, packed, mult, B, H,  \
-                           W, alpha);                                                                                          \
+        if (g_uh_enc_variant == 2) {                                                                                           \
+            if (bf_set_max_lds(reinterpret_cast<const void*>(uh_enc32u_kernel<KK, A>), LDS_S) != hipSuccess) return BF_EHIP;   \
+            hipLaunchKernelGGL((uh_enc32u_kernel<KK, A>), dim3(grid_s), dim3(512), LDS_S, s, x, out, dw, ln_gamma, eps, packed, mult, B, \
+                               H, W, alpha);                                                                                   \
+        } else {                                                                                                               \
+            if (bf_set_max_lds(reinterpret_cast<const void*>(uh_enc32s_kernel<KK, A>), LDS_S) != hipSuccess) return BF_EHIP;   \
+            hipLaunchKernelGGL((uh_enc32s_kernel<KK, A>), dim3(grid_s), dim3(512), LDS_S, s, x, out, dw, ln_gamma, eps, packed, mult, B, \
+                               H, W, alpha);                                                                                   \
+        }                                                                                                                      \
     }
 #define UH_ENCS_K(KK)                                                                                                          \
     switch (act) {                                                                                                             \

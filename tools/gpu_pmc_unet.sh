@@ -15,4 +15,4 @@ pass fetch FETCH_SIZE && pass write WRITE_SIZE && pass sq1 SQ_WAVE_CYCLES SQ_BUS
 pass sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM && pass grbm GRBM_GUI_ACTIVE GRBM_COUNT
 cd "$repo"
 python tools/pmc_summary.py "$out" > "$out/summary.txt"
-grep -A12 "uh_enc32\|uh_mlp_kernel<32" "$out/summary.txt" | head -60
+grep -A22 "uh_enc32\|uh_mlp_kernel<32" "$out/summary.txt" | head -60

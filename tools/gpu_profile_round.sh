@@ -10,7 +10,7 @@ out="$repo/gpurun_out/profiles_$tag"
 mkdir -p "$out"
 export TMPDIR=/tmp
 declare -A ARGS=( [inference]="" [train]="--mode train" [unet]="--mode unet" [unet56]="--mode unet --unet-graph v5.6" [pyramid]="--mode pyramid" )
-declare -A KERNEL=( [inference]="fused_block_h3v_kernel" [train]="bwd3x3_h3_kernel" [unet]="uh_enc32s_kernel" [unet56]="uh_enc32s_kernel" [pyramid]="avgpool" )
+declare -A KERNEL=( [inference]="fused_block_h3v_kernel" [train]="bwd3x3_h3_kernel" [unet]="uh_enc32u_kernel" [unet56]="uh_enc32u_kernel" [pyramid]="avgpool" )
 rc_all=0
 for m in "${modes[@]}"; do
     a="${ARGS[$m]}"
