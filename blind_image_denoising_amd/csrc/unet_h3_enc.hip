@@ -480,47 +480,76 @@ __global__ __launch_bounds__(512, 1) void uh_enc32u_kernel(const float* __restri
             m4[t] = (f32x4){inv2, inv2, inv2, inv2};
             if (mult) m4[t] *= *reinterpret_cast<const f32x4*>(mult + 16 * t + 4 * q);
         }
+        // The skip (x at the batch's own pixels) is fetched ONE STEP AHEAD, while the producers are still reading those rows:
+        // loaded at the top of the step that consumes it, it cost the consumers 295 of their 791 us (one wave per SIMD keeps
+        // too few bytes in flight to hide a memory round trip inside a 5 us step).
+        struct TileAt { int64_t img; int x0, y0; };
+        auto tile_at = [&](const int64_t ti) {
+            const int tile = (int)(blockIdx.x + ti * gridDim.x);          // ntiles < 2^31 (checked by the launcher)
+            const int tx = tile % tiles_x, rest = tile / tiles_x;
+            return TileAt{(int64_t)(rest / tiles_y) * H * W, tx * 32 + strip * 8, (rest % tiles_y) * UH_ENC_ROWS};
+        };
+        auto pixel_of = [&](const TileAt& t, const int yb, const int i, bool& ok) {
+            const int py = yb + 2 * i + (n >> 3), px = t.x0 + (n & 7);
+            ok = py < H && px < W;
+            return t.img + (int64_t)min(py, H - 1) * W + min(px, W - 1);
+        };
+        f32x4 skn[T2][NP];
+#pragma unroll
+        for (int t = 0; t < T2; ++t)
+#pragma unroll
+            for (int i = 0; i < NP; ++i) skn[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        TileAt cur = tile_at(0), prev = cur;
         for (int64_t step = 0; step <= nsteps; ++step) {
-            if (step >= 1) {
-            const int64_t cs = step - 1;                    // the batch the producers finished in the previous step
-            const int batch = (int)(cs & 1);
-            const float* stg = stg_base + (cs & 1) * 4 * STG_FLOATS;
-            const int64_t tile = blockIdx.x + (cs >> 1) * gridDim.x;
-            const int tx = (int)(tile % tiles_x);
-            const int ty = (int)((tile / tiles_x) % tiles_y);
-            const int64_t img = (tile / ((int64_t)tiles_x * tiles_y)) * H * W;
-            const int x0 = tx * 32 + strip * 8, yb = ty * UH_ENC_ROWS + batch * RB;
-            if (x0 < W && yb < H && !(UH_ROLE_ABLATE & 1)) {
-                int wl = lane * 16;
-                asm volatile("" : "+v"(wl));
-                const char* w1l = lds + wl;
-                const char* w2l = lds + 16 * C * C + wl;
-                uh8 xh[1][NP], xl[1][NP];
-                f32x4 sk[T2][NP];
-                int64_t pix[NP];
-                bool ok[NP];
+            const int b = (int)(step & 1);
+            if (b == 0 && step > 0) { prev = cur; cur = tile_at(step >> 1); }
+            f32x4 sk[T2][NP];
 #pragma unroll
-                for (int i = 0; i < NP; ++i) {
-                    const int s = 16 * i + n;             // staged pixel: row 2i + n / 8, column n % 8
-                    const float* sp = stg + s * UH_STG_PITCH + 8 * q;
-                    uh_split8(*reinterpret_cast<const f32x4*>(sp), *reinterpret_cast<const f32x4*>(sp + 4), xh[0][i], xl[0][i]);
-                    const int py = yb + 2 * i + (n >> 3), px = x0 + (n & 7);
-                    ok[i] = py < H && px < W;
-                    pix[i] = img + (int64_t)min(py, H - 1) * W + min(px, W - 1);
+            for (int t = 0; t < T2; ++t)
 #pragma unroll
-                    for (int t = 0; t < T2; ++t)
-                        sk[t][i] = (UH_ROLE_ABLATE & 4) ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(x + pix[i] * C + 16 * t + 4 * q);
-                }
-                f32x4 acc2[T2][NP];
-                uh_mlp_core<C, NP, ACT>(xh, xl, w1l, w2l, inv1, alpha, acc2);
+                for (int i = 0; i < NP; ++i) sk[t][i] = skn[t][i];
+            if (step < nsteps && !(UH_ROLE_ABLATE & 5)) {          // the batch the producers work on now: consumed in the next step
+                const int ybn = cur.y0 + b * RB;
+                if (cur.x0 < W && ybn < H) {
 #pragma unroll
-                for (int i = 0; i < NP; ++i) {
-                    if (!ok[i] || ((UH_ROLE_ABLATE & 4) && acc2[0][i][0] != 12345.678f)) continue;
+                    for (int i = 0; i < NP; ++i) {
+                        bool okn;
+                        const int64_t pn = pixel_of(cur, ybn, i, okn);
 #pragma unroll
-                    for (int t = 0; t < T2; ++t)
-                        *reinterpret_cast<f32x4*>(out + pix[i] * C + 16 * t + 4 * q) = bf_acc_ready(acc2[t][i]) * m4[t] + sk[t][i];
+                        for (int t = 0; t < T2; ++t) skn[t][i] = *reinterpret_cast<const f32x4*>(x + pn * C + 16 * t + 4 * q);
+                    }
                 }
             }
+            if (step >= 1) {
+                const int64_t cs = step - 1;                    // the batch the producers finished in the previous step
+                const float* stg = stg_base + (cs & 1) * 4 * STG_FLOATS;
+                const TileAt& tl = b == 0 ? prev : cur;         // cs odd: second batch of the previous tile; even: first of this one
+                const int yb = tl.y0 + (int)(cs & 1) * RB;
+                if (tl.x0 < W && yb < H && !(UH_ROLE_ABLATE & 1)) {
+                    int wl = lane * 16;
+                    asm volatile("" : "+v"(wl));
+                    const char* w1l = lds + wl;
+                    const char* w2l = lds + 16 * C * C + wl;
+                    uh8 xh[1][NP], xl[1][NP];
+                    int64_t pix[NP];
+                    bool ok[NP];
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) {
+                        const int s = 16 * i + n;             // staged pixel: row 2i + n / 8, column n % 8
+                        const float* sp = stg + s * UH_STG_PITCH + 8 * q;
+                        uh_split8(*reinterpret_cast<const f32x4*>(sp), *reinterpret_cast<const f32x4*>(sp + 4), xh[0][i], xl[0][i]);
+                        pix[i] = pixel_of(tl, yb, i, ok[i]);
+                    }
+                    f32x4 acc2[T2][NP];
+                    uh_mlp_core<C, NP, ACT>(xh, xl, w1l, w2l, inv1, alpha, acc2);
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) {
+                        if (!ok[i] || ((UH_ROLE_ABLATE & 4) && acc2[0][i][0] != 12345.678f)) continue;
+#pragma unroll
+                        for (int t = 0; t < T2; ++t)
+                            *reinterpret_cast<f32x4*>(out + pix[i] * C + 16 * t + 4 * q) = bf_acc_ready(acc2[t][i]) * m4[t] + sk[t][i];
+                    }
+                }
             }
             uh_step_barrier();
         }
@@ -545,6 +574,7 @@ extern "C" int bf_op_convnext_block_h3(const float* x, float* out, const float* 
     if (x == out) return BF_EINVAL;                      // neighbouring strips read the halo of this one
     hipStream_t s = (hipStream_t)stream;
     const int64_t ntiles = (int64_t)B * ((H + UH_ENC_ROWS - 1) / UH_ENC_ROWS) * ((W + 31) / 32);
+    if (ntiles >= 0x7fffffff) return BF_EUNSUPPORTED;      // 32-bit tile arithmetic in the kernels
     if (g_uh_enc_variant >= 1) {
         constexpr int LDS_S = 32 * 32 * 32 + 2 * 4 * 8 * 8 * UH_STG_PITCH * 4 + 4 * 2 * UH_ROWBUF_F4 * 16;
         const int grid_s = (int)(ntiles < 256 ? ntiles : 256);
