@@ -161,22 +161,27 @@ def test_batch_is_independent_and_deterministic():
 
 
 def test_full_size_config_properties():
-    """BASELINE.json config 2/3 scale (1x18, 256x256): size-independent properties instead of the
-    (slow) oracle on the whole batch: oracle on ONE image, batch independence for the rest,
-    fused == unfused path within fp32 reassociation."""
+    """BASELINE.json configs[2] at its real size (1x18, batch 128, 256x256: the full-row streaming kernel, which the default
+    picks from 3 072 image rows per batch on): size-independent properties instead of the (slow) oracle on the whole batch --
+    the oracle on ONE image, position independence inside the batch (the same 16 images at eight places; the reversed batch),
+    fused == unfused path within one LSB -- and the same properties at batch 8 (the tile kernel the default picks there)."""
     cfg, spec, params, state, m = _model(18, seed=42)
-    _, noisy = O.synthetic_batch(8, 256, 256, seed=1234)
+    _, noisy16 = O.synthetic_batch(16, 256, 256, seed=1234)
     mod = bf.DenoiserModule(m)
-    out = mod(noisy)
-    _check_u8(out[:1], O.denoiser_module_call(spec, params, state, noisy[:1]))
-    assert np.array_equal(out[5:6], mod(noisy[5:6]))
-    m.set_option("fused_blocks", 0)
-    out2 = mod(noisy)
-    m.set_option("fused_blocks", 1)
-    assert np.abs(out.astype(int) - out2.astype(int)).max() <= 1
-    # denoising a smooth+noise image must not increase the error against the clean image by much
-    # for a random net; what we can assert is sanity: finite, full range used
-    assert out.min() >= 0 and out.max() <= 255
+    want = O.denoiser_module_call(spec, params, state, noisy16[:1])
+    for reps in (8, 0):                                   # batch 128, then batch 8
+        noisy = np.concatenate([noisy16] * reps) if reps else noisy16[:8]
+        out = mod(noisy)
+        _check_u8(out[:1], want)
+        assert out.min() >= 0 and out.max() <= 255
+        assert np.array_equal(mod(noisy[::-1].copy())[::-1], out)                  # an image's result does not depend on its place
+        if reps:
+            for r in range(1, reps):
+                assert np.array_equal(out[16 * r:16 * (r + 1)], out[:16])
+        m.set_option("fused_blocks", 0)
+        out2 = mod(noisy)
+        m.set_option("fused_blocks", 1)
+        assert np.abs(out.astype(int) - out2.astype(int)).max() <= 1
 
 
 def test_f16_range_guard():
