@@ -99,6 +99,7 @@ def _build_generic_resnet_train_functions(model, denoiser_loss_fn) -> TrainFunct
             state["grads"] = torch.zeros(model.n_params, dtype=torch.float32, device=model.device)
         grads = state["grads"]
         dw = p_depth_weight[0] if hasattr(p_depth_weight, "__len__") else p_depth_weight
+        dw = 1.0 if dw is None else dw
         pred, sl, totals = graph.step(p_input_image_batch, p_noisy_image_batch, grads, float(dw))
         model_loss = {REGULARIZATION_LOSS_STR: totals[1], TOTAL_LOSS_STR: totals[2]}
         denoiser_loss = {TOTAL_LOSS_STR: sl[N.BF_LOSS_DENOISER_TOTAL], MSE_LOSS_STR: sl[N.BF_LOSS_MSE], MAE_LOSS_STR: sl[N.BF_LOSS_MAE],
