@@ -21,7 +21,7 @@ from .constants import *
 from .custom_logger import logger
 from .loss import loss_function_builder
 from .model import HydraModel, model_builder, save_model
-from .optimizer import optimizer_builder
+from .optimizer import optimizer_builder, deep_supervision_schedule_builder
 from .utilities import load_config
 
 TrainFunctions = namedtuple("TrainFunctions", ["train_step", "test_step", "train_step_single_gpu", "apply_grads"])
@@ -309,14 +309,27 @@ def train_loop(pipeline_config_path, model_dir: str, dataset: Iterable = None, w
         w = load_hydra(weights_dir, device=device).get_weights()
         model.set_weights(*w) if isinstance(w, tuple) else model.set_weights(w)
     fns = build_train_functions(model, loss_fn_map)
+    # per-output loss weights over the course of training (bfcnn/train_loop.py:350-381, optimizer.py:21-78)
+    no_outputs = int(getattr(model, "depth", 1)) if getattr(model, "multi_output", False) else 1
+    deep_supervision_schedule = deep_supervision_schedule_builder(
+        config=train_config.get("deep_supervision", {TYPE_STR: "linear_low_to_high"}), no_outputs=no_outputs)
     accumulated = torch.empty(model.n_params, dtype=torch.float32, device=model.device)
     history = []
     finished = 0 < total_steps <= ckpt.step          # a restored run may already be complete
     while not finished and ckpt.epoch < epochs:
         counter = 0
         t0 = time.time()
+        if epochs > 0:                               # train_loop.py:366-371
+            percentage_done = float(ckpt.epoch) / float(epochs)
+        elif total_steps > 0:
+            percentage_done = float(ckpt.step) / float(total_steps)
+        else:
+            percentage_done = 0.0
+        depth_weight = tuple(float(v) for v in deep_supervision_schedule(percentage_done=percentage_done))
+        logger.info("percentage done [{:.2f}], weight per output index: {}".format(percentage_done, ["{0:.2f}".format(d) for d in depth_weight]))
         for input_image_batch, noisy_image_batch in dataset:
-            total, _, denoiser_loss, _, grads = fns.train_step_single_gpu(input_image_batch, noisy_image_batch, (1.0,), 0.0, None)
+            total, _, denoiser_loss, _, grads = fns.train_step_single_gpu(input_image_batch, noisy_image_batch, depth_weight,
+                                                                          percentage_done, None)
             # accumulated (+)= grads on the engine's stream (first micro-batch of a step: overwrite)
             N.check(N.lib().bf_op_axpy(N.ptr(accumulated), N.ptr(grads), 1.0, int(counter == 0), accumulated.numel(),
                                        N.stream_ptr(accumulated)), None, "bf_op_axpy")

@@ -275,3 +275,39 @@ def test_training_randomness_is_drawn_per_step():
     c = fns.train_step_single_gpu(gt, x, [1.0, 0.5])[4].clone()
     d = fns.train_step_single_gpu(gt, x, [1.0, 0.5])[4].clone()
     assert torch.equal(c, d) and torch.isfinite(c).all()
+
+
+def test_train_loop_applies_the_deep_supervision_schedule(tmp_path, caplog):
+    """bfcnn/train_loop.py:350-381: per-output loss weights from deep_supervision_schedule(percentage_done), recomputed every epoch,
+    reach train_step_single_gpu; resumable loop, model directories per epoch."""
+    import logging
+    from oracle import unet_oracle as U
+    ucfg = U.canonical_config(depth=2, width=1, filters=32)
+    cfg = {"model": ucfg["model"], "loss": dict(LOSS_V5),
+           "train": {"epochs": 2, "gpu_batches_per_step": 1, "deep_supervision": {"type": "linear_low_to_high"},
+                     "optimizer": {"type": "Adam", "gradient_clipping_by_norm_local": 1.0,
+                                   "schedule": {"type": "exponential_decay", "config": {"decay_rate": 0.9, "decay_steps": 100, "learning_rate": 1e-3}}}}}
+    clean, noisy = O.synthetic_batch(2, 32, 32, seed=4)
+    data = [(torch.from_numpy(clean.astype(np.float32)), torch.from_numpy(noisy.astype(np.float32)))] * 2
+    seen = []
+    import sys
+    TL = sys.modules["blind_image_denoising_amd.train_loop"]          # (the package attribute of that name is the function)
+    orig = TL.build_train_functions
+
+    def spy(model, loss_fn_map):
+        fns = orig(model, loss_fn_map)
+
+        def step(gt, x, dw, pct, tv):
+            seen.append((tuple(dw), pct))
+            return fns.train_step_single_gpu(gt, x, dw, pct, tv)
+        return TL.TrainFunctions(fns.train_step, fns.test_step, step, fns.apply_grads)
+    TL.build_train_functions = spy
+    try:
+        model, hist = bf.train_loop(cfg, str(tmp_path), dataset=data)
+    finally:
+        TL.build_train_functions = orig
+    assert len(hist) == 4 and all(np.isfinite(hist))
+    # two outputs: base = [1, 2] / 3; epoch 0 -> base, epoch 1 (50 % done) -> the mean of base and its reverse
+    assert seen[0][0] == pytest.approx((1 / 3, 2 / 3)) and seen[0][1] == 0.0
+    assert seen[2][0] == pytest.approx((0.5, 0.5)) and seen[2][1] == 0.5
+    assert (tmp_path / "final").exists()
