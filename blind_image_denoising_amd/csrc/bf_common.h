@@ -138,9 +138,12 @@ struct BwdH3Args {
     float* wpartial;       // [grid][2304]
     float* stats;          // [grid][32]
     int B, H, W, reverse;  // reverse: walk the tiles from the last to the first (Infinity Cache reuse across launches)
+    int dbuf;              // 1: the 512-thread kernel with double-buffered LDS images (one workgroup per CU, 256 partial rows)
+    int* grid_out;         // if not NULL: number of partial rows (workgroups) the launch wrote
     int tiles_x, tiles_y, ntiles;               // filled in by the launcher
 };
-int        bf_bwd3x3_h3_grid(int B, int H, int W);
+int        bf_bwd3x3_h3_grid(int B, int H, int W);                 // partial rows of the 256-thread kernel (the larger count: sizing)
+int        bf_bwd3x3_h3_grid_ex(int B, int H, int W, int dbuf);    // partial rows a launch writes
 hipError_t bf_launch_bwd3x3_h3(const BwdH3Args& a, int epi, float* dw, hipStream_t s);
 hipError_t bf_launch_reduce_wgrad_slots(const float* slots, int64_t slot_floats, int nblk, float* out, int64_t p_stride, int layers,
                                         int nconv, int unit, hipStream_t s);

@@ -36,6 +36,7 @@ struct bf_engine {
     int train_arith = 1;
     int train_zigzag = 1;           // split-f16 training: consecutive kernels walk their tiles in opposite directions
     int train_fused_fwd = 1;        // split-f16 training: BatchNorm apply + skip Add of block i formed while block i+1's first convolution stages its tile
+    int train_bwd_dbuf = 0;         // fused backward kernel: 512-thread form with double-buffered LDS images (A/B: 10 % slower)
     int train_fused_bwd = 1;        // split-f16 training: weight + data gradient (+ BatchNorm backward) of a convolution in one kernel
     // optional HIP-event bracket around the residual-block launches of a forward (bench.py roofline)
     int timing = 0;
@@ -198,6 +199,7 @@ extern "C" int bf_set_option(bf_handle h, const char* key, int value)
     if (!strcmp(key, "fused_head")) { h->fused_head = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_zigzag")) { h->train_zigzag = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_fused_fwd")) { h->train_fused_fwd = value ? 1 : 0; return BF_OK; }
+    if (!strcmp(key, "train_bwd_dbuf")) { h->train_bwd_dbuf = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_fused_bwd")) { h->train_fused_bwd = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_arith")) { h->train_arith = value < 0 ? 1 : (value ? 1 : 0); return BF_OK; }
     if (!strcmp(key, "arith")) { h->arith = value < 0 ? 1 : (value ? 1 : 0); return BF_OK; }
@@ -819,7 +821,9 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
                 BF_HIP(bf_launch_bn_finalize(partial, conv_grid, count, params + h->p_blocks + i * h->p_block_stride + conv_off(j) + 2304,
                                              state + bn_idx(i, j) * 32, state + bn_idx(i, j) * 32 + 16, d.bn_eps, d.bn_momentum, scale,
                                              scale + 16, w + L.bn_meaninv + bn_idx(i, j) * 32, stage1, s), "bn_finalize");
-                if (last && h3t && h->train_fused_fwd && nb >= 2) pending_affine = true;      // block i+1's conv_0 (or the head) forms A(i+1)
+                // block i+1's conv_0 forms A(i+1) on load.  (The head could do the same for the last block -- HeadTrainArgs::pre_c --
+                // but its pixel-per-thread loads are poorly coalesced: +105 us in the head for the 79 us of affine_add.)
+                if (last && h3t && h->train_fused_fwd && i + 1 < N && nb >= 2) pending_affine = true;
                 else if (last) BF_HIP(bf_launch_affine_add(A(i), C(i, j), scale, scale + 16, A(i + 1), npix, s), "affine_add");
                 else BF_HIP(bf_launch_affine_act(C(i, j), scale, scale + 16, T(i, j + 1), relu, npix, s), "affine_act");
             } else if (last) {
@@ -901,7 +905,7 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     const bool fused_bwd = h3t && h->train_fused_bwd;
     // gradient buffers: dA (the head's output) and two spares; the fused kernel ping-pongs between them
     float* const gbuf[3] = {dA, ACT(N + 2 + 2 * (int64_t)N * (nb - 1)), ACT(N + 3 + 2 * (int64_t)N * (nb - 1))};
-    const int bwd_grid = bf_bwd3x3_h3_grid(B, H, W);
+    const int bwd_grid = bf_bwd3x3_h3_grid_ex(B, H, W, h->train_bwd_dbuf);
     float* bwd_stats = partial + (int64_t)bwd_grid * 2304;
     for (int i = N - 1; i >= 0; --i) {
         const float* wp = w + L.wpack + (int64_t)i * 2 * nb * BF_TRAIN_PACK_STRIDE;
@@ -934,7 +938,7 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
                 fa.g = g;
                 if (bn) { fa.c = C(i, j); fa.coef = w + L.coef; }
                 fa.wpack = wp + (int64_t)(nb + j) * BF_TRAIN_PACK_STRIDE;
-                fa.wpartial = w + L.wslots + ((int64_t)i * nb + j) * L.wslot_floats; fa.stats = bwd_stats; fa.reverse = next_reverse();
+                fa.wpartial = w + L.wslots + ((int64_t)i * nb + j) * L.wslot_floats; fa.stats = bwd_stats; fa.reverse = next_reverse(); fa.dbuf = h->train_bwd_dbuf;
                 float* out = nullptr;
                 for (int k = 0; k < 3 && !out; ++k)
                     if (gbuf[k] != g && gbuf[k] != dA) out = gbuf[k];
@@ -1281,6 +1285,7 @@ extern "C" int64_t bf_debug_bwd3x3_h3_scratch_floats(int B, int H, int W)
     return bf_debug_conv3x3_h3_scratch_floats() + (int64_t)bf_bwd3x3_h3_grid(B, H, W) * (2304 + 32);
 }
 extern "C" int bf_debug_bwd3x3_h3_grid(int B, int H, int W) { return bf_bwd3x3_h3_grid(B, H, W); }
+extern "C" int bf_debug_bwd3x3_h3_grid_ex(int B, int H, int W, int dbuf) { return bf_bwd3x3_h3_grid_ex(B, H, W, dbuf); }
 extern "C" int bf_debug_bwd3x3_h3(const float* x, const float* g, const float* c, const float* coef, const float* w_hwio, float* out,
                                   const float* res, const float* bnc, float* dw, float* stats, float* scratch, int B, int H, int W,
                                   int epi, int reverse, int repack, void* stream)
@@ -1297,10 +1302,10 @@ extern "C" int bf_debug_bwd3x3_h3(const float* x, const float* g, const float* c
     memset(&a, 0, sizeof(a));
     a.x = x; a.g = g; a.c = c; a.coef = coef; a.wpack = scratch + 2 * BF_H3_TRAIN_PACK_FLOATS; a.out = out; a.res = res; a.bnc = bnc;
     a.wpartial = partial; a.stats = partial + (int64_t)bf_bwd3x3_h3_grid(B, H, W) * 2304;
-    a.B = B; a.H = H; a.W = W; a.reverse = reverse;
+    a.B = B; a.H = H; a.W = W; a.reverse = reverse & 1; a.dbuf = (reverse >> 1) & 1;       // reverse: bit 0 walk direction, bit 1 kernel form
     if (bf_launch_bwd3x3_h3(a, epi, dw, s) != hipSuccess) return BF_EHIP;
     if (stats && (epi & EPI_BNBWD) &&
-        hipMemcpyAsync(stats, a.stats, (size_t)bf_bwd3x3_h3_grid(B, H, W) * 32 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+        hipMemcpyAsync(stats, a.stats, (size_t)bf_bwd3x3_h3_grid_ex(B, H, W, a.dbuf) * 32 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
         return BF_EHIP;
     return BF_OK;
 }

@@ -46,11 +46,12 @@ struct BwdH3Epi {
     struct Pre {};
     enum { EXTRA_MFMA = 0 };
     const BwdH3Args& a; float inv_s;
-    const char* mask_lds;           // this lane's 4 channels of output row 0 of its strip in the x image (hi plane)
+    mutable const char* mask_lds;   // this lane's 4 channels of output row 0 of its strip in the x image (hi plane)
     // per tile (set_tile); the BatchNorm sums live here across tiles (a pointer to kernel locals put them in scratch memory)
     mutable size_t base; mutable int gy0, gx;
     mutable f32x4 s1, s2;
     __device__ __forceinline__ void set_tile(const size_t base_, const int gy0_, const int gx_) const { base = base_; gy0 = gy0_; gx = gx_; }
+    __device__ __forceinline__ void set_mask(const char* m) const { mask_lds = m; }
     __device__ __forceinline__ Pre pre(const int) const { return Pre{}; }
     __device__ __forceinline__ f32x4 finish(const int, const f32x4 v, const Pre&) const { return v; }
     __device__ __forceinline__ void operator()(const int o, const f32x4 av) const
@@ -251,6 +252,198 @@ __global__ __launch_bounds__(256, 2) void bwd3x3_h3_kernel(BwdH3Args a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same work with the staging of tile t+1 overlapped with the arithmetic of tile t: 512 threads, ONE workgroup per CU,
+// two sets of LDS images (157 KB).  A thread issues the global loads of the next tile (15 x 16 bytes with the BatchNorm
+// operand, 10 without) BEFORE the matrix work of the current one and converts / stores them into the other image set
+// after it; one barrier per tile.  The two-workgroups-per-CU form above only overlaps when the two workgroups happen to be
+// in different phases and runs at 4.3-5.0 TB/s; plain streaming kernels with the same read : write mix reach ~6 on this
+// chip (tools/exp/copy_bw.py).  Waves: weight gradient rows 2w, 2w+1; data gradient strip w & 1, rows 4 (w >> 1) .. +3.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool BNAPPLY, int EPI>
+__global__ __launch_bounds__(512, 1) void bwd3x3_h3d_kernel(BwdH3Args a)
+{
+    using G = BwdH3Geom;
+    constexpr int NT = 512, NW = 8, RQ = G::TH / (NW / 2);              // 4 rows of a strip per wave
+    extern __shared__ __attribute__((aligned(16))) char tb_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const float inv_s = a.wpack[BF_H3R_WPACK_FLOATS];
+    f32x4 k1 = {1.f, 1.f, 1.f, 1.f}, k2 = {0.f, 0.f, 0.f, 0.f}, k3 = {0.f, 0.f, 0.f, 0.f};
+    if (BNAPPLY) {
+        k1 = *reinterpret_cast<const f32x4*>(a.coef + (tid & 3) * 4);
+        k2 = *reinterpret_cast<const f32x4*>(a.coef + 16 + (tid & 3) * 4);
+        k3 = *reinterpret_cast<const f32x4*>(a.coef + 32 + (tid & 3) * 4);
+    }
+    const int tr_off = ((lane & 3) >> 1) * G::PLANE + (4 * (lane >> 4) + ((lane & 15) >> 2)) * 16 + (lane & 1) * 8;
+    f32x4 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int strip = wave & 1, quarter = wave >> 1;
+    const int px_l = strip * 16 + n;
+    const int o0 = quarter * RQ;
+    const int b1 = (q & 1) * G::PLANE + (o0 * G::IW + px_l) * 16;
+    const int mask_off = (q >> 1) * G::PLANE + ((o0 + 1) * G::IW + px_l + 1) * 16 + (q & 1) * 8;
+    const BwdH3Epi<EPI> epi{a, inv_s, tb_lds + mask_off, 0, 0, 0, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+
+    constexpr int NX = (G::IH * G::IW * 4 + NT - 1) / NT;                 // 5
+    f32x4 rx[NX], rg[NX], rc[BNAPPLY ? NX : 1];
+    struct Tile { int y0, x0; size_t img; };
+    auto tile_of = [&](const int t0) {
+        const int t = a.reverse ? a.ntiles - 1 - t0 : t0;
+        const int txi = t % a.tiles_x, rest = t / a.tiles_x;
+        return Tile{(rest % a.tiles_y) * G::TH, txi * G::TW, (size_t)(rest / a.tiles_y) * a.H * a.W * 16};
+    };
+    auto fetch = [&](const Tile& tl) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = tid + i * NT;
+            const int px = e >> 2, quad = e & 3;
+            const int row = px / G::IW, col = px - row * G::IW;
+            const int gy = tl.y0 - 1 + row, gx = tl.x0 - 1 + col;
+            rx[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            rg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (BNAPPLY) rc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (e < G::IH * G::IW * 4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                const size_t idx = tl.img + ((size_t)gy * a.W + gx) * 16 + quad * 4;
+                rx[i] = *reinterpret_cast<const f32x4*>(a.x + idx);
+                rg[i] = *reinterpret_cast<const f32x4*>(a.g + idx);
+                if (BNAPPLY) rc[i] = *reinterpret_cast<const f32x4*>(a.c + idx);
+            }
+        }
+    };
+    auto stash = [&](const Tile& tl, char* xs, char* gs) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = tid + i * NT;
+            if (e < G::IH * G::IW * 4) {
+                const int px = e >> 2, quad = e & 3;
+                const int off = (quad >> 1) * G::PLANE + px * 16 + (quad & 1) * 8;
+                h4 hi, lo;
+                f32x4 xv = rx[i];
+                if (EPI & EPI_MASK) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xv[k] = xv[k] > 0.f ? fmaxf(xv[k], 0x1p-24f) : xv[k];      // see the kernel above
+                }
+                h3_split(xv, hi, lo);
+                *reinterpret_cast<h4*>(xs + off) = hi;
+                *reinterpret_cast<h4*>(xs + off + 2 * G::PLANE) = lo;
+                f32x4 gv = rg[i];
+                if (BNAPPLY) {
+                    const int row = px / G::IW, col = px - row * G::IW;
+                    const int gy = tl.y0 - 1 + row, gx = tl.x0 - 1 + col;
+                    const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) gv[k] = in ? fmaf(k1[k], rg[i][k], fmaf(k2[k], rc[i][k], k3[k])) : 0.f;
+                }
+                h3_split(gv, hi, lo);
+                *reinterpret_cast<h4*>(gs + off) = hi;
+                *reinterpret_cast<h4*>(gs + off + 2 * G::PLANE) = lo;
+            }
+        }
+    };
+
+    int t0 = blockIdx.x;
+    Tile cur = tile_of(t0 < a.ntiles ? t0 : 0);
+    if (t0 < a.ntiles) {
+        fetch(cur);
+        stash(cur, tb_lds, tb_lds + G::IMG);
+    }
+    __syncthreads();
+    for (int k = 0; t0 < a.ntiles; t0 += gridDim.x, ++k) {
+        char* xs = tb_lds + (k & 1) * 2 * G::IMG;
+        char* gs = xs + G::IMG;
+        const bool more = t0 + (int)gridDim.x < a.ntiles;
+        const Tile nxt = tile_of(more ? t0 + (int)gridDim.x : t0);
+        if (more) fetch(nxt);                                   // in flight behind the matrix work below
+
+        h8 w[13];
+        {
+            int opaque = 0;
+            asm volatile("" : "+s"(opaque));
+            const h8* wp = reinterpret_cast<const h8*>(a.wpack + opaque) + lane;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) w[i] = wp[i * 64];
+            w[12] = w[0];
+        }
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * wave + rr;
+            const int gaddr = ((r + 1) * G::IW + 1) * 16 + tr_off;
+            const h8 bh = tb_tr_operand(gs, gaddr);
+            const h8 bl = tb_tr_operand(gs + 2 * G::PLANE, gaddr);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ax = ((r + tap / 3) * G::IW + tap % 3) * 16 + tr_off;
+                const h8 ah = tb_tr_operand(xs, ax);
+                const h8 al = tb_tr_operand(xs + 2 * G::PLANE, ax);
+                acc[tap] = MFMA_H(ah, bh, acc[tap]);
+                acc[tap] = MFMA_H(al, bh, acc[tap]);
+                acc[tap] = MFMA_H(ah, bl, acc[tap]);
+            }
+        }
+        {
+            const int gx = cur.x0 + px_l;
+            epi.set_tile(cur.img + ((size_t)(cur.y0 + o0) * a.W + gx) * 16 + q * 4, cur.y0 + o0, gx);
+            epi.set_mask(xs + mask_off);
+            h3r_rows<RQ, G::IW * 16, 2 * G::PLANE>(gs, b1 + (q >> 1) * 16, b1 + 32 + (q >> 1) * 2 * G::PLANE, w, epi, H3NoHook{});
+        }
+        if (more) stash(nxt, tb_lds + ((k + 1) & 1) * 2 * G::IMG, tb_lds + ((k + 1) & 1) * 2 * G::IMG + G::IMG);
+        cur = nxt;
+        __syncthreads();                       // the other image set is complete; this one is free
+    }
+
+    float* red = reinterpret_cast<float*>(tb_lds);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const f32x4 v = bf_acc_ready(acc[tap]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[(wave * 9 + tap) * 256 + (4 * q + j) * 16 + n] = v[j];
+    }
+    __syncthreads();
+    for (int i = tid; i < 2304; i += NT) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) sacc += red[wv * 2304 + i];
+        a.wpartial[(size_t)blockIdx.x * 2304 + i] = sacc;
+    }
+    if (EPI & EPI_BNBWD) {
+        f32x4 s1 = epi.s1, s2 = epi.s2;
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s1[c] += __shfl_xor(s1[c], m);
+                s2[c] += __shfl_xor(s2[c], m);
+            }
+        }
+        __syncthreads();
+        if (n == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                red[wave * 32 + q * 4 + c] = s1[c];
+                red[wave * 32 + 16 + q * 4 + c] = s2[c];
+            }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv) sacc += red[wv * 32 + tid];
+            a.stats[(size_t)blockIdx.x * 32 + tid] = sacc;
+        }
+    }
+}
+
+int bf_bwd3x3_h3_grid_ex(int B, int H, int W, int dbuf)
+{
+    using G = BwdH3Geom;
+    const int64_t ntiles = (int64_t)B * ((H + G::TH - 1) / G::TH) * ((W + G::TW - 1) / G::TW);
+    const int cap = dbuf ? 256 : 512;
+    return (int)(ntiles < cap ? ntiles : cap);
+}
+
 int bf_bwd3x3_h3_grid(int B, int H, int W)
 {
     using G = BwdH3Geom;
@@ -269,8 +462,32 @@ hipError_t bf_launch_bwd3x3_h3(const BwdH3Args& a0, int epi, float* dw, hipStrea
     a.tiles_y = (a.H + G::TH - 1) / G::TH;
     a.ntiles = a.B * a.tiles_x * a.tiles_y;
     if (a.out == a.x || a.out == a.g || (a.coef && a.out == a.c)) return hipErrorInvalidValue;
-    const int grid = bf_bwd3x3_h3_grid(a.B, a.H, a.W);
+    int grid = bf_bwd3x3_h3_grid(a.B, a.H, a.W);
     const bool bn = a.coef != nullptr;
+    if (a.dbuf) {
+        // one 512-thread workgroup per CU; the partial buffers are sized for bf_bwd3x3_h3_grid rows (>= 256)
+        grid = a.ntiles < 256 ? a.ntiles : 256;
+#define BF_CASE_D(BN, E)                                                                                                  \
+    if (bn == BN && epi == (E)) {                                                                                        \
+        const hipError_t ea = bf_set_max_lds(reinterpret_cast<const void*>(bwd3x3_h3d_kernel<BN, E>), 2 * G::LDS_BYTES);  \
+        if (ea != hipSuccess) return ea;                                                                                 \
+        hipLaunchKernelGGL((bwd3x3_h3d_kernel<BN, E>), dim3(grid), dim3(512), 2 * G::LDS_BYTES, s, a);                    \
+    } else
+        BF_CASE_D(true, EPI_MASK)
+        BF_CASE_D(true, 0)
+        BF_CASE_D(false, EPI_MASK)
+        BF_CASE_D(false, 0)
+        BF_CASE_D(false, EPI_RES)
+        BF_CASE_D(false, EPI_RES | EPI_BNBWD)
+        return hipErrorInvalidValue;
+#undef BF_CASE_D
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        // rows grid .. bf_bwd3x3_h3_grid - 1 of the partial buffers are not written: sum the rows that are
+        if (a.grid_out) *a.grid_out = grid;
+        return dw ? bf_launch_reduce_partials(a.wpartial, grid, 2304, dw, 1.0f, s) : hipSuccess;
+    }
+    if (a.grid_out) *a.grid_out = grid;
 #define BF_CASE(BN, E)                                                                                                    \
     if (bn == BN && epi == (E)) {                                                                                        \
         const hipError_t ea = bf_set_max_lds(reinterpret_cast<const void*>(bwd3x3_h3_kernel<BN, E>), G::LDS_BYTES);       \

@@ -507,6 +507,7 @@ int bf_debug_conv3x3_h3_pre(const float* in, const float* pre_c, const float* pr
                             int reverse, void* stream);
 int64_t bf_debug_bwd3x3_h3_scratch_floats(int batch, int height, int width);
 int bf_debug_bwd3x3_h3_grid(int batch, int height, int width);
+int bf_debug_bwd3x3_h3_grid_ex(int batch, int height, int width, int dbuf);    /* partial rows written; `reverse` bit 1 of the call below = dbuf */
 int bf_debug_bwd3x3_h3(const float* x, const float* g, const float* c, const float* coef, const float* w_hwio, float* out,
                        const float* res, const float* bnc, float* dw, float* stats, float* scratch, int batch, int height,
                        int width, int epi, int reverse, int repack, void* stream);

@@ -122,7 +122,7 @@ def conv3x3_h3_pre_gpu(x, c, scale, shift, w, relu=1, reverse=0):
     return host(y), host(out)
 
 
-def bwd3x3_h3_gpu(x, g, w, epi, c=None, coef=None, res=None, bnc=None, reverse=0):
+def bwd3x3_h3_gpu(x, g, w, epi, c=None, coef=None, res=None, bnc=None, reverse=0, dbuf=0):
     """the fused backward kernel of one convolution: returns (dx, dw[, stats [grid, 32]])."""
     L = N.lib()
     B, H, W, _ = x.shape
@@ -133,11 +133,11 @@ def bwd3x3_h3_gpu(x, g, w, epi, c=None, coef=None, res=None, bnc=None, reverse=0
     bd = dev(bnc) if bnc is not None else None
     out = torch.full((B, H, W, 16), float("nan"), dtype=torch.float32, device="cuda")
     dw = torch.full((3, 3, 16, 16), float("nan"), dtype=torch.float32, device="cuda")
-    grid = L.bf_debug_bwd3x3_h3_grid(B, H, W)
+    grid = L.bf_debug_bwd3x3_h3_grid_ex(B, H, W, dbuf)
     stats = torch.full((grid * 32,), float("nan"), dtype=torch.float32, device="cuda") if epi & N.EPI_BNBWD else None
     scratch = torch.full((int(L.bf_debug_bwd3x3_h3_scratch_floats(B, H, W)),), float("nan"), dtype=torch.float32, device="cuda")
     rc = L.bf_debug_bwd3x3_h3(N.ptr(xd), N.ptr(gd), N.ptr(cd), N.ptr(kd), N.ptr(wd), N.ptr(out), N.ptr(rd), N.ptr(bd), N.ptr(dw),
-                              N.ptr(stats), N.ptr(scratch), B, H, W, epi, reverse, 1, N.stream_ptr(xd))
+                              N.ptr(stats), N.ptr(scratch), B, H, W, epi, reverse | (dbuf << 1), 1, N.stream_ptr(xd))
     assert rc == 0, rc
     if stats is not None:
         return host(out), host(dw), host(stats).reshape(grid, 32)

@@ -240,9 +240,10 @@ def test_wgrad3x3(shape, h3):
 BWD_SHAPES = SHAPES + [(24, 128, 160)]          # the last one: more tiles (1200) than persistent workgroups (512)
 
 
+@pytest.mark.parametrize("dbuf", [0, 1], ids=["2wg", "dbuf"])
 @pytest.mark.parametrize("shape", BWD_SHAPES)
 @pytest.mark.parametrize("reverse", [0, 1])
-def test_bwd3x3_h3_second_convolution(shape, reverse):
+def test_bwd3x3_h3_second_convolution(shape, reverse, dbuf):
     """BatchNorm-backward apply on load + weight gradient + masked data gradient (a block's convolution j >= 1)."""
     B, H, W = shape
     x = np.maximum(_rand((B, H, W, 16), 40), 0)                       # activated input: also the mask
@@ -252,16 +253,17 @@ def test_bwd3x3_h3_second_convolution(shape, reverse):
     gp = coef[:16].astype(np.float64) * g + coef[16:32].astype(np.float64) * c + coef[32:].astype(np.float64)
     ref_dw = O.conv2d_same_grad_kernel(x.astype(np.float64), gp, 3, 3)
     ref_dx = O.conv2d_same_grad_input(gp, w.astype(np.float64)) * (x > 0)
-    dx, dw = bwd3x3_h3_gpu(x, g, w, N.EPI_MASK, c=c, coef=coef, reverse=reverse)
+    dx, dw = bwd3x3_h3_gpu(x, g, w, N.EPI_MASK, c=c, coef=coef, reverse=reverse, dbuf=dbuf)
     assert_close(dx, ref_dx, what=f"dx {shape}")
     assert_close(dw, ref_dw, rel=3e-6 * np.sqrt(B * H * W), what=f"dw {shape}")
-    dx0, dw0 = bwd3x3_h3_gpu(x, gp.astype(np.float32), w, 0, reverse=reverse)           # no BatchNorm, linear activation
+    dx0, dw0 = bwd3x3_h3_gpu(x, gp.astype(np.float32), w, 0, reverse=reverse, dbuf=dbuf)           # no BatchNorm, linear activation
     assert_close(dx0, O.conv2d_same_grad_input(gp, w.astype(np.float64)), what=f"dx plain {shape}")
     assert_close(dw0, ref_dw, rel=3e-6 * np.sqrt(B * H * W), what=f"dw plain {shape}")
 
 
+@pytest.mark.parametrize("dbuf", [0, 1], ids=["2wg", "dbuf"])
 @pytest.mark.parametrize("shape", BWD_SHAPES)
-def test_bwd3x3_h3_first_convolution(shape):
+def test_bwd3x3_h3_first_convolution(shape, dbuf):
     """weight gradient + data gradient + skip gradient, and the sums the BatchNorm backward of the block in front needs."""
     B, H, W = shape
     x, g = _rand((B, H, W, 16), 50), _rand((B, H, W, 16), 51)
@@ -270,13 +272,13 @@ def test_bwd3x3_h3_first_convolution(shape):
     g64 = g.astype(np.float64)
     ref_dx = O.conv2d_same_grad_input(g64, w.astype(np.float64)) + res
     ref_dw = O.conv2d_same_grad_kernel(x.astype(np.float64), g64, 3, 3)
-    dx, dw, stats = bwd3x3_h3_gpu(x, g, w, N.EPI_RES | N.EPI_BNBWD, res=res, bnc=bnc)
+    dx, dw, stats = bwd3x3_h3_gpu(x, g, w, N.EPI_RES | N.EPI_BNBWD, res=res, bnc=bnc, dbuf=dbuf)
     assert_close(dx, ref_dx, what=f"dx {shape}")
     assert_close(dw, ref_dw, rel=3e-6 * np.sqrt(B * H * W), what=f"dw {shape}")
     tot = stats.astype(np.float64).sum(axis=0)
     assert_close(tot[:16], ref_dx.sum(axis=(0, 1, 2)), rel=1e-5 * np.sqrt(ref_dx.size), what="sum dx")
     assert_close(tot[16:], (ref_dx * bnc).sum(axis=(0, 1, 2)), rel=1e-5 * np.sqrt(ref_dx.size), what="sum dx * c")
-    dx1, dw1 = bwd3x3_h3_gpu(x, g, w, N.EPI_RES, res=res)
+    dx1, dw1 = bwd3x3_h3_gpu(x, g, w, N.EPI_RES, res=res, dbuf=dbuf)
     assert np.array_equal(dx1, dx) and np.array_equal(dw1, dw)
 
 
