@@ -203,8 +203,7 @@ struct HeadTrainArgs {
     int B, H, W, cout, denormalize;
     float v_min, v_max, hinge, cutoff, dscale; // dscale = mae_multiplier*depth_weight/numel
     float dfeat_scale;                         // power of two on the dfeat output only (gradient scaling of the split-f16
-                                               // backward, engine.hip bf_train_step); the head's own gradients (M) are not scaled    // feat = feat + pre_scale * pre_c + pre_shift formed on load (the last block's BatchNorm apply + skip Add; pre_c NULL: feat as is)
-    const float* pre_c; const float* pre_scale; const float* pre_shift;
+                                               // backward, engine.hip bf_train_step); the head's own gradients (M) are not scaled
 };
 hipError_t bf_launch_head_train(const HeadTrainArgs& a, int grid, hipStream_t s);
 // RMSE / SSIM loss terms (loss_terms.hip): additive dL/dpred from the prediction and the head's per-image sums

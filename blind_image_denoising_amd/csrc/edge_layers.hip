@@ -351,9 +351,7 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadTrainArgs a, int bl
 {
     __shared__ float whs[64];
     __shared__ float red[4][80];
-    __shared__ float pre_s[32];
     if (threadIdx.x < 64) whs[threadIdx.x] = a.wh[threadIdx.x];
-    if (a.pre_c && threadIdx.x < 32) pre_s[threadIdx.x] = threadIdx.x < 16 ? a.pre_scale[threadIdx.x] : a.pre_shift[threadIdx.x - 16];
     __syncthreads();
     const int b = blockIdx.x / blocks_per_image, sub = blockIdx.x % blocks_per_image;
     const int hw = a.H * a.W;
@@ -369,17 +367,6 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadTrainArgs a, int bl
         for (int i = 0; i < 4; ++i) {
             const float4 v = fp[i];
             f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
-        }
-        if (a.pre_c) {                         // x + (scale * c + shift), rounded as affine_add_kernel rounds it
-            const float4* cp = reinterpret_cast<const float4*>(a.pre_c + pix * 16);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 c = cp[i];
-                f[4 * i] += fmaf(pre_s[4 * i], c.x, pre_s[16 + 4 * i]);
-                f[4 * i + 1] += fmaf(pre_s[4 * i + 1], c.y, pre_s[16 + 4 * i + 1]);
-                f[4 * i + 2] += fmaf(pre_s[4 * i + 2], c.z, pre_s[16 + 4 * i + 2]);
-                f[4 * i + 3] += fmaf(pre_s[4 * i + 3], c.w, pre_s[16 + 4 * i + 3]);
-            }
         }
         float dh1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

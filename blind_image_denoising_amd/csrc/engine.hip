@@ -821,8 +821,8 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
                 BF_HIP(bf_launch_bn_finalize(partial, conv_grid, count, params + h->p_blocks + i * h->p_block_stride + conv_off(j) + 2304,
                                              state + bn_idx(i, j) * 32, state + bn_idx(i, j) * 32 + 16, d.bn_eps, d.bn_momentum, scale,
                                              scale + 16, w + L.bn_meaninv + bn_idx(i, j) * 32, stage1, s), "bn_finalize");
-                // block i+1's conv_0 forms A(i+1) on load.  (The head could do the same for the last block -- HeadTrainArgs::pre_c --
-                // but its pixel-per-thread loads are poorly coalesced: +105 us in the head for the 79 us of affine_add.)
+                // block i+1's conv_0 forms A(i+1) on load.  (The head kernel doing the same for the last block was tried: its register
+                // count went past 256, one wave per SIMD, +105 us in the head for the 79 us of affine_add.)
                 if (last && h3t && h->train_fused_fwd && i + 1 < N && nb >= 2) pending_affine = true;
                 else if (last) BF_HIP(bf_launch_affine_add(A(i), C(i, j), scale, scale + 16, A(i + 1), npix, s), "affine_add");
                 else BF_HIP(bf_launch_affine_act(C(i, j), scale, scale + 16, T(i, j + 1), relu, npix, s), "affine_act");
@@ -840,12 +840,7 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     // ---- head forward + loss + head backward ---------------------------------------------------
     const double numel = (double)npix * d.out_channels;
     HeadTrainArgs ta;
-    ta.pre_c = nullptr; ta.pre_scale = nullptr; ta.pre_shift = nullptr;
     ta.feat = A(N); ta.wh = w + L.wh;
-    if (pending_affine) {                          // the last block's BatchNorm apply + skip Add: formed by the head on load
-        ta.feat = A(N - 1); ta.pre_c = C(N - 1, nb - 1);
-        ta.pre_scale = w + L.bn_scale + bn_idx(N - 1, nb - 1) * 32; ta.pre_shift = ta.pre_scale + 16;
-    }
     ta.gt = gt; ta.pred = predictions; ta.dfeat = dA; ta.partial = partial; ta.dextra = nullptr;
     ta.B = B; ta.H = H; ta.W = W; ta.cout = d.out_channels; ta.denormalize = d.denormalize;
     ta.v_min = d.v_min; ta.v_max = d.v_max; ta.hinge = loss->hinge; ta.cutoff = loss->cutoff;

@@ -41,17 +41,18 @@ __device__ __forceinline__ h8 tb_tr_operand(const char* img, const int addr)
     return __builtin_bit_cast(h8, (u4){ua[0], ua[1], ub[0], ub[1]});
 }
 
+extern __shared__ __attribute__((aligned(16))) char tb_lds[];       // the kernels' LDS arena (dynamic)
+
 template <int EPI>
 struct BwdH3Epi {
     struct Pre {};
     enum { EXTRA_MFMA = 0 };
-    const BwdH3Args& a; float inv_s;
-    mutable const char* mask_lds;   // this lane's 4 channels of output row 0 of its strip in the x image (hi plane)
-    // per tile (set_tile); the BatchNorm sums live here across tiles (a pointer to kernel locals put them in scratch memory)
-    mutable size_t base; mutable int gy0, gx;
+    // A fresh object per tile, everything but the BatchNorm sums const: per-tile fields that were `mutable` members of one
+    // long-lived object ended up in scratch memory (a scratch load per output row), and so did sums reached through a pointer.
+    const BwdH3Args& a; const float inv_s;
+    const int mask_off;             // arena offset of this lane's 4 channels of output row 0 of its strip in the x image (hi plane)
+    const size_t base; const int gy0, gx;
     mutable f32x4 s1, s2;
-    __device__ __forceinline__ void set_tile(const size_t base_, const int gy0_, const int gx_) const { base = base_; gy0 = gy0_; gx = gx_; }
-    __device__ __forceinline__ void set_mask(const char* m) const { mask_lds = m; }
     __device__ __forceinline__ Pre pre(const int) const { return Pre{}; }
     __device__ __forceinline__ f32x4 finish(const int, const f32x4 v, const Pre&) const { return v; }
     __device__ __forceinline__ void operator()(const int o, const f32x4 av) const
@@ -62,7 +63,7 @@ struct BwdH3Epi {
             if (EPI & EPI_MASK) {
                 // the activated input IS the mask, and its hi half sits in LDS: x > 0 <=> hi > 0 (the staging keeps x >= 2^-24)
                 // (a second global read of the tile missed L2 more often than not: 117 KB per tile, 64 tiles in flight per XCD)
-                const h4 mh = *reinterpret_cast<const h4*>(mask_lds + o * (BwdH3Geom::IW * 16));
+                const h4 mh = *reinterpret_cast<const h4*>(tb_lds + mask_off + o * (BwdH3Geom::IW * 16));
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = (float)mh[k] > 0.f ? v[k] : 0.f;
             }
@@ -77,7 +78,6 @@ template <bool BNAPPLY, int EPI>
 __global__ __launch_bounds__(256, 2) void bwd3x3_h3_kernel(BwdH3Args a)
 {
     using G = BwdH3Geom;
-    extern __shared__ __attribute__((aligned(16))) char tb_lds[];
     char* xs = tb_lds;
     char* gs = tb_lds + G::IMG;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -104,10 +104,31 @@ __global__ __launch_bounds__(256, 2) void bwd3x3_h3_kernel(BwdH3Args a)
     const int px_l = strip * 16 + n;                              // column inside the tile
     const int o0 = half * G::R;                                   // first output row of this wave
     const int b1 = (q & 1) * G::PLANE + (o0 * G::IW + px_l) * 16;
-    const BwdH3Epi<EPI> epi{a, inv_s, xs + (q >> 1) * G::PLANE + ((o0 + 1) * G::IW + px_l + 1) * 16 + (q & 1) * 8, 0, 0, 0,
-                            {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const int mask_lds = (q >> 1) * G::PLANE + ((o0 + 1) * G::IW + px_l + 1) * 16 + (q & 1) * 8;
+    f32x4 bs1 = {0.f, 0.f, 0.f, 0.f}, bs2 = {0.f, 0.f, 0.f, 0.f};          // BatchNorm sums across the tiles
 
     constexpr int NX = (G::IH * G::IW * 4 + 255) / 256;
+    // Without the BatchNorm operand there are registers to spare: the x operand of the NEXT tile is requested behind the staging
+    // of the current one and stays in flight through its matrix work (+ 1/3 more bytes in flight per workgroup).
+    constexpr bool PREX = !BNAPPLY;
+    f32x4 px_next[PREX ? NX : 1];
+    auto load_x = [&](const int t0n, f32x4 (&dst)[PREX ? NX : 1]) {
+        const int t = a.reverse ? a.ntiles - 1 - t0n : t0n;
+        const int txi = t % a.tiles_x, rest = t / a.tiles_x;
+        const int y0 = (rest % a.tiles_y) * G::TH, x0 = txi * G::TW;
+        const size_t img = (size_t)(rest / a.tiles_y) * a.H * a.W * 16;
+#pragma unroll
+        for (int i = 0; i < (PREX ? NX : 1); ++i) {
+            const int e = tid + i * 256;
+            const int px = e >> 2, quad = e & 3;
+            const int row = px / G::IW, col = px - row * G::IW;
+            const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+            dst[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (e < G::IH * G::IW * 4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                dst[i] = *reinterpret_cast<const f32x4*>(a.x + img + ((size_t)gy * a.W + gx) * 16 + quad * 4);
+        }
+    };
+    if (PREX && (int)blockIdx.x < a.ntiles) load_x(blockIdx.x, px_next);
     // Tiles are dealt round-robin (tile = workgroup + k * grid): at any moment the grid covers one contiguous window of the
     // tensors (every HBM channel busy; a contiguous RUN of tiles per workgroup put all workgroups on the same channels and
     // was 10 % slower), x-neighbours sit on neighbouring workgroups and, with eight tiles per image row, y-neighbours on the
@@ -134,9 +155,10 @@ __global__ __launch_bounds__(256, 2) void bwd3x3_h3_kernel(BwdH3Args a)
                 rx[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 rg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (BNAPPLY) rc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (PREX) rx[i] = px_next[i];
                 if (e < G::IH * G::IW * 4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
                     const size_t idx = img + ((size_t)gy * a.W + gx) * 16 + quad * 4;
-                    rx[i] = *reinterpret_cast<const f32x4*>(a.x + idx);
+                    if (!PREX) rx[i] = *reinterpret_cast<const f32x4*>(a.x + idx);
                     rg[i] = *reinterpret_cast<const f32x4*>(a.g + idx);
                     if (BNAPPLY) rc[i] = *reinterpret_cast<const f32x4*>(a.c + idx);
                 }
@@ -175,6 +197,7 @@ __global__ __launch_bounds__(256, 2) void bwd3x3_h3_kernel(BwdH3Args a)
             }
         }
         __syncthreads();
+        if (PREX && t0 + (int)gridDim.x < a.ntiles) load_x(t0 + gridDim.x, px_next);
 
         // data-gradient weights: 12 A-operand images (pack_h3_train_kernel, transposed + flipped pack).  Fetched per tile (L2
         // hits, in flight behind the weight-gradient MFMAs) rather than once per kernel: 52 registers that would otherwise be
@@ -210,8 +233,9 @@ __global__ __launch_bounds__(256, 2) void bwd3x3_h3_kernel(BwdH3Args a)
         // ---- data gradient: 8 rows of one 16-column strip per wave, streamed from the g image ----
         {
             const int gx = x0 + px_l;
-            epi.set_tile(img + ((size_t)(y0 + o0) * a.W + gx) * 16 + q * 4, y0 + o0, gx);
+            const BwdH3Epi<EPI> epi{a, inv_s, mask_lds, img + ((size_t)(y0 + o0) * a.W + gx) * 16 + q * 4, y0 + o0, gx, bs1, bs2};
             h3r_rows<G::R, G::IW * 16, 2 * G::PLANE>(gs, b1 + (q >> 1) * 16, b1 + 32 + (q >> 1) * 2 * G::PLANE, w, epi, H3NoHook{});
+            bs1 = epi.s1; bs2 = epi.s2;
         }
         __syncthreads();                       // images free for the next tile
     }
@@ -228,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void bwd3x3_h3_kernel(BwdH3Args a)
     for (int i = tid; i < 2304; i += 256)
         a.wpartial[(size_t)blockIdx.x * 2304 + i] = (red[i] + red[2304 + i]) + (red[2 * 2304 + i] + red[3 * 2304 + i]);
     if (EPI & EPI_BNBWD) {
-        f32x4 s1 = epi.s1, s2 = epi.s2;
+        f32x4 s1 = bs1, s2 = bs2;
         // over the 16 pixel lanes that share a channel quad, then over the 4 waves (fixed order)
 #pragma unroll
         for (int m = 1; m < 16; m <<= 1) {
@@ -265,7 +289,6 @@ __global__ __launch_bounds__(512, 1) void bwd3x3_h3d_kernel(BwdH3Args a)
 {
     using G = BwdH3Geom;
     constexpr int NT = 512, NW = 8, RQ = G::TH / (NW / 2);              // 4 rows of a strip per wave
-    extern __shared__ __attribute__((aligned(16))) char tb_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
@@ -285,7 +308,7 @@ __global__ __launch_bounds__(512, 1) void bwd3x3_h3d_kernel(BwdH3Args a)
     const int o0 = quarter * RQ;
     const int b1 = (q & 1) * G::PLANE + (o0 * G::IW + px_l) * 16;
     const int mask_off = (q >> 1) * G::PLANE + ((o0 + 1) * G::IW + px_l + 1) * 16 + (q & 1) * 8;
-    const BwdH3Epi<EPI> epi{a, inv_s, tb_lds + mask_off, 0, 0, 0, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 bs1 = {0.f, 0.f, 0.f, 0.f}, bs2 = {0.f, 0.f, 0.f, 0.f};
 
     constexpr int NX = (G::IH * G::IW * 4 + NT - 1) / NT;                 // 5
     f32x4 rx[NX], rg[NX], rc[BNAPPLY ? NX : 1];
@@ -385,9 +408,10 @@ __global__ __launch_bounds__(512, 1) void bwd3x3_h3d_kernel(BwdH3Args a)
         }
         {
             const int gx = cur.x0 + px_l;
-            epi.set_tile(cur.img + ((size_t)(cur.y0 + o0) * a.W + gx) * 16 + q * 4, cur.y0 + o0, gx);
-            epi.set_mask(xs + mask_off);
+            const BwdH3Epi<EPI> epi{a, inv_s, (k & 1) * 2 * G::IMG + mask_off, cur.img + ((size_t)(cur.y0 + o0) * a.W + gx) * 16 + q * 4, cur.y0 + o0, gx,
+                                    bs1, bs2};
             h3r_rows<RQ, G::IW * 16, 2 * G::PLANE>(gs, b1 + (q >> 1) * 16, b1 + 32 + (q >> 1) * 2 * G::PLANE, w, epi, H3NoHook{});
+            bs1 = epi.s1; bs2 = epi.s2;
         }
         if (more) stash(nxt, tb_lds + ((k + 1) & 1) * 2 * G::IMG, tb_lds + ((k + 1) & 1) * 2 * G::IMG + G::IMG);
         cur = nxt;
@@ -409,7 +433,7 @@ __global__ __launch_bounds__(512, 1) void bwd3x3_h3d_kernel(BwdH3Args a)
         a.wpartial[(size_t)blockIdx.x * 2304 + i] = sacc;
     }
     if (EPI & EPI_BNBWD) {
-        f32x4 s1 = epi.s1, s2 = epi.s2;
+        f32x4 s1 = bs1, s2 = bs2;
 #pragma unroll
         for (int m = 1; m < 16; m <<= 1) {
 #pragma unroll
