@@ -10,8 +10,10 @@
 //
 //   * waves 0..3 ("A") run conv1, waves 4..7 ("B") conv2; wave k of a role owns columns [64k, 64k+64) = four 16-pixel
 //     MFMA groups and holds ONE kernel's weights (52 VGPRs).  Neither role ever issues a vector-memory instruction;
-//   * waves 8..11 ("C") move the data: LDS-DMA of input row s+3 into the input ring, and the finished output row from
-//     its LDS staging slot to global memory.  A vector-memory instruction costs the issuing wave 100-200 cycles when the
+//   * waves 8..11 ("C") move the data: waves 8-9 request input row s+3 into the input ring by LDS-DMA (two planes each),
+//     waves 10-11 store the finished output row from its LDS staging slot to global memory -- loaders and storers are
+//     DIFFERENT waves because `s_waitcnt vmcnt(N)` counts a wave's loads and stores together while stores retire early: a
+//     wave that did both saw its count reached with DMA pieces still in flight.  A vector-memory instruction costs the issuing wave 100-200 cycles when the
 //     CU streams 32 KiB per step; on the matrix waves those stalls did not overlap with anything (ablations of the first
 //     version, where A issued the DMA and B the stores: 248 us per launch, 150 us without memory instructions, 95 us
 //     without matrix / vector work -- the sum, not the maximum);
