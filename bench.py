@@ -56,12 +56,17 @@ def cpu_baseline_port(spec, params, state, noisy_u8, budget_s=10.0):
     t0 = time.perf_counter()
     port.forward_u8(spec, params, state, noisy_u8[:1], h)
     one = time.perf_counter() - t0
+    # ~budget_s of CPU work (the contract asks for 10-30 s): the bench batch, repeated as often as that takes
     n = int(max(2, min(noisy_u8.shape[0], budget_s / max(one, 1e-3))))
     t0 = time.perf_counter()
     port.forward_u8(spec, params, state, noisy_u8[:n], h)
+    first = time.perf_counter() - t0
+    reps = 1 + int(max(0, min(63, round((budget_s - first) / max(first, 1e-3)))))
+    for _ in range(reps - 1):
+        port.forward_u8(spec, params, state, noisy_u8[:n], h)
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "images/s", "cores": int(h.bfcnn_port_max_threads()), "kind": "port",
-            "sample": f"{n} images of the same 1x18 256x256x3 uint8 workload, oracle/bfcnn_port.c fp32 OpenMP "
+    return {"value": n * reps / dt, "unit": "images/s", "cores": int(h.bfcnn_port_max_threads()), "kind": "port",
+            "sample": f"{reps} x {n} images of the same 1x18 256x256x3 uint8 workload ({dt:.1f} s), oracle/bfcnn_port.c fp32 OpenMP "
                       f"(CPU restatement, not TensorFlow)"}
 
 
@@ -105,9 +110,13 @@ def cpu_baseline_torch(spec, params, state, noisy_u8, budget_s=10.0, nthreads=No
         n = int(max(2, min(noisy_u8.shape[0], 16, budget_s / max(one, 1e-3))))
         t0 = time.perf_counter()
         forward(noisy_u8[:n])
+        first = time.perf_counter() - t0
+        reps = 1 + int(max(0, min(15, round((budget_s - first) / max(first, 1e-3)))))
+        for _ in range(reps - 1):
+            forward(noisy_u8[:n])
         dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "images/s", "cores": nthreads, "kind": "port",
-            "sample": f"{n} images of the same workload in one batch, torch-CPU {torch.__version__} conv2d (oneDNN, channels_last, "
+    return {"value": n * reps / dt, "unit": "images/s", "cores": nthreads, "kind": "port",
+            "sample": f"{reps} x {n} images of the same workload ({dt:.1f} s), torch-CPU {torch.__version__} conv2d (oneDNN, channels_last, "
                       f"{nthreads} threads) with the restatement's tensors"}, out1
 
 
