@@ -1419,6 +1419,20 @@ extern "C" int bf_op_head_out(const float* in, const float* w, void* out, int ou
 // accumulators: lane (q, n) holds hidden channels 16t + 4q + r of pixel n, multiplies them with its rows of the last
 // kernel and the four q-lanes of a pixel are summed with two cross-row shuffles.
 // ------------------------------------------------------------------------------------------
+// v + (v of lane ^ 16) + (v of lane ^ 32) + (v of lane ^ 48): the sum over the four lanes (q = 0..3) that hold one pixel in the
+// matrix-core layout, on the vector ALU (v_permlane16_swap / v_permlane32_swap, gfx950) instead of two ds_bpermute round trips
+// through the LDS crossbar: with two waves per SIMD nothing hides those (the head kernel has 12 of them per 16-pixel group).
+// swap(a, b): rows 1, 3 (16-lane groups) of a <-> rows 0, 2 of b; with a = b = v: a = [r0 r0 r2 r2], b = [r1 r1 r3 r3].
+__device__ __forceinline__ float uo_sum_q(float v)
+{
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    float s = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);          // rows 0, 1: r0 + r1 ; rows 2, 3: r2 + r3
+    a = __builtin_bit_cast(unsigned, s); b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));   // lanes 32..63 of a <-> lanes 0..31 of b
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+
 template <int CIN>
 __global__ __launch_bounds__(256, 2) void uo_head_fused_kernel(const float* __restrict__ in, const float* __restrict__ gamma, float eps,
                                                                const float* __restrict__ w0p, int act, float alpha,
@@ -1483,8 +1497,7 @@ __global__ __launch_bounds__(256, 2) void uo_head_fused_kernel(const float* __re
 #pragma unroll
             for (int c = 0; c < KC; ++c) sum += b[i][c][0] + b[i][c][1] + b[i][c][2] + b[i][c][3];
             if (gamma) {
-                sum += __shfl_xor(sum, 16, 64);
-                sum += __shfl_xor(sum, 32, 64);
+                sum = uo_sum_q(sum);
                 const float mean = sum * (1.f / CIN);
                 float sq = 0.f;
 #pragma unroll
@@ -1492,8 +1505,7 @@ __global__ __launch_bounds__(256, 2) void uo_head_fused_kernel(const float* __re
                     b[i][c] = b[i][c] - mean;
                     sq += b[i][c][0] * b[i][c][0] + b[i][c][1] * b[i][c][1] + b[i][c][2] * b[i][c][2] + b[i][c][3] * b[i][c][3];
                 }
-                sq += __shfl_xor(sq, 16, 64);
-                sq += __shfl_xor(sq, 32, 64);
+                sq = uo_sum_q(sq);
                 const float rs = rsqrtf(sq * (1.f / CIN) + eps);
 #pragma unroll
                 for (int c = 0; c < KC; ++c) b[i][c] = b[i][c] * (gm[c] * rs);
@@ -1529,8 +1541,7 @@ __global__ __launch_bounds__(256, 2) void uo_head_fused_kernel(const float* __re
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                o[k] += __shfl_xor(o[k], 16, 64);
-                o[k] += __shfl_xor(o[k], 32, 64);
+                o[k] = uo_sum_q(o[k]);
             }
             // every lane holds the pixel's sums now: lane group q finishes output channel q (one tanh per lane instead of
             // cout in a quarter of the lanes; one store instruction per group).  tanh(2x) = 1 - 2 / (exp(4x) + 1), the form
