@@ -600,10 +600,10 @@ __global__ __launch_bounds__(256) void tp_reg_elementwise_kernel(const float* __
         const float x = w[i];
         if (kind == BF_REG_L1) {
             acc += fabs((double)x);
-            grad[i] += grad_scale * coef * (x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f));
+            if (grad) grad[i] += grad_scale * coef * (x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f));
         } else {
             acc += (double)x * (double)x;
-            grad[i] += grad_scale * coef * 2.f * x;
+            if (grad) grad[i] += grad_scale * coef * 2.f * x;
         }
     }
     red[threadIdx.x] = acc;
@@ -886,7 +886,7 @@ extern "C" int bf_op_resize_bilinear_bwd(const float* dy, float* dx, int B, int 
 // value[0] += coef * sum |w| (L1) or coef * sum w^2 (L2) ; grad += grad_scale * d/dw
 extern "C" int bf_op_reg_elementwise(const float* w, float* grad, int64_t n, int kind, float coef, float grad_scale, float* value, void* stream)
 {
-    if (!w || !grad || !value || n <= 0) return BF_EINVAL;
+    if (!w || !value || n <= 0) return BF_EINVAL;              // grad may be NULL: the value alone
     if (kind != BF_REG_L1 && kind != BF_REG_L2) return BF_EUNSUPPORTED;
     hipLaunchKernelGGL(tp_reg_elementwise_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w, grad, n, kind, coef, grad_scale, value);
     return TP_OK();

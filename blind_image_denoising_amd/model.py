@@ -412,14 +412,15 @@ class HydraModel:
 
     @property
     def losses(self):
-        """keras model.losses: one regularisation scalar per regularised kernel (bfcnn/loss.py:181-187)."""
-        out = []
-        for v in self.trainable_variables:
-            if v.regularizer == N.BF_REG_L1:
-                out.append(0.01 * v.tensor.abs().sum())
-            elif v.regularizer == N.BF_REG_L2:
-                out.append(0.01 * (v.tensor * v.tensor).sum())
-        return out
+        """keras model.losses: one regularisation scalar per regularised kernel (bfcnn/loss.py:181-187), computed by the
+        regulariser kernel of the operator library (0-d views of one device buffer)."""
+        self._require_gpu()
+        regs = [v for v in self.trainable_variables if v.regularizer in (N.BF_REG_L1, N.BF_REG_L2)]
+        vals = torch.zeros(max(len(regs), 1), dtype=torch.float32, device=self.device)
+        for k, v in enumerate(regs):
+            N.check(self._lib.bf_op_reg_elementwise(N.ptr(v.tensor.reshape(-1)), None, v.tensor.numel(), v.regularizer, 0.01, 0.0,
+                                                    N.ptr(vals[k:k + 1]), N.stream_ptr(vals)), None, "bf_op_reg_elementwise")
+        return [vals[k] for k in range(len(regs))]
 
 
 def build_normalize_model(input_dims=None, min_value: float = 0.0, max_value: float = 255.0, name: str = "normalize"):

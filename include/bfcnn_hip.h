@@ -373,7 +373,8 @@ int bf_op_attention_bwd(const float* q, const float* v, const float* k, const fl
 /* adjoint of bf_op_resize_bilinear; scratch: B*H*out_width*C floats */
 int bf_op_resize_bilinear_bwd(const float* dy, float* dx, int batch, int height, int width, int channels, int out_height,
                               int out_width, float* scratch, void* stream);
-/* regularisers: value[0] += term, grad += grad_scale * d(term)/dw.  kind BF_REG_L1 / BF_REG_L2 with coefficient coef;
+/* regularisers: value[0] += term, grad += grad_scale * d(term)/dw (bf_op_reg_elementwise: grad may be NULL, the value alone).
+ * kind BF_REG_L1 / BF_REG_L2 with coefficient coef;
  * SoftOrthonormalConstraintRegularizer (regularizers.py:283-338) on a 1x1 kernel [cin][cout], scratch 2*cout*cout floats */
 int bf_op_reg_elementwise(const float* w, float* grad, int64_t n, int kind, float coef, float grad_scale, float* value, void* stream);
 int bf_op_reg_soft_orthonormal(const float* w, float* grad, int cin, int cout, float lambda, float l1, float l2, float grad_scale,

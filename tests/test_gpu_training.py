@@ -431,3 +431,13 @@ def test_monitoring_losses_match_oracle_through_the_c_abi():
         ref = O.denoiser_loss(O.LossSpec.from_config(cfg), gt, pr)
         for k in ("total_loss", "mae_loss", "mse_loss", "ssim_loss"):
             assert abs(float(got[k]) - ref[k]) <= 2e-5 * max(1.0, abs(ref[k])), (k, float(got[k]), ref[k])
+
+
+def test_model_losses_and_model_loss_match_oracle():
+    """keras model.losses / loss_fn_map["model"](model) (bfcnn/loss.py:181-187): the regulariser kernel, not torch arithmetic."""
+    cfg, spec, ls, params, state, m, fns = _setup(2)
+    got = bf.loss_function_builder(cfg["loss"])["model"](m)
+    ref = O.model_loss(spec, ls, params, np.float64)
+    assert abs(float(got["regularization_loss"]) - ref["regularization_loss"]) <= 1e-5 * ref["regularization_loss"]
+    assert abs(float(got["total_loss"]) - ref["total_loss"]) <= 1e-5 * ref["total_loss"]
+    assert len(m.losses) == 1 + 2 * 2 + 2                          # base, two kernels per block, two head kernels
