@@ -446,3 +446,23 @@ extern "C" int bf_op_group_kernel(float* w, float* dense, int cin, int cout, int
                        groups, extract);
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
+
+// build_normalize_model / build_denormalize_model as standalone layers (bfcnn/model.py:364-430, utilities.py:435-461):
+// inverse = 0: out = (clip(x, lo, hi) - lo) / (hi - lo) - 0.5 ; inverse = 1: out = (clip(x, -0.5, 0.5) + 0.5) * (hi - lo) + lo
+__global__ __launch_bounds__(256) void tg_normalize_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n, float lo,
+                                                           float hi, int inverse)
+{
+    const float range = hi - lo;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = x[i];
+        out[i] = inverse ? (fminf(fmaxf(v, -0.5f), 0.5f) + 0.5f) * range + lo : (fminf(fmaxf(v, lo), hi) - lo) / range - 0.5f;
+    }
+}
+
+extern "C" int bf_op_normalize(const float* x, float* out, int64_t n, float v_min, float v_max, int inverse, void* stream)
+{
+    if (!x || !out || n <= 0 || !(v_max > v_min)) return BF_EINVAL;
+    hipLaunchKernelGGL(tg_normalize_kernel, dim3(tg_grid(n)), dim3(256), 0, (hipStream_t)stream, x, out, n, v_min, v_max, inverse);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+

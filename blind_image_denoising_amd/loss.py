@@ -57,9 +57,17 @@ def loss_function_builder(config: Dict) -> Dict[str, Callable]:
         return d
 
     def model_loss(model):
-        regularization_loss = torch.stack(list(model.losses)).sum() if model.losses else torch.zeros(())
-        return {REGULARIZATION_LOSS_STR: regularization_loss,
-                TOTAL_LOSS_STR: regularization_loss * regularization_multiplier}
+        # tf.add_n(model.losses): the regulariser kernel accumulates every tensor's term into ONE device scalar
+        terms = list(model.losses)
+        if not terms:
+            z = torch.zeros(())
+            return {REGULARIZATION_LOSS_STR: z, TOTAL_LOSS_STR: z}
+        out = terms[0].new_zeros(2)                      # [0] sum of the terms, [1] the sum times `regularization`
+        for t in terms:
+            N.check(N.lib().bf_op_axpy(N.ptr(out[0:1]), N.ptr(t), 1.0, 0, 1, N.stream_ptr(t)), None, "bf_op_axpy")
+        N.check(N.lib().bf_op_axpy(N.ptr(out[1:2]), N.ptr(out[0:1]), float(regularization_multiplier), 0, 1, N.stream_ptr(out)), None,
+                "bf_op_axpy")
+        return {REGULARIZATION_LOSS_STR: out[0], TOTAL_LOSS_STR: out[1]}
 
     def denoiser_loss(gt_batch: torch.Tensor, predicted_batch: torch.Tensor) -> Dict[str, torch.Tensor]:
         """bfcnn/loss.py:190-247 on arbitrary batches (monitoring / evaluation): 0-d views of one device buffer"""

@@ -423,13 +423,23 @@ class HydraModel:
         return [vals[k] for k in range(len(regs))]
 
 
+def _normalize_op(x, lo: float, hi: float, inverse: int):
+    """the standalone (de)normalisation layer through the C ABI (bf_op_normalize); GPU tensors only"""
+    if not isinstance(x, torch.Tensor) or x.device.type != "cuda":
+        raise RuntimeError("normalize / denormalize need a GPU tensor: there is no CPU execution path")
+    x = x.to(torch.float32).contiguous()
+    out = torch.empty_like(x)
+    N.check(N.lib().bf_op_normalize(N.ptr(x), N.ptr(out), x.numel(), lo, hi, inverse, N.stream_ptr(x)), None, "bf_op_normalize")
+    return out
+
+
 def build_normalize_model(input_dims=None, min_value: float = 0.0, max_value: float = 255.0, name: str = "normalize"):
     """bfcnn/model.py:364-394: [min,max] -> [-0.5,+0.5].  Standalone helper only; inside the
     hydra this is fused into the base-convolution kernel."""
     lo, hi = float(min_value), float(max_value)
 
     def normalize(x, training=False):
-        return (x.clamp(lo, hi) - lo) / (hi - lo) - 0.5
+        return _normalize_op(x, lo, hi, 0)
     normalize.name = name
     return normalize
 
@@ -439,7 +449,7 @@ def build_denormalize_model(input_dims=None, min_value: float = 0.0, max_value: 
     lo, hi = float(min_value), float(max_value)
 
     def denormalize(y, training=False):
-        return (y.clamp(-0.5, 0.5) + 0.5) * (hi - lo) + lo
+        return _normalize_op(y, lo, hi, 1)
     denormalize.name = name
     return denormalize
 

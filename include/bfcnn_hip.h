@@ -419,6 +419,9 @@ int bf_op_dense2(const float* in, const float* w0, const float* b0, const float*
 int bf_op_selector_mix(const float* x1, const float* x2, const float* u, float* out, int64_t n, int soft, void* stream);
 int bf_op_avgpool_same(const float* in, float* out, int batch, int height, int width, int channels, int pool_h, int pool_w,
                        int stride_h, int stride_w, void* stream);
+/* the normalise / denormalise layers on their own (bfcnn/model.py:364-430; inside the hydras they are fused into the first
+   convolution and the head): inverse 0: (clip(x, v_min, v_max) - v_min) / (v_max - v_min) - 0.5; 1: (clip(x, -.5, .5) + .5) * range + v_min */
+int bf_op_normalize(const float* x, float* out, int64_t n, float v_min, float v_max, int inverse, void* stream);
 /* layout helpers: out[r][c * m + j] = x[r][c] (a DepthwiseConv2D with depth_multiplier m is a plain depthwise convolution of the
    repeated tensor) and its adjoint out[r][c] = sum_j x[r][c * m + j]; keras Conv2D(groups) kernel [cin / groups][cout] to / from the
    block-diagonal dense [cin][cout] (extract = 1 writes w from dense) */

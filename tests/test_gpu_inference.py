@@ -249,3 +249,15 @@ def test_model_on_a_device_that_is_not_the_current_one():
     assert out.device.index == 1 and torch.cuda.current_device() == 0
     ref = O.denoiser_module_call(spec, params, state, noisy)
     assert np.abs(out.cpu().numpy().astype(np.int32) - ref.astype(np.int32)).max() <= 1
+
+
+def test_standalone_normalize_and_denormalize_layers():
+    """build_normalize_model / build_denormalize_model (bfcnn/model.py:364-430) through bf_op_normalize"""
+    x = np.random.default_rng(0).uniform(-20, 280, (2, 5, 7, 3)).astype(np.float32)
+    n = bf.model.build_normalize_model(None, 0.0, 255.0)(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert np.array_equal(n, (np.clip(x, 0, 255) - 0.0) / np.float32(255.0) - np.float32(0.5))
+    y = np.random.default_rng(1).uniform(-0.7, 0.7, (2, 5, 7, 3)).astype(np.float32)
+    d = bf.model.build_denormalize_model(None, 0.0, 255.0)(torch.from_numpy(y).cuda()).cpu().numpy()
+    assert np.abs(d - ((np.clip(y, -0.5, 0.5) + 0.5) * 255.0)).max() <= 2e-5
+    with pytest.raises(RuntimeError, match="GPU"):
+        bf.model.build_normalize_model()(torch.zeros(1))
