@@ -562,10 +562,228 @@ __global__ __launch_bounds__(512, 1) void uh_enc32u_kernel(const float* __restri
     }
 }
 
-static int g_uh_enc_variant = 2;     // 2 wave-specialised, unrolled producer (default), 1 wave-specialised, 0 one kind of wave (A/B, tests)
+// uh_enc32u_kernel reshaped for TWO workgroups per CU (four waves per SIMD: two producers + two consumers, so that a stalled
+// wave of either role has a sibling to issue): batches of 4 rows instead of 8 (half the staging area), one wave-private row
+// buffer per strip (a wave's LDS operations execute in order: the next row's writes queue behind this row's reads), two
+// 16-pixel groups per consumer step, and the 25 depthwise weight vectors read from LDS every row instead of living in 100
+// registers: 78 976 bytes of LDS and <= 128 registers per wave.
+template <int K, int ACT>
+__global__ __launch_bounds__(512, 4) void uh_enc32w_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                           const float* __restrict__ dww, const float* __restrict__ gamma, float eps,
+                                                           const void* __restrict__ packed, const float* __restrict__ mult, int B, int H,
+                                                           int W, float alpha)
+{
+    constexpr int C = 32, NP = 2, RAD = K / 2, T2 = 2, RB = 4, NB = UH_ENC_ROWS / RB;
+    constexpr int W_BYTES = 32 * C * C, STG_FLOATS = RB * 8 * UH_STG_PITCH;       // one strip of one batch
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    {
+        const int4* src = reinterpret_cast<const int4*>(packed);
+        int4* dstv = reinterpret_cast<int4*>(lds);
+        for (int i = threadIdx.x; i < W_BYTES / 16; i += 512) dstv[i] = src[i];
+    }
+    constexpr int DW_OFF = W_BYTES + 2 * 4 * STG_FLOATS * 4 + 4 * UH_ROWBUF_F4 * 16;       // depthwise weights [K*K][32] behind the row buffers
+    for (int i = threadIdx.x; i < K * K * C; i += 512) reinterpret_cast<float*>(lds + DW_OFF)[i] = dww[i];
+    const float* aux = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed) + W_BYTES);
+    const float inv1 = aux[0], inv2 = aux[1];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifndef UH_ENC_ROLE_MAP
+#define UH_ENC_ROLE_MAP 0
+#endif
+    // Waves go to the four SIMDs round-robin (wave w -> SIMD w & 3).  Map 0 (default): one wave of each role per SIMD -- the
+    // producer's vector work and the consumer's matrix work share a SIMD; map 1 (producers = even waves: a SIMD hosts two waves
+    // of ONE role) measured 4.5 % slower (1 002 vs 958 us): complementary pipes beat latency hiding within a role.
+    const bool producer = UH_ENC_ROLE_MAP ? !(wave & 1) : wave < 4;
+    const int strip = UH_ENC_ROLE_MAP ? wave >> 1 : wave & 3;
+    float* stg_base = reinterpret_cast<float*>(lds + W_BYTES) + strip * STG_FLOATS;     // + (step & 1) * 4 * STG_FLOATS
+    const int tiles_x = (W + 31) / 32, tiles_y = (H + UH_ENC_ROWS - 1) / UH_ENC_ROWS;
+    const int64_t ntiles = (int64_t)B * tiles_y * tiles_x;
+    const int64_t my_tiles = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const int64_t nsteps = NB * my_tiles;                  // batches of RB rows
+    static_assert(NB == 4, "four batches per tile below");
+    static_assert(NB % 2 == 0, "the staging parity of a batch is its index inside the tile");
+
+    // The two roles are two separate loops (wave-uniform branch) with the same number of barrier arrivals per wave: as one
+    // loop hipcc kept the producers' 100 weight registers AND the consumers' matrix state live together (spills).
+    if (producer) {
+        // ---- depthwise layout: channels 4cl..4cl+3 of strip column pl.  The 16 + 2 RAD input rows of a tile are FULLY
+        // UNROLLED: the ring slot of a row (R % PD), the accumulator of an output row (o % K) and which (row, ky) pairs
+        // exist at the tile's top / bottom are compile-time facts -- no register rotation (16 moves per row in
+        // uh_enc32s_kernel), no arithmetic for the output rows a halo row does not reach (-20 % of the FMAs), no row-mask
+        // multiplies, and no loads for rows past the tile's last one (4 of 24 issued there).
+        const int cl = lane & 7, pl = lane >> 3;
+        constexpr int PD = 4, ROWF4 = (8 + 2 * RAD) * 8, HALVES = 2 * (ROWF4 - 64), NROWS = UH_ENC_ROWS + 2 * RAD;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        struct RowRegs { f32x4 a; f32x2 b; };
+        f32x4 gm = {1.f, 1.f, 1.f, 1.f}, acc[K];
+        const f32x4* wl = reinterpret_cast<const f32x4*>(lds + DW_OFF) + cl;          // tap t: wl[t * 8]
+        RowRegs ring[PD];
+        const int h1 = lane & (HALVES - 1);
+        f32x4* rowbuf = reinterpret_cast<f32x4*>(lds + W_BYTES + 2 * 4 * STG_FLOATS * 4) + strip * UH_ROWBUF_F4;
+        if (gamma) gm = *reinterpret_cast<const f32x4*>(gamma + 4 * cl);
+        for (int64_t ti = 0; ti < my_tiles; ++ti) {
+            const int64_t tile = blockIdx.x + ti * gridDim.x;
+            const int tx = (int)(tile % tiles_x);
+            const int ty = (int)((tile / tiles_x) % tiles_y);
+            const int64_t pimg = (tile / ((int64_t)tiles_x * tiles_y)) * H * W;
+            const int x0 = tx * 32 + strip * 8, py0 = ty * UH_ENC_ROWS;
+            const bool plive = x0 < W && !(UH_ROLE_ABLATE & 2);
+            const int xg0 = x0 - RAD + (lane >> 3), xg1 = x0 - RAD + 8 + (h1 >> 4);
+            const float gm0 = (xg0 >= 0 && xg0 < W) ? 1.f : 0.f, gm1 = (xg1 >= 0 && xg1 < W) ? 1.f : 0.f;
+            const int go0 = min(max(xg0, 0), W - 1) * C + 4 * cl, go1 = min(max(xg1, 0), W - 1) * C + 2 * (h1 & 15);
+            auto issue = [&](int yy, RowRegs& r) {
+                const float* row = x + (pimg + (int64_t)min(max(yy, 0), H - 1) * W) * C;
+                r.a = *reinterpret_cast<const f32x4*>(row + go0);
+                r.b = *reinterpret_cast<const f32x2*>(row + go1);
+            };
+            float* stg0 = stg_base;                                           // batch b of a tile: parity b & 1 (NB is even)
+            float* stg1 = stg_base + 4 * STG_FLOATS;
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (plive) {
+#pragma unroll
+                for (int d = 0; d < PD; ++d) issue(py0 - RAD + d, ring[d]);
+            }
+            auto rows = [&](auto lo_c, auto hi_c, float* stg, const int out0) {
+                constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+#pragma unroll
+                for (int R = LO; R < HI; ++R) {
+                    RowRegs& slot = ring[R % PD];
+                    f32x4* rb = rowbuf;
+                    rb[lane] = slot.a * gm0;
+                    if (lane < HALVES) reinterpret_cast<f32x2*>(rb + 64)[lane] = slot.b * gm1;
+                    if (R + PD < NROWS) issue(py0 - RAD + R + PD, slot);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const int yi = py0 - RAD + R;
+                    if (yi >= 0 && yi < H) {                   // wave-uniform: a row outside the image contributes nothing
+                        f32x4 v[K];
+#pragma unroll
+                        for (int kx = 0; kx < K; ++kx) v[kx] = rb[(pl + kx) * 8 + cl];
+#pragma unroll
+                        for (int ky = 0; ky < K; ++ky) {
+                            const int o = R - ky;              // output row (of the tile) this input row feeds through tap row ky
+                            if (o >= 0 && o < UH_ENC_ROWS) {
+#pragma unroll
+                                for (int kx = 0; kx < K; ++kx) acc[o % K] += wl[(ky * K + kx) * 8] * v[kx];
+                            }
+                        }
+                    }
+                    if (R >= K - 1) {
+                        const int o = R - (K - 1);
+                        f32x4 r = acc[o % K];
+                        acc[o % K] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (gamma) {
+                            const float mean = uh_pixel_sum8(r[0] + r[1] + r[2] + r[3]) * (1.f / C);
+                            const f32x4 d = r - mean;
+                            const float var = uh_pixel_sum8(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / C);
+                            r = d * (gm * rsqrtf(var + eps));
+                        }
+                        *reinterpret_cast<f32x4*>(stg + ((o - out0) * 8 + pl) * UH_STG_PITCH + 4 * cl) = r;
+                    }
+                }
+            };
+            constexpr int R0 = RB + 2 * RAD;                                  // input rows of the first batch
+            if (plive && py0 < H) rows(std::integral_constant<int, 0>{}, std::integral_constant<int, R0>{}, stg0, 0);
+            uh_step_barrier();
+            if (plive && py0 + RB < H) rows(std::integral_constant<int, R0>{}, std::integral_constant<int, R0 + RB>{}, stg1, RB);
+            uh_step_barrier();
+            if (plive && py0 + 2 * RB < H) rows(std::integral_constant<int, R0 + RB>{}, std::integral_constant<int, R0 + 2 * RB>{}, stg0, 2 * RB);
+            uh_step_barrier();
+            if (plive && py0 + 3 * RB < H) rows(std::integral_constant<int, R0 + 2 * RB>{}, std::integral_constant<int, NROWS>{}, stg1, 3 * RB);
+            uh_step_barrier();
+        }
+        uh_step_barrier();                                   // the consumers' last step
+    } else {
+        // ---- matrix-core layout
+        const int q = lane >> 4, n = lane & 15;
+        f32x4 m4[T2];
+#pragma unroll
+        for (int t = 0; t < T2; ++t) {
+            m4[t] = (f32x4){inv2, inv2, inv2, inv2};
+            if (mult) m4[t] *= *reinterpret_cast<const f32x4*>(mult + 16 * t + 4 * q);
+        }
+        // The skip (x at the batch's own pixels) is fetched ONE STEP AHEAD, while the producers are still reading those rows:
+        // loaded at the top of the step that consumes it, it cost the consumers 295 of their 791 us (one wave per SIMD keeps
+        // too few bytes in flight to hide a memory round trip inside a 5 us step).
+        struct TileAt { int64_t img; int x0, y0; };
+        auto tile_at = [&](const int64_t ti) {
+            const int tile = (int)(blockIdx.x + ti * gridDim.x);          // ntiles < 2^31 (checked by the launcher)
+            const int tx = tile % tiles_x, rest = tile / tiles_x;
+            return TileAt{(int64_t)(rest / tiles_y) * H * W, tx * 32 + strip * 8, (rest % tiles_y) * UH_ENC_ROWS};
+        };
+        auto pixel_of = [&](const TileAt& t, const int yb, const int i, bool& ok) {
+            const int py = yb + 2 * i + (n >> 3), px = t.x0 + (n & 7);
+            ok = py < H && px < W;
+            return t.img + (int64_t)min(py, H - 1) * W + min(px, W - 1);
+        };
+        f32x4 skn[T2][NP];
+#pragma unroll
+        for (int t = 0; t < T2; ++t)
+#pragma unroll
+            for (int i = 0; i < NP; ++i) skn[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        TileAt cur = tile_at(0), prev = cur;
+        for (int64_t step = 0; step <= nsteps; ++step) {
+            const int b = (int)(step % NB);
+            if (b == 0 && step > 0) { prev = cur; cur = tile_at(step / NB); }
+            f32x4 sk[T2][NP];
+#pragma unroll
+            for (int t = 0; t < T2; ++t)
+#pragma unroll
+                for (int i = 0; i < NP; ++i) sk[t][i] = skn[t][i];
+            if (step < nsteps && !(UH_ROLE_ABLATE & 5)) {          // the batch the producers work on now: consumed in the next step
+                const int ybn = cur.y0 + b * RB;
+                if (cur.x0 < W && ybn < H) {
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) {
+                        bool okn;
+                        const int64_t pn = pixel_of(cur, ybn, i, okn);
+#pragma unroll
+                        for (int t = 0; t < T2; ++t) skn[t][i] = *reinterpret_cast<const f32x4*>(x + pn * C + 16 * t + 4 * q);
+                    }
+                }
+            }
+            if (step >= 1) {
+                const int64_t cs = step - 1;                    // the batch the producers finished in the previous step
+                const float* stg = stg_base + (cs & 1) * 4 * STG_FLOATS;
+                const TileAt& tl = b == 0 ? prev : cur;         // b == 0: the last batch of the previous tile
+                const int yb = tl.y0 + (int)(cs % NB) * RB;
+                if (tl.x0 < W && yb < H && !(UH_ROLE_ABLATE & 1)) {
+                    int wl = lane * 16;
+                    asm volatile("" : "+v"(wl));
+                    const char* w1l = lds + wl;
+                    const char* w2l = lds + 16 * C * C + wl;
+                    uh8 xh[1][NP], xl[1][NP];
+                    int64_t pix[NP];
+                    bool ok[NP];
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) {
+                        const int s = 16 * i + n;             // staged pixel: row 2i + n / 8, column n % 8
+                        const float* sp = stg + s * UH_STG_PITCH + 8 * q;
+                        uh_split8(*reinterpret_cast<const f32x4*>(sp), *reinterpret_cast<const f32x4*>(sp + 4), xh[0][i], xl[0][i]);
+                        pix[i] = pixel_of(tl, yb, i, ok[i]);
+                    }
+                    f32x4 acc2[T2][NP];
+                    uh_mlp_core<C, NP, ACT>(xh, xl, w1l, w2l, inv1, alpha, acc2);
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) {
+                        if (!ok[i] || ((UH_ROLE_ABLATE & 4) && acc2[0][i][0] != 12345.678f)) continue;
+#pragma unroll
+                        for (int t = 0; t < T2; ++t)
+                            *reinterpret_cast<f32x4*>(out + pix[i] * C + 16 * t + 4 * q) = bf_acc_ready(acc2[t][i]) * m4[t] + sk[t][i];
+                    }
+                }
+            }
+            uh_step_barrier();
+        }
+    }
+}
+
+static int g_uh_enc_variant = 2;     // 3 two workgroups per CU, 2 wave-specialised + unrolled producer (default), 1 wave-specialised, 0 one kind of wave
 extern "C" int bf_op_set_variant(const char* key, int value)
 {
-    if (key && !strcmp(key, "enc32")) { g_uh_enc_variant = value < 0 ? 2 : (value > 2 ? 2 : value); return BF_OK; }
+    if (key && !strcmp(key, "enc32")) { g_uh_enc_variant = value < 0 ? 2 : (value > 3 ? 2 : value); return BF_OK; }
     return BF_EINVAL;
 }
 
@@ -586,7 +804,13 @@ extern "C" int bf_op_convnext_block_h3(const float* x, float* out, const float* 
         const int grid_s = (int)(ntiles < 256 ? ntiles : 256);
 #define UH_ENCS(KK, A)                                                                                                         \
     {                                                                                                                          \
-        if (g_uh_enc_variant == 2) {                                                                                           \
+        if (g_uh_enc_variant == 3) {                                                                                           \
+            constexpr int LDS_W = 32 * 32 * 32 + 2 * 4 * 4 * 8 * UH_STG_PITCH * 4 + 4 * UH_ROWBUF_F4 * 16 + KK * KK * 32 * 4;  \
+            const int grid_w = (int)(ntiles < 512 ? ntiles : 512);                                                             \
+            if (bf_set_max_lds(reinterpret_cast<const void*>(uh_enc32w_kernel<KK, A>), LDS_W) != hipSuccess) return BF_EHIP;   \
+            hipLaunchKernelGGL((uh_enc32w_kernel<KK, A>), dim3(grid_w), dim3(512), LDS_W, s, x, out, dw, ln_gamma, eps, packed, mult, B, \
+                               H, W, alpha);                                                                                   \
+        } else if (g_uh_enc_variant == 2) {                                                                                    \
             if (bf_set_max_lds(reinterpret_cast<const void*>(uh_enc32u_kernel<KK, A>), LDS_S) != hipSuccess) return BF_EHIP;   \
             hipLaunchKernelGGL((uh_enc32u_kernel<KK, A>), dim3(grid_s), dim3(512), LDS_S, s, x, out, dw, ln_gamma, eps, packed, mult, B, \
                                H, W, alpha);                                                                                   \
