@@ -35,6 +35,33 @@ def test_library_exports_every_declared_symbol():
     assert N.lib().bf_abi_version() == 1
 
 
+def test_ctypes_signatures_match_the_header_prototypes():
+    """every prototype of include/bfcnn_hip.h against _native.SIGNATURES: same number of parameters, pointers bound as pointers,
+    int / int64_t / float / uint64_t as the ctypes type of that width (a binding that drifts from the header corrupts calls
+    silently: ctypes does not check)."""
+    text = (ROOT / "include" / "bfcnn_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    protos = re.findall(r"\b(?:const\s+char\s*\*|int64_t|int|void|bf_handle)\s*(bf_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S)
+    names = [n for n, _ in protos]
+    assert sorted(set(names)) == _declared_symbols(), sorted(set(_declared_symbols()) - set(names))
+    scalar = {"int": C.c_int, "int32_t": C.c_int, "int64_t": C.c_int64, "float": C.c_float, "uint64_t": C.c_uint64, "unsigned": C.c_uint,
+              "double": C.c_double}
+    for name, args in protos:
+        args = " ".join(args.split())
+        params = [] if args in ("", "void") else [a.strip() for a in args.split(",")]
+        _, argtypes = N.SIGNATURES[name]
+        assert len(params) == len(argtypes), (name, len(params), len(argtypes))
+        for i, (p, t) in enumerate(zip(params, argtypes)):
+            words = p.replace("const", " ").replace("*", " * ").split()
+            is_pointer = "*" in words or "[" in p or words[0] in ("bf_handle",)
+            if is_pointer:
+                assert t in (C.c_void_p, C.c_char_p) or hasattr(t, "contents") or hasattr(t, "_type_"), (name, i, p, t)
+            else:
+                assert words[0] in scalar, (name, i, p)
+                assert C.sizeof(t) == C.sizeof(scalar[words[0]]) and (t is C.c_float) == (words[0] == "float"), (name, i, p, t)
+
+
 def test_struct_layouts_match_header():
     assert C.sizeof(N.ResnetDesc) == 17 * 4 + 5 * 4
     assert C.sizeof(N.LossDesc) == 8 * 4
