@@ -105,6 +105,7 @@ SIGNATURES = {
     "bf_op_scale_add_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _I64, _P]),
     "bf_op_multiplier_bwd": (_I, [_P, _P, _P, _I, _P]),
     "bf_op_smooth_split_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "bf_op_smooth_split_bwd_ex": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "bf_op_upsample2x_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "bf_op_conv2d_wgrad": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _I64, _P]),
     "bf_op_head_out_bwd": (_I, [_P, _P, _P, _P, _P, _I64, _I, _I, _I, _F, _F, _P, _I64, _P]),

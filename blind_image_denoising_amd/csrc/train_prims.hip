@@ -221,9 +221,11 @@ __global__ void tp_multiplier_bwd_kernel(const float* __restrict__ w, const floa
 // gs = -dlap + scatter(ddown) is the gradient with respect to smooth; dx = dlap + smooth^T(gs):
 //   average: sum over the in-bounds neighbours q of gs[q] / count(q) ; Gaussian: sum of gs[q] * g[p - q] (symmetric window)
 __global__ void tp_smooth_split_bwd_kernel(const float* __restrict__ dlap, const float* __restrict__ ddown,
-                                           const float* __restrict__ gauss, float* __restrict__ dx, int B, int H, int W, int C, int k)
+                                           const float* __restrict__ gauss, float* __restrict__ dx, int B, int H, int W, int C, int k,
+                                           int down_stride)
 {
-    const int pad = (k - 1) / 2, Hd = (H + 1) / 2, Wd = (W + 1) / 2;
+    // window of output q: inputs q - pb .. q - pb + k - 1 (TF "same": pad_before = (k - 1) / 2, the extra one after for even k)
+    const int pb = (k - 1) / 2, Hd = (H + 1) / 2, Wd = (W + 1) / 2;
     const int64_t n = (int64_t)B * H * W * C;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
         const int c = (int)(e % C);
@@ -233,18 +235,19 @@ __global__ void tp_smooth_split_bwd_kernel(const float* __restrict__ dlap, const
         const int y = (int)(p % H);
         const int64_t b = p / H;
         float acc = 0.f;
-        for (int i = -pad; i <= pad; ++i) {
-            const int qy = y + i;
+        for (int i = 0; i < k; ++i) {
+            const int qy = y + pb - i;                        // the outputs whose window holds input row y (tap i)
             if (qy < 0 || qy >= H) continue;
-            for (int j = -pad; j <= pad; ++j) {
-                const int qx = x + j;
+            for (int j = 0; j < k; ++j) {
+                const int qx = x + pb - j;
                 if (qx < 0 || qx >= W) continue;
                 float gs = -dlap[((b * H + qy) * W + qx) * C + c];
-                if (!(qy & 1) && !(qx & 1)) gs += ddown[((b * Hd + (qy >> 1)) * Wd + (qx >> 1)) * C + c];
+                if (down_stride == 1) gs += ddown[((b * H + qy) * W + qx) * C + c];
+                else if (!(qy & 1) && !(qx & 1)) gs += ddown[((b * Hd + (qy >> 1)) * Wd + (qx >> 1)) * C + c];
                 if (gauss) {
-                    acc = fmaf(gs, gauss[(pad - i) * k + (pad - j)], acc);
+                    acc = fmaf(gs, gauss[i * k + j], acc);
                 } else {
-                    const int cy = min(qy + pad, H - 1) - max(qy - pad, 0) + 1, cx = min(qx + pad, W - 1) - max(qx - pad, 0) + 1;
+                    const int cy = min(qy - pb + k - 1, H - 1) - max(qy - pb, 0) + 1, cx = min(qx - pb + k - 1, W - 1) - max(qx - pb, 0) + 1;
                     acc += gs / (float)(cy * cx);
                 }
             }
@@ -754,14 +757,23 @@ extern "C" int bf_op_multiplier_bwd(const float* w, const float* dm, float* dw, 
     return TP_OK();
 }
 
+// down_stride 2: ddown is the gradient of smooth[:, ::2, ::2]; 1: of smooth itself (conv2d / maxpool down-sampling take the
+// full-resolution smooth map).  Averaging: any k <= 7; Gaussian: odd k (symmetric window)
+extern "C" int bf_op_smooth_split_bwd_ex(const float* dlap, const float* ddown, const float* gauss, float* dx, int B, int H, int W, int C,
+                                         int k, int down_stride, void* stream)
+{
+    if (!dlap || !ddown || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (down_stride != 1 && down_stride != 2)) return BF_EINVAL;
+    if (k < 1 || k > 7 || (gauss && !(k & 1))) return BF_EUNSUPPORTED;
+    const int64_t n = (int64_t)B * H * W * C;
+    hipLaunchKernelGGL(tp_smooth_split_bwd_kernel, dim3(tp_grid(n)), dim3(256), 0, (hipStream_t)stream, dlap, ddown, gauss, dx, B, H, W, C, k,
+                       down_stride);
+    return TP_OK();
+}
+
 extern "C" int bf_op_smooth_split_bwd(const float* dlap, const float* ddown, const float* gauss, float* dx, int B, int H, int W, int C,
                                       int k, void* stream)
 {
-    if (!dlap || !ddown || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0) return BF_EINVAL;
-    if (k < 1 || k > 7 || !(k & 1)) return BF_EUNSUPPORTED;
-    const int64_t n = (int64_t)B * H * W * C;
-    hipLaunchKernelGGL(tp_smooth_split_bwd_kernel, dim3(tp_grid(n)), dim3(256), 0, (hipStream_t)stream, dlap, ddown, gauss, dx, B, H, W, C, k);
-    return TP_OK();
+    return bf_op_smooth_split_bwd_ex(dlap, ddown, gauss, dx, B, H, W, C, k, 2, stream);
 }
 
 extern "C" int bf_op_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, int bilinear, void* stream)

@@ -5,10 +5,10 @@ of the total with respect to every trainable tensor -- what `tf.GradientTape` do
 the graph of bfcnn/backbone_unet_laplacian.py:281-606 over the operator library's C-ABI entry points (`bf_op_*`: forward
 operators of unet_ops.hip, backward primitives of train_prims.hip).  PyTorch holds the tensors; it computes nothing.
 
-Scope: the graph family of configs/unet_laplacian_v5.json -- ConvNext blocks (depthwise k x k, LayerNorm, 1x1 C->4C + activation,
+Scope: the graph family of configs/unet_laplacian_v5.json and v6.json -- ConvNext blocks (depthwise k x k, LayerNorm, 1x1 C->4C + activation,
 1x1 4C->C, ChannelLearnableMultiplier, StochasticDepth, Add), self-attention blocks on the deepest level (resize to 16x16,
 LayerNorm, query / key / value, dot-product attention with dropout, resize back, output convolution, multiplier), level
-LayerNorm + activation, the averaging / Gaussian Laplacian split, strided down-sampling + 1x1, `upsample_laplacian_conv2d`,
+LayerNorm + activation, the averaging / Gaussian Laplacian split, strided down-sampling + 1x1 or 2x2 stride-2 convolution, `upsample_laplacian_conv2d` / nearest or bilinear + 3x3 convolution,
 per-scale denoiser heads -- with any depth / width / filters.  Attention gates, mix projections, the other resamplers and the
 trained archive's graph revision raise NotImplementedError (inference covers them).
 
@@ -110,8 +110,9 @@ class UnetTrainGraph:
         bad = []
         if model.use_attention_gates: bad.append("use_attention_gates")
         if getattr(model, "use_mix_project", False): bad.append("use_mix_project")
-        if model.downsample_type != "strides": bad.append(f"downsample_type {model.downsample_type}")
-        if model.upsample_type != "upsample_laplacian_conv2d": bad.append(f"upsample_type {model.upsample_type}")
+        if model.downsample_type not in ("strides", "conv2d"): bad.append(f"downsample_type {model.downsample_type}")
+        if model.upsample_type not in ("upsample_laplacian_conv2d", "upsample_nearest_conv2d", "upsample_bilinear_conv2d"):
+            bad.append(f"upsample_type {model.upsample_type}")
         if getattr(model, "attention_full", False) or getattr(model, "output_norm_at_heads", False) or \
                 getattr(model, "upsample_linear", False) or not getattr(model, "level_activation", True):
             bad.append("the trained archive's graph revision")
@@ -269,6 +270,48 @@ class UnetTrainGraph:
                 return UL.pointwise(dp, pack(ops.transpose(w)), cin)
             return y, bwd
 
+        def conv3x3_act(name, x, cout, act):
+            """Conv2D 3 x 3, same, + activation (the convolution behind an UpSampling2D: upsampling.py:52-76)"""
+            Bc, Hc, Wc, cin = x.shape
+            w = self.W(name)                                                      # [3,3,cin,cout]
+            y = UL.conv2d(x, UL.pack_conv(w.contiguous()), cout, 3, 1, act)
+
+            def bwd(dy):
+                dp = ops.act_bwd(y, dy, act)
+                sp, sn = ops._s()
+                _call("bf_op_conv2d_wgrad", N.ptr(x), 0, N.ptr(dp), N.ptr(self.G(name, grads)), Bc, Hc, Wc, cin, cout, 3, 0, 0.0, 0.0, sp, sn,
+                      N.stream_ptr(dp))
+                wf = torch.empty_like(w)                                          # data gradient: taps flipped, every tap transposed
+                _call("bf_op_flip_hw", N.ptr(w), N.ptr(wf), 3, cin * cout, N.stream_ptr(w))
+                wt = torch.empty((3, 3, cout, cin), dtype=torch.float32, device=dev)
+                for t_ in range(9):
+                    _call("bf_op_transpose2d", N.ptr(wf.view(9, cin, cout)[t_]), N.ptr(wt.view(9, cout, cin)[t_]), cin, cout, N.stream_ptr(wf))
+                return UL.conv2d(dp, UL.pack_conv(wt), cin, 3, 1, "linear")
+            return y, bwd
+
+        def conv2x2_s2_act(name, x, cout, act):
+            """Conv2D 2 x 2, strides 2, same (downsample_type "conv2d", downsampling.py:45-55); even sizes: no padding, every output
+            sees its own 2 x 2 block, so the weight gradient is four 1 x 1 weight gradients on the strided slices of x and the data
+            gradient the transposed convolution with the same kernel array"""
+            Bc, Hc, Wc, cin = x.shape
+            if Hc % 2 or Wc % 2:
+                raise ValueError(f"conv2d down-sampling in training needs even sizes (got {Hc}x{Wc})")
+            w = self.W(name)                                                      # [2,2,cin,cout]
+            y = UL.conv2d(x, UL.pack_conv(w.contiguous()), cout, 2, 2, act)
+
+            def bwd(dy):
+                dp = ops.act_bwd(y, dy, act)
+                gw = self.G(name, grads).view(4, cin * cout)
+                xs = torch.empty((Bc, Hc // 2, Wc // 2, cin), dtype=torch.float32, device=dev)
+                flat = x.reshape(-1)
+                for ky in range(2):
+                    for kx in range(2):
+                        src = flat[(ky * Wc + kx) * cin:]                         # x[:, ky::2, kx::2, :] as a strided slice from a shifted base
+                        _call("bf_strided_slice2", N.ptr(src), N.ptr(xs), Bc, Hc, Wc, cin, N.stream_ptr(x))
+                        ops.matmul_wgrad(xs, dp, gw[ky * 2 + kx])
+                return UL.conv2d_transpose(dp, w.contiguous(), 2, "linear")     # keras Conv2D kernel [k,k,cin,cout] = Conv2DTranspose's [k,k,out,in]
+            return y, bwd
+
         # -- forward ----------------------------------------------------------------------------------------------------------
         wb = self.W("base/kernel")
         x = UL.first_conv(noisy, wb, H, Wd, a, True, m.v_min, m.v_max, arith=0)
@@ -301,11 +344,15 @@ class UnetTrainGraph:
                 x = UL.dwconv_ln(y, None, None, a)
                 enc_chain.append(("op", (lambda yy: (lambda dy: ops.act_bwd(yy, dy, a)))(x)))
             if d != m.depth - 1:
-                lp, down = UL.smooth_split(x, k_g, gauss)
+                ds = 2 if m.downsample_type == "strides" else 1              # conv2d takes the full-resolution smooth map
+                lp, down = UL.smooth_split(x, k_g, gauss, ds)
                 lap[d] = lp
                 Bx, Hx, Wx, Cx = x.shape
-                enc_chain.append(("split", d, (Bx, Hx, Wx, Cx)))
-                x, b_ = conv1x1_act(f"down{d}/kernel", down, m.level_filters(d + 1), a)
+                enc_chain.append(("split", d, (Bx, Hx, Wx, Cx), ds))
+                if ds == 2:
+                    x, b_ = conv1x1_act(f"down{d}/kernel", down, m.level_filters(d + 1), a)
+                else:
+                    x, b_ = conv2x2_s2_act(f"down{d}/kernel", down, m.level_filters(d + 1), a)
                 enc_chain.append(("op", b_))
         deep = x                                                      # nodes[depth - 1]
 
@@ -315,10 +362,14 @@ class UnetTrainGraph:
         for d in reversed(range(m.depth - 1)):
             low = outs[d + 1]
             Cc = m.level_filters(d)
-            u2 = upsample_2x(low, bilinear=True)
-            up, b_up = conv1x1_act(f"up{d}/kernel", u2, Cc, a)
+            bil = m.upsample_type != "upsample_nearest_conv2d"
+            u2 = upsample_2x(low, bilinear=bil)
+            if m.upsample_type == "upsample_laplacian_conv2d":
+                up, b_up = conv1x1_act(f"up{d}/kernel", u2, Cc, a)
+            else:
+                up, b_up = conv3x3_act(f"up{d}/kernel", u2, Cc, a)
             x = ops.add(lap[d], up)
-            chain = [("up", b_up, low.shape)]
+            chain = [("up", b_up, low.shape, bil)]
             for w_ in range(m.width):
                 x, b_ = convnext(f"dec{d}_{w_}", x, m.dec_k)
                 chain.append(("op", b_))
@@ -374,10 +425,11 @@ class UnetTrainGraph:
             for item in reversed(chain[1:]):
                 g = item[1](g)
             dlap[d] = g                                                 # x = lap[d] + up
-            _, b_up, low_shape = chain[0]
+            _, b_up, low_shape, bil = chain[0]
             du2 = b_up(g)
             dl = torch.empty(low_shape, dtype=torch.float32, device=dev)
-            _call("bf_op_upsample2x_bwd", N.ptr(du2), N.ptr(dl), low_shape[0], low_shape[1], low_shape[2], low_shape[3], 1, N.stream_ptr(du2))
+            _call("bf_op_upsample2x_bwd", N.ptr(du2), N.ptr(dl), low_shape[0], low_shape[1], low_shape[2], low_shape[3], int(bil),
+                  N.stream_ptr(du2))
             dlow[d + 1] = dl
         last = m.depth - 1
         g = dfeat[last] if last not in dlow else ops.add(dfeat[last], dlow[last])
@@ -385,9 +437,10 @@ class UnetTrainGraph:
             if item[0] == "op":
                 g = item[1](g)
             else:                                                      # the split of level d: g = d(down), dlap[d] = d(lap)
-                _, d, (Bx, Hx, Wx, Cx) = item
+                _, d, (Bx, Hx, Wx, Cx), ds = item
                 dx = torch.empty((Bx, Hx, Wx, Cx), dtype=torch.float32, device=dev)
-                _call("bf_op_smooth_split_bwd", N.ptr(dlap[d]), N.ptr(g), N.ptr(gauss), N.ptr(dx), Bx, Hx, Wx, Cx, k_g, N.stream_ptr(g))
+                _call("bf_op_smooth_split_bwd_ex", N.ptr(dlap[d]), N.ptr(g), N.ptr(gauss), N.ptr(dx), Bx, Hx, Wx, Cx, k_g, ds,
+                      N.stream_ptr(g))
                 g = dx
         base_bwd(g)
 

@@ -351,6 +351,10 @@ int bf_op_multiplier_bwd(const float* w, const float* dm, float* dw, int n, void
 /* adjoint of bf_op_smooth_split (gauss NULL: AveragePooling2D with the in-bounds divisor): dx from (dlap, ddown) */
 int bf_op_smooth_split_bwd(const float* dlap, const float* ddown, const float* gauss, float* dx, int batch, int height, int width,
                            int channels, int k, void* stream);
+/* the same with ddown the gradient of the full-resolution smooth map (down_stride 1: conv2d / maxpool down-sampling) or of
+   smooth[:, ::2, ::2] (2); averaging windows of any size k <= 7 (TF same padding: the extra tap after for even k) */
+int bf_op_smooth_split_bwd_ex(const float* dlap, const float* ddown, const float* gauss, float* dx, int batch, int height, int width,
+                              int channels, int k, int down_stride, void* stream);
 /* adjoint of UpSampling2D(2, bilinear | nearest): dx [B,H,W,C] from dy [B,2H,2W,C] */
 int bf_op_upsample2x_bwd(const float* dy, float* dx, int batch, int height, int width, int channels, int bilinear, void* stream);
 /* k x k convolution (same, stride 1) weight gradient for the first convolution; x = the raw image, normalised as the forward does */

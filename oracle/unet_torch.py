@@ -73,12 +73,22 @@ def _multiplier(x, w):
 
 
 def _avg_pool_same(x, k):
-    """AveragePooling2D(k, strides 1, same): divisor = in-bounds taps."""
-    return F.avg_pool2d(x.permute(0, 3, 1, 2), k, stride=1, padding=k // 2, count_include_pad=False).permute(0, 2, 3, 1)
+    """AveragePooling2D(k, strides 1, same): TF padding (the extra tap after for even k), divisor = in-bounds taps."""
+    _, pt, pb = O.same_pads(x.shape[1], k, 1)
+    _, pl, pr = O.same_pads(x.shape[2], k, 1)
+    xp = F.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb))
+    ones = F.pad(torch.ones((1, 1, x.shape[1], x.shape[2]), dtype=x.dtype), (pl, pr, pt, pb))
+    ssum = F.avg_pool2d(xp, k, stride=1) * (k * k)
+    cnt = F.avg_pool2d(ones, k, stride=1) * (k * k)
+    return (ssum / cnt).permute(0, 2, 3, 1)
 
 
 def _up2(x):
     return F.interpolate(x.permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+
+
+def _up2_nearest(x):
+    return x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
 
 
 def _resize(x, oh, ow):
@@ -95,8 +105,9 @@ def check_trainable_graph(spec: U.UnetLaplacianSpec):
     bad = []
     if spec.use_attention_gates: bad.append("use_attention_gates")
     if spec.use_mix_project: bad.append("use_mix_project")
-    if spec.downsample_type != "strides": bad.append(f"downsample_type {spec.downsample_type}")
-    if spec.upsample_type != "upsample_laplacian_conv2d": bad.append(f"upsample_type {spec.upsample_type}")
+    if spec.downsample_type not in ("strides", "conv2d"): bad.append(f"downsample_type {spec.downsample_type}")
+    if spec.upsample_type not in ("upsample_laplacian_conv2d", "upsample_nearest_conv2d", "upsample_bilinear_conv2d"):
+        bad.append(f"upsample_type {spec.upsample_type}")
     if spec.attention_full or spec.output_norm_at_heads or spec.upsample_linear or not spec.level_activation: bad.append("archive graph revision")
     if (spec.mlp_activation or spec.activation) == "gelu": bad.append("gelu")
     if not (spec.use_laplacian or spec.use_laplacian_averaging): bad.append("no laplacian split")
@@ -154,10 +165,14 @@ def backbone(spec, P, xn, depth_scale=None, attn_scale=None):
                 g = torch.from_numpy(U.gaussian_kernel_3((k, k)))
                 smooth = _depthwise(x, g[:, :, None, None].repeat(1, 1, x.shape[-1], 1))
             nodes[d] = x - smooth
-            x = _act(_conv(smooth[:, ::2, ::2, :], P[f"down{d}/kernel"]), a)
+            if spec.downsample_type == "strides":
+                x = _act(_conv(smooth[:, ::2, ::2, :], P[f"down{d}/kernel"]), a)
+            else:                                                     # conv2d: 2 x 2, strides 2, same (downsampling.py:45-55)
+                x = _act(_conv(smooth, P[f"down{d}/kernel"], stride=2), a)
     outs = {spec.depth - 1: nodes[spec.depth - 1]}
     for d in reversed(range(spec.depth - 1)):
-        up = _act(_conv(_up2(outs[d + 1]), P[f"up{d}/kernel"]), a)
+        low = outs[d + 1]
+        up = _act(_conv(_up2_nearest(low) if spec.upsample_type == "upsample_nearest_conv2d" else _up2(low), P[f"up{d}/kernel"]), a)
         x = nodes[d] + up
         for w in range(spec.width):
             pre = f"dec{d}_{w}"

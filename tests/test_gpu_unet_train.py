@@ -151,8 +151,13 @@ def test_regularisers():
 
 # ---- the whole training step ------------------------------------------------------------------------------------------------
 
-def _setup(depth, width, filters, S, B=2, seed=11):
+V6 = {"decoder_kernel_size": 5, "downsample_type": "conv2d", "gaussian_kernel_size": 2, "upsample_type": "upsample_nearest_conv2d",
+      "use_laplacian_averaging": True}            # what configs/unet_laplacian_v6.json changes against v5
+
+
+def _setup(depth, width, filters, S, B=2, seed=11, backbone=None):
     cfg = U.canonical_config(depth=depth, width=width, filters=filters)
+    cfg["model"]["backbone"].update(backbone or {})
     spec = U.UnetLaplacianSpec.from_config(cfg["model"])
     params = U.init_params(spec, seed=seed)
     model = bf.model_builder(cfg["model"], device="cuda").hydra
@@ -198,6 +203,16 @@ LOSS_V5 = {"hinge": 3.5, "cutoff": 255.0, "mae_multiplier": 1.0, "mse_multiplier
 def test_train_step_matches_the_gradient_oracle(depth, width, filters, S):
     cfg, spec, params, model, clean, noisy = _setup(depth, width, filters, S)
     _check_step(spec, params, model, clean, noisy, LOSS_V5, [1.0, 0.6, 0.3][:depth])
+
+
+@pytest.mark.parametrize("backbone", [V6, {"upsample_type": "upsample_bilinear_conv2d"}, {"downsample_type": "conv2d"},
+                                      {"gaussian_kernel_size": 2, "use_laplacian_averaging": True}],
+                         ids=["v6", "bilinear-conv-upsample", "conv2d-downsample", "2x2-averaging"])
+def test_train_step_of_the_v6_graph_family(backbone):
+    """configs/unet_laplacian_v6.json: 2 x 2 averaging split, 2 x 2 stride-2 convolution down, nearest + 3 x 3 convolution up,
+    5 x 5 decoder depthwise -- all together and one at a time"""
+    cfg, spec, params, model, clean, noisy = _setup(3, 1, 32, 32, backbone=backbone)
+    _check_step(spec, params, model, clean, noisy, LOSS_V5, [1.0, 0.6, 0.3])
 
 
 def test_train_step_with_stochastic_depth_and_attention_dropout():
