@@ -466,3 +466,40 @@ extern "C" int bf_op_normalize(const float* x, float* out, int64_t n, float v_mi
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
 
+// AdditiveAttentionGate's last stage (bfcnn/custom_layers.py:826-832) + the Add behind it: out = enc * sigmoid(4 o) + up, and
+// its backward: denc = dy * s, do = dy * enc * 4 s (1 - s)  (the gradient with respect to `up` through the Add is dy itself)
+__global__ __launch_bounds__(256) void tg_sigmoid_gate_kernel(const float* __restrict__ enc, const float* __restrict__ o,
+                                                              const float* __restrict__ up, float* __restrict__ out, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float sg = 1.f / (1.f + expf(-4.f * o[i]));
+        out[i] = fmaf(enc[i], sg, up ? up[i] : 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void tg_sigmoid_gate_bwd_kernel(const float* __restrict__ enc, const float* __restrict__ o,
+                                                                  const float* __restrict__ dy, float* __restrict__ denc,
+                                                                  float* __restrict__ dout_o, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float sg = 1.f / (1.f + expf(-4.f * o[i]));
+        const float d = dy[i];
+        denc[i] = d * sg;
+        dout_o[i] = d * enc[i] * 4.f * sg * (1.f - sg);
+    }
+}
+
+extern "C" int bf_op_sigmoid_gate(const float* enc, const float* o, const float* up, float* out, int64_t n, void* stream)
+{
+    if (!enc || !o || !out || n <= 0) return BF_EINVAL;
+    hipLaunchKernelGGL(tg_sigmoid_gate_kernel, dim3(tg_grid(n)), dim3(256), 0, (hipStream_t)stream, enc, o, up, out, n);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+extern "C" int bf_op_sigmoid_gate_bwd(const float* enc, const float* o, const float* dy, float* denc, float* dout_o, int64_t n, void* stream)
+{
+    if (!enc || !o || !dy || !denc || !dout_o || n <= 0) return BF_EINVAL;
+    hipLaunchKernelGGL(tg_sigmoid_gate_bwd_kernel, dim3(tg_grid(n)), dim3(256), 0, (hipStream_t)stream, enc, o, dy, denc, dout_o, n);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+

@@ -9,8 +9,8 @@ Scope: the graph family of configs/unet_laplacian_v5.json and v6.json -- ConvNex
 1x1 4C->C, ChannelLearnableMultiplier, StochasticDepth, Add), self-attention blocks on the deepest level (resize to 16x16,
 LayerNorm, query / key / value, dot-product attention with dropout, resize back, output convolution, multiplier), level
 LayerNorm + activation, the averaging / Gaussian Laplacian split, strided down-sampling + 1x1 or 2x2 stride-2 convolution, `upsample_laplacian_conv2d` / nearest or bilinear + 3x3 convolution,
-per-scale denoiser heads -- with any depth / width / filters.  Attention gates, mix projections, the other resamplers and the
-trained archive's graph revision raise NotImplementedError (inference covers them).
+per-scale denoiser heads, AdditiveAttentionGate in front of the decoder Add (v3 / v4) -- with any depth / width / filters.
+Mix projections, the other resamplers and the trained archive's graph revision raise NotImplementedError (inference covers them).
 
 Exact fp32 throughout (the split-f16 inference operators are not used here): gradients are compared with the torch-autograd
 oracle (oracle/unet_torch.py) in tests/test_gpu_unet_train.py.
@@ -28,6 +28,7 @@ from .pyramid import avg_pool2_valid, upsample_2x
 SOFTORTHONORMAL = (0.01, 0.0, 1e-4)        # bfcnn/constants.py:19-21: lambda, l1, l2
 MULTIPLIER_L1 = 1e-6                        # ChannelLearnableMultiplier's regulariser (custom_layers.py:267)
 KERNEL_L2 = 0.01                            # keras "l2" string regulariser
+GATE_L2 = 1e-4                              # AdditiveAttentionGate's default kernel regulariser (custom_layers.py:726)
 
 
 def _call(fn_name: str, *args):
@@ -108,7 +109,6 @@ class UnetTrainGraph:
     def __init__(self, model: "UL.UnetLaplacianHydra", loss_config: Dict, soft_orthonormal: Optional[bool] = None):
         self.m = model
         bad = []
-        if model.use_attention_gates: bad.append("use_attention_gates")
         if getattr(model, "use_mix_project", False): bad.append("use_mix_project")
         if model.downsample_type not in ("strides", "conv2d"): bad.append(f"downsample_type {model.downsample_type}")
         if model.upsample_type not in ("upsample_laplacian_conv2d", "upsample_nearest_conv2d", "upsample_bilinear_conv2d"):
@@ -180,8 +180,17 @@ class UnetTrainGraph:
             t1 = UL.dwconv_mult(x, wdw, None)
             gamma = self.W(f"{prefix}/ln/gamma") if m.use_ln else None
             t2 = UL.dwconv_ln(t1, None, gamma) if m.use_ln else t1
-            t3 = UL.pointwise(t2, pack(w1), 4 * Cc, a)
-            t4 = UL.pointwise(t3, pack(w2), Cc)
+            # the hidden layer in chunks of at most 256 units (the widest 1x1 convolution of the operator library): one chunk up
+            # to 64 channels, two for the 128-channel levels of the 4-level models
+            Hh = 4 * Cc
+            Hc = min(Hh, 256)
+            chunks = range(Hh // Hc)
+            w1c = [w1 if Hc == Hh else w1[:, j * Hc:(j + 1) * Hc].contiguous() for j in chunks]
+            w2c = [w2[j * Hc:(j + 1) * Hc] for j in chunks]
+            t3 = [UL.pointwise(t2, pack(w1c[j]), Hc, a) for j in chunks]
+            t4 = None
+            for j in chunks:
+                t4 = UL.pointwise(t3[j], pack(w2c[j]), Cc, res=t4)
             wm = self.W(f"{prefix}/gamma/w") if m.use_gamma else None
             mult = UL.channel_multiplier(wm) if m.use_gamma else None
             s = depth_scale.get(prefix)
@@ -192,10 +201,18 @@ class UnetTrainGraph:
                 dt4 = ops.scale_add_bwd(t4, mult, s, dout, dm)
                 if m.use_gamma:
                     _call("bf_op_multiplier_bwd", N.ptr(wm), N.ptr(dm), N.ptr(self.G(f"{prefix}/gamma/w", grads)), Cc, N.stream_ptr(dm))
-                ops.matmul_wgrad(t3, dt4, self.G(f"{prefix}/pw2/kernel", grads))
-                dt3 = ops.act_bwd(t3, UL.pointwise(dt4, pack(ops.transpose(w2)), 4 * Cc), a)
-                ops.matmul_wgrad(t2, dt3, self.G(f"{prefix}/pw1/kernel", grads))
-                dt2 = UL.pointwise(dt3, pack(ops.transpose(w1)), Cc)
+                gw2, gw1 = self.G(f"{prefix}/pw2/kernel", grads).view(Hh, Cc), self.G(f"{prefix}/pw1/kernel", grads).view(Cc, Hh)
+                dt2 = None
+                for j in chunks:
+                    ops.matmul_wgrad(t3[j], dt4, gw2[j * Hc:(j + 1) * Hc])
+                    dt3 = ops.act_bwd(t3[j], UL.pointwise(dt4, pack(ops.transpose(w2c[j].contiguous())), Hc), a)
+                    if Hc == Hh:
+                        ops.matmul_wgrad(t2, dt3, gw1)
+                    else:                                          # a column block of the kernel gradient: staged, then copied in
+                        blk = torch.empty((Cc, Hc), dtype=torch.float32, device=dev)
+                        ops.matmul_wgrad(t2, dt3, blk)
+                        gw1[:, j * Hc:(j + 1) * Hc].copy_(blk)
+                    dt2 = UL.pointwise(dt3, pack(ops.transpose(w1c[j])), Cc, res=dt2)
                 dt1 = ops.layernorm_bwd(t1, gamma, dt2, self.G(f"{prefix}/ln/gamma", grads)) if m.use_ln else dt2
                 ops.dwconv_wgrad(x, dt1, self.G(f"{prefix}/dw/kernel", grads), k)
                 wf = torch.empty_like(wdw)
@@ -312,6 +329,43 @@ class UnetTrainGraph:
                 return UL.conv2d_transpose(dp, w.contiguous(), 2, "linear")     # keras Conv2D kernel [k,k,cin,cout] = Conv2DTranspose's [k,k,out,in]
             return y, bwd
 
+        def attention_gate(d, enc, up):
+            """AdditiveAttentionGate (custom_layers.py:805-832) and the Add behind it (backbone_unet_laplacian.py:497-519):
+            x = enc * sigmoid(4 * scale(conv_o(leaky_relu_0.1(conv_x(LN up) + conv_y(LN enc))))) + up.
+            Returns (x, backward: dx -> (d enc, d up))."""
+            Cc = enc.shape[-1]
+            pre = f"gate{d}"
+            gx = self.W(f"{pre}/x_ln/gamma") if m.use_ln else None
+            gy = self.W(f"{pre}/y_ln/gamma") if m.use_ln else None
+            wx, wy, wo = (self.W(f"{pre}/{n_}/kernel").view(Cc, Cc) for n_ in ("x", "y", "o"))
+            lx = UL.dwconv_ln(up, None, gx) if m.use_ln else up
+            ly = UL.dwconv_ln(enc, None, gy) if m.use_ln else enc
+            z = ops.add(UL.pointwise(lx, pack(wx), Cc), UL.pointwise(ly, pack(wy), Cc))
+            sact = UL.dwconv_ln(z, None, None, "leaky_relu_01")
+            o_raw = UL.pointwise(sact, pack(wo), Cc)
+            wm = self.W(f"{pre}/scale/w")
+            mult = UL.channel_multiplier(wm)
+            o = ops.scale_add(None, o_raw, mult, None)
+            out = torch.empty_like(enc)
+            _call("bf_op_sigmoid_gate", N.ptr(enc), N.ptr(o), N.ptr(up), N.ptr(out), enc.numel(), N.stream_ptr(enc))
+
+            def bwd(dout):
+                denc, do = torch.empty_like(enc), torch.empty_like(enc)
+                _call("bf_op_sigmoid_gate_bwd", N.ptr(enc), N.ptr(o), N.ptr(dout), N.ptr(denc), N.ptr(do), enc.numel(), N.stream_ptr(enc))
+                dm = torch.empty(Cc, dtype=torch.float32, device=dev)
+                do_raw = ops.scale_add_bwd(o_raw, mult, None, do, dm)
+                _call("bf_op_multiplier_bwd", N.ptr(wm), N.ptr(dm), N.ptr(self.G(f"{pre}/scale/w", grads)), Cc, N.stream_ptr(dm))
+                ops.matmul_wgrad(sact, do_raw, self.G(f"{pre}/o/kernel", grads))
+                dz = ops.act_bwd(sact, UL.pointwise(do_raw, pack(ops.transpose(wo)), Cc), "leaky_relu_01")
+                ops.matmul_wgrad(lx, dz, self.G(f"{pre}/x/kernel", grads))
+                ops.matmul_wgrad(ly, dz, self.G(f"{pre}/y/kernel", grads))
+                dlx = UL.pointwise(dz, pack(ops.transpose(wx)), Cc)
+                dly = UL.pointwise(dz, pack(ops.transpose(wy)), Cc)
+                dup = ops.layernorm_bwd(up, gx, dlx, self.G(f"{pre}/x_ln/gamma", grads)) if m.use_ln else dlx
+                dency = ops.layernorm_bwd(enc, gy, dly, self.G(f"{pre}/y_ln/gamma", grads)) if m.use_ln else dly
+                return ops.add(denc, dency), ops.add(dout, dup)
+            return out, bwd
+
         # -- forward ----------------------------------------------------------------------------------------------------------
         wb = self.W("base/kernel")
         x = UL.first_conv(noisy, wb, H, Wd, a, True, m.v_min, m.v_max, arith=0)
@@ -368,8 +422,12 @@ class UnetTrainGraph:
                 up, b_up = conv1x1_act(f"up{d}/kernel", u2, Cc, a)
             else:
                 up, b_up = conv3x3_act(f"up{d}/kernel", u2, Cc, a)
-            x = ops.add(lap[d], up)
-            chain = [("up", b_up, low.shape, bil)]
+            b_gate = None
+            if m.use_attention_gates:
+                x, b_gate = attention_gate(d, lap[d], up)
+            else:
+                x = ops.add(lap[d], up)
+            chain = [("up", b_up, low.shape, bil, b_gate)]
             for w_ in range(m.width):
                 x, b_ = convnext(f"dec{d}_{w_}", x, m.dec_k)
                 chain.append(("op", b_))
@@ -424,8 +482,11 @@ class UnetTrainGraph:
             chain = dec_chain[d]
             for item in reversed(chain[1:]):
                 g = item[1](g)
-            dlap[d] = g                                                 # x = lap[d] + up
-            _, b_up, low_shape, bil = chain[0]
+            _, b_up, low_shape, bil, b_gate = chain[0]
+            if b_gate is not None:
+                dlap[d], g = b_gate(g)                                   # x = gate(lap[d], up) + up
+            else:
+                dlap[d] = g                                             # x = lap[d] + up
             du2 = b_up(g)
             dl = torch.empty(low_shape, dtype=torch.float32, device=dev)
             _call("bf_op_upsample2x_bwd", N.ptr(du2), N.ptr(dl), low_shape[0], low_shape[1], low_shape[2], low_shape[3], int(bil),
@@ -454,14 +515,17 @@ class UnetTrainGraph:
             gslice = self._grad_view(name, grads)
             w = self.W(name)
             leaf = name.split("/")[1]
-            soft = leaf in ("key", "query", "value", "out") or (leaf in ("pw1", "pw2") and self.soft_orthonormal)
+            is_gate = name.startswith("gate")            # AdditiveAttentionGate convolutions: soft-orthonormal with the flag, else l2(1e-4)
+            soft = leaf in ("key", "query", "value", "out") or (leaf in ("pw1", "pw2") and self.soft_orthonormal) or \
+                (is_gate and kind == "conv" and self.soft_orthonormal)
             if kind == "multiplier":
                 _call("bf_op_reg_elementwise", N.ptr(w), N.ptr(gslice), n, N.BF_REG_L1, MULTIPLIER_L1, reg, N.ptr(total[1:2]), N.stream_ptr(w))
             elif soft:
                 _call("bf_op_reg_soft_orthonormal", N.ptr(w), N.ptr(gslice), shape[2], shape[3], SOFTORTHONORMAL[0], SOFTORTHONORMAL[1],
                       SOFTORTHONORMAL[2], reg, N.ptr(total[1:2]), N.ptr(sob), N.stream_ptr(w))
             else:
-                _call("bf_op_reg_elementwise", N.ptr(w), N.ptr(gslice), n, N.BF_REG_L2, KERNEL_L2, reg, N.ptr(total[1:2]), N.stream_ptr(w))
+                _call("bf_op_reg_elementwise", N.ptr(w), N.ptr(gslice), n, N.BF_REG_L2, GATE_L2 if is_gate else KERNEL_L2, reg,
+                      N.ptr(total[1:2]), N.stream_ptr(w))
         for buf, off, n in self._unaligned:                            # staged gradients of tensors at unaligned offsets (a copy)
             grads[off:off + n].copy_(buf)
         _call("bf_op_axpy", N.ptr(total[2:3]), N.ptr(total[1:2]), reg, 0, 1, N.stream_ptr(total))

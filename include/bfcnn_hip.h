@@ -423,6 +423,10 @@ int bf_op_dense2(const float* in, const float* w0, const float* b0, const float*
 int bf_op_selector_mix(const float* x1, const float* x2, const float* u, float* out, int64_t n, int soft, void* stream);
 int bf_op_avgpool_same(const float* in, float* out, int batch, int height, int width, int channels, int pool_h, int pool_w,
                        int stride_h, int stride_w, void* stream);
+/* the last stage of AdditiveAttentionGate (bfcnn/custom_layers.py:826-832) with the Add behind it, for training:
+   out = enc * sigmoid(4 o) [+ up]; backward: denc = dy * s, do = dy * enc * 4 s (1 - s) */
+int bf_op_sigmoid_gate(const float* enc, const float* o, const float* up, float* out, int64_t n, void* stream);
+int bf_op_sigmoid_gate_bwd(const float* enc, const float* o, const float* dy, float* denc, float* dout_o, int64_t n, void* stream);
 /* the normalise / denormalise layers on their own (bfcnn/model.py:364-430; inside the hydras they are fused into the first
    convolution and the head): inverse 0: (clip(x, v_min, v_max) - v_min) / (v_max - v_min) - 0.5; 1: (clip(x, -.5, .5) + .5) * range + v_min */
 int bf_op_normalize(const float* x, float* out, int64_t n, float v_min, float v_max, int inverse, void* stream);

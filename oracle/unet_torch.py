@@ -103,7 +103,6 @@ def check_trainable_graph(spec: U.UnetLaplacianSpec):
     """the graph family the training path is built for (configs/unet_laplacian_v5.json and its depth / width / filter
     variations)."""
     bad = []
-    if spec.use_attention_gates: bad.append("use_attention_gates")
     if spec.use_mix_project: bad.append("use_mix_project")
     if spec.downsample_type not in ("strides", "conv2d"): bad.append(f"downsample_type {spec.downsample_type}")
     if spec.upsample_type not in ("upsample_laplacian_conv2d", "upsample_nearest_conv2d", "upsample_bilinear_conv2d"):
@@ -173,7 +172,14 @@ def backbone(spec, P, xn, depth_scale=None, attn_scale=None):
     for d in reversed(range(spec.depth - 1)):
         low = outs[d + 1]
         up = _act(_conv(_up2_nearest(low) if spec.upsample_type == "upsample_nearest_conv2d" else _up2(low), P[f"up{d}/kernel"]), a)
-        x = nodes[d] + up
+        enc = nodes[d]
+        if spec.use_attention_gates:                                  # AdditiveAttentionGate.call (custom_layers.py:805-832)
+            yg = _conv(_layer_norm(enc, P[f"gate{d}/y_ln/gamma"]) if spec.use_ln else enc, P[f"gate{d}/y/kernel"])
+            xg = _conv(_layer_norm(up, P[f"gate{d}/x_ln/gamma"]) if spec.use_ln else up, P[f"gate{d}/x/kernel"])
+            z = xg + yg
+            o = _multiplier(_conv(torch.where(z > 0, z, 0.1 * z), P[f"gate{d}/o/kernel"]), P[f"gate{d}/scale/w"])
+            enc = enc * torch.sigmoid(4.0 * o)
+        x = enc + up
         for w in range(spec.width):
             pre = f"dec{d}_{w}"
             x = x + branch(pre, convnext(pre, x))
@@ -244,6 +250,8 @@ def regularizer_kind(spec: U.UnetLaplacianSpec, name: str, kind: str, soft_ortho
     if kind == "depthwise":
         return "l2"
     leaf = name.split("/")[1]
+    if name.startswith("gate"):                # AdditiveAttentionGate convolutions (custom_layers.py:726-740)
+        return "soft_orthonormal" if soft_orthonormal_convnext else "l2_1e-4"
     if leaf in ("pw1", "pw2"):
         return "soft_orthonormal" if soft_orthonormal_convnext else "l2"
     if leaf in ("key", "query", "value", "out"):
@@ -257,6 +265,8 @@ def regularization(spec, P, soft_orthonormal_convnext=True):
         rk = regularizer_kind(spec, name, kind, soft_orthonormal_convnext)
         if rk == "l2":
             total = total + 0.01 * (P[name] ** 2).sum()
+        elif rk == "l2_1e-4":
+            total = total + 1e-4 * (P[name] ** 2).sum()
         elif rk == "l1_1e-6":
             total = total + 1e-6 * P[name].abs().sum()
         elif rk == "soft_orthonormal":

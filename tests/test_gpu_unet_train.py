@@ -215,6 +215,17 @@ def test_train_step_of_the_v6_graph_family(backbone):
     _check_step(spec, params, model, clean, noisy, LOSS_V5, [1.0, 0.6, 0.3])
 
 
+@pytest.mark.parametrize("depth,backbone", [(3, {"use_attention_gates": True}),
+                                            (3, {"use_attention_gates": True, "upsample_type": "upsample_nearest_conv2d"}),
+                                            (4, {"use_attention_gates": True})],
+                         ids=["gates", "v3-options", "v4-depth-4"])
+def test_train_step_with_attention_gates(depth, backbone):
+    """configs/unet_laplacian_v3.json / v4.json: AdditiveAttentionGate in front of every decoder Add (custom_layers.py:805-832),
+    four levels (32 / 64 / 128 / 256 channels, self-attention on the 256-channel level)"""
+    cfg, spec, params, model, clean, noisy = _setup(depth, 1, 32, 64 if depth == 4 else 32, backbone=backbone)
+    _check_step(spec, params, model, clean, noisy, LOSS_V5, [1.0, 0.6, 0.3, 0.1][:depth])
+
+
 def test_train_step_with_stochastic_depth_and_attention_dropout():
     """training-mode randomness as explicit inputs: per-sample StochasticDepth scales (0 or 1 / (1 - rate)) and the attention's
     dropout keep-mask / keep-probability"""

@@ -57,13 +57,15 @@ def test_soft_orthonormal_matches_its_definition():
     assert abs(float(T.soft_orthonormal(torch.from_numpy(w))) - want) < 1e-10 * want
 
 
-def test_forward_of_the_v6_graph_family_equals_the_numpy_restatement():
-    """configs/unet_laplacian_v6.json's options (2 x 2 averaging, conv2d down-sampling, nearest + 3 x 3 up-sampling, 5 x 5 decoder
-    depthwise) in the torch gradient oracle against unet_oracle.py"""
+@pytest.mark.parametrize("options", [{"decoder_kernel_size": 5, "downsample_type": "conv2d", "gaussian_kernel_size": 2,
+                                      "upsample_type": "upsample_nearest_conv2d", "use_laplacian_averaging": True},
+                                     {"use_attention_gates": True, "upsample_type": "upsample_nearest_conv2d"}], ids=["v6", "v3"])
+def test_forward_of_the_other_shipped_graphs_equals_the_numpy_restatement(options):
+    """the options of configs/unet_laplacian_v6.json (2 x 2 averaging, conv2d down-sampling, nearest + 3 x 3 up-sampling, 5 x 5
+    decoder depthwise) and v3 / v4 (AdditiveAttentionGate) in the torch gradient oracle against unet_oracle.py"""
     import torch
     cfg = U.canonical_config(depth=3, width=1, filters=32)
-    cfg["model"]["backbone"].update({"decoder_kernel_size": 5, "downsample_type": "conv2d", "gaussian_kernel_size": 2,
-                                     "upsample_type": "upsample_nearest_conv2d", "use_laplacian_averaging": True})
+    cfg["model"]["backbone"].update(options)
     spec = U.UnetLaplacianSpec.from_config(cfg["model"])
     params = U.init_params(spec, seed=2)
     x = np.random.default_rng(0).uniform(0, 255, (2, 32, 32, 3))
