@@ -128,6 +128,8 @@ SIGNATURES = {
     "bf_op_dense2": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, _F, _I, _P]),
     "bf_op_selector_mix": (_I, [_P, _P, _P, _P, _I64, _I, _P]),
     "bf_op_avgpool_same": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "bf_op_concat_channels": (_I, [_P, _P, _P, _P, _I64, _I, _I, _I, _P]),
+    "bf_op_channel_mean_broadcast": (_I, [_P, _P, _I, _I64, _I, _I64, _P, _I64, _P]),
     "bf_op_sigmoid_gate": (_I, [_P, _P, _P, _P, _I64, _P]),
     "bf_op_sigmoid_gate_bwd": (_I, [_P, _P, _P, _P, _P, _I64, _P]),
     "bf_op_normalize": (_I, [_P, _P, _I64, _F, _F, _I, _P]),

@@ -503,3 +503,51 @@ extern "C" int bf_op_sigmoid_gate_bwd(const float* enc, const float* o, const fl
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
 
+// out[r][0:Ca | Ca:Ca+Cb | ...] = a[r] | b[r] | c[r]  (keras Concatenate on the channel axis; b, c may be NULL with Cb = Cc = 0)
+__global__ __launch_bounds__(256) void tg_concat_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                        float* __restrict__ out, int64_t rows, int Ca, int Cb, int Cc)
+{
+    const int Ct = Ca + Cb + Cc;
+    const int64_t n = rows * Ct;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / Ct;
+        const int k = (int)(i % Ct);
+        out[i] = k < Ca ? a[r * Ca + k] : (k < Ca + Cb ? b[r * Cb + k - Ca] : c[r * Cc + k - Ca - Cb]);
+    }
+}
+
+// mean[b][c] = mean over the hw positions of x[b][.][c] (tf.reduce_mean(x, axis=[1, 2])), broadcast to out[b][rows_out][c]
+__global__ __launch_bounds__(256) void tg_mean_bcast_kernel(const double* __restrict__ partial, int nblk, double hw, int C, float* __restrict__ out,
+                                                            int64_t rows_out)
+{
+    __shared__ float m[256];
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (t < C) {
+        double s = 0.0;
+        for (int k = 0; k < nblk; ++k) s += partial[((int64_t)b * nblk + k) * 2 * C + t];
+        m[t] = (float)(s / hw);
+    }
+    __syncthreads();
+    for (int64_t i = t; i < rows_out * C; i += 256) out[(int64_t)b * rows_out * C + i] = m[i % C];
+}
+
+extern "C" int bf_op_concat_channels(const float* a, const float* b, const float* c, float* out, int64_t rows, int Ca, int Cb, int Cc, void* stream)
+{
+    if (!a || !out || rows <= 0 || Ca <= 0 || Cb < 0 || Cc < 0 || (Cb > 0 && !b) || (Cc > 0 && !c)) return BF_EINVAL;
+    hipLaunchKernelGGL(tg_concat_kernel, dim3(tg_grid(rows * (Ca + Cb + Cc))), dim3(256), 0, (hipStream_t)stream, a, b, c, out, rows, Ca, Cb, Cc);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+extern "C" int bf_op_channel_mean_broadcast(const float* x, float* out, int B, int64_t hw, int C, int64_t rows_out, float* scratch,
+                                            int64_t scratch_floats, void* stream)
+{
+    if (!x || !out || !scratch || B <= 0 || hw <= 0 || rows_out <= 0) return BF_EINVAL;
+    if (!tg_ok_c(C)) return BF_EUNSUPPORTED;
+    if (scratch_floats < bf_op_gate_scratch_floats(B, C) || (uintptr_t)scratch % 8) return BF_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    double* partial = reinterpret_cast<double*>(scratch);
+    hipLaunchKernelGGL(tg_colsum2_kernel, dim3(CS_GRID, B), dim3(256), 0, s, x, x, hw, C, partial);
+    hipLaunchKernelGGL(tg_mean_bcast_kernel, dim3(B), dim3(256), 0, s, partial, CS_GRID, (double)hw, C, out, rows_out);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+

@@ -56,7 +56,7 @@ SELECTOR_GLOBAL_LEAKY = 0.2      # Dense(activation="leaky_relu"): unresolvable 
 
 def selector_block(x1: torch.Tensor, x2: torch.Tensor, sel: torch.Tensor, w0: torch.Tensor, w1: torch.Tensor, scale_type: str = "local",
                    activation_type: str = "hard", pool=(32, 32), stride=(8, 8), compress: Optional[int] = None) -> torch.Tensor:
-    """selector_block (bfcnn/custom_layers_selector.py:81-330), scale types LOCAL and GLOBAL: x1 * s + x2 * (1 - s) with
+    """selector_block (bfcnn/custom_layers_selector.py:81-330), all four scale types: x1 * s + x2 * (1 - s) with
     s = hard_sigmoid | sigmoid (2.5 - u), u >= 0 computed from the selector layer."""
     soft = activation_type == "soft"
     if scale_type == "global":
@@ -66,9 +66,26 @@ def selector_block(x1: torch.Tensor, x2: torch.Tensor, sel: torch.Tensor, w0: to
         raise ValueError(f"selector_block LOCAL: the image ({H}x{W}) must be a multiple of the strides {stride} (UpSampling2D restores it)")
     L = N.lib()
     OH, OW = H // stride[0], W // stride[1]
-    pooled = torch.empty((B, OH, OW, Cs), dtype=torch.float32, device=sel.device)
-    N.check(L.bf_op_avgpool_same(N.ptr(sel), N.ptr(pooled), B, H, W, Cs, pool[0], pool[1], stride[0], stride[1], N.stream_ptr(sel)), None,
-            "bf_op_avgpool_same")
+
+    def pool_map(ph, pw):
+        out_ = torch.empty((B, OH, OW, Cs), dtype=torch.float32, device=sel.device)
+        N.check(L.bf_op_avgpool_same(N.ptr(sel), N.ptr(out_), B, H, W, Cs, ph, pw, stride[0], stride[1], N.stream_ptr(sel)), None,
+                "bf_op_avgpool_same")
+        return out_
+    pooled = pool_map(pool[0], pool[1])
+    if scale_type in ("multiscale", "mixed"):
+        if scale_type == "multiscale":          # pool / 2 | pool | 2 pool, same strides (custom_layers_selector.py:203-232)
+            parts = [pool_map(pool[0] // 2, pool[1] // 2), pooled, pool_map(pool[0] * 2, pool[1] * 2)]
+        else:                                   # local means | the global mean on the same grid (:284-299)
+            glob = torch.empty_like(pooled)
+            scratch = torch.empty(int(L.bf_op_gate_scratch_floats(B, Cs)) + 2, dtype=torch.float32, device=sel.device)
+            N.check(L.bf_op_channel_mean_broadcast(N.ptr(sel), N.ptr(glob), B, H * W, Cs, OH * OW, N.ptr(scratch), scratch.numel(),
+                                                   N.stream_ptr(sel)), None, "bf_op_channel_mean_broadcast")
+            parts = [pooled, glob]
+        cat = torch.empty((B, OH, OW, Cs * len(parts)), dtype=torch.float32, device=sel.device)
+        N.check(L.bf_op_concat_channels(N.ptr(parts[0]), N.ptr(parts[1]), N.ptr(parts[2]) if len(parts) > 2 else None, N.ptr(cat),
+                                        B * OH * OW, Cs, Cs, Cs if len(parts) > 2 else 0, N.stream_ptr(sel)), None, "bf_op_concat_channels")
+        pooled, Cs = cat, Cs * len(parts)
     Ct = x1.shape[-1]
     u = torch.empty((B, OH, OW, Ct), dtype=torch.float32, device=sel.device)
     N.check(L.bf_op_dense2(N.ptr(pooled), N.ptr(w0), None, N.ptr(w1), None, N.ptr(u), B * OH * OW, Cs, Ct, int(w0.shape[1]), 2, 0.3, 4,
@@ -106,8 +123,8 @@ class GenericResnetHydra:
                 if sp.get(key, False):
                     raise NotImplementedError(f"selector_block: {key} is outside the built graph")
             st, at = str(sp.get("scale_type", "local")).strip().lower(), str(sp.get("activation_type", "hard")).strip().lower()
-            if st not in ("local", "global"):
-                raise NotImplementedError(f"selector_block: scale_type {st} (local and global are built)")
+            if st not in ("local", "global", "mixed", "multiscale"):
+                raise KeyError(st.upper())                                          # ScaleType[...] (custom_layers_selector.py:45)
             if at not in ("hard", "soft"):
                 raise KeyError(at.upper())
             pool = tuple(int(v) for v in sp.get("pool_size", (32, 32)))
@@ -196,7 +213,8 @@ class GenericResnetHydra:
             if self.selector:
                 cs = self.block_filters[0] if self.block_depthwise[0] == -1 else self.filters * self.block_depthwise[0]
                 cc = self.selector["compress"]
-                if self.selector["scale_type"] == "local":
+                if self.selector["scale_type"] != "global":
+                    cs *= {"local": 1, "mixed": 2, "multiscale": 3}[self.selector["scale_type"]]
                     out.append((f"block{i}/selector/conv0/kernel", (1, 1, cs, cc), "conv"))
                     out.append((f"block{i}/selector/conv1/kernel", (1, 1, cc, self.filters), "conv"))
                 else:
@@ -291,7 +309,7 @@ class GenericResnetHydra:
                     P[f"b{i}gate"] = (dev(W[f"block{i}/gate/dense0/kernel"]), dev(W[f"block{i}/gate/dense1/kernel"]))
                 cin = cout
             if self.selector:
-                kind = "conv" if self.selector["scale_type"] == "local" else "dense"
+                kind = "dense" if self.selector["scale_type"] == "global" else "conv"
                 w0, w1 = W[f"block{i}/selector/{kind}0/kernel"], W[f"block{i}/selector/{kind}1/kernel"]
                 P[f"b{i}sel"] = (dev(w0.reshape(w0.shape[-2], w0.shape[-1])), dev(w1.reshape(w1.shape[-2], w1.shape[-1])))
         P["head0"] = UL.pack_pointwise(dev(W["head/conv0/kernel"][0, 0]))

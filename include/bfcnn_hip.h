@@ -423,6 +423,12 @@ int bf_op_dense2(const float* in, const float* w0, const float* b0, const float*
 int bf_op_selector_mix(const float* x1, const float* x2, const float* u, float* out, int64_t n, int soft, void* stream);
 int bf_op_avgpool_same(const float* in, float* out, int batch, int height, int width, int channels, int pool_h, int pool_w,
                        int stride_h, int stride_w, void* stream);
+/* selector_block's MIXED / MULTISCALE inputs (custom_layers_selector.py:203-262): keras Concatenate on the channel axis of up to
+   three [rows][C*] tensors; the per-sample channel mean of x [B][hw][C] broadcast to out [B][rows_out][C]
+   (tf.reduce_mean(x, axis=[1, 2], keepdims=True) added to a zeroed pooled map); scratch: bf_op_gate_scratch_floats(B, C) */
+int bf_op_concat_channels(const float* a, const float* b, const float* c, float* out, int64_t rows, int ca, int cb, int cc, void* stream);
+int bf_op_channel_mean_broadcast(const float* x, float* out, int batch, int64_t hw, int channels, int64_t rows_out, float* scratch,
+                                 int64_t scratch_floats, void* stream);
 /* the last stage of AdditiveAttentionGate (bfcnn/custom_layers.py:826-832) with the Add behind it, for training:
    out = enc * sigmoid(4 o) [+ up]; backward: denc = dy * s, do = dy * enc * 4 s (1 - s) */
 int bf_op_sigmoid_gate(const float* enc, const float* o, const float* up, float* out, int64_t n, void* stream);

@@ -93,18 +93,27 @@ SELECTOR_GLOBAL_LEAKY = 0.2      # Dense(activation="leaky_relu") does not resol
 
 
 def selector_block(x1, x2, sel, w0, w1, scale_type="local", activation_type="hard", pool_size=(32, 32), strides_size=None):
-    """custom_layers_selector.py:81-330, scale types LOCAL (the default) and GLOBAL, no optional pre-filters:
+    """custom_layers_selector.py:81-330, scale types LOCAL (the default), MULTISCALE, MIXED and GLOBAL, no optional pre-filters:
     LOCAL: AveragePooling2D(pool, strides = pool / 4, same) -> 1x1 conv leaky_relu (0.3, activation_wrapper) -> 1x1 conv relu ->
     UpSampling2D(strides, bilinear); GLOBAL: mean -> Dense leaky_relu -> Dense relu; then s = F(2.5 - x), x1 s + x2 (1 - s)."""
     from . import unet_oracle as U
     strides_size = strides_size or (pool_size[0] // 4, pool_size[1] // 4)
-    if scale_type.lower() == "local":
-        u = avgpool_same(sel, pool_size, strides_size)
+    st = scale_type.lower()
+    if st in ("local", "multiscale", "mixed"):
+        if st == "local":
+            u = avgpool_same(sel, pool_size, strides_size)
+        elif st == "multiscale":                               # three window sizes side by side (:203-232)
+            u = np.concatenate([avgpool_same(sel, (pool_size[0] // 2, pool_size[1] // 2), strides_size),
+                                avgpool_same(sel, pool_size, strides_size),
+                                avgpool_same(sel, (pool_size[0] * 2, pool_size[1] * 2), strides_size)], axis=-1)
+        else:                                                  # local means next to the image's global mean (:284-299)
+            loc = avgpool_same(sel, pool_size, strides_size)
+            u = np.concatenate([loc, np.zeros_like(loc) + sel.mean(axis=(1, 2), keepdims=True)], axis=-1)
         u = u @ w0.reshape(w0.shape[-2], w0.shape[-1])
         u = np.where(u > 0, u, 0.3 * u)
         u = np.maximum(u @ w1.reshape(w1.shape[-2], w1.shape[-1]), 0.0)
         u = U.resize_bilinear(u, u.shape[1] * strides_size[0], u.shape[2] * strides_size[1])
-    elif scale_type.lower() == "global":
+    elif st == "global":
         u = sel.mean(axis=(1, 2)) @ w0
         u = np.where(u > 0, u, SELECTOR_GLOBAL_LEAKY * u)
         u = np.maximum(u @ w1, 0.0)[:, None, None, :]
@@ -200,7 +209,8 @@ class GenericResnetSpec:
                 cin = cout
             if self.selector:                                      # the selector's two layers close the block (backbone_blocks.py:227-239)
                 cs, cc = self.block_filters[0] if self.block_depthwise[0] == -1 else self.filters * self.block_depthwise[0], self.selector[2]
-                if self.selector[0] == "local":
+                if self.selector[0] != "global":
+                    cs *= {"local": 1, "mixed": 2, "multiscale": 3}[self.selector[0]]
                     out.append((f"block{i}/selector/conv0/kernel", (1, 1, cs, cc), "conv"))
                     out.append((f"block{i}/selector/conv1/kernel", (1, 1, cc, self.filters), "conv"))
                 else:
@@ -263,7 +273,7 @@ def hydra_forward(spec: GenericResnetSpec, params: np.ndarray, state: np.ndarray
             if j == 1 and spec.add_gates:
                 t = gate(t, P[f"block{i}/gate/dense0/kernel"], P[f"block{i}/gate/dense1/kernel"])
         if spec.selector:
-            kind = "conv" if spec.selector[0] == "local" else "dense"
+            kind = "dense" if spec.selector[0] == "global" else "conv"
             f = selector_block(f, t, first, P[f"block{i}/selector/{kind}0/kernel"], P[f"block{i}/selector/{kind}1/kernel"],
                                spec.selector[0], spec.selector[1], spec.selector[3], spec.selector[4])
         else:

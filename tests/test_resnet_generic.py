@@ -115,8 +115,9 @@ def test_oracle_avgpool_and_squeeze_excite_match_torch():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("sp", [dict(scale_type="local", pool_size=(16, 16)), dict(scale_type="local", activation_type="soft", pool_size=(8, 8), strides_size=(4, 4)),
-                                dict(scale_type="global"), dict(scale_type="global", activation_type="soft", filters_compress_ratio=0.5)],
-                         ids=["local-hard", "local-soft", "global-hard", "global-soft"])
+                                dict(scale_type="global"), dict(scale_type="global", activation_type="soft", filters_compress_ratio=0.5),
+                                dict(scale_type="multiscale", pool_size=(8, 8)), dict(scale_type="mixed", pool_size=(16, 16), activation_type="soft")],
+                         ids=["local-hard", "local-soft", "global-hard", "global-soft", "multiscale", "mixed"])
 def test_selector_block_matches_oracle(sp):
     """selector_params: selector_block (custom_layers_selector.py:81-330) mixes the block's input and output in place of the Add"""
     cfg = G.shipped_config()
