@@ -138,7 +138,7 @@ def _build_multi_output_train_functions(model, denoiser_loss_fn, seed: int = 0) 
         """bfcnn/train_loop.py:253-257: the first (full-resolution) output"""
         return model(n, training=False)[0]
 
-    def _randomness(B):
+    def _randomness(B, H=0, W=0):
         ds, at = {}, {}
         if not train_step_single_gpu.randomness:
             return ds, at
@@ -150,8 +150,11 @@ def _build_multi_output_train_functions(model, denoiser_loss_fn, seed: int = 0) 
                 keep = (rng.uniform(size=B) >= rate).astype(np.float32) / np.float32(1.0 - rate)
                 ds[prefix] = torch.from_numpy(keep).to(model.device)
             if attn_drop > 0.0 and prefix.startswith(f"enc{model.depth - 1}_") and model._is_attention(model.depth - 1):
-                T = model.attention_resolution[0] * model.attention_resolution[1]
-                keep = (rng.uniform(size=(B, T, T)) >= attn_drop).astype(np.float32) / np.float32(1.0 - attn_drop)
+                if model.attention_rows:          # one sequence per image row of the deepest level
+                    NB, T = B * (H >> (model.depth - 1)), W >> (model.depth - 1)
+                else:
+                    NB, T = B, model.attention_resolution[0] * model.attention_resolution[1]
+                keep = (rng.uniform(size=(NB, T, T)) >= attn_drop).astype(np.float32) / np.float32(1.0 - attn_drop)
                 at[prefix] = torch.from_numpy(keep).to(model.device)
         return ds, at
 
@@ -163,7 +166,7 @@ def _build_multi_output_train_functions(model, denoiser_loss_fn, seed: int = 0) 
         dw = [1.0] * model.depth if p_depth_weight is None else [float(v) for v in p_depth_weight]
         if len(dw) < model.depth:
             raise ValueError(f"{model.depth} output scales need {model.depth} depth weights, got {len(dw)}")
-        ds, at = _randomness(int(p_noisy_image_batch.shape[0]))
+        ds, at = _randomness(*(int(v) for v in p_noisy_image_batch.shape[:3]))
         preds, scale_losses, totals = graph.step(p_input_image_batch, p_noisy_image_batch, dw, grads, ds, at)
         model_loss = {REGULARIZATION_LOSS_STR: totals[1], TOTAL_LOSS_STR: totals[2]}
         all_denoiser_loss = [{TOTAL_LOSS_STR: sl[N.BF_LOSS_DENOISER_TOTAL], MSE_LOSS_STR: sl[N.BF_LOSS_MSE], MAE_LOSS_STR: sl[N.BF_LOSS_MAE],

@@ -10,7 +10,10 @@ Scope: the graph family of configs/unet_laplacian_v5.json and v6.json -- ConvNex
 LayerNorm, query / key / value, dot-product attention with dropout, resize back, output convolution, multiplier), level
 LayerNorm + activation, the averaging / Gaussian Laplacian split, strided down-sampling + 1x1 or 2x2 stride-2 convolution, `upsample_laplacian_conv2d` / nearest or bilinear + 3x3 convolution,
 per-scale denoiser heads, AdditiveAttentionGate in front of the decoder Add (v3 / v4) -- with any depth / width / filters.
-Mix projections, the other resamplers and the trained archive's graph revision raise NotImplementedError (inference covers them).
+The graph revision of the reference's trained archive (tests/golden/unet_v56.npz: GELU in the MLP and on query / key / value,
+row-wise full-resolution attention with a second LayerNorm, no level activation, 1x1-then-resize up-sampling, the output
+LayerNorms in front of the heads) trains as well, so the shipped network can be fine-tuned.  Mix projections and the other
+resamplers raise NotImplementedError (inference covers them).
 
 Exact fp32 throughout (the split-f16 inference operators are not used here): gradients are compared with the torch-autograd
 oracle (oracle/unet_torch.py) in tests/test_gpu_unet_train.py.
@@ -45,12 +48,18 @@ class _Ops:
     def _s(self):
         return N.ptr(self.scratch), self.scratch.numel()
 
-    def act_bwd(self, out, dy, act):
+    def act_bwd(self, out, dy, act, pre=None):
+        """dy * act'(.): from the activation's OUTPUT for the sign-preserving ones, from its input `pre` for GELU"""
         code, a = UL._act(act)
         if code == 0:
             return dy
         dx = torch.empty_like(dy)
-        _call("bf_op_act_bwd", N.ptr(out), N.ptr(dy), N.ptr(dx), dy.numel(), code, a, 1, N.stream_ptr(dy))
+        if code == 3:
+            if pre is None:
+                raise ValueError("the GELU derivative needs the pre-activation")
+            _call("bf_op_act_bwd", N.ptr(pre), N.ptr(dy), N.ptr(dx), dy.numel(), code, a, 0, N.stream_ptr(dy))
+        else:
+            _call("bf_op_act_bwd", N.ptr(out), N.ptr(dy), N.ptr(dx), dy.numel(), code, a, 1, N.stream_ptr(dy))
         return dx
 
     def act_bwd_alpha(self, out, dy, alpha):
@@ -113,10 +122,7 @@ class UnetTrainGraph:
         if model.downsample_type not in ("strides", "conv2d"): bad.append(f"downsample_type {model.downsample_type}")
         if model.upsample_type not in ("upsample_laplacian_conv2d", "upsample_nearest_conv2d", "upsample_bilinear_conv2d"):
             bad.append(f"upsample_type {model.upsample_type}")
-        if getattr(model, "attention_full", False) or getattr(model, "output_norm_at_heads", False) or \
-                getattr(model, "upsample_linear", False) or not getattr(model, "level_activation", True):
-            bad.append("the trained archive's graph revision")
-        if (getattr(model, "mlp_activation", None) or model.activation) == "gelu": bad.append("gelu")
+        if model.activation == "gelu": bad.append("gelu outside the convnext MLP / the attention projections")
         if model.activation == "linear": bad.append("linear activation")
         if bad:
             raise NotImplementedError("unet_laplacian training is built for the configs/unet_laplacian_v5.json graph family: " + ", ".join(bad))
@@ -172,6 +178,16 @@ class UnetTrainGraph:
         def pack(w2d):
             return UL.pack_pointwise(w2d.contiguous())
 
+        def pointwise_act(x_, wp, cout, act, alpha=None):
+            """(act(x W), what its derivative is taken from): the fused epilogue for the sign-preserving activations, the
+            product kept and the activation as its own pass for GELU"""
+            if UL._act(act)[0] == 3:
+                pre_ = UL.pointwise(x_, wp, cout)
+                y_ = UL.dwconv_ln(pre_.view(1, 1, -1, 32), None, None, act).view(pre_.shape)
+                return y_, pre_
+            y_ = UL.pointwise(x_, wp, cout, act) if alpha is None else UL.pointwise(x_, wp, cout, act, alpha=alpha)
+            return y_, None
+
         # -- blocks -------------------------------------------------------------------------------------------------------
         def convnext(prefix, x, k):
             Cc = x.shape[-1]
@@ -187,7 +203,8 @@ class UnetTrainGraph:
             chunks = range(Hh // Hc)
             w1c = [w1 if Hc == Hh else w1[:, j * Hc:(j + 1) * Hc].contiguous() for j in chunks]
             w2c = [w2[j * Hc:(j + 1) * Hc] for j in chunks]
-            t3 = [UL.pointwise(t2, pack(w1c[j]), Hc, a) for j in chunks]
+            am = m.mlp_activation
+            t3, t3pre = zip(*[pointwise_act(t2, pack(w1c[j]), Hc, am) for j in chunks])
             t4 = None
             for j in chunks:
                 t4 = UL.pointwise(t3[j], pack(w2c[j]), Cc, res=t4)
@@ -205,7 +222,7 @@ class UnetTrainGraph:
                 dt2 = None
                 for j in chunks:
                     ops.matmul_wgrad(t3[j], dt4, gw2[j * Hc:(j + 1) * Hc])
-                    dt3 = ops.act_bwd(t3[j], UL.pointwise(dt4, pack(ops.transpose(w2c[j].contiguous())), Hc), a)
+                    dt3 = ops.act_bwd(t3[j], UL.pointwise(dt4, pack(ops.transpose(w2c[j].contiguous())), Hc), am, t3pre[j])
                     if Hc == Hh:
                         ops.matmul_wgrad(t2, dt3, gw1)
                     else:                                          # a column block of the kernel gradient: staged, then copied in
@@ -223,19 +240,29 @@ class UnetTrainGraph:
         def attention(prefix, x):
             Bc, Hc, Wc, Cc = x.shape
             A = m.filters
-            rh, rw = m.attention_resolution
-            T = rh * rw
-            r = UL.resize_bilinear(x, rh, rw)
+            rows = m.attention_rows                  # the trained archive's graph: no resize, one sequence per image row
+            rh, rw = (Hc, Wc) if rows else m.attention_resolution
+            NB, T = (Bc * rh, rw) if rows else (Bc, rh * rw)
+            r = x if rows else UL.resize_bilinear(x, rh, rw)
             gamma = self.W(f"{prefix}/ln/gamma") if m.use_ln else None
             n_ = UL.dwconv_ln(r, None, gamma) if m.use_ln else r
-            alpha = m.attention_alpha
-            ws = {n: self.W(f"{prefix}/{n}/kernel").view(Cc, A) for n in ("query", "value", "key")}
-            q, v, k_ = (UL.pointwise(n_, pack(ws[n]), A, "leaky_relu", alpha=alpha).view(Bc, T, A) for n in ("query", "value", "key"))
+            qact, alpha = (m.attention_activation, None) if m.attention_activation else ("leaky_relu", m.attention_alpha)
+            # keras reads [query, value, key]; the archive's graph hands the key convolution over as the value and the value
+            # convolution as the key (unet_laplacian._attention)
+            order = ("query", "key", "value") if rows else ("query", "value", "key")
+            ws = {n: self.W(f"{prefix}/{n}/kernel").view(Cc, A) for n in order}
+            (q, qpre), (v, vpre), (k_, kpre) = (tuple(None if z is None else z.view(NB, T, A) for z in pointwise_act(n_, pack(ws[n]), A, qact, alpha))
+                                                for n in order)
             ps = attn_scale.get(prefix)
-            o = torch.empty((Bc, T, A), dtype=torch.float32, device=dev)
-            P = torch.empty((Bc, T, T), dtype=torch.float32, device=dev)
-            _call("bf_op_attention_train", N.ptr(q), N.ptr(v), N.ptr(k_), N.ptr(ps), N.ptr(o), N.ptr(P), Bc, T, A, N.stream_ptr(q))
-            u = UL.resize_bilinear(o.view(Bc, rh, rw, A), Hc, Wc)
+            o = torch.empty((NB, T, A), dtype=torch.float32, device=dev)
+            P = torch.empty((NB, T, T), dtype=torch.float32, device=dev)
+            _call("bf_op_attention_train", N.ptr(q), N.ptr(v), N.ptr(k_), N.ptr(ps), N.ptr(o), N.ptr(P), NB, T, A, N.stream_ptr(q))
+            o4 = o.view(Bc, rh, rw, A)
+            gamma1 = self.W(f"{prefix}/ln1/gamma") if (rows and m.use_ln) else None
+            if rows:
+                u = UL.dwconv_ln(o4, None, gamma1) if m.use_ln else o4
+            else:
+                u = UL.resize_bilinear(o4, Hc, Wc)
             wo = self.W(f"{prefix}/out/kernel").view(A, Cc)
             t = UL.pointwise(u, pack(wo), Cc)
             wm = self.W(f"{prefix}/gamma/w")
@@ -249,19 +276,24 @@ class UnetTrainGraph:
                 _call("bf_op_multiplier_bwd", N.ptr(wm), N.ptr(dm), N.ptr(self.G(f"{prefix}/gamma/w", grads)), Cc, N.stream_ptr(dm))
                 ops.matmul_wgrad(u, dt, self.G(f"{prefix}/out/kernel", grads))
                 du = UL.pointwise(dt, pack(ops.transpose(wo)), A)
-                do = torch.empty((Bc, rh, rw, A), dtype=torch.float32, device=dev)
-                _call("bf_op_resize_bilinear_bwd", N.ptr(du), N.ptr(do), Bc, rh, rw, A, Hc, Wc, N.ptr(ops.scratch), N.stream_ptr(du))
-                dq, dv, dk = (torch.empty((Bc, T, A), dtype=torch.float32, device=dev) for _ in range(3))
-                dS = torch.empty((Bc, T, T), dtype=torch.float32, device=dev)
+                if rows:
+                    do = ops.layernorm_bwd(o4, gamma1, du, self.G(f"{prefix}/ln1/gamma", grads)) if m.use_ln else du
+                else:
+                    do = torch.empty((Bc, rh, rw, A), dtype=torch.float32, device=dev)
+                    _call("bf_op_resize_bilinear_bwd", N.ptr(du), N.ptr(do), Bc, rh, rw, A, Hc, Wc, N.ptr(ops.scratch), N.stream_ptr(du))
+                dq, dv, dk = (torch.empty((NB, T, A), dtype=torch.float32, device=dev) for _ in range(3))
+                dS = torch.empty((NB, T, T), dtype=torch.float32, device=dev)
                 _call("bf_op_attention_bwd", N.ptr(q), N.ptr(v), N.ptr(k_), N.ptr(ps), N.ptr(P), N.ptr(do), N.ptr(dq), N.ptr(dv),
-                      N.ptr(dk), N.ptr(dS), Bc, T, A, N.stream_ptr(q))
+                      N.ptr(dk), N.ptr(dS), NB, T, A, N.stream_ptr(q))
                 dn = None
-                for name, y, dy in (("query", q, dq), ("value", v, dv), ("key", k_, dk)):
-                    dp = ops.act_bwd_alpha(y, dy, alpha).view(Bc, rh, rw, A)
+                for name, y, ypre, dy in zip(order, (q, v, k_), (qpre, vpre, kpre), (dq, dv, dk)):
+                    dp = (ops.act_bwd_alpha(y, dy, alpha) if alpha is not None else ops.act_bwd(y, dy, qact, ypre)).view(Bc, rh, rw, A)
                     ops.matmul_wgrad(n_, dp, self.G(f"{prefix}/{name}/kernel", grads))
                     part = UL.pointwise(dp, pack(ops.transpose(ws[name])), Cc)
                     dn = part if dn is None else ops.add(dn, part)
                 dr = ops.layernorm_bwd(r, gamma, dn, self.G(f"{prefix}/ln/gamma", grads)) if m.use_ln else dn
+                if rows:
+                    return ops.add(dout, dr)
                 dxb = torch.empty_like(x)
                 _call("bf_op_resize_bilinear_bwd", N.ptr(dr), N.ptr(dxb), Bc, Hc, Wc, Cc, rh, rw, N.ptr(ops.scratch), N.stream_ptr(dr))
                 return ops.add(dout, dxb)
@@ -390,13 +422,14 @@ class UnetTrainGraph:
                 pre = f"enc{d}_{w_}"
                 x, b_ = attention(pre, x) if m._is_attention(d) else convnext(pre, x, m.enc_k)
                 enc_chain.append(("op", b_))
-            if m.use_output_normalization and m.use_ln:
-                x, b_ = norm_act(f"enc{d}/out_ln/gamma", x, a)
+            la = a if m.level_activation else "linear"
+            if m.use_output_normalization and m.use_ln and not m.output_norm_at_heads:
+                x, b_ = norm_act(f"enc{d}/out_ln/gamma", x, la)
                 enc_chain.append(("op", b_))
-            else:
+            elif la != "linear":
                 y = x
-                x = UL.dwconv_ln(y, None, None, a)
-                enc_chain.append(("op", (lambda yy: (lambda dy: ops.act_bwd(yy, dy, a)))(x)))
+                x = UL.dwconv_ln(y, None, None, la)
+                enc_chain.append(("op", (lambda yy: (lambda dy: ops.act_bwd(yy, dy, la)))(x)))
             if d != m.depth - 1:
                 ds = 2 if m.downsample_type == "strides" else 1              # conv2d takes the full-resolution smooth map
                 lp, down = UL.smooth_split(x, k_g, gauss, ds)
@@ -417,21 +450,24 @@ class UnetTrainGraph:
             low = outs[d + 1]
             Cc = m.level_filters(d)
             bil = m.upsample_type != "upsample_nearest_conv2d"
-            u2 = upsample_2x(low, bilinear=bil)
-            if m.upsample_type == "upsample_laplacian_conv2d":
-                up, b_up = conv1x1_act(f"up{d}/kernel", u2, Cc, a)
+            conv_first = m.upsample_type == "upsample_laplacian_conv2d" and m.upsample_linear   # upsampling.py:80-90: 1x1, then resize
+            if conv_first:
+                c_, b_up = conv1x1_act(f"up{d}/kernel", low, Cc, "linear")
+                up = upsample_2x(c_, bilinear=True)
+            elif m.upsample_type == "upsample_laplacian_conv2d":
+                up, b_up = conv1x1_act(f"up{d}/kernel", upsample_2x(low, bilinear=bil), Cc, a)
             else:
-                up, b_up = conv3x3_act(f"up{d}/kernel", u2, Cc, a)
+                up, b_up = conv3x3_act(f"up{d}/kernel", upsample_2x(low, bilinear=bil), Cc, a)
             b_gate = None
             if m.use_attention_gates:
                 x, b_gate = attention_gate(d, lap[d], up)
             else:
                 x = ops.add(lap[d], up)
-            chain = [("up", b_up, low.shape, bil, b_gate)]
+            chain = [("up", b_up, low.shape, bil, b_gate, conv_first)]
             for w_ in range(m.width):
                 x, b_ = convnext(f"dec{d}_{w_}", x, m.dec_k)
                 chain.append(("op", b_))
-            if m.use_output_normalization and m.use_ln:
+            if m.use_output_normalization and m.use_ln and not m.output_norm_at_heads:
                 x, b_ = norm_act(f"dec{d}/out_ln/gamma", x, "linear")
                 chain.append(("op", b_))
             outs[d] = x
@@ -450,7 +486,9 @@ class UnetTrainGraph:
         preds, scale_losses, dfeat = [], [], {}
         total = torch.zeros(3, dtype=torch.float32, device=dev)       # [0] total loss, [1] regularisation value, [2] [1] * regularization
         for i in range(m.depth):
-            f = outs[i]
+            f, b_head_ln = outs[i], None
+            if m.use_output_normalization and m.use_ln and m.output_norm_at_heads:     # the archive's graph: only the heads read the
+                f, b_head_ln = norm_act(m._out_ln_name(i), f, "linear")                # normalised maps, the decoder the raw ones
             Bc, Hc, Wc, Cc = f.shape
             w0 = self.W(f"head{i}/conv0/kernel").view(Cc, m.head_filters)
             w1 = self.W(f"head{i}/conv1/kernel").view(m.head_filters, m.out_channels).contiguous()
@@ -472,6 +510,8 @@ class UnetTrainGraph:
             dh0p = ops.act_bwd(h0, dh0, m.head_activation)
             ops.matmul_wgrad(f, dh0p, self.G(f"head{i}/conv0/kernel", grads))
             dfeat[i] = UL.pointwise(dh0p, pack(ops.transpose(w0)), Cc)
+            if b_head_ln is not None:
+                dfeat[i] = b_head_ln(dfeat[i])
 
         # -- backward ---------------------------------------------------------------------------------------------------------
         # decoder levels top (d = 0) to bottom: each yields the gradient of the Laplacian skip and of the level below
@@ -482,11 +522,16 @@ class UnetTrainGraph:
             chain = dec_chain[d]
             for item in reversed(chain[1:]):
                 g = item[1](g)
-            _, b_up, low_shape, bil, b_gate = chain[0]
+            _, b_up, low_shape, bil, b_gate, conv_first = chain[0]
             if b_gate is not None:
                 dlap[d], g = b_gate(g)                                   # x = gate(lap[d], up) + up
             else:
                 dlap[d] = g                                             # x = lap[d] + up
+            if conv_first:                                              # up = resize(conv(low))
+                dc = torch.empty(tuple(low_shape[:3]) + (g.shape[-1],), dtype=torch.float32, device=dev)
+                _call("bf_op_upsample2x_bwd", N.ptr(g), N.ptr(dc), low_shape[0], low_shape[1], low_shape[2], g.shape[-1], 1, N.stream_ptr(g))
+                dlow[d + 1] = b_up(dc)
+                continue
             du2 = b_up(g)
             dl = torch.empty(low_shape, dtype=torch.float32, device=dev)
             _call("bf_op_upsample2x_bwd", N.ptr(du2), N.ptr(dl), low_shape[0], low_shape[1], low_shape[2], low_shape[3], int(bil),

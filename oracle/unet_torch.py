@@ -107,8 +107,6 @@ def check_trainable_graph(spec: U.UnetLaplacianSpec):
     if spec.downsample_type not in ("strides", "conv2d"): bad.append(f"downsample_type {spec.downsample_type}")
     if spec.upsample_type not in ("upsample_laplacian_conv2d", "upsample_nearest_conv2d", "upsample_bilinear_conv2d"):
         bad.append(f"upsample_type {spec.upsample_type}")
-    if spec.attention_full or spec.output_norm_at_heads or spec.upsample_linear or not spec.level_activation: bad.append("archive graph revision")
-    if (spec.mlp_activation or spec.activation) == "gelu": bad.append("gelu")
     if not (spec.use_laplacian or spec.use_laplacian_averaging): bad.append("no laplacian split")
     if bad:
         raise NotImplementedError("unet_laplacian training: " + ", ".join(bad))
@@ -130,16 +128,26 @@ def backbone(spec, P, xn, depth_scale=None, attn_scale=None):
 
     def attention(prefix, x):
         B, H, W, C = x.shape
-        rh, rw = spec.attention_resolution
-        t = _resize(x, rh, rw)
+        rh, rw = (H, W) if spec.attention_full else spec.attention_resolution
+        t = x if spec.attention_full else _resize(x, rh, rw)
         if spec.use_ln:
             t = _layer_norm(t, P[f"{prefix}/ln/gamma"])
-        qkv = lambda n: torch.where((z := _conv(t, P[f"{prefix}/{n}/kernel"])) > 0, z, spec.attention_alpha * z).reshape(B, rh * rw, -1)
-        q, v, k = qkv("query"), qkv("value"), qkv("key")
+        seq = (B * rh, rw) if spec.attention_full else (B, rh * rw)   # the archive's graph: one sequence per image row
+        def qkv(n):
+            z = _conv(t, P[f"{prefix}/{n}/kernel"])
+            z = _act(z, spec.attention_activation) if spec.attention_activation else torch.where(z > 0, z, spec.attention_alpha * z)
+            return z.reshape(*seq, -1)
+        # ... and its [query, key, value] hand-over where keras reads [query, value, key] (oracle/unet_oracle.py attention)
+        q, v, k = (qkv("query"), qkv("key"), qkv("value")) if spec.attention_full else (qkv("query"), qkv("value"), qkv("key"))
         p = torch.softmax(q @ k.transpose(1, 2), dim=-1)
         if prefix in attn_scale:
             p = p * attn_scale[prefix]
-        t = _resize((p @ v).reshape(B, rh, rw, -1), H, W)
+        t = (p @ v).reshape(B, rh, rw, -1)
+        if spec.attention_full:
+            if spec.use_ln:
+                t = _layer_norm(t, P[f"{prefix}/ln1/gamma"])
+        else:
+            t = _resize(t, H, W)
         t = _conv(t, P[f"{prefix}/out/kernel"])
         return _multiplier(t, P[f"{prefix}/gamma/w"])
 
@@ -152,9 +160,10 @@ def backbone(spec, P, xn, depth_scale=None, attn_scale=None):
         for w in range(spec.width):
             pre = f"enc{d}_{w}"
             x = x + branch(pre, attention(pre, x) if (spec.use_self_attention and d == spec.depth - 1) else convnext(pre, x))
-        if spec.use_output_normalization and spec.use_ln:
+        if spec.use_output_normalization and spec.use_ln and not spec.output_norm_at_heads:
             x = _layer_norm(x, P[f"enc{d}/out_ln/gamma"])
-        x = _act(x, a)
+        if spec.level_activation:
+            x = _act(x, a)
         nodes[d] = x
         if d != spec.depth - 1:
             k = spec.gaussian_kernel_size
@@ -171,7 +180,10 @@ def backbone(spec, P, xn, depth_scale=None, attn_scale=None):
     outs = {spec.depth - 1: nodes[spec.depth - 1]}
     for d in reversed(range(spec.depth - 1)):
         low = outs[d + 1]
-        up = _act(_conv(_up2_nearest(low) if spec.upsample_type == "upsample_nearest_conv2d" else _up2(low), P[f"up{d}/kernel"]), a)
+        if spec.upsample_type == "upsample_laplacian_conv2d" and (a == "linear" or spec.upsample_linear):   # upsampling.py:80-90
+            up = _up2(_conv(low, P[f"up{d}/kernel"]))
+        else:
+            up = _act(_conv(_up2_nearest(low) if spec.upsample_type == "upsample_nearest_conv2d" else _up2(low), P[f"up{d}/kernel"]), a)
         enc = nodes[d]
         if spec.use_attention_gates:                                  # AdditiveAttentionGate.call (custom_layers.py:805-832)
             yg = _conv(_layer_norm(enc, P[f"gate{d}/y_ln/gamma"]) if spec.use_ln else enc, P[f"gate{d}/y/kernel"])
@@ -183,9 +195,12 @@ def backbone(spec, P, xn, depth_scale=None, attn_scale=None):
         for w in range(spec.width):
             pre = f"dec{d}_{w}"
             x = x + branch(pre, convnext(pre, x))
-        if spec.use_output_normalization and spec.use_ln:
+        if spec.use_output_normalization and spec.use_ln and not spec.output_norm_at_heads:
             x = _layer_norm(x, P[f"dec{d}/out_ln/gamma"])
         outs[d] = x
+    if spec.use_output_normalization and spec.use_ln and spec.output_norm_at_heads:
+        last = spec.depth - 1
+        outs = {d: _layer_norm(outs[d], P[f"enc{d}/out_ln/gamma" if d == last else f"dec{d}/out_ln/gamma"]) for d in outs}
     return [outs[d] for d in range(spec.depth)]
 
 

@@ -169,7 +169,8 @@ def _setup(depth, width, filters, S, B=2, seed=11, backbone=None):
 def _check_step(spec, params, model, clean, noisy, loss_cfg, dw, depth_scale=None, attn_scale=None):
     ls = O.LossSpec.from_config(loss_cfg)
     r_total, r_ml, r_dls, r_preds, r_grads = T.train_step(spec, ls, params, clean.astype(np.float64), noisy.astype(np.float64), dw,
-                                                          depth_scale, attn_scale)
+                                                          depth_scale, attn_scale,
+                                                          bool(model.config["backbone"].get("use_soft_orthonormal_regularization", False)))
     graph = UnetTrainGraph(model, loss_cfg)
     grads = torch.zeros(model.n_params, dtype=torch.float32, device="cuda")
     dsc = {k: _t(v) for k, v in (depth_scale or {}).items()}
@@ -337,3 +338,57 @@ def test_train_loop_applies_the_deep_supervision_schedule(tmp_path, caplog):
     assert seen[0][0] == pytest.approx((1 / 3, 2 / 3)) and seen[0][1] == 0.0
     assert seen[2][0] == pytest.approx((0.5, 0.5)) and seen[2][1] == 0.5
     assert (tmp_path / "final").exists()
+
+
+def test_trained_archive_graph_trains():
+    """the reference's trained unet_laplacian_v5.6 network (tests/golden/unet_v56.npz) can be fine-tuned: its graph revision
+    (GELU MLP and projections, row attention + second LayerNorm, no level activation, 1x1-then-resize up-sampling, output
+    LayerNorms at the heads) through train_step on a noisy KITTI crop, StochasticDepth and attention dropout included,
+    against the torch-autograd oracle on the archive's own weights"""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import unet_v56 as V
+    z, cfg = V.load()
+    spec = U.UnetLaplacianSpec.from_config(cfg)
+    params = np.asarray(z["params"], np.float32)
+    model = bf.model_builder(cfg, device="cuda").hydra
+    model.set_weights(params)
+    clean = z["kitti"][:2, 32:96, 16:112].astype(np.float32)               # 64 x 96: rows and columns differ
+    noisy = V.corrupt(z["kitti"][:2, 32:96, 16:112], 20.0, seed=5).astype(np.float32)
+    _check_step(spec, params, model, clean, noisy, LOSS_V5, [1.0, 0.6, 0.3])
+    rng = np.random.default_rng(3)
+    ds = {"enc0_1": np.array([2.0, 0.0]), "enc2_2": np.array([0.0, 2.0]), "dec1_0": np.array([2.0, 2.0])}
+    at = {"enc2_0": (rng.uniform(size=(2 * 16, 24, 24)) > 0.25) / 0.75}
+    _check_step(spec, params, model, clean, noisy, LOSS_V5, [1.0, 0.6, 0.3], ds, at)
+
+
+def test_trained_archive_fine_tunes_through_the_public_api():
+    """model_builder on the archive's config + its weights -> build_train_functions -> a few Adam steps on noisy KITTI crops with
+    the training-mode randomness on (StochasticDepth, dropout on the [B * rows, W, W] attention weights): the loss stays finite,
+    the weights move, and the fine-tuned network still passes the reference's acceptance inequalities (test_pretrained.py:62-78)"""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import unet_v56 as V
+    z, cfg = V.load()
+    cfg = {"backbone": dict(cfg["backbone"], depth_drop_rate=0.2, convolutional_self_attention_dropout_rate=0.1), "denoiser": cfg["denoiser"]}
+    model = bf.model_builder(cfg, device="cuda").hydra
+    model.set_weights(np.asarray(z["params"], np.float32))
+    before = model.params.clone()
+    fns = bf.build_train_functions(model, bf.loss_function_builder(dict(LOSS_V5)))
+    opt, _ = bf.optimizer_builder({"type": "Adam", "gradient_clipping_by_norm_local": 1.0,
+                                   "schedule": {"type": "exponential_decay", "config": {"learning_rate": 1e-5, "decay_steps": 1000,
+                                                                                        "decay_rate": 0.9}}})
+    clean = z["kitti"][:2, 0:128, 0:192]
+    totals = []
+    for step in range(4):
+        noisy = V.corrupt(clean, 20.0, seed=10 + step)
+        total, ml, dls, preds, grads = fns.train_step_single_gpu(torch.from_numpy(clean.astype(np.float32)),
+                                                                 torch.from_numpy(noisy.astype(np.float32)), [1.0, 0.5, 0.25])
+        assert torch.isfinite(grads).all() and len(preds) == 3
+        fns.apply_grads(opt, grads, None)
+        totals.append(float(total))
+    assert np.isfinite(totals).all()
+    moved = (model.params - before).abs().max().item()
+    assert 0.0 < moved < 1e-3
+    noisy = V.corrupt(z["kitti"][:1], 20.0, seed=20)
+    V.assert_denoised(z["kitti"][:1], noisy, bf.DenoiserModule(model)(noisy), "fine-tuned")

@@ -74,3 +74,31 @@ def test_forward_of_the_other_shipped_graphs_equals_the_numpy_restatement(option
     for g, r in zip(got, ref):
         assert np.abs(g.numpy() - r).max() < 1e-9
 
+
+
+def test_forward_of_the_trained_archive_graph_equals_the_numpy_restatement():
+    """the graph revision of the reference's trained unet_laplacian_v5.6 archive (GELU in the convnext MLP and on query / key /
+    value, row-wise full-resolution attention with its second LayerNorm, no level activation, linear up-sampling, the output
+    LayerNorms in front of the heads) on the archive's own weights: the torch gradient oracle against unet_oracle.py, which
+    tests/test_unet_pretrained.py pins on the archive's operator list and the reference's acceptance test."""
+    import sys, os, torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import unet_v56 as V
+    z, cfg = V.load()
+    spec = U.UnetLaplacianSpec.from_config(cfg)
+    T.check_trainable_graph(spec)
+    params = np.asarray(z["params"], np.float64)
+    x = V.corrupt(z["kitti"][:1, 32:96, 16:112], 20.0, seed=3).astype(np.float64)
+    ref = U.hydra_forward(spec, params, x)
+    got = T.hydra(spec, T.views(spec, torch.tensor(params)), torch.from_numpy(x))
+    for g, r in zip(got, ref):
+        assert np.abs(g.numpy() - r).max() < 1e-8
+    ls = O.LossSpec(hinge=0.0, cutoff=255.0, mae_multiplier=1.0, ssim_multiplier=1.0, mse_multiplier=0.5, regularization=0.01)
+    clean = z["kitti"][:1, 32:96, 16:112].astype(np.float64)
+    total, _, _, _, grads = T.train_step(spec, ls, params, clean, x, [1.0, 0.5, 0.25])
+    d = np.random.default_rng(0).standard_normal(params.size)
+    d /= np.linalg.norm(d)
+    eps = 1e-5
+    lp = T.train_step(spec, ls, params + eps * d, clean, x, [1.0, 0.5, 0.25])[0]
+    lm = T.train_step(spec, ls, params - eps * d, clean, x, [1.0, 0.5, 0.25])[0]
+    assert abs((lp - lm) / (2 * eps) - grads @ d) <= 2e-4 * max(1.0, abs(grads @ d))
