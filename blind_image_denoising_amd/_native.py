@@ -132,6 +132,8 @@ SIGNATURES = {
     "bf_op_channel_mean_broadcast": (_I, [_P, _P, _I, _I64, _I, _I64, _P, _I64, _P]),
     "bf_op_sigmoid_gate": (_I, [_P, _P, _P, _P, _I64, _P]),
     "bf_op_sigmoid_gate_bwd": (_I, [_P, _P, _P, _P, _P, _I64, _P]),
+    "bf_op_relu_shift": (_I, [_P, _I, _F, _P, _I, _P]),
+    "bf_op_relu_shift_bwd": (_I, [_P, _I, _F, _P, _P, _I, _P]),
     "bf_op_normalize": (_I, [_P, _P, _I64, _F, _F, _I, _P]),
     "bf_op_channel_repeat": (_I, [_P, _P, _I64, _I, _I, _P]),
     "bf_op_channel_group_sum": (_I, [_P, _P, _I64, _I, _I, _P]),

@@ -551,3 +551,43 @@ extern "C" int bf_op_channel_mean_broadcast(const float* x, float* out, int B, i
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// ChannelwiseMultiplier / Multiplier (bfcnn/custom_layers.py:1028-1160): x * relu(w0 + w1), w0 trainable ([C] or [1]), w1 a
+// constant.  The factor as a [C] vector (what bf_op_scale_add multiplies by), and the gradient of w0 from the gradient of that
+// vector (bf_op_scale_add_bwd's dm): dw0[c] = dm[c] [w0[c] + w1 > 0], summed over the channels for the scalar form.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tg_relu_shift_kernel(const float* __restrict__ w0, int nw, float w1, float* __restrict__ m, int C)
+{
+    for (int c = threadIdx.x; c < C; c += 256) m[c] = fmaxf(w0[nw == 1 ? 0 : c] + w1, 0.f);
+}
+
+__global__ __launch_bounds__(256) void tg_relu_shift_bwd_kernel(const float* __restrict__ w0, int nw, float w1, const float* __restrict__ dm,
+                                                                float* __restrict__ dw0, int C)
+{
+    if (nw != 1) {
+        for (int c = threadIdx.x; c < C; c += 256) dw0[c] = w0[c] + w1 > 0.f ? dm[c] : 0.f;
+        return;
+    }
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int c = threadIdx.x; c < C; c += 256) s += (double)dm[c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) { if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
+    if (threadIdx.x == 0) dw0[0] = w0[0] + w1 > 0.f ? (float)red[0] : 0.f;
+}
+
+extern "C" int bf_op_relu_shift(const float* w0, int nw, float w1, float* m, int C, void* stream)
+{
+    if (!w0 || !m || C <= 0 || (nw != 1 && nw != C)) return BF_EINVAL;
+    hipLaunchKernelGGL(tg_relu_shift_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w0, nw, w1, m, C);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+extern "C" int bf_op_relu_shift_bwd(const float* w0, int nw, float w1, const float* dm, float* dw0, int C, void* stream)
+{
+    if (!w0 || !dm || !dw0 || C <= 0 || (nw != 1 && nw != C)) return BF_EINVAL;
+    hipLaunchKernelGGL(tg_relu_shift_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w0, nw, w1, dm, dw0, C);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}

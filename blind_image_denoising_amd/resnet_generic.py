@@ -29,6 +29,15 @@ def channel_gate(x: torch.Tensor, w0: torch.Tensor, w1: torch.Tensor, res: Optio
     return out
 
 
+def scale_add(res: Optional[torch.Tensor], t: torch.Tensor, m: Optional[torch.Tensor], s: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """res + t * m[channel] * s[sample] (each of res / m / s optional)"""
+    B, Cc = t.shape[0], t.shape[-1]
+    out = torch.empty_like(t)
+    N.check(N.lib().bf_op_scale_add(N.ptr(res), N.ptr(t), N.ptr(m), N.ptr(s), N.ptr(out), B, t.numel() // (B * Cc), Cc, N.stream_ptr(t)),
+            None, "bf_op_scale_add")
+    return out
+
+
 def _gate_ex(sel, x, x2, res, w0, b0, w1, b1, act0, alpha0, mode):
     B, H, W, Cc = x.shape
     Cs, C8 = sel.shape[-1], int(w0.shape[1])
@@ -109,10 +118,20 @@ class GenericResnetHydra:
     def __init__(self, config: Dict, device=None, seed: Optional[int] = None):
         bb, dn = config["backbone"], config["denoiser"]
         self.config = config
-        for key in ("add_gelu", "add_final_bn", "add_initial_bn", "add_concat_input", "add_gradient_dropout",
-                    "add_channelwise_scaling", "add_learnable_multiplier", "add_mean_sigma_normalization", "use_bias"):
+        for key in ("add_concat_input", "use_bias"):
             if bb.get(key, False):
                 raise NotImplementedError(f"resnet: {key} is outside the built graph")
+        # add_gelu / add_gradient_dropout / add_mean_sigma_normalization: the builder turns them into gelu_params /
+        # gradient_dropout_params / mean_sigma_params (backbone_resnet.py:207-223), which resnet_blocks_full accepts and never reads
+        # (backbone_blocks.py:118-125 sets use_mean_sigma / use_gradient_dropout, the block body :164-243 uses neither; gelu_params
+        # lands in **kwargs): the graph is the same with or without them.
+        self.add_initial_bn = bool(bb.get("add_initial_bn", False))                    # backbone_resnet.py:264-265
+        self.add_final_bn = bool(bb.get("add_final_bn", False))                        # :274-275
+        self.add_channelwise = bool(bb.get("add_channelwise_scaling", False))          # :236-238, 282-283; backbone_blocks.py:215-217
+        self.add_multiplier = bool(bb.get("add_learnable_multiplier", False))          # :240-242, 286-287; backbone_blocks.py:219-221
+        self.dropout_rate = float(bb.get("dropout_rate", -1))                          # RandomOnOff (:231-235): identity at inference
+        if self.dropout_rate != -1 and not 0.0 <= self.dropout_rate < 1.0:
+            raise ValueError("dropout_rate must be in [0, 1)")
         if bb.get("base_conv_params") is not None:
             raise NotImplementedError("resnet: base_conv_params is outside the built graph")
         self.selector = None
@@ -193,6 +212,9 @@ class GenericResnetHydra:
         k = self.kernel_size
         out = [("base/kernel", (k, k, self.in_channels, self.filters), "conv")]
         state = []
+        if self.add_initial_bn:
+            out.append(("initial_bn/gamma", (self.filters,), "bn_gamma"))
+            state += [("initial_bn/moving_mean", (self.filters,)), ("initial_bn/moving_variance", (self.filters,))]
         for i in range(self.no_layers):
             cin = self.filters
             for j, (kk, cf, dm, g) in enumerate(zip(self.block_kernels, self.block_filters, self.block_depthwise, self.block_groups)):
@@ -210,6 +232,12 @@ class GenericResnetHydra:
                     out.append((f"block{i}/gate/dense0/kernel", (cout, c8), "dense"))
                     out.append((f"block{i}/gate/dense1/kernel", (c8, cout), "dense"))
                 cin = cout
+            # ChannelwiseMultiplier / Multiplier (custom_layers.py:1028-1160): x * relu(w0 + w1); the trainable w0 (zeros at
+            # creation) is a parameter, the non-trainable w1 keeps its creation value `multiplier` = 1.0 and is a constant here
+            if self.add_channelwise:
+                out.append((f"block{i}/channelwise/w0", (cin,), "channelwise"))
+            if self.add_multiplier:
+                out.append((f"block{i}/multiplier/w0", (1,), "multiplier"))
             if self.selector:
                 cs = self.block_filters[0] if self.block_depthwise[0] == -1 else self.filters * self.block_depthwise[0]
                 cc = self.selector["compress"]
@@ -220,6 +248,13 @@ class GenericResnetHydra:
                 else:
                     out.append((f"block{i}/selector/dense0/kernel", (cs, cc), "dense"))
                     out.append((f"block{i}/selector/dense1/kernel", (cc, self.filters), "dense"))
+        if self.add_final_bn:
+            out.append(("final_bn/gamma", (self.filters,), "bn_gamma"))
+            state += [("final_bn/moving_mean", (self.filters,)), ("final_bn/moving_variance", (self.filters,))]
+        if self.add_channelwise:
+            out.append(("channelwise/w0", (self.filters,), "channelwise"))
+        if self.add_multiplier:
+            out.append(("multiplier/w0", (1,), "multiplier"))
         out.append(("head/conv0/kernel", (1, 1, self.filters, self.head_filters), "conv"))
         out.append(("head/conv1/kernel", (1, 1, self.head_filters, self.out_channels), "conv"))
         return out, state
@@ -246,8 +281,8 @@ class GenericResnetHydra:
     def _initial_values(self, seed) -> np.ndarray:
         from .model import glorot_normal
         rng = np.random.default_rng(seed)
-        init = lambda s, kind: np.ones(s) if kind == "bn_gamma" else \
-            (glorot_normal((1, 1) + tuple(s), rng).reshape(s) if kind == "dense" else glorot_normal(s, rng))
+        init = lambda s, kind: np.ones(s) if kind == "bn_gamma" else (np.zeros(s) if kind in ("channelwise", "multiplier") else
+            (glorot_normal((1, 1) + tuple(s), rng).reshape(s) if kind == "dense" else glorot_normal(s, rng)))
         return np.concatenate([np.asarray(init(s, kind), np.float32).ravel() for _, s, kind in self._inventory])
 
     def get_weights(self):
@@ -284,6 +319,24 @@ class GenericResnetHydra:
         S = {n: st[o:o + int(np.prod(s))].reshape(s).astype(np.float64) for n, s, o in self.non_trainable_variables}
         dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.device)
         P = {"base": dev(W["base/kernel"])}
+        homogeneous = lambda a: UL._act(a)[0] in (0, 1, 2)                 # act(s z) = s act(z) for s >= 0: linear, relu, leaky relu
+
+        def bn_affine(base):
+            sc = W[base + "/gamma"] / np.sqrt(S[base + "/moving_variance"] + BN_EPSILON)
+            return sc, -sc * S[base + "/moving_mean"]
+
+        def end_scale(prefix, n):
+            """relu(w0 + 1) of the ChannelwiseMultiplier times that of the Multiplier behind it: a factor >= 0 per channel"""
+            sc = np.ones(n)
+            if self.add_channelwise:
+                sc = sc * np.maximum(W[prefix + "channelwise/w0"] + 1.0, 0.0)
+            if self.add_multiplier:
+                sc = sc * np.maximum(W[prefix + "multiplier/w0"] + 1.0, 0.0)
+            return sc
+        if self.add_initial_bn:                                           # per-channel affine behind the base convolution's activation
+            sc, sh = bn_affine("initial_bn")
+            P["initial_bn"] = (dev(sc.reshape(1, 1, -1, 1)), dev(sh))
+        nb_ = len(self.block_kernels)
         for i in range(self.no_layers):
             cin = self.filters
             for j, (kk, cf, dm, g) in enumerate(zip(self.block_kernels, self.block_filters, self.block_depthwise, self.block_groups)):
@@ -294,6 +347,14 @@ class GenericResnetHydra:
                     base = f"block{i}/bn{j}"
                     scale = W[base + "/gamma"] / np.sqrt(S[base + "/moving_variance"] + BN_EPSILON)
                     shift = -scale * S[base + "/moving_mean"]
+                if j == nb_ - 1 and (self.add_channelwise or self.add_multiplier):
+                    # the block's closing multipliers are >= 0 and its last activation is base_activation: folded into the last
+                    # convolution's scale / shift when that commutes (and no gate sits between), else applied as their own pass
+                    es = end_scale(f"block{i}/", cout)
+                    if homogeneous(self.block_activation[j]) and not (self.add_gates and j == 1):
+                        scale, shift = scale * es, (None if shift is None else shift * es)
+                    else:
+                        P[f"b{i}scale"] = dev(es)
                 if dm != -1:
                     kf = (k * scale.reshape(cin, dm)[None, None]).reshape(kk, kk, cin * dm)
                     P[f"b{i}c{j}"] = ("dw", dev(kf.reshape(kk, kk, cin, dm)), None if shift is None else dev(shift))
@@ -312,7 +373,14 @@ class GenericResnetHydra:
                 kind = "dense" if self.selector["scale_type"] == "global" else "conv"
                 w0, w1 = W[f"block{i}/selector/{kind}0/kernel"], W[f"block{i}/selector/{kind}1/kernel"]
                 P[f"b{i}sel"] = (dev(w0.reshape(w0.shape[-2], w0.shape[-1])), dev(w1.reshape(w1.shape[-2], w1.shape[-1])))
-        P["head0"] = UL.pack_pointwise(dev(W["head/conv0/kernel"][0, 0]))
+        w_head0 = W["head/conv0/kernel"][0, 0]
+        if self.add_final_bn:                                             # BN, then the closing multipliers: one per-channel affine
+            sc, sh = bn_affine("final_bn")
+            es = end_scale("", self.filters)
+            P["final_affine"] = (dev((sc * es).reshape(1, 1, -1, 1)), dev(sh * es))
+        elif self.add_channelwise or self.add_multiplier:                 # no shift: the head's first 1x1 absorbs the factor (rows of W)
+            w_head0 = w_head0 * end_scale("", self.filters)[:, None]
+        P["head0"] = UL.pack_pointwise(dev(w_head0))
         P["head1"] = dev(W["head/conv1/kernel"])
         self._packed = P
         return P
@@ -325,12 +393,15 @@ class GenericResnetHydra:
     def _features(self, x: torch.Tensor, H: int, W: int) -> torch.Tensor:
         P = self._pack()
         f = UL.first_conv(x, P["base"], H, W, self.base_activation, True, self.v_min, self.v_max)
+        if self.add_initial_bn:
+            f = UL.dwconv_mult(f, P["initial_bn"][0], P["initial_bn"][1])
         nb = len(self.block_kernels)
         fused = {(32, 4, 32, 3), (32, 2, 32, 3), (64, 2, 64, 3), (32, 4, 64, 3), (32, 1, 32, 3), (64, 1, 64, 3)}   # built instances
         for i in range(self.no_layers):
             t = f
             first = None
             j = 0
+            tail = P.get(f"b{i}scale")                       # closing multipliers that could not be folded: own pass, carries the Add
             while j < nb:
                 kind, wp, shift = P[f"b{i}c{j}"]
                 gate_here = self.add_gates and j == 1
@@ -339,14 +410,15 @@ class GenericResnetHydra:
                     # depthwise (+BN, act) and the 1x1 after it (+BN, act, +skip) in one kernel: the wide tensor stays on chip
                     _, wp2, shift2 = P[f"b{i}c{j + 1}"]
                     t = UL.dwmult_pointwise(t, wp, shift, self.block_activation[j], wp2, self.block_filters[j + 1], shift2,
-                                            self.block_activation[j + 1], f if j + 1 == nb - 1 and not self.selector else None)
+                                            self.block_activation[j + 1],
+                                            f if j + 1 == nb - 1 and not self.selector and tail is None else None)
                     j += 2
                     continue
-                res = f if j == nb - 1 and not gate_here and not self.selector else None   # Add(block output, block input) (:242)
+                res = f if j == nb - 1 and not gate_here and not self.selector and tail is None else None   # Add(block output, block input) (:242)
                 a = self.block_activation[j]
                 if kind == "dw":
                     t = UL.dwconv_mult(t, wp, shift, a)
-                    if j == nb - 1 and not gate_here and not self.selector:
+                    if j == nb - 1 and not gate_here and not self.selector and tail is None:
                         raise NotImplementedError("a depthwise convolution as the last convolution of a block")
                 elif kind == "pw":
                     cout = self.block_filters[j]
@@ -354,11 +426,15 @@ class GenericResnetHydra:
                 else:
                     t = UL.conv2d(t, wp, self.block_filters[j], self.block_kernels[j], 1, a, res=res, bias=shift)
                 if gate_here:                                # x * hard_sigmoid(relu(mean(x) W0) W1) [+ skip when the block ends here]
-                    t = channel_gate(t, *P[f"b{i}gate"], res=f if j == nb - 1 and not self.selector else None)
+                    t = channel_gate(t, *P[f"b{i}gate"], res=f if j == nb - 1 and not self.selector and tail is None else None)
                 if j == 0:
                     first = t                                # x_1st_conv: the selector layer (backbone_blocks.py:229-231)
                 j += 1
+            if tail is not None:
+                t = scale_add(None if self.selector else f, t, tail)
             f = selector_block(f, t, first, *P[f"b{i}sel"], **self.selector) if self.selector else t
+        if self.add_final_bn:
+            f = UL.dwconv_mult(f, P["final_affine"][0], P["final_affine"][1])
         return f
 
     def _as_device(self, x):

@@ -23,6 +23,8 @@ from .unet_train import _Ops, _call
 
 BN_MOMENTUM = 0.995                # DEFAULT_BN_MOMENTUM (bfcnn/constants.py:10)
 REG_COEF = 0.01                    # keras "l1" / "l2" string regularisers
+CHANNELWISE_L1 = 0.1               # DEFAULT_CHANNELWISE_MULTIPLIER_L1 (bfcnn/constants.py:13)
+MULTIPLIER_L1 = 1.0                # DEFAULT_MULTIPLIER_L1 (:12)
 
 
 class GenericResnetTrainGraph:
@@ -37,6 +39,8 @@ class GenericResnetTrainGraph:
         for j, (kk, g) in enumerate(zip(model.block_kernels, model.block_groups)):
             if g != 1 and kk != 1:
                 raise NotImplementedError("training: grouped convolutions are built for 1x1 kernels")
+        if any(UL._act(a_)[0] == 3 for a_ in list(model.block_activation) + [model.base_activation]):
+            raise NotImplementedError("training: GELU in the resnet blocks is built for inference only")
         if getattr(model, "selector", None):
             raise NotImplementedError("training: selector_block is built for inference only")
         self.ops = None
@@ -76,6 +80,8 @@ class GenericResnetTrainGraph:
         bb, dn = self.m.config["backbone"], self.m.config["denoiser"]
         if kind == "bn_gamma":
             return None
+        if kind in ("channelwise", "multiplier"):                  # handled where the regularisers are summed (their own coefficients)
+            return kind
         if name.startswith("base/"):
             return bb.get("kernel_regularizer", "l1")
         if name.startswith("head/"):
@@ -87,8 +93,10 @@ class GenericResnetTrainGraph:
         return br[j]
 
     # ---- one training step -------------------------------------------------------------------------------------------------
-    def step(self, gt: torch.Tensor, noisy: torch.Tensor, grads: torch.Tensor, depth_weight: float = 1.0):
+    def step(self, gt: torch.Tensor, noisy: torch.Tensor, grads: torch.Tensor, depth_weight: float = 1.0, drop_scale=None):
+        """drop_scale: {block index: per-sample factor [B] on the device} = RandomOnOff's draw (0 or 1 / (1 - rate))"""
         m = self.m
+        drop_scale = drop_scale or {}
         dev = m.device
         gt = gt.to(device=dev, dtype=torch.float32).contiguous()
         noisy = noisy.to(device=dev).contiguous()
@@ -170,11 +178,54 @@ class GenericResnetTrainGraph:
                 return UL.conv2d(dy, UL.pack_conv(wt), cin, kk, 1, "linear")
             return y, bwd
 
+        def bn_step(base, c, a):
+            """BatchNormalization on batch statistics (+ activation a), moving statistics updated: (y, backward dy -> dc)"""
+            code, alpha = UL._act(a)
+            Cc = c.shape[-1]
+            gamma = self.W(base + "/gamma")
+            save = torch.empty(2 * Cc, **f32)
+            y = torch.empty_like(c)
+            sp, sn = ops._s()
+            _call("bf_op_bn_train_fwd", N.ptr(c), N.ptr(gamma), N.ptr(y), N.ptr(save), N.ptr(self.S(base + "/moving_mean")),
+                  N.ptr(self.S(base + "/moving_variance")), c.numel() // Cc, Cc, BN_EPSILON, BN_MOMENTUM, code, alpha,
+                  sp, sn, N.stream_ptr(c))
+
+            def bwd(dy):
+                dpre = ops.act_bwd(y, dy, a)
+                dx = torch.empty_like(c)
+                sp, sn = ops._s()
+                _call("bf_op_bn_train_bwd", N.ptr(c), N.ptr(gamma), N.ptr(save), N.ptr(dpre), N.ptr(dx), N.ptr(self.G(base + "/gamma", grads)),
+                      c.numel() // Cc, Cc, sp, sn, N.stream_ptr(c))
+                return dx
+            return y, bwd
+
+        def mult_step(name, t, s_=None):
+            """ChannelwiseMultiplier / Multiplier: t * relu(w0 + 1) [* the per-sample RandomOnOff factor]; name None: the factor alone"""
+            Cc = t.shape[-1]
+            mvec = None
+            if name is not None:
+                w0 = self.W(name)
+                nw = w0.numel()
+                mvec = torch.empty(Cc, **f32)
+                _call("bf_op_relu_shift", N.ptr(w0), nw, 1.0, N.ptr(mvec), Cc, N.stream_ptr(mvec))
+            y = ops.scale_add(None, t, mvec, s_)
+
+            def bwd(dy):
+                dm = torch.empty(Cc, **f32) if name is not None else None
+                dt = ops.scale_add_bwd(t, mvec, s_, dy, dm)
+                if name is not None:
+                    _call("bf_op_relu_shift_bwd", N.ptr(w0), nw, 1.0, N.ptr(dm), N.ptr(self.G(name, grads)), Cc, N.stream_ptr(dm))
+                return dt
+            return y, bwd
+
         # -- forward -------------------------------------------------------------------------------------------------------------
         wb = self.W("base/kernel")
         f = UL.first_conv(noisy, wb, H, Wd, m.base_activation, True, m.v_min, m.v_max, arith=0)
         f0 = f
         chain = []                                   # per block: closure d(block output) -> d(block input)
+        if m.add_initial_bn:
+            f, b_ = bn_step("initial_bn", f, "linear")
+            chain.append(b_)
         for i in range(m.no_layers):
             t = f
             steps = []
@@ -224,6 +275,14 @@ class GenericResnetTrainGraph:
                         return dx
                     steps.append((None, b_gate))
                     t = gout
+            # backbone_blocks.py:215-225: ChannelwiseMultiplier, Multiplier, RandomOnOff in front of the Add
+            tails = ([f"block{i}/channelwise/w0"] if m.add_channelwise else []) + ([f"block{i}/multiplier/w0"] if m.add_multiplier else [])
+            ds_ = drop_scale.get(i)
+            if ds_ is not None and not tails:
+                tails = [None]
+            for q_, name_ in enumerate(tails):
+                t, b_ = mult_step(name_, t, ds_ if q_ == len(tails) - 1 else None)
+                steps.append((None, b_))
             f = ops.add(f, t)                                         # Add()([x, previous_layer]) (backbone_blocks.py:242)
 
             def b_block(dout, steps=steps):
@@ -234,6 +293,13 @@ class GenericResnetTrainGraph:
                         g = b_conv(g)
                 return ops.add(dout, g)
             chain.append(b_block)
+
+        if m.add_final_bn:                                            # backbone_resnet.py:274-287
+            f, b_ = bn_step("final_bn", f, "linear")
+            chain.append(b_)
+        for name_ in (["channelwise/w0"] if m.add_channelwise else []) + (["multiplier/w0"] if m.add_multiplier else []):
+            f, b_ = mult_step(name_, f)
+            chain.append(b_)
 
         # -- head + loss ---------------------------------------------------------------------------------------------------------
         ld = N.LossDesc()
@@ -273,15 +339,27 @@ class GenericResnetTrainGraph:
 
         # -- regularisers: value into total[1], gradients added times `regularization` ------------------------------------------
         reg = float(ld.regularization)
+        n_mult = 0
         for name, shape, kind, off in m.trainable_variables:
             rk = self.regularizer(name, kind)
             if rk in (None, "none"):
+                continue
+            if rk in ("channelwise", "multiplier"):
+                w = self.W(name)
+                _call("bf_op_reg_elementwise", N.ptr(w), N.ptr(self._grad_view(name, grads)), int(np.prod(shape)), N.BF_REG_L1,
+                      CHANNELWISE_L1 if rk == "channelwise" else MULTIPLIER_L1, reg, N.ptr(total[1:2]), N.stream_ptr(w))
+                n_mult += rk == "multiplier"
                 continue
             if rk not in ("l1", "l2"):
                 raise NotImplementedError(f"regularizer {rk}")
             w = self.W(name)
             _call("bf_op_reg_elementwise", N.ptr(w), N.ptr(self._grad_view(name, grads)), int(np.prod(shape)),
                   N.BF_REG_L1 if rk == "l1" else N.BF_REG_L2, REG_COEF, reg, N.ptr(total[1:2]), N.stream_ptr(w))
+        if n_mult:
+            # Multiplier hands its regulariser to the non-trainable w1 (= 1.0) as well (custom_layers.py:1067-1074): L1(1.0) of a
+            # constant 1.0 per layer in model.losses, no gradient
+            ones = torch.ones(n_mult, **f32)
+            _call("bf_op_reg_elementwise", N.ptr(ones), None, n_mult, N.BF_REG_L1, MULTIPLIER_L1, reg, N.ptr(total[1:2]), N.stream_ptr(ones))
         for buf, off, n in self._unaligned:
             grads[off:off + n].copy_(buf)
         _call("bf_op_axpy", N.ptr(total[2:3]), N.ptr(total[1:2]), reg, 0, 1, N.stream_ptr(total))

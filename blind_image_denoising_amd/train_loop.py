@@ -77,10 +77,15 @@ def build_train_functions(model: HydraModel, loss_fn_map: Dict[str, Callable]) -
     return TrainFunctions(train_step, test_step, train_step_single_gpu, apply_grads)
 
 
-def _build_generic_resnet_train_functions(model, denoiser_loss_fn) -> TrainFunctions:
+def _build_generic_resnet_train_functions(model, denoiser_loss_fn, seed: int = 0) -> TrainFunctions:
     """the four closures for the resnet configs outside the 16-filter 3x3 engine (GenericResnetHydra), through
-    resnet_generic_train.GenericResnetTrainGraph (explicit forward / backward over the operator library)."""
+    resnet_generic_train.GenericResnetTrainGraph (explicit forward / backward over the operator library).
+    `dropout_rate` (RandomOnOff on every block's branch, backbone_blocks.py:223-225): the per-sample keep factors are drawn here per
+    step from a NumPy generator; `train_step_single_gpu.randomness = False` switches them off, `.drop_scale = {block: [B] tensor}`
+    pins them (parity tests)."""
+    import numpy as np
     from .resnet_generic_train import GenericResnetTrainGraph
+    rng = np.random.default_rng(seed)
     d = denoiser_loss_fn.desc(1.0)
     loss_config = {"hinge": d.hinge, "cutoff": d.cutoff, "mae_multiplier": d.mae_multiplier, "mse_multiplier": d.mse_multiplier,
                    "ssim_multiplier": d.ssim_multiplier, "regularization": d.regularization}
@@ -100,11 +105,20 @@ def _build_generic_resnet_train_functions(model, denoiser_loss_fn) -> TrainFunct
         grads = state["grads"]
         dw = p_depth_weight[0] if hasattr(p_depth_weight, "__len__") else p_depth_weight
         dw = 1.0 if dw is None else dw
-        pred, sl, totals = graph.step(p_input_image_batch, p_noisy_image_batch, grads, float(dw))
+        ds = train_step_single_gpu.drop_scale
+        rate = getattr(model, "dropout_rate", -1)
+        if ds is None and train_step_single_gpu.randomness and rate > 0.0:
+            B = int(p_noisy_image_batch.shape[0])
+            ds = {i: torch.from_numpy((rng.uniform(size=B) >= rate).astype(np.float32) / np.float32(1.0 - rate)).to(model.device)
+                  for i in range(model.no_layers)}
+        pred, sl, totals = graph.step(p_input_image_batch, p_noisy_image_batch, grads, float(dw), ds)
         model_loss = {REGULARIZATION_LOSS_STR: totals[1], TOTAL_LOSS_STR: totals[2]}
         denoiser_loss = {TOTAL_LOSS_STR: sl[N.BF_LOSS_DENOISER_TOTAL], MSE_LOSS_STR: sl[N.BF_LOSS_MSE], MAE_LOSS_STR: sl[N.BF_LOSS_MAE],
                          SSIM_LOSS_STR: sl[N.BF_LOSS_SSIM]}
         return totals[0], model_loss, [denoiser_loss], pred, grads
+
+    train_step_single_gpu.randomness = True
+    train_step_single_gpu.drop_scale = None
 
     def apply_grads(internal_optimizer, internal_gradients, internal_trainable_variables=None, grad_scale: float = 1.0):
         internal_optimizer.apply_gradients(internal_gradients, model, grad_scale=grad_scale, losses=None)

@@ -433,6 +433,10 @@ int bf_op_channel_mean_broadcast(const float* x, float* out, int batch, int64_t 
    out = enc * sigmoid(4 o) [+ up]; backward: denc = dy * s, do = dy * enc * 4 s (1 - s) */
 int bf_op_sigmoid_gate(const float* enc, const float* o, const float* up, float* out, int64_t n, void* stream);
 int bf_op_sigmoid_gate_bwd(const float* enc, const float* o, const float* dy, float* denc, float* dout_o, int64_t n, void* stream);
+/* ChannelwiseMultiplier / Multiplier of the resnet builder (bfcnn/custom_layers.py:1028-1160; backbone_blocks.py:215-221): the factor
+   m[c] = relu(w0[c or 0] + w1) for bf_op_scale_add (nw = C: per channel, nw = 1: one scalar), and d w0 from d m */
+int bf_op_relu_shift(const float* w0, int nw, float w1, float* m, int channels, void* stream);
+int bf_op_relu_shift_bwd(const float* w0, int nw, float w1, const float* dm, float* dw0, int channels, void* stream);
 /* the normalise / denormalise layers on their own (bfcnn/model.py:364-430; inside the hydras they are fused into the first
    convolution and the head): inverse 0: (clip(x, v_min, v_max) - v_min) / (v_max - v_min) - 0.5; 1: (clip(x, -.5, .5) + .5) * range + v_min */
 int bf_op_normalize(const float* x, float* out, int64_t n, float v_min, float v_max, int inverse, void* stream);

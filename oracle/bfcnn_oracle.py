@@ -115,6 +115,9 @@ def activation_fwd(x: np.ndarray, name: Optional[str]) -> np.ndarray:
         return np.where(x > 0, x, 0.01 * x)
     if name == "tanh":
         return np.tanh(x)
+    if name == "gelu":                     # keras "gelu": the exact erf form (approximate=False)
+        from scipy.special import erf
+        return 0.5 * x * (1.0 + erf(x / np.sqrt(2.0)))
     raise NotImplementedError(f"activation [{name}] is outside the hot path")
 
 

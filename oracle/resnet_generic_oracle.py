@@ -147,6 +147,11 @@ class GenericResnetSpec:
     block_regularizer: Tuple[str, ...] = ()
     head_regularizer: str = "l2"
     selector: Tuple = ()                  # () or (scale_type, activation_type, compress channels, pool, stride)
+    add_initial_bn: bool = False          # BatchNormalization behind the base convolution (backbone_resnet.py:264-265)
+    add_final_bn: bool = False            # ... behind the last block (:274-275)
+    add_channelwise_scaling: bool = False   # ChannelwiseMultiplier closing every block and the backbone (:236-238, 282-283)
+    add_learnable_multiplier: bool = False  # Multiplier, likewise (:240-242, 286-287)
+    dropout_rate: float = -1.0            # RandomOnOff on every block's branch (:231-235): training only
 
     @staticmethod
     def from_config(model_config: Dict) -> "GenericResnetSpec":
@@ -168,7 +173,10 @@ class GenericResnetSpec:
             add_gates=bool(bb.get("add_gates", False)), kernel_regularizer=bb.get("kernel_regularizer", "l1"),
             block_regularizer=tuple(bb.get("block_regularizer") or [bb.get("kernel_regularizer", "l1")] * len(bk)),
             head_regularizer=dn.get("kernel_regularizer", "l2"),
-            selector=GenericResnetSpec._selector(bb))
+            selector=GenericResnetSpec._selector(bb),
+            add_initial_bn=bool(bb.get("add_initial_bn", False)), add_final_bn=bool(bb.get("add_final_bn", False)),
+            add_channelwise_scaling=bool(bb.get("add_channelwise_scaling", False)),
+            add_learnable_multiplier=bool(bb.get("add_learnable_multiplier", False)), dropout_rate=float(bb.get("dropout_rate", -1)))
 
     @staticmethod
     def _selector(bb) -> Tuple:
@@ -188,9 +196,13 @@ class GenericResnetSpec:
         return self.block_filters[1] if self.block_depthwise[1] == -1 else self.block_filters[0] * self.block_depthwise[1]
 
     def tensors(self) -> List[Tuple[str, Tuple[int, ...], str]]:
-        """(name, shape, kind) in graph-construction order; kind in conv | depthwise | bn_gamma."""
+        """(name, shape, kind) in graph-construction order; kind in conv | depthwise | bn_gamma | dense | channelwise | multiplier.
+        ChannelwiseMultiplier / Multiplier (custom_layers.py:1028-1160): the trainable `w0` (zeros at creation); their
+        non-trainable `w1` stays at its creation value `multiplier` = 1.0 and is a constant here."""
         k = self.kernel_size
         out = [("base/kernel", (k, k, self.in_channels, self.filters), "conv")]
+        if self.add_initial_bn:
+            out.append(("initial_bn/gamma", (self.filters,), "bn_gamma"))
         for i in range(self.no_layers):
             cin = self.filters
             for j, (kk, cf, dm, g) in enumerate(zip(self.block_kernels, self.block_filters, self.block_depthwise, self.block_groups)):
@@ -207,6 +219,10 @@ class GenericResnetSpec:
                     out.append((f"block{i}/gate/dense0/kernel", (gc, max(int(gc / 8), 2)), "dense"))
                     out.append((f"block{i}/gate/dense1/kernel", (max(int(gc / 8), 2), gc), "dense"))
                 cin = cout
+            if self.add_channelwise_scaling:                       # backbone_blocks.py:215-221, ahead of the Add / selector
+                out.append((f"block{i}/channelwise/w0", (cin,), "channelwise"))
+            if self.add_learnable_multiplier:
+                out.append((f"block{i}/multiplier/w0", (1,), "multiplier"))
             if self.selector:                                      # the selector's two layers close the block (backbone_blocks.py:227-239)
                 cs, cc = self.block_filters[0] if self.block_depthwise[0] == -1 else self.filters * self.block_depthwise[0], self.selector[2]
                 if self.selector[0] != "global":
@@ -216,6 +232,12 @@ class GenericResnetSpec:
                 else:
                     out.append((f"block{i}/selector/dense0/kernel", (cs, cc), "dense"))
                     out.append((f"block{i}/selector/dense1/kernel", (cc, self.filters), "dense"))
+        if self.add_final_bn:
+            out.append(("final_bn/gamma", (self.filters,), "bn_gamma"))
+        if self.add_channelwise_scaling:
+            out.append(("channelwise/w0", (self.filters,), "channelwise"))
+        if self.add_learnable_multiplier:
+            out.append(("multiplier/w0", (1,), "multiplier"))
         out.append(("head/conv0/kernel", (1, 1, self.filters, self.head_filters), "conv"))
         out.append(("head/conv1/kernel", (1, 1, self.head_filters, self.out_channels), "conv"))
         return out
@@ -235,6 +257,8 @@ def init_params(spec: GenericResnetSpec, seed: int = 42) -> Tuple[np.ndarray, np
     for name, shape, kind in spec.tensors():
         if kind == "bn_gamma":
             params.append(rng.uniform(0.5, 1.5, shape))
+        elif kind in ("channelwise", "multiplier"):                  # zeros at creation; spread out so that a wrong one shows
+            params.append(rng.uniform(-1.2, 0.6, shape) if kind == "channelwise" else rng.uniform(-0.5, 0.5, shape))
         else:
             params.append(O.glorot_normal(shape, rng) if len(shape) == 4 else O.glorot_normal((1, 1) + tuple(shape), rng).reshape(shape))
     state = []
@@ -259,6 +283,9 @@ def hydra_forward(spec: GenericResnetSpec, params: np.ndarray, state: np.ndarray
     S = _views(spec.state_tensors(), state, dtype)
     f = O.activation_fwd(O.conv2d_same(O.layer_normalize(x.astype(dtype), spec.v_min, spec.v_max), P["base/kernel"]),
                          spec.base_activation)
+    scaled = lambda t, name: t * np.maximum(P[name] + 1.0, 0.0)        # activation "relu" of (w0 + w1), w1 = 1 (backbone_resnet.py:190-202)
+    if spec.add_initial_bn:
+        f = O.bn_infer(f, P["initial_bn/gamma"], S["initial_bn/moving_mean"], S["initial_bn/moving_variance"], BN_EPS)
     for i in range(spec.no_layers):
         t = f
         for j, (dm, g, a) in enumerate(zip(spec.block_depthwise, spec.block_groups, spec.block_activation)):
@@ -272,12 +299,23 @@ def hydra_forward(spec: GenericResnetSpec, params: np.ndarray, state: np.ndarray
                 first = t                                                # x_1st_conv: the selector layer
             if j == 1 and spec.add_gates:
                 t = gate(t, P[f"block{i}/gate/dense0/kernel"], P[f"block{i}/gate/dense1/kernel"])
+        if spec.add_channelwise_scaling:
+            t = scaled(t, f"block{i}/channelwise/w0")
+        if spec.add_learnable_multiplier:
+            t = scaled(t, f"block{i}/multiplier/w0")
+        # RandomOnOff (dropout_rate): Dropout is the identity outside training
         if spec.selector:
             kind = "dense" if spec.selector[0] == "global" else "conv"
             f = selector_block(f, t, first, P[f"block{i}/selector/{kind}0/kernel"], P[f"block{i}/selector/{kind}1/kernel"],
                                spec.selector[0], spec.selector[1], spec.selector[3], spec.selector[4])
         else:
             f = t + f
+    if spec.add_final_bn:
+        f = O.bn_infer(f, P["final_bn/gamma"], S["final_bn/moving_mean"], S["final_bn/moving_variance"], BN_EPS)
+    if spec.add_channelwise_scaling:
+        f = scaled(f, "channelwise/w0")
+    if spec.add_learnable_multiplier:
+        f = scaled(f, "multiplier/w0")
     h = O.activation_fwd(O.conv2d_same(f, P["head/conv0/kernel"]), spec.head_activation)
     h = O.conv2d_same(h, P["head/conv1/kernel"])
     return O.layer_denormalize(np.tanh(2.0 * h) * 0.51, spec.v_min, spec.v_max)

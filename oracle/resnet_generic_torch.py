@@ -33,15 +33,7 @@ def _nhwc(x):
     return x.permute(0, 2, 3, 1)
 
 
-def _act(x, name):
-    name = (name or "linear").lower()
-    if name == "linear":
-        return x
-    if name == "relu":
-        return torch.relu(x)
-    if name.startswith("leaky_relu"):
-        return F.leaky_relu(x, 0.3)
-    raise ValueError(name)
+_act = T._act                       # linear | relu | leaky_relu (0.3) / _01 / _001 | gelu (erf form)
 
 
 def conv_same(x, w, groups=1):
@@ -75,13 +67,32 @@ def state_views(spec, flat):
     return out
 
 
-def hydra(spec: R.GenericResnetSpec, P, S, x, training: bool):
-    """returns (prediction, new state dict)"""
+def _batch_norm(t, base, P, S, new_state, training):
+    """keras BatchNormalization(scale=True, center=False) (backbone_resnet.py:129-135)"""
+    gamma = P[base + "/gamma"]
+    if not training:
+        return gamma * (t - S[base + "/moving_mean"]) / torch.sqrt(S[base + "/moving_variance"] + R.BN_EPS)
+    n = t.shape[0] * t.shape[1] * t.shape[2]
+    mu = t.mean(dim=(0, 1, 2))
+    var = ((t - mu) ** 2).mean(dim=(0, 1, 2))
+    mom = O.DEFAULT_BN_MOMENTUM
+    new_state[base + "/moving_mean"] = (S[base + "/moving_mean"] * mom + mu * (1 - mom)).detach()
+    new_state[base + "/moving_variance"] = (S[base + "/moving_variance"] * mom + var * (n / max(n - 1, 1)) * (1 - mom)).detach()
+    return gamma * (t - mu) / torch.sqrt(var + R.BN_EPS)
+
+
+def hydra(spec: R.GenericResnetSpec, P, S, x, training: bool, drop_scale=None):
+    """returns (prediction, new state dict).  drop_scale: {block index: per-sample factor [B]} = RandomOnOff's draw
+    (0 or 1 / (1 - rate); custom_layers.py:107-127), training only."""
     if spec.selector:
         raise NotImplementedError("the gradient oracle does not restate selector_block (inference only in the product as well)")
     new_state = dict(S)
+    drop_scale = drop_scale or {}
+    scaled = lambda t, name: t * torch.relu(P[name] + 1.0)
     xn = (torch.clamp(x, spec.v_min, spec.v_max) - spec.v_min) / (spec.v_max - spec.v_min) - 0.5
     f = _act(conv_same(xn, P["base/kernel"]), spec.base_activation)
+    if spec.add_initial_bn:
+        f = _batch_norm(f, "initial_bn", P, S, new_state, training)
     for i in range(spec.no_layers):
         t = f
         for j, (dm, g, a) in enumerate(zip(spec.block_depthwise, spec.block_groups, spec.block_activation)):
@@ -105,7 +116,19 @@ def hydra(spec: R.GenericResnetSpec, P, S, x, training: bool):
                 y = torch.relu(t.mean(dim=(1, 2)) @ P[f"block{i}/gate/dense0/kernel"])
                 y = torch.clamp(0.2 * (y @ P[f"block{i}/gate/dense1/kernel"]) + 0.5, 0.0, 1.0)
                 t = t * y[:, None, None, :]
+        if spec.add_channelwise_scaling:
+            t = scaled(t, f"block{i}/channelwise/w0")
+        if spec.add_learnable_multiplier:
+            t = scaled(t, f"block{i}/multiplier/w0")
+        if training and i in drop_scale:
+            t = t * drop_scale[i].reshape(-1, 1, 1, 1)
         f = t + f
+    if spec.add_final_bn:
+        f = _batch_norm(f, "final_bn", P, S, new_state, training)
+    if spec.add_channelwise_scaling:
+        f = scaled(f, "channelwise/w0")
+    if spec.add_learnable_multiplier:
+        f = scaled(f, "multiplier/w0")
     h = _act(conv_same(f, P["head/conv0/kernel"]), spec.head_activation)
     h = conv_same(h, P["head/conv1/kernel"])
     p = torch.tanh(2.0 * h) * 0.51
@@ -115,6 +138,10 @@ def hydra(spec: R.GenericResnetSpec, P, S, x, training: bool):
 def regularizer_kind(spec: R.GenericResnetSpec, name: str, kind: str):
     if kind == "bn_gamma":
         return None
+    if kind == "channelwise":
+        return "l1_0.1"                      # L1(DEFAULT_CHANNELWISE_MULTIPLIER_L1) (backbone_resnet.py:190-195; constants.py:13)
+    if kind == "multiplier":
+        return "l1_1.0"                      # L1(DEFAULT_MULTIPLIER_L1) (:197-202; constants.py:12)
     if name.startswith("base/"):
         return spec.kernel_regularizer
     if name.startswith("head/"):
@@ -133,19 +160,25 @@ def regularization(spec, P):
             total = total + 0.01 * P[name].abs().sum()
         elif rk == "l2":
             total = total + 0.01 * (P[name] ** 2).sum()
+        elif rk == "l1_0.1":
+            total = total + 0.1 * P[name].abs().sum()
+        elif rk == "l1_1.0":
+            # Multiplier hands its regulariser to the non-trainable w1 (= 1.0) as well (custom_layers.py:1067-1074): a constant 1.0
+            total = total + 1.0 * P[name].abs().sum() + 1.0
         elif rk not in (None, "none"):
             raise ValueError(rk)
     return total
 
 
 def train_step(spec: R.GenericResnetSpec, ls: O.LossSpec, params: np.ndarray, state: np.ndarray, gt: np.ndarray, noisy: np.ndarray,
-               depth_weight: float = 1.0):
+               depth_weight: float = 1.0, drop_scale=None):
     """train_step_single_gpu (bfcnn/train_loop.py:259-312): returns (total, model-loss dict, denoiser-loss dict, prediction,
     flat gradient, new flat state)."""
     flat = torch.tensor(np.asarray(params, np.float64), dtype=DT, requires_grad=True)
     P = views(spec, flat)
     S = state_views(spec, torch.tensor(np.asarray(state, np.float64), dtype=DT))
-    pred, new_state = hydra(spec, P, S, torch.from_numpy(noisy.astype(np.float64)), True)
+    ds = {k: torch.tensor(np.asarray(v, np.float64)) for k, v in (drop_scale or {}).items()}
+    pred, new_state = hydra(spec, P, S, torch.from_numpy(noisy.astype(np.float64)), True, ds)
     dl = T.denoiser_loss(ls, torch.from_numpy(gt.astype(np.float64)), pred)
     reg = regularization(spec, P)
     total = dl["total_loss"] * depth_weight + reg * ls.regularization

@@ -95,7 +95,17 @@ CONFIGS = {
     "bottleneck-64-groups-nobn": dict(filters=64, kernel_size=5, block_kernels=[1, 3, 1], block_filters=[64, 128, 64],
                                       block_depthwise=[-1, 2, -1], block_groups=[2, 1, 4], block_activation=["relu", "relu", "linear"],
                                       block_regularizer=["l1", "l1", "l1"], no_layers=1, use_bn=False),
+    # the builder's remaining flags (backbone_resnet.py:225-242, 264-287): BatchNorm around the blocks, ChannelwiseMultiplier and
+    # Multiplier closing every block and the backbone, RandomOnOff on the branches
+    "bn-around-blocks": dict(no_layers=2, add_initial_bn=True, add_final_bn=True),
+    "multipliers-and-dropout": dict(no_layers=2, add_channelwise_scaling=True, add_learnable_multiplier=True, dropout_rate=0.5),
+    "two-conv-everything": dict(filters=32, kernel_size=3, block_kernels=[3, 3], block_filters=[32, 32], block_depthwise=[-1, -1],
+                                block_groups=[1, 1], block_activation=["relu", "relu"], block_regularizer=["l1", "l2"], no_layers=2,
+                                add_gates=True, add_initial_bn=True, add_final_bn=True, add_channelwise_scaling=True,
+                                add_learnable_multiplier=True, dropout_rate=0.5, base_activation="relu"),
+    "dropout-alone": dict(no_layers=2, dropout_rate=0.5),
 }
+DROP = {0: np.array([2.0, 0.0]), 1: np.array([2.0, 2.0])}
 
 
 def _setup(name, shape, seed):
@@ -111,10 +121,13 @@ def _setup(name, shape, seed):
 def test_train_step_matches_the_gradient_oracle(name):
     cfg, spec, params, state, clean, noisy = _setup(name, (2, 24, 32), 21)
     ls = O.LossSpec.from_config(LOSS)
-    r_total, r_ml, r_dl, r_pred, r_grads, r_state = T.train_step(spec, ls, params, state, clean, noisy)
+    drop = DROP if spec.dropout_rate > 0 else None
+    r_total, r_ml, r_dl, r_pred, r_grads, r_state = T.train_step(spec, ls, params, state, clean, noisy, drop_scale=drop)
     model = bf.model_builder(cfg, device="cuda").hydra
     model.set_weights(params, state)
     fns = bf.build_train_functions(model, bf.loss_function_builder(LOSS))
+    if drop:
+        fns.train_step_single_gpu.drop_scale = {k: torch.from_numpy(v.astype(np.float32)).cuda() for k, v in drop.items()}
     total, ml, dls, pred, grads = fns.train_step_single_gpu(torch.from_numpy(clean.astype(np.float32)), torch.from_numpy(noisy.astype(np.float32)))
     torch.cuda.synchronize()
     assert abs(total.item() - r_total) <= 1e-5 * abs(r_total)

@@ -35,9 +35,21 @@ def test_shipped_config_inventory_and_host_logic():
     bad = G.shipped_config(); bad["backbone"]["block_filters"] = [32, 128, 64]     # residual Add needs `filters` channels
     with pytest.raises(ValueError, match="residual Add"):
         bf.model_builder(bad, device="cpu")
-    bad = G.shipped_config(); bad["backbone"]["add_gelu"] = True
+    bad = G.shipped_config(); bad["backbone"]["add_concat_input"] = True
     with pytest.raises(NotImplementedError):
         bf.model_builder(bad, device="cpu")
+    # flags the builder turns into parameters resnet_blocks_full never reads (backbone_resnet.py:207-223): same graph
+    same = G.shipped_config(); same["backbone"].update(add_gelu=True, add_gradient_dropout=True, add_mean_sigma_normalization=True)
+    assert bf.model_builder(same, device="cpu", seed=0).hydra.trainable_variables == m.trainable_variables
+    # BatchNorm around the blocks, ChannelwiseMultiplier / Multiplier closing every block and the backbone, RandomOnOff
+    full = G.shipped_config(); full["backbone"].update(add_initial_bn=True, add_final_bn=True, add_channelwise_scaling=True,
+                                                         add_learnable_multiplier=True, dropout_rate=0.25)
+    mf, sf = bf.model_builder(full, device="cpu", seed=0).hydra, G.GenericResnetSpec.from_config(full)
+    assert [(v[0], tuple(v[1]), v[2]) for v in mf.trainable_variables] == [(n, tuple(s), k) for n, s, k in sf.tensors()]
+    assert [(v[0], tuple(v[1])) for v in mf.non_trainable_variables] == [(n, tuple(s)) for n, s in sf.state_tensors()]
+    assert mf.count_params() == m.count_params() + 2 * 32 + 7 * (32 + 1)
+    w0 = {v[0]: mf.get_weights()[0][v[3]:v[3] + int(np.prod(v[1]))] for v in mf.trainable_variables if v[2] in ("channelwise", "multiplier")}
+    assert len(w0) == 14 and all((v == 0).all() for v in w0.values())              # zeros at creation (custom_layers.py:1048-1060)
     gated = G.shipped_config(); gated["backbone"]["add_gates"] = True
     mg, sg = bf.model_builder(gated, device="cpu", seed=0).hydra, G.GenericResnetSpec.from_config(gated)
     assert [(v[0], tuple(v[1]), v[2]) for v in mg.trainable_variables] == [(n, tuple(s), k) for n, s, k in sg.tensors()]
@@ -85,10 +97,33 @@ def test_other_resnet_shapes_match_oracle(bb):
     _check(cfg, (1, 48, 64), seed=5)
 
 
+TWO_CONV = dict(filters=32, kernel_size=3, block_kernels=[3, 3], block_filters=[32, 32], block_depthwise=[-1, -1], block_groups=[1, 1],
+                block_activation=["relu", "relu"], block_regularizer=["l1", "l1"], no_layers=2)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("bb", [dict(), dict(filters=32, kernel_size=3, block_kernels=[3, 3], block_filters=[32, 32], block_depthwise=[-1, -1],
-                                             block_groups=[1, 1], block_activation=["relu", "relu"], block_regularizer=["l1", "l1"], no_layers=2)],
-                         ids=["shipped-bottleneck", "two-conv"])
+@pytest.mark.parametrize("bb", [dict(add_initial_bn=True, add_final_bn=True),
+                                dict(add_channelwise_scaling=True, add_learnable_multiplier=True),
+                                dict(add_initial_bn=True, add_final_bn=True, add_channelwise_scaling=True, add_learnable_multiplier=True,
+                                     dropout_rate=0.3, add_gelu=True, add_gradient_dropout=True, add_mean_sigma_normalization=True),
+                                dict(TWO_CONV, add_channelwise_scaling=True, add_gates=True),
+                                dict(TWO_CONV, add_learnable_multiplier=True, add_final_bn=True, base_activation="relu"),
+                                dict(TWO_CONV, add_channelwise_scaling=True, base_activation="gelu"),
+                                dict(add_channelwise_scaling=True, selector_params=dict(scale_type="local", pool_size=(16, 16)))],
+                         ids=["bn-around-blocks", "multipliers-folded", "everything", "gate-then-channelwise", "relu-base-final-bn",
+                              "gelu-base-unfolded", "selector-after-channelwise"])
+def test_builder_flags_match_oracle(bb):
+    """add_initial_bn / add_final_bn (backbone_resnet.py:264-275), add_channelwise_scaling / add_learnable_multiplier closing every block
+    and the backbone (backbone_blocks.py:215-221, backbone_resnet.py:282-287), dropout_rate (identity at inference), the three flags
+    without effect on the graph; multipliers folded into the last convolution where they commute with its activation, their own
+    pass otherwise (behind a gate, GELU)"""
+    cfg = G.shipped_config()
+    cfg["backbone"].update(bb)
+    _check(cfg, (2, 40, 48), seed=13)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bb", [dict(), TWO_CONV], ids=["shipped-bottleneck", "two-conv"])
 def test_add_gates_matches_oracle(bb):
     """the channel gate of backbone_blocks.py:199-208 (mean -> Dense relu -> Dense hard_sigmoid -> Multiply) behind the second
     convolution: in front of the third one, or in front of the Add when the block ends there"""

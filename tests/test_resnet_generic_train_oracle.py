@@ -68,3 +68,58 @@ def test_batchnorm_training_semantics_match_bfcnn_oracle():
     _, _, nm, nv = O.bn_train(t, Pn["block0/bn1/gamma"], S["block0/bn1/moving_mean"].numpy(), S["block0/bn1/moving_variance"].numpy())
     assert np.abs(new["block0/bn1/moving_mean"].numpy() - nm).max() < 1e-12
     assert np.abs(new["block0/bn1/moving_variance"].numpy() - nv).max() < 1e-12
+
+
+FLAGS = dict(add_initial_bn=True, add_final_bn=True, add_channelwise_scaling=True, add_learnable_multiplier=True, dropout_rate=0.5)
+
+
+def test_builder_flags_forward_and_regularisers():
+    """add_initial_bn / add_final_bn, ChannelwiseMultiplier / Multiplier closing every block and the backbone, RandomOnOff: the torch
+    restatement equals the NumPy one at inference; the regularisers are L1(0.1) on a channelwise w0, L1(1.0) on a multiplier w0 plus the
+    constant L1(1.0)|w1 = 1| the Multiplier layer adds for its non-trainable weight (custom_layers.py:1067-1074)"""
+    import torch
+    spec = _spec(False, **FLAGS)
+    names = [n for n, _, _ in spec.tensors()]
+    assert names.index("initial_bn/gamma") == 1 and names[-5:-2] == ["final_bn/gamma", "channelwise/w0", "multiplier/w0"]
+    assert names.index("block0/multiplier/w0") == names.index("block0/channelwise/w0") + 1 == names.index("block1/conv0/kernel") - 1
+    assert [n for n, _ in spec.state_tensors()][:2] == ["initial_bn/moving_mean", "initial_bn/moving_variance"]
+    params, state = R.init_params(spec, seed=4)
+    x = np.random.default_rng(0).uniform(0, 255, (2, 16, 24, 3))
+    a, b = T.infer(spec, params, state, x), R.hydra_forward(spec, params, state, x)
+    assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max())
+    plain = _spec(False)
+    P = T.views(spec, torch.tensor(params.astype(np.float64)))
+    extra = float(T.regularization(spec, P)) - float(T.regularization(plain, {n: P[n] for n, _, _ in plain.tensors()}))
+    w = {n: P[n].numpy() for n, _, k in spec.tensors() if k in ("channelwise", "multiplier")}
+    want = sum(0.1 * np.abs(v).sum() if "channelwise" in n else 1.0 * np.abs(v).sum() + 1.0 for n, v in w.items())
+    assert abs(extra - want) < 1e-9
+
+
+def test_builder_flags_training_step_central_differences():
+    spec = _spec(True, layers=1, **FLAGS)
+    ls = O.LossSpec.from_config({"hinge": 0.5, "cutoff": 255.0, "mae_multiplier": 1.0, "regularization": 0.01})
+    params, state = R.init_params(spec, seed=6)
+    params = params.astype(np.float64)
+    clean, noisy = O.synthetic_batch(2, 12, 12, seed=2)
+    drop = {0: np.array([2.0, 0.0])}
+    total, ml, dl, pred, grads, new_state = T.train_step(spec, ls, params, state, clean, noisy, drop_scale=drop)
+    off = {}
+    o = 0
+    for n, s, k in spec.tensors():
+        off[n] = o
+        o += int(np.prod(s))
+    for name in ("initial_bn/gamma", "final_bn/gamma", "block0/channelwise/w0", "block0/multiplier/w0", "channelwise/w0", "multiplier/w0"):
+        i = off[name]
+        e = 1e-5
+        p1, p2 = params.copy(), params.copy()
+        p1[i] += e
+        p2[i] -= e
+        num = (T.train_step(spec, ls, p1, state, clean, noisy, drop_scale=drop)[0] -
+               T.train_step(spec, ls, p2, state, clean, noisy, drop_scale=drop)[0]) / (2 * e)
+        assert abs(num - grads[i]) <= 3e-3 * max(abs(grads[i]), 1e-3), (name, num, grads[i])
+    # a dropped sample's branch contributes nothing: its prediction does not depend on block 0's weights
+    p3 = params.copy()
+    p3[off["block0/conv0/kernel"]:off["block0/conv0/kernel"] + 64] += 0.1
+    pred3 = T.train_step(spec, ls, p3, state, clean, noisy, drop_scale={0: np.array([0.0, 0.0])})[3]
+    pred0 = T.train_step(spec, ls, params, state, clean, noisy, drop_scale={0: np.array([0.0, 0.0])})[3]
+    assert np.abs(pred3 - pred0).max() < 1e-12
