@@ -84,6 +84,7 @@ SIGNATURES = {
     "bf_op_dwconv_mult": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "bf_op_dwmult_pointwise": (_I, [_P, _P, _P, _P, _I, _F, _P, _P, _I, _F, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "bf_op_maxpool2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "bf_op_maxpool2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "bf_op_norm_smooth_split": (_I, [_P, _P, _F, _I, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "bf_op_upsample_act_add": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "bf_op_resize_bilinear": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

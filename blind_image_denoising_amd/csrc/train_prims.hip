@@ -668,6 +668,43 @@ __global__ void tp_transpose_kernel(const float* __restrict__ w, float* __restri
     out[(e % b) * a + e / b] = w[e];
 }
 
+// adjoint of MaxPooling2D(2, 2, same) (downsampling.py:56-68): the 2 x 2 windows do not overlap, so every input belongs to one
+// window: dx = dy at the window's maximum (the first one in row-major window order on a tie, as TensorFlow's and torch's
+// max-pool gradients route it), 0 elsewhere.  Thread = 4 channels of one OUTPUT element.
+__global__ __launch_bounds__(256) void tp_maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                                              int B, int H, int W, int C)
+{
+    const int Cv = C / 4, OH = (H + 1) / 2, OW = (W + 1) / 2;
+    const int64_t n = (int64_t)B * OH * OW * Cv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % Cv);
+        int64_t t = i / Cv;
+        const int ox = (int)(t % OW); t /= OW;
+        const int oy = (int)(t % OH);
+        const int b = (int)(t / OH);
+        const int64_t base = (int64_t)b * H * W * Cv + c;
+        const f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int arg[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 4; ++k) {
+            const int yy = 2 * oy + (k >> 1), xx = 2 * ox + (k & 1);
+            if (yy >= H || xx >= W) continue;
+            const f32x4 v = reinterpret_cast<const f32x4*>(x)[base + ((int64_t)yy * W + xx) * Cv];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (v[j] > best[j]) { best[j] = v[j]; arg[j] = k; }
+        }
+        for (int k = 0; k < 4; ++k) {
+            const int yy = 2 * oy + (k >> 1), xx = 2 * ox + (k & 1);
+            if (yy >= H || xx >= W) continue;
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = arg[j] == k ? g[j] : 0.f;
+            reinterpret_cast<f32x4*>(dx)[base + ((int64_t)yy * W + xx) * Cv] = o;
+        }
+    }
+}
+
 }  // namespace
 
 #define TP_OK() (hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP)
@@ -930,5 +967,14 @@ extern "C" int bf_op_transpose2d(const float* w, float* out, int a, int b, void*
 {
     if (!w || !out || a <= 0 || b <= 0) return BF_EINVAL;
     hipLaunchKernelGGL(tp_transpose_kernel, dim3((a * b + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, out, a, b);
+    return TP_OK();
+}
+
+extern "C" int bf_op_maxpool2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, void* stream)
+{
+    if (!x || !dy || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4) return BF_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) % 16) return BF_EINVAL;
+    const int64_t n = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+    hipLaunchKernelGGL(tp_maxpool2_bwd_kernel, dim3(tp_grid(n)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, B, H, W, C);
     return TP_OK();
 }

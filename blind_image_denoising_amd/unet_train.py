@@ -12,8 +12,8 @@ LayerNorm + activation, the averaging / Gaussian Laplacian split, strided down-s
 per-scale denoiser heads, AdditiveAttentionGate in front of the decoder Add (v3 / v4) -- with any depth / width / filters.
 The graph revision of the reference's trained archive (tests/golden/unet_v56.npz: GELU in the MLP and on query / key / value,
 row-wise full-resolution attention with a second LayerNorm, no level activation, 1x1-then-resize up-sampling, the output
-LayerNorms in front of the heads) trains as well, so the shipped network can be fine-tuned.  Mix projections and the other
-resamplers raise NotImplementedError (inference covers them).
+LayerNorms in front of the heads) trains as well, so the shipped network can be fine-tuned.  So do mix projections, maxpool
+down-sampling and plain bilinear / nearest up-sampling; conv2d_transpose up-sampling raises NotImplementedError (as in inference).
 
 Exact fp32 throughout (the split-f16 inference operators are not used here): gradients are compared with the torch-autograd
 oracle (oracle/unet_torch.py) in tests/test_gpu_unet_train.py.
@@ -118,9 +118,9 @@ class UnetTrainGraph:
     def __init__(self, model: "UL.UnetLaplacianHydra", loss_config: Dict, soft_orthonormal: Optional[bool] = None):
         self.m = model
         bad = []
-        if getattr(model, "use_mix_project", False): bad.append("use_mix_project")
-        if model.downsample_type not in ("strides", "conv2d"): bad.append(f"downsample_type {model.downsample_type}")
-        if model.upsample_type not in ("upsample_laplacian_conv2d", "upsample_nearest_conv2d", "upsample_bilinear_conv2d"):
+        if model.downsample_type not in ("strides", "conv2d", "maxpool"): bad.append(f"downsample_type {model.downsample_type}")
+        if model.upsample_type not in ("upsample_laplacian_conv2d", "upsample_nearest_conv2d", "upsample_bilinear_conv2d", "bilinear",
+                                       "nn", "nearest"):
             bad.append(f"upsample_type {model.upsample_type}")
         if model.activation == "gelu": bad.append("gelu outside the convnext MLP / the attention projections")
         if model.activation == "linear": bad.append("linear activation")
@@ -431,13 +431,22 @@ class UnetTrainGraph:
                 x = UL.dwconv_ln(y, None, None, la)
                 enc_chain.append(("op", (lambda yy: (lambda dy: ops.act_bwd(yy, dy, la)))(x)))
             if d != m.depth - 1:
-                ds = 2 if m.downsample_type == "strides" else 1              # conv2d takes the full-resolution smooth map
+                ds = 2 if m.downsample_type == "strides" else 1              # conv2d / maxpool take the full-resolution smooth map
                 lp, down = UL.smooth_split(x, k_g, gauss, ds)
                 lap[d] = lp
                 Bx, Hx, Wx, Cx = x.shape
                 enc_chain.append(("split", d, (Bx, Hx, Wx, Cx), ds))
                 if ds == 2:
                     x, b_ = conv1x1_act(f"down{d}/kernel", down, m.level_filters(d + 1), a)
+                elif m.downsample_type == "maxpool":                        # MaxPooling2D(2, 2, same) + 1x1 (downsampling.py:56-68)
+                    x, b_c = conv1x1_act(f"down{d}/kernel", UL.maxpool2(down), m.level_filters(d + 1), a)
+
+                    def b_(dy, down=down, b_c=b_c):
+                        dmp = b_c(dy)
+                        dd = torch.empty_like(down)
+                        _call("bf_op_maxpool2_bwd", N.ptr(down), N.ptr(dmp), N.ptr(dd), down.shape[0], down.shape[1], down.shape[2],
+                              down.shape[3], N.stream_ptr(dmp))
+                        return dd
                 else:
                     x, b_ = conv2x2_s2_act(f"down{d}/kernel", down, m.level_filters(d + 1), a)
                 enc_chain.append(("op", b_))
@@ -451,7 +460,14 @@ class UnetTrainGraph:
             Cc = m.level_filters(d)
             bil = m.upsample_type != "upsample_nearest_conv2d"
             conv_first = m.upsample_type == "upsample_laplacian_conv2d" and m.upsample_linear   # upsampling.py:80-90: 1x1, then resize
-            if conv_first:
+            plain = m.upsample_type in ("bilinear", "nn", "nearest")          # UpSampling2D alone (upsampling.py:103-116)
+            if plain:
+                if low.shape[-1] != Cc:
+                    raise ValueError(f"Add of [{Cc}] and [{low.shape[-1]}] channels: upsample_type [{m.upsample_type}] needs equal "
+                                     f"filters on both levels")
+                bil = m.upsample_type == "bilinear"
+                up, b_up = upsample_2x(low, bilinear=bil), (lambda g_: g_)
+            elif conv_first:
                 c_, b_up = conv1x1_act(f"up{d}/kernel", low, Cc, "linear")
                 up = upsample_2x(c_, bilinear=True)
             elif m.upsample_type == "upsample_laplacian_conv2d":
@@ -464,6 +480,9 @@ class UnetTrainGraph:
             else:
                 x = ops.add(lap[d], up)
             chain = [("up", b_up, low.shape, bil, b_gate, conv_first)]
+            if m.use_mix_project:                                             # backbone_unet_laplacian.py:521-527
+                x, b_ = conv1x1_act(f"mix{d}/kernel", x, Cc, a)
+                chain.append(("op", b_))
             for w_ in range(m.width):
                 x, b_ = convnext(f"dec{d}_{w_}", x, m.dec_k)
                 chain.append(("op", b_))

@@ -355,6 +355,9 @@ int bf_op_smooth_split_bwd(const float* dlap, const float* ddown, const float* g
    smooth[:, ::2, ::2] (2); averaging windows of any size k <= 7 (TF same padding: the extra tap after for even k) */
 int bf_op_smooth_split_bwd_ex(const float* dlap, const float* ddown, const float* gauss, float* dx, int batch, int height, int width,
                               int channels, int k, int down_stride, void* stream);
+/* adjoint of MaxPooling2D(2, 2, same) (bfcnn/downsampling.py:56-68): dx [B,H,W,C] = dy [B,ceil(H/2),ceil(W/2),C] at each window's
+   first maximum, 0 elsewhere */
+int bf_op_maxpool2_bwd(const float* x, const float* dy, float* dx, int batch, int height, int width, int channels, void* stream);
 /* adjoint of UpSampling2D(2, bilinear | nearest): dx [B,H,W,C] from dy [B,2H,2W,C] */
 int bf_op_upsample2x_bwd(const float* dy, float* dx, int batch, int height, int width, int channels, int bilinear, void* stream);
 /* k x k convolution (same, stride 1) weight gradient for the first convolution; x = the raw image, normalised as the forward does */

@@ -103,9 +103,8 @@ def check_trainable_graph(spec: U.UnetLaplacianSpec):
     """the graph family the training path is built for (configs/unet_laplacian_v5.json and its depth / width / filter
     variations)."""
     bad = []
-    if spec.use_mix_project: bad.append("use_mix_project")
-    if spec.downsample_type not in ("strides", "conv2d"): bad.append(f"downsample_type {spec.downsample_type}")
-    if spec.upsample_type not in ("upsample_laplacian_conv2d", "upsample_nearest_conv2d", "upsample_bilinear_conv2d"):
+    if spec.downsample_type not in ("strides", "conv2d", "maxpool"): bad.append(f"downsample_type {spec.downsample_type}")
+    if spec.upsample_type not in ("upsample_laplacian_conv2d", "upsample_nearest_conv2d", "upsample_bilinear_conv2d", "bilinear", "nn", "nearest"):
         bad.append(f"upsample_type {spec.upsample_type}")
     if not (spec.use_laplacian or spec.use_laplacian_averaging): bad.append("no laplacian split")
     if bad:
@@ -175,6 +174,9 @@ def backbone(spec, P, xn, depth_scale=None, attn_scale=None):
             nodes[d] = x - smooth
             if spec.downsample_type == "strides":
                 x = _act(_conv(smooth[:, ::2, ::2, :], P[f"down{d}/kernel"]), a)
+            elif spec.downsample_type == "maxpool":                   # MaxPooling2D(2, 2, same) + 1x1 (downsampling.py:56-68)
+                mp = F.max_pool2d(smooth.permute(0, 3, 1, 2), 2, 2, ceil_mode=True).permute(0, 2, 3, 1)
+                x = _act(_conv(mp, P[f"down{d}/kernel"]), a)
             else:                                                     # conv2d: 2 x 2, strides 2, same (downsampling.py:45-55)
                 x = _act(_conv(smooth, P[f"down{d}/kernel"], stride=2), a)
     outs = {spec.depth - 1: nodes[spec.depth - 1]}
@@ -182,6 +184,8 @@ def backbone(spec, P, xn, depth_scale=None, attn_scale=None):
         low = outs[d + 1]
         if spec.upsample_type == "upsample_laplacian_conv2d" and (a == "linear" or spec.upsample_linear):   # upsampling.py:80-90
             up = _up2(_conv(low, P[f"up{d}/kernel"]))
+        elif spec.upsample_type in ("bilinear", "nn", "nearest"):     # UpSampling2D alone (upsampling.py:103-116)
+            up = _up2(low) if spec.upsample_type == "bilinear" else _up2_nearest(low)
         else:
             up = _act(_conv(_up2_nearest(low) if spec.upsample_type == "upsample_nearest_conv2d" else _up2(low), P[f"up{d}/kernel"]), a)
         enc = nodes[d]
@@ -192,6 +196,8 @@ def backbone(spec, P, xn, depth_scale=None, attn_scale=None):
             o = _multiplier(_conv(torch.where(z > 0, z, 0.1 * z), P[f"gate{d}/o/kernel"]), P[f"gate{d}/scale/w"])
             enc = enc * torch.sigmoid(4.0 * o)
         x = enc + up
+        if spec.use_mix_project:                                      # backbone_unet_laplacian.py:521-527
+            x = _act(_conv(x, P[f"mix{d}/kernel"]), a)
         for w in range(spec.width):
             pre = f"dec{d}_{w}"
             x = x + branch(pre, convnext(pre, x))

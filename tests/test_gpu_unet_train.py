@@ -227,6 +227,19 @@ def test_train_step_with_attention_gates(depth, backbone):
     _check_step(spec, params, model, clean, noisy, LOSS_V5, [1.0, 0.6, 0.3, 0.1][:depth])
 
 
+@pytest.mark.parametrize("backbone", [{"use_mix_project": True}, {"downsample_type": "maxpool"},
+                                      {"upsample_type": "bilinear", "filters_level_multiplier": 1.0},
+                                      {"upsample_type": "nearest", "filters_level_multiplier": 1.0, "use_mix_project": True,
+                                       "downsample_type": "maxpool", "activation": "relu"}],
+                         ids=["mix-project", "maxpool-down", "plain-bilinear-up", "nearest-maxpool-mix-relu"])
+def test_train_step_with_the_remaining_graph_options(backbone):
+    """use_mix_project (1x1 + activation behind the decoder Add, backbone_unet_laplacian.py:521-527), MaxPooling2D + 1x1 down-sampling
+    (downsampling.py:56-68; ReLU maps tie at zero inside a window: the gradient goes to the first maximum), UpSampling2D alone as the
+    up-sampler (upsampling.py:103-116; equal filters on every level)"""
+    cfg, spec, params, model, clean, noisy = _setup(3, 1, 32, 32, backbone=backbone)
+    _check_step(spec, params, model, clean, noisy, LOSS_V5, [1.0, 0.6, 0.3])
+
+
 def test_train_step_with_stochastic_depth_and_attention_dropout():
     """training-mode randomness as explicit inputs: per-sample StochasticDepth scales (0 or 1 / (1 - rate)) and the attention's
     dropout keep-mask / keep-probability"""
