@@ -438,6 +438,15 @@ def test_full_size_config_512_batch_properties_and_256_oracle():
     full = mod(big)
     assert full.shape == big.shape and np.array_equal(full, mod(big))
     assert np.array_equal(full[2:3], mod(big[2:3]))
+    # the batch of the config itself: 32 x 512 x 512 (the three images above tiled; device tensors in, device tensor out)
+    import torch
+    b32 = torch.from_numpy(np.concatenate([big] * 11)[:32]).cuda()
+    out32 = mod(b32)
+    assert out32.shape == b32.shape and out32.dtype == torch.uint8 and torch.equal(out32, mod(b32))
+    got = out32.cpu().numpy()
+    for i in (0, 1, 2, 17, 31):                                   # image i of the batch = image i % 3 on its own
+        assert np.array_equal(got[i], full[i % 3]), i
+    assert m.check_status()
 
 
 def test_shape_and_config_errors():
