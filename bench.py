@@ -499,10 +499,11 @@ def self_launch(n):
     raise SystemExit(proc.returncode)
 
 
-def sub_record(model, module, noisy, noisy_host, spec, params, state, O, N, torch, arith, steps, warmup, S):
-    """one more timed loop of the default workload on `model` with another arithmetic / batch (rank 0, N = 1)."""
+def sub_record(model, module, noisy, noisy_host, spec, params, state, O, N, torch, arith, steps, warmup, S, compact=0):
+    """one more timed loop of the default workload on `model` with another arithmetic / batch / activation layout (rank 0, N = 1)."""
     B = int(noisy.shape[0])
     model.set_option("arith", arith)
+    model.set_option("h3_compact", compact)
     model.set_option("timing", 1)
     for _ in range(warmup):
         out = module(noisy)
@@ -533,7 +534,14 @@ def sub_record(model, module, noisy, noisy_host, spec, params, state, O, N, torc
                                  "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                  "launch_us": launch_s * 1e6, "traffic": None,
                                  "mfma_algorithmic_tflops": px * FLOP_PER_PX_BLOCK / launch_s / 1e12}})
+    if compact:
+        # 48 instead of 64 bytes per pixel between the launches (fp8 lo planes): `achieved` stays on the ALGORITHMIC 128 B per pixel and
+        # block of SURVEY 8(d), `stored_gbs` is what the layout actually moves
+        rec["activation_layout"] = "compact split-planar: f16 hi planes + fp8 (e4m3, x 2^12) lo planes, 48 B per pixel"
+        rec["roofline"]["stored_bytes_per_px_block"] = 96
+        rec["roofline"]["stored_gbs"] = px * 96 / launch_s / 1e9
     model.set_option("arith", 1)
+    model.set_option("h3_compact", 0)
     return rec
 
 
@@ -708,12 +716,15 @@ def main():
             #   fp32_exact : --arith 0, exact fp32 on the f32 matrix cores (fused_block_v4_kernel), vs the 157.3 TF fp32 MFMA peak
             #   batch64    : default arithmetic at batch 64 (BASELINE.json north_star: "1x18 resnet 3x3 conv stack at batch 64")
             #   fp32_exact_batch64 : the exact-fp32 kernel at that batch (the north star's ">= 60 % MFMA roofline" reading)
+            #   compact24  : default arithmetic, activations between the launches as f16 hi + fp8 lo planes (set_option h3_compact 1)
             result["fp32_exact"] = sub_record(model, module, noisy, noisy_host, spec, params, state, O, N, torch, arith=0,
                                               steps=max(args.steps // 4, 10), warmup=max(args.warmup // 4, 3), S=S)
             result["fp32_exact_batch64"] = sub_record(model, module, noisy[:64].contiguous(), noisy_host[:64], spec, params, state, O, N,
                                                       torch, arith=0, steps=max(args.steps // 4, 10), warmup=max(args.warmup // 4, 3), S=S)
             result["batch64"] = sub_record(model, module, noisy[:64].contiguous(), noisy_host[:64], spec, params, state, O, N, torch,
                                            arith=1, steps=max(args.steps // 2, 10), warmup=max(args.warmup // 2, 3), S=S)
+            result["compact24"] = sub_record(model, module, noisy, noisy_host, spec, params, state, O, N, torch, arith=1,
+                                             steps=max(args.steps // 2, 10), warmup=max(args.warmup // 2, 3), S=S, compact=1)
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

@@ -37,6 +37,46 @@ inline hipError_t bf_set_max_lds(const void* kernel, int bytes)
     return e;
 }
 
+// ------------------------------------------------------------------------------------------
+// Compact split-planar activations ("h3c": 48 instead of 64 bytes per pixel).  The hi planes stay f16; a lo plane holds the
+// OCP fp8 (e4m3) number nearest to lo * 2^12, 8 bytes per pixel: lo is the rounding residual of hi (|lo| <= 2^-11 |x|), three
+// mantissa bits of it keep the pair at 15-16 significant bits.  Sized on the CPU before it was built
+// (tools/exp/emulate_f16x3.py, storage fp8lo): 5.8e-6 normalised MAE through 1x18 against the fp64 oracle, max 1 LSB (bar 1e-4;
+// 2.2e-7 with f16 lo planes).  v_cvt_scalef32_pk_fp8_f16 does not saturate (|lo| * 2^12 > 448 would become NaN: |x| > 224), so
+// lo is clamped first; a clamped lo leaves x at f16 precision, and inf / NaN still travel in the hi plane to the status check.
+// Semantics of the two conversions probed in tools/exp/fp8_probe.hip: encode = fp8(src / scale) into the selected 16-bit half,
+// decode = fp8 * scale from the selected half; element 0 in the low byte.
+// ------------------------------------------------------------------------------------------
+typedef _Float16 bf_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 bf_h2 __attribute__((ext_vector_type(2)));
+typedef short bf_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned bf_u2 __attribute__((ext_vector_type(2)));
+#define BF_H3C_SCALE (1.0f / 4096.0f)
+__device__ __forceinline__ bf_u2 bf_h3c_encode8(const bf_h8 v)
+{
+    const bf_h2 lim = {(_Float16)(448.0f / 4096.0f), (_Float16)(448.0f / 4096.0f)};
+    bf_h2 p[4] = {{v[0], v[1]}, {v[2], v[3]}, {v[4], v[5]}, {v[6], v[7]}};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = __builtin_elementwise_min(__builtin_elementwise_max(p[i], -lim), lim);
+    bf_s2 r0 = {0, 0}, r1 = {0, 0};
+    r0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r0, p[0], BF_H3C_SCALE, false);
+    r0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r0, p[1], BF_H3C_SCALE, true);
+    r1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r1, p[2], BF_H3C_SCALE, false);
+    r1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r1, p[3], BF_H3C_SCALE, true);
+    bf_u2 out;
+    out[0] = ((unsigned)(unsigned short)r0[0]) | ((unsigned)(unsigned short)r0[1] << 16);
+    out[1] = ((unsigned)(unsigned short)r1[0]) | ((unsigned)(unsigned short)r1[1] << 16);
+    return out;
+}
+__device__ __forceinline__ bf_h8 bf_h3c_decode8(const bf_u2 b)
+{
+    const bf_h2 a0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(b[0], BF_H3C_SCALE, false);
+    const bf_h2 a1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(b[0], BF_H3C_SCALE, true);
+    const bf_h2 a2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(b[1], BF_H3C_SCALE, false);
+    const bf_h2 a3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(b[1], BF_H3C_SCALE, true);
+    return (bf_h8){a0[0], a0[1], a1[0], a1[1], a2[0], a2[1], a3[0], a3[1]};
+}
+
 #define BF_C 16             // feature channels of the MFMA path (filters == 16)
 #define BF_WPACK_FLOATS (36 * 64)   // one 3x3 16->16 kernel as MFMA A-operand register images
 
@@ -108,8 +148,12 @@ struct FusedH3Args {
     int head_u8, Ho, Wo, denormalize;
     float v_min, v_max;
     int* status;           // |= BF_STATUS_F16_RANGE when a block output is not finite
+    int compact = 0;       // full-row streaming kernel only: in / out are compact split-planar (fp8 lo planes, see bf_h3c_encode8)
 };
 hipError_t bf_launch_fused_block_h3(const FusedH3Args& a, hipStream_t s);
+// true when bf_launch_fused_block_h3 would run the full-row streaming kernel for these arguments (the one kernel that reads and
+// writes the compact layout)
+bool       bf_fused_block_h3_is_streaming(const FusedH3Args& a);
 // library default of FusedH3Args::variant (handle-less debug entries): 4 = full-row streaming kernel where it applies
 // (W <= 256), 1 = row-streaming tile kernel, 0 / 2 / 3 = earlier tile kernels (A/B only)
 void       bf_set_h3_variant(int v);
@@ -170,7 +214,7 @@ struct BaseConvArgs {
     const void* in; float* out; const float* w;  // w: [k,k,cin,16] HWIO
     int B, Hs, Ws, H, W, cin, k, in_is_u8, act_relu;
     float v_min, v_max;
-    int out_split;        // 1: write split-planar f16 hi/lo (input of the f16x3 blocks) instead of fp32 NHWC
+    int out_split;        // 1: write split-planar f16 hi/lo (input of the f16x3 blocks) instead of fp32 NHWC; 2: compact (fp8 lo planes)
     int* status;          // inference: forward status word, zeroed here (first kernel of a forward); may be NULL
 };
 hipError_t bf_launch_base_conv(const BaseConvArgs& a, hipStream_t s);
@@ -187,7 +231,7 @@ struct HeadArgs {
     void* out;            // u8 or f32 [B,Ho,Wo,cout]
     int B, H, W, Ho, Wo, hf, cout, act, out_is_u8, denormalize;
     float v_min, v_max, leaky_alpha;
-    int feat_split;       // 1: feat is split-planar f16 hi/lo
+    int feat_split;       // 1: feat is split-planar f16 hi/lo; 2: compact split-planar (fp8 lo planes)
     int* status;          // |= BF_STATUS_F16_RANGE when a split-planar feature is not finite (f16 overflow upstream); may be NULL
 };
 #define BF_STATUS_BYTES 2048  // tail of the inference workspace: [0] status word, [1024, 2048) store sink of out-of-image lanes

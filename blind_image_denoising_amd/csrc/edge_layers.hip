@@ -93,6 +93,12 @@ __global__ __launch_bounds__(256) void base_conv_kernel(BaseConvArgs a)
             }
             *reinterpret_cast<h8*>(base) = hi[0];
             *reinterpret_cast<h8*>(base + hw * 16) = hi[1];
+            if (a.out_split == 2) {                                  // compact: fp8 lo planes of 8 bytes per pixel
+                char* lob = reinterpret_cast<char*>(a.out) + (int64_t)b * hw * 64 + hw * 32 + ((int64_t)y * a.W + x) * 8;
+                *reinterpret_cast<bf_u2*>(lob) = bf_h3c_encode8(lo[0]);
+                *reinterpret_cast<bf_u2*>(lob + hw * 8) = bf_h3c_encode8(lo[1]);
+                return;
+            }
             *reinterpret_cast<h8*>(base + hw * 32) = lo[0];
             *reinterpret_cast<h8*>(base + hw * 48) = lo[1];
             return;
@@ -281,7 +287,15 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a)
             const int64_t hw = (int64_t)a.H * a.W;
             const char* base = reinterpret_cast<const char*>(a.feat) + (int64_t)b * hw * 64 + ((int64_t)y * a.W + x) * 16;
             const h8 hi0 = *reinterpret_cast<const h8*>(base), hi1 = *reinterpret_cast<const h8*>(base + hw * 16);
-            const h8 lo0 = *reinterpret_cast<const h8*>(base + hw * 32), lo1 = *reinterpret_cast<const h8*>(base + hw * 48);
+            h8 lo0, lo1;
+            if (a.feat_split == 2) {
+                const char* lob = reinterpret_cast<const char*>(a.feat) + (int64_t)b * hw * 64 + hw * 32 + ((int64_t)y * a.W + x) * 8;
+                lo0 = bf_h3c_decode8(*reinterpret_cast<const bf_u2*>(lob));
+                lo1 = bf_h3c_decode8(*reinterpret_cast<const bf_u2*>(lob + hw * 8));
+            } else {
+                lo0 = *reinterpret_cast<const h8*>(base + hw * 32);
+                lo1 = *reinterpret_cast<const h8*>(base + hw * 48);
+            }
             bool finite = true;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {

@@ -1433,6 +1433,12 @@ static hipError_t launch_h3(void (*kernel)(FusedH3Args), const FusedH3Args& a, h
     return hipGetLastError();
 }
 
+bool bf_fused_block_h3_is_streaming(const FusedH3Args& a)
+{
+    const int variant = (a.variant >= 0 ? a.variant : (g_h3_variant >= 0 ? g_h3_variant : h3_default_variant(a))) & 255;
+    return variant == 4 && !a.head_wh && bf_fused_block_h3v_supports(a.H, a.W);
+}
+
 hipError_t bf_launch_fused_block_h3(const FusedH3Args& args, hipStream_t s)
 {
     FusedH3Args a = args;
@@ -1443,6 +1449,7 @@ hipError_t bf_launch_fused_block_h3(const FusedH3Args& args, hipStream_t s)
     variant &= 255;
     // full-row streaming kernel: images up to 256 columns, no head epilogue (the tile kernel below takes the rest)
     if (variant == 4 && !a.head_wh && bf_fused_block_h3v_supports(a.H, a.W)) return bf_launch_fused_block_h3v(a, s);
+    if (a.compact) return hipErrorInvalidValue;                 // only the streaming kernel reads the compact layout
     if (variant == 2) {                                    // two 4-wave workgroups per CU on 16x16 tiles
         using Cfg = H3Small;
         a.tiles_x = (a.W + Cfg::TW - 1) / Cfg::TW;

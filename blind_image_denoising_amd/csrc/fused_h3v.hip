@@ -448,6 +448,73 @@ struct H3VRoleC {
         }
     }
 
+    // ---- compact layout (a.compact; bf_common.h): the lo planes are fp8 in memory, 8 bytes per pixel.  LDS-DMA cannot convert, so
+    // the loader of the lo planes (wave 9) takes them through registers: lane l owns the pixel pairs 2 (64 jj + l), +1 of both
+    // planes (one 16-byte load each), requests row s+3 in step s, and in step s+1 -- a whole step later, the data has arrived --
+    // decodes it to f16 and writes it to the ring: row s+2 is complete at the end of step s, one step before conv1 reads it
+    // (the DMA rows are complete one step later).  The storer of the lo planes (wave 11) encodes while it stores.
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 lo_raw[2][2];                   // [plane - 2][jj]: two pixels x 8 fp8 of ring row "pending"
+
+    __device__ __forceinline__ void lo_request(const H3VTile& t, const int r)
+    {
+        const int y = t.y(r - 2);
+        const bool ok = (y >= 0) & (y < a.H) & (r < t.nrows + 4);                   // wave-uniform
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const char* base = reinterpret_cast<const char*>(a.in) + t.img + 2 * (size_t)plane_g + (size_t)pl * (plane_g / 2) +
+                               (size_t)(ok ? y : 0) * a.W * 8;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int px = 2 * (64 * jj + lane);
+                u4 v = {0u, 0u, 0u, 0u};
+                if (ok && (FULLW || px < a.W)) v = *reinterpret_cast<const u4*>(base + (size_t)px * 8);
+                if (!FULLW) {
+                    if (px + 1 >= a.W) { v[2] = 0u; v[3] = 0u; }
+                }
+                lo_raw[pl][jj] = v;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void lo_commit(const int slot) const
+    {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const u4 v = lo_raw[pl][jj];
+                char* dst = tin + (2 + pl) * Gm::IN_PLANE + slot * Gm::PITCH + (1 + 2 * (64 * jj + lane)) * 16;
+                *reinterpret_cast<h8*>(dst) = bf_h3c_decode8((bf_u2){v[0], v[1]});
+                *reinterpret_cast<h8*>(dst + 16) = bf_h3c_decode8((bf_u2){v[2], v[3]});
+            }
+    }
+
+    __device__ __forceinline__ void lo_store_row(const H3VTile& t, const int o, const int oslot) const
+    {
+        if (H3V_ABLATE & 2) return;
+        const bool ok = (o >= 0) & (o < t.nrows);                                    // wave-uniform
+        if (!ok) return;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            char* base = reinterpret_cast<char*>(a.out) + t.img + 2 * (size_t)plane_g + (size_t)pl * (plane_g / 2) + (size_t)t.y(o) * a.W * 8;
+            h8 rec[2][2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const char* src = tout + oslot * Gm::OUT_SLOT + (2 + pl) * Gm::OUT_PLANE + 2 * (64 * jj + lane) * 16;
+                rec[jj][0] = *reinterpret_cast<const h8*>(src);
+                rec[jj][1] = *reinterpret_cast<const h8*>(src + 16);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int px = 2 * (64 * jj + lane);
+                const bf_u2 e0 = bf_h3c_encode8(rec[jj][0]), e1 = bf_h3c_encode8(rec[jj][1]);
+                if (FULLW || px + 1 < a.W) *reinterpret_cast<u4*>(base + (size_t)px * 8) = (u4){e0[0], e0[1], e1[0], e1[1]};
+                else if (px < a.W) *reinterpret_cast<bf_u2*>(base + (size_t)px * 8) = e0;
+            }
+        }
+    }
+
     // output row o (image row y0 + o) from staging slot `oslot` to global memory
     __device__ __forceinline__ void store_row(const H3VTile& t, const int o, const int oslot) const
     {
@@ -587,9 +654,15 @@ __global__ __launch_bounds__(H3VGeom::NT, 3) void fused_block_h3v_kernel(FusedH3
             Cv.col_ok[j] = 64 * j + lane < a.W;
         }
         constexpr int INFLIGHT = 2 * 2 * Gm::PIECES;           // pieces of the two rows younger than the one awaited
+        const bool lo_regs = a.compact && Cv.plane0 == 2;      // compact layout: this wave's planes are the fp8 lo planes
         for (int ti = blockIdx.x; ti < a.ntiles; ti += gridDim.x) {
             const H3VTile t = h3v_tile(a, ti);
-            if (loader) {
+            if (loader && lo_regs) {
+                // prologue: rows 0 and 1 decoded into their slots, row 2 requested
+                Cv.lo_request(t, 0); Cv.lo_commit(0);
+                Cv.lo_request(t, 1); Cv.lo_commit(1);
+                Cv.lo_request(t, 2);
+            } else if (loader) {
                 // prologue: rows 0 .. PD-1 requested, row 0 landed
 #pragma unroll
                 for (int r = 0; r < Gm::PD; ++r) Cv.dma_row(t, r, r);
@@ -602,12 +675,19 @@ __global__ __launch_bounds__(H3VGeom::NT, 3) void fused_block_h3v_kernel(FusedH3
 #define H3V_STEP_C(PH)                                                                                        \
                 do {                                                                                          \
                     const int s = s0 + PH;                                                                    \
-                    if (loader) {                                                                             \
+                    if (loader && lo_regs) {                                                                  \
+                        Cv.lo_commit(h3v_wrap(dslot + Gm::NRI - 1, Gm::NRI));    /* row s+2, requested a step ago */ \
+                        Cv.lo_request(t, s + Gm::PD);                                                         \
+                        H3V_STAMP(0);                                                                         \
+                    } else if (loader) {                                                                      \
                         Cv.dma_row(t, s + Gm::PD, dslot);                                                     \
                         H3V_STAMP(0);                                                                         \
                         /* row s+1 (requested two steps ago) has landed <=> at most the two younger rows are outstanding */ \
                         __builtin_amdgcn_s_waitcnt(h3_vmcnt((H3V_ABLATE & 1) ? 0 : INFLIGHT));                 \
                         H3V_STAMP(1);                                                                         \
+                    } else if (lo_regs) {                                                                     \
+                        Cv.lo_store_row(t, s - 6, PH % Gm::NRO);                                              \
+                        H3V_STAMP(0);                                                                         \
                     } else {                                                                                  \
                         Cv.store_row(t, s - 6, PH % Gm::NRO);    /* staged by B in step s-1: (s - 6) mod 2 */ \
                         H3V_STAMP(0);                                                                         \

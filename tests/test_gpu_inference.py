@@ -184,6 +184,54 @@ def test_full_size_config_properties():
         assert np.abs(out.astype(int) - out2.astype(int)).max() <= 1
 
 
+@pytest.mark.parametrize("shape,no_layers", [((12, 256, 256), 18), ((16, 192, 200), 6), ((13, 240, 199), 3), ((3100, 1, 7), 2)],
+                         ids=["full-width", "narrower", "odd-width", "one-row-images"])
+def test_compact_activation_layout(shape, no_layers):
+    """set_option("h3_compact", 1): between the launches of the full-row streaming kernel the lo planes travel as fp8 (e4m3 of
+    lo * 2^12, 48 instead of 64 bytes per pixel; csrc/bf_common.h).  Same bars as the default layout against the oracle (north star:
+    +-1 LSB, normalised MAE <= 1e-4; the emulation of tools/exp/emulate_f16x3.py predicts 6e-6), all columns / rows of ragged
+    sizes, bottom-up bands on alternate blocks, values beyond the fp8 range of lo (|x| > 224) degrading to f16 precision, and the
+    f16-range status still raised through the hi planes."""
+    cfg, spec, params, state, m = _model(no_layers, seed=31)
+    B, H, W = shape
+    _, noisy = O.synthetic_batch(B, H, W, seed=77)
+    x = noisy.astype(np.float32)
+    ref = O.hydra_forward(spec, params, state, x[:2].astype(np.float64))
+    plain = np.asarray(m(x), np.float64)
+    m.set_option("h3_compact", 1)
+    got = np.asarray(m(x), np.float64)
+    assert got.shape == plain.shape and np.isfinite(got).all()
+    assert not np.array_equal(got, plain)                                     # the other layout did run
+    assert np.abs(got[:2] - ref).mean() / 255.0 <= 1e-4 and np.abs(got[:2] - ref).max() / 255.0 <= 2e-3
+    assert np.abs(got - plain).mean() / 255.0 <= 5e-5
+    u8 = bf.DenoiserModule(m)(noisy)
+    _check_u8(u8[:2], O.denoiser_module_call(spec, params, state, noisy[:2]))
+    assert np.array_equal(bf.DenoiserModule(m)(noisy[::-1].copy())[::-1], u8)  # deterministic, position independent
+    m.set_option("h3_compact", 0)
+    assert np.array_equal(np.asarray(m(x), np.float64), plain)
+
+
+def test_compact_activation_layout_large_values_and_status():
+    cfg, spec, params, state, m = _model(3, seed=9)
+    big = params.copy()
+    o, shape = spec.offsets()["base/kernel"]
+    big[o:o + int(np.prod(shape))] *= 400.0                                    # activations in the hundreds: lo beyond the fp8 range
+    m.set_weights(big, state)
+    m.set_option("h3_compact", 1)
+    _, noisy = O.synthetic_batch(16, 192, 64, seed=4)
+    x = noisy.astype(np.float32)
+    ref = O.hydra_forward(spec, big, state, x[:1].astype(np.float64))
+    got = np.asarray(m(x), np.float64)
+    assert np.isfinite(got).all() and np.abs(got[:1] - ref).mean() / 255.0 <= 1e-3
+    for name in ("base/kernel", "block0/conv0/kernel"):
+        o, shape = spec.offsets()[name]
+        big[o:o + int(np.prod(shape))] *= 3000.0
+    m.set_weights(big, state)
+    m.auto_exact_fallback = False
+    with pytest.raises(FloatingPointError):
+        m(x)
+
+
 def test_f16_range_guard():
     """split-f16 blocks need |activation| < 65504: weights that blow the activations up must be reported (status
     word -> FloatingPointError when host arrays are handed back), and the exact-fp32 kernels must still be right."""

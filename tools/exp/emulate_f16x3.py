@@ -17,6 +17,20 @@ def conv(x, w):   # x NHWC f32 tensor, w HWIO
     return torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), padding=w.shape[0] // 2).permute(0, 2, 3, 1)
 
 MODE = "f16x3"
+STORE = "f16x2"          # what a block's output carries between launches: f16x2 = (hi, lo) f16 pair, 32 bits per value (as built);
+                         # fp8lo = hi f16 + lo as fp8 e4m3 of lo * 2^12; i8lo = hi f16 + lo as int8 in units of ulp(hi) / 256 (24 bits)
+
+def store(x):
+    """the (hi, lo) pair a block reads back from memory"""
+    hi, lo = split(x)
+    if STORE == "fp8lo":
+        lo = (lo * 4096.0).to(torch.float8_e4m3fn).to(torch.float32) / 4096.0
+    elif STORE == "i8lo":
+        ulp = torch.ldexp(torch.ones_like(hi), torch.frexp(hi)[1] - 11)          # spacing of f16 numbers at hi (normal range)
+        ulp = torch.where(hi == 0, torch.full_like(hi, 2.0 ** -24), torch.clamp(ulp, min=2.0 ** -24))
+        q = torch.clamp(torch.round(lo / ulp * 256.0), -128, 127)
+        lo = (q * ulp / 256.0).to(torch.float16).to(torch.float32)
+    return hi, lo
 
 def conv3(xh, xl, w):
     m = float(w.abs().max())
@@ -30,9 +44,9 @@ def conv3(xh, xl, w):
         return conv(xh, wh) / s
     return (conv(xh, wh) + conv(xl, wh) + conv(xh, wl)) / s
 
-def run(no_layers=18, size=128, mode="f16x3", seed=1234):
-    global MODE
-    MODE = mode
+def run(no_layers=18, size=128, mode="f16x3", seed=1234, storage="f16x2"):
+    global MODE, STORE
+    MODE, STORE = mode, storage
     cfg = O.canonical_config(no_layers=no_layers)
     spec = O.ResnetSpec.from_config(cfg["model"])
     params, state = O.init_params(spec, seed=42, nontrivial_bn=True)
@@ -49,7 +63,7 @@ def run(no_layers=18, size=128, mode="f16x3", seed=1234):
         if mode == "f32":
             t = torch.relu(conv(f, w1)); f = f + conv(t, w2) * a + sh
         else:
-            fh, fl = split(f)
+            fh, fl = store(f)
             f22 = fh if mode in ("f16x2a", "f16x1") else fh + fl   # what the activation storage carries
             t = torch.relu(conv3(fh, fl, w1))
             th, tl = split(t)
@@ -59,8 +73,10 @@ def run(no_layers=18, size=128, mode="f16x3", seed=1234):
     y = y.numpy().astype(np.float64)
     d = np.abs(y - ref)
     u = np.abs(np.clip(np.rint(y), 0, 255) - np.clip(np.rint(ref), 0, 255))
-    print(f"{mode:6s} layers={no_layers} size={size}: MAE(normalised)={d.mean()/255:.3e} max={d.max()/255:.3e}  u8 diff: mean={u.mean():.2e} max={u.max():.0f}  max|act|={float(f.abs().max()):.2f}")
+    print(f"{mode:6s} store={storage:6s} layers={no_layers} size={size}: MAE(normalised)={d.mean()/255:.3e} max={d.max()/255:.3e}  u8 diff: mean={u.mean():.2e} max={u.max():.0f}  max|act|={float(f.abs().max()):.2f}")
 
 if __name__ == "__main__":
     for mode in ("f32", "f16x3", "f16x2w", "f16x2a", "f16x1"):
         run(18, 128, mode)
+    for storage in ("fp8lo", "i8lo"):
+        run(18, 128, "f16x3", storage=storage)
