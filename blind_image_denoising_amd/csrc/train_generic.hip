@@ -591,3 +591,174 @@ extern "C" int bf_op_relu_shift_bwd(const float* w0, int nw, float w1, const flo
     hipLaunchKernelGGL(tg_relu_shift_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w0, nw, w1, dm, dw0, C);
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
+
+// ------------------------------------------------------------------------------------------
+// selector_block in training (bfcnn/custom_layers_selector.py:81-330): the adjoints of bf_op_selector_mix, bf_op_avgpool_same and
+// bf_op_dense2 (bias-free, act0 = leaky ReLU, final ReLU: the selector's two layers), and the channel slice that undoes
+// bf_op_concat_channels.  The up-sampling's adjoint is bf_op_resize_bilinear_bwd; scale_type GLOBAL is the same chain with one
+// pooling window over the whole image.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tg_selector_mix_bwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                                  const float* __restrict__ u, const float* __restrict__ dy,
+                                                                  float* __restrict__ dx1, float* __restrict__ dx2, float* __restrict__ du,
+                                                                  int64_t n, int soft)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float p = 2.5f - u[i];
+        float sv, dsdu;
+        if (soft) {
+            sv = 1.f / (1.f + expf(-p));
+            dsdu = -sv * (1.f - sv);
+        } else {
+            const float lin = 0.2f * p + 0.5f;
+            sv = fminf(fmaxf(lin, 0.f), 1.f);
+            dsdu = (lin >= 0.f && lin <= 1.f) ? -0.2f : 0.f;           // clip_by_value passes the gradient on its closed interval
+        }
+        const float g = dy[i];
+        dx1[i] = g * sv;
+        dx2[i] = g * (1.f - sv);
+        du[i] = g * (x1[i] - x2[i]) * dsdu;
+    }
+}
+
+// gather form: an input element collects dp / (taps of the window inside the image) from every window that covers it
+__global__ __launch_bounds__(256) void tg_avgpool_bwd_kernel(const float* __restrict__ dp, float* __restrict__ dx, int B, int H, int W, int C,
+                                                             int ph, int pw, int sh, int sw, int OH, int OW, int pt, int pl, int accumulate)
+{
+    const int64_t n = (int64_t)B * H * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int x = (int)(t % W); t /= W;
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        int oy0 = y + pt - ph + 1, ox0 = x + pl - pw + 1;
+        oy0 = oy0 <= 0 ? 0 : (oy0 + sh - 1) / sh;
+        ox0 = ox0 <= 0 ? 0 : (ox0 + sw - 1) / sw;
+        const int oy1 = min((y + pt) / sh, OH - 1), ox1 = min((x + pl) / sw, OW - 1);
+        float a = 0.f;
+        for (int oy = oy0; oy <= oy1; ++oy) {
+            const int ny = min(oy * sh - pt + ph, H) - max(oy * sh - pt, 0);
+            for (int ox = ox0; ox <= ox1; ++ox) {
+                const int nx = min(ox * sw - pl + pw, W) - max(ox * sw - pl, 0);
+                a += dp[(((int64_t)b * OH + oy) * OW + ox) * C + c] / (float)(ny * nx);
+            }
+        }
+        dx[i] = accumulate ? dx[i] + a : a;
+    }
+}
+
+// one workgroup per row r: h_pre = p W0, h = leaky(h_pre), u_pre = h W1; g = du [u_pre > 0]; dh = (g W1^T) leaky'(h_pre); dp = dh W0^T.
+// g, dh and h are kept for the weight gradients (tg_dense2_wgrad_kernel)
+__global__ __launch_bounds__(256) void tg_dense2_bwd_kernel(const float* __restrict__ p, const float* __restrict__ w0, const float* __restrict__ w1,
+                                                            const float* __restrict__ du, int Cs, int C, int C8, float alpha0,
+                                                            float* __restrict__ dp, float* __restrict__ G, float* __restrict__ DH,
+                                                            float* __restrict__ Hs)
+{
+    __shared__ float ps[256], hp[64], hh[64], gs[256], dh[64];
+    const int r = blockIdx.x, t = threadIdx.x;
+    if (t < Cs) ps[t] = p[(int64_t)r * Cs + t];
+    __syncthreads();
+    if (t < C8) {
+        float a = 0.f;
+        for (int i = 0; i < Cs; ++i) a = fmaf(ps[i], w0[i * C8 + t], a);
+        hp[t] = a;
+        hh[t] = a > 0.f ? a : alpha0 * a;
+        Hs[(int64_t)r * C8 + t] = hh[t];
+    }
+    __syncthreads();
+    if (t < C) {
+        float a = 0.f;
+        for (int j = 0; j < C8; ++j) a = fmaf(hh[j], w1[j * C + t], a);
+        const float g = a > 0.f ? du[(int64_t)r * C + t] : 0.f;
+        gs[t] = g;
+        G[(int64_t)r * C + t] = g;
+    }
+    __syncthreads();
+    if (t < C8) {
+        float a = 0.f;
+        for (int k = 0; k < C; ++k) a = fmaf(gs[k], w1[t * C + k], a);
+        a *= hp[t] > 0.f ? 1.f : alpha0;
+        dh[t] = a;
+        DH[(int64_t)r * C8 + t] = a;
+    }
+    __syncthreads();
+    if (t < Cs) {
+        float a = 0.f;
+        for (int j = 0; j < C8; ++j) a = fmaf(dh[j], w0[t * C8 + j], a);
+        dp[(int64_t)r * Cs + t] = a;
+    }
+}
+
+// dW0[i][j] = sum_r p[r][i] DH[r][j] ; dW1[j][k] = sum_r Hs[r][j] G[r][k]: one thread per element, rows in order (fixed summation order)
+__global__ __launch_bounds__(256) void tg_dense2_wgrad_kernel(const float* __restrict__ p, const float* __restrict__ G, const float* __restrict__ DH,
+                                                              const float* __restrict__ Hs, int64_t n, int Cs, int C, int C8,
+                                                              float* __restrict__ dw0, float* __restrict__ dw1)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < Cs * C8) {
+        const int i = e / C8, j = e % C8;
+        double a = 0.0;
+        for (int64_t r = 0; r < n; ++r) a += (double)p[r * Cs + i] * (double)DH[r * C8 + j];
+        dw0[e] = (float)a;
+    } else if (e < Cs * C8 + C8 * C) {
+        const int f = e - Cs * C8, j = f / C, k = f % C;
+        double a = 0.0;
+        for (int64_t r = 0; r < n; ++r) a += (double)Hs[r * C8 + j] * (double)G[r * C + k];
+        dw1[f] = (float)a;
+    }
+}
+
+__global__ __launch_bounds__(256) void tg_slice_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t rows, int Csrc,
+                                                                int off, int C)
+{
+    const int64_t n = rows * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dst[i] = src[(i / C) * Csrc + off + i % C];
+}
+
+extern "C" int bf_op_selector_mix_bwd(const float* x1, const float* x2, const float* u, const float* dy, float* dx1, float* dx2, float* du,
+                                      int64_t n, int soft, void* stream)
+{
+    if (!x1 || !x2 || !u || !dy || !dx1 || !dx2 || !du || n <= 0) return BF_EINVAL;
+    hipLaunchKernelGGL(tg_selector_mix_bwd_kernel, dim3(tg_grid(n)), dim3(256), 0, (hipStream_t)stream, x1, x2, u, dy, dx1, dx2, du, n, soft);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+extern "C" int bf_op_avgpool_same_bwd(const float* dp, float* dx, int B, int H, int W, int C, int pool_h, int pool_w, int stride_h,
+                                      int stride_w, int accumulate, void* stream)
+{
+    if (!dp || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || pool_h <= 0 || pool_w <= 0 || stride_h <= 0 || stride_w <= 0) return BF_EINVAL;
+    const int OH = (H + stride_h - 1) / stride_h, OW = (W + stride_w - 1) / stride_w;
+    int th = (OH - 1) * stride_h + pool_h - H, tw = (OW - 1) * stride_w + pool_w - W;
+    if (th < 0) th = 0;
+    if (tw < 0) tw = 0;
+    hipLaunchKernelGGL(tg_avgpool_bwd_kernel, dim3(tg_grid((int64_t)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, dp, dx, B, H, W, C,
+                       pool_h, pool_w, stride_h, stride_w, OH, OW, th / 2, tw / 2, accumulate);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+extern "C" int64_t bf_op_dense2_bwd_scratch_floats(int64_t n, int C, int C8) { return n > 0 ? n * (C + 2 * (int64_t)C8) : -1; }
+
+extern "C" int bf_op_dense2_bwd(const float* in, const float* w0, const float* w1, const float* dout, float* din, float* dw0, float* dw1,
+                                int64_t n, int Cs, int C, int C8, float alpha0, float* scratch, int64_t scratch_floats, void* stream)
+{
+    if (!in || !w0 || !w1 || !dout || !din || !dw0 || !dw1 || !scratch || n <= 0 || n > 0x7fffffff) return BF_EINVAL;
+    if (Cs <= 0 || Cs > 256 || C <= 0 || C > 256 || C8 <= 0 || C8 > 64) return BF_EUNSUPPORTED;
+    if (scratch_floats < bf_op_dense2_bwd_scratch_floats(n, C, C8)) return BF_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* G = scratch;
+    float* DH = G + n * C;
+    float* Hs = DH + n * C8;
+    hipLaunchKernelGGL(tg_dense2_bwd_kernel, dim3((int)n), dim3(256), 0, s, in, w0, w1, dout, Cs, C, C8, alpha0, din, G, DH, Hs);
+    hipLaunchKernelGGL(tg_dense2_wgrad_kernel, dim3((Cs * C8 + C8 * C + 255) / 256), dim3(256), 0, s, in, G, DH, Hs, n, Cs, C, C8, dw0, dw1);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+extern "C" int bf_op_slice_channels(const float* src, float* dst, int64_t rows, int src_channels, int offset, int channels, void* stream)
+{
+    if (!src || !dst || rows <= 0 || channels <= 0 || offset < 0 || offset + channels > src_channels) return BF_EINVAL;
+    hipLaunchKernelGGL(tg_slice_channels_kernel, dim3(tg_grid(rows * channels)), dim3(256), 0, (hipStream_t)stream, src, dst, rows, src_channels,
+                       offset, channels);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}

@@ -426,6 +426,18 @@ int bf_op_dense2(const float* in, const float* w0, const float* b0, const float*
 int bf_op_selector_mix(const float* x1, const float* x2, const float* u, float* out, int64_t n, int soft, void* stream);
 int bf_op_avgpool_same(const float* in, float* out, int batch, int height, int width, int channels, int pool_h, int pool_w,
                        int stride_h, int stride_w, void* stream);
+/* selector_block in training: adjoints of bf_op_selector_mix (dx1, dx2, du from dy), bf_op_avgpool_same (dx [B,H,W,C] from the pooled
+   map's gradient; accumulate != 0: added to dx), bf_op_dense2 in its selector form (no biases, act0 = leaky ReLU alpha0, final ReLU:
+   din, dw0 [in_channels][squeeze], dw1 [squeeze][channels]; scratch: bf_op_dense2_bwd_scratch_floats), and the channel slice
+   dst[r][0:channels] = src[r][offset:offset+channels] that undoes bf_op_concat_channels */
+int bf_op_selector_mix_bwd(const float* x1, const float* x2, const float* u, const float* dy, float* dx1, float* dx2, float* du, int64_t n,
+                           int soft, void* stream);
+int bf_op_avgpool_same_bwd(const float* dpooled, float* dx, int batch, int height, int width, int channels, int pool_h, int pool_w,
+                           int stride_h, int stride_w, int accumulate, void* stream);
+int64_t bf_op_dense2_bwd_scratch_floats(int64_t n, int channels, int squeeze);
+int bf_op_dense2_bwd(const float* in, const float* w0, const float* w1, const float* dout, float* din, float* dw0, float* dw1, int64_t n,
+                     int in_channels, int channels, int squeeze, float alpha0, float* scratch, int64_t scratch_floats, void* stream);
+int bf_op_slice_channels(const float* src, float* dst, int64_t rows, int src_channels, int offset, int channels, void* stream);
 /* selector_block's MIXED / MULTISCALE inputs (custom_layers_selector.py:203-262): keras Concatenate on the channel axis of up to
    three [rows][C*] tensors; the per-sample channel mean of x [B][hw][C] broadcast to out [B][rows_out][C]
    (tf.reduce_mean(x, axis=[1, 2], keepdims=True) added to a zeroed pooled map); scratch: bf_op_gate_scratch_floats(B, C) */

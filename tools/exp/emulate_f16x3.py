@@ -25,6 +25,8 @@ def store(x):
     hi, lo = split(x)
     if STORE == "fp8lo":
         lo = (lo * 4096.0).to(torch.float8_e4m3fn).to(torch.float32) / 4096.0
+    elif STORE == "bf8lo":                           # e5m2 of lo itself: no scale, no clamp (range 57344 > any lo), 2 mantissa bits
+        lo = lo.to(torch.float8_e5m2).to(torch.float32)
     elif STORE == "i8lo":
         ulp = torch.ldexp(torch.ones_like(hi), torch.frexp(hi)[1] - 11)          # spacing of f16 numbers at hi (normal range)
         ulp = torch.where(hi == 0, torch.full_like(hi, 2.0 ** -24), torch.clamp(ulp, min=2.0 ** -24))
@@ -78,5 +80,5 @@ def run(no_layers=18, size=128, mode="f16x3", seed=1234, storage="f16x2"):
 if __name__ == "__main__":
     for mode in ("f32", "f16x3", "f16x2w", "f16x2a", "f16x1"):
         run(18, 128, mode)
-    for storage in ("fp8lo", "i8lo"):
+    for storage in ("fp8lo", "bf8lo", "i8lo"):
         run(18, 128, "f16x3", storage=storage)
