@@ -18,7 +18,7 @@ import torch
 
 from . import _native as N
 from . import unet_laplacian as UL
-from .resnet_generic import BN_EPSILON, GenericResnetHydra
+from .resnet_generic import BN_EPSILON, SELECTOR_GLOBAL_LEAKY, GenericResnetHydra
 from .unet_train import _Ops, _call
 
 BN_MOMENTUM = 0.995                # DEFAULT_BN_MOMENTUM (bfcnn/constants.py:10)
@@ -41,8 +41,6 @@ class GenericResnetTrainGraph:
                 raise NotImplementedError("training: grouped convolutions are built for 1x1 kernels")
         if any(UL._act(a_)[0] == 3 for a_ in list(model.block_activation) + [model.base_activation]):
             raise NotImplementedError("training: GELU in the resnet blocks is built for inference only")
-        if getattr(model, "selector", None):
-            raise NotImplementedError("training: selector_block is built for inference only")
         self.ops = None
         self.totals = None
 
@@ -88,6 +86,8 @@ class GenericResnetTrainGraph:
             return dn.get("kernel_regularizer", "l2")
         if "/gate/" in name:
             return "l2"
+        if "/selector/" in name:                                   # custom_layers_selector.py:88
+            return (bb.get("selector_params") or {}).get("kernel_regularizer", "l1")
         j = int(name.split("/")[1][4:])
         br = bb.get("block_regularizer") or [bb.get("kernel_regularizer", "l1")] * len(self.m.block_kernels)
         return br[j]
@@ -107,7 +107,8 @@ class GenericResnetTrainGraph:
         L = N.lib()
         cmax = max([m.filters] + [c for c in self._channels()])
         need = max(8 * 1024 * 1024, int(L.bf_op_denoiser_loss_scratch_floats(B, H, Wd, m.out_channels)) + 1024, npix * 4,
-                   int(L.bf_op_gate_scratch_floats(B, cmax)) + 64, int(L.bf_op_bn_train_scratch_floats(cmax)) + 64)
+                   int(L.bf_op_gate_scratch_floats(B, cmax)) + 64, int(L.bf_op_bn_train_scratch_floats(cmax)) + 64,
+                   npix * m.filters if m.selector else 0)        # the selector's resize / dense adjoints (at most one row set per pixel)
         if self.ops is None or self.ops.scratch.numel() < need:
             self.ops = _Ops(dev, need)
         ops = self.ops
@@ -218,6 +219,77 @@ class GenericResnetTrainGraph:
                 return dt
             return y, bwd
 
+        def selector_step(i, x1, x2, sel):
+            """selector_block (custom_layers_selector.py:81-330) in place of the skip Add: out = x1 s + x2 (1 - s), s = F(2.5 - u),
+            u = up(relu(leaky(pool(sel) W0) W1)).  scale_type GLOBAL is the same chain with one window over the whole image
+            (Dense layers, slope SELECTOR_GLOBAL_LEAKY).  Returns (out, backward: d out -> (d x1, d x2, d sel))."""
+            sp = m.selector
+            st, soft = sp["scale_type"], int(sp["activation_type"] == "soft")
+            Bs, Hs, Ws, Cs = sel.shape
+            Ct = x1.shape[-1]
+            if st == "global":
+                stride, pools, alpha0, kind = (Hs, Ws), [(Hs, Ws)], SELECTOR_GLOBAL_LEAKY, "dense"
+            else:
+                stride, pool, alpha0, kind = sp["stride"], sp["pool"], 0.3, "conv"
+                if Hs % stride[0] or Ws % stride[1]:
+                    raise ValueError(f"selector_block: the image ({Hs}x{Ws}) must be a multiple of the strides {stride}")
+                pools = [(pool[0] // 2, pool[1] // 2), pool, (pool[0] * 2, pool[1] * 2)] if st == "multiscale" else [pool]
+            OH, OW = Hs // stride[0], Ws // stride[1]
+            rows = Bs * OH * OW
+            parts = []
+            for ph, pw in pools:
+                pm = torch.empty((Bs, OH, OW, Cs), **f32)
+                _call("bf_op_avgpool_same", N.ptr(sel), N.ptr(pm), Bs, Hs, Ws, Cs, ph, pw, stride[0], stride[1], N.stream_ptr(sel))
+                parts.append(pm)
+            if st == "mixed":                                    # local means next to the image's global mean on the same grid
+                gm = torch.empty((Bs, OH, OW, Cs), **f32)
+                sp_, sn_ = ops._s()
+                _call("bf_op_channel_mean_broadcast", N.ptr(sel), N.ptr(gm), Bs, Hs * Ws, Cs, OH * OW, sp_, sn_, N.stream_ptr(sel))
+                parts.append(gm)
+            if len(parts) > 1:
+                cat = torch.empty((Bs, OH, OW, Cs * len(parts)), **f32)
+                _call("bf_op_concat_channels", N.ptr(parts[0]), N.ptr(parts[1]), N.ptr(parts[2]) if len(parts) > 2 else None, N.ptr(cat),
+                      rows, Cs, Cs, Cs if len(parts) > 2 else 0, N.stream_ptr(sel))
+            else:
+                cat = parts[0]
+            Cc = cat.shape[-1]
+            n0, n1 = f"block{i}/selector/{kind}0/kernel", f"block{i}/selector/{kind}1/kernel"
+            w0, w1 = self.W(n0), self.W(n1)
+            C8 = int(w0.shape[-1])
+            u = torch.empty((Bs, OH, OW, Ct), **f32)
+            _call("bf_op_dense2", N.ptr(cat), N.ptr(w0), None, N.ptr(w1), None, N.ptr(u), rows, Cc, Ct, C8, 2, alpha0, 4, N.stream_ptr(cat))
+            up = UL.resize_bilinear(u, Hs, Ws)
+            out = torch.empty_like(x1)
+            _call("bf_op_selector_mix", N.ptr(x1), N.ptr(x2), N.ptr(up), N.ptr(out), x1.numel(), soft, N.stream_ptr(x1))
+
+            def bwd(dout):
+                dx1, dx2, dup = torch.empty_like(x1), torch.empty_like(x1), torch.empty_like(x1)
+                _call("bf_op_selector_mix_bwd", N.ptr(x1), N.ptr(x2), N.ptr(up), N.ptr(dout), N.ptr(dx1), N.ptr(dx2), N.ptr(dup), x1.numel(),
+                      soft, N.stream_ptr(dout))
+                du = torch.empty_like(u)
+                _call("bf_op_resize_bilinear_bwd", N.ptr(dup), N.ptr(du), Bs, OH, OW, Ct, Hs, Ws, N.ptr(ops.scratch), N.stream_ptr(dup))
+                dcat = torch.empty_like(cat)
+                sp_, sn_ = ops._s()
+                _call("bf_op_dense2_bwd", N.ptr(cat), N.ptr(w0), N.ptr(w1), N.ptr(du), N.ptr(dcat), N.ptr(self.G(n0, grads)),
+                      N.ptr(self.G(n1, grads)), rows, Cc, Ct, C8, alpha0, sp_, sn_, N.stream_ptr(du))
+                dsel = torch.empty_like(sel)
+                for k_, (ph, pw) in enumerate(pools):
+                    dpart = dcat
+                    if len(parts) > 1:
+                        dpart = torch.empty((Bs, OH, OW, Cs), **f32)
+                        _call("bf_op_slice_channels", N.ptr(dcat), N.ptr(dpart), rows, Cc, k_ * Cs, Cs, N.stream_ptr(dcat))
+                    _call("bf_op_avgpool_same_bwd", N.ptr(dpart), N.ptr(dsel), Bs, Hs, Ws, Cs, ph, pw, stride[0], stride[1], int(k_ > 0),
+                          N.stream_ptr(dpart))
+                if st == "mixed":                                # d mean: the column sums of its gradient, spread over the image
+                    dgm = torch.empty((Bs, OH, OW, Cs), **f32)
+                    _call("bf_op_slice_channels", N.ptr(dcat), N.ptr(dgm), rows, Cc, Cs, Cs, N.stream_ptr(dcat))
+                    spread = torch.empty_like(sel)
+                    sp_, sn_ = ops._s()
+                    _call("bf_op_channel_mean_broadcast", N.ptr(dgm), N.ptr(spread), Bs, OH * OW, Cs, Hs * Ws, sp_, sn_, N.stream_ptr(dgm))
+                    _call("bf_op_axpy", N.ptr(dsel), N.ptr(spread), float(OH * OW) / float(Hs * Ws), 0, dsel.numel(), N.stream_ptr(dsel))
+                return dx1, dx2, dsel
+            return out, bwd
+
         # -- forward -------------------------------------------------------------------------------------------------------------
         wb = self.W("base/kernel")
         f = UL.first_conv(noisy, wb, H, Wd, m.base_activation, True, m.v_min, m.v_max, arith=0)
@@ -257,6 +329,8 @@ class GenericResnetTrainGraph:
                         return ops.act_bwd(y, dy, a)
                 steps.append((b_conv, b_norm))
                 t = y
+                if j == 0:
+                    first, n_first = t, len(steps)                    # x_1st_conv: the selector layer; steps[:n_first] produce it
                 if j == 1 and m.add_gates:
                     w0, w1 = self.W(f"block{i}/gate/dense0/kernel"), self.W(f"block{i}/gate/dense1/kernel")
                     C8 = w0.shape[1]
@@ -283,15 +357,25 @@ class GenericResnetTrainGraph:
             for q_, name_ in enumerate(tails):
                 t, b_ = mult_step(name_, t, ds_ if q_ == len(tails) - 1 else None)
                 steps.append((None, b_))
-            f = ops.add(f, t)                                         # Add()([x, previous_layer]) (backbone_blocks.py:242)
+            b_sel = None
+            if m.selector:                                            # selector_block instead of the Add (backbone_blocks.py:227-239)
+                f, b_sel = selector_step(i, f, t, first)
+            else:
+                f = ops.add(f, t)                                     # Add()([x, previous_layer]) (backbone_blocks.py:242)
 
-            def b_block(dout, steps=steps):
-                g = dout
-                for b_conv, b_norm in reversed(steps):
+            def b_block(dout, steps=steps, b_sel=b_sel, n_first=n_first):
+                if b_sel is not None:
+                    dskip, g, dsel = b_sel(dout)
+                else:
+                    dskip, g, dsel = dout, dout, None
+                for idx in range(len(steps) - 1, -1, -1):
+                    if dsel is not None and idx == n_first - 1:       # g is the gradient at the first convolution's output here
+                        g = ops.add(g, dsel)
+                    b_conv, b_norm = steps[idx]
                     g = b_norm(g)
                     if b_conv is not None:
                         g = b_conv(g)
-                return ops.add(dout, g)
+                return ops.add(dskip, g)
             chain.append(b_block)
 
         if m.add_final_bn:                                            # backbone_resnet.py:274-287

@@ -146,7 +146,7 @@ class GenericResnetSpec:
     kernel_regularizer: str = "l1"
     block_regularizer: Tuple[str, ...] = ()
     head_regularizer: str = "l2"
-    selector: Tuple = ()                  # () or (scale_type, activation_type, compress channels, pool, stride)
+    selector: Tuple = ()                  # () or (scale_type, activation_type, compress channels, pool, stride, regulariser)
     add_initial_bn: bool = False          # BatchNormalization behind the base convolution (backbone_resnet.py:264-265)
     add_final_bn: bool = False            # ... behind the last block (:274-275)
     add_channelwise_scaling: bool = False   # ChannelwiseMultiplier closing every block and the backbone (:236-238, 282-283)
@@ -187,7 +187,8 @@ class GenericResnetSpec:
         stride = tuple(int(v) for v in sp.get("strides_size", (pool[0] / 4, pool[1] / 4)))
         filters = bb.get("filters", 32)
         return (str(sp.get("scale_type", "local")).lower(), str(sp.get("activation_type", "hard")).lower(),
-                max(1, int(round(filters * sp.get("filters_compress_ratio", 0.25)))), pool, stride)
+                max(1, int(round(filters * sp.get("filters_compress_ratio", 0.25)))), pool, stride,
+                sp.get("kernel_regularizer", "l1"))                       # custom_layers_selector.py:88: the selector layers' regulariser
 
     def gate_channels(self) -> int:
         """backbone_blocks.py:131-141: the second convolution's filters, or filters x depth_multiplier for a depthwise one"""

@@ -81,11 +81,54 @@ def _batch_norm(t, base, P, S, new_state, training):
     return gamma * (t - mu) / torch.sqrt(var + R.BN_EPS)
 
 
+def avgpool_same(x, pool, stride):
+    """keras AveragePooling2D(pool, strides, padding="same"): TF SAME padding, divisor = taps inside the image (resnet_generic_oracle.avgpool_same)"""
+    B, H, W, C = x.shape
+    OH, OW = -(-H // stride[0]), -(-W // stride[1])
+    pt = max((OH - 1) * stride[0] + pool[0] - H, 0) // 2
+    pl = max((OW - 1) * stride[1] + pool[1] - W, 0) // 2
+    rows = []
+    for oy in range(OH):
+        y0, y1 = max(oy * stride[0] - pt, 0), min(oy * stride[0] - pt + pool[0], H)
+        cols = []
+        for ox in range(OW):
+            x0, x1 = max(ox * stride[1] - pl, 0), min(ox * stride[1] - pl + pool[1], W)
+            cols.append(x[:, y0:y1, x0:x1].mean(dim=(1, 2)))
+        rows.append(torch.stack(cols, dim=1))
+    return torch.stack(rows, dim=1)
+
+
+def selector_block(x1, x2, sel, w0, w1, scale_type, activation_type, pool, stride):
+    """custom_layers_selector.py:81-330 as resnet_generic_oracle.selector_block restates it (no optional pre-filters)"""
+    st = scale_type.lower()
+    w0, w1 = w0.reshape(w0.shape[-2], w0.shape[-1]), w1.reshape(w1.shape[-2], w1.shape[-1])
+    if st in ("local", "multiscale", "mixed"):
+        if st == "local":
+            u = avgpool_same(sel, pool, stride)
+        elif st == "multiscale":
+            u = torch.cat([avgpool_same(sel, (pool[0] // 2, pool[1] // 2), stride), avgpool_same(sel, pool, stride),
+                           avgpool_same(sel, (pool[0] * 2, pool[1] * 2), stride)], dim=-1)
+        else:
+            loc = avgpool_same(sel, pool, stride)
+            u = torch.cat([loc, torch.zeros_like(loc) + sel.mean(dim=(1, 2), keepdim=True)], dim=-1)
+        u = u @ w0
+        u = torch.where(u > 0, u, 0.3 * u)
+        u = torch.relu(u @ w1)
+        u = T._resize(u, u.shape[1] * stride[0], u.shape[2] * stride[1])
+    elif st == "global":
+        u = sel.mean(dim=(1, 2)) @ w0
+        u = torch.where(u > 0, u, R.SELECTOR_GLOBAL_LEAKY * u)
+        u = torch.relu(u @ w1)[:, None, None, :]
+    else:
+        raise ValueError(scale_type)
+    p = 2.5 - u
+    s = torch.clamp(0.2 * p + 0.5, 0.0, 1.0) if activation_type.lower() == "hard" else torch.sigmoid(p)
+    return x1 * s + x2 * (1.0 - s)
+
+
 def hydra(spec: R.GenericResnetSpec, P, S, x, training: bool, drop_scale=None):
     """returns (prediction, new state dict).  drop_scale: {block index: per-sample factor [B]} = RandomOnOff's draw
     (0 or 1 / (1 - rate); custom_layers.py:107-127), training only."""
-    if spec.selector:
-        raise NotImplementedError("the gradient oracle does not restate selector_block (inference only in the product as well)")
     new_state = dict(S)
     drop_scale = drop_scale or {}
     scaled = lambda t, name: t * torch.relu(P[name] + 1.0)
@@ -112,6 +155,8 @@ def hydra(spec: R.GenericResnetSpec, P, S, x, training: bool, drop_scale=None):
                 else:
                     t = gamma * (t - S[base + "/moving_mean"]) / torch.sqrt(S[base + "/moving_variance"] + R.BN_EPS)
             t = _act(t, a)
+            if j == 0:
+                first = t                                                # x_1st_conv: the selector layer (backbone_blocks.py:229-231)
             if j == 1 and spec.add_gates:
                 y = torch.relu(t.mean(dim=(1, 2)) @ P[f"block{i}/gate/dense0/kernel"])
                 y = torch.clamp(0.2 * (y @ P[f"block{i}/gate/dense1/kernel"]) + 0.5, 0.0, 1.0)
@@ -122,7 +167,12 @@ def hydra(spec: R.GenericResnetSpec, P, S, x, training: bool, drop_scale=None):
             t = scaled(t, f"block{i}/multiplier/w0")
         if training and i in drop_scale:
             t = t * drop_scale[i].reshape(-1, 1, 1, 1)
-        f = t + f
+        if spec.selector:
+            kind = "dense" if spec.selector[0] == "global" else "conv"
+            f = selector_block(f, t, first, P[f"block{i}/selector/{kind}0/kernel"], P[f"block{i}/selector/{kind}1/kernel"],
+                               spec.selector[0], spec.selector[1], spec.selector[3], spec.selector[4])
+        else:
+            f = t + f
     if spec.add_final_bn:
         f = _batch_norm(f, "final_bn", P, S, new_state, training)
     if spec.add_channelwise_scaling:
@@ -148,6 +198,8 @@ def regularizer_kind(spec: R.GenericResnetSpec, name: str, kind: str):
         return spec.head_regularizer
     if "/gate/" in name:
         return "l2"
+    if "/selector/" in name:
+        return spec.selector[5]
     j = int(name.split("/")[1][4:])
     return spec.block_regularizer[j] if spec.block_regularizer else spec.kernel_regularizer
 

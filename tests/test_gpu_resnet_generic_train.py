@@ -104,6 +104,17 @@ CONFIGS = {
                                 add_gates=True, add_initial_bn=True, add_final_bn=True, add_channelwise_scaling=True,
                                 add_learnable_multiplier=True, dropout_rate=0.5, base_activation="relu"),
     "dropout-alone": dict(no_layers=2, dropout_rate=0.5),
+    # selector_block in place of the skip Add (backbone_blocks.py:227-239), all four scale types
+    "selector-local": dict(no_layers=2, selector_params=dict(scale_type="local", pool_size=(8, 8))),
+    "selector-local-soft-stride2": dict(no_layers=2, selector_params=dict(scale_type="local", activation_type="soft", pool_size=(8, 8),
+                                                                         strides_size=(4, 2), kernel_regularizer="l2")),
+    "selector-multiscale": dict(no_layers=1, selector_params=dict(scale_type="multiscale", pool_size=(8, 8))),
+    "selector-mixed-gates-multipliers": dict(no_layers=2, add_gates=True, add_channelwise_scaling=True,
+                                             selector_params=dict(scale_type="mixed", pool_size=(16, 16))),
+    "selector-global": dict(no_layers=2, selector_params=dict(scale_type="global")),
+    "selector-two-conv": dict(filters=32, kernel_size=3, block_kernels=[3, 3], block_filters=[32, 32], block_depthwise=[-1, -1],
+                              block_groups=[1, 1], block_activation=["relu", "relu"], block_regularizer=["l1", "l2"], no_layers=2,
+                              selector_params=dict(scale_type="local", pool_size=(8, 8))),
 }
 DROP = {0: np.array([2.0, 0.0]), 1: np.array([2.0, 2.0])}
 

@@ -123,3 +123,35 @@ def test_builder_flags_training_step_central_differences():
     pred3 = T.train_step(spec, ls, p3, state, clean, noisy, drop_scale={0: np.array([0.0, 0.0])})[3]
     pred0 = T.train_step(spec, ls, params, state, clean, noisy, drop_scale={0: np.array([0.0, 0.0])})[3]
     assert np.abs(pred3 - pred0).max() < 1e-12
+
+
+@pytest.mark.parametrize("sp", [dict(scale_type="local", pool_size=(8, 8)), dict(scale_type="multiscale", pool_size=(8, 8), activation_type="soft"),
+                                dict(scale_type="mixed", pool_size=(16, 16)), dict(scale_type="global")],
+                         ids=["local", "multiscale-soft", "mixed", "global"])
+def test_selector_block_forward_and_gradient(sp):
+    """selector_block (custom_layers_selector.py:81-330) in the torch restatement: equal to the NumPy one at inference, its kernels
+    regularised with the block's `kernel_regularizer` (default "l1", :88), autograd against central differences on them"""
+    spec = _spec(False, selector_params=sp)
+    params, state = R.init_params(spec, seed=9)
+    x = np.random.default_rng(1).uniform(0, 255, (2, 16, 24, 3))
+    a, b = T.infer(spec, params, state, x), R.hydra_forward(spec, params, state, x)
+    assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max())
+    ls = O.LossSpec.from_config({"hinge": 0.0, "cutoff": 255.0, "mae_multiplier": 1.0, "regularization": 0.01})
+    params = params.astype(np.float64)
+    clean, noisy = O.synthetic_batch(2, 16, 24, seed=2)
+    total, ml, dl, pred, grads, _ = T.train_step(spec, ls, params, state, clean, noisy)
+    off, o = {}, 0
+    for n, s, k in spec.tensors():
+        off[n] = (o, int(np.prod(s)))
+        o += int(np.prod(s))
+    kind = "dense" if sp["scale_type"] == "global" else "conv"
+    rng = np.random.default_rng(3)
+    for name in (f"block0/selector/{kind}0/kernel", f"block1/selector/{kind}1/kernel"):
+        o0, n0 = off[name]
+        assert np.abs(grads[o0:o0 + n0]).max() > 0
+        d = np.zeros(params.size)
+        d[o0:o0 + n0] = rng.standard_normal(n0)
+        d /= np.linalg.norm(d)
+        e = 1e-5
+        num = (T.train_step(spec, ls, params + e * d, state, clean, noisy)[0] - T.train_step(spec, ls, params - e * d, state, clean, noisy)[0]) / (2 * e)
+        assert abs(num - grads @ d) <= 5e-3 * max(abs(grads @ d), 1e-3), (name, num, grads @ d)
