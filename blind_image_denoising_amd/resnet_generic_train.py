@@ -39,8 +39,6 @@ class GenericResnetTrainGraph:
         for j, (kk, g) in enumerate(zip(model.block_kernels, model.block_groups)):
             if g != 1 and kk != 1:
                 raise NotImplementedError("training: grouped convolutions are built for 1x1 kernels")
-        if any(UL._act(a_)[0] == 3 for a_ in list(model.block_activation) + [model.base_activation]):
-            raise NotImplementedError("training: GELU in the resnet blocks is built for inference only")
         self.ops = None
         self.totals = None
 
@@ -292,7 +290,16 @@ class GenericResnetTrainGraph:
 
         # -- forward -------------------------------------------------------------------------------------------------------------
         wb = self.W("base/kernel")
-        f = UL.first_conv(noisy, wb, H, Wd, m.base_activation, True, m.v_min, m.v_max, arith=0)
+        # GELU is not sign-preserving: its derivative needs the pre-activation, so the convolution output is kept and the activation
+        # runs as its own pass (the other activations are fused and differentiated from their output)
+        gelu = lambda a_: UL._act(a_)[0] == 3
+        act_only = lambda t_, a_: UL.dwconv_ln(t_.view(1, 1, -1, 32), None, None, a_).view(t_.shape)
+        if gelu(m.base_activation):
+            f0pre = UL.first_conv(noisy, wb, H, Wd, "linear", True, m.v_min, m.v_max, arith=0)
+            f = act_only(f0pre, m.base_activation)
+        else:
+            f0pre = None
+            f = UL.first_conv(noisy, wb, H, Wd, m.base_activation, True, m.v_min, m.v_max, arith=0)
         f0 = f
         chain = []                                   # per block: closure d(block output) -> d(block input)
         if m.add_initial_bn:
@@ -312,21 +319,24 @@ class GenericResnetTrainGraph:
                     y = torch.empty_like(c)
                     sp, sn = ops._s()
                     _call("bf_op_bn_train_fwd", N.ptr(c), N.ptr(gamma), N.ptr(y), N.ptr(save), N.ptr(self.S(f"block{i}/bn{j}/moving_mean")),
-                          N.ptr(self.S(f"block{i}/bn{j}/moving_variance")), c.numel() // Cc, Cc, BN_EPSILON, BN_MOMENTUM, code, alpha,
-                          sp, sn, N.stream_ptr(c))
+                          N.ptr(self.S(f"block{i}/bn{j}/moving_variance")), c.numel() // Cc, Cc, BN_EPSILON, BN_MOMENTUM,
+                          0 if gelu(a) else code, alpha, sp, sn, N.stream_ptr(c))
+                    ypre = None
+                    if gelu(a):
+                        ypre, y = y, act_only(y, a)
 
-                    def b_norm(dy, c=c, y=y, gamma=gamma, save=save, a=a, Cc=Cc, name=f"block{i}/bn{j}/gamma"):
-                        dpre = ops.act_bwd(y, dy, a)
+                    def b_norm(dy, c=c, y=y, ypre=ypre, gamma=gamma, save=save, a=a, Cc=Cc, name=f"block{i}/bn{j}/gamma"):
+                        dpre = ops.act_bwd(y, dy, a, ypre)
                         dx = torch.empty_like(c)
                         sp, sn = ops._s()
                         _call("bf_op_bn_train_bwd", N.ptr(c), N.ptr(gamma), N.ptr(save), N.ptr(dpre), N.ptr(dx), N.ptr(self.G(name, grads)),
                               c.numel() // Cc, Cc, sp, sn, N.stream_ptr(c))
                         return dx
                 else:
-                    y = c if code == 0 else UL.dwconv_ln(c, None, None, a)
+                    y = c if code == 0 else act_only(c, a)
 
-                    def b_norm(dy, y=y, a=a):
-                        return ops.act_bwd(y, dy, a)
+                    def b_norm(dy, y=y, c=c, a=a):
+                        return ops.act_bwd(y, dy, a, c)
                 steps.append((b_conv, b_norm))
                 t = y
                 if j == 0:
@@ -416,7 +426,7 @@ class GenericResnetTrainGraph:
         # -- backward ------------------------------------------------------------------------------------------------------------
         for b_block in reversed(chain):
             g = b_block(g)
-        dpre = ops.act_bwd(f0, g, m.base_activation)
+        dpre = ops.act_bwd(f0, g, m.base_activation, f0pre)
         sp, sn = ops._s()
         _call("bf_op_conv2d_wgrad", N.ptr(noisy), int(noisy.dtype == torch.uint8), N.ptr(dpre), N.ptr(self.G("base/kernel", grads)),
               B, H, Wd, m.in_channels, m.filters, m.kernel_size, 1, m.v_min, m.v_max, sp, sn, N.stream_ptr(dpre))

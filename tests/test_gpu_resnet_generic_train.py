@@ -104,6 +104,11 @@ CONFIGS = {
                                 add_gates=True, add_initial_bn=True, add_final_bn=True, add_channelwise_scaling=True,
                                 add_learnable_multiplier=True, dropout_rate=0.5, base_activation="relu"),
     "dropout-alone": dict(no_layers=2, dropout_rate=0.5),
+    # GELU (utilities.py:229-267, the exact erf form) as block / base activation: differentiated from the kept pre-activation
+    "gelu-blocks": dict(no_layers=2, block_activation=["gelu", "gelu", "linear"], base_activation="gelu"),
+    "gelu-two-conv-nobn": dict(filters=32, kernel_size=3, block_kernels=[3, 3], block_filters=[32, 32], block_depthwise=[-1, -1],
+                               block_groups=[1, 1], block_activation=["gelu", "gelu"], block_regularizer=["l1", "l2"], no_layers=2,
+                               use_bn=False, base_activation="gelu"),
     # selector_block in place of the skip Add (backbone_blocks.py:227-239), all four scale types
     "selector-local": dict(no_layers=2, selector_params=dict(scale_type="local", pool_size=(8, 8))),
     "selector-local-soft-stride2": dict(no_layers=2, selector_params=dict(scale_type="local", activation_type="soft", pool_size=(8, 8),
