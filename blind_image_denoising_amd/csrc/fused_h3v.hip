@@ -449,12 +449,12 @@ struct H3VRoleC {
     }
 
     // ---- compact layout (a.compact; bf_common.h): the lo planes are fp8 in memory, 8 bytes per pixel.  LDS-DMA cannot convert, so
-    // the loader of the lo planes (wave 9) takes them through registers: lane l owns the pixel pairs 2 (64 jj + l), +1 of both
-    // planes (one 16-byte load each), requests row s+3 in step s, and in step s+1 -- a whole step later, the data has arrived --
-    // decodes it to f16 and writes it to the ring: row s+2 is complete at the end of step s, one step before conv1 reads it
-    // (the DMA rows are complete one step later).  The storer of the lo planes (wave 11) encodes while it stores.
-    typedef unsigned u4 __attribute__((ext_vector_type(4)));
-    u4 lo_raw[2][2];                   // [plane - 2][jj]: two pixels x 8 fp8 of ring row "pending"
+    // the loader of the lo planes (wave 9) takes them through registers: lane l owns the pixels 64 j + l of both planes (one
+    // 8-byte load each; consecutive lanes = consecutive 16-byte ring records, the bank-conflict-free pattern of the DMA),
+    // requests row s+3 in step s, and in step s+1 -- a whole step later, the data has arrived -- decodes it to f16 and writes it
+    // to the ring: row s+2 is complete at the end of step s, one step before conv1 reads it (the DMA rows are complete one step
+    // later).  The storer of the lo planes (wave 11) encodes while it stores.
+    bf_u2 lo_raw[2][Gm::PIECES];       // [plane - 2][j]: 8 fp8 of one pixel of ring row "pending"
 
     __device__ __forceinline__ void lo_request(const H3VTile& t, const int r)
     {
@@ -465,14 +465,10 @@ struct H3VRoleC {
             const char* base = reinterpret_cast<const char*>(a.in) + t.img + 2 * (size_t)plane_g + (size_t)pl * (plane_g / 2) +
                                (size_t)(ok ? y : 0) * a.W * 8;
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int px = 2 * (64 * jj + lane);
-                u4 v = {0u, 0u, 0u, 0u};
-                if (ok && (FULLW || px < a.W)) v = *reinterpret_cast<const u4*>(base + (size_t)px * 8);
-                if (!FULLW) {
-                    if (px + 1 >= a.W) { v[2] = 0u; v[3] = 0u; }
-                }
-                lo_raw[pl][jj] = v;
+            for (int j = 0; j < Gm::PIECES; ++j) {
+                bf_u2 v = {0u, 0u};
+                if (ok && (FULLW || col_ok[j])) v = *reinterpret_cast<const bf_u2*>(base + (col_off[j] >> 1));
+                lo_raw[pl][j] = v;
             }
         }
     }
@@ -482,12 +478,8 @@ struct H3VRoleC {
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const u4 v = lo_raw[pl][jj];
-                char* dst = tin + (2 + pl) * Gm::IN_PLANE + slot * Gm::PITCH + (1 + 2 * (64 * jj + lane)) * 16;
-                *reinterpret_cast<h8*>(dst) = bf_h3c_decode8((bf_u2){v[0], v[1]});
-                *reinterpret_cast<h8*>(dst + 16) = bf_h3c_decode8((bf_u2){v[2], v[3]});
-            }
+            for (int j = 0; j < Gm::PIECES; ++j)
+                *reinterpret_cast<h8*>(tin + (2 + pl) * Gm::IN_PLANE + slot * Gm::PITCH + (1 + 64 * j + lane) * 16) = bf_h3c_decode8(lo_raw[pl][j]);
     }
 
     __device__ __forceinline__ void lo_store_row(const H3VTile& t, const int o, const int oslot) const
@@ -498,19 +490,13 @@ struct H3VRoleC {
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
             char* base = reinterpret_cast<char*>(a.out) + t.img + 2 * (size_t)plane_g + (size_t)pl * (plane_g / 2) + (size_t)t.y(o) * a.W * 8;
-            h8 rec[2][2];
+            h8 rec[Gm::PIECES];
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const char* src = tout + oslot * Gm::OUT_SLOT + (2 + pl) * Gm::OUT_PLANE + 2 * (64 * jj + lane) * 16;
-                rec[jj][0] = *reinterpret_cast<const h8*>(src);
-                rec[jj][1] = *reinterpret_cast<const h8*>(src + 16);
-            }
+            for (int j = 0; j < Gm::PIECES; ++j)
+                rec[j] = *reinterpret_cast<const h8*>(tout + oslot * Gm::OUT_SLOT + (2 + pl) * Gm::OUT_PLANE + (64 * j + lane) * 16);
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int px = 2 * (64 * jj + lane);
-                const bf_u2 e0 = bf_h3c_encode8(rec[jj][0]), e1 = bf_h3c_encode8(rec[jj][1]);
-                if (FULLW || px + 1 < a.W) *reinterpret_cast<u4*>(base + (size_t)px * 8) = (u4){e0[0], e0[1], e1[0], e1[1]};
-                else if (px < a.W) *reinterpret_cast<bf_u2*>(base + (size_t)px * 8) = e0;
+            for (int j = 0; j < Gm::PIECES; ++j) {
+                if (FULLW || col_ok[j]) *reinterpret_cast<bf_u2*>(base + (col_off[j] >> 1)) = bf_h3c_encode8(rec[j]);
             }
         }
     }
