@@ -762,3 +762,47 @@ extern "C" int bf_op_slice_channels(const float* src, float* dst, int64_t rows, 
                        offset, channels);
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
+
+// ------------------------------------------------------------------------------------------
+// add_concat_input (bfcnn/backbone_resnet.py:277-279): Concatenate([backbone features, backbone input]) in front of the head.  The
+// backbone input is the NORMALISED image (model.py:100-102), zero-padded as pad_to_power_of_2 pads the raw image (value 0 -> its
+// normalised value).  out [B,H,W,Cout] = feat [C] | normalise(x) [cin] | zeros up to Cout (the channel count the head's matrix
+// kernel takes; the head's first kernel carries zero rows there).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tg_concat_input_kernel(const float* __restrict__ feat, const void* __restrict__ x, int x_is_u8,
+                                                              float* __restrict__ out, int B, int H, int W, int Hs, int Ws, int C, int cin,
+                                                              int Cout, float v_min, float v_max)
+{
+    const int64_t n = (int64_t)B * H * W * Cout;
+    const float range = v_max - v_min;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % Cout);
+        const int64_t px = i / Cout;
+        float v = 0.f;
+        if (c < C) {
+            v = feat[px * C + c];
+        } else if (c < C + cin) {
+            const int xx = (int)(px % W);
+            const int yy = (int)((px / W) % H);
+            const int64_t b = px / ((int64_t)W * H);
+            float raw = 0.f;
+            if (yy < Hs && xx < Ws) {
+                const int64_t si = ((b * Hs + yy) * Ws + xx) * cin + (c - C);
+                raw = x_is_u8 ? (float)reinterpret_cast<const uint8_t*>(x)[si] : reinterpret_cast<const float*>(x)[si];
+            }
+            v = (fminf(fmaxf(raw, v_min), v_max) - v_min) / range - 0.5f;
+        }
+        out[i] = v;
+    }
+}
+
+extern "C" int bf_op_concat_input(const float* feat, const void* x, int x_is_u8, float* out, int B, int H, int W, int Hs, int Ws, int C,
+                                  int cin, int Cout, float v_min, float v_max, void* stream)
+{
+    if (!feat || !x || !out || B <= 0 || H <= 0 || W <= 0 || Hs <= 0 || Ws <= 0 || Hs > H || Ws > W || C <= 0 || cin <= 0 || Cout < C + cin)
+        return BF_EINVAL;
+    if (!(v_max > v_min)) return BF_EINVAL;
+    hipLaunchKernelGGL(tg_concat_input_kernel, dim3(tg_grid((int64_t)B * H * W * Cout)), dim3(256), 0, (hipStream_t)stream, feat, x, x_is_u8, out,
+                       B, H, W, Hs, Ws, C, cin, Cout, v_min, v_max);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}

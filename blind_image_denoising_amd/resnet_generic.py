@@ -118,9 +118,9 @@ class GenericResnetHydra:
     def __init__(self, config: Dict, device=None, seed: Optional[int] = None):
         bb, dn = config["backbone"], config["denoiser"]
         self.config = config
-        for key in ("add_concat_input", "use_bias"):
-            if bb.get(key, False):
-                raise NotImplementedError(f"resnet: {key} is outside the built graph")
+        if bb.get("use_bias", False):
+            raise NotImplementedError("resnet: use_bias is outside the built graph")
+        self.add_concat_input = bool(bb.get("add_concat_input", False))                # backbone_resnet.py:277-279
         # add_gelu / add_gradient_dropout / add_mean_sigma_normalization: the builder turns them into gelu_params /
         # gradient_dropout_params / mean_sigma_params (backbone_resnet.py:207-223), which resnet_blocks_full accepts and never reads
         # (backbone_blocks.py:118-125 sets use_mean_sigma / use_gradient_dropout, the block body :164-243 uses neither; gelu_params
@@ -251,11 +251,12 @@ class GenericResnetHydra:
         if self.add_final_bn:
             out.append(("final_bn/gamma", (self.filters,), "bn_gamma"))
             state += [("final_bn/moving_mean", (self.filters,)), ("final_bn/moving_variance", (self.filters,))]
+        cf = self.filters + (self.in_channels if self.add_concat_input else 0)   # Concatenate([x, backbone input]) ahead of the closing layers
         if self.add_channelwise:
-            out.append(("channelwise/w0", (self.filters,), "channelwise"))
+            out.append(("channelwise/w0", (cf,), "channelwise"))
         if self.add_multiplier:
             out.append(("multiplier/w0", (1,), "multiplier"))
-        out.append(("head/conv0/kernel", (1, 1, self.filters, self.head_filters), "conv"))
+        out.append(("head/conv0/kernel", (1, 1, cf, self.head_filters), "conv"))
         out.append(("head/conv1/kernel", (1, 1, self.head_filters, self.out_channels), "conv"))
         return out, state
 
@@ -374,12 +375,20 @@ class GenericResnetHydra:
                 w0, w1 = W[f"block{i}/selector/{kind}0/kernel"], W[f"block{i}/selector/{kind}1/kernel"]
                 P[f"b{i}sel"] = (dev(w0.reshape(w0.shape[-2], w0.shape[-1])), dev(w1.reshape(w1.shape[-2], w1.shape[-1])))
         w_head0 = W["head/conv0/kernel"][0, 0]
-        if self.add_final_bn:                                             # BN, then the closing multipliers: one per-channel affine
+        cf = w_head0.shape[0]
+        if self.add_final_bn and not self.add_concat_input:               # BN, then the closing multipliers: one per-channel affine
             sc, sh = bn_affine("final_bn")
             es = end_scale("", self.filters)
             P["final_affine"] = (dev((sc * es).reshape(1, 1, -1, 1)), dev(sh * es))
-        elif self.add_channelwise or self.add_multiplier:                 # no shift: the head's first 1x1 absorbs the factor (rows of W)
-            w_head0 = w_head0 * end_scale("", self.filters)[:, None]
+        else:
+            if self.add_final_bn:                                         # the input joins behind the BN: the multipliers cannot ride on it
+                sc, sh = bn_affine("final_bn")
+                P["final_affine"] = (dev(sc.reshape(1, 1, -1, 1)), dev(sh))
+            if self.add_channelwise or self.add_multiplier:               # no shift: the head's first 1x1 absorbs the factor (rows of W)
+                w_head0 = w_head0 * end_scale("", cf)[:, None]
+        if self.add_concat_input:                                         # zero rows up to the channel count the head kernel takes
+            self._head_cin = next(c for c in (32, 64, 128, 256) if c >= cf)
+            w_head0 = np.concatenate([w_head0, np.zeros((self._head_cin - cf, w_head0.shape[1]))], axis=0)
         P["head0"] = UL.pack_pointwise(dev(w_head0))
         P["head1"] = dev(W["head/conv1/kernel"])
         self._packed = P
@@ -435,6 +444,12 @@ class GenericResnetHydra:
             f = selector_block(f, t, first, *P[f"b{i}sel"], **self.selector) if self.selector else t
         if self.add_final_bn:
             f = UL.dwconv_mult(f, P["final_affine"][0], P["final_affine"][1])
+        if self.add_concat_input:
+            B, Hs, Ws, cin = x.shape
+            cat = torch.empty((B, H, W, self._head_cin), dtype=torch.float32, device=f.device)
+            N.check(N.lib().bf_op_concat_input(N.ptr(f), N.ptr(x), int(x.dtype == torch.uint8), N.ptr(cat), B, H, W, Hs, Ws, self.filters, cin,
+                                               self._head_cin, self.v_min, self.v_max, N.stream_ptr(f)), None, "bf_op_concat_input")
+            f = cat
         return f
 
     def _as_device(self, x):

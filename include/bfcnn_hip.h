@@ -426,6 +426,10 @@ int bf_op_dense2(const float* in, const float* w0, const float* b0, const float*
 int bf_op_selector_mix(const float* x1, const float* x2, const float* u, float* out, int64_t n, int soft, void* stream);
 int bf_op_avgpool_same(const float* in, float* out, int batch, int height, int width, int channels, int pool_h, int pool_w,
                        int stride_h, int stride_w, void* stream);
+/* add_concat_input (bfcnn/backbone_resnet.py:277-279): out [B,H,W,out_channels] = feat [channels] | normalise(x) [in_channels] | 0 ...,
+   x the raw image [B,Hs,Ws,in_channels] (u8 or f32), zero-padded to [H,W] before normalisation as the first convolution sees it */
+int bf_op_concat_input(const float* feat, const void* x, int x_is_u8, float* out, int batch, int height, int width, int src_height,
+                       int src_width, int channels, int in_channels, int out_channels, float v_min, float v_max, void* stream);
 /* selector_block in training: adjoints of bf_op_selector_mix (dx1, dx2, du from dy), bf_op_avgpool_same (dx [B,H,W,C] from the pooled
    map's gradient; accumulate != 0: added to dx), bf_op_dense2 in its selector form (no biases, act0 = leaky ReLU alpha0, final ReLU:
    din, dw0 [in_channels][squeeze], dw1 [squeeze][channels]; scratch: bf_op_dense2_bwd_scratch_floats), and the channel slice

@@ -152,6 +152,7 @@ class GenericResnetSpec:
     add_channelwise_scaling: bool = False   # ChannelwiseMultiplier closing every block and the backbone (:236-238, 282-283)
     add_learnable_multiplier: bool = False  # Multiplier, likewise (:240-242, 286-287)
     dropout_rate: float = -1.0            # RandomOnOff on every block's branch (:231-235): training only
+    add_concat_input: bool = False        # Concatenate([features, the backbone's (normalised) input]) ahead of the closing layers (:277-279)
 
     @staticmethod
     def from_config(model_config: Dict) -> "GenericResnetSpec":
@@ -176,7 +177,8 @@ class GenericResnetSpec:
             selector=GenericResnetSpec._selector(bb),
             add_initial_bn=bool(bb.get("add_initial_bn", False)), add_final_bn=bool(bb.get("add_final_bn", False)),
             add_channelwise_scaling=bool(bb.get("add_channelwise_scaling", False)),
-            add_learnable_multiplier=bool(bb.get("add_learnable_multiplier", False)), dropout_rate=float(bb.get("dropout_rate", -1)))
+            add_learnable_multiplier=bool(bb.get("add_learnable_multiplier", False)), dropout_rate=float(bb.get("dropout_rate", -1)),
+            add_concat_input=bool(bb.get("add_concat_input", False)))
 
     @staticmethod
     def _selector(bb) -> Tuple:
@@ -235,11 +237,12 @@ class GenericResnetSpec:
                     out.append((f"block{i}/selector/dense1/kernel", (cc, self.filters), "dense"))
         if self.add_final_bn:
             out.append(("final_bn/gamma", (self.filters,), "bn_gamma"))
+        cf = self.filters + (self.in_channels if self.add_concat_input else 0)
         if self.add_channelwise_scaling:
-            out.append(("channelwise/w0", (self.filters,), "channelwise"))
+            out.append(("channelwise/w0", (cf,), "channelwise"))
         if self.add_learnable_multiplier:
             out.append(("multiplier/w0", (1,), "multiplier"))
-        out.append(("head/conv0/kernel", (1, 1, self.filters, self.head_filters), "conv"))
+        out.append(("head/conv0/kernel", (1, 1, cf, self.head_filters), "conv"))
         out.append(("head/conv1/kernel", (1, 1, self.head_filters, self.out_channels), "conv"))
         return out
 
@@ -282,8 +285,8 @@ def _views(items, flat, dtype):
 def hydra_forward(spec: GenericResnetSpec, params: np.ndarray, state: np.ndarray, x: np.ndarray, dtype=F64) -> np.ndarray:
     P = _views(spec.tensors(), params, dtype)
     S = _views(spec.state_tensors(), state, dtype)
-    f = O.activation_fwd(O.conv2d_same(O.layer_normalize(x.astype(dtype), spec.v_min, spec.v_max), P["base/kernel"]),
-                         spec.base_activation)
+    xn = O.layer_normalize(x.astype(dtype), spec.v_min, spec.v_max)
+    f = O.activation_fwd(O.conv2d_same(xn, P["base/kernel"]), spec.base_activation)
     scaled = lambda t, name: t * np.maximum(P[name] + 1.0, 0.0)        # activation "relu" of (w0 + w1), w1 = 1 (backbone_resnet.py:190-202)
     if spec.add_initial_bn:
         f = O.bn_infer(f, P["initial_bn/gamma"], S["initial_bn/moving_mean"], S["initial_bn/moving_variance"], BN_EPS)
@@ -313,6 +316,8 @@ def hydra_forward(spec: GenericResnetSpec, params: np.ndarray, state: np.ndarray
             f = t + f
     if spec.add_final_bn:
         f = O.bn_infer(f, P["final_bn/gamma"], S["final_bn/moving_mean"], S["final_bn/moving_variance"], BN_EPS)
+    if spec.add_concat_input:
+        f = np.concatenate([f, xn], axis=-1)
     if spec.add_channelwise_scaling:
         f = scaled(f, "channelwise/w0")
     if spec.add_learnable_multiplier:

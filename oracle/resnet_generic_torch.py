@@ -175,6 +175,8 @@ def hydra(spec: R.GenericResnetSpec, P, S, x, training: bool, drop_scale=None):
             f = t + f
     if spec.add_final_bn:
         f = _batch_norm(f, "final_bn", P, S, new_state, training)
+    if spec.add_concat_input:
+        f = torch.cat([f, xn], dim=-1)
     if spec.add_channelwise_scaling:
         f = scaled(f, "channelwise/w0")
     if spec.add_learnable_multiplier:

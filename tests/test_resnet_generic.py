@@ -35,9 +35,14 @@ def test_shipped_config_inventory_and_host_logic():
     bad = G.shipped_config(); bad["backbone"]["block_filters"] = [32, 128, 64]     # residual Add needs `filters` channels
     with pytest.raises(ValueError, match="residual Add"):
         bf.model_builder(bad, device="cpu")
-    bad = G.shipped_config(); bad["backbone"]["add_concat_input"] = True
+    bad = G.shipped_config(); bad["backbone"]["use_bias"] = True
     with pytest.raises(NotImplementedError):
         bf.model_builder(bad, device="cpu")
+    cat = G.shipped_config(); cat["backbone"].update(add_concat_input=True, add_channelwise_scaling=True)
+    mc, sc = bf.model_builder(cat, device="cpu", seed=0).hydra, G.GenericResnetSpec.from_config(cat)
+    assert [(v[0], tuple(v[1]), v[2]) for v in mc.trainable_variables] == [(n, tuple(s), k) for n, s, k in sc.tensors()]
+    assert dict((v[0], tuple(v[1])) for v in mc.trainable_variables)["head/conv0/kernel"] == (1, 1, 35, 32)     # features | input
+    assert dict((v[0], tuple(v[1])) for v in mc.trainable_variables)["channelwise/w0"] == (35,)
     # flags the builder turns into parameters resnet_blocks_full never reads (backbone_resnet.py:207-223): same graph
     same = G.shipped_config(); same["backbone"].update(add_gelu=True, add_gradient_dropout=True, add_mean_sigma_normalization=True)
     assert bf.model_builder(same, device="cpu", seed=0).hydra.trainable_variables == m.trainable_variables
@@ -109,14 +114,19 @@ TWO_CONV = dict(filters=32, kernel_size=3, block_kernels=[3, 3], block_filters=[
                                 dict(TWO_CONV, add_channelwise_scaling=True, add_gates=True),
                                 dict(TWO_CONV, add_learnable_multiplier=True, add_final_bn=True, base_activation="relu"),
                                 dict(TWO_CONV, add_channelwise_scaling=True, base_activation="gelu"),
-                                dict(add_channelwise_scaling=True, selector_params=dict(scale_type="local", pool_size=(16, 16)))],
+                                dict(add_channelwise_scaling=True, selector_params=dict(scale_type="local", pool_size=(16, 16))),
+                                dict(add_concat_input=True),
+                                dict(add_concat_input=True, add_final_bn=True, add_channelwise_scaling=True, add_learnable_multiplier=True),
+                                dict(TWO_CONV, filters=64, block_filters=[64, 64], add_concat_input=True, add_channelwise_scaling=True)],
                          ids=["bn-around-blocks", "multipliers-folded", "everything", "gate-then-channelwise", "relu-base-final-bn",
-                              "gelu-base-unfolded", "selector-after-channelwise"])
+                              "gelu-base-unfolded", "selector-after-channelwise", "concat-input", "concat-input-bn-multipliers",
+                              "concat-input-64"])
 def test_builder_flags_match_oracle(bb):
     """add_initial_bn / add_final_bn (backbone_resnet.py:264-275), add_channelwise_scaling / add_learnable_multiplier closing every block
     and the backbone (backbone_blocks.py:215-221, backbone_resnet.py:282-287), dropout_rate (identity at inference), the three flags
     without effect on the graph; multipliers folded into the last convolution where they commute with its activation, their own
-    pass otherwise (behind a gate, GELU)"""
+    pass otherwise (behind a gate, GELU); add_concat_input (backbone_resnet.py:277-279): the normalised input, pad band included, joins
+    the features in front of the closing multipliers and the head (35 / 67 channels, run as 64 / 128 with zero kernel rows)"""
     cfg = G.shipped_config()
     cfg["backbone"].update(bb)
     _check(cfg, (2, 40, 48), seed=13)
