@@ -806,3 +806,43 @@ extern "C" int bf_op_concat_input(const float* feat, const void* x, int x_is_u8,
                        B, H, W, Hs, Ws, C, cin, Cout, v_min, v_max);
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
+
+// ------------------------------------------------------------------------------------------
+// selector_block's optional pre-filters on the selector layer (bfcnn/custom_layers_selector.py:160-185; utilities.py:566-620):
+//   local_normalization: (x - m) / sqrt(pool((x - m)^2) + eps), m = AveragePooling2D(pool, strides 1, same)(x): the two poolings are
+//     bf_op_avgpool_same, the two element-wise stages bf_op_center_scale (var NULL: (x - m)^2; else (x - m) / sqrt(var + eps));
+//   global_normalization is bf_op_bn_train_fwd per sample with gamma = 1 (same formula, biased variance);
+//   lowpass / highpass: x (1 - tanh(a x)^b) / x tanh(a x)^b, b a small positive integer (the reference passes 4.0).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tg_center_scale_kernel(const float* __restrict__ x, const float* __restrict__ m, const float* __restrict__ var,
+                                                              float* __restrict__ out, int64_t n, float eps)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float d = x[i] - m[i];
+        out[i] = var ? d / sqrtf(var[i] + eps) : d * d;
+    }
+}
+
+__global__ __launch_bounds__(256) void tg_pass_filter_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n, float a, int b, int highpass)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = x[i], t = tanhf(a * v);
+        float f = 1.f;
+        for (int k = 0; k < b; ++k) f *= t;
+        out[i] = (highpass ? f : 1.f - f) * v;
+    }
+}
+
+extern "C" int bf_op_center_scale(const float* x, const float* mean, const float* var, float* out, int64_t n, float eps, void* stream)
+{
+    if (!x || !mean || !out || n <= 0) return BF_EINVAL;
+    hipLaunchKernelGGL(tg_center_scale_kernel, dim3(tg_grid(n)), dim3(256), 0, (hipStream_t)stream, x, mean, var, out, n, eps);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+extern "C" int bf_op_pass_filter(const float* x, float* out, int64_t n, float a, int b, int highpass, void* stream)
+{
+    if (!x || !out || n <= 0 || b < 1 || b > 16) return BF_EINVAL;
+    hipLaunchKernelGGL(tg_pass_filter_kernel, dim3(tg_grid(n)), dim3(256), 0, (hipStream_t)stream, x, out, n, a, b, highpass);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}

@@ -60,14 +60,57 @@ def squeeze_and_excite_block(x: torch.Tensor, w0: torch.Tensor, b0: Optional[tor
     return _gate_ex(x, x, None, None, w0, b0, w1, b1, 2, 0.1, mode)
 
 
+SELECTOR_EPSILON = 1e-3          # DEFAULT_EPSILON (bfcnn/constants.py:7) of global_normalization / local_normalization
 SELECTOR_GLOBAL_LEAKY = 0.2      # Dense(activation="leaky_relu"): unresolvable in Keras 2.13, slope 0.2 from Keras 2.15 on
 
 
+def _selector_prefilter(sel: torch.Tensor, pre: Dict, pre_w: Optional[torch.Tensor], pool, Ct: int) -> torch.Tensor:
+    """the optional stages in front of the pooling (custom_layers_selector.py:160-185): Conv2D 1x1 linear -> global_normalization ->
+    local_normalization(pool) -> lowpass_filter(4, 4) -> highpass_filter(4, 4) (utilities.py:566-620)"""
+    L = N.lib()
+    x = sel
+    if pre.get("conv1x1"):
+        x = UL.pointwise(x, pre_w, Ct)
+    B, H, W, C = x.shape
+    if pre.get("gn"):            # per sample and channel (x - mean) / sqrt(var + 1e-3): BatchNorm's batch-statistics forward on one sample
+        ones, mm, mv = (torch.ones(C, dtype=torch.float32, device=x.device) for _ in range(3))
+        save = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+        scratch = torch.empty(int(L.bf_op_bn_train_scratch_floats(C)) + 2, dtype=torch.float32, device=x.device)
+        out = torch.empty_like(x)
+        for b in range(B):
+            xb, ob = x[b], out[b]
+            N.check(L.bf_op_bn_train_fwd(N.ptr(xb), N.ptr(ones), N.ptr(ob), N.ptr(save), N.ptr(mm), N.ptr(mv), H * W, C, SELECTOR_EPSILON, 0.0, 0,
+                                         0.0, N.ptr(scratch), scratch.numel(), N.stream_ptr(x)), None, "bf_op_bn_train_fwd")
+        x = out
+    if pre.get("ln"):
+        def pooled(t):
+            o = torch.empty_like(t)
+            N.check(L.bf_op_avgpool_same(N.ptr(t), N.ptr(o), B, H, W, C, pool[0], pool[1], 1, 1, N.stream_ptr(t)), None, "bf_op_avgpool_same")
+            return o
+        mean = pooled(x)
+        sq = torch.empty_like(x)
+        N.check(L.bf_op_center_scale(N.ptr(x), N.ptr(mean), None, N.ptr(sq), x.numel(), SELECTOR_EPSILON, N.stream_ptr(x)), None, "bf_op_center_scale")
+        var = pooled(sq)
+        out = torch.empty_like(x)
+        N.check(L.bf_op_center_scale(N.ptr(x), N.ptr(mean), N.ptr(var), N.ptr(out), x.numel(), SELECTOR_EPSILON, N.stream_ptr(x)), None,
+                "bf_op_center_scale")
+        x = out
+    for key, high in (("lp", 0), ("hp", 1)):
+        if pre.get(key):
+            out = torch.empty_like(x)
+            N.check(L.bf_op_pass_filter(N.ptr(x), N.ptr(out), x.numel(), 4.0, 4, high, N.stream_ptr(x)), None, "bf_op_pass_filter")
+            x = out
+    return x
+
+
 def selector_block(x1: torch.Tensor, x2: torch.Tensor, sel: torch.Tensor, w0: torch.Tensor, w1: torch.Tensor, scale_type: str = "local",
-                   activation_type: str = "hard", pool=(32, 32), stride=(8, 8), compress: Optional[int] = None) -> torch.Tensor:
+                   activation_type: str = "hard", pool=(32, 32), stride=(8, 8), compress: Optional[int] = None,
+                   pre: Optional[Dict] = None, pre_w: Optional[torch.Tensor] = None) -> torch.Tensor:
     """selector_block (bfcnn/custom_layers_selector.py:81-330), all four scale types: x1 * s + x2 * (1 - s) with
-    s = hard_sigmoid | sigmoid (2.5 - u), u >= 0 computed from the selector layer."""
+    s = hard_sigmoid | sigmoid (2.5 - u), u >= 0 computed from the selector layer (through its optional pre-filters)."""
     soft = activation_type == "soft"
+    if pre:
+        sel = _selector_prefilter(sel, pre, pre_w, pool, int(x1.shape[-1]))
     if scale_type == "global":
         return _gate_ex(sel, x1, x2, None, w0, None, w1, None, 2, SELECTOR_GLOBAL_LEAKY, 3 if soft else 2)
     B, H, W, Cs = sel.shape
@@ -138,9 +181,10 @@ class GenericResnetHydra:
         sp = bb.get("selector_params")
         if sp is not None:
             # selector_block (custom_layers_selector.py:81-330) in place of the skip Add (backbone_blocks.py:227-239)
-            for key in ("use_lowpass", "use_highpass", "use_conv1x1_selector", "use_local_normalization", "use_global_normalization"):
-                if sp.get(key, False):
-                    raise NotImplementedError(f"selector_block: {key} is outside the built graph")
+            # optional pre-filters on the selector layer, in the reference's order (custom_layers_selector.py:160-185)
+            pre = dict(conv1x1=bool(sp.get("use_conv1x1_selector", False)), gn=bool(sp.get("use_global_normalization", False)),
+                       ln=bool(sp.get("use_local_normalization", False)), lp=bool(sp.get("use_lowpass", False)),
+                       hp=bool(sp.get("use_highpass", False)))
             st, at = str(sp.get("scale_type", "local")).strip().lower(), str(sp.get("activation_type", "hard")).strip().lower()
             if st not in ("local", "global", "mixed", "multiscale"):
                 raise KeyError(st.upper())                                          # ScaleType[...] (custom_layers_selector.py:45)
@@ -149,7 +193,8 @@ class GenericResnetHydra:
             pool = tuple(int(v) for v in sp.get("pool_size", (32, 32)))
             stride = tuple(int(v) for v in sp.get("strides_size", (pool[0] / 4, pool[1] / 4)))
             self.selector = dict(scale_type=st, activation_type=at, pool=pool, stride=stride,
-                                 compress=max(1, int(round(int(bb.get("filters", 32)) * sp.get("filters_compress_ratio", 0.25)))))
+                                 compress=max(1, int(round(int(bb.get("filters", 32)) * sp.get("filters_compress_ratio", 0.25)))),
+                                 pre=pre if any(pre.values()) else None)
         if dn.get("use_bias", False) or dn.get("use_bn", False) or dn.get("use_ln", False):
             raise NotImplementedError("denoiser head: use_bias / use_bn / use_ln are outside the built graph")
         self.filters = int(bb.get("filters", 32))
@@ -241,6 +286,9 @@ class GenericResnetHydra:
             if self.selector:
                 cs = self.block_filters[0] if self.block_depthwise[0] == -1 else self.filters * self.block_depthwise[0]
                 cc = self.selector["compress"]
+                if (self.selector["pre"] or {}).get("conv1x1"):       # Conv2D 1x1, linear, to the target filters: created first (:162-169)
+                    out.append((f"block{i}/selector/pre/kernel", (1, 1, cs, self.filters), "conv"))
+                    cs = self.filters
                 if self.selector["scale_type"] != "global":
                     cs *= {"local": 1, "mixed": 2, "multiscale": 3}[self.selector["scale_type"]]
                     out.append((f"block{i}/selector/conv0/kernel", (1, 1, cs, cc), "conv"))
@@ -374,6 +422,8 @@ class GenericResnetHydra:
                 kind = "dense" if self.selector["scale_type"] == "global" else "conv"
                 w0, w1 = W[f"block{i}/selector/{kind}0/kernel"], W[f"block{i}/selector/{kind}1/kernel"]
                 P[f"b{i}sel"] = (dev(w0.reshape(w0.shape[-2], w0.shape[-1])), dev(w1.reshape(w1.shape[-2], w1.shape[-1])))
+                if f"block{i}/selector/pre/kernel" in W:
+                    P[f"b{i}selpre"] = UL.pack_pointwise(dev(W[f"block{i}/selector/pre/kernel"][0, 0]))
         w_head0 = W["head/conv0/kernel"][0, 0]
         cf = w_head0.shape[0]
         if self.add_final_bn and not self.add_concat_input:               # BN, then the closing multipliers: one per-channel affine
@@ -441,7 +491,7 @@ class GenericResnetHydra:
                 j += 1
             if tail is not None:
                 t = scale_add(None if self.selector else f, t, tail)
-            f = selector_block(f, t, first, *P[f"b{i}sel"], **self.selector) if self.selector else t
+            f = selector_block(f, t, first, *P[f"b{i}sel"], pre_w=P.get(f"b{i}selpre"), **self.selector) if self.selector else t
         if self.add_final_bn:
             f = UL.dwconv_mult(f, P["final_affine"][0], P["final_affine"][1])
         if self.add_concat_input:

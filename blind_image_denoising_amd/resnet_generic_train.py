@@ -39,6 +39,8 @@ class GenericResnetTrainGraph:
         for j, (kk, g) in enumerate(zip(model.block_kernels, model.block_groups)):
             if g != 1 and kk != 1:
                 raise NotImplementedError("training: grouped convolutions are built for 1x1 kernels")
+        if getattr(model, "selector", None) and model.selector.get("pre"):
+            raise NotImplementedError("training: the selector's optional pre-filters are built for inference only")
         if getattr(model, "add_concat_input", False):
             raise NotImplementedError("training: add_concat_input is built for inference only")
         self.ops = None

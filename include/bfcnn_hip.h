@@ -430,6 +430,11 @@ int bf_op_avgpool_same(const float* in, float* out, int batch, int height, int w
    x the raw image [B,Hs,Ws,in_channels] (u8 or f32), zero-padded to [H,W] before normalisation as the first convolution sees it */
 int bf_op_concat_input(const float* feat, const void* x, int x_is_u8, float* out, int batch, int height, int width, int src_height,
                        int src_width, int channels, int in_channels, int out_channels, float v_min, float v_max, void* stream);
+/* selector_block's optional pre-filters (bfcnn/custom_layers_selector.py:160-185; utilities.py:566-620).  local_normalization =
+   bf_op_avgpool_same (strides 1) + bf_op_center_scale (var NULL: out = (x - mean)^2; else out = (x - mean) / sqrt(var + eps));
+   global_normalization = bf_op_bn_train_fwd per sample with gamma 1; lowpass / highpass: out = x (1 - tanh(a x)^b) / x tanh(a x)^b */
+int bf_op_center_scale(const float* x, const float* mean, const float* var, float* out, int64_t n, float eps, void* stream);
+int bf_op_pass_filter(const float* x, float* out, int64_t n, float a, int b, int highpass, void* stream);
 /* selector_block in training: adjoints of bf_op_selector_mix (dx1, dx2, du from dy), bf_op_avgpool_same (dx [B,H,W,C] from the pooled
    map's gradient; accumulate != 0: added to dx), bf_op_dense2 in its selector form (no biases, act0 = leaky ReLU alpha0, final ReLU:
    din, dw0 [in_channels][squeeze], dw1 [squeeze][channels]; scratch: bf_op_dense2_bwd_scratch_floats), and the channel slice

@@ -92,6 +92,25 @@ def squeeze_and_excite_block(x, w0, b0, w1, b1, hard_sigmoid_version=False, lear
 SELECTOR_GLOBAL_LEAKY = 0.2      # Dense(activation="leaky_relu") does not resolve in Keras 2.13; Keras >= 2.15 gives slope 0.2
 
 
+def selector_prefilter(sel, flags, pre_w, pool_size):
+    """custom_layers_selector.py:160-185 with utilities.py:566-620: Conv2D 1x1 (linear) -> global_normalization -> local_normalization
+    -> lowpass_filter(a=4, b=4) -> highpass_filter(a=4, b=4), each optional, in this order"""
+    x = sel
+    if "use_conv1x1_selector" in flags:
+        x = x @ pre_w.reshape(pre_w.shape[-2], pre_w.shape[-1])
+    if "use_global_normalization" in flags:
+        m = x.mean(axis=(1, 2), keepdims=True)
+        x = (x - m) / np.sqrt(((x - m) ** 2).mean(axis=(1, 2), keepdims=True) + 1e-3)
+    if "use_local_normalization" in flags:
+        m = avgpool_same(x, pool_size, (1, 1))
+        x = (x - m) / np.sqrt(avgpool_same((x - m) ** 2, pool_size, (1, 1)) + 1e-3)
+    if "use_lowpass" in flags:
+        x = (1.0 - np.tanh(4.0 * x) ** 4.0) * x
+    if "use_highpass" in flags:
+        x = np.tanh(4.0 * x) ** 4.0 * x
+    return x
+
+
 def selector_block(x1, x2, sel, w0, w1, scale_type="local", activation_type="hard", pool_size=(32, 32), strides_size=None):
     """custom_layers_selector.py:81-330, scale types LOCAL (the default), MULTISCALE, MIXED and GLOBAL, no optional pre-filters:
     LOCAL: AveragePooling2D(pool, strides = pool / 4, same) -> 1x1 conv leaky_relu (0.3, activation_wrapper) -> 1x1 conv relu ->
@@ -190,7 +209,9 @@ class GenericResnetSpec:
         filters = bb.get("filters", 32)
         return (str(sp.get("scale_type", "local")).lower(), str(sp.get("activation_type", "hard")).lower(),
                 max(1, int(round(filters * sp.get("filters_compress_ratio", 0.25)))), pool, stride,
-                sp.get("kernel_regularizer", "l1"))                       # custom_layers_selector.py:88: the selector layers' regulariser
+                sp.get("kernel_regularizer", "l1"),                       # custom_layers_selector.py:88: the selector layers' regulariser
+                tuple(k for k in ("use_conv1x1_selector", "use_global_normalization", "use_local_normalization", "use_lowpass",
+                                  "use_highpass") if sp.get(k, False)))   # optional pre-filters (:160-185)
 
     def gate_channels(self) -> int:
         """backbone_blocks.py:131-141: the second convolution's filters, or filters x depth_multiplier for a depthwise one"""
@@ -228,6 +249,9 @@ class GenericResnetSpec:
                 out.append((f"block{i}/multiplier/w0", (1,), "multiplier"))
             if self.selector:                                      # the selector's two layers close the block (backbone_blocks.py:227-239)
                 cs, cc = self.block_filters[0] if self.block_depthwise[0] == -1 else self.filters * self.block_depthwise[0], self.selector[2]
+                if "use_conv1x1_selector" in self.selector[6]:
+                    out.append((f"block{i}/selector/pre/kernel", (1, 1, cs, self.filters), "conv"))
+                    cs = self.filters
                 if self.selector[0] != "global":
                     cs *= {"local": 1, "mixed": 2, "multiscale": 3}[self.selector[0]]
                     out.append((f"block{i}/selector/conv0/kernel", (1, 1, cs, cc), "conv"))
@@ -310,6 +334,8 @@ def hydra_forward(spec: GenericResnetSpec, params: np.ndarray, state: np.ndarray
         # RandomOnOff (dropout_rate): Dropout is the identity outside training
         if spec.selector:
             kind = "dense" if spec.selector[0] == "global" else "conv"
+            if spec.selector[6]:
+                first = selector_prefilter(first, spec.selector[6], P.get(f"block{i}/selector/pre/kernel"), spec.selector[3])
             f = selector_block(f, t, first, P[f"block{i}/selector/{kind}0/kernel"], P[f"block{i}/selector/{kind}1/kernel"],
                                spec.selector[0], spec.selector[1], spec.selector[3], spec.selector[4])
         else:

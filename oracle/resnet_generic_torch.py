@@ -168,6 +168,8 @@ def hydra(spec: R.GenericResnetSpec, P, S, x, training: bool, drop_scale=None):
         if training and i in drop_scale:
             t = t * drop_scale[i].reshape(-1, 1, 1, 1)
         if spec.selector:
+            if spec.selector[6]:
+                raise NotImplementedError("the gradient oracle does not restate the selector's optional pre-filters (inference only in the product)")
             kind = "dense" if spec.selector[0] == "global" else "conv"
             f = selector_block(f, t, first, P[f"block{i}/selector/{kind}0/kernel"], P[f"block{i}/selector/{kind}1/kernel"],
                                spec.selector[0], spec.selector[1], spec.selector[3], spec.selector[4])

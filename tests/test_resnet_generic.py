@@ -159,6 +159,31 @@ def test_oracle_avgpool_and_squeeze_excite_match_torch():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sp", [dict(scale_type="local", pool_size=(8, 8), use_conv1x1_selector=True),
+                                dict(scale_type="local", pool_size=(8, 8), use_global_normalization=True),
+                                dict(scale_type="global", use_local_normalization=True, pool_size=(8, 8)),
+                                dict(scale_type="multiscale", pool_size=(8, 8), use_lowpass=True),
+                                dict(scale_type="mixed", pool_size=(8, 8), use_highpass=True, activation_type="soft"),
+                                dict(scale_type="local", pool_size=(8, 8), use_conv1x1_selector=True, use_global_normalization=True,
+                                     use_local_normalization=True, use_lowpass=True, use_highpass=True)],
+                         ids=["conv1x1", "global-norm", "local-norm-global-scale", "lowpass-multiscale", "highpass-mixed", "all-five"])
+def test_selector_prefilters_match_oracle(sp):
+    """the optional stages in front of the selector's pooling (custom_layers_selector.py:160-185; utilities.py:566-620): 1x1
+    convolution to the target filters, global / local normalisation (DEFAULT_EPSILON 1e-3), lowpass / highpass (a = b = 4)"""
+    cfg = G.shipped_config()
+    cfg["backbone"].update(no_layers=2, selector_params=sp)
+    m = _check(cfg, (2, 32, 48), seed=17)
+    if sp.get("use_conv1x1_selector"):
+        assert "block0/selector/pre/kernel" in [v[0] for v in m.trainable_variables]
+    fns_error = None
+    try:
+        bf.build_train_functions(m, bf.loss_function_builder({"hinge": 0.0}))
+    except NotImplementedError as e:
+        fns_error = e
+    assert fns_error is not None                                              # training with pre-filters: refused, not wrong
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("sp", [dict(scale_type="local", pool_size=(16, 16)), dict(scale_type="local", activation_type="soft", pool_size=(8, 8), strides_size=(4, 4)),
                                 dict(scale_type="global"), dict(scale_type="global", activation_type="soft", filters_compress_ratio=0.5),
                                 dict(scale_type="multiscale", pool_size=(8, 8)), dict(scale_type="mixed", pool_size=(16, 16), activation_type="soft")],
