@@ -55,9 +55,16 @@ def test_prepare_data_draws_follow_the_reference_config():
     assert on.min() >= 5 and on.max() <= 20 and abs(on.mean() - 12.5) < 0.4
     assert len({d["seed"] for d in draws}) == len(draws)
     assert bf.PrepareData({}, seed=1).draw()["add_std"] == 0.0
-    for bad in ({"random_blur": True}, {"use_jpeg_noise": True}, {"random_rotate": 0.1}, {"quantization": 4}, {"inpaint_drop_rate": 0.1}):
-        with pytest.raises(NotImplementedError):
-            bf.PrepareData(bad)
+    # options dataset_builder reads (dataset.py:84-105) and prepare_data_fn never uses (:123-239): every shipped config sets some of
+    # them; they are accepted and change nothing, as in the reference
+    shipped = {"random_blur": True, "round_values": True, "random_rotate": 1.57, "use_jpeg_noise": False, "random_up_down": True,
+               "random_left_right": True, "inpaint_drop_rate": 0.5, "quantization": -1, "multiplicative_noise": [0.05, 0.1],
+               "additional_noise": [5, 40]}                                    # dataset section of configs/unet_laplacian_v5.json
+    pd_ = bf.PrepareData(shipped, seed=3)
+    assert sorted(pd_.ignored) == ["inpaint_drop_rate", "random_blur", "random_rotate"]
+    plain = bf.PrepareData({k: v for k, v in shipped.items() if k not in pd_.ignored}, seed=3)
+    assert [pd_.draw() for _ in range(5)] == [plain.draw() for _ in range(5)]
+    assert bf.PrepareData({"quantization": 4, "use_jpeg_noise": True}).ignored == ["use_jpeg_noise", "quantization"]
     with pytest.raises(ValueError):
         bf.dataset_builder({}, None)
 
@@ -102,5 +109,4 @@ def test_prepare_data_builder_and_statistics():
     assert seen_add > 3 and seen_clean > 3                      # each noise is applied with probability 1/2
     batches = list(bf.dataset_builder(cfg, [np.zeros((2, 8, 8, 3), np.float32)] * 3, seed=1))
     assert len(batches) == 3 and batches[0][0].is_cuda and batches[0][1].shape == (2, 8, 8, 3)
-    with pytest.raises(NotImplementedError):
-        bf.PrepareData({"random_blur": True})
+    assert bf.PrepareData({"random_blur": True}).ignored == ["random_blur"]

@@ -186,3 +186,27 @@ def test_shipped_config_trains_through_the_public_api():
     model.state.copy_(st)                                                          # (moving statistics advance every step)
     b = fns.train_step_single_gpu(gt, x)[4]
     assert torch.equal(a, b)                                                       # fixed-order reductions: bitwise reproducible
+
+
+def test_shipped_resnet_pipeline_config_runs_unchanged(tmp_path):
+    """every section of the one resnet config the reference ships (configs/resnet_color_1x6_bn_32x128x32_1x3x1_128x128_depthwise_l1_relu.json)
+    with its shipped values, restated -- only `epochs`, the batch / crop size and the data source (an in-memory list instead of the
+    image directories) differ: dataset_builder takes the options the reference reads and never uses (random_blur, random_rotate),
+    train_loop builds everything from the file's sections, trains with gradient accumulation over 2 micro-batches, checkpoints"""
+    cfg = {"model": R.shipped_config(),
+           "train": {"epochs": 1, "total_steps": -1, "gpu_batches_per_step": 2, "use_test_images": True, "checkpoints_to_keep": 3,
+                     "checkpoint_every": 10000, "visualization_number": 4, "visualization_every": 1000,
+                     "optimizer": {"type": "ADAM", "gradient_clipping_by_norm": 1.0,
+                                   "schedule": {"type": "exponential_decay", "config": {"decay_rate": 0.9, "decay_steps": 40000,
+                                                                                        "learning_rate": 0.001}}}},
+           "loss": {"hinge": 0.5, "cutoff": 255.0, "mae_multiplier": 1.0, "ssim_multiplier": 1.0, "regularization": 0.01},
+           "dataset": {"batch_size": 4, "color_mode": "rgb", "no_crops_per_image": 1, "value_range": [0, 255], "clip_value": True,
+                       "random_blur": True, "round_values": True, "random_rotate": 1.57, "random_up_down": True, "random_left_right": True,
+                       "input_shape": [64, 64, 3], "multiplicative_noise": [0.05, 0.1], "additional_noise": [5, 10, 20, 30, 40]}}
+    clean, _ = O.synthetic_batch(4, 64, 64, seed=3)
+    data = list(bf.dataset_builder(cfg["dataset"], [clean.astype(np.float32)] * 4, seed=5))
+    model, hist = bf.train_loop(cfg, str(tmp_path), dataset=data)
+    assert type(model).__name__ == "GenericResnetHydra" and len(hist) == 2 and np.isfinite(hist).all()
+    assert (tmp_path / "final").exists()
+    out = bf.load_model(str(tmp_path / "final"))(clean.astype(np.uint8))
+    assert out.shape == clean.shape and out.dtype == np.uint8

@@ -405,3 +405,31 @@ def test_trained_archive_fine_tunes_through_the_public_api():
     assert 0.0 < moved < 1e-3
     noisy = V.corrupt(z["kitti"][:1], 20.0, seed=20)
     V.assert_denoised(z["kitti"][:1], noisy, bf.DenoiserModule(model)(noisy), "fine-tuned")
+
+
+def test_shipped_v5_pipeline_config_runs_unchanged(tmp_path):
+    """every section of bfcnn/configs/unet_laplacian_v5.json with its shipped values (restated; only `epochs`, the accumulation count and
+    the data source differ: an in-memory list instead of image directories, 64 x 64 crops): dataset_builder accepts the options the
+    reference reads and never uses (random_blur, random_rotate, inpaint_drop_rate: dataset.py:84-105 vs :123-239), train_loop builds
+    model / loss / optimizer / schedules from it, trains, checkpoints and writes the model directories"""
+    cfg = {
+        "model": U.canonical_config(depth=3, width=3, filters=32)["model"],
+        "train": {"epochs": 1, "total_steps": -1, "gpu_batches_per_step": 2, "use_test_images": True, "checkpoints_to_keep": 3,
+                  "checkpoint_every": 10000, "visualization_number": 4, "visualization_every": 500,
+                  "optimizer": {"type": "ADAM", "gradient_clipping_by_norm_local": 1.0,
+                                "schedule": {"type": "cosine_decay_restarts",
+                                             "config": {"t_mul": 1.1, "epsilon": 0.00001, "decay_rate": 0.9, "decay_steps": 40000,
+                                                        "learning_rate": 0.001}}}},
+        "loss": {"hinge": 3.5, "cutoff": 255.0, "mae_multiplier": 1.0, "mse_multiplier": 0.5, "ssim_multiplier": 1.0, "regularization": 0.01},
+        "dataset": {"batch_size": 4, "color_mode": "rgb", "no_crops_per_image": 4, "value_range": [0, 255], "clip_value": True,
+                    "quantization": -1, "random_blur": True, "round_values": True, "random_rotate": 1.57, "use_jpeg_noise": False,
+                    "random_up_down": True, "random_left_right": True, "input_shape": [64, 64, 3], "inpaint_drop_rate": 0.5,
+                    "multiplicative_noise": [0.05, 0.1], "additional_noise": [5, 40]}}
+    clean, _ = O.synthetic_batch(4, 64, 64, seed=12)
+    data = list(bf.dataset_builder(cfg["dataset"], [clean.astype(np.float32)] * 4, seed=2))
+    assert len(data) == 4 and data[0][0].shape == (4, 64, 64, 3) and data[0][0].is_cuda
+    model, hist = bf.train_loop(cfg, str(tmp_path), dataset=data)
+    assert len(hist) == 2 and np.isfinite(hist).all()                         # 4 micro-batches, 2 per optimizer step
+    assert (tmp_path / "final").exists()
+    out = bf.load_model(str(tmp_path / "final"))(clean.astype(np.uint8))
+    assert out.shape == clean.shape and out.dtype == np.uint8
