@@ -27,6 +27,8 @@ from .checkpoint import Checkpoint, CheckpointManager
 from .resnet_generic import squeeze_and_excite_block, selector_block
 from .pyramid import (build_pyramid_model, build_inverse_pyramid_model, multiscales_generator_fn)
 from .dataset import dataset_builder, PrepareData, noise_augment
+from .export_model import export_model
+from .custom_layers import RandomOnOff, Multiplier, ChannelwiseMultiplier
 
 current_dir = pathlib.Path(__file__).parent.resolve()
 
@@ -39,6 +41,8 @@ if configs_dir.is_dir():
             configs.append((os.path.basename(str(_f)), load_config(str(_f))))
         except Exception as _e:     # a broken config must not break import
             logger.error(f"failed to load config [{_f}]: {_e}")
+
+CONFIGS_DICT = {os.path.splitext(name)[0]: cfg for name, cfg in configs}          # bfcnn/__init__.py:41-44
 
 # ---- pretrained registry (bfcnn/__init__.py:48-75) --------------------------------------------
 pretrained_dir = current_dir / "pretrained"

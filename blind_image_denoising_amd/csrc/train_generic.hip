@@ -578,6 +578,19 @@ __global__ __launch_bounds__(256) void tg_relu_shift_bwd_kernel(const float* __r
     if (threadIdx.x == 0) dw0[0] = w0[0] + w1 > 0.f ? (float)red[0] : 0.f;
 }
 
+// the same factor with the layers' default activation "linear": m[c] = w0[c or 0] + w1
+__global__ __launch_bounds__(256) void tg_shift_kernel(const float* __restrict__ w0, int nw, float w1, float* __restrict__ m, int C)
+{
+    for (int c = threadIdx.x; c < C; c += 256) m[c] = w0[nw == 1 ? 0 : c] + w1;
+}
+
+extern "C" int bf_op_linear_shift(const float* w0, int nw, float w1, float* m, int C, void* stream)
+{
+    if (!w0 || !m || C <= 0 || (nw != 1 && nw != C)) return BF_EINVAL;
+    hipLaunchKernelGGL(tg_shift_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w0, nw, w1, m, C);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
 extern "C" int bf_op_relu_shift(const float* w0, int nw, float w1, float* m, int C, void* stream)
 {
     if (!w0 || !m || C <= 0 || (nw != 1 && nw != C)) return BF_EINVAL;

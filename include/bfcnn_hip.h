@@ -461,6 +461,7 @@ int bf_op_sigmoid_gate_bwd(const float* enc, const float* o, const float* dy, fl
    m[c] = relu(w0[c or 0] + w1) for bf_op_scale_add (nw = C: per channel, nw = 1: one scalar), and d w0 from d m */
 int bf_op_relu_shift(const float* w0, int nw, float w1, float* m, int channels, void* stream);
 int bf_op_relu_shift_bwd(const float* w0, int nw, float w1, const float* dm, float* dw0, int channels, void* stream);
+int bf_op_linear_shift(const float* w0, int nw, float w1, float* m, int channels, void* stream);   /* activation "linear": m = w0 + w1 */
 /* the normalise / denormalise layers on their own (bfcnn/model.py:364-430; inside the hydras they are fused into the first
    convolution and the head): inverse 0: (clip(x, v_min, v_max) - v_min) / (v_max - v_min) - 0.5; 1: (clip(x, -.5, .5) + .5) * range + v_min */
 int bf_op_normalize(const float* x, float* out, int64_t n, float v_min, float v_max, int inverse, void* stream);

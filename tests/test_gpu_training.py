@@ -3,6 +3,8 @@ Tolerances (fp32 kernels vs fp64 oracle): losses 1e-5 relative; gradients 2e-4 o
 max |g| (sums over up to 1e5 pixels of fp32 products); Adam update 1e-6 absolute."""
 import pathlib
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -234,6 +236,56 @@ def test_train_loop_runs_and_saves(tmp_path):
     assert len(hist) == 2 and all(np.isfinite(hist))
     mod = bf.load_model(str(tmp_path / "final"))
     assert mod(noisy).shape == noisy.shape
+
+
+def test_export_model_from_a_training_run(tmp_path):
+    """bfcnn/export_model.py:19-190: config + checkpoint directory of a training run -> model directory (pipeline.json + weights) ->
+    load_model returns the same uint8 denoiser as the trained model; argument checks as in the reference"""
+    cfg = O.canonical_config(no_layers=2)
+    cfg["train"].update({"epochs": 1, "gpu_batches_per_step": 1})
+    clean, noisy = O.synthetic_batch(2, 16, 16, seed=2)
+    data = [(torch.from_numpy(clean.astype(np.float32)), torch.from_numpy(noisy.astype(np.float32)))] * 3
+    run, out = tmp_path / "run", tmp_path / "exported" / "model"
+    model, _ = bf.train_loop(cfg, str(run), dataset=data)
+    module = bf.export_model(cfg, str(run), out, to_tflite=True, test_model=True)
+    assert (out / "pipeline.json").exists()
+    want = bf.DenoiserModule(model)(noisy)
+    assert np.array_equal(module(noisy), want) and np.array_equal(bf.load_model(str(out))(noisy), want)
+    with pytest.raises(ValueError, match="Checkpoint directory"):
+        bf.export_model(cfg, str(tmp_path / "nowhere"), out)
+    empty = tmp_path / "empty"
+    empty.mkdir()
+    with pytest.raises(ValueError, match="no checkpoint"):
+        bf.export_model(cfg, str(empty), out)
+
+
+def test_package_level_layers():
+    """bfcnn/__init__.py:25-28 exports RandomOnOff, Multiplier, ChannelwiseMultiplier (custom_layers.py:107-127, 1028-1160)"""
+    r = np.random.default_rng(0)
+    x = r.normal(size=(3, 5, 7, 32)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    for cls, n in ((bf.Multiplier, 1), (bf.ChannelwiseMultiplier, 32)):
+        for act in ("linear", "relu"):
+            layer = cls(multiplier=1.0, activation=act)
+            assert np.array_equal(layer(xd).cpu().numpy(), x)                          # w0 = 0 at creation: x * (0 + 1)
+            w0 = r.uniform(-2.0, 1.0, n).astype(np.float32)
+            layer.w0.copy_(torch.from_numpy(w0))
+            f = w0 + 1.0
+            f = np.maximum(f, 0.0) if act == "relu" else f
+            assert np.abs(layer(xd).cpu().numpy() - x * f).max() <= 1e-6
+            assert layer.get_config()["w1"][0] == 1.0
+    drop = bf.RandomOnOff(rate=0.5, seed=3)
+    assert torch.equal(drop(xd), xd) and torch.equal(drop(xd, training=False), xd)
+    seen = set()
+    for _ in range(20):
+        y = drop(xd, training=True).cpu().numpy()
+        for b in range(3):
+            assert np.array_equal(y[b], 0 * x[b]) or np.allclose(y[b], 2.0 * x[b])     # a whole sample: dropped or scaled by 1 / (1 - rate)
+            seen.add(bool(y[b].any()))
+    assert seen == {True, False}
+    with pytest.raises(RuntimeError, match="MI355X"):
+        bf.Multiplier()(torch.from_numpy(x))
+    assert sorted(bf.CONFIGS_DICT) == sorted(os.path.splitext(n)[0] for n, _ in bf.configs)
 
 
 # ---- BASELINE configs[3]: resnet 1x18 training step, 32 images of 256x256 per GPU ------------------------------------
