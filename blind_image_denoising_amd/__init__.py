@@ -28,6 +28,8 @@ from .resnet_generic import squeeze_and_excite_block, selector_block
 from .pyramid import (build_pyramid_model, build_inverse_pyramid_model, multiscales_generator_fn)
 from .dataset import dataset_builder, PrepareData, noise_augment
 from .export_model import export_model
+from .file_operations import load_image
+from . import regularizers
 from .custom_layers import RandomOnOff, Multiplier, ChannelwiseMultiplier
 
 current_dir = pathlib.Path(__file__).parent.resolve()

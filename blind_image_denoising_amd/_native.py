@@ -117,6 +117,7 @@ SIGNATURES = {
     "bf_op_resize_bilinear_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "bf_op_reg_elementwise": (_I, [_P, _P, _I64, _I, _F, _F, _P, _P]),
     "bf_op_reg_soft_orthonormal": (_I, [_P, _P, _I, _I, _F, _F, _F, _F, _P, _P, _P]),
+    "bf_op_reg_soft_orthogonal_ex": (_I, [_P, _P, _I, _I, _F, _F, _F, _F, _P, _P, _I, _P]),
     "bf_op_bn_train_scratch_floats": (_I64, [_I]),
     "bf_op_bn_train_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I, _F, _F, _I, _F, _P, _I64, _P]),
     "bf_op_bn_train_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I, _P, _I64, _P]),

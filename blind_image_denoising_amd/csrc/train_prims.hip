@@ -618,14 +618,22 @@ __global__ __launch_bounds__(256) void tp_reg_elementwise_kernel(const float* __
 // SoftOrthonormalConstraintRegularizer (regularizers.py:283-338) on a 1x1 kernel W [cin][cout]: G = W^T W [cout][cout],
 // value = lambda ||G - I||_F^2 + l1 sum|G| + l2 sum G^2 ; D = dvalue/dG = 2 lambda (G - I) + l1 sign(G) + 2 l2 G ;
 // dvalue/dW = 2 W D (D symmetric)
+// mask_diagonal: SoftOrthogonalConstraintRegularizer (regularizers.py:208-280) -- the same three terms on G with its diagonal zeroed
+// (no pull of the norms towards 1)
 __global__ void tp_so_gram_kernel(const float* __restrict__ w, float* __restrict__ G, float* __restrict__ D, int cin, int cout, float lam,
-                                  float l1, float l2)
+                                  float l1, float l2, int mask_diagonal)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= cout * cout) return;
     const int a = e / cout, b = e % cout;
     double s = 0.0;
     for (int c = 0; c < cin; ++c) s += (double)w[c * cout + a] * (double)w[c * cout + b];
+    if (mask_diagonal) {
+        if (a == b) s = 0.0;
+        G[e] = (float)(lam * s * s + l1 * fabs(s) + l2 * s * s);
+        D[e] = a == b ? 0.f : (float)(2.0 * lam * s + l1 * (s > 0 ? 1.0 : (s < 0 ? -1.0 : 0.0)) + 2.0 * l2 * s);
+        return;
+    }
     const double gm = s - (a == b ? 1.0 : 0.0);
     G[e] = (float)(lam * gm * gm + l1 * fabs(s) + l2 * s * s);                                    // this element's share of the value
     D[e] = (float)(2.0 * lam * gm + l1 * (s > 0 ? 1.0 : (s < 0 ? -1.0 : 0.0)) + 2.0 * l2 * s);
@@ -637,7 +645,7 @@ __global__ __launch_bounds__(256) void tp_so_apply_kernel(const float* __restric
 {
     // one workgroup: the gradient 2 W D element by element, then the value in a fixed order
     __shared__ double red[256];
-    for (int e = threadIdx.x; e < cin * cout; e += 256) {
+    for (int e = threadIdx.x; grad && e < cin * cout; e += 256) {
         const int c = e / cout, a = e % cout;
         double s = 0.0;
         for (int b = 0; b < cout; ++b) s += (double)w[c * cout + b] * (double)D[b * cout + a];
@@ -942,16 +950,23 @@ extern "C" int bf_op_reg_elementwise(const float* w, float* grad, int64_t n, int
 }
 
 // SoftOrthonormalConstraintRegularizer on a 1x1 kernel [cin][cout]; scratch: 2 * cout * cout floats
-extern "C" int bf_op_reg_soft_orthonormal(const float* w, float* grad, int cin, int cout, float lambda, float l1, float l2, float grad_scale,
-                                          float* value, float* scratch, void* stream)
+extern "C" int bf_op_reg_soft_orthogonal_ex(const float* w, float* grad, int cin, int cout, float lambda, float l1, float l2, float grad_scale,
+                                            float* value, float* scratch, int mask_diagonal, void* stream)
 {
-    if (!w || !grad || !value || !scratch || cin <= 0 || cout <= 0) return BF_EINVAL;
+    if (!w || !value || !scratch || cin <= 0 || cout <= 0) return BF_EINVAL;                // grad may be NULL: the value alone
     hipStream_t s = (hipStream_t)stream;
     float* G = scratch;
     float* D = scratch + (size_t)cout * cout;
-    hipLaunchKernelGGL(tp_so_gram_kernel, dim3((cout * cout + 255) / 256), dim3(256), 0, s, w, G, D, cin, cout, lambda, l1, l2);
+    hipLaunchKernelGGL(tp_so_gram_kernel, dim3((cout * cout + 255) / 256), dim3(256), 0, s, w, G, D, cin, cout, lambda, l1, l2, mask_diagonal);
     hipLaunchKernelGGL(tp_so_apply_kernel, dim3(1), dim3(256), 0, s, w, G, D, grad, cin, cout, grad_scale, value);
     return TP_OK();
+}
+
+extern "C" int bf_op_reg_soft_orthonormal(const float* w, float* grad, int cin, int cout, float lambda, float l1, float l2, float grad_scale,
+                                          float* value, float* scratch, void* stream)
+{
+    if (!grad) return BF_EINVAL;
+    return bf_op_reg_soft_orthogonal_ex(w, grad, cin, cout, lambda, l1, l2, grad_scale, value, scratch, 0, stream);
 }
 
 // spatially flipped copy of a [k][k][inner] kernel (depthwise data gradient = depthwise convolution with it)

@@ -386,6 +386,10 @@ int bf_op_resize_bilinear_bwd(const float* dy, float* dx, int batch, int height,
 int bf_op_reg_elementwise(const float* w, float* grad, int64_t n, int kind, float coef, float grad_scale, float* value, void* stream);
 int bf_op_reg_soft_orthonormal(const float* w, float* grad, int cin, int cout, float lambda, float l1, float l2, float grad_scale,
                                float* value, float* scratch, void* stream);
+/* the same with grad NULL allowed (the value alone) and mask_diagonal 1 = SoftOrthogonalConstraintRegularizer (regularizers.py:208-280:
+   the terms on W^T W with its diagonal zeroed); w is any [rows][cout] matrix: an HWIO kernel [k,k,cin,cout] with rows = k k cin */
+int bf_op_reg_soft_orthogonal_ex(const float* w, float* grad, int cin, int cout, float lambda, float l1, float l2, float grad_scale,
+                                 float* value, float* scratch, int mask_diagonal, void* stream);
 /* weight re-layouts for the data gradients: spatial flip of [k][k][inner]; transpose of [a][b] */
 /* ---- training-mode operators of the resnet builder outside the 16-filter 3x3 engine (csrc/train_generic.hip) ----
    BatchNormalization(center=False) with batch statistics, bfcnn/utilities.py:204-206 under training=True: y = act(gamma (x - mean)
