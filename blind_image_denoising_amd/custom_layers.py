@@ -44,6 +44,13 @@ class _ScaleLayer:
                 "bf_op_scale_add")
         return out
 
+    @property
+    def weights(self):
+        """[w0 (trainable), w1 (constant)] as host tensors, in keras' order (custom_layers.py:1053-1074)"""
+        if self.w0 is None:
+            return []
+        return [self.w0.detach().cpu(), torch.full((1,), self._multiplier, dtype=torch.float32)]
+
     def get_config(self):
         return {"w0": None if self.w0 is None else self.w0.cpu().numpy(), "w1": np.array([self._multiplier], np.float32),
                 "regularizer": self.regularizer, "activation": self._activation}

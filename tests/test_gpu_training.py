@@ -274,6 +274,15 @@ def test_package_level_layers():
             f = np.maximum(f, 0.0) if act == "relu" else f
             assert np.abs(layer(xd).cpu().numpy() - x * f).max() <= 1e-6
             assert layer.get_config()["w1"][0] == 1.0
+    # tests/bfcnn/test_custom_layers.py: behind a Dense layer ([B, units]) and behind a convolution; two weights, w0 [1] / [units]
+    for units in (8, 16, 32, 64):
+        d2 = torch.from_numpy(r.normal(size=(10, units)).astype(np.float32)).cuda()
+        for cls, n in ((bf.Multiplier, 1), (bf.ChannelwiseMultiplier, units)):
+            layer = cls(multiplier=1.0, regularizer=None, trainable=True, activation="linear")
+            assert layer(d2).shape == (10, units)
+            assert len(layer.weights) == 2 and layer.weights[0].numpy().shape == (n,)
+        d4 = torch.from_numpy(r.normal(size=(10, 32, 32, units)).astype(np.float32)).cuda()
+        assert bf.ChannelwiseMultiplier(multiplier=1.0, activation="linear")(d4).shape == (10, 32, 32, units)
     drop = bf.RandomOnOff(rate=0.5, seed=3)
     assert torch.equal(drop(xd), xd) and torch.equal(drop(xd, training=False), xd)
     seen = set()
