@@ -10,6 +10,7 @@ deviations ~ U[min, max]) come from a seeded host generator; the per-element noi
 element, keyed by a per-batch seed from the same generator (TensorFlow's own stream cannot be reproduced outside
 TensorFlow; the distribution and the order of operations are the reference's).
 """
+from collections import namedtuple
 from typing import Dict, Iterable, Iterator, Optional, Tuple
 
 import numpy as np
@@ -75,13 +76,86 @@ class PrepareData:
         return noise_augment(input_batch, **self.draw())
 
 
-def dataset_builder(config: Dict, clean_batches: Iterable = None, device=None, seed: Optional[int] = None) -> Iterator:
-    """bfcnn/dataset.py:40-305 reduced to the corruption stage: `clean_batches` is any iterable of clean [B,H,W,C]
-    batches in value range (numpy or torch); yields (input_image_batch, noisy_image_batch) device tensors."""
-    if clean_batches is None:
-        raise ValueError("clean_batches must be an iterable of clean image batches (image I/O is out of scope)")
-    prepare = PrepareData(config, seed)
+DatasetResults = namedtuple("DatasetResults", ["config", "batch_size", "input_shape", "training", "testing"])      # dataset.py:27-35
+
+
+class _DirectoryDataset:
+    """the tf.data pipeline of bfcnn/dataset.py:241-297 as a re-iterable: every iteration is one pass over the image files --
+    shuffle the filenames (buffer 1024) -> load_image -> `no_crops_per_image` random crops of `input_shape` -> prepare_data_fn on
+    that image's crops (ONE draw of the flip / noise scalars per image, on the device: bf_noise_augment) -> unbatch -> shuffle
+    (buffer batch_size * 128) -> batches of `batch_size`, remainder dropped.  Decoding and cropping are host-side I/O; everything
+    from the clean crops on lives on the GPU."""
+
+    def __init__(self, config: Dict, directories, device=None, seed: Optional[int] = None):
+        from .file_operations import image_filenames_generator
+        self.config, self.device = config, device
+        self.batch_size = int(config["batch_size"])
+        self.input_shape = list(config["input_shape"])
+        color_mode = config.get("color_mode", "rgb").strip().lower()
+        if color_mode not in ("rgb", "rgba", "grayscale"):
+            raise ValueError('`color_mode` must be one of {"rgb", "rgba", "grayscale"}. ' f"Received: color_mode={color_mode}")
+        self.num_channels = {"rgb": 3, "rgba": 4, "grayscale": 1}[color_mode]
+        self.no_crops = int(config.get("no_crops_per_image", 1))
+        self.prepare = PrepareData(config, seed)
+        self.rng = np.random.default_rng(seed)
+        self.filenames_fn = image_filenames_generator(directory=directories)
+
+    @staticmethod
+    def _shuffled(it, buffer_size, rng):
+        """tf.data shuffle(buffer_size): a buffer that is filled, then one random element out for every element in"""
+        buf = []
+        for item in it:
+            buf.append(item)
+            if len(buf) >= buffer_size:
+                yield buf.pop(int(rng.integers(len(buf))))
+        while buf:
+            yield buf.pop(int(rng.integers(len(buf))))
+
+    def _samples(self):
+        from .file_operations import load_image, random_crops
+        dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+        for path in self._shuffled(self.filenames_fn(), 1024, self.rng):
+            try:
+                img = load_image(path=path, image_size=None, num_channels=self.num_channels, expand_dims=False, normalize=False)
+            except Exception as e:                       # an unreadable file must not end an epoch
+                logger.warning(f"skipping [{path}]: {e}")
+                continue
+            crops = random_crops(img, no_crops_per_image=self.no_crops, crop_size=(self.input_shape[0], self.input_shape[1]), rng=self.rng)
+            clean, noisy = self.prepare(torch.from_numpy(crops).to(dev))
+            for k in range(clean.shape[0]):
+                yield clean[k], noisy[k]
+
+    def __iter__(self):
+        batch = []
+        for sample in self._shuffled(self._samples(), self.batch_size * 128, self.rng):
+            batch.append(sample)
+            if len(batch) == self.batch_size:            # drop_remainder=True
+                yield torch.stack([c for c, _ in batch]), torch.stack([n for _, n in batch])
+                batch = []
+
+
+def dataset_builder(config: Dict, clean_batches: Iterable = None, device=None, seed: Optional[int] = None):
+    """bfcnn/dataset.py:40-305.  With `config["inputs"]` (image directories) and no `clean_batches`: the reference's pipeline, returned
+    as `DatasetResults(config, batch_size, input_shape, training, testing=None)` whose `training` yields (input_image_batch,
+    noisy_image_batch) device tensors, one pass over the files per iteration.  With `clean_batches` (any iterable of clean [B,H,W,C]
+    batches in value range, numpy or torch): the corruption stage alone, as a generator of the same pairs."""
     logger.info(f"creating dataset_builder with configuration [{config}]")
+    if clean_batches is None:
+        inputs = config.get("inputs") if isinstance(config, dict) else None
+        if inputs is None:
+            raise ValueError("the dataset configuration names no `inputs` directories and no clean_batches were given")
+        if isinstance(inputs, list):
+            directories = [i.get("directory", None) for i in inputs]
+        elif isinstance(inputs, dict):
+            directories = [config.get("directory", None)]                     # dataset.py:68-69 (as written there)
+        else:
+            raise ValueError("dont know how to handle anything else than list and dict")
+        directories = [d for d in directories if d]
+        if not directories:
+            raise ValueError("don't know how to handle non directory datasets")  # dataset.py:254-255
+        ds = _DirectoryDataset(config, directories, device=device, seed=seed)
+        return DatasetResults(config=config, batch_size=ds.batch_size, input_shape=ds.input_shape, training=ds, testing=None)
+    prepare = PrepareData(config, seed)
 
     def gen():
         for batch in clean_batches:

@@ -1,10 +1,84 @@
 """`load_image` (bfcnn/file_operations.py:101-159): read an image file, decode it, optionally fit it into `image_size` the way
 `tf.image.resize_with_pad` does, add a batch axis, normalise.  Host-side I/O in front of the engine (decoding through Pillow; nothing
 here is on the hot path, and nothing here touches the GPU): returns a NumPy array where the reference returns a tf.Tensor."""
+import glob
+import itertools
+import os
 from pathlib import Path
-from typing import Any, Optional, Tuple
+from typing import Any, Generator, List, Optional, Tuple, Union
 
 import numpy as np
+
+from .custom_logger import logger
+
+SUPPORTED_IMAGE_LIST_FORMATS = (".bmp", ".gif", ".jpeg", ".jpg", ".png")            # file_operations.py:18
+
+
+def merge_iterators(*iterators):
+    """file_operations.py:23-35: round-robin over the iterators until all are exhausted"""
+    empty = {}
+    for values in itertools.zip_longest(*iterators, fillvalue=empty):
+        for value in values:
+            if value is not empty:
+                yield value
+
+
+def index_directory_gen(directory: str, formats: Tuple = SUPPORTED_IMAGE_LIST_FORMATS) -> Generator[str, None, None]:
+    """file_operations.py:87-96: every image file below `directory`"""
+    for filename in glob.iglob(os.path.join(directory, "**/*"), recursive=True):
+        if filename.lower().endswith(formats):
+            yield filename
+
+
+def image_filenames_generator(directory: Union[str, List[str]], verbose: bool = True):
+    """file_operations.py:40-83: a function returning a generator of the image filenames of one or several directories (interleaved)"""
+    if isinstance(directory, str):
+        directory = [directory]
+    if not isinstance(directory, list):
+        raise ValueError(f"don't know what to do with [{directory}]")
+
+    def gen_fn():
+        return merge_iterators(*[index_directory_gen(directory=d) for d in directory])
+    if verbose:
+        total = 0
+        for d in directory:
+            n = sum(1 for _ in index_directory_gen(directory=d))
+            total += n
+            logger.info(f"directory [{d}]: [{n}] samples")
+        logger.info(f"total number of samples: [{total}]")
+    return gen_fn
+
+
+def random_crops(image: np.ndarray, no_crops_per_image: int = 16, crop_size: Tuple[int, int] = (64, 64), rng=None,
+                 extrapolation_value: float = 0.0) -> np.ndarray:
+    """utilities.random_crops (utilities.py:467-561) of ONE image [H,W,C] (the loader hands it one image at a time): boxes of
+    crop_size / image_size of the image at uniformly random positions, sampled with tf.image.crop_and_resize's bilinear rule
+    (output row i reads y1 (H-1) + i (y2 - y1)(H-1) / (crop_h - 1): the crop is resampled, not sliced), cast back to the image's dtype"""
+    rng = rng or np.random.default_rng()
+    H, W, C = image.shape
+    ch, cw = int(crop_size[0]), int(crop_size[1])
+    if H <= 0 or W <= 0:
+        return np.zeros((no_crops_per_image, ch, cw, C), image.dtype)
+    ry, rx = ch / float(H), cw / float(W)
+    out = np.empty((no_crops_per_image, ch, cw, C), np.float32)
+    img = image.astype(np.float32)
+    for k in range(no_crops_per_image):
+        y1 = max(rng.uniform(0.0, max(1.0 - ry, 0.0)), 0.0)
+        x1 = max(rng.uniform(0.0, max(1.0 - rx, 0.0)), 0.0)
+        y2, x2 = min(y1 + ry, 1.0), min(x1 + rx, 1.0)
+        ys = y1 * (H - 1) + np.arange(ch) * ((y2 - y1) * (H - 1) / (ch - 1) if ch > 1 else 0.0) if ch > 1 else np.array([0.5 * (y1 + y2) * (H - 1)])
+        xs = x1 * (W - 1) + np.arange(cw) * ((x2 - x1) * (W - 1) / (cw - 1) if cw > 1 else 0.0) if cw > 1 else np.array([0.5 * (x1 + x2) * (W - 1)])
+        y0, x0 = np.floor(ys).astype(np.int64), np.floor(xs).astype(np.int64)
+        fy, fx = (ys - y0).astype(np.float32), (xs - x0).astype(np.float32)
+        oky, okx = (ys >= 0) & (ys <= H - 1), (xs >= 0) & (xs <= W - 1)
+        y0c, y1c = np.clip(y0, 0, H - 1), np.clip(y0 + 1, 0, H - 1)
+        x0c, x1c = np.clip(x0, 0, W - 1), np.clip(x0 + 1, 0, W - 1)
+        rows = img[y0c] * (1.0 - fy)[:, None, None] + img[y1c] * fy[:, None, None]
+        crop = rows[:, x0c] * (1.0 - fx)[None, :, None] + rows[:, x1c] * fx[None, :, None]
+        crop[~oky] = extrapolation_value
+        crop[:, ~okx] = extrapolation_value
+        out[k] = crop
+    return out.astype(image.dtype)
 
 
 def _resize_bilinear(img: np.ndarray, oh: int, ow: int) -> np.ndarray:

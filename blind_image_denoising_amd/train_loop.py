@@ -300,7 +300,7 @@ def train_loop(pipeline_config_path, model_dir: str, dataset: Iterable = None, w
     loss / optimizer / model builders -> checkpoint manager (restore the latest checkpoint of `model_dir` if there is one:
     weights, BN statistics, Adam slots, step, epoch -- train_loop.py:158-181) -> epochs over `dataset` (an iterable
     yielding (input_image_batch, noisy_image_batch) float tensors in value range) with gradient accumulation over
-    `gpu_batches_per_step` micro-batches, a checkpoint every `checkpoint_every` steps and at the end of every epoch
+    `gpu_batches_per_step` micro-batches; `dataset=None`: the configuration's own `dataset` section, image directories and all), a checkpoint every `checkpoint_every` steps and at the end of every epoch
     (train_loop.py:563-566, 597) -> model directory per epoch.
     The tf.data pipeline, TensorBoard summaries and TF's checkpoint format are out of scope."""
     from .checkpoint import Checkpoint, CheckpointManager
@@ -314,7 +314,11 @@ def train_loop(pipeline_config_path, model_dir: str, dataset: Iterable = None, w
     if gpu_batches_per_step <= 0:
         raise ValueError("gpu_batches_per_step must be > 0")               # train_loop.py:114-115
     if dataset is None:
-        raise ValueError("dataset must be an iterable of (input_image_batch, noisy_image_batch)")
+        # bfcnn/train_loop.py:81-85: the dataset of the configuration's own `dataset` section (image directories)
+        if DATASET_STR not in config:
+            raise ValueError("no dataset: pass an iterable of (input_image_batch, noisy_image_batch) or a configuration with a dataset section")
+        from .dataset import dataset_builder
+        dataset = dataset_builder(config[DATASET_STR], device=device).training
     loss_fn_map = loss_function_builder(config=config["loss"])
     optimizer, lr_schedule = optimizer_builder(config=train_config["optimizer"])
     model = model_builder(config[MODEL_STR], device=device).hydra

@@ -1,4 +1,6 @@
 """Training-data corruption (bfcnn/dataset.py:126-239): oracle restatement on the CPU, HIP kernel against it on the GPU."""
+import pathlib
+
 import numpy as np
 import pytest
 
@@ -110,3 +112,60 @@ def test_prepare_data_builder_and_statistics():
     batches = list(bf.dataset_builder(cfg, [np.zeros((2, 8, 8, 3), np.float32)] * 3, seed=1))
     assert len(batches) == 3 and batches[0][0].is_cuda and batches[0][1].shape == (2, 8, 8, 3)
     assert bf.PrepareData({"random_blur": True}).ignored == ["random_blur"]
+
+
+@pytest.mark.gpu
+def test_dataset_builder_from_image_directories(tmp_path):
+    """the reference's tests/bfcnn/test_dataset.py::test_dataset_builder_build on directories written here (crops of lena.jpg as png / jpg
+    files, two directories, a file that is no image): DatasetResults, batches of `batch_size` crops of `input_shape` in value range,
+    the colour mode's channel count, every epoch a fresh pass"""
+    from PIL import Image
+    import blind_image_denoising_amd as bf
+    lena = Image.open(pathlib.Path(__file__).parent / "golden" / "lena.jpg")
+    d1, d2 = tmp_path / "a", tmp_path / "b" / "nested"
+    d1.mkdir(parents=True); d2.mkdir(parents=True)
+    for k in range(5):
+        lena.crop((40 * k, 30 * k, 40 * k + 200, 30 * k + 160)).save(d1 / f"im{k}.png")
+    for k in range(3):
+        lena.crop((20 * k, 0, 20 * k + 300, 260)).save(d2 / f"im{k}.jpg", quality=95)
+    (d1 / "notes.txt").write_text("not an image")
+    for color_mode, channels, shape in (("rgb", 3, [64, 64, 3]), ("grayscale", 1, [128, 96, 1])):
+        config = {"batch_size": 2, "value_range": [0, 255], "clip_value": True, "random_blur": True, "round_values": True,
+                  "random_invert": True, "random_rotate": 0.314, "random_up_down": True, "color_mode": color_mode, "random_left_right": True,
+                  "input_shape": shape, "no_crops_per_image": 3, "multiplicative_noise": [0.1, 0.2], "additional_noise": [1, 5, 10, 20, 40],
+                  "inputs": [{"directory": str(d1)}, {"directory": str(tmp_path / "b")}]}
+        d = bf.dataset.dataset_builder(config=config, seed=4)
+        assert d.batch_size == 2 and d.input_shape == shape and d.testing is None and d.config is config
+        for epoch in range(2):
+            n = 0
+            for input_batch, noisy_batch in d.training:
+                assert input_batch.is_cuda and input_batch.shape == noisy_batch.shape == (2, shape[0], shape[1], channels)
+                a = input_batch.cpu().numpy()
+                assert a.min() >= 0 and a.max() <= 255 and np.array_equal(a, np.round(a)) and a.std() > 1.0
+                n += 1
+            assert n == 8 * 3 // 2                                                  # 8 images x 3 crops, batches of 2
+    with pytest.raises(ValueError):
+        bf.dataset.dataset_builder(config={"batch_size": 2, "input_shape": [8, 8, 3], "inputs": [{}]})
+    with pytest.raises(ValueError, match="color_mode"):
+        bf.dataset.dataset_builder(config={"batch_size": 2, "input_shape": [8, 8, 3], "color_mode": "cmyk", "inputs": [{"directory": str(d1)}]})
+
+
+@pytest.mark.gpu
+def test_train_loop_reads_its_dataset_from_the_configuration(tmp_path):
+    """bfcnn/train_loop.py:81-85: train_loop(pipeline_config, model_dir) with nothing else -- the images come from the directories of the
+    configuration's dataset section"""
+    from PIL import Image
+    import blind_image_denoising_amd as bf
+    lena = Image.open(pathlib.Path(__file__).parent / "golden" / "lena.jpg")
+    imgs = tmp_path / "images"
+    imgs.mkdir()
+    for k in range(4):
+        lena.crop((60 * k, 50 * k, 60 * k + 160, 50 * k + 128)).save(imgs / f"im{k}.png")
+    cfg = O.canonical_config(no_layers=2)
+    cfg["train"].update({"epochs": 2, "gpu_batches_per_step": 1})
+    cfg["dataset"] = {"batch_size": 4, "color_mode": "rgb", "no_crops_per_image": 2, "value_range": [0, 255], "clip_value": True,
+                      "round_values": True, "random_up_down": True, "random_left_right": True, "input_shape": [32, 32, 3],
+                      "multiplicative_noise": [0.05, 0.1], "additional_noise": [5, 10, 20], "inputs": [{"directory": str(imgs)}]}
+    model, hist = bf.train_loop(cfg, str(tmp_path / "run"))
+    assert len(hist) == 2 * (4 * 2 // 4) and np.isfinite(hist).all()
+    assert (tmp_path / "run" / "final").exists()
