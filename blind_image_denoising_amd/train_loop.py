@@ -294,8 +294,18 @@ class DataParallelTrainer:
 
 # ---- outer loop --------------------------------------------------------------------------------
 
-def train_loop(pipeline_config_path, model_dir: str, dataset: Iterable = None, weights_dir: str = None,
-               device=None, max_steps: Optional[int] = None):
+def train_loop(pipeline_config_path, checkpoint_directory: str = None, weights_dir: str = None, dataset: Iterable = None,
+               device=None, max_steps: Optional[int] = None, model_dir: str = None):
+    """bfcnn/train_loop.py:40-601 with the reference's positional order (pipeline_config_path, checkpoint_directory, weights_dir);
+    `model_dir` is this package's older keyword for the same directory.  Returns (model, loss history).  See `_train_loop`."""
+    model_dir = checkpoint_directory if checkpoint_directory is not None else model_dir
+    if model_dir is None:
+        raise ValueError("checkpoint_directory must be given")
+    return _train_loop(pipeline_config_path, str(model_dir), dataset, None if weights_dir is None else str(weights_dir), device, max_steps)
+
+
+def _train_loop(pipeline_config_path, model_dir: str, dataset: Iterable = None, weights_dir: str = None,
+                device=None, max_steps: Optional[int] = None):
     """Outer loop of bfcnn/train_loop.py:40-601 reduced to what surrounds the hot path: config ->
     loss / optimizer / model builders -> checkpoint manager (restore the latest checkpoint of `model_dir` if there is one:
     weights, BN statistics, Adam slots, step, epoch -- train_loop.py:158-181) -> epochs over `dataset` (an iterable
