@@ -502,3 +502,31 @@ def test_model_losses_and_model_loss_match_oracle():
     assert abs(float(got["regularization_loss"]) - ref["regularization_loss"]) <= 1e-5 * ref["regularization_loss"]
     assert abs(float(got["total_loss"]) - ref["total_loss"]) <= 1e-5 * ref["total_loss"]
     assert len(m.losses) == 1 + 2 * 2 + 2                          # base, two kernels per block, two head kernels
+
+
+def test_the_engine_learns_to_denoise(tmp_path):
+    """end to end through the public API, as a user of the reference would run it: an image directory -> dataset_builder (random crops,
+    flips, additive noise on the device) -> train_loop (canonical resnet 1x6 from its glorot initialisation, L1 loss, Adam, checkpoints)
+    -> load_model -> uint8 denoiser, judged like the reference's test_pretrained.py on a part of the image the training never saw:
+    PSNR and MAE better than the noisy input's (measured: 22.3 -> 30.5 dB; tools/exp/learn_to_denoise.py is the same run as a script)."""
+    import pathlib
+    from PIL import Image
+    lena = Image.open(pathlib.Path(__file__).parent / "golden" / "lena.jpg")
+    (tmp_path / "img").mkdir()
+    lena.crop((0, 0, 512, 384)).save(tmp_path / "img" / "train.png")
+    held = np.asarray(lena.convert("RGB"))[384:512, 0:512][None]
+    cfg = O.canonical_config(no_layers=6)
+    cfg["train"].update({"epochs": 30, "gpu_batches_per_step": 1})                 # 1 920 steps of 16 crops: about 6 s
+    cfg["train"]["optimizer"]["schedule"]["config"]["learning_rate"] = 2e-3
+    cfg["loss"] = {"hinge": 0.0, "cutoff": 255.0, "mae_multiplier": 1.0, "ssim_multiplier": 0.0, "regularization": 0.01}
+    cfg["dataset"] = {"batch_size": 16, "color_mode": "rgb", "no_crops_per_image": 64 * 16, "value_range": [0, 255], "clip_value": True,
+                      "round_values": True, "random_up_down": True, "random_left_right": True, "input_shape": [64, 64, 3],
+                      "additional_noise": [20, 20.0001], "inputs": [{"directory": str(tmp_path / "img")}]}
+    model, hist = bf.train_loop(cfg, str(tmp_path / "run"))
+    assert len(hist) == 1920 and np.isfinite(hist).all() and np.mean(hist[-20:]) < 0.1 * hist[0]
+    noisy = np.clip(np.round(held + np.random.default_rng(0).normal(0, 20.0, held.shape)), 0, 255).astype(np.uint8)
+    den = bf.load_model(str(tmp_path / "run" / "final"))(noisy)
+    psnr = lambda a, b: 10 * np.log10(255.0 ** 2 / np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2))
+    mae = lambda a, b: np.abs(a.astype(np.float64) - b.astype(np.float64)).mean()
+    assert psnr(held, den) > psnr(held, noisy) + 5.0, (psnr(held, noisy), psnr(held, den))
+    assert mae(held, den) < 0.6 * mae(held, noisy)
