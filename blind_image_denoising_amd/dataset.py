@@ -2,8 +2,9 @@
 The corruption half of the reference's input pipeline on the device: `prepare_data_fn` of
 bfcnn/dataset.py:126-239 (whole-batch flips, multiplicative and additive truncated-normal noise, rounding) as ONE
 HIP kernel (`bf_noise_augment`), so that a training step is not fed by a host pipeline.  The tf.data part of
-`dataset_builder` (file listing, decoding, cropping, shuffling, batching) is out of scope: `dataset_builder` here
-takes an iterable of clean batches and yields (input_batch, noisy_batch) pairs, which is what `train_loop` consumes.
+`dataset_builder` (file listing, decoding, cropping, shuffling, batching: dataset.py:241-297) is host-side I/O in front of it
+(`_DirectoryDataset`, file_operations.py); `dataset_builder` also takes an iterable of clean batches directly and yields the
+(input_batch, noisy_batch) pairs `train_loop` consumes.
 
 Random numbers: the per-BATCH choices of the reference (two flips, whether each noise is applied, the two standard
 deviations ~ U[min, max]) come from a seeded host generator; the per-element noise is Philox4x32-10 indexed by the
