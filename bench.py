@@ -173,6 +173,20 @@ def pyramid_bench(args, torch, bf, O, rank, local_rank, world, dist):
     err = float((y - x).abs().mean().item())
     if rank == 0:
         gbs = nbytes * args.steps / elapsed / 1e9
+        cpu = None
+        if not args.no_cpu_baseline:
+            # the oracle's NumPy restatement of the same split + merge (oracle/bfcnn_oracle.py laplacian_pyramid / inverse) on a bounded
+            # sample: single images of the same size until about 8 s have passed
+            xs = x[:1].cpu().numpy().astype(np.float32)
+            t1, reps = time.perf_counter(), 0
+            while reps < 1 or time.perf_counter() - t1 < 8.0:
+                back = O.inverse_laplacian_pyramid(O.laplacian_pyramid(xs, levels, (5, 5)))
+                reps += 1
+            dt = time.perf_counter() - t1
+            cpu = {"value": reps / dt, "unit": "images/s", "cores": 1, "kind": "port",
+                   "sample": f"{reps} x one {S}x{S}x{C} float32 image through oracle/bfcnn_oracle.py laplacian_pyramid + inverse_laplacian_pyramid "
+                             f"(NumPy restatement, not TensorFlow; {dt:.1f} s)",
+                   "round_trip_mean_abs_error": float(np.abs(back - xs).mean())}
         print(json.dumps({
             "metric": "laplacian pyramid split + merge images/sec (512x512x3, 3 levels)", "value": B * args.steps / elapsed,
             "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -181,7 +195,8 @@ def pyramid_bench(args, torch, bf, O, rank, local_rank, world, dist):
             "round_trip_mean_abs_error": err,      # reference test bar: < 1e-7 (tests/bfcnn/test_pyramid.py)
             "roofline": {"bound": "hbm", "kernel": "avgpool_s2_same + upsample2x (4 launches per level pair)", "achieved": gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_step": nbytes}}), flush=True)
+                         "algorithmic_bytes_per_step": nbytes},
+            **({"cpu_baseline": cpu} if cpu is not None else {})}), flush=True)
 
 
 def unet_flop_per_px(m):
