@@ -328,10 +328,12 @@ def _train_loop(pipeline_config_path, model_dir: str, dataset: Iterable = None, 
         if DATASET_STR not in config:
             raise ValueError("no dataset: pass an iterable of (input_image_batch, noisy_image_batch) or a configuration with a dataset section")
         from .dataset import dataset_builder
-        dataset = dataset_builder(config[DATASET_STR], device=device).training
+        dataset = dataset_builder(config[DATASET_STR], device=device, seed=train_config.get("seed")).training
     loss_fn_map = loss_function_builder(config=config["loss"])
     optimizer, lr_schedule = optimizer_builder(config=train_config["optimizer"])
-    model = model_builder(config[MODEL_STR], device=device).hydra
+    # `seed` in the train section (an extension; absent = keras-like non-deterministic initialisation): initial weights and the
+    # dataset's draws reproducible
+    model = model_builder(config[MODEL_STR], device=device, seed=train_config.get("seed")).hydra
     ckpt = Checkpoint(model=model, optimizer=optimizer)
     manager = CheckpointManager(checkpoint=ckpt, directory=model_dir, max_to_keep=checkpoints_to_keep)
     if not manager.restore_latest() and weights_dir:
