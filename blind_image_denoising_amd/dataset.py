@@ -12,7 +12,7 @@ element, keyed by a per-batch seed from the same generator (TensorFlow's own str
 TensorFlow; the distribution and the order of operations are the reference's).
 """
 from collections import namedtuple
-from typing import Dict, Iterable, Iterator, Optional, Tuple
+from typing import Dict, Iterable, Optional, Tuple
 
 import numpy as np
 import torch

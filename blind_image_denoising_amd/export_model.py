@@ -4,7 +4,6 @@ training run, write `pipeline.json` and the model into `output_directory`, optio
 What it writes is this engine's model directory (`pipeline.json` + `weights.npz`, `save_model`), the directory `load_model` /
 `load_denoiser_model` read back as the uint8 -> uint8 denoiser module; TensorFlow's SavedModel and TFLite serialisations of the
 reference (`:106-190`) are out of scope -- `to_tflite` is accepted and logged."""
-import json
 import os
 from pathlib import Path
 from typing import Dict, Union

@@ -5,14 +5,13 @@ of `add_gates` (backbone_blocks.py:199-208).  This file is inference (training: 
 the operator library of csrc/unet_ops.hip: first convolution, 1x1 / k x k matrix-core convolutions with the BatchNorm
 folded (scale into the weights at pack time, shift as the epilogue bias), depthwise-with-multiplier kernel, fused head.
 The 16-filter 3x3 family keeps its own engine (`HydraModel`, fused split-f16 blocks, training)."""
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, Optional
 
 import numpy as np
 import torch
 
 from . import _native as N
 from . import unet_laplacian as UL
-from .custom_logger import logger
 
 BN_EPSILON = 1e-3          # DEFAULT_BN_EPSILON (bfcnn/constants.py:9)
 

@@ -11,13 +11,12 @@ per fused group (torch tensors are the containers of the intermediate activation
     decoder d:     skip + act(bilinear x2 (1x1 (lower)))  ->  width x ConvNextBlock(dw 1x1)  ->  LayerNorm
     head i:        1x1 C_i -> 32 + activation,  1x1 32 -> 3, tanh(2x)*0.51, denormalise
 """
-from typing import Dict, List, Optional, Sequence, Tuple, Union
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
 
 from . import _native as N
-from .custom_logger import logger
 
 LN_EPSILON = 1e-3          # DEFAULT_LN_EPSILON (bfcnn/constants.py:10); keras LayerNormalization default as well
 ACT_CODES = {"linear": (0, 0.0), "relu": (1, 0.0), "leaky_relu": (2, 0.3), "leakyrelu": (2, 0.3),

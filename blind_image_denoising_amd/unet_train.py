@@ -19,7 +19,7 @@ Exact fp32 throughout (the split-f16 inference operators are not used here): gra
 oracle (oracle/unet_torch.py) in tests/test_gpu_unet_train.py.
 """
 import ctypes as C
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
