@@ -77,6 +77,24 @@ __device__ __forceinline__ bf_h8 bf_h3c_decode8(const bf_u2 b)
     return (bf_h8){a0[0], a0[1], a1[0], a1[1], a2[0], a2[1], a3[0], a3[1]};
 }
 
+// exact (erf) GELU = v * Phi(v) with one transcendental and no branch: Phi(|v|) = 1 - h, Phi(-|v|) = h, h = 0.5 (1 - erf(a)) =
+// 2^(-a Q(a) - 1), a = |v| / sqrt 2, Q a degree-7 polynomial fitted to -log2(1 - erf(a)) / a on [0, 4] (a Q(a) keeps growing beyond:
+// h -> 0).  |erf error| <= 1.1e-7 in fp32, GELU within 1.2e-7 |v| of 0.5 v (1 + erf(v / sqrt 2)) over [-12, 12] (erff: the same
+// class of error with a two-branch polynomial that doubled the time of the MLP kernels).
+__device__ __forceinline__ float bf_gelu(const float v)
+{
+    const float a = fabsf(v) * 0.70710678f;
+    float q = fmaf(4.22452448e-05f, a, -4.19236813e-04f);
+    q = fmaf(q, a, 1.40204388e-03f);
+    q = fmaf(q, a, 9.21467334e-04f);
+    q = fmaf(q, a, -2.83861113e-02f);
+    q = fmaf(q, a, 1.48544322e-01f);
+    q = fmaf(q, a, 9.18402423e-01f);
+    q = fmaf(q, a, 1.62790967f);
+    const float h = __builtin_amdgcn_exp2f(fmaf(-a, q, -1.f));
+    return v * (v >= 0.f ? 1.f - h : h);
+}
+
 #define BF_C 16             // feature channels of the MFMA path (filters == 16)
 #define BF_WPACK_FLOATS (36 * 64)   // one 3x3 16->16 kernel as MFMA A-operand register images
 

@@ -72,16 +72,7 @@ __device__ __forceinline__ float uh_act(float v, float alpha)
     if (ACT == 1) return fmaxf(v, 0.f);
     if (ACT == 2) return fmaxf(v, alpha * v);                      // leaky relu, 0 <= alpha <= 1
     if (ACT == 3) {
-        // exact (erf) GELU = v * Phi(v) without erff's two-branch polynomial (it doubled the time of the MLP kernels):
-        // Phi(|v|) = 1 - h, Phi(-|v|) = h, h = 0.5 (a1 t + .. + a5 t^5) exp(-v^2 / 2), t = 1 / (1 + p |v| / sqrt 2)
-        // (Abramowitz-Stegun 7.1.26).  Max |error| 4.2e-7 over [-12, 12] in fp32, the same as 0.5 v (1 + erff(v / sqrt 2)).
-        const float t = __builtin_amdgcn_rcpf(fmaf(0.231641888f, fabsf(v), 1.f));
-        float poly = fmaf(0.5307027145f, t, -0.7265760135f);
-        poly = fmaf(poly, t, 0.7107068705f);
-        poly = fmaf(poly, t, -0.142248368f);
-        poly = fmaf(poly, t, 0.127414796f) * t;
-        const float h = poly * __builtin_amdgcn_exp2f(v * v * -0.72134752044f);
-        return v * (v >= 0.f ? 1.f - h : h);
+        return bf_gelu(v);                                         // bf_common.h: erf form, one transcendental, no branch
     }
     return v;
 }

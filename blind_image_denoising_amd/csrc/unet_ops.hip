@@ -30,7 +30,7 @@ __device__ __forceinline__ float uo_act(float v, float alpha)
 {
     if (ACT == 1) return fmaxf(v, 0.f);
     if (ACT == 2) return v > 0.f ? v : alpha * v;
-    if (ACT == 3) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    if (ACT == 3) return bf_gelu(v);
     if (ACT == 4) return tanhf(v);
     return v;
 }
@@ -39,7 +39,7 @@ __device__ __forceinline__ float uo_act_rt(float v, int act, float alpha)
     switch (act) {
     case 1: return fmaxf(v, 0.f);
     case 2: return v > 0.f ? v : alpha * v;
-    case 3: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    case 3: return bf_gelu(v);
     case 4: return tanhf(v);
     default: return v;
     }
