@@ -41,8 +41,6 @@ class GenericResnetTrainGraph:
                 raise NotImplementedError("training: grouped convolutions are built for 1x1 kernels")
         if getattr(model, "selector", None) and model.selector.get("pre"):
             raise NotImplementedError("training: the selector's optional pre-filters are built for inference only")
-        if getattr(model, "add_concat_input", False):
-            raise NotImplementedError("training: add_concat_input is built for inference only")
         self.ops = None
         self.totals = None
 
@@ -395,8 +393,45 @@ class GenericResnetTrainGraph:
         if m.add_final_bn:                                            # backbone_resnet.py:274-287
             f, b_ = bn_step("final_bn", f, "linear")
             chain.append(b_)
+        Cf = m.filters
+        if m.add_concat_input:
+            # Concatenate([features, the backbone's normalised input]) (backbone_resnet.py:277-279) as the inference path runs it: padded
+            # with zero channels to the width the head's matrix kernel takes; the closing multipliers and the head's first kernel are
+            # padded likewise (factor 1 / zero rows) and their gradients sliced back.  The image carries no gradient.
+            cin = m.in_channels
+            cf, Cp = Cf + cin, next(c for c in (32, 64, 128, 256) if c >= Cf + cin)
+            cat = torch.empty((B, H, Wd, Cp), **f32)
+            _call("bf_op_concat_input", N.ptr(f), N.ptr(noisy), int(noisy.dtype == torch.uint8), N.ptr(cat), B, H, Wd, H, Wd, Cf, cin, Cp,
+                  m.v_min, m.v_max, N.stream_ptr(f))
+
+            def b_cat(dcat):
+                df = torch.empty((B, H, Wd, Cf), **f32)
+                _call("bf_op_slice_channels", N.ptr(dcat), N.ptr(df), npix, Cp, 0, Cf, N.stream_ptr(dcat))
+                return df
+            chain.append(b_cat)
+            f = cat
+            ones_pad = torch.ones(Cp - cf, **f32) if Cp > cf else None
+
+            def padded_mult(name_, t):
+                """mult_step on the padded tensor: the factor's cf entries (or its one scalar) followed by ones"""
+                w0_ = self.W(name_)
+                nw = w0_.numel()
+                mv = torch.empty(cf, **f32)
+                _call("bf_op_relu_shift", N.ptr(w0_), nw, 1.0, N.ptr(mv), cf, N.stream_ptr(mv))
+                mp = mv
+                if ones_pad is not None:
+                    mp = torch.empty(Cp, **f32)
+                    _call("bf_op_concat_channels", N.ptr(mv), N.ptr(ones_pad), None, N.ptr(mp), 1, cf, Cp - cf, 0, N.stream_ptr(mv))
+                y = ops.scale_add(None, t, mp, None)
+
+                def bwd(dy):
+                    dmp = torch.empty(Cp, **f32)
+                    dt = ops.scale_add_bwd(t, mp, None, dy, dmp)
+                    _call("bf_op_relu_shift_bwd", N.ptr(w0_), nw, 1.0, N.ptr(dmp), N.ptr(self.G(name_, grads)), cf, N.stream_ptr(dmp))
+                    return dt
+                return y, bwd
         for name_ in (["channelwise/w0"] if m.add_channelwise else []) + (["multiplier/w0"] if m.add_multiplier else []):
-            f, b_ = mult_step(name_, f)
+            f, b_ = padded_mult(name_, f) if m.add_concat_input else mult_step(name_, f)
             chain.append(b_)
 
         # -- head + loss ---------------------------------------------------------------------------------------------------------
@@ -407,8 +442,13 @@ class GenericResnetTrainGraph:
         ld.mae_multiplier, ld.mse_multiplier = float(lc.get("mae_multiplier", 1.0)), float(lc.get("mse_multiplier", 0.0))
         ld.ssim_multiplier, ld.regularization = float(lc.get("ssim_multiplier", 0.0)), float(lc.get("regularization", 1.0))
         ld.depth_weight = float(depth_weight)
-        Cf = m.filters
-        w0 = self.W("head/conv0/kernel").view(Cf, m.head_filters)
+        w0 = self.W("head/conv0/kernel").view(-1, m.head_filters)
+        Ch = int(f.shape[-1])                                         # Cf, or the padded width behind add_concat_input
+        if Ch != w0.shape[0]:                                         # zero rows for the padding channels
+            w0p = torch.empty((Ch, m.head_filters), **f32)
+            zrows = torch.zeros((Ch - w0.shape[0]) * m.head_filters, **f32)
+            _call("bf_op_concat_channels", N.ptr(w0), N.ptr(zrows), None, N.ptr(w0p), 1, w0.numel(), zrows.numel(), 0, N.stream_ptr(w0))
+            w0 = w0p
         w1 = self.W("head/conv1/kernel").view(m.head_filters, m.out_channels).contiguous()
         h0 = UL.pointwise(f, pack(w0), m.head_filters, m.head_activation)
         pred = UL.head_out(h0, w1, H, Wd, False, True, m.v_min, m.v_max)
@@ -424,8 +464,14 @@ class GenericResnetTrainGraph:
         _call("bf_op_head_out_bwd", N.ptr(h0), N.ptr(w1), N.ptr(dpred), N.ptr(dh0), N.ptr(self.G("head/conv1/kernel", grads)), npix,
               m.head_filters, m.out_channels, 1, m.v_min, m.v_max, sp, sn, N.stream_ptr(h0))
         dh0p = ops.act_bwd(h0, dh0, m.head_activation)
-        ops.matmul_wgrad(f, dh0p, self.G("head/conv0/kernel", grads))
-        g = UL.pointwise(dh0p, pack(ops.transpose(w0)), Cf)
+        g0 = self.G("head/conv0/kernel", grads)
+        if Ch * m.head_filters != g0.numel():                         # the padded rows' gradient is dropped (those channels are zero)
+            gp = torch.empty(Ch * m.head_filters, **f32)
+            ops.matmul_wgrad(f, dh0p, gp)
+            _call("bf_op_slice_channels", N.ptr(gp), N.ptr(g0), 1, gp.numel(), 0, g0.numel(), N.stream_ptr(gp))
+        else:
+            ops.matmul_wgrad(f, dh0p, g0)
+        g = UL.pointwise(dh0p, pack(ops.transpose(w0)), Ch)
 
         # -- backward ------------------------------------------------------------------------------------------------------------
         for b_block in reversed(chain):

@@ -104,6 +104,10 @@ CONFIGS = {
                                 add_gates=True, add_initial_bn=True, add_final_bn=True, add_channelwise_scaling=True,
                                 add_learnable_multiplier=True, dropout_rate=0.5, base_activation="relu"),
     "dropout-alone": dict(no_layers=2, dropout_rate=0.5),
+    # add_concat_input (backbone_resnet.py:277-279): the normalised input joins the features ahead of the closing layers and the head
+    "concat-input": dict(no_layers=2, add_concat_input=True),
+    "concat-input-bn-multipliers": dict(no_layers=2, add_concat_input=True, add_final_bn=True, add_channelwise_scaling=True,
+                                        add_learnable_multiplier=True),
     # GELU (utilities.py:229-267, the exact erf form) as block / base activation: differentiated from the kept pre-activation
     "gelu-blocks": dict(no_layers=2, block_activation=["gelu", "gelu", "linear"], base_activation="gelu"),
     "gelu-two-conv-nobn": dict(filters=32, kernel_size=3, block_kernels=[3, 3], block_filters=[32, 32], block_depthwise=[-1, -1],
