@@ -138,6 +138,9 @@ SIGNATURES = {
     "bf_op_linear_shift": (_I, [_P, _I, _F, _P, _I, _P]),
     "bf_op_center_scale": (_I, [_P, _P, _P, _P, _I64, _F, _P]),
     "bf_op_pass_filter": (_I, [_P, _P, _I64, _F, _I, _I, _P]),
+    "bf_op_pass_filter_bwd": (_I, [_P, _P, _P, _I64, _F, _I, _I, _P]),
+    "bf_op_center_scale_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I64, _F, _P]),
+    "bf_op_center_sq_bwd": (_I, [_P, _P, _P, _P, _P, _I64, _P]),
     "bf_op_concat_input": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
     "bf_op_selector_mix_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _P]),
     "bf_op_avgpool_same_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

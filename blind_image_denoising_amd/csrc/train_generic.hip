@@ -859,3 +859,60 @@ extern "C" int bf_op_pass_filter(const float* x, float* out, int64_t n, float a,
     hipLaunchKernelGGL(tg_pass_filter_kernel, dim3(tg_grid(n)), dim3(256), 0, (hipStream_t)stream, x, out, n, a, b, highpass);
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
+
+// ------------------------------------------------------------------------------------------
+// adjoints of the selector's pre-filters (training): bf_op_pass_filter_bwd; local_normalization y = d r, d = x - m, r = (v + eps)^-1/2,
+// m = pool(x), v = pool(d^2): bf_op_center_scale_bwd gives dd = dy r and dv = -0.5 dy d r^3; with t = pool^T(dv) (bf_op_avgpool_same_bwd)
+// bf_op_center_sq_bwd forms dd + 2 d t, and dx = that - pool^T(that).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tg_pass_filter_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                                                 int64_t n, float a, int b, int highpass)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = x[i], t = tanhf(a * v);
+        float fm1 = 1.f;                                   // t^(b-1)
+        for (int k = 0; k < b - 1; ++k) fm1 *= t;
+        const float f = fm1 * t, df = (float)b * fm1 * a * (1.f - t * t);
+        dx[i] = dy[i] * (highpass ? f + v * df : (1.f - f) - v * df);
+    }
+}
+
+__global__ __launch_bounds__(256) void tg_center_scale_bwd_kernel(const float* __restrict__ x, const float* __restrict__ m, const float* __restrict__ var,
+                                                                  const float* __restrict__ dy, float* __restrict__ dd, float* __restrict__ dv,
+                                                                  int64_t n, float eps)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float d = x[i] - m[i], r = 1.f / sqrtf(var[i] + eps), g = dy[i];
+        dd[i] = g * r;
+        dv[i] = -0.5f * g * d * r * r * r;
+    }
+}
+
+__global__ __launch_bounds__(256) void tg_center_sq_bwd_kernel(const float* __restrict__ x, const float* __restrict__ m, const float* __restrict__ t,
+                                                               const float* __restrict__ dd, float* __restrict__ out, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = fmaf(2.f * (x[i] - m[i]), t[i], dd[i]);
+}
+
+extern "C" int bf_op_pass_filter_bwd(const float* x, const float* dy, float* dx, int64_t n, float a, int b, int highpass, void* stream)
+{
+    if (!x || !dy || !dx || n <= 0 || b < 1 || b > 16) return BF_EINVAL;
+    hipLaunchKernelGGL(tg_pass_filter_bwd_kernel, dim3(tg_grid(n)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n, a, b, highpass);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+extern "C" int bf_op_center_scale_bwd(const float* x, const float* mean, const float* var, const float* dy, float* dd, float* dv, int64_t n,
+                                      float eps, void* stream)
+{
+    if (!x || !mean || !var || !dy || !dd || !dv || n <= 0) return BF_EINVAL;
+    hipLaunchKernelGGL(tg_center_scale_bwd_kernel, dim3(tg_grid(n)), dim3(256), 0, (hipStream_t)stream, x, mean, var, dy, dd, dv, n, eps);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+extern "C" int bf_op_center_sq_bwd(const float* x, const float* mean, const float* t, const float* dd, float* out, int64_t n, void* stream)
+{
+    if (!x || !mean || !t || !dd || !out || n <= 0) return BF_EINVAL;
+    hipLaunchKernelGGL(tg_center_sq_bwd_kernel, dim3(tg_grid(n)), dim3(256), 0, (hipStream_t)stream, x, mean, t, dd, out, n);
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}

@@ -39,8 +39,6 @@ class GenericResnetTrainGraph:
         for j, (kk, g) in enumerate(zip(model.block_kernels, model.block_groups)):
             if g != 1 and kk != 1:
                 raise NotImplementedError("training: grouped convolutions are built for 1x1 kernels")
-        if getattr(model, "selector", None) and model.selector.get("pre"):
-            raise NotImplementedError("training: the selector's optional pre-filters are built for inference only")
         self.ops = None
         self.totals = None
 
@@ -219,14 +217,94 @@ class GenericResnetTrainGraph:
                 return dt
             return y, bwd
 
+        def prefilter_step(i, x, pre, pool, Ct, chain_):
+            """the selector's optional pre-filters (custom_layers_selector.py:160-185) forward, their adjoints appended to chain_"""
+            from .resnet_generic import SELECTOR_EPSILON
+            if pre.get("conv1x1"):
+                name = f"block{i}/selector/pre/kernel"
+                xin, w = x, self.W(name).view(x.shape[-1], Ct)
+                x = UL.pointwise(xin, pack(w), Ct)
+
+                def b_conv(dy, xin=xin, w=w, name=name):
+                    ops.matmul_wgrad(xin, dy, self.G(name, grads))
+                    return UL.pointwise(dy, pack(ops.transpose(w)), int(xin.shape[-1]))
+                chain_.append(b_conv)
+            Bx, Hx, Wx, Cx = x.shape
+            if pre.get("gn"):                                    # per sample: BatchNorm's batch-statistics forward / backward with gamma 1
+                xin = x
+                ones, mm, mv = (torch.ones(Cx, **f32) for _ in range(3))
+                saves = torch.empty((Bx, 2 * Cx), **f32)
+                x = torch.empty_like(xin)
+                for b in range(Bx):
+                    xb, ob, sb = xin[b], x[b], saves[b]
+                    sp_, sn_ = ops._s()
+                    _call("bf_op_bn_train_fwd", N.ptr(xb), N.ptr(ones), N.ptr(ob), N.ptr(sb), N.ptr(mm), N.ptr(mv), Hx * Wx, Cx, SELECTOR_EPSILON,
+                          0.0, 0, 0.0, sp_, sn_, N.stream_ptr(xin))
+
+                def b_gn(dy, xin=xin, ones=ones, saves=saves):
+                    dx = torch.empty_like(xin)
+                    dgamma = torch.empty(Cx, **f32)
+                    for b in range(Bx):
+                        xb, db, ob, sb = xin[b], dy[b], dx[b], saves[b]
+                        sp_, sn_ = ops._s()
+                        _call("bf_op_bn_train_bwd", N.ptr(xb), N.ptr(ones), N.ptr(sb), N.ptr(db), N.ptr(ob), N.ptr(dgamma), Hx * Wx, Cx, sp_, sn_,
+                              N.stream_ptr(xin))
+                    return dx
+                chain_.append(b_gn)
+            if pre.get("ln"):
+                xin = x
+
+                def pooled(t):
+                    o = torch.empty_like(t)
+                    _call("bf_op_avgpool_same", N.ptr(t), N.ptr(o), Bx, Hx, Wx, Cx, pool[0], pool[1], 1, 1, N.stream_ptr(t))
+                    return o
+
+                def pooled_t(t):                                 # the pooling's adjoint
+                    o = torch.empty_like(t)
+                    _call("bf_op_avgpool_same_bwd", N.ptr(t), N.ptr(o), Bx, Hx, Wx, Cx, pool[0], pool[1], 1, 1, 0, N.stream_ptr(t))
+                    return o
+                mean = pooled(xin)
+                sq = torch.empty_like(xin)
+                _call("bf_op_center_scale", N.ptr(xin), N.ptr(mean), None, N.ptr(sq), xin.numel(), SELECTOR_EPSILON, N.stream_ptr(xin))
+                var = pooled(sq)
+                x = torch.empty_like(xin)
+                _call("bf_op_center_scale", N.ptr(xin), N.ptr(mean), N.ptr(var), N.ptr(x), xin.numel(), SELECTOR_EPSILON, N.stream_ptr(xin))
+
+                def b_ln(dy, xin=xin, mean=mean, var=var):
+                    dd, dv = torch.empty_like(xin), torch.empty_like(xin)
+                    _call("bf_op_center_scale_bwd", N.ptr(xin), N.ptr(mean), N.ptr(var), N.ptr(dy), N.ptr(dd), N.ptr(dv), xin.numel(),
+                          SELECTOR_EPSILON, N.stream_ptr(dy))
+                    t = pooled_t(dv)
+                    tot = torch.empty_like(xin)
+                    _call("bf_op_center_sq_bwd", N.ptr(xin), N.ptr(mean), N.ptr(t), N.ptr(dd), N.ptr(tot), xin.numel(), N.stream_ptr(dd))
+                    back = pooled_t(tot)
+                    _call("bf_op_axpy", N.ptr(tot), N.ptr(back), -1.0, 0, tot.numel(), N.stream_ptr(tot))     # d (x - pool x)
+                    return tot
+                chain_.append(b_ln)
+            for key, high in (("lp", 0), ("hp", 1)):
+                if pre.get(key):
+                    xin = x
+                    x = torch.empty_like(xin)
+                    _call("bf_op_pass_filter", N.ptr(xin), N.ptr(x), xin.numel(), 4.0, 4, high, N.stream_ptr(xin))
+
+                    def b_pf(dy, xin=xin, high=high):
+                        dx = torch.empty_like(xin)
+                        _call("bf_op_pass_filter_bwd", N.ptr(xin), N.ptr(dy), N.ptr(dx), xin.numel(), 4.0, 4, high, N.stream_ptr(dy))
+                        return dx
+                    chain_.append(b_pf)
+            return x
+
         def selector_step(i, x1, x2, sel):
             """selector_block (custom_layers_selector.py:81-330) in place of the skip Add: out = x1 s + x2 (1 - s), s = F(2.5 - u),
             u = up(relu(leaky(pool(sel) W0) W1)).  scale_type GLOBAL is the same chain with one window over the whole image
             (Dense layers, slope SELECTOR_GLOBAL_LEAKY).  Returns (out, backward: d out -> (d x1, d x2, d sel))."""
             sp = m.selector
             st, soft = sp["scale_type"], int(sp["activation_type"] == "soft")
-            Bs, Hs, Ws, Cs = sel.shape
             Ct = x1.shape[-1]
+            pre_chain = []                                       # adjoints of the optional pre-filters, in forward order
+            if sp.get("pre"):
+                sel = prefilter_step(i, sel, sp["pre"], sp["pool"], Ct, pre_chain)
+            Bs, Hs, Ws, Cs = sel.shape
             if st == "global":
                 stride, pools, alpha0, kind = (Hs, Ws), [(Hs, Ws)], SELECTOR_GLOBAL_LEAKY, "dense"
             else:
@@ -287,6 +365,8 @@ class GenericResnetTrainGraph:
                     sp_, sn_ = ops._s()
                     _call("bf_op_channel_mean_broadcast", N.ptr(dgm), N.ptr(spread), Bs, OH * OW, Cs, Hs * Ws, sp_, sn_, N.stream_ptr(dgm))
                     _call("bf_op_axpy", N.ptr(dsel), N.ptr(spread), float(OH * OW) / float(Hs * Ws), 0, dsel.numel(), N.stream_ptr(dsel))
+                for b_pre in reversed(pre_chain):
+                    dsel = b_pre(dsel)
                 return dx1, dx2, dsel
             return out, bwd
 

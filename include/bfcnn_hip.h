@@ -439,6 +439,12 @@ int bf_op_concat_input(const float* feat, const void* x, int x_is_u8, float* out
    global_normalization = bf_op_bn_train_fwd per sample with gamma 1; lowpass / highpass: out = x (1 - tanh(a x)^b) / x tanh(a x)^b */
 int bf_op_center_scale(const float* x, const float* mean, const float* var, float* out, int64_t n, float eps, void* stream);
 int bf_op_pass_filter(const float* x, float* out, int64_t n, float a, int b, int highpass, void* stream);
+/* their adjoints: dx of the pass filters; for y = (x - m) / sqrt(v + eps): dd = dy / sqrt(v + eps) and dv = d y / d v (bf_op_center_scale_bwd),
+   then out = dd + 2 (x - m) t with t = the pooling's adjoint of dv (bf_op_center_sq_bwd); dx = out - pooling adjoint of out */
+int bf_op_pass_filter_bwd(const float* x, const float* dy, float* dx, int64_t n, float a, int b, int highpass, void* stream);
+int bf_op_center_scale_bwd(const float* x, const float* mean, const float* var, const float* dy, float* dd, float* dv, int64_t n, float eps,
+                           void* stream);
+int bf_op_center_sq_bwd(const float* x, const float* mean, const float* t, const float* dd, float* out, int64_t n, void* stream);
 /* selector_block in training: adjoints of bf_op_selector_mix (dx1, dx2, du from dy), bf_op_avgpool_same (dx [B,H,W,C] from the pooled
    map's gradient; accumulate != 0: added to dx), bf_op_dense2 in its selector form (no biases, act0 = leaky ReLU alpha0, final ReLU:
    din, dw0 [in_channels][squeeze], dw1 [squeeze][channels]; scratch: bf_op_dense2_bwd_scratch_floats), and the channel slice

@@ -98,6 +98,24 @@ def avgpool_same(x, pool, stride):
     return torch.stack(rows, dim=1)
 
 
+def selector_prefilter(sel, flags, pre_w, pool):
+    """resnet_generic_oracle.selector_prefilter (custom_layers_selector.py:160-185; utilities.py:566-620) in torch"""
+    x = sel
+    if "use_conv1x1_selector" in flags:
+        x = x @ pre_w.reshape(pre_w.shape[-2], pre_w.shape[-1])
+    if "use_global_normalization" in flags:
+        mu = x.mean(dim=(1, 2), keepdim=True)
+        x = (x - mu) / torch.sqrt(((x - mu) ** 2).mean(dim=(1, 2), keepdim=True) + 1e-3)
+    if "use_local_normalization" in flags:
+        mu = avgpool_same(x, pool, (1, 1))
+        x = (x - mu) / torch.sqrt(avgpool_same((x - mu) ** 2, pool, (1, 1)) + 1e-3)
+    if "use_lowpass" in flags:
+        x = (1.0 - torch.tanh(4.0 * x) ** 4) * x
+    if "use_highpass" in flags:
+        x = torch.tanh(4.0 * x) ** 4 * x
+    return x
+
+
 def selector_block(x1, x2, sel, w0, w1, scale_type, activation_type, pool, stride):
     """custom_layers_selector.py:81-330 as resnet_generic_oracle.selector_block restates it (no optional pre-filters)"""
     st = scale_type.lower()
@@ -169,7 +187,7 @@ def hydra(spec: R.GenericResnetSpec, P, S, x, training: bool, drop_scale=None):
             t = t * drop_scale[i].reshape(-1, 1, 1, 1)
         if spec.selector:
             if spec.selector[6]:
-                raise NotImplementedError("the gradient oracle does not restate the selector's optional pre-filters (inference only in the product)")
+                first = selector_prefilter(first, spec.selector[6], P.get(f"block{i}/selector/pre/kernel"), spec.selector[3])
             kind = "dense" if spec.selector[0] == "global" else "conv"
             f = selector_block(f, t, first, P[f"block{i}/selector/{kind}0/kernel"], P[f"block{i}/selector/{kind}1/kernel"],
                                spec.selector[0], spec.selector[1], spec.selector[3], spec.selector[4])

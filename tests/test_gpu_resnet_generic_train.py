@@ -121,6 +121,10 @@ CONFIGS = {
     "selector-mixed-gates-multipliers": dict(no_layers=2, add_gates=True, add_channelwise_scaling=True,
                                              selector_params=dict(scale_type="mixed", pool_size=(16, 16))),
     "selector-global": dict(no_layers=2, selector_params=dict(scale_type="global")),
+    # ... and its optional pre-filters (custom_layers_selector.py:160-185)
+    "selector-prefilters-conv-norms": dict(no_layers=2, selector_params=dict(scale_type="local", pool_size=(8, 8), use_conv1x1_selector=True,
+                                                                           use_global_normalization=True, use_local_normalization=True)),
+    "selector-prefilters-pass": dict(no_layers=2, selector_params=dict(scale_type="mixed", pool_size=(8, 8), use_lowpass=True, use_highpass=True)),
     "selector-two-conv": dict(filters=32, kernel_size=3, block_kernels=[3, 3], block_filters=[32, 32], block_depthwise=[-1, -1],
                               block_groups=[1, 1], block_activation=["relu", "relu"], block_regularizer=["l1", "l2"], no_layers=2,
                               selector_params=dict(scale_type="local", pool_size=(8, 8))),
