@@ -399,7 +399,9 @@ class GenericResnetHydra:
                     # the block's closing multipliers are >= 0 and its last activation is base_activation: folded into the last
                     # convolution's scale / shift when that commutes (and no gate sits between), else applied as their own pass
                     es = end_scale(f"block{i}/", cout)
-                    if homogeneous(self.block_activation[j]) and not (self.add_gates and j == 1):
+                    # (a one-convolution block with a selector: that convolution's output is also the selector layer, which the
+                    # reference takes BEFORE the multipliers -- backbone_blocks.py:174-179 vs 215-221 -- so nothing may ride on it)
+                    if homogeneous(self.block_activation[j]) and not (self.add_gates and j == 1) and not (self.selector and nb_ == 1):
                         scale, shift = scale * es, (None if shift is None else shift * es)
                     else:
                         P[f"b{i}scale"] = dev(es)

@@ -218,3 +218,45 @@ def test_shipped_resnet_pipeline_config_runs_unchanged(tmp_path):
     assert (tmp_path / "final").exists()
     out = bf.load_model(str(tmp_path / "final"))(clean.astype(np.uint8))
     assert out.shape == clean.shape and out.dtype == np.uint8
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_random_builder_configurations_train(seed):
+    """the seeded sweep of tests/test_resnet_generic.py over the builder's option space, through the training step: loss, prediction and
+    every gradient tensor against the autograd oracle (RandomOnOff pinned when the configuration has it)"""
+    import importlib.util, os
+    spec_ = importlib.util.spec_from_file_location("_rg", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_resnet_generic.py"))
+    rg = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(rg)
+    rng = np.random.default_rng(5000 + seed)
+    bb = rg._random_resnet_config(rng)
+    bb["no_layers"] = min(bb["no_layers"], 2)
+    if any(k != 1 and g != 1 for k, g in zip(bb["block_kernels"], bb["block_groups"])):
+        pytest.skip("training: grouped convolutions are built for 1x1 kernels")
+    cfg = R.shipped_config()
+    cfg["backbone"].update(bb)
+    spec = R.GenericResnetSpec.from_config(cfg)
+    params, state = R.init_params(spec, seed=seed)
+    clean, noisy = O.synthetic_batch(2, 24, 32, seed=seed)
+    ls = O.LossSpec.from_config(LOSS)
+    drop = DROP if spec.dropout_rate > 0 else None
+    r_total, r_ml, r_dl, r_pred, r_grads, r_state = T.train_step(spec, ls, params, state, clean, noisy, drop_scale={k: v for k, v in (drop or {}).items() if k < spec.no_layers} or None)
+    model = bf.model_builder(cfg, device="cuda").hydra
+    model.set_weights(params, state)
+    try:
+        fns = bf.build_train_functions(model, bf.loss_function_builder(LOSS))
+    except NotImplementedError:
+        pytest.skip("refused by the training graph")
+    if drop:
+        fns.train_step_single_gpu.drop_scale = {k: torch.from_numpy(v.astype(np.float32)).cuda() for k, v in drop.items() if k < spec.no_layers}
+    total, ml, dls, pred, grads = fns.train_step_single_gpu(torch.from_numpy(clean.astype(np.float32)), torch.from_numpy(noisy.astype(np.float32)))
+    assert abs(total.item() - r_total) <= 2e-5 * abs(r_total)
+    assert np.abs(pred.cpu().numpy() - r_pred).max() <= 0.05
+    g = grads.cpu().numpy().astype(np.float64)
+    worst = []
+    for n, shape, kind, off in model.trainable_variables:
+        sz = int(np.prod(shape))
+        a, b = g[off:off + sz], r_grads[off:off + sz]
+        worst.append((np.abs(a - b).max() / max(np.abs(b).max(), 1e-7), n))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 2e-3, worst[:5]

@@ -232,3 +232,58 @@ def test_generic_resnet_save_and_load_roundtrip(tmp_path):
     mod = bf.load_model(str(tmp_path / "r"))
     _, noisy = O.synthetic_batch(1, 32, 32, seed=3)
     assert np.array_equal(mod(noisy), bf.DenoiserModule(m)(noisy))
+
+
+def _random_resnet_config(rng):
+    """a random point of the resnet builder's option space (within the channel counts the operators are built for)"""
+    filters = int(rng.choice([32, 64]))
+    layout = rng.choice(["bottleneck", "two-conv", "single", "three-dense"])
+    if layout == "bottleneck":
+        dm = int(rng.choice([1, 2, 4])) if filters == 32 else int(rng.choice([1, 2]))
+        bb = dict(block_kernels=[1, int(rng.choice([3, 5])), 1], block_filters=[filters, filters * dm, filters], block_depthwise=[-1, dm, -1],
+                  block_groups=[1, 1, int(rng.choice([1, 2]))])
+    elif layout == "two-conv":
+        bb = dict(block_kernels=[int(rng.choice([1, 3])), 3], block_filters=[filters, filters], block_depthwise=[-1, -1], block_groups=[1, 1])
+    elif layout == "single":
+        bb = dict(block_kernels=[3], block_filters=[filters], block_depthwise=[-1], block_groups=[1])
+    else:
+        bb = dict(block_kernels=[1, 3, 1], block_filters=[filters, 2 * filters if filters == 32 else filters, filters], block_depthwise=[-1, -1, -1],
+                  block_groups=[1, 1, 1])
+    nb = len(bb["block_kernels"])
+    acts = ["relu", "leaky_relu", "leaky_relu_01", "gelu", "linear"]
+    bb.update(filters=filters, kernel_size=int(rng.choice([3, 5, 7])), no_layers=int(rng.integers(1, 4)),
+              block_activation=[str(rng.choice(acts)) for _ in range(nb)], block_regularizer=["l1"] * nb,
+              base_activation=str(rng.choice(["linear", "relu", "gelu"])), use_bn=bool(rng.integers(2)))
+    for flag in ("add_initial_bn", "add_final_bn", "add_channelwise_scaling", "add_learnable_multiplier", "add_concat_input"):
+        bb[flag] = bool(rng.random() < 0.35)
+    if nb >= 2 and rng.random() < 0.35:
+        bb["add_gates"] = True
+    if rng.random() < 0.4:
+        sp = dict(scale_type=str(rng.choice(["local", "global", "mixed", "multiscale"])), activation_type=str(rng.choice(["hard", "soft"])),
+                  pool_size=(8, 8))
+        for k in ("use_conv1x1_selector", "use_global_normalization", "use_local_normalization", "use_lowpass", "use_highpass"):
+            if rng.random() < 0.25:
+                sp[k] = True
+        bb["selector_params"] = sp
+    if rng.random() < 0.3:
+        bb["dropout_rate"] = 0.25
+    return bb
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(64))
+def test_random_builder_configurations_match_oracle(seed):
+    """a seeded sweep over the builder's option space (block layouts, kernel sizes, depth multipliers, groups, activations, BatchNorm on /
+    off and around the blocks, gates, multipliers, concat input, the selector with its scale types and pre-filters): every combination
+    that builds must match the oracle; the ones the operators do not cover must refuse with NotImplementedError, never miscompute"""
+    rng = np.random.default_rng(1000 + seed)
+    cfg = G.shipped_config()
+    cfg["backbone"].update(_random_resnet_config(rng))
+    try:
+        bf.model_builder(cfg, device="cpu")
+    except NotImplementedError:
+        pytest.skip("outside the built operators (refused)")
+    try:
+        _check(cfg, (2, 32, 40), seed=seed)
+    except NotImplementedError:
+        pytest.skip("outside the built operators (refused at run time)")
