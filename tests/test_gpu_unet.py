@@ -480,3 +480,49 @@ def test_conv2d_transpose_matches_oracle(k, s, shape):
         ref = U.act(U.conv2d_transpose_same(x.astype(np.float64), w.astype(np.float64), s), act)
         assert got.shape == ref.shape
         assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def _random_unet_backbone(rng):
+    """a random point of the unet_laplacian builder's option space (backbone_unet_laplacian.py:35-130), filters 32"""
+    depth = int(rng.integers(2, 5))
+    bb = dict(depth=depth, width=int(rng.integers(1, 4)), filters=32,
+              encoder_kernel_size=int(rng.choice([3, 5])), decoder_kernel_size=int(rng.choice([1, 3, 5])),
+              activation=str(rng.choice(["leaky_relu_01", "leaky_relu", "relu"])),
+              use_ln=bool(rng.random() < 0.8), use_gamma=bool(rng.random() < 0.8),
+              use_mix_project=bool(rng.random() < 0.3), use_self_attention=bool(rng.random() < 0.6),
+              use_attention_gates=bool(rng.random() < 0.3), use_output_normalization=bool(rng.random() < 0.7),
+              use_laplacian=True, use_laplacian_averaging=bool(rng.random() < 0.5), gaussian_kernel_size=int(rng.choice([2, 3, 5])),
+              downsample_type=str(rng.choice(["strides", "conv2d", "maxpool"])),
+              upsample_type=str(rng.choice(["upsample_laplacian_conv2d", "upsample_bilinear_conv2d", "upsample_nearest_conv2d", "bilinear", "nn"])))
+    if bb["upsample_type"] in ("bilinear", "nn"):
+        bb["filters_level_multiplier"] = 1.0
+    if rng.random() < 0.3:                         # the trained archive's graph revision, option by option
+        bb.update(convnext_activation="gelu", encoder_level_activation=bool(rng.integers(2)),
+                  output_normalization_at_heads=bool(rng.integers(2)), upsample_linear=bool(rng.integers(2)),
+                  attention_full_resolution=bool(rng.integers(2)), attention_activation=str(rng.choice(["", "gelu"])))
+    return bb
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_unet_configurations_match_oracle(seed):
+    """a seeded sweep over the unet_laplacian builder's options (depth 2-4, width, kernel sizes, LayerNorm / multiplier / mix projection /
+    attention / attention gates / output normalisation on or off, both Laplacian splits, all three down-samplers, five up-samplers, the
+    archive revision's switches): what builds must match the oracle on every output scale; what the operators do not cover must refuse"""
+    rng = np.random.default_rng(3000 + seed)
+    bb = _random_unet_backbone(rng)
+    try:
+        rest = {k: v for k, v in bb.items() if k not in ("depth", "width")}
+        cfg, spec, params, m = _model(depth=bb["depth"], width=bb["width"], seed=seed, arith=int(rng.integers(2)), **rest)
+    except NotImplementedError as e:
+        pytest.skip(f"outside the built graph (refused): {e}")
+    S = 16 * 2 ** (bb["depth"] - 2)
+    _, noisy = O.synthetic_batch(2, 2 * S, 3 * S, seed=seed)
+    x = noisy.astype(np.float32)
+    try:
+        got = m(x)
+    except NotImplementedError as e:
+        pytest.skip(f"outside the built operators (refused at run time): {e}")
+    ref = U.hydra_forward(spec, params, x.astype(np.float64))
+    assert len(got) == len(ref) == bb["depth"]
+    for g, r in zip(got, ref):
+        _check_f32(g, r)

@@ -433,3 +433,27 @@ def test_shipped_v5_pipeline_config_runs_unchanged(tmp_path):
     assert (tmp_path / "final").exists()
     out = bf.load_model(str(tmp_path / "final"))(clean.astype(np.uint8))
     assert out.shape == clean.shape and out.dtype == np.uint8
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_unet_configurations_train(seed):
+    """the seeded sweep of tests/test_gpu_unet.py over the unet_laplacian builder's options, through the training step (depth 2-3): losses,
+    predictions and every gradient tensor against the autograd oracle"""
+    import importlib.util, os
+    spec_ = importlib.util.spec_from_file_location("_gu", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_unet.py"))
+    gu = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(gu)
+    rng = np.random.default_rng(7000 + seed)
+    bb = gu._random_unet_backbone(rng)
+    bb["depth"] = min(bb["depth"], 3)
+    bb["width"] = min(bb["width"], 2)
+    depth = bb["depth"]
+    try:
+        cfg, spec, params, model, clean, noisy = _setup(depth, bb["width"], 32, 32, backbone={k: v for k, v in bb.items() if k not in ("depth", "width", "filters")})
+        T.check_trainable_graph(spec)
+    except NotImplementedError as e:
+        pytest.skip(f"refused: {e}")
+    try:
+        _check_step(spec, params, model, clean, noisy, LOSS_V5, [1.0, 0.6, 0.3][:depth])
+    except NotImplementedError as e:
+        pytest.skip(f"refused: {e}")
