@@ -309,3 +309,36 @@ def test_standalone_normalize_and_denormalize_layers():
     assert np.abs(d - ((np.clip(y, -0.5, 0.5) + 0.5) * 255.0)).max() <= 2e-5
     with pytest.raises(RuntimeError, match="GPU"):
         bf.model.build_normalize_model()(torch.zeros(1))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_engine_configurations_and_options_match_oracle(seed):
+    """a seeded sweep over the 16-filter engine's configuration and option space: depth, base kernel size, 1 / 2 / 3 convolutions per
+    block, activations, BatchNorm on / off, head activation, ragged image sizes and batches on both sides of the row count where the
+    default moves from the tile kernel to the full-row streaming kernel, every set_option switch of the inference path (arithmetic,
+    fused blocks, kernel variant, band order, head folding, compact layout).  Whatever combination is asked for must match the oracle."""
+    rng = np.random.default_rng(9000 + seed)
+    nb = int(rng.choice([1, 2, 2, 2, 3]))
+    cfg = O.canonical_config(no_layers=int(rng.integers(1, 7)), kernel_size=int(rng.choice([1, 3, 5, 7])))
+    cfg["model"]["backbone"].update(block_kernels=[3] * nb, block_filters=[16] * nb, activation=str(rng.choice(["relu", "relu", "linear"])),
+                                    use_bn=bool(rng.random() < 0.8))
+    cfg["model"]["denoiser"]["activation"] = str(rng.choice(["linear", "relu", "leaky_relu"]))
+    spec = O.ResnetSpec.from_config(cfg["model"])
+    params, state = O.init_params(spec, seed=seed, nontrivial_bn=True)
+    try:
+        m = bf.model_builder(cfg["model"], device="cuda").hydra
+    except NotImplementedError as e:
+        pytest.skip(f"refused: {e}")
+    m.set_weights(params, state)
+    big = rng.random() < 0.5                                   # big: >= 3072 image rows in the batch
+    H, W = (int(rng.integers(96, 200)), int(rng.integers(8, 257))) if big else (int(rng.integers(1, 70)), int(rng.integers(1, 300)))
+    B = -(-3072 // H) + int(rng.integers(0, 3)) if big else int(rng.integers(1, 4))
+    opts = {"arith": int(rng.random() < 0.75), "fused_blocks": int(rng.random() < 0.85), "h3_zigzag": int(rng.integers(2)),
+            "fused_head": int(rng.random() < 0.3), "h3_compact": int(rng.random() < 0.4),
+            "h3_variant": int(rng.choice([-1, -1, 1, 4]))}
+    for k, v in opts.items():
+        m.set_option(k, v)
+    _, noisy = O.synthetic_batch(B, H, W, seed=seed)
+    x = noisy.astype(np.float32)
+    _check_f32(np.asarray(m(x))[:2], O.hydra_forward(spec, params, state, x[:2].astype(np.float64)))
+    _check_u8(bf.DenoiserModule(m)(noisy)[:2], O.denoiser_module_call(spec, params, state, noisy[:2]))

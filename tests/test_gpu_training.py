@@ -531,3 +531,46 @@ def test_the_engine_learns_to_denoise(tmp_path):
     # (unseeded runs of tools/exp/learn_to_denoise.py end between +3.9 and +8.2 dB; the seed in the train section pins this one)
     assert psnr(held, den) > psnr(held, noisy) + 3.0, (psnr(held, noisy), psnr(held, den))
     assert mae(held, den) < 0.75 * mae(held, noisy)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_training_configurations_and_options_match_oracle(seed):
+    """a seeded sweep over the engine's training path: depth, base kernel size, 1 / 2 / 3 convolutions per block, BatchNorm on / off, the
+    three loss terms and the hinge, ragged shapes, and every set_option switch of the training step (arithmetic of the convolutions,
+    fused forward / backward kernels, double-buffered backward, tile order): loss, prediction, every gradient tensor and the moving
+    statistics against the oracle"""
+    rng = np.random.default_rng(11000 + seed)
+    nb = int(rng.choice([1, 2, 2, 2, 3]))
+    cfg = O.canonical_config(no_layers=int(rng.integers(1, 5)), kernel_size=int(rng.choice([1, 3, 5, 7])))
+    cfg["model"]["backbone"].update(block_kernels=[3] * nb, block_filters=[16] * nb, use_bn=bool(rng.random() < 0.8))
+    cfg["loss"].update({"hinge": float(rng.choice([0.0, 0.5, 3.5])), "mse_multiplier": float(rng.choice([0.0, 0.5])),
+                        "ssim_multiplier": float(rng.choice([0.0, 1.0])), "regularization": 0.01})
+    spec = O.ResnetSpec.from_config(cfg["model"])
+    ls = O.LossSpec.from_config(cfg["loss"])
+    params, state = O.init_params(spec, seed=seed, nontrivial_bn=True)
+    for name, (o, s) in spec.offsets().items():              # keep tanh(2x) * 0.51 inside the denormaliser's clip (see the config-4 test)
+        if name.startswith("head"):
+            params[o:o + int(np.prod(s))] *= 0.3
+    m = bf.model_builder(cfg["model"], device="cuda").hydra
+    m.set_weights(params, state)
+    try:
+        fns = bf.build_train_functions(m, bf.loss_function_builder(cfg["loss"]))
+    except NotImplementedError as e:
+        pytest.skip(f"refused: {e}")
+    opts = {"train_arith": int(rng.random() < 0.7), "train_fused_fwd": int(rng.integers(2)), "train_fused_bwd": int(rng.integers(2)),
+            "train_bwd_dbuf": int(rng.random() < 0.3), "train_zigzag": int(rng.integers(2))}
+    for k, v in opts.items():
+        m.set_option(k, v)
+    B, H, W = int(rng.integers(1, 4)), int(rng.integers(8, 60)), int(rng.integers(8, 70))
+    clean, noisy = O.synthetic_batch(B, H, W, seed=seed)
+    gt, x = clean.astype(np.float32), noisy.astype(np.float32)
+    try:
+        total, ml, dl, pred, grads = fns.train_step_single_gpu(torch.from_numpy(gt), torch.from_numpy(x), (1.0,), 0.0, None)
+    except NotImplementedError as e:
+        pytest.skip(f"refused: {e}")
+    r_total, r_ml, r_dl, r_pred, r_grads, r_state = O.train_step_single_gpu(spec, ls, params, state, gt.astype(np.float64), x.astype(np.float64))
+    assert abs(total.item() - r_total) <= 2e-5 * abs(r_total), (opts, total.item(), r_total)
+    assert np.abs(pred.cpu().numpy() - r_pred).max() < 0.02
+    _cmp_grads(spec, grads.cpu().numpy().astype(np.float64), r_grads, rel=6e-4)
+    if state.size:
+        assert np.abs(m.state.cpu().numpy() - r_state).max() < 1e-5
