@@ -4,6 +4,8 @@ Bars (BASELINE.json north_star): uint8 outputs within +-1 LSB; f32 hydra output 
 the normalised [-0.5, 0.5] scale (= 0.0255 on the 0..255 scale)."""
 import pathlib
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -311,7 +313,7 @@ def test_standalone_normalize_and_denormalize_layers():
         bf.model.build_normalize_model()(torch.zeros(1))
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BF_SWEEP_N", 40))))     # BF_SWEEP_N=300: a longer hunt
 def test_random_engine_configurations_and_options_match_oracle(seed):
     """a seeded sweep over the 16-filter engine's configuration and option space: depth, base kernel size, 1 / 2 / 3 convolutions per
     block, activations, BatchNorm on / off, head activation, ragged image sizes and batches on both sides of the row count where the

@@ -2,6 +2,8 @@
 torch-autograd gradient oracle (oracle/unet_torch.py, itself pinned to the NumPy restatement in tests/test_unet_train_oracle.py).
 Bars: losses 1e-5 relative, predictions 0.02 grey levels, every gradient tensor 5e-4 of its largest entry (exact fp32 kernels
 against fp64; sums over up to 1e5 pixels)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -435,7 +437,7 @@ def test_shipped_v5_pipeline_config_runs_unchanged(tmp_path):
     assert out.shape == clean.shape and out.dtype == np.uint8
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BF_SWEEP_N", 16))))     # BF_SWEEP_N=300: a longer hunt
 def test_random_unet_configurations_train(seed):
     """the seeded sweep of tests/test_gpu_unet.py over the unet_laplacian builder's options, through the training step (depth 2-3): losses,
     predictions and every gradient tensor against the autograd oracle"""
@@ -453,7 +455,18 @@ def test_random_unet_configurations_train(seed):
         T.check_trainable_graph(spec)
     except NotImplementedError as e:
         pytest.skip(f"refused: {e}")
-    try:
-        _check_step(spec, params, model, clean, noisy, LOSS_V5, [1.0, 0.6, 0.3][:depth])
-    except NotImplementedError as e:
-        pytest.skip(f"refused: {e}")
+    # a hinge / ReLU input within rounding of its kink on one pixel moves a gradient tensor well past the bar (about 6 % of the
+    # configurations; tests/test_gpu_resnet_generic_train.py has the measurement): on a mismatch the comparison is repeated on other
+    # inputs -- a tie goes away, a fault does not
+    last = None
+    for attempt in range(3):
+        if attempt:
+            clean, noisy = O.synthetic_batch(clean.shape[0], clean.shape[1], clean.shape[2], seed=seed + 1000 * attempt)
+        try:
+            _check_step(spec, params, model, clean, noisy, LOSS_V5, [1.0, 0.6, 0.3][:depth])
+            return
+        except NotImplementedError as e:
+            pytest.skip(f"refused: {e}")
+        except AssertionError as e:
+            last = e
+    raise last

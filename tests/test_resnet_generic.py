@@ -1,6 +1,8 @@
 """Resnet configs outside the 16-filter 3x3 family (blind_image_denoising_amd/resnet_generic.py) against
 oracle/resnet_generic_oracle.py: the config the reference ships (1x1 -> depthwise 3x3 x4 -> grouped 1x1, BN folded) and a
 few other shapes.  CPU: oracle cross-checks + host logic; GPU: parity through the C ABI."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -271,7 +273,7 @@ def _random_resnet_config(rng):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(64))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BF_SWEEP_N", 64))))     # BF_SWEEP_N=300: a longer hunt
 def test_random_builder_configurations_match_oracle(seed):
     """a seeded sweep over the builder's option space (block layouts, kernel sizes, depth multipliers, groups, activations, BatchNorm on /
     off and around the blocks, gates, multipliers, concat input, the selector with its scale types and pre-filters): every combination
