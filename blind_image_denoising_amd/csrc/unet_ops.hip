@@ -327,6 +327,7 @@ extern "C" int bf_op_conv2d(const float* in, float* out, const float* wp, const 
         }                                                                                                                      \
     }
     UO_CV(32, 32, 4) UO_CV(32, 64, 4) UO_CV(64, 32, 4) UO_CV(64, 64, 4) UO_CV(64, 128, 2) UO_CV(128, 64, 4) UO_CV(128, 128, 2) UO_CV(256, 128, 2)
+    UO_CV(128, 256, 1)                     // conv2d down-sampling into the 256-channel attention level of the four-level models
 #undef UO_CV
 #undef UO_CV_A
     if (!ok) return BF_EUNSUPPORTED;
