@@ -808,7 +808,7 @@ extern "C" int bf_op_smooth_split_bwd_ex(const float* dlap, const float* ddown, 
                                          int k, int down_stride, void* stream)
 {
     if (!dlap || !ddown || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (down_stride != 1 && down_stride != 2)) return BF_EINVAL;
-    if (k < 1 || k > 7 || (gauss && !(k & 1))) return BF_EUNSUPPORTED;
+    if (k < 1 || k > 7) return BF_EUNSUPPORTED;                      // any window, even or odd, averaging or Gaussian (same pad_before as the forward)
     const int64_t n = (int64_t)B * H * W * C;
     hipLaunchKernelGGL(tp_smooth_split_bwd_kernel, dim3(tp_grid(n)), dim3(256), 0, (hipStream_t)stream, dlap, ddown, gauss, dx, B, H, W, C, k,
                        down_stride);

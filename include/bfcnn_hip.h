@@ -352,7 +352,7 @@ int bf_op_multiplier_bwd(const float* w, const float* dm, float* dw, int n, void
 int bf_op_smooth_split_bwd(const float* dlap, const float* ddown, const float* gauss, float* dx, int batch, int height, int width,
                            int channels, int k, void* stream);
 /* the same with ddown the gradient of the full-resolution smooth map (down_stride 1: conv2d / maxpool down-sampling) or of
-   smooth[:, ::2, ::2] (2); averaging windows of any size k <= 7 (TF same padding: the extra tap after for even k) */
+   smooth[:, ::2, ::2] (2); averaging or Gaussian windows of any size k <= 7 (TF same padding: the extra tap after for even k) */
 int bf_op_smooth_split_bwd_ex(const float* dlap, const float* ddown, const float* gauss, float* dx, int batch, int height, int width,
                               int channels, int k, int down_stride, void* stream);
 /* adjoint of MaxPooling2D(2, 2, same) (bfcnn/downsampling.py:56-68): dx [B,H,W,C] = dy [B,ceil(H/2),ceil(W/2),C] at each window's
