@@ -92,3 +92,33 @@ def test_config5_scale_laplacian_split_merge():
     assert (rec - x).abs().mean().item() < 1e-7
     pyr2 = bf.build_pyramid_model((None, None, 3), cfg)(2.0 * x)       # the split is linear
     assert all((a * 2.0 - b).abs().max().item() < 1e-5 for a, b in zip(pyr, pyr2))
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("BF_SWEEP_N", 40))))
+def test_random_pyramid_configurations_match_oracle(seed):
+    """a seeded sweep over the pyramid builder's options and ragged shapes (both types, 1-4 levels, square and rectangular pooling
+    windows, 1 / 3 / 16 channels, batches, sizes that are multiples of 2^(levels-1) but otherwise arbitrary): every level against the
+    oracle, the round trip, and device-tensor in / out"""
+    rng = np.random.default_rng(13000 + seed)
+    levels = int(rng.integers(1, 5))
+    step = 2 ** (levels - 1)
+    H, W = step * int(rng.integers(1, 40)), step * int(rng.integers(1, 40))
+    C, B = int(rng.choice([1, 3, 16])), int(rng.integers(1, 4))
+    ptype = str(rng.choice(["laplacian", "gaussian"]))
+    k = (int(rng.choice([2, 3, 4, 5, 7])), int(rng.choice([2, 3, 4, 5, 7])))
+    cfg = {"levels": levels, "type": ptype, "kernel_size": k}
+    x = rng.uniform(-0.5, 0.5, (B, H, W, C)).astype(np.float32)
+    pyr = bf.build_pyramid_model((None, None, C), cfg)
+    inv = bf.build_inverse_pyramid_model((None, None, C), cfg)
+    got = pyr.predict(x)
+    ref = O.build_pyramid(cfg)(x.astype(np.float64))
+    assert len(got) == len(ref) == levels
+    for g, r in zip(got, ref):
+        assert g.shape == r.shape and np.abs(g - r).max() < 3e-6, (cfg, x.shape)
+    rec = inv.predict(got)
+    want = O.build_inverse_pyramid(cfg)(ref)
+    assert rec.shape == want.shape and np.abs(rec - want).max() < 5e-6
+    if ptype == "laplacian":
+        assert np.abs(rec - x).mean() < 1e-7
+    xd = torch.from_numpy(x).cuda()
+    assert all(torch.equal(a, torch.from_numpy(b).cuda()) for a, b in zip(pyr(xd), got))
