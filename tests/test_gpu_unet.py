@@ -528,3 +528,6 @@ def test_random_unet_configurations_match_oracle(seed):
     assert len(got) == len(ref) == bb["depth"]
     for g, r in zip(got, ref):
         _check_f32(g, r)
+    if seed % 3 == 0:                                          # and the uint8 module on a ragged frame (padded to a power of two inside)
+        ragged = noisy[:1, :2 * S - 3, :3 * S - 5]
+        _check_u8(bf.DenoiserModule(m)(ragged), U.denoiser_module_call(spec, params, ragged))
