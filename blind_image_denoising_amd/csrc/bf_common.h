@@ -172,11 +172,29 @@ hipError_t bf_launch_fused_block_h3(const FusedH3Args& a, hipStream_t s);
 // true when bf_launch_fused_block_h3 would run the full-row streaming kernel for these arguments (the one kernel that reads and
 // writes the compact layout)
 bool       bf_fused_block_h3_is_streaming(const FusedH3Args& a);
+const char* bf_fused_block_h3_kernel_name(const FusedH3Args& a);
+const char* bf_fused_block_kernel_name();                      // conv3x3_c16.hip: the exact-fp32 fused block
 // library default of FusedH3Args::variant (handle-less debug entries): 4 = full-row streaming kernel where it applies
 // (W <= 256), 1 = row-streaming tile kernel, 0 / 2 / 3 = earlier tile kernels (A/B only)
 void       bf_set_h3_variant(int v);
 hipError_t bf_launch_fused_block_h3v(const FusedH3Args& a, hipStream_t s);      // fused_h3v.hip
 bool       bf_fused_block_h3v_supports(int H, int W);
+// two residual blocks per launch on 128-column strips (fused_h3w.hip); same weight images / aux / layout as FusedH3Args
+struct FusedH3WArgs {
+    const void* in;       // split-planar x0
+    void* out;            // split-planar x2 = block_b(block_a(x0)); must not alias in
+    const void* w1r[2];   // [13][64] x 16 B row-streaming images of the first convolution of block a, b
+    const void* w2r[2];
+    const float* aux[2];  // per block: [0..15] 1/s1, [32..47] shift, [48..63] 1/s2r
+    int B, H, W;
+    int nstrips, tiles_y, ntiles, rows_per_tile;    // filled in by the launcher
+    int reverse_tiles;    // walk the units last to first and the rows bottom-up
+    int act1_relu;
+    const void* zeros;    // >= 64 B of zeros, 16-B aligned (source of rows outside the image)
+    unsigned long long* dbg;  // diagnostic builds only (per-wave phase cycle sums), else NULL
+};
+hipError_t bf_launch_fused_block2_h3w(const FusedH3WArgs& a, hipStream_t s);
+bool       bf_fused_block2_h3w_supports(int H, int W);
 hipError_t bf_launch_pack_h3(const float* params, const float* state, int64_t p_blocks, int64_t p_stride, float* dst,
                              int64_t d_stride, int layers, int use_bn, float eps, const float* ext_scale,
                              const float* ext_shift, hipStream_t s);

@@ -1030,6 +1030,16 @@ static hipError_t launch_fused(FusedBlockArgs a, int wgs_per_cu, hipStream_t s)
     return hipGetLastError();
 }
 
+// name of the kernel bf_launch_fused_block launches (bench.py looks its counter traffic up by this name)
+const char* bf_fused_block_kernel_name()
+{
+    switch (g_fused_tile) {
+        case 1: case 2: case 0: return "fused_block_kernel";
+        case 3: return "fused_block_dma_kernel";
+        default: return "fused_block_v4_kernel";
+    }
+}
+
 hipError_t bf_launch_fused_block(const FusedBlockArgs& a, hipStream_t s)
 {
     switch (g_fused_tile) {

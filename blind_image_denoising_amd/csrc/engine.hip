@@ -29,6 +29,9 @@ struct bf_engine {
     int h3_zigzag = 1;              // alternate the band order of consecutive split-f16 blocks (Infinity Cache reuse)
     int h3_variant = -1;            // split-f16 block kernel: < 0 = library default (bf_set_h3_variant), else that variant
     int h3_compact = 0;             // 1: full-row streaming kernel keeps the activations between the launches in the compact layout
+    int h3_pair = 1;                // 1: where the streaming kernel applies, consecutive blocks run two per launch (fused_h3w.hip)
+    int block_launches = 0;         // launches of the last forward's residual blocks (bf_get_timing)
+    const char* block_kernel = "";  // name of the kernel that ran most of them
                                     // (fp8 lo planes, 48 B per pixel; bf_common.h): +5 % images/s for 6e-6 instead of 2e-7 normalised MAE
     // arithmetic of the fused inference blocks: 1 = split-f16 on the f16 matrix cores (fused_h3.hip, needs
     // |activation| < 65504), 0 = exact fp32 on the f32 matrix cores (conv3x3_c16.hip)
@@ -199,6 +202,7 @@ extern "C" int bf_set_option(bf_handle h, const char* key, int value)
     if (!strcmp(key, "h3_variant")) { h->h3_variant = value; return BF_OK; }      // per handle; < 0 = library default
     if (!strcmp(key, "h3_zigzag")) { h->h3_zigzag = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "h3_compact")) { h->h3_compact = value ? 1 : 0; return BF_OK; }
+    if (!strcmp(key, "h3_pair")) { h->h3_pair = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "fused_head")) { h->fused_head = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_zigzag")) { h->train_zigzag = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_fused_fwd")) { h->train_fused_fwd = value ? 1 : 0; return BF_OK; }
@@ -237,6 +241,14 @@ extern "C" int bf_get_timing(bf_handle h, float* ms, int* launches)
     *ms = (float)total;
     *launches = (int)(h->timed_launches * n);
     return BF_OK;
+}
+
+// name of the kernel that ran most of the residual-block launches of the last forward, and how many launches one forward made
+extern "C" const char* bf_get_block_kernel(bf_handle h, int* launches_per_forward)
+{
+    if (!h) return "";
+    if (launches_per_forward) *launches_per_forward = h->block_launches;
+    return h->block_kernel;
 }
 
 extern "C" int64_t bf_packed_bytes(bf_handle h) { return h ? h->k_total * 4 : -1; }
@@ -459,8 +471,36 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
     int cur = 0;
     const int64_t tslot = h->n_timed % BF_TIMING_RING;
     if (h->timing) BF_HIP(hipEventRecord(h->ev[2 * tslot], s), "hipEventRecord");
+    // two blocks per launch (fused_h3w.hip) wherever the one-block streaming kernel would run: x1 and both intermediate
+    // activations stay in LDS, 128 instead of 256 bytes per pixel through HBM for a pair
+    bool pair_ok = false;
+    if (h3 && h->h3_pair && !compact) {
+        FusedH3Args probe;
+        memset(&probe, 0, sizeof(probe));
+        probe.B = B; probe.H = H; probe.W = W; probe.variant = h->h3_variant;
+        pair_ok = bf_fused_block_h3_is_streaming(probe) && bf_fused_block2_h3w_supports(H, W);
+    }
+    int launches = 0, pair_launches = 0;
     for (int i = 0; i < d.no_layers; ++i) {
         const float* blk = pk + h->k_blocks + i * h->k_block_stride;
+        if (pair_ok && i + 1 < d.no_layers && !(head_in_block && i + 1 == d.no_layers - 1)) {
+            FusedH3WArgs fa;
+            memset(&fa, 0, sizeof(fa));
+            fa.in = buf[cur]; fa.out = buf[cur ^ 1];
+            for (int b = 0; b < 2; ++b) {
+                const float* aux = pk + h->k_h3 + (int64_t)(i + b) * BF_H3_BLOCK_FLOATS + 2 * BF_H3_WPACK_FLOATS;
+                fa.aux[b] = aux; fa.w1r[b] = aux + 64; fa.w2r[b] = aux + 64 + BF_H3R_WPACK_FLOATS;
+            }
+            fa.B = B; fa.H = H; fa.W = W;
+            fa.reverse_tiles = h->h3_zigzag ? (launches & 1) : 0;
+            fa.act1_relu = d.activation == BF_ACT_RELU; fa.zeros = pk + h->k_zero; fa.dbg = nullptr;
+            BF_HIP(bf_launch_fused_block2_h3w(fa, s), "fused_block2_h3w");
+            cur ^= 1;
+            ++i;
+            ++launches; ++pair_launches;
+            continue;
+        }
+        launches += d.block_convs != 2 ? d.block_convs : ((h3 || h->fused_blocks) ? 1 : 2);
         if (d.block_convs != 2) {
             // general block: conv1 (no BN) + act, [conv2 + BN + act,] conv_last + BN + linear, + skip (backbone_blocks.py:174-242;
             // a one-convolution block is conv (no BN, linear) + skip: the last activation is forced to base_activation)
@@ -490,7 +530,7 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
             fa.B = B; fa.H = H; fa.W = W; fa.tiles_x = fa.tiles_y = fa.ntiles = 0; fa.rows_per_tile = 0; fa.variant = h->h3_variant;
             // consecutive blocks walk the batch in opposite directions: a block starts on the bands the previous one wrote
             // last, which are the ones still in the 256 MB Infinity Cache
-            fa.reverse_tiles = h->h3_zigzag ? (i & 1) : 0;
+            fa.reverse_tiles = h->h3_zigzag ? ((launches - 1) & 1) : 0;
             fa.act1_relu = d.activation == BF_ACT_RELU; fa.zeros = pk + h->k_zero; fa.dump = (char*)status + 1024; fa.dbg = nullptr;
             fa.head_wh = nullptr; fa.head_out = nullptr; fa.head_u8 = 0; fa.Ho = fa.Wo = 0; fa.denormalize = 0;
             fa.v_min = fa.v_max = 0.f; fa.status = nullptr; fa.compact = compact;
@@ -525,9 +565,18 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
     }
     if (h->timing) {
         BF_HIP(hipEventRecord(h->ev[2 * tslot + 1], s), "hipEventRecord");
-        h->timed_launches = d.no_layers * (d.block_convs != 2 ? d.block_convs : (h->fused_blocks ? 1 : 2));
+        h->timed_launches = launches;
         ++h->n_timed;
     }
+    h->block_launches = launches;
+    if (2 * pair_launches >= launches && pair_launches) h->block_kernel = "fused_block2_h3w_kernel";
+    else if (d.block_convs != 2 || !(h3 || h->fused_blocks)) h->block_kernel = "conv3x3_c16_kernel";
+    else if (h3) {
+        FusedH3Args probe;
+        memset(&probe, 0, sizeof(probe));
+        probe.B = B; probe.H = H; probe.W = W; probe.variant = h->h3_variant;
+        h->block_kernel = bf_fused_block_h3_kernel_name(probe);
+    } else h->block_kernel = bf_fused_block_kernel_name();
     if (head_in_block) return BF_OK;
     HeadArgs ha;
     ha.feat = buf[cur];
@@ -1240,6 +1289,45 @@ extern "C" int bf_debug_fused_block_h3(const float* in, const float* w1_hwio, co
     fa.head_wh = nullptr; fa.head_out = nullptr; fa.head_u8 = 0; fa.Ho = fa.Wo = 0; fa.denormalize = 0; fa.v_min = fa.v_max = 0.f;
     fa.status = nullptr;
     if (bf_launch_fused_block_h3(fa, s) != hipSuccess) return BF_EHIP;
+    return bf_launch_h3_to_f32(ya, out, B, H, W, s) == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// TWO split-f16 fused blocks in one launch (fused_h3w.hip) on fp32 NHWC tensors: convert in, run, convert out.
+// w_hwio = [4][3][3][16][16] (conv1a, conv2a, conv1b, conv2b), scale / shift = [2][16] (block a, b).
+extern "C" int64_t bf_debug_fused_block2_h3_scratch_floats(int B, int H, int W)
+{
+    return 2 * (int64_t)B * H * W * 16 + 2 * (int64_t)BF_H3_BLOCK_FLOATS + 2 * (4608 + 16) + 32 + 64;
+}
+
+extern "C" int bf_debug_fused_block2_h3(const float* in, const float* w_hwio, const float* scale, const float* shift, float* out,
+                                        float* scratch, int B, int H, int W, int act1_relu, int reverse, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (!in || !w_hwio || !scale || !shift || !out || !scratch || B <= 0 || H <= 0 || W <= 0) return BF_EINVAL;
+    const int64_t act = (int64_t)B * H * W * 16;
+    float* xa = scratch;
+    float* ya = scratch + act;
+    float* pk = ya + act;                              // 2 x BF_H3_BLOCK_FLOATS
+    float* params = pk + 2 * BF_H3_BLOCK_FLOATS;       // 2 x [w1 2304][w2 2304][gamma 16]
+    float* state = params + 2 * (4608 + 16);           // [mean 16][var 16] (unused: the caller's scale / shift stand in)
+    float* zeros = state + 32;                         // 64
+    if (hipMemcpyAsync(params, w_hwio, 4608 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;
+    if (hipMemcpyAsync(params + 4608 + 16, w_hwio + 4608, 4608 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;
+    if (bf_launch_zero(zeros, 64, s) != hipSuccess) return BF_EHIP;
+    for (int b = 0; b < 2; ++b)
+        if (bf_launch_pack_h3(params + b * (4608 + 16), state, 0, 4608 + 16, pk + b * BF_H3_BLOCK_FLOATS, BF_H3_BLOCK_FLOATS, 1, 0,
+                              0.f, scale + 16 * b, shift + 16 * b, s) != hipSuccess) return BF_EHIP;
+    if (bf_launch_h3_from_f32(in, xa, B, H, W, s) != hipSuccess) return BF_EHIP;
+    FusedH3WArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.in = xa; fa.out = ya;
+    for (int b = 0; b < 2; ++b) {
+        const float* aux = pk + b * BF_H3_BLOCK_FLOATS + 2 * BF_H3_WPACK_FLOATS;
+        fa.aux[b] = aux; fa.w1r[b] = aux + 64; fa.w2r[b] = aux + 64 + BF_H3R_WPACK_FLOATS;
+    }
+    fa.B = B; fa.H = H; fa.W = W; fa.reverse_tiles = reverse ? 1 : 0; fa.act1_relu = act1_relu;
+    fa.zeros = zeros; fa.dbg = g_fused_dbg;
+    if (bf_launch_fused_block2_h3w(fa, s) != hipSuccess) return BF_EHIP;
     return bf_launch_h3_to_f32(ya, out, B, H, W, s) == hipSuccess ? BF_OK : BF_EHIP;
 }
 

@@ -1439,6 +1439,14 @@ bool bf_fused_block_h3_is_streaming(const FusedH3Args& a)
     return variant == 4 && !a.head_wh && bf_fused_block_h3v_supports(a.H, a.W);
 }
 
+// name of the kernel bf_launch_fused_block_h3 launches for these arguments
+const char* bf_fused_block_h3_kernel_name(const FusedH3Args& a)
+{
+    if (bf_fused_block_h3_is_streaming(a)) return "fused_block_h3v_kernel";
+    const int variant = (a.variant >= 0 ? a.variant : (g_h3_variant >= 0 ? g_h3_variant : h3_default_variant(a))) & 255;
+    return variant == 0 ? "fused_block_h3_kernel" : (variant == 3 ? "fused_block_h3s_kernel" : "fused_block_h3r_kernel");
+}
+
 hipError_t bf_launch_fused_block_h3(const FusedH3Args& args, hipStream_t s)
 {
     FusedH3Args a = args;

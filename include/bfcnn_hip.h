@@ -528,6 +528,10 @@ int bf_set_option(bf_handle h, const char* key, int value);
  * forwards since the option was set (the last 256 at most) and the number of kernel launches inside
  * them (bench.py roofline: average launch duration over the timed region). */
 int bf_get_timing(bf_handle h, float* ms, int* launches);
+/* name of the kernel that ran most of the residual-block launches of the handle's LAST forward ("" before the first one) and
+ * the number of block launches that forward made: what a profile of the run must show, and the key bench.py looks counter
+ * traffic up by.  The string is static storage. */
+const char* bf_get_block_kernel(bf_handle h, int* launches_per_forward);
 
 /* single 3x3 16->16 convolution with epilogue flags (1 relu, 2 affine, 4 residual, 8 mask,
  * 16 stats); transpose_flip = 1 runs the data-gradient form.  wpack_scratch = 2*2304 + 64 floats. */
@@ -543,6 +547,11 @@ int64_t bf_debug_fused_block_h3_scratch_floats(int batch, int height, int width)
 int bf_debug_fused_block_h3(const float* in, const float* w1_hwio, const float* w2_hwio, const float* scale,
                             const float* shift, float* out, float* scratch,
                             int batch, int height, int width, int act1_relu, void* stream);
+/* two consecutive split-f16 fused blocks in ONE launch (fused_block2_h3w_kernel) on fp32 NHWC tensors: w_hwio = [4][3][3][16][16]
+   (conv1 and conv2 of block a, then of block b), scale / shift = [2][16]; reverse = 1 walks the bands bottom-up */
+int64_t bf_debug_fused_block2_h3_scratch_floats(int batch, int height, int width);
+int bf_debug_fused_block2_h3(const float* in, const float* w_hwio, const float* scale, const float* shift, float* out,
+                             float* scratch, int batch, int height, int width, int act1_relu, int reverse, void* stream);
 /* kernel the handle-less entry above launches (a handle's own choice is bf_set_option "h3_variant"): 4 full-row streaming
    (falls back to 1 beyond 256 columns), 1 row-streaming tiles, 0 / 2 / 3 earlier tile kernels; < 0 = library default */
 int bf_debug_set_h3_variant(int variant);

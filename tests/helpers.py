@@ -96,6 +96,22 @@ def fused_block_h3_gpu(x, w1, w2, scale, shift, act1_relu=1):
     return host(out)
 
 
+def fused_block2_h3_gpu(x, w4, scale2, shift2, act1_relu=1, reverse=0):
+    """TWO consecutive split-f16 fused blocks in one launch (fused_h3w.hip) on fp32 NHWC tensors through bf_debug_fused_block2_h3:
+    w4 = [4,3,3,16,16] (conv1, conv2 of block a, then of block b), scale2 / shift2 = [2,16]."""
+    L = N.lib()
+    B, H, W, _ = x.shape
+    xd = dev(x)
+    out = torch.full((B, H, W, 16), float("nan"), dtype=torch.float32, device="cuda")
+    scratch = torch.full((int(L.bf_debug_fused_block2_h3_scratch_floats(B, H, W)),), float("nan"), dtype=torch.float32,
+                         device="cuda")
+    wd, sd, hd = dev(np.ascontiguousarray(w4)), dev(np.ascontiguousarray(scale2)), dev(np.ascontiguousarray(shift2))
+    rc = L.bf_debug_fused_block2_h3(N.ptr(xd), N.ptr(wd), N.ptr(sd), N.ptr(hd), N.ptr(out), N.ptr(scratch), B, H, W, act1_relu,
+                                    reverse, N.stream_ptr(xd))
+    assert rc == 0, rc
+    return host(out)
+
+
 def wgrad_gpu(x, dy, h3=False):
     L = N.lib()
     B, H, W, _ = x.shape

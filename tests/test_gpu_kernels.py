@@ -6,7 +6,8 @@ import torch
 
 from oracle import bfcnn_oracle as O
 from blind_image_denoising_amd import _native as N
-from helpers import bwd3x3_h3_gpu, conv3x3_h3_pre_gpu, assert_close, conv3x3_gpu, conv3x3_h3_gpu, dev, fused_block_gpu, fused_block_h3_gpu, host, wgrad_gpu
+from helpers import (bwd3x3_h3_gpu, conv3x3_h3_pre_gpu, assert_close, conv3x3_gpu, conv3x3_h3_gpu, dev, fused_block_gpu, fused_block_h3_gpu,
+                     fused_block2_h3_gpu, host, wgrad_gpu)
 
 pytestmark = pytest.mark.gpu
 
@@ -225,6 +226,70 @@ def test_fused_block_h3_many_tiles_persistent_schedule(h3_variant):
     sub = slice(1, 2)
     t64 = np.maximum(O.conv2d_same(x[sub].astype(np.float64), w1.astype(np.float64)), 0)
     assert_close(got[sub], x[sub] + O.conv2d_same(t64, w2.astype(np.float64)), what="h3 vs oracle")
+
+
+# ---- two blocks per launch on 128-column strips (fused_h3w.hip): same oracle, same bar -------------------------------------
+def _two_blocks_oracle(x, w4, sc2, sh2, relu):
+    y = x.astype(np.float64)
+    for b in range(2):
+        t = O.conv2d_same(y, w4[2 * b].astype(np.float64))
+        if relu:
+            t = np.maximum(t, 0)
+        y = y + O.conv2d_same(t, w4[2 * b + 1].astype(np.float64)) * sc2[b] + sh2[b]
+    return y
+
+
+# one strip (W <= 144), two strips with the second grid clamped to the right edge (145 .. 256), interior strips (> 256), ragged
+# heights, bands shorter than the 12-step pipeline
+PAIR_SHAPES = SHAPES + [(1, 16, 256), (2, 40, 256), (1, 33, 144), (1, 20, 145), (1, 24, 150), (2, 17, 200), (1, 9, 129), (1, 2, 2),
+                        (1, 1, 1), (1, 12, 300), (1, 10, 512), (1, 14, 400), (3, 48, 100)]
+
+
+@pytest.mark.parametrize("shape", PAIR_SHAPES)
+@pytest.mark.parametrize("relu", [1, 0])
+@pytest.mark.parametrize("reverse", [0, 1], ids=["down", "up"])
+def test_fused_block2_h3(shape, relu, reverse):
+    B, H, W = shape
+    x = _rand((B, H, W, 16), 15)
+    w4 = _rand((4, 3, 3, 16, 16), 16) * 0.1
+    sc2, sh2 = _rand((2, 16), 18), _rand((2, 16), 19)
+    ref = _two_blocks_oracle(x, w4, sc2, sh2, relu)
+    assert_close(fused_block2_h3_gpu(x, w4, sc2, sh2, relu, reverse), ref, what=f"two fused h3 blocks {shape}")
+
+
+@pytest.mark.parametrize("reverse", [0, 1], ids=["down", "up"])
+def test_fused_block2_h3_is_exact_on_small_integers(reverse):
+    """integers that hi + lo hold exactly through BOTH blocks: the result must equal the oracle bit for bit (pins the ring
+    bookkeeping of the four chained convolutions: slots, halo columns, which row each accumulator belongs to)."""
+    rng = np.random.default_rng(7)
+    x = rng.integers(-3, 4, (2, 20, 150, 16)).astype(np.float32)
+
+    def sparse(p, lo, hi):
+        w = rng.integers(lo, hi + 1, (3, 3, 16, 16)).astype(np.float32)
+        return w * (rng.random((3, 3, 16, 16)) < p)
+
+    w4 = np.stack([sparse(0.15, -2, 2), sparse(0.15, -2, 2), sparse(0.06, -1, 1), sparse(0.06, -1, 1)])
+    sc2, sh2 = np.ones((2, 16), np.float32), rng.integers(-3, 4, (2, 16)).astype(np.float32)
+    ref = _two_blocks_oracle(x, w4, sc2, sh2, 1)
+    assert np.abs(ref).max() < 2 ** 20
+    assert np.array_equal(fused_block2_h3_gpu(x, w4, sc2, sh2, 1, reverse).astype(np.float64), ref)
+
+
+def test_fused_block2_h3_many_units_persistent_schedule():
+    """more (image, band, strip) units than workgroups and several bands per image: every unit exactly once, ring state of one
+    unit must not leak into the next (left strip after right strip and the other way round)."""
+    for B, H, W in [(70, 40, 256), (9, 300, 200), (5, 64, 520)]:
+        x = _rand((B, H, W, 16), 20)
+        w4 = _rand((4, 3, 3, 16, 16), 21) * 0.1
+        sc2, sh2 = np.ones((2, 16), np.float32), np.zeros((2, 16), np.float32)
+        got = fused_block2_h3_gpu(x, w4, sc2, sh2, 1, 0)
+        y = x                                           # exact-fp32 GPU path as the comparator at this size
+        for b in range(2):
+            t = conv3x3_gpu(y, w4[2 * b], N.EPI_RELU)
+            y = conv3x3_gpu(t, w4[2 * b + 1], N.EPI_RES, res=y)
+        assert_close(got, y, rel=1e-5, what=f"two blocks vs unfused {(B, H, W)}")
+        sub = slice(B - 1, B)
+        assert_close(got[sub], _two_blocks_oracle(x[sub], w4, sc2, sh2, 1), what="two blocks vs oracle")
 
 
 @pytest.mark.parametrize("shape", SHAPES + [(8, 64, 64)])
