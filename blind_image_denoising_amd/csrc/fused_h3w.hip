@@ -104,11 +104,6 @@ __device__ __forceinline__ int h3w_wimage(const FusedH3WArgs& a, const int i)
     return (a.reverse_tiles && i < 12) ? (2 - i / 4) * 4 + i % 4 : i;
 }
 
-// no-op hook of a matrix role's step (the A1 / A2 waves pass their memory work instead)
-struct H3WNoHook {
-    __device__ __forceinline__ void after_first_group() {}
-};
-
 // ---------------------------------------------------------------------------------------------------------------------
 // role A: a block's first convolution (+ activation): ring row -> three vertical-tap contributions -> intermediate ring.
 // State across steps: acc[g][3] (intermediate rows of steps s, s-1, s-2 modulo 3).
@@ -313,8 +308,8 @@ struct H3WRoleB {
 
     // step s (s % UNROLL == PH): consumes the intermediate row completed in step s-1, starts an output row with the residual at
     // byte offset xslot_bytes of its ring, completes the output row of byte offset oslot_bytes
-    template <int PH>
-    __device__ __forceinline__ void step(const int xslot_bytes, const int oslot_bytes, const bool rowok)
+    template <int PH, class Hook>
+    __device__ __forceinline__ void step(const int xslot_bytes, const int oslot_bytes, const bool rowok, Hook& hook)
     {
         constexpr int mslot = (PH + 1) % Gm::NRM;                              // (s - 1) mod 2
         constexpr int a0 = PH % 3, a1 = (PH + 2) % 3, a2 = (PH + 1) % 3;
@@ -335,6 +330,8 @@ struct H3WRoleB {
                 mfmas<0>(g, a1, a2, cur, xr, c0, &e);
             } else {
                 mfmas<0>(g, a1, a2, cur, xr, c0, (H3VEpi<false>*)nullptr);
+                hook.after_first_group();
+                __builtin_amdgcn_sched_barrier(0);
             }
             acc[g][a0] = c0;
             if (g + 1 < Gm::G) {
@@ -348,11 +345,36 @@ struct H3WRoleB {
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
-// memory work of the A2 waves: LDS-DMA of the x0 rows.  Wave j moves piece j (grid columns [64j, 64j+64), the third piece 16
+// Memory work rides on matrix waves (H3WMem<KIND> is the hook of a role's steps; KIND 0 = none).
+// KIND 1, the loader: LDS-DMA of the x0 rows.  Wave j of its role moves piece j (grid columns [64j, 64j+64), the third piece 16
 // columns) of all four planes: four wave-instructions per step, EVERY step (rows outside the band / the image read the zero
 // line), so that the vmcnt of the wait is a constant.
+// KIND 2, the storer: the staged output row -> global memory.  Eight 1-KiB pieces (plane, half) per row; wave j moves pieces
+// 3j .. 3j+2.  The staging reads are issued at the start of the step, the stores behind the first group's MFMAs.
+// Loads and stores sit on DIFFERENT waves: `s_waitcnt vmcnt(N)` counts both and stores retire early (fused_h3v.hip).
 // ---------------------------------------------------------------------------------------------------------------------
-struct H3WLoader {
+#ifndef H3W_MEM_ROLES
+#define H3W_MEM_ROLES 0          // which roles carry {loader, storer}: 0 = {A2, A1}, 1 = {A1, B1}, 2 = {B1, A1}, 3 = {B2, A1}
+#endif
+constexpr int h3w_mem_kind(const int role)
+{
+    constexpr int loader[4] = {2, 0, 1, 3}, storer[4] = {0, 1, 0, 0};
+    return role == loader[H3W_MEM_ROLES] ? 1 : (role == storer[H3W_MEM_ROLES] ? 2 : 0);
+}
+
+template <int KIND>
+struct H3WMem {
+    __device__ __forceinline__ H3WMem(const FusedH3WArgs&, char*, const char*, int, unsigned) {}
+    __device__ __forceinline__ void set_tile(const H3WTile&, int) {}
+    __device__ __forceinline__ void prologue(const H3WTile&) {}
+    __device__ __forceinline__ void begin(const H3WTile&, int, int) {}
+    __device__ __forceinline__ void after_first_group() {}
+    __device__ __forceinline__ void end() {}
+    __device__ __forceinline__ void finish() {}
+};
+
+template <>
+struct H3WMem<1> {
     using Gm = H3WGeom;
     const FusedH3WArgs& a;
     char* tin;
@@ -360,7 +382,10 @@ struct H3WLoader {
     unsigned plane_g;
     unsigned col_off;            // lane's byte offset inside a plane-row of the image
     bool active;                 // lane's column is fetched: inside [D0, D1) and the piece
+    int dslot;                   // (s + PD) mod 5
 
+    __device__ __forceinline__ H3WMem(const FusedH3WArgs& a_, char* tx0, const char*, const int rw, const unsigned pg)
+        : a(a_), tin(tx0), piece(rw), plane_g(pg), col_off(0), active(false), dslot(0) {}
     __device__ __forceinline__ void set_tile(const H3WTile& t, const int lane)
     {
         const int c = t.G0 + 64 * piece + lane;
@@ -384,15 +409,28 @@ struct H3WLoader {
         }
     }
     static constexpr int INFLIGHT = 2 * 4;             // pieces of the two rows younger than the one awaited
-    __device__ __forceinline__ void wait_landed() const
+    __device__ __forceinline__ void wait_landed() const { __builtin_amdgcn_s_waitcnt(h3_vmcnt((H3V_ABLATE & 1) ? 0 : INFLIGHT)); }
+    // rows 0 .. PD-1 requested, row 0 landed
+    __device__ __forceinline__ void prologue(const H3WTile& t)
     {
-        __builtin_amdgcn_s_waitcnt(h3_vmcnt((H3V_ABLATE & 1) ? 0 : INFLIGHT));
+#pragma unroll
+        for (int r = 0; r < Gm::PD; ++r) dma_row(t, r, r);
+        wait_landed();
+        dslot = Gm::PD;
     }
+    __device__ __forceinline__ void begin(const H3WTile& t, const int s, int)
+    {
+        dma_row(t, s + Gm::PD, dslot);
+        dslot = h3v_wrap(dslot + 1, Gm::NRX0);
+    }
+    __device__ __forceinline__ void after_first_group() {}
+    __device__ __forceinline__ void end() { wait_landed(); }      // row s+1 (requested two steps ago) has landed
+    // the rows requested past the band's end (zero-line reads into dead slots) must not land in the next band's rows
+    __device__ __forceinline__ void finish() { __builtin_amdgcn_s_waitcnt(h3_vmcnt(0)); }
 };
 
-// memory work of the A1 waves: the staged output row -> global memory.  Eight 1-KiB pieces (plane, half) per row; wave j moves
-// pieces 3j .. 3j+2.  The staging reads are issued at the start of the step, the stores behind the first group's MFMAs.
-struct H3WStorer {
+template <>
+struct H3WMem<2> {
     using Gm = H3WGeom;
     const FusedH3WArgs& a;
     const char* tout;
@@ -405,6 +443,8 @@ struct H3WStorer {
     bool have;
     char* grow;
 
+    __device__ __forceinline__ H3WMem(const FusedH3WArgs& a_, char*, const char* tout_, const int rw, const unsigned pg)
+        : a(a_), tout(tout_), first(3 * rw), np(rw < 2 ? 3 : 2), plane_g(pg), have(false), grow(nullptr) {}
     __device__ __forceinline__ void set_tile(const H3WTile& t, const int lane)
     {
 #pragma unroll
@@ -415,9 +455,11 @@ struct H3WStorer {
             g_off[i] = (unsigned)plane * plane_g + (unsigned)c * 16u;
         }
     }
-    // output row k (band-relative) from staging slot `oslot`
-    __device__ __forceinline__ void begin(const H3WTile& t, const int k, const int oslot)
+    __device__ __forceinline__ void prologue(const H3WTile&) {}
+    // step s (phase PH = s mod 6): output row s - 12, staged by B2 in step s-1
+    __device__ __forceinline__ void begin(const H3WTile& t, const int s, const int PH)
     {
+        const int k = s - Gm::LEAD, oslot = (PH + 1) % Gm::NRO;
         have = (k >= 0) & (k < t.nrows) & !(H3V_ABLATE & 2);                          // wave-uniform
         if (!have) return;
         grow = reinterpret_cast<char*>(a.out) + t.img + (size_t)t.y(k) * a.W * 16;
@@ -432,6 +474,8 @@ struct H3WStorer {
         for (int i = 0; i < 3; ++i)
             if (okc[i]) *reinterpret_cast<h8*>(grow + g_off[i]) = rec[i];
     }
+    __device__ __forceinline__ void end() {}
+    __device__ __forceinline__ void finish() {}
 };
 
 __global__ __launch_bounds__(H3WGeom::NT, 3) void fused_block2_h3w_kernel(FusedH3WArgs a)
@@ -459,137 +503,95 @@ __global__ __launch_bounds__(H3WGeom::NT, 3) void fused_block2_h3w_kernel(FusedH
     asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(real0), "=s"(stamp_prev)::"memory");
 #endif
 
-#define H3W_LOOP(BODY)                                                                                        \
-    for (int s0 = 0; s0 < nsteps; s0 += Gm::UNROLL) {                                                         \
-        BODY(0); BODY(1); BODY(2); BODY(3); BODY(4); BODY(5);                                                 \
-    }
 #define H3W_ROW_IN_IMAGE(k) ((t.y(k) >= 0) & (t.y(k) < a.H))
-#define H3W_END_STEP()                                                                                        \
-    H3V_STAMP(0);                                                                                             \
-    h3v_barrier();                                                                                            \
-    H3V_STAMP(2)
+// one band of one strip: R = the matrix role object, M = its memory hook, ACTIVE(s) = the role has a row in step s,
+// STEP(PH) = the role's step call.  Every role runs the same number of barriers.
+#define H3W_BAND(R, M, ACTIVE, STEP)                                                                          \
+    for (int ti = blockIdx.x; ti < a.ntiles; ti += gridDim.x) {                                               \
+        const H3WTile t = h3w_tile(a, ti);                                                                    \
+        R.set_tile(t, a.W, gc0);                                                                              \
+        M.set_tile(t, lane);                                                                                  \
+        M.prologue(t);                                                                                        \
+        h3v_barrier();                                       /* x0 row 0 has landed */                        \
+        const int nsteps = t.nrows + Gm::LEAD;                                                                \
+        int slot5 = 0;                                       /* s mod 5 */                                    \
+        for (int s0 = 0; s0 < nsteps; s0 += Gm::UNROLL) {                                                     \
+            H3W_ONE(0, M, ACTIVE, STEP); H3W_ONE(1, M, ACTIVE, STEP); H3W_ONE(2, M, ACTIVE, STEP);            \
+            H3W_ONE(3, M, ACTIVE, STEP); H3W_ONE(4, M, ACTIVE, STEP); H3W_ONE(5, M, ACTIVE, STEP);            \
+        }                                                                                                     \
+        M.finish();                                                                                           \
+        h3v_barrier();                                                                                        \
+    }
+#define H3W_ONE(PH, M, ACTIVE, STEP)                                                                          \
+    do {                                                                                                      \
+        const int s = s0 + PH;                                                                                \
+        M.begin(t, s, PH);                                                                                    \
+        if (ACTIVE(s)) { STEP(PH); }                                                                          \
+        else M.after_first_group();                                                                           \
+        slot5 = h3v_wrap(slot5 + 1, Gm::NRX0);                                                                \
+        H3V_STAMP(0);                                                                                         \
+        M.end();                                                                                              \
+        H3V_STAMP(1);                                                                                         \
+        h3v_barrier();                                                                                        \
+        H3V_STAMP(2);                                                                                         \
+    } while (0)
 
     if (role == 0) {
-        // ---- A1: conv1a on the x0 ring (dynamic slot s mod 5) -> first intermediate ring; stores the staged output rows
+        // ---- A1: conv1a on the x0 ring (dynamic slot s mod 5) -> first intermediate ring
         __builtin_amdgcn_s_setprio(H3W_PRIO_A1);
-        H3WRoleA<Gm::X0_PLANE> A;
-        A.tin = tx0; A.tmid = tm1;
-        A.init(a.w1r[0], a, a.aux[0], lane, gc0);
-        H3WStorer St{a, tout};
-        St.first = 3 * rw; St.np = rw < 2 ? 3 : 2; St.plane_g = plane_g;
+        H3WRoleA<Gm::X0_PLANE> R;
+        R.tin = tx0; R.tmid = tm1;
+        R.init(a.w1r[0], a, a.aux[0], lane, gc0);
+        H3WMem<h3w_mem_kind(0)> M(a, tx0, tout, rw, plane_g);
         __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));               // weight / scale loads
-        for (int ti = blockIdx.x; ti < a.ntiles; ti += gridDim.x) {
-            const H3WTile t = h3w_tile(a, ti);
-            A.set_tile(t, a.W, gc0);
-            St.set_tile(t, lane);
-            h3v_barrier();                                       // prologue: x0 row 0 has landed
-            const int nsteps = t.nrows + Gm::LEAD;
-            int islot = 0;                                       // s mod 5
-#define H3W_STEP(PH)                                                                                          \
-            do {                                                                                              \
-                const int s = s0 + PH;                                                                        \
-                St.begin(t, s - Gm::LEAD, (PH + 1) % Gm::NRO);     /* staged by B2 in step s-1 */             \
-                if (s < t.nrows + 8) A.template step<PH>(islot * Gm::PITCH, (s >= 2) & H3W_ROW_IN_IMAGE(s - 5), St);   \
-                else St.after_first_group();                                                                  \
-                islot = h3v_wrap(islot + 1, Gm::NRX0);                                                        \
-                H3W_END_STEP();                                                                               \
-            } while (0)
-            H3W_LOOP(H3W_STEP)
+#define H3W_ACTIVE(s) ((s) < t.nrows + 8)
+#define H3W_STEP(PH) R.template step<PH>(slot5 * Gm::PITCH, (s >= 2) & H3W_ROW_IN_IMAGE(s - 5), M)
+        H3W_BAND(R, M, H3W_ACTIVE, H3W_STEP)
+#undef H3W_ACTIVE
 #undef H3W_STEP
-            h3v_barrier();
-        }
     } else if (role == 1) {
-        // ---- B1: conv2a + residual x0 -> x1 ring
+        // ---- B1: conv2a + residual x0 (ring row s-1) -> x1 ring
         __builtin_amdgcn_s_setprio(H3W_PRIO_B1);
-        H3WRoleB<Gm::X0_PLANE, Gm::X1_PLANE> Bv;
-        Bv.tmid = tm1; Bv.tres = tx0; Bv.tout = tx1;
-        Bv.init(a.w2r[0], a, a.aux[0], lane, gc0, true);
+        H3WRoleB<Gm::X0_PLANE, Gm::X1_PLANE> R;
+        R.tmid = tm1; R.tres = tx0; R.tout = tx1;
+        R.init(a.w2r[0], a, a.aux[0], lane, gc0, true);
+        H3WMem<h3w_mem_kind(1)> M(a, tx0, tout, rw, plane_g);
         __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));
-        for (int ti = blockIdx.x; ti < a.ntiles; ti += gridDim.x) {
-            const H3WTile t = h3w_tile(a, ti);
-            Bv.set_tile(t, a.W, gc0);
-            h3v_barrier();
-            const int nsteps = t.nrows + Gm::LEAD;
-            int xslot = Gm::NRX0 - 1;                            // (s - 1) mod 5
-#define H3W_STEP(PH)                                                                                          \
-            do {                                                                                              \
-                const int s = s0 + PH;                                                                        \
-                if ((s >= 3) & (s < t.nrows + 9))                                                             \
-                    Bv.template step<PH>(xslot * Gm::PITCH, (PH % Gm::NRX1) * Gm::PITCH, H3W_ROW_IN_IMAGE(s - 7));    \
-                xslot = h3v_wrap(xslot + 1, Gm::NRX0);                                                        \
-                H3W_END_STEP();                                                                               \
-            } while (0)
-            H3W_LOOP(H3W_STEP)
+#define H3W_ACTIVE(s) (((s) >= 3) & ((s) < t.nrows + 9))
+#define H3W_STEP(PH) R.template step<PH>(h3v_wrap(slot5 + Gm::NRX0 - 1, Gm::NRX0) * Gm::PITCH, (PH % Gm::NRX1) * Gm::PITCH, H3W_ROW_IN_IMAGE(s - 7), M)
+        H3W_BAND(R, M, H3W_ACTIVE, H3W_STEP)
+#undef H3W_ACTIVE
 #undef H3W_STEP
-            h3v_barrier();
-        }
     } else if (role == 2) {
-        // ---- A2: conv1b on the x1 ring -> second intermediate ring; requests the x0 rows
+        // ---- A2: conv1b on the x1 ring -> second intermediate ring
         __builtin_amdgcn_s_setprio(H3W_PRIO_A2);
-        H3WRoleA<Gm::X1_PLANE> A;
-        A.tin = tx1; A.tmid = tm2;
-        A.init(a.w1r[1], a, a.aux[1], lane, gc0);
-        H3WLoader Ld{a, tx0};
-        Ld.piece = rw; Ld.plane_g = plane_g;
-        H3WNoHook nohook;
+        H3WRoleA<Gm::X1_PLANE> R;
+        R.tin = tx1; R.tmid = tm2;
+        R.init(a.w1r[1], a, a.aux[1], lane, gc0);
+        H3WMem<h3w_mem_kind(2)> M(a, tx0, tout, rw, plane_g);
         __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));
-        for (int ti = blockIdx.x; ti < a.ntiles; ti += gridDim.x) {
-            const H3WTile t = h3w_tile(a, ti);
-            A.set_tile(t, a.W, gc0);
-            Ld.set_tile(t, lane);
-            // prologue: rows 0 .. PD-1 requested, row 0 landed
-#pragma unroll
-            for (int r = 0; r < Gm::PD; ++r) Ld.dma_row(t, r, r);
-            Ld.wait_landed();
-            h3v_barrier();
-            const int nsteps = t.nrows + Gm::LEAD;
-            int dslot = Gm::PD;                                  // (s + PD) mod 5
-#define H3W_STEP(PH)                                                                                          \
-            do {                                                                                              \
-                const int s = s0 + PH;                                                                        \
-                Ld.dma_row(t, s + Gm::PD, dslot);                                                             \
-                if ((s >= 6) & (s < t.nrows + 10))                                                            \
-                    A.template step<PH>(((PH + 2) % Gm::NRX1) * Gm::PITCH, H3W_ROW_IN_IMAGE(s - 9), nohook);  \
-                dslot = h3v_wrap(dslot + 1, Gm::NRX0);                                                        \
-                H3V_STAMP(0);                                                                                 \
-                Ld.wait_landed();              /* row s+1 (requested two steps ago) has landed */             \
-                H3V_STAMP(1);                                                                                 \
-                h3v_barrier();                                                                                \
-                H3V_STAMP(2);                                                                                 \
-            } while (0)
-            H3W_LOOP(H3W_STEP)
+#define H3W_ACTIVE(s) (((s) >= 6) & ((s) < t.nrows + 10))
+#define H3W_STEP(PH) R.template step<PH>(((PH + 2) % Gm::NRX1) * Gm::PITCH, H3W_ROW_IN_IMAGE(s - 9), M)
+        H3W_BAND(R, M, H3W_ACTIVE, H3W_STEP)
+#undef H3W_ACTIVE
 #undef H3W_STEP
-            // the rows requested past the band's end (zero-line reads into dead slots) must not land in the next band's rows
-            __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));
-            h3v_barrier();
-        }
     } else {
         // ---- B2: conv2b + residual x1 -> staging rows
         __builtin_amdgcn_s_setprio(H3W_PRIO_B2);
-        H3WRoleB<Gm::X1_PLANE, Gm::OUT_PLANE> Bv;
-        Bv.tmid = tm2; Bv.tres = tx1; Bv.tout = tout;
-        Bv.init(a.w2r[1], a, a.aux[1], lane, gc0, false);
+        H3WRoleB<Gm::X1_PLANE, Gm::OUT_PLANE> R;
+        R.tmid = tm2; R.tres = tx1; R.tout = tout;
+        R.init(a.w2r[1], a, a.aux[1], lane, gc0, false);
+        H3WMem<h3w_mem_kind(3)> M(a, tx0, tout, rw, plane_g);
         __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));
-        for (int ti = blockIdx.x; ti < a.ntiles; ti += gridDim.x) {
-            const H3WTile t = h3w_tile(a, ti);
-            Bv.set_tile(t, a.W, gc0);
-            h3v_barrier();
-            const int nsteps = t.nrows + Gm::LEAD;
-#define H3W_STEP(PH)                                                                                          \
-            do {                                                                                              \
-                const int s = s0 + PH;                                                                        \
-                if ((s >= 9) & (s < t.nrows + 11))                                                            \
-                    Bv.template step<PH>(((PH + 1) % Gm::NRX1) * Gm::PITCH, (PH % Gm::NRO) * Gm::OUT_SLOT, true);     \
-                H3W_END_STEP();                                                                               \
-            } while (0)
-            H3W_LOOP(H3W_STEP)
+#define H3W_ACTIVE(s) (((s) >= 9) & ((s) < t.nrows + 11))
+#define H3W_STEP(PH) R.template step<PH>(((PH + 1) % Gm::NRX1) * Gm::PITCH, (PH % Gm::NRO) * Gm::OUT_SLOT, true, M)
+        H3W_BAND(R, M, H3W_ACTIVE, H3W_STEP)
+#undef H3W_ACTIVE
 #undef H3W_STEP
-            h3v_barrier();
-        }
     }
-#undef H3W_LOOP
+#undef H3W_BAND
+#undef H3W_ONE
 #undef H3W_ROW_IN_IMAGE
-#undef H3W_END_STEP
 #if H3V_ABLATE & 32
     {
         unsigned long long real1;

@@ -67,19 +67,18 @@ __device__ __forceinline__ int h3v_wrap(const int v, const int n) { return v >= 
 // of the NEXT group's MFMAs (an MFMA holds the vector-issue port for half of its 16 cycles; an in-order wave gets its other
 // vector instructions for free only if they sit right there, and hipcc neither interleaves inline asm nor selects the
 // mix instructions from C):
-//   [RELU: 4 x v_med3]  hi = f16(v * sc): 4 x v_fma_mixlo/hi_f16   d = v * sc - hi: 4 x v_fma_mix_f32   lo = f16(d): 2 x
-//   v_cvt_pk   2 x ds_write_b64 (hi plane, lo plane).  v * sc is exact (sc a power of two, or 0 for a row / column outside
+//   [RELU: 4 x v_max]  hi = f16(v * sc): 4 x v_fma_mixlo/hi_f16   lo = f16(v * sc - hi): 4 x v_fma_mixlo/hi_f16 with the f16 hi as
+//   third source   2 x ds_write_b64 (hi plane, lo plane).  v * sc is exact (sc a power of two, or 0 for a row / column outside
 //   the image), so hi is the correctly rounded f16 of the value and the scale costs no instruction.
 // Every micro-op reads accumulator registers no earlier than two MFMAs after the MFMA that finished them (the caller's
 // placement), which covers the MFMA -> VALU hazard hipcc does not pad for inline asm.
 typedef unsigned h3v_u2 __attribute__((ext_vector_type(2)));
 template <bool RELU>
 struct H3VEpi {
-    static constexpr int NOPS = (RELU ? 4 : 0) + 12;
+    static constexpr int NOPS = (RELU ? 4 : 0) + 10;
     f32x4 v;
     float sc, floor_;
     unsigned h0, h1, l0, l1;
-    float d0, d1, d2, d3;
     char* p;
     int lo_off;
     template <int I> __device__ __forceinline__ void op()
@@ -97,14 +96,14 @@ struct H3VEpi {
         else if constexpr (K == 1) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h1) : "v"(v.z), "v"(sc));
         else if constexpr (K == 2) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h0) : "v"(v.y), "v"(sc));
         else if constexpr (K == 3) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h1) : "v"(v.w), "v"(sc));
-        else if constexpr (K == 4) asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(d0) : "v"(v.x), "v"(sc), "v"(h0));
-        else if constexpr (K == 5) asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d1) : "v"(v.y), "v"(sc), "v"(h0));
-        else if constexpr (K == 6) asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(d2) : "v"(v.z), "v"(sc), "v"(h1));
-        else if constexpr (K == 7) asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d3) : "v"(v.w), "v"(sc), "v"(h1));
-        else if constexpr (K == 8) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l0) : "v"(d0), "v"(d1));
-        else if constexpr (K == 9) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l1) : "v"(d2), "v"(d3));
-        else if constexpr (K == 10) *reinterpret_cast<h3v_u2*>(p) = (H3V_ABLATE & 64) ? (h3v_u2){__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y)} : (h3v_u2){h0, h1};
-        else if constexpr (K == 11) *reinterpret_cast<h3v_u2*>(p + lo_off) = (H3V_ABLATE & 64) ? (h3v_u2){__builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w)} : (h3v_u2){l0, l1};
+        // lo = f16(v * sc - hi) in ONE instruction: the third source is the f16 half of the packed hi pair (op_sel_hi[2] = 1:
+        // f16 source, op_sel[2]: which half); v * sc - hi is exact in fp32, so this rounds once, like a cvt of the difference
+        else if constexpr (K == 4) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(v.x), "v"(sc), "v"(h0));
+        else if constexpr (K == 5) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(v.z), "v"(sc), "v"(h1));
+        else if constexpr (K == 6) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l0) : "v"(v.y), "v"(sc), "v"(h0));
+        else if constexpr (K == 7) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l1) : "v"(v.w), "v"(sc), "v"(h1));
+        else if constexpr (K == 8) *reinterpret_cast<h3v_u2*>(p) = (H3V_ABLATE & 64) ? (h3v_u2){__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y)} : (h3v_u2){h0, h1};
+        else if constexpr (K == 9) *reinterpret_cast<h3v_u2*>(p + lo_off) = (H3V_ABLATE & 64) ? (h3v_u2){__builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w)} : (h3v_u2){l0, l1};
         __builtin_amdgcn_sched_barrier(0);
     }
     // micro-ops 2*slot, 2*slot+1 (no-ops past the end)
