@@ -478,7 +478,7 @@ def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
             "end_to_end_tflops": value / world * per_px * S * S / 1e12,
             "roofline": {"bound": "hbm", "kernel": "bwd3x3_h3_kernel<true, 8> (+ reduce_partials_kernel)", "achieved": gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": wbytes,
-                         "launch_us": launch_us, "launches_per_step": args.layers}}
+                         "launch_us": launch_us, "launches_of_this_kernel_per_step": args.layers}}
         if world == 1 and not args.no_cpu_baseline:
             # the oracle's training step (fp64 NumPy restatement) on ONE image of the same shape
             cfg1 = O.canonical_config(no_layers=args.layers)
@@ -514,6 +514,49 @@ def self_launch(n):
     raise SystemExit(proc.returncode)
 
 
+def block_kernel_info(N, model):
+    """name of the kernel that ran most of the residual-block launches of the model's last forward and the number of block
+    launches of one forward, as the LIBRARY reports them (bf_get_block_kernel): never derived from option values here."""
+    lpf = C.c_int()
+    name = N.lib().bf_get_block_kernel(model._h, C.byref(lpf))
+    return (name.decode() if name else ""), int(lpf.value)
+
+
+def parity_sample(B):
+    """indices of the images checked against the oracle: spread over the batch (band scheduling gives different CUs different images)"""
+    return sorted(set([0, B // 3, (2 * B) // 3, B - 1]))
+
+
+def block_roofline(kernel, launches_per_forward, layers, B, S, launch_s, traffic):
+    """roofline object of the dominant residual-block kernel.  Algorithmic work per launch: one activation read and
+    one written = B*S*S*128 bytes; 9 216 FLOP per pixel and BLOCK, times the blocks a launch runs (2 for fused_block2_h3w_kernel,
+    1 for the one-block kernels, 1/2 for one convolution per launch)."""
+    px = B * S * S
+    blocks_per_launch = layers / max(launches_per_forward, 1)
+    flop = px * FLOP_PER_PX_BLOCK * blocks_per_launch
+    nbytes = px * BYTES_PER_PX_BLOCK
+    tf, gbs = flop / launch_s / 1e12, nbytes / launch_s / 1e9
+    common = {"kernel": kernel, "launch_us": launch_s * 1e6, "launches_per_forward": launches_per_forward,
+              "blocks_per_launch": blocks_per_launch, "algorithmic_bytes_per_launch": nbytes,
+              "algorithmic_gflop_per_launch": flop / 1e9, "traffic": traffic}
+    if kernel == "fused_block2_h3w_kernel":
+        # two blocks per launch: the activation between them never leaves the CU, the launch is bound by the f16 matrix pipe under
+        # the 1 400 W package cap (DESIGN 4.1c: 233 us without its MFMAs, 349 us without its memory instructions, 437-455 us with
+        # both).  issued = 3 split products + residual, on the 144-column grid of a 128-column strip (x 9/8)
+        issued = px * H3_MFMA_FLOP_PER_PX * blocks_per_launch * 9 / 8 / launch_s / 1e12
+        return dict(common, bound="mfma", achieved=tf, peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / MFMA_F16_PEAK_TFLOPS,
+                    dtype="f16 (split hi/lo, 3 products), fp32 accumulate", issued_tflops=issued,
+                    issued_frac=issued / MFMA_F16_PEAK_TFLOPS,
+                    hbm={"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
+    if kernel.startswith("fused_block_h3"):
+        issued = px * H3_MFMA_FLOP_PER_PX * blocks_per_launch / launch_s / 1e12
+        return dict(common, bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
+                    mfma={"dtype": "f16 (split hi/lo, 3 products)", "algorithmic_tflops": tf, "issued_tflops": issued,
+                          "peak_tflops": MFMA_F16_PEAK_TFLOPS, "issued_frac": issued / MFMA_F16_PEAK_TFLOPS})
+    return dict(common, bound="mfma", achieved=tf, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / MFMA_F32_PEAK_TFLOPS,
+                dtype="f32")
+
+
 def sub_record(model, module, noisy, noisy_host, spec, params, state, O, N, torch, arith, steps, warmup, S, compact=0):
     """one more timed loop of the default workload on `model` with another arithmetic / batch / activation layout (rank 0, N = 1)."""
     B = int(noisy.shape[0])
@@ -532,23 +575,17 @@ def sub_record(model, module, noisy, noisy_host, spec, params, state, O, N, torc
     ms, ln = C.c_float(), C.c_int()
     N.check(N.lib().bf_get_timing(model._h, C.byref(ms), C.byref(ln)), model._h)
     launch_s = float(ms.value) / 1e3 / max(int(ln.value), 1)
-    ref = O.denoiser_module_call(spec, params, state, noisy_host[:1])
-    diff = np.abs(out[:1].cpu().numpy().astype(np.int32) - ref.astype(np.int32))
+    kernel, lpf = block_kernel_info(N, model)
+    idx = parity_sample(B)
+    ref = O.denoiser_module_call(spec, params, state, noisy_host[idx])
+    diff = np.abs(out[idx].cpu().numpy().astype(np.int32) - ref.astype(np.int32))
     px = B * S * S
     rec = {"value": B * steps / elapsed, "unit": "images/s", "batch_per_gpu": B, "steps": steps, "warmup": warmup,
-           "ms_per_step": elapsed / steps * 1e3, "parity": {"mae_vs_oracle_lsb": float(diff.mean()), "max_abs_lsb": int(diff.max())}}
-    if arith == 0:
-        tf = px * FLOP_PER_PX_BLOCK / launch_s / 1e12
-        rec.update({"dtype": "f32", "arithmetic": "exact fp32 MFMA",
-                    "roofline": {"bound": "mfma", "kernel": "fused_block_v4_kernel", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS,
-                                 "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS, "launch_us": launch_s * 1e6, "traffic": None}})
-    else:
-        gbs = px * BYTES_PER_PX_BLOCK / launch_s / 1e9
-        rec.update({"dtype": "f16x2 split (hi+lo, fp32 accumulate)", "arithmetic": "split-f16 MFMA (f16x3), fp32 accumulate",
-                    "roofline": {"bound": "hbm", "kernel": "fused_block_h3v_kernel" if S <= 256 and B * S >= 3072 else "fused_block_h3r_kernel",
-                                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                 "launch_us": launch_s * 1e6, "traffic": None,
-                                 "mfma_algorithmic_tflops": px * FLOP_PER_PX_BLOCK / launch_s / 1e12}})
+           "ms_per_step": elapsed / steps * 1e3,
+           "parity": {"mae_vs_oracle_lsb": float(diff.mean()), "max_abs_lsb": int(diff.max()), "checked_images": len(idx)},
+           "dtype": "f32" if arith == 0 else "f16x2 split (hi+lo, fp32 accumulate)",
+           "arithmetic": "exact fp32 MFMA" if arith == 0 else "split-f16 MFMA (f16x3), fp32 accumulate",
+           "roofline": block_roofline(kernel, lpf, spec.no_layers, B, S, launch_s, None)}
     if compact:
         # 48 instead of 64 bytes per pixel between the launches (fp8 lo planes): `achieved` stays on the ALGORITHMIC 128 B per pixel and
         # block of SURVEY 8(d), `stored_gbs` is what the layout actually moves
@@ -616,6 +653,11 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # a scaling run must prove that the collective backend saw N ranks on N devices
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
+    if not rehearse and torch.cuda.device_count() < min(args.gpus, world):
+        raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} device(s) are visible to rank {rank}")
 
     if args.mode == "train":
         return train_bench(args, torch, bf, O, rank, local_rank, world, dist)
@@ -678,37 +720,17 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        # parity of the timed configuration: one image against the fp64 oracle (+-1 LSB bar)
-        ref = O.denoiser_module_call(spec, params, state, noisy_host[:1])
-        got = out[:1].cpu().numpy()
+        # parity of the timed configuration: four images spread over the batch against the fp64 oracle (+-1 LSB bar)
+        idx = parity_sample(B)
+        ref = O.denoiser_module_call(spec, params, state, noisy_host[idx])
+        got = out[idx].cpu().numpy()
         diff = np.abs(got.astype(np.int32) - ref.astype(np.int32))
         images = B * world * args.steps
         value = images / elapsed
-        per_launch_flop = B * S * S * FLOP_PER_PX_BLOCK * (1 if not args.unfused else 0.5)
-        per_launch_bytes = B * S * S * BYTES_PER_PX_BLOCK
         avg_launch_s = block_ms / 1e3 / max(launches, 1)
-        achieved = per_launch_flop / avg_launch_s / 1e12
-        if h3:
-            kernel = {None: "fused_block_h3v_kernel", 4: "fused_block_h3v_kernel", 1: "fused_block_h3r_kernel"}.get(args.h3_variant, "fused_block_h3_kernel")
-            if kernel == "fused_block_h3v_kernel" and (S > 256 or (args.h3_variant is None and B * S < 3072)):
-                kernel = "fused_block_h3r_kernel"          # the full-row kernel: images up to 256 columns, batches of >= 3072 rows
-            gbs = per_launch_bytes / avg_launch_s / 1e9
-            roofline = {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(args.layers, B, S, True, kernel),
-                        "algorithmic_bytes_per_launch": per_launch_bytes,
-                        "launch_us": avg_launch_s * 1e6, "launches_per_step": launches,
-                        "mfma": {"dtype": "f16 (split hi/lo, 3 products)", "algorithmic_tflops": achieved,
-                                 "issued_tflops": B * S * S * H3_MFMA_FLOP_PER_PX / avg_launch_s / 1e12,
-                                 "peak_tflops": MFMA_F16_PEAK_TFLOPS,
-                                 "issued_frac": B * S * S * H3_MFMA_FLOP_PER_PX / avg_launch_s / 1e12 / MFMA_F16_PEAK_TFLOPS}}
-        else:
-            kernel = "fused_block_v4_kernel" if not args.unfused else "conv3x3_c16_kernel"
-            roofline = {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-                        "traffic": pmc_traffic(args.layers, B, S, not args.unfused, kernel),
-                        "algorithmic_bytes_per_launch": per_launch_bytes,
-                        "launch_us": avg_launch_s * 1e6, "launches_per_step": launches,
-                        "algorithmic_gflop_per_launch": per_launch_flop / 1e9}
+        kernel, lpf = block_kernel_info(N, model)
+        roofline = block_roofline(kernel, lpf, args.layers, B, S, avg_launch_s, pmc_traffic(args.layers, B, S, not args.unfused, kernel))
+        roofline["launches_in_timed_region"] = launches
         result = {
             "metric": "denoised images/sec (256x256x3) + MAE vs ref, resnet_1x18",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -720,10 +742,15 @@ def main():
                        "blocks": args.layers, "fused_blocks": not args.unfused,
                        "arithmetic": "split-f16 MFMA (f16x3), fp32 accumulate" if h3 else "exact fp32 MFMA",
                        "parallelism": f"replicas x{world}, no collective"},
-            "parity": {"mae_vs_oracle_lsb": float(diff.mean()), "max_abs_lsb": int(diff.max()), "checked_images": 1},
+            "parity": {"mae_vs_oracle_lsb": float(diff.mean()), "max_abs_lsb": int(diff.max()), "checked_images": len(idx)},
             "end_to_end_tflops": value / world * gflop_per_image(args.layers, S, S) / 1e3,
             "roofline": roofline,
         }
+        if rehearse:
+            result["rehearsal"] = True              # ranks shared a GPU over gloo: exercises the launch path, not a measurement
+        if dist is not None:
+            result["world_size_seen"] = int(dist.get_world_size())
+        result["visible_gpus"] = int(torch.cuda.device_count())
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(spec, params, state, noisy_host)
         if world == 1 and not args.no_sub_records and h3 and args.h3_variant is None:

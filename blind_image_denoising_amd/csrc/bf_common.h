@@ -192,6 +192,14 @@ struct FusedH3WArgs {
     int act1_relu;
     const void* zeros;    // >= 64 B of zeros, 16-B aligned (source of rows outside the image)
     unsigned long long* dbg;  // diagnostic builds only (per-wave phase cycle sums), else NULL
+    // last pair of a network with a LINEAR denoiser head of 3 output channels folded into the launch (head_wh != NULL): x2 is
+    // not written; head_out = [round, u8](denormalise(tanh(2 x2 . wh) * 0.51)) cropped to [Ho, Wo] (bfcnn/model.py:297-342,
+    // utilities.py:435-443, 755-764, module_denoiser.py:71-73)
+    const float* head_wh;  // [16][4] premultiplied head_conv0 . head_conv1 (pack_edges_kernel), or NULL
+    void* head_out;        // u8 or f32 [B,Ho,Wo,3]
+    int head_u8, Ho, Wo, denormalize;
+    float v_min, v_max;
+    int* status;           // |= BF_STATUS_F16_RANGE when a block output is not finite; may be NULL
 };
 hipError_t bf_launch_fused_block2_h3w(const FusedH3WArgs& a, hipStream_t s);
 bool       bf_fused_block2_h3w_supports(int H, int W);

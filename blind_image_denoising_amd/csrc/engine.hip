@@ -30,6 +30,9 @@ struct bf_engine {
     int h3_variant = -1;            // split-f16 block kernel: < 0 = library default (bf_set_h3_variant), else that variant
     int h3_compact = 0;             // 1: full-row streaming kernel keeps the activations between the launches in the compact layout
     int h3_pair = 1;                // 1: where the streaming kernel applies, consecutive blocks run two per launch (fused_h3w.hip)
+    int h3_pair_head = 0;           // 1: the last pair launch also runs a linear 3-channel head (no head kernel, the last activation is
+                                    // never written).  Off by default: measured equal (4.437 vs 4.435 ms per batch of 128): the ~250
+                                    // vector instructions per 64 pixels cost the issue-bound launch what the head kernel's pass costs
     int block_launches = 0;         // launches of the last forward's residual blocks (bf_get_timing)
     const char* block_kernel = "";  // name of the kernel that ran most of them
                                     // (fp8 lo planes, 48 B per pixel; bf_common.h): +5 % images/s for 6e-6 instead of 2e-7 normalised MAE
@@ -203,6 +206,7 @@ extern "C" int bf_set_option(bf_handle h, const char* key, int value)
     if (!strcmp(key, "h3_zigzag")) { h->h3_zigzag = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "h3_compact")) { h->h3_compact = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "h3_pair")) { h->h3_pair = value ? 1 : 0; return BF_OK; }
+    if (!strcmp(key, "h3_pair_head")) { h->h3_pair_head = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "fused_head")) { h->fused_head = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_zigzag")) { h->train_zigzag = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_fused_fwd")) { h->train_fused_fwd = value ? 1 : 0; return BF_OK; }
@@ -481,9 +485,12 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
         pair_ok = bf_fused_block_h3_is_streaming(probe) && bf_fused_block2_h3w_supports(H, W);
     }
     int launches = 0, pair_launches = 0;
+    // an odd block count runs its single block FIRST, so that the last launch is a pair and can carry the head
+    const bool head_in_pair = pair_ok && !head_in_block && h->h3_pair_head && d.no_layers >= 2 &&
+                              d.head_activation == BF_ACT_LINEAR && d.out_channels == 3;
     for (int i = 0; i < d.no_layers; ++i) {
         const float* blk = pk + h->k_blocks + i * h->k_block_stride;
-        if (pair_ok && i + 1 < d.no_layers && !(head_in_block && i + 1 == d.no_layers - 1)) {
+        if (pair_ok && i + 1 < d.no_layers && !(head_in_block && i + 1 == d.no_layers - 1) && !(i == 0 && (d.no_layers & 1))) {
             FusedH3WArgs fa;
             memset(&fa, 0, sizeof(fa));
             fa.in = buf[cur]; fa.out = buf[cur ^ 1];
@@ -494,6 +501,10 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
             fa.B = B; fa.H = H; fa.W = W;
             fa.reverse_tiles = h->h3_zigzag ? (launches & 1) : 0;
             fa.act1_relu = d.activation == BF_ACT_RELU; fa.zeros = pk + h->k_zero; fa.dbg = nullptr;
+            if (head_in_pair && i + 2 == d.no_layers) {          // last pair: the linear head rides in its store step
+                fa.head_wh = pk + h->k_wh; fa.head_out = out; fa.head_u8 = out_is_u8; fa.Ho = Hs; fa.Wo = Ws;
+                fa.denormalize = d.denormalize; fa.v_min = d.v_min; fa.v_max = d.v_max; fa.status = status;
+            }
             BF_HIP(bf_launch_fused_block2_h3w(fa, s), "fused_block2_h3w");
             cur ^= 1;
             ++i;
@@ -577,7 +588,7 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
         probe.B = B; probe.H = H; probe.W = W; probe.variant = h->h3_variant;
         h->block_kernel = bf_fused_block_h3_kernel_name(probe);
     } else h->block_kernel = bf_fused_block_kernel_name();
-    if (head_in_block) return BF_OK;
+    if (head_in_block || head_in_pair) return BF_OK;
     HeadArgs ha;
     ha.feat = buf[cur];
     ha.w0 = pk + h->k_w0; ha.w1 = pk + h->k_w1;

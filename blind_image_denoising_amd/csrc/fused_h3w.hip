@@ -68,7 +68,7 @@ struct H3WGeom {
 };
 
 struct H3WTile {
-    int nrows;
+    int nrows, b;                // rows of the band, image index
     size_t img;
     int ybase, ystep;            // image row of band-relative row k: ybase + ystep * k (a reversed band walks bottom-up)
     int X0, X1;                  // output columns [X0, X1)
@@ -88,6 +88,7 @@ __device__ __forceinline__ H3WTile h3w_tile(const FusedH3WArgs& a, const int t)
     const int b = rest / a.tiles_y, ty = rest - b * a.tiles_y;
     const int y0 = ty * a.rows_per_tile;
     r.nrows = min(a.rows_per_tile, a.H - y0);
+    r.b = b;
     r.img = (size_t)b * a.H * a.W * 64;
     r.ybase = a.reverse_tiles ? y0 + r.nrows - 1 : y0;
     r.ystep = a.reverse_tiles ? -1 : 1;
@@ -478,6 +479,81 @@ struct H3WMem<2> {
     __device__ __forceinline__ void finish() {}
 };
 
+// KIND 3, the head storer (last pair of a network, FusedH3WArgs::head_wh): instead of storing the staged row, waves 0 and 1 of the
+// role take one pixel per lane (64 columns each), read its 16 channels (hi + lo: four 16-byte records), multiply by the
+// premultiplied 16 x 3 head matrix and store tanh(2 h) * 0.51 denormalised, cropped, [rounded to uint8]: 3 bytes instead of 64
+// per pixel leave the chip and the head kernel's pass over the activation disappears.
+template <>
+struct H3WMem<3> {
+    using Gm = H3WGeom;
+    const FusedH3WArgs& a;
+    const char* tout;
+    int half;                    // columns [64 half, 64 half + 64) of the strip; >= 2: nothing to do
+    int st_off;                  // lane's byte offset inside plane 0 of a staging slot
+    int col;                     // lane's image column
+    bool okc;
+
+    __device__ __forceinline__ H3WMem(const FusedH3WArgs& a_, char*, const char* tout_, const int rw, const unsigned)
+        : a(a_), tout(tout_), half(rw), st_off(0), col(0), okc(false) {}
+    __device__ __forceinline__ void set_tile(const H3WTile& t, const int lane)
+    {
+        col = t.X0 + 64 * half + lane;
+        okc = (half < 2) & (col < t.X1) & (col < a.Wo);
+        st_off = (col - t.G0) * 16;
+    }
+    __device__ __forceinline__ void prologue(const H3WTile&) {}
+    __device__ __forceinline__ void begin(const H3WTile& t, const int s, const int PH)
+    {
+        const int k = s - Gm::LEAD, oslot = (PH + 1) % Gm::NRO;
+        bool have = (half < 2) & (k >= 0) & (k < t.nrows) & !(H3V_ABLATE & 2);        // wave-uniform
+        if (have) have = t.y(k) < a.Ho;
+        if (!have) return;
+        char* orow = reinterpret_cast<char*>(a.head_out) + ((size_t)t.b * a.Ho + (size_t)t.y(k)) * a.Wo * 3 * (a.head_u8 ? 1 : 4);
+        const char* src = tout + oslot * Gm::OUT_SLOT + st_off;
+        // the whole head sits HERE, in front of the role's step (not behind its first group's MFMAs): no fragment is live yet
+        float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const h8 hi = *reinterpret_cast<const h8*>(src + hf * Gm::OUT_PLANE), lo = *reinterpret_cast<const h8*>(src + (2 + hf) * Gm::OUT_PLANE);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float v = (float)hi[c] + (float)lo[c];
+                const f32x4 w = *reinterpret_cast<const f32x4*>(a.head_wh + (hf * 8 + c) * 4);
+                h0 = fmaf(v, w.x, h0);
+                h1 = fmaf(v, w.y, h1);
+                h2 = fmaf(v, w.z, h2);
+            }
+        }
+        // an activation left the f16 range somewhere in the split-f16 blocks: inf / NaN propagate to here (0 * inf = NaN: a zero
+        // head weight does not hide one)
+        const bool finite = fabsf(h0) <= 3.0e38f && fabsf(h1) <= 3.0e38f && fabsf(h2) <= 3.0e38f;
+        if (!finite && a.status) atomicOr(a.status, BF_STATUS_F16_RANGE);
+        float r[3] = {h0, h1, h2};
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            // tanh(2h) = 1 - 2 / (exp(4h) + 1): a handful of instructions (libm tanhf: ~30)
+            float v = (1.0f - 2.0f / (__expf(4.0f * r[o]) + 1.0f)) * 0.51f;
+            if (a.denormalize) v = (fminf(fmaxf(v, -0.5f), 0.5f) + 0.5f) * (a.v_max - a.v_min) + a.v_min;
+            r[o] = v;
+        }
+        if (!okc) return;
+        if (a.head_u8) {
+            unsigned char* p = reinterpret_cast<unsigned char*>(orow) + (size_t)col * 3;
+#pragma unroll
+            for (int o = 0; o < 3; ++o) p[o] = (unsigned char)fminf(fmaxf(rintf(r[o]), 0.f), 255.f);      // rintf = round-half-even
+        } else {
+            float* p = reinterpret_cast<float*>(orow) + (size_t)col * 3;
+#pragma unroll
+            for (int o = 0; o < 3; ++o) p[o] = r[o];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void after_first_group() {}
+    __device__ __forceinline__ void end() {}
+    __device__ __forceinline__ void finish() {}
+};
+
+template <bool HEAD>
 __global__ __launch_bounds__(H3WGeom::NT, 3) void fused_block2_h3w_kernel(FusedH3WArgs a)
 {
     using Gm = H3WGeom;
@@ -542,7 +618,7 @@ __global__ __launch_bounds__(H3WGeom::NT, 3) void fused_block2_h3w_kernel(FusedH
         H3WRoleA<Gm::X0_PLANE> R;
         R.tin = tx0; R.tmid = tm1;
         R.init(a.w1r[0], a, a.aux[0], lane, gc0);
-        H3WMem<h3w_mem_kind(0)> M(a, tx0, tout, rw, plane_g);
+        H3WMem<(HEAD && h3w_mem_kind(0) == 2) ? 3 : h3w_mem_kind(0)> M(a, tx0, tout, rw, plane_g);
         __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));               // weight / scale loads
 #define H3W_ACTIVE(s) ((s) < t.nrows + 8)
 #define H3W_STEP(PH) R.template step<PH>(slot5 * Gm::PITCH, (s >= 2) & H3W_ROW_IN_IMAGE(s - 5), M)
@@ -555,7 +631,7 @@ __global__ __launch_bounds__(H3WGeom::NT, 3) void fused_block2_h3w_kernel(FusedH
         H3WRoleB<Gm::X0_PLANE, Gm::X1_PLANE> R;
         R.tmid = tm1; R.tres = tx0; R.tout = tx1;
         R.init(a.w2r[0], a, a.aux[0], lane, gc0, true);
-        H3WMem<h3w_mem_kind(1)> M(a, tx0, tout, rw, plane_g);
+        H3WMem<(HEAD && h3w_mem_kind(1) == 2) ? 3 : h3w_mem_kind(1)> M(a, tx0, tout, rw, plane_g);
         __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));
 #define H3W_ACTIVE(s) (((s) >= 3) & ((s) < t.nrows + 9))
 #define H3W_STEP(PH) R.template step<PH>(h3v_wrap(slot5 + Gm::NRX0 - 1, Gm::NRX0) * Gm::PITCH, (PH % Gm::NRX1) * Gm::PITCH, H3W_ROW_IN_IMAGE(s - 7), M)
@@ -568,7 +644,7 @@ __global__ __launch_bounds__(H3WGeom::NT, 3) void fused_block2_h3w_kernel(FusedH
         H3WRoleA<Gm::X1_PLANE> R;
         R.tin = tx1; R.tmid = tm2;
         R.init(a.w1r[1], a, a.aux[1], lane, gc0);
-        H3WMem<h3w_mem_kind(2)> M(a, tx0, tout, rw, plane_g);
+        H3WMem<(HEAD && h3w_mem_kind(2) == 2) ? 3 : h3w_mem_kind(2)> M(a, tx0, tout, rw, plane_g);
         __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));
 #define H3W_ACTIVE(s) (((s) >= 6) & ((s) < t.nrows + 10))
 #define H3W_STEP(PH) R.template step<PH>(((PH + 2) % Gm::NRX1) * Gm::PITCH, H3W_ROW_IN_IMAGE(s - 9), M)
@@ -581,7 +657,7 @@ __global__ __launch_bounds__(H3WGeom::NT, 3) void fused_block2_h3w_kernel(FusedH
         H3WRoleB<Gm::X1_PLANE, Gm::OUT_PLANE> R;
         R.tmid = tm2; R.tres = tx1; R.tout = tout;
         R.init(a.w2r[1], a, a.aux[1], lane, gc0, false);
-        H3WMem<h3w_mem_kind(3)> M(a, tx0, tout, rw, plane_g);
+        H3WMem<(HEAD && h3w_mem_kind(3) == 2) ? 3 : h3w_mem_kind(3)> M(a, tx0, tout, rw, plane_g);
         __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));
 #define H3W_ACTIVE(s) (((s) >= 9) & ((s) < t.nrows + 11))
 #define H3W_STEP(PH) R.template step<PH>(((PH + 1) % Gm::NRX1) * Gm::PITCH, (PH % Gm::NRO) * Gm::OUT_SLOT, true, M)
@@ -631,7 +707,7 @@ hipError_t bf_launch_fused_block2_h3w(const FusedH3WArgs& args, hipStream_t s)
 {
     using Gm = H3WGeom;
     FusedH3WArgs a = args;
-    if (!a.zeros || !a.in || !a.out || !bf_fused_block2_h3w_supports(a.H, a.W)) return hipErrorInvalidValue;
+    if (!a.zeros || !a.in || (!a.out && !a.head_wh) || !bf_fused_block2_h3w_supports(a.H, a.W)) return hipErrorInvalidValue;
     if ((int64_t)a.H * a.W * 64 >= ((int64_t)1 << 32)) return hipErrorInvalidValue;      // 32-bit in-image offsets
     const int cus = 256;
     a.nstrips = h3w_nstrips(a.W);
@@ -639,7 +715,8 @@ hipError_t bf_launch_fused_block2_h3w(const FusedH3WArgs& args, hipStream_t s)
     a.tiles_y = (a.H + a.rows_per_tile - 1) / a.rows_per_tile;
     a.ntiles = a.B * a.tiles_y * a.nstrips;
     const int grid = a.ntiles < cus ? a.ntiles : cus;
-    void (*kernel)(FusedH3WArgs) = fused_block2_h3w_kernel;
+    if (a.head_wh && (!a.head_out || a.Ho < 1 || a.Wo < 1 || a.Ho > a.H || a.Wo > a.W)) return hipErrorInvalidValue;
+    void (*kernel)(FusedH3WArgs) = a.head_wh ? fused_block2_h3w_kernel<true> : fused_block2_h3w_kernel<false>;
     const hipError_t e = bf_set_max_lds(reinterpret_cast<const void*>(kernel), Gm::LDS_BYTES);      // once per device
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(Gm::NT), Gm::LDS_BYTES, s, a);

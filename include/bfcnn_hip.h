@@ -519,6 +519,10 @@ int bf_op_axpy(float* y, const float* x, float a, int overwrite, int64_t n, void
  * "fused_head" = 1: with split-f16 blocks, a linear denoiser head and 3 output channels, the head (premultiplied 16 x 3
  *   matrix, tanh, denormalise, rounding) runs in the epilogue of the last block: no head kernel, the last block output is
  *   never written; 0 (default): separate head kernel (the two measure within 0.5 % of each other).
+ * "h3_pair": 1 (default): wherever the full-row streaming kernel applies, consecutive residual blocks run TWO per launch
+ *   (fused_block2_h3w_kernel: the activation between them stays in LDS; an odd block count runs its single block first); 0: one
+ *   block per launch.  "h3_pair_head": 1: the last pair launch also runs a linear 3-channel head in its store step (no head
+ *   kernel); 0 (default; the two measure the same).
  * "fused_tile" / "h3_variant": kernel variants of the fused blocks (A/B only; negative = default). */
 int bf_set_option(bf_handle h, const char* key, int value);
 

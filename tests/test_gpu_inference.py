@@ -110,6 +110,49 @@ def test_head_folded_into_the_last_block(hw, no_layers):
     assert np.abs(bf.DenoiserModule(m)(noisy).astype(int) - O.denoiser_module_call(spec, params, state, noisy).astype(int)).max() <= 1
 
 
+@pytest.mark.parametrize("hw", [(64, 64), (40, 256), (17, 23), (33, 144), (20, 150), (12, 200)])
+@pytest.mark.parametrize("no_layers", [2, 3, 6])
+@pytest.mark.parametrize("pair_head", [0, 1])
+def test_two_blocks_per_launch(hw, no_layers, pair_head):
+    """h3_pair (default on wherever the full-row streaming kernel runs; forced here with h3_variant = 4 at small sizes): consecutive
+    residual blocks run two per launch (fused_block2_h3w_kernel), an odd count runs its single block first; with h3_pair_head the
+    last pair launch also carries the linear head (u8 and f32 outputs, ragged sizes, virtual power-of-two padding, crop).  Same
+    oracle, same bars as one block per launch, and the two schedules agree with each other to the last bit of the u8 output
+    except where a value sits on a rounding boundary."""
+    cfg, spec, params, state, m = _model(no_layers, seed=21)
+    m.set_option("h3_variant", 4)
+    m.set_option("h3_pair_head", pair_head)
+    _, noisy = O.synthetic_batch(3, hw[0], hw[1], seed=hw[0] + 3 * hw[1])
+    ref8 = O.denoiser_module_call(spec, params, state, noisy)
+    got = bf.DenoiserModule(m)(noisy)
+    _check_u8(got, ref8)
+    _check_f32(bf.DenoiserModule(m, cast_to_uint8=False)(noisy), O.denoiser_module_call(spec, params, state, noisy, cast_to_uint8=False))
+    m.set_option("h3_pair", 0)
+    one = bf.DenoiserModule(m)(noisy)
+    _check_u8(one, ref8)
+    assert np.abs(one.astype(int) - got.astype(int)).max() <= 1
+    m.set_option("h3_pair", 1)
+    m.set_option("h3_pair_head", 0)
+    m.set_option("h3_variant", -1)
+
+
+def test_two_blocks_per_launch_status_word_with_the_head_in_the_launch():
+    """activations beyond the f16 range must still reach the status word when the head runs inside the last pair launch"""
+    cfg, spec, params, state, m = _model(2, seed=5)
+    big = params.copy()
+    off = spec.offsets()
+    for name in ("base/kernel", "block0/conv0/kernel"):
+        o, shape = off[name]
+        big[o:o + int(np.prod(shape))] *= 3000.0
+    m.set_weights(big, state)
+    m.set_option("h3_variant", 4)
+    m.set_option("h3_pair_head", 1)
+    m.auto_exact_fallback = False
+    _, noisy = O.synthetic_batch(2, 64, 64, seed=3)
+    with pytest.raises(FloatingPointError):
+        bf.DenoiserModule(m)(noisy)
+
+
 def test_denoiser_module_device_tensors_and_float_output():
     cfg, spec, params, state, m = _model(1, seed=9)
     _, noisy = O.synthetic_batch(2, 24, 40, seed=1)
