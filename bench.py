@@ -477,7 +477,8 @@ def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
             "last_total_loss": float(total.item()),
             "end_to_end_tflops": value / world * per_px * S * S / 1e12,
             "roofline": {"bound": "hbm", "kernel": "bwd3x3_h3_kernel<true, 8> (+ reduce_partials_kernel)", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": wbytes,
+                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(args.layers, B, S, True, "bwd3x3_h3_kernel<true, 8>"), "algorithmic_bytes_per_launch": wbytes,
                          "launch_us": launch_us, "launches_of_this_kernel_per_step": args.layers}}
         if world == 1 and not args.no_cpu_baseline:
             # the oracle's training step (fp64 NumPy restatement) on ONE image of the same shape

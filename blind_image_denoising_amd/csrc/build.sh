@@ -27,5 +27,6 @@ for p in "${pids[@]}"; do wait "$p" || fail=1; done
 [ "$fail" -eq 0 ] || { echo "compilation failed" >&2; exit 1; }
 objs=()
 for u in "${units[@]}"; do objs+=("$obj/$u.o"); done
+printf '%s\n' "${units[@]}" > "$obj/.units"          # tools/ablate_unit.sh links exactly these objects (never a stale one)
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -ldl -o "$out/$name"
 echo "built $out/$name"

@@ -71,6 +71,7 @@ extern "C" const char* bf_comm_last_error(void) { return g_comm_error[0] ? g_com
 // rank 0 makes the 128-byte rendezvous id and hands it to the other ranks by any host channel (file, socket, MPI, ...)
 extern "C" int bf_comm_unique_id(char id_out[128])
 {
+    g_comm_error[0] = 0;                       // bf_comm_last_error reports THIS call
     Rccl& r = rccl();
     if (!id_out) return BF_EINVAL;
     if (!r.lib) return BF_EUNSUPPORTED;
@@ -84,6 +85,7 @@ extern "C" int bf_comm_unique_id(char id_out[128])
 // one communicator per process / GPU: call with that GPU current (hipSetDevice); collective over all `world` ranks
 extern "C" int bf_comm_init_rank(void** comm_out, int world, int rank, const char id[128])
 {
+    g_comm_error[0] = 0;                       // bf_comm_last_error reports THIS call
     Rccl& r = rccl();
     if (!comm_out || !id || world <= 0 || rank < 0 || rank >= world) return BF_EINVAL;
     if (!r.lib) return BF_EUNSUPPORTED;
@@ -98,6 +100,7 @@ extern "C" int bf_comm_init_rank(void** comm_out, int world, int rank, const cha
 
 extern "C" int bf_comm_destroy(void* comm)
 {
+    g_comm_error[0] = 0;                       // bf_comm_last_error reports THIS call
     Rccl& r = rccl();
     if (!comm) return BF_OK;
     if (!r.lib) return BF_EUNSUPPORTED;
@@ -110,6 +113,7 @@ extern "C" int bf_comm_destroy(void* comm)
 extern "C" int bf_allreduce_grads(bf_handle h, float* grads, int64_t n, void* comm, void* stream)
 {
     (void)h;
+    g_comm_error[0] = 0;
     Rccl& r = rccl();
     if (!grads || n <= 0 || !comm) return BF_EINVAL;
     if (!r.lib) return BF_EUNSUPPORTED;

@@ -6,30 +6,45 @@ from .constants import DENOISER_STR
 
 
 class _DeferredStatus:
-    """The f16-range status word of a call that handed back DEVICE tensors: copied to pinned host memory behind that call
-    (stream-ordered, nothing synchronises) and looked at when the next call starts or when the caller asks.  Host-array
-    calls do not need it: they synchronise anyway and check at once."""
+    """The f16-range status words of calls that handed back DEVICE tensors: each is copied to its own pinned host slot behind its
+    call (stream-ordered, nothing synchronises) and looked at when a later call starts or when the caller asks.  The engine clears
+    the device word at the start of every forward, so one shared slot would only ever show the LAST call of a pipelined loop
+    (the host runs ahead of the GPU: the earlier events are not complete when the next call polls); here every call keeps its
+    slot until it has been read, and a slot about to be reused is waited for first.  Host-array calls do not need any of this:
+    they synchronise anyway and check at once."""
+    SLOTS = 16
 
     def __init__(self):
-        self.host, self.event = None, None
+        self.host, self.pending, self.free, self.carried = None, [], [], 0
 
     def post(self, status_dev: torch.Tensor):
         if self.host is None:
-            self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        self.host.copy_(status_dev, non_blocking=True)
-        self.event = torch.cuda.Event()
-        self.event.record(torch.cuda.current_stream(status_dev.device))
+            self.host = torch.zeros(self.SLOTS, dtype=torch.int32).pin_memory()
+            self.free = list(range(self.SLOTS))
+        if not self.free:                                   # every slot is waiting to be read: read the oldest now
+            slot, event = self.pending.pop(0)
+            event.synchronize()
+            self.carried |= int(self.host[slot])
+            self.free.append(slot)
+        slot = self.free.pop(0)
+        self.host[slot:slot + 1].copy_(status_dev.reshape(-1)[:1], non_blocking=True)
+        event = torch.cuda.Event()
+        event.record(torch.cuda.current_stream(status_dev.device))
+        self.pending.append((slot, event))
 
     def poll(self, wait: bool = False) -> int:
-        """status of the posted call if it is known (0 when nothing is pending or the copy has not finished yet)."""
-        if self.event is None:
-            return 0
-        if wait:
-            self.event.synchronize()
-        elif not self.event.query():
-            return 0
-        self.event = None
-        return int(self.host[0])
+        """OR of the status words of every posted call that is known by now (all of them with wait=True); each is reported once."""
+        status, self.carried = self.carried, 0
+        while self.pending:
+            slot, event = self.pending[0]
+            if wait:
+                event.synchronize()
+            elif not event.query():
+                break                                       # completion is in stream order: the later ones are not done either
+            self.pending.pop(0)
+            status |= int(self.host[slot])
+            self.free.append(slot)
+        return status
 
 
 class DenoiserModule:

@@ -230,18 +230,35 @@ class NativeCommunicator:
             buf = C.create_string_buffer(128)
             N.check(lib.bf_comm_unique_id(buf), None, "bf_comm_unique_id")
             box[0] = buf.raw
-        dist.broadcast_object_list(box, src=0, group=group)
+        # `src` of a torch broadcast is a GLOBAL rank: the group's rank 0 is not global rank 0 in a sub-group
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast_object_list(box, src=src, group=group)
         comm = C.c_void_p()
         with torch.cuda.device(device):
             rc = lib.bf_comm_init_rank(C.byref(comm), self.world, self.rank, box[0])
         if rc != N.BF_OK:
             raise RuntimeError(f"bf_comm_init_rank: {lib.bf_comm_last_error().decode()}")
         self._comm, self._lib = comm, lib
+        # the collective runs on its OWN stream, ordered against the compute stream by events, so that whatever the caller queues
+        # on the compute stream between launch() and wait() really overlaps with it
+        self._stream = torch.cuda.Stream(device=device)
 
-    def allreduce(self, grads: torch.Tensor):
-        rc = self._lib.bf_allreduce_grads(None, N.ptr(grads), grads.numel(), self._comm, N.stream_ptr(grads))
+    def launch(self, grads: torch.Tensor):
+        """all-reduce of `grads` on the communicator's stream, behind everything the compute stream has queued so far"""
+        cur = torch.cuda.current_stream(grads.device)
+        self._stream.wait_stream(cur)
+        rc = self._lib.bf_allreduce_grads(None, N.ptr(grads), grads.numel(), self._comm, self._stream.cuda_stream)
         if rc != N.BF_OK:
             raise RuntimeError(f"bf_allreduce_grads: {self._lib.bf_comm_last_error().decode()}")
+        grads.record_stream(self._stream)
+
+    def wait(self, grads: torch.Tensor):
+        """the compute stream waits (stream-ordered, no host block) for the all-reduce launch() started"""
+        torch.cuda.current_stream(grads.device).wait_stream(self._stream)
+
+    def allreduce(self, grads: torch.Tensor):
+        self.launch(grads)
+        self.wait(grads)
 
     def close(self):
         if self._comm:
@@ -269,17 +286,29 @@ class DataParallelTrainer:
         import torch.distributed as dist
         if self.world_size > 1:
             dist.broadcast(self.model.params, src=src, group=self.group)
-            dist.broadcast(self.model.state, src=src, group=self.group)
+            state = getattr(self.model, "state", None)      # BatchNorm statistics: unet_laplacian graphs have none
+            if state is not None and state.numel() > 0:
+                dist.broadcast(state, src=src, group=self.group)
             self.model.mark_dirty()
 
-    def step(self, gt_shard: torch.Tensor, noisy_shard: torch.Tensor, depth_weight: float = 1.0, overlap: Optional[Callable] = None):
+    def _depth_weights(self, depth_weight):
+        """a scalar stands for every output scale of a multi-output (unet_laplacian) model; a sequence is passed through"""
+        if isinstance(depth_weight, (tuple, list)):
+            return tuple(float(v) for v in depth_weight)
+        n = int(getattr(self.model, "depth", 1)) if getattr(self.model, "multi_output", False) else 1
+        return (float(depth_weight),) * n
+
+    def step(self, gt_shard: torch.Tensor, noisy_shard: torch.Tensor, depth_weight=1.0, overlap: Optional[Callable] = None):
+        """one data-parallel step on this rank's shard.  Always returns (total, model_loss, denoiser_loss, predictions, side):
+        side = overlap()'s result, None without an overlap function."""
         total, model_loss, denoiser_loss, predictions, grads = self.fns.train_step_single_gpu(
-            gt_shard, noisy_shard, (depth_weight,), 0.0, None)
+            gt_shard, noisy_shard, self._depth_weights(depth_weight), 0.0, None)
         side = None
         if self.comm is not None:
-            self.comm.allreduce(grads)      # stream-ordered on the compute stream (RCCL kernel); `overlap` queues behind it
+            self.comm.launch(grads)         # RCCL kernel on the communicator's own stream, behind the backward pass
             if overlap is not None:
-                side = overlap()
+                side = overlap()            # runs on the compute stream while the all-reduce is in flight
+            self.comm.wait(grads)           # stream-ordered: no host block, the Adam kernels queue behind it
         else:
             work = allreduce_gradients(grads, self.group, async_op=True)
             if overlap is not None:
@@ -287,9 +316,7 @@ class DataParallelTrainer:
             if work is not None:
                 work.wait()                 # stream-ordered on RCCL: no host block, the Adam kernels queue behind it
         self.fns.apply_grads(self.optimizer, grads, None, grad_scale=1.0 / self.world_size)
-        if overlap is not None:
-            return total, model_loss, denoiser_loss, predictions, side
-        return total, model_loss, denoiser_loss, predictions
+        return total, model_loss, denoiser_loss, predictions, side
 
 
 # ---- outer loop --------------------------------------------------------------------------------
@@ -349,7 +376,8 @@ def _train_loop(pipeline_config_path, model_dir: str, dataset: Iterable = None, 
     accumulated = torch.empty(model.n_params, dtype=torch.float32, device=model.device)
     history = []
     finished = 0 < total_steps <= ckpt.step          # a restored run may already be complete
-    while not finished and ckpt.epoch < epochs:
+    # bfcnn/train_loop.py:359: epochs == -1 trains until total_steps
+    while not finished and (epochs == -1 or ckpt.epoch < epochs):
         counter = 0
         t0 = time.time()
         if epochs > 0:                               # train_loop.py:366-371

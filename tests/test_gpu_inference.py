@@ -310,6 +310,38 @@ def test_f16_range_guard():
     _check_f32(m(x), O.hydra_forward(spec, params, state, x.astype(np.float64)))    # status word is cleared by the next forward
 
 
+def test_device_tensor_calls_in_a_pipelined_loop_do_not_lose_an_overflow():
+    """device tensors in, device tensors out, nothing synchronises: the status word of EVERY call must be seen (the engine clears
+    the device word at the start of each forward, and the host runs ahead of the GPU), also when a clean call follows the bad one."""
+    cfg, spec, params, state, m = _model(3, seed=9)
+    big = params.copy()
+    off = spec.offsets()
+    for name in ("base/kernel", "block0/conv0/kernel"):
+        o, shape = off[name]
+        big[o:o + int(np.prod(shape))] *= 3000.0
+    m.auto_exact_fallback = False
+    _, noisy = O.synthetic_batch(4, 64, 64, seed=4)
+    t = torch.from_numpy(noisy).cuda()
+    mod = bf.DenoiserModule(m)
+    m.set_weights(big, state)
+    mod(t)                                            # overflows
+    m.set_weights(params, state)
+    raised, out = 0, None
+    for _ in range(24):                               # clean calls queue behind it (more than the status slots)
+        try:
+            out = mod(t)                              # a call looks at the words that have arrived by now: may raise here ...
+        except FloatingPointError:
+            raised += 1
+    try:
+        mod.check_status(wait=True)                   # ... or here, at the latest
+    except FloatingPointError:
+        raised += 1
+    assert raised == 1                                # seen, and reported once
+    assert mod.check_status(wait=True)
+    ref = O.denoiser_module_call(spec, params, state, noisy)
+    _check_u8(mod(t).cpu().numpy(), ref)
+
+
 def test_errors_surface_as_python_exceptions():
     cfg, spec, params, state, m = _model(1)
     with pytest.raises(ValueError):

@@ -9,8 +9,10 @@ src=blind_image_denoising_amd/csrc
 obj=blind_image_denoising_amd/lib/obj
 out=blind_image_denoising_amd/lib/variants
 mkdir -p "$out"
+# the unit list csrc/build.sh wrote with its last build: an object left behind by a renamed or removed unit is never linked
+[ -f "$obj/.units" ] || { echo "run blind_image_denoising_amd/csrc/build.sh first ($obj/.units is missing)" >&2; exit 1; }
 others=()
-for o in "$obj"/*.o; do [ "$(basename "$o")" = "$unit.o" ] || others+=("$o"); done
+while IFS= read -r u; do [ "$u" = "$unit" ] || others+=("$obj/$u.o"); done < "$obj/.units"
 pids=()
 for v in "$@"; do
     (
