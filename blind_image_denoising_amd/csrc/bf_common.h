@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include "../../include/bfcnn_hip.h"
+#include "../../include/bfcnn_hip_debug.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

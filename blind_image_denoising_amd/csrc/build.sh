@@ -14,7 +14,7 @@ units=(conv3x3_c16 fused_h3 fused_h3v fused_h3w train_bwd_h3 edge_layers train_o
 # incremental: a unit is recompiled when its source, any header or the flag set is newer than / differs from its object
 flags_sig="$*"
 [ -f "$obj/.flags" ] && [ "$(cat "$obj/.flags")" = "$flags_sig" ] || { rm -f "$obj"/*.o; printf '%s' "$flags_sig" > "$obj/.flags"; }
-newest_hdr="$(ls -t "$here"/*.h "$here/../../include/bfcnn_hip.h" "${BASH_SOURCE[0]}" | head -1)"
+newest_hdr="$(ls -t "$here"/*.h "$here/../../include/bfcnn_hip.h" "$here/../../include/bfcnn_hip_debug.h" "${BASH_SOURCE[0]}" | head -1)"
 pids=()
 for u in "${units[@]}"; do
     if [ -f "$obj/$u.o" ] && [ "$obj/$u.o" -nt "$here/$u.hip" ] && [ "$obj/$u.o" -nt "$newest_hdr" ]; then continue; fi

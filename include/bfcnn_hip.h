@@ -537,51 +537,9 @@ int bf_get_timing(bf_handle h, float* ms, int* launches);
  * traffic up by.  The string is static storage. */
 const char* bf_get_block_kernel(bf_handle h, int* launches_per_forward);
 
-/* single 3x3 16->16 convolution with epilogue flags (1 relu, 2 affine, 4 residual, 8 mask,
- * 16 stats); transpose_flip = 1 runs the data-gradient form.  wpack_scratch = 2*2304 + 64 floats. */
-int bf_debug_conv3x3(const float* in, const float* w_hwio, float* out, const float* scale, const float* shift,
-                     const float* res, const float* mask, float* stats, float* wpack_scratch,
-                     int batch, int height, int width, int epi, int transpose_flip, void* stream);
-int bf_debug_conv3x3_grid(int batch, int height, int width);
-int bf_debug_fused_block(const float* in, const float* w1_hwio, const float* w2_hwio, const float* scale,
-                         const float* shift, float* out, float* wpack_scratch,
-                         int batch, int height, int width, int act1_relu, void* stream);
-/* the split-f16 fused block on fp32 NHWC tensors (converts in and out); scratch = the float count below */
-int64_t bf_debug_fused_block_h3_scratch_floats(int batch, int height, int width);
-int bf_debug_fused_block_h3(const float* in, const float* w1_hwio, const float* w2_hwio, const float* scale,
-                            const float* shift, float* out, float* scratch,
-                            int batch, int height, int width, int act1_relu, void* stream);
-/* two consecutive split-f16 fused blocks in ONE launch (fused_block2_h3w_kernel) on fp32 NHWC tensors: w_hwio = [4][3][3][16][16]
-   (conv1 and conv2 of block a, then of block b), scale / shift = [2][16]; reverse = 1 walks the bands bottom-up */
-int64_t bf_debug_fused_block2_h3_scratch_floats(int batch, int height, int width);
-int bf_debug_fused_block2_h3(const float* in, const float* w_hwio, const float* scale, const float* shift, float* out,
-                             float* scratch, int batch, int height, int width, int act1_relu, int reverse, void* stream);
-/* kernel the handle-less entry above launches (a handle's own choice is bf_set_option "h3_variant"): 4 full-row streaming
-   (falls back to 1 beyond 256 columns), 1 row-streaming tiles, 0 / 2 / 3 earlier tile kernels; < 0 = library default */
-int bf_debug_set_h3_variant(int variant);
-int64_t bf_debug_conv3x3_h3_scratch_floats(void);
-int bf_debug_conv3x3_h3(const float* in, const float* w_hwio, float* out, const float* res, const float* mask, float* stats,
-                        float* scratch, int batch, int height, int width, int epi, int transpose_flip, void* stream);
-int64_t bf_debug_wgrad_partial_floats(int batch, int height, int width);
-int bf_debug_wgrad3x3(const float* x, const float* dy, float* partial, float* dw,
-                      int batch, int height, int width, void* stream);
-int bf_debug_wgrad3x3_h3(const float* x, const float* dy, float* partial, float* dw,
-                         int batch, int height, int width, void* stream);
-/* split-f16 training kernels of bf_train_step, one at a time (tests, bench.py's live roofline):
-   conv3x3_h3 with the BatchNorm apply + skip Add of the block in front formed on load (y = in + pre_scale * pre_c + pre_shift
-   -> pre_out; out = [relu] conv(y)); and the fused backward of one convolution: dw = x^T g', dx = dgrad(g') [* (x > 0) with
-   epi 8 | + res with epi 4 | + sums of dx and dx * bnc with epi 4 + 32], g' = coef[0:16] * g + coef[16:32] * c + coef[32:48]
-   when coef is not NULL (the BatchNorm backward of bfcnn/backbone_blocks.py:214-240's BatchNormalization). */
-int bf_debug_conv3x3_h3_pre(const float* in, const float* pre_c, const float* pre_scale, const float* pre_shift, float* pre_out,
-                            const float* w_hwio, float* out, float* scratch, int batch, int height, int width, int relu,
-                            int reverse, void* stream);
-int64_t bf_debug_bwd3x3_h3_scratch_floats(int batch, int height, int width);
-int bf_debug_bwd3x3_h3_grid(int batch, int height, int width);
-int bf_debug_bwd3x3_h3_grid_ex(int batch, int height, int width, int dbuf);    /* partial rows written; `reverse` bit 1 of the call below = dbuf */
-int bf_debug_bwd3x3_h3(const float* x, const float* g, const float* c, const float* coef, const float* w_hwio, float* out,
-                       const float* res, const float* bnc, float* dw, float* stats, float* scratch, int batch, int height,
-                       int width, int epi, int reverse, int repack, void* stream);
-int bf_debug_mfma_probe(const float* a, const float* b, float* d, void* stream);
+/* The single-kernel diagnostic entries (bf_debug_*: one kernel at a time on fp32 NHWC tensors, used by the parity tests, the
+ * profiling tools and bench.py's live roofline of the training kernel) are declared in bfcnn_hip_debug.h; they are exported by
+ * the same library and are not part of the drop-in ABI above. */
 
 #ifdef __cplusplus
 }

@@ -613,16 +613,71 @@ def model_loss(spec: ResnetSpec, ls: LossSpec, params, dtype=F64) -> Dict[str, f
     return {"regularization_loss": reg, "total_loss": reg * ls.regularization}
 
 
+def _relu_sites(spec: ResnetSpec, C):
+    """(name, pre-activation array) of every ReLU-type gate of a training forward's cache, in a fixed order"""
+    sites = []
+    if spec.base_activation in ("relu", "leaky_relu"):
+        sites.append(("base", C["base_pre"]))
+    for i, blk in enumerate(C["blocks"]):
+        for j, ent in enumerate(blk["convs"]):
+            if ent["act"] in ("relu", "leaky_relu"):
+                sites.append((f"block{i}/conv{j}", ent["pre_act"]))
+    if spec.head_activation in ("relu", "leaky_relu"):
+        sites.append(("head0", C["h0p"]))
+    return sites
+
+
+def training_step_ties(spec: ResnetSpec, ls: LossSpec, params, state, gt, noisy, rel: float = 2e-6, dtype=F64):
+    """Elements of a training step that sit within fp32 rounding of a KINK of the graph (test infrastructure for the GPU parity
+    tests: where fp32 and fp64 may legitimately take different sides).  A kink is a point where the backward pass is discontinuous:
+    a ReLU gate (pre-activation 0; backbone_blocks.py:174-213 activations), the L1 / RMSE hinge and cutoff thresholds on
+    |gt - prediction| (loss.py:40-65: keras relu with threshold / max_value), the denormaliser's clip at +-0.5
+    (utilities.py:435-443).  An element counts when its distance to the kink is below `rel` times the largest magnitude of its
+    tensor (pre-activations: sums of O(100) fp32 products) or 4 fp32 ulps of the prediction (thresholds on the 0..255 scale).
+    Returns a list of (site, flat_index, margin)."""
+    pred, _, C = hydra_forward(spec, params, state, noisy, training=True, dtype=dtype, want_cache=True)
+    ties = []
+    for name, pre in _relu_sites(spec, C):
+        tol = rel * max(float(np.abs(pre).max()), 1e-30)
+        for idx in np.flatnonzero(np.abs(pre) < tol):
+            ties.append((name, int(idx), float(abs(pre.ravel()[idx]))))
+    a = np.abs(gt.astype(dtype) - pred)
+    ulp4 = 4 * np.spacing(np.maximum(np.abs(pred), 1.0).astype(np.float32)).astype(dtype)
+    for name, thr in (("hinge", ls.hinge), ("cutoff", ls.cutoff)):
+        if ls.mae_multiplier > 0 or ls.mse_multiplier > 0:
+            for idx in np.flatnonzero(np.abs(a - thr) < ulp4):
+                ties.append((name, int(idx), float(abs(a.ravel()[idx] - thr))))
+    if spec.denormalize:
+        p = C["p"]
+        for idx in np.flatnonzero(np.abs(np.abs(p) - 0.5) < 4 * 6e-8):
+            ties.append(("clip", int(idx), float(abs(abs(p.ravel()[idx]) - 0.5))))
+    return ties
+
+
 def train_step_single_gpu(spec: ResnetSpec, ls: LossSpec, params, state, gt, noisy,
-                          depth_weight: float = 1.0, dtype=F64):
+                          depth_weight: float = 1.0, dtype=F64, flips=None):
     """bfcnn/train_loop.py:259-312 for a single-output model: training-mode forward,
     denoiser loss * depth_weight[0] + model loss, gradients w.r.t. every trainable
     variable.  Returns (total_loss, model_loss, [denoiser_loss], predictions, grads_flat,
-    new_state_flat)."""
+    new_state_flat).
+    flips (tests only): entries of training_step_ties whose gate the BACKWARD pass takes on the other side -- what an fp32
+    evaluation may do with an element that sits within rounding of the kink (the forward values are left as they are: the two
+    sides differ by less than the tie tolerance there)."""
     P = _views(spec, params, dtype)
     pred, new_state, C = hydra_forward(spec, params, state, noisy, training=True, dtype=dtype,
                                        want_cache=True)
     gt = gt.astype(dtype)
+    flip_mask = {}
+    if flips:
+        sites = dict(_relu_sites(spec, C))
+        for name, idx, _ in flips:
+            if name in sites:                       # the gate reads the sign of the cached pre-activation: invert it
+                v = sites[name].ravel()
+                v[idx] = -v[idx] if v[idx] != 0 else 1e-300
+            else:
+                flip_mask.setdefault(name, np.zeros(pred.size, bool))[idx] = True
+    def _flipped(mask, name):
+        return mask ^ flip_mask[name].reshape(mask.shape) if name in flip_mask else mask
     dl = denoiser_loss(ls, gt, pred)
     ml = model_loss(spec, ls, params, dtype)
     total = dl["total_loss"] * depth_weight + ml["total_loss"]
@@ -631,11 +686,11 @@ def train_step_single_gpu(spec: ResnetSpec, ls: LossSpec, params, state, gt, noi
     n_el = pred.size
     err = gt - pred
     a = np.abs(err)
-    dpred = np.where((a > ls.hinge) & (a < ls.cutoff), -np.sign(err), 0.0) \
+    dpred = np.where(_flipped(a > ls.hinge, "hinge") & _flipped(a < ls.cutoff, "cutoff"), -np.sign(err), 0.0) \
         * (ls.mae_multiplier * depth_weight / n_el) if ls.mae_multiplier > 0 else np.zeros_like(pred)
     if ls.mse_multiplier > 0:          # d/dpred of mean_b sqrt(mean(d^2) + eps), d = relu(gt - pred, hinge, cutoff^2)
         d = keras_relu(err, ls.hinge, ls.cutoff * ls.cutoff)
-        live = (err > ls.hinge) & (err < ls.cutoff * ls.cutoff)
+        live = _flipped(err > ls.hinge, "hinge") & (err < ls.cutoff * ls.cutoff)
         per_image = d[0].size
         rm = np.sqrt((d * d).mean(axis=(1, 2, 3)) + DEFAULT_EPSILON)
         dpred = dpred - (ls.mse_multiplier * depth_weight / (pred.shape[0] * per_image)) * (d * live) / rm[:, None, None, None]
@@ -643,7 +698,7 @@ def train_step_single_gpu(spec: ResnetSpec, ls: LossSpec, params, state, gt, noi
         dpred = dpred - (ls.ssim_multiplier * depth_weight) * ssim_mean_and_grad(gt, pred)[1]
     if spec.denormalize:
         p = C["p"]
-        dp = dpred * (spec.v_max - spec.v_min) * ((p >= -0.5) & (p <= 0.5))
+        dp = dpred * (spec.v_max - spec.v_min) * _flipped((p >= -0.5) & (p <= 0.5), "clip")
     else:
         dp = dpred
     G = {}

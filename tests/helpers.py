@@ -158,3 +158,50 @@ def bwd3x3_h3_gpu(x, g, w, epi, c=None, coef=None, res=None, bnc=None, reverse=0
     if stats is not None:
         return host(out), host(dw), host(stats).reshape(grid, 32)
     return host(out), host(dw)
+
+
+def compare_or_explain_by_ties(compare, oracle_step, find_ties, max_ties=6):
+    """A training step of the GPU engine against the fp64 oracle, with the ONE legitimate source of disagreement checked instead
+    of assumed: `compare(ref)` raises AssertionError on a mismatch with ref = oracle_step(flips).  On a mismatch the oracle lists
+    the elements that sit within fp32 rounding of a kink of the graph (ReLU gates, hinge / cutoff thresholds, the denormaliser's
+    clip: oracle.training_step_ties).  No such element -> the mismatch is a fault and is raised.  Otherwise the GPU result must
+    equal the oracle evaluated with some subset of exactly those gates taken on the other side (what fp32 may do there); if no
+    subset explains it, the mismatch is raised.  Returns the number of flipped gates (0: plain agreement)."""
+    import itertools
+    try:
+        compare(oracle_step(None))
+        return 0
+    except AssertionError as first:
+        ties = find_ties()
+        if not ties:
+            raise AssertionError(f"mismatch and no element within rounding of a kink: {first}") from first
+        if len(ties) > max_ties:
+            raise AssertionError(f"mismatch with {len(ties)} near-kink elements (more than {max_ties}: not enumerated): {first}") from first
+        for n in range(1, len(ties) + 1):
+            for combo in itertools.combinations(ties, n):
+                try:
+                    compare(oracle_step(list(combo)))
+                    return n
+                except AssertionError:
+                    pass
+        raise AssertionError(f"mismatch that no side of the {len(ties)} near-kink elements explains: {first}") from first
+
+
+def oracle_is_on_a_kink(oracle_grads, noisy, tol_rel, segments=None, eps=2e-4, trials=3, seed=0):
+    """The tie hypothesis of the autograd-oracle sweeps, CHECKED on the oracle alone: does the fp64 oracle's own gradient jump when
+    its input moves by `eps` (on the 0..255 scale: a relative change of 1e-6, far below what moves a smooth gradient past the bar)?
+    oracle_grads(noisy) -> flat fp64 gradient; segments = [(offset, size)] of the gradient tensors (each is judged against its own
+    largest entry, as the comparison does).  True: some ReLU / hinge / clip input sits within rounding of its kink, fp32 may take
+    the other side there and a mismatch on this input proves nothing.  False: the gradient is smooth around this input and a
+    mismatch is a fault."""
+    rng = np.random.default_rng(seed)
+    g0 = oracle_grads(noisy)
+    segments = segments or [(0, g0.size)]
+    floor = 1e-3 * float(np.abs(g0).max())
+    for _ in range(trials):
+        g1 = oracle_grads(noisy + eps * rng.choice([-1.0, 1.0], size=noisy.shape))
+        for o, n in segments:
+            scale = max(float(np.abs(g0[o:o + n]).max()), floor, 1e-30)
+            if np.abs(g1[o:o + n] - g0[o:o + n]).max() > 0.25 * tol_rel * scale:
+                return True
+    return False

@@ -229,6 +229,32 @@ def test_full_size_config_properties():
         assert np.abs(out.astype(int) - out2.astype(int)).max() <= 1
 
 
+@pytest.mark.parametrize("arith", [1, 0], ids=["f16x3", "f32"])
+def test_baseline_config2_shape_f32_hydra(arith):
+    """BASELINE.json configs[1] at its real shape: resnet 1x6, batch 64, 256 x 256 x 3 float32 through bf_forward_f32 (the
+    hydra-level entry: floats in value range in, denormalised floats out).  The oracle on one image at each end of the batch
+    (normalised MAE <= 1e-4), and at the full size: finite, inside the value range, position independence (the reversed batch;
+    the same 16 images at four places), the two block arithmetics within the parity bar of each other."""
+    cfg, spec, params, state, m = _model(6, seed=42)
+    m.set_option("arith", arith)
+    _, noisy16 = O.synthetic_batch(16, 256, 256, seed=4321)
+    x = np.concatenate([noisy16] * 4).astype(np.float32)
+    assert x.shape == (64, 256, 256, 3)
+    got = np.asarray(m(x))
+    assert got.shape == x.shape and got.dtype == np.float32 and np.isfinite(got).all()
+    assert got.min() >= spec.v_min and got.max() <= spec.v_max
+    for i in (0, 63):
+        ref = O.hydra_forward(spec, params, state, x[i:i + 1].astype(np.float64))
+        _check_f32(got[i:i + 1], ref)
+    assert np.array_equal(np.asarray(m(x[::-1].copy()))[::-1], got)
+    for r in range(1, 4):
+        assert np.array_equal(got[16 * r:16 * (r + 1)], got[:16])
+    m.set_option("arith", 1 - arith)
+    other = np.asarray(m(x))
+    assert np.abs(other.astype(np.float64) - got).mean() / 255.0 <= 1e-4
+    m.set_option("arith", 1)
+
+
 @pytest.mark.parametrize("shape,no_layers", [((12, 256, 256), 18), ((16, 192, 200), 6), ((13, 240, 199), 3), ((3100, 1, 7), 2)],
                          ids=["full-width", "narrower", "odd-width", "one-row-images"])
 def test_compact_activation_layout(shape, no_layers):

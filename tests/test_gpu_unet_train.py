@@ -456,17 +456,26 @@ def test_random_unet_configurations_train(seed):
     except NotImplementedError as e:
         pytest.skip(f"refused: {e}")
     # a hinge / ReLU input within rounding of its kink on one pixel moves a gradient tensor well past the bar (about 6 % of the
-    # configurations; tests/test_gpu_resnet_generic_train.py has the measurement): on a mismatch the comparison is repeated on other
-    # inputs -- a tie goes away, a fault does not
+    # configurations; tests/test_gpu_resnet_generic_train.py has the measurement).  The tie is CHECKED, not assumed: a mismatch is
+    # only set aside (and the comparison repeated on other inputs) when the fp64 oracle's OWN gradient jumps under a 1e-6 relative
+    # change of this input (helpers.oracle_is_on_a_kink); where the oracle is smooth, the mismatch is a fault and is raised at once
+    from helpers import oracle_is_on_a_kink
+    dw = [1.0, 0.6, 0.3][:depth]
     last = None
     for attempt in range(3):
         if attempt:
             clean, noisy = O.synthetic_batch(clean.shape[0], clean.shape[1], clean.shape[2], seed=seed + 1000 * attempt)
         try:
-            _check_step(spec, params, model, clean, noisy, LOSS_V5, [1.0, 0.6, 0.3][:depth])
+            _check_step(spec, params, model, clean, noisy, LOSS_V5, dw)
             return
         except NotImplementedError as e:
             pytest.skip(f"refused: {e}")
         except AssertionError as e:
+            ls_ = O.LossSpec.from_config(LOSS_V5)
+            soft = bool(model.config["backbone"].get("use_soft_orthonormal_regularization", False))
+            grads_of = lambda nz: np.asarray(T.train_step(spec, ls_, params, clean.astype(np.float64), nz, dw, None, None, soft)[-1], np.float64)
+            segs = [(o, int(np.prod(sh))) for o, sh in spec.offsets().values()]
+            if not oracle_is_on_a_kink(grads_of, noisy.astype(np.float64), tol_rel=5e-4, segments=segs, seed=seed):
+                raise AssertionError(f"mismatch where the oracle's gradient is smooth (no kink within rounding of this input): {e}") from e
             last = e
     raise last

@@ -18,8 +18,15 @@ from oracle import bfcnn_oracle as O
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 
 
+HEADERS = ("bfcnn_hip.h", "bfcnn_hip_debug.h")      # the drop-in ABI and the single-kernel diagnostic entries
+
+
+def _header_text():
+    return "\n".join((ROOT / "include" / h).read_text() for h in HEADERS)
+
+
 def _declared_symbols():
-    text = (ROOT / "include" / "bfcnn_hip.h").read_text()
+    text = _header_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(bf_[a-z0-9_]+)\s*\(", text)))
 
@@ -39,7 +46,7 @@ def test_ctypes_signatures_match_the_header_prototypes():
     """every prototype of include/bfcnn_hip.h against _native.SIGNATURES: same number of parameters, pointers bound as pointers,
     int / int64_t / float / uint64_t as the ctypes type of that width (a binding that drifts from the header corrupts calls
     silently: ctypes does not check)."""
-    text = (ROOT / "include" / "bfcnn_hip.h").read_text()
+    text = _header_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"//[^\n]*", "", text)
     protos = re.findall(r"\b(?:const\s+char\s*\*|int64_t|int|void|bf_handle)\s*(bf_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S)
