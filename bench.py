@@ -48,6 +48,31 @@ def gflop_per_image(no_layers, h, w, k=3, cin=3, hf=32, cout=3):
     return per_px * h * w / 1e9
 
 
+def host_cores():
+    """the host cores this process may actually use: a GPU box hands out a SHARE of its 256 hardware threads (a cgroup CPU quota),
+    which os.sched_getaffinity does not show -- 256 torch threads on a 16-core share ran a training step in 84 s.  The quota
+    (cgroup v2 cpu.max / v1 cfs_quota_us) bounds the affinity count; OMP_NUM_THREADS, when the launcher set it, bounds both."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    try:
+        n = min(n, max(1, int(os.environ["OMP_NUM_THREADS"])))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline_port(spec, params, state, noisy_u8, budget_s=10.0):
     """the oracle's C port on the host cores: bounded sample, ~budget_s of CPU work."""
     from oracle import port
@@ -76,7 +101,7 @@ def cpu_baseline_torch(spec, params, state, noisy_u8, budget_s=10.0, nthreads=No
     import torch
     import torch.nn.functional as F
     if nthreads is None:            # the cores this process may run on (a GPU box hands out a share of its 256)
-        nthreads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        nthreads = host_cores()
     torch.set_num_threads(int(nthreads))
     off = spec.offsets()
     P = lambda name: torch.from_numpy(np.asarray(params[off[name][0]:off[name][0] + int(np.prod(off[name][1]))], np.float32).reshape(off[name][1]))
@@ -120,6 +145,114 @@ def cpu_baseline_torch(spec, params, state, noisy_u8, budget_s=10.0, nthreads=No
                       f"{nthreads} threads) with the restatement's tensors"}, out1
 
 
+def time_gradient_exchange(torch, bf, model, prep, clean_dev, world, dist):
+    """what the ONE collective of a training step costs on this box, next to the work it is supposed to hide behind
+    (DataParallelTrainer.step(overlap=...): the next batch's on-device corruption): HIP-event time per call of
+    torch.distributed.all_reduce and of the C ABI's bf_allreduce_grads on the flat gradient buffer, in the process group of this
+    run (world > 1) or in a one-rank RCCL group made for the measurement (world = 1: launch + kernel cost without the wire)."""
+    import socket
+    out = {"payload_floats": int(model.n_params), "world": int(world)}
+    own_group = False
+    try:
+        import torch.distributed as d
+        if dist is None:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            d.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                 device_id=torch.device("cuda", torch.cuda.current_device()))
+            own_group = True
+        g = torch.zeros(model.n_params, dtype=torch.float32, device="cuda")
+
+        def timed(fn, n=50):
+            for _ in range(5):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / n
+
+        out["torch_distributed_all_reduce_us"] = timed(lambda: d.all_reduce(g))
+        try:
+            comm = bf.NativeCommunicator(torch.device("cuda", torch.cuda.current_device()))
+            out["c_abi_bf_allreduce_grads_us"] = timed(lambda: comm.allreduce(g))
+            comm.close()
+        except Exception as e:
+            out["c_abi_bf_allreduce_grads_us"] = None
+            out["c_abi_note"] = str(e)[:200]
+        out["overlap_work_us"] = timed(lambda: prep(clean_dev), n=20)
+        out["overlap_work"] = "PrepareData on the next batch (flips + truncated-normal noise on the device, bf_noise_augment)"
+    except Exception as e:
+        out["note"] = f"not measured: {str(e)[:200]}"
+    finally:
+        if own_group:
+            try:
+                import torch.distributed as d
+                d.destroy_process_group()
+            except Exception:
+                pass
+    return out
+
+
+def cpu_train_baseline_torch(spec, ls, params, state, S, budget_s=12.0, nthreads=None):
+    """the training step of configs[3] on PyTorch-CPU, fp32, all host cores ("the same graph on all host cores"):
+    normalise -> base conv -> N x [conv + ReLU -> conv -> BatchNorm (training statistics, scale only) -> + skip] -> head ->
+    tanh(2x) * 0.51 -> denormalise; L1 with hinge / cutoff (keras relu threshold, loss.py:40-65) + L1 / L2 kernel regularisers;
+    autograd backward; Adam with global-norm clipping.  Independent restatement on torch.nn.functional (oneDNN), not TensorFlow."""
+    import torch
+    import torch.nn.functional as F
+    if nthreads is None:
+        nthreads = host_cores()
+    torch.set_num_threads(int(nthreads))
+    off = spec.offsets()
+    flat = torch.tensor(np.asarray(params, np.float32), requires_grad=True)
+    V = lambda name: flat[off[name][0]:off[name][0] + int(np.prod(off[name][1]))].view(*off[name][1])
+    W = lambda name: V(name).permute(3, 2, 0, 1)                                  # HWIO -> OIHW
+    opt = torch.optim.Adam([flat], lr=1e-3, betas=(0.9, 0.999), eps=1e-7)
+
+    def step(gt, noisy):
+        x = (torch.clamp(noisy, spec.v_min, spec.v_max) / (spec.v_max - spec.v_min) - 0.5).permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+        f = F.conv2d(x, W("base/kernel"), padding=spec.kernel_size // 2)
+        reg = V("base/kernel").abs().sum() * 0.01
+        for i in range(spec.no_layers):
+            t = F.relu(F.conv2d(f, W(f"block{i}/conv0/kernel"), padding=1))
+            c = F.conv2d(t, W(f"block{i}/conv1/kernel"), padding=1)
+            c = F.batch_norm(c, None, None, weight=V(f"block{i}/bn1/gamma"), bias=None, training=True, eps=spec.bn_eps)
+            f = f + c
+            reg = reg + (V(f"block{i}/conv0/kernel").abs().sum() + V(f"block{i}/conv1/kernel").abs().sum()) * 0.01
+        h = F.conv2d(F.conv2d(f, W("head/conv0/kernel")), W("head/conv1/kernel"))
+        reg = reg + ((V("head/conv0/kernel") ** 2).sum() + (V("head/conv1/kernel") ** 2).sum()) * 0.01
+        p = torch.tanh(2.0 * h) * 0.51
+        pred = ((torch.clamp(p, -0.5, 0.5) + 0.5) * (spec.v_max - spec.v_min) + spec.v_min).permute(0, 2, 3, 1)
+        a = (gt - pred).abs()
+        d = torch.where((a > ls.hinge) & (a < ls.cutoff), a, torch.zeros_like(a)) + torch.where(a >= ls.cutoff, torch.full_like(a, ls.cutoff), torch.zeros_like(a))
+        total = d.mean() * ls.mae_multiplier + reg * ls.regularization
+        opt.zero_grad(set_to_none=True)
+        total.backward()
+        torch.nn.utils.clip_grad_norm_([flat], 1.0)
+        opt.step()
+        return float(total.detach())
+
+    nb = 2
+    from oracle import bfcnn_oracle as O
+    c1, n1 = O.synthetic_batch(nb, S, S, sigma=20.0, seed=99)
+    gt, noisy = torch.from_numpy(c1.astype(np.float32)), torch.from_numpy(n1.astype(np.float32))
+    first_loss = step(gt, noisy)                                                  # warm-up (oneDNN primitive creation)
+    t0 = time.perf_counter()
+    nrep = 0
+    while nrep < 1 or (time.perf_counter() - t0 < budget_s and nrep < 64):
+        step(gt, noisy)
+        nrep += 1
+    dt = (time.perf_counter() - t0) / nrep
+    return {"value": nb / dt, "unit": "images/s", "cores": int(nthreads), "kind": "port", "first_loss": first_loss,
+            "sample": f"{nrep} training steps (forward + L1 loss + autograd backward + clipped Adam) of {nb} x {S}x{S} images, "
+                      f"torch-CPU fp32 (oneDNN, channels_last, {nthreads} threads): CPU restatement of the same graph, not TensorFlow"}
+
+
 def cpu_baseline(spec, params, state, noisy_u8):
     """both CPU legs of SURVEY 8d; the faster one is the reported baseline, the other rides along."""
     a = cpu_baseline_port(spec, params, state, noisy_u8)
@@ -151,8 +284,8 @@ def pmc_traffic(layers, batch, size, fused, kernel=None):
 def pyramid_bench(args, torch, bf, O, rank, local_rank, world, dist):
     """configs[4]'s resampling part (pyramid.py + upsampling.py): 3-level Laplacian pyramid + its inverse on a
     [32,512,512,3] float32 batch; HBM-bound kernels, so the figure of merit is algorithmic GB/s against the 8 TB/s roof.
-    Algorithmic bytes (4 B elements, n = B*H*W*C): split level l (n_l elements): avg-pool reads n_l writes n_l/4, the fused
-    x - up(down) reads n_l/4 + n_l and writes n_l -> 3.5 n_l; merge level l: reads n_l/4 + n_l, writes n_l -> 2.25 n_l."""
+    Algorithmic bytes (4 B elements, n = B*H*W*C): split level l (n_l elements): x read once, down (n_l / 4) and x - up(down)
+    (n_l) written -> 2.25 n_l (one kernel, bf_laplacian_split); merge level l: reads n_l/4 + n_l, writes n_l -> 2.25 n_l."""
     B, S, C, levels = (32 if args.batch == 128 else args.batch), (512 if args.size == 256 else args.size), 3, 3
     x = (torch.rand((B, S, S, C), device=f"cuda:{local_rank}") - 0.5).contiguous()
     cfg = {"type": "laplacian", "levels": levels, "kernel_size": (5, 5)}
@@ -169,7 +302,8 @@ def pyramid_bench(args, torch, bf, O, rank, local_rank, world, dist):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     n = B * S * S * C
-    nbytes = 4 * sum((3.5 + 2.25) * n / 4 ** l for l in range(levels - 1))
+    # "Laplacian split fused: read 1, write 1 + 1/4" per level; the merge reads 1/4 + 1 and writes 1: 2.25 n each
+    nbytes = 4 * sum((2.25 + 2.25) * n / 4 ** l for l in range(levels - 1))
     err = float((y - x).abs().mean().item())
     if rank == 0:
         gbs = nbytes * args.steps / elapsed / 1e9
@@ -193,7 +327,7 @@ def pyramid_bench(args, torch, bf, O, rank, local_rank, world, dist):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"laplacian pyramid (avg-pool 5x5 s2 SAME, bilinear x2) + inverse, batch={B} {S}x{S}x{C} float32"},
             "round_trip_mean_abs_error": err,      # reference test bar: < 1e-7 (tests/bfcnn/test_pyramid.py)
-            "roofline": {"bound": "hbm", "kernel": "avgpool_s2_same + upsample2x (4 launches per level pair)", "achieved": gbs,
+            "roofline": {"bound": "hbm", "kernel": "lap_split_kernel + upsample2x_rows_kernel (one launch per level and direction)", "achieved": gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_step": nbytes},
             **({"cpu_baseline": cpu} if cpu is not None else {})}), flush=True)
@@ -428,6 +562,7 @@ def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    exchange = time_gradient_exchange(torch, bf, model, prep, clean_dev, world, dist)      # every rank takes part
     if rank == 0:
         # algorithmic FLOPs per image: fwd + dgrad + wgrad of every 3x3 16->16 conv, fwd + wgrad of the base conv, head fwd + bwd
         per_px = 3 * args.layers * FLOP_PER_PX_BLOCK + 2 * 2 * 9 * 3 * 16 + 3 * 2 * (16 * 32 + 32 * 3)
@@ -480,20 +615,36 @@ def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
                          "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args.layers, B, S, True, "bwd3x3_h3_kernel<true, 8>"), "algorithmic_bytes_per_launch": wbytes,
                          "launch_us": launch_us, "launches_of_this_kernel_per_step": args.layers}}
+        rec["gradient_exchange"] = exchange
+        if os.environ.get("BF_BENCH_REHEARSE") == "1":
+            rec["rehearsal"] = True              # ranks shared a GPU over gloo: exercises the launch path, not a measurement
+        if dist is not None:
+            rec["world_size_seen"] = int(dist.get_world_size())
+        rec["visible_gpus"] = int(torch.cuda.device_count())
         if world == 1 and not args.no_cpu_baseline:
-            # the oracle's training step (fp64 NumPy restatement) on ONE image of the same shape
-            cfg1 = O.canonical_config(no_layers=args.layers)
+            # leg (i): the same graph on torch-CPU fp32 autograd with all host cores (the reported baseline); leg (ii): the oracle's
+            # training step (fp64 NumPy restatement) on ONE image of the same shape, kept beside it
             ls = O.LossSpec.from_config(cfg["loss"])
             c1, n1 = O.synthetic_batch(1, S, S, sigma=20.0, seed=99)
             t0 = time.perf_counter()
             nrep = 0
-            while nrep < 1 or (time.perf_counter() - t0 < 8.0 and nrep < 16):          # ~10 s of CPU work
+            while nrep < 1 or (time.perf_counter() - t0 < 6.0 and nrep < 16):           # ~6 s of CPU work
                 O.train_step_single_gpu(spec, ls, params, state, c1.astype(np.float64), n1.astype(np.float64))
                 nrep += 1
             dt = (time.perf_counter() - t0) / nrep
-            rec["cpu_baseline"] = {"value": 1.0 / dt, "unit": "images/s", "cores": 1, "kind": "port",
-                                   "sample": f"{nrep} x one {S}x{S} image through oracle/bfcnn_oracle.py train_step_single_gpu (fp64 NumPy "
-                                             f"restatement of forward + loss + backward, BLAS threads as NumPy picks them; not TensorFlow)"}
+            oracle_leg = {"value": 1.0 / dt, "unit": "images/s", "cores": 1, "kind": "port",
+                          "sample": f"{nrep} x one {S}x{S} image through oracle/bfcnn_oracle.py train_step_single_gpu (fp64 NumPy "
+                                    f"restatement of forward + loss + backward, BLAS threads as NumPy picks them; not TensorFlow)"}
+            try:
+                try:                                # the C port's OpenMP team size is what the inference legs use on this box
+                    from oracle import port
+                    nthreads = min(host_cores(), int(port.lib(rebuild=False).bfcnn_port_max_threads()))
+                except Exception:
+                    nthreads = host_cores()
+                rec["cpu_baseline"] = cpu_train_baseline_torch(spec, ls, params, state, S, nthreads=nthreads)
+                rec["cpu_baseline"]["other_leg"] = oracle_leg
+            except Exception as e:                      # the torch-CPU leg must never fail the bench
+                rec["cpu_baseline"] = dict(oracle_leg, note=f"torch-CPU leg failed: {e}")
         print(json.dumps(rec), flush=True)
     if dist is not None:
         dist.barrier()

@@ -66,6 +66,7 @@ SIGNATURES = {
     "bf_avgpool_s2_same": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "bf_avgpool2_valid": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "bf_upsample2x": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P]),
+    "bf_laplacian_split": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "bf_strided_slice2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "bf_noise_augment": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, C.c_uint64, _P]),
     "bf_op_pack_pointwise": (_I, [_P, _P, _I, _I, _P]),

@@ -233,6 +233,20 @@ extern "C" int bf_avgpool2_valid(const float* in, float* out, int B, int H, int 
 // out[2i] = .25 in[i-1] + .75 in[i], out[2i+1] = .75 in[i] + .25 in[i+1] (pyramid.py:319-325,380-382,
 // 434-436); nearest = pixel replication (upsampling.py:65,105).  out = alpha*up(in) + beta*other
 // fuses the Laplacian split (x - up(down), pyramid.py:383) and merge (up(acc) + level, :437).
+// The bilinear x2 value of one output element and the combination with `other`, written with explicit fused multiply-adds so
+// that every kernel that forms them (element-per-thread, row-oriented, fused Laplacian split) produces the SAME bits: hipcc picks
+// its own contractions per kernel otherwise.  rows first (as the separable resize does), then columns.
+__device__ __forceinline__ float bf_bilinear_tap(const float v00, const float v01, const float m0, const float m1)
+{
+    const float a = __builtin_fmaf(0.75f, v00, 0.25f * m0);
+    const float b = __builtin_fmaf(0.75f, v01, 0.25f * m1);
+    return __builtin_fmaf(0.75f, a, 0.25f * b);
+}
+__device__ __forceinline__ float bf_axpby(const float alpha, const float up, const float beta, const float other)
+{
+    return __builtin_fmaf(alpha, up, beta * other);
+}
+
 template <typename T, int V>
 __global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ in, const T* __restrict__ other, T* __restrict__ out,
                                                          int B, int H, int W, int C, int bilinear, float alpha, float beta)
@@ -255,12 +269,7 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ i
             const T v10 = base[((int64_t)y1 * W + ix) * Cv], v11 = base[((int64_t)y1 * W + x1) * Cv];
             const float *p00 = (const float*)&v00, *p01 = (const float*)&v01, *p10 = (const float*)&v10, *p11 = (const float*)&v11;
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
-                // rows first (as the separable resize does), then columns
-                const float top = 0.75f * p00[v] + 0.25f * p10[v];
-                const float top1 = 0.75f * p01[v] + 0.25f * p11[v];
-                r[v] = 0.75f * top + 0.25f * top1;
-            }
+            for (int v = 0; v < V; ++v) r[v] = bf_bilinear_tap(p00[v], p01[v], p10[v], p11[v]);
         } else {
             const T v00 = base[((int64_t)iy * W + ix) * Cv];
             const float* p00 = (const float*)&v00;
@@ -273,7 +282,7 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ i
             const T ov = other[i];
             const float* pp = (const float*)&ov;
 #pragma unroll
-            for (int v = 0; v < V; ++v) po[v] = alpha * r[v] + beta * pp[v];
+            for (int v = 0; v < V; ++v) po[v] = bf_axpby(alpha, r[v], beta, pp[v]);
         } else {
 #pragma unroll
             for (int v = 0; v < V; ++v) po[v] = alpha * r[v];
@@ -304,16 +313,15 @@ __global__ __launch_bounds__(256) void upsample2x_rows_kernel(const float* __res
         const int x1 = (ox & 1) ? min(ix + 1, W - 1) : max(ix - 1, 0);
         const float v00 = r0[ix * C], v01 = r0[x1 * C];
         const float m0 = rm[ix * C], m1 = rm[x1 * C], p0 = rp[ix * C], p1 = rp[x1 * C];
-        // rows first (as the separable resize does), then columns: same expression as upsample2x_kernel
-        top_a = 0.75f * (0.75f * v00 + 0.25f * m0) + 0.25f * (0.75f * v01 + 0.25f * m1);
-        top_b = 0.75f * (0.75f * v00 + 0.25f * p0) + 0.25f * (0.75f * v01 + 0.25f * p1);
+        top_a = bf_bilinear_tap(v00, v01, m0, m1);
+        top_b = bf_bilinear_tap(v00, v01, p0, p1);
     } else {
         top_a = top_b = r0[ix * C];
     }
     const int64_t o = ((int64_t)b * 2 * H + 2 * iy) * row_floats + xo;
     if (other) {
-        out[o] = alpha * top_a + beta * other[o];
-        out[o + row_floats] = alpha * top_b + beta * other[o + row_floats];
+        out[o] = bf_axpby(alpha, top_a, beta, other[o]);
+        out[o + row_floats] = bf_axpby(alpha, top_b, beta, other[o + row_floats]);
     } else {
         out[o] = alpha * top_a;
         out[o + row_floats] = alpha * top_b;
@@ -338,6 +346,158 @@ extern "C" int bf_upsample2x(const float* in, const float* other, float* out, in
         hipLaunchKernelGGL((upsample2x_kernel<float, 1>), dim3(grid_for(n)), dim3(256), 0, s, in, other, out, B, H, W, C,
                            bilinear, alpha, beta);
     }
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// ------------------------------------------------------------------------------------------
+// One level of the Laplacian split in ONE kernel (bfcnn/pyramid.py:374-385): down = AveragePooling2D(k, strides 2, same)(x) and
+// lap = x - UpSampling2D(2, bilinear)(down).  The two-kernel form (bf_avgpool_s2_same, then bf_upsample2x with other = x) reads x
+// twice and down once: 3.5 n floats per level where this reads x once and never reads down back: 2.25 n (x in, lap out, down out).
+// Same arithmetic, operation by operation, as those two kernels (rows summed top to bottom, then the kw taps, one division by the
+// number of valid taps; rows first, then columns in the resize): bitwise the same results.
+//
+// A workgroup (128 threads) owns DP down-pixels x DR down-rows of one image and walks down its band one down-row per step:
+//   * thread t carries a sliding window of x rows 2d-2 .. 2d-PT+KH-1 for the four consecutive floats f0 + 4t .. of the x line
+//     the chunk needs (16-byte loads and stores; the next step's two rows are requested before this step's arithmetic);
+//   * step d: column sums of the KH pooling rows -> LDS; the down row d (one float per thread, halo pixel either side) from kw
+//     LDS taps -> a ring of four down rows in LDS (+ global, where owned); then the two lap rows of down-row d-1, whose x values
+//     are still in the window and whose bilinear taps are the ring's rows d-2, d-1, d.
+// Needs even H and W (the reference's Laplacian levels have them: up(down) must match x), W * C % 4 == 0 and 16-byte aligned
+// tensors; kh in {3, 5, 7}.
+// ------------------------------------------------------------------------------------------
+constexpr int LS_NT = 128, LS_XLINE = 4 * LS_NT, LS_DLINE = 2 * LS_NT;
+template <int KH>
+__global__ __launch_bounds__(LS_NT) void lap_split_kernel(const float* __restrict__ in, float* __restrict__ down, float* __restrict__ lap,
+                                                          int H, int W, int C, int kw, int OH, int OW, int pl, int DP, int DR,
+                                                          int nchunks, int nbands)
+{
+    constexpr int PT = (KH - 2) / 2;                    // SAME padding above the first row for an even H
+    constexpr int WIN = KH - PT + 2;                    // window rows: x rows 2d-2 .. 2d-PT+KH-1
+    __shared__ __attribute__((aligned(16))) float colsum[LS_XLINE];
+    __shared__ float dring[4][LS_DLINE];
+    const int t = threadIdx.x;
+    int bx = blockIdx.x;
+    const int ch = bx % nchunks; bx /= nchunks;
+    const int band = bx % nbands;
+    const int b = bx / nbands;
+    const int pd0 = ch * DP, pd1 = min(pd0 + DP, OW);               // owned down pixels
+    const int d0 = band * DR, d1 = min(d0 + DR, OH);                // owned down rows
+    const int hp0 = max(pd0 - 1, 0), hp1 = min(pd1 + 1, OW);        // with the halo pixel either side
+    const int row_x = W * C, row_d = OW * C;
+    const int xin0 = 2 * hp0 - pl;
+    const int f0 = (xin0 * C) >= 0 ? (xin0 * C) / 4 * 4 : -((-(xin0 * C) + 3) / 4 * 4);      // floor to a multiple of 4
+    const int fx = f0 + 4 * t;                                      // this thread's first x float (of the row)
+    const bool live = fx >= 0 && fx + 4 <= row_x && fx < (2 * (hp1 - 1) - pl + kw) * C;
+    const bool owned = fx >= 2 * pd0 * C && fx < 2 * pd1 * C;       // its lap outputs belong to this chunk (float4 granular)
+    const float* xb = in + (int64_t)b * H * row_x + fx;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto load_row = [&](const int y) -> f32x4 {
+        return (live && y >= 0 && y < H) ? *reinterpret_cast<const f32x4*>(xb + (int64_t)y * row_x) : zero4;
+    };
+    const int ds = max(d0 - 1, 0), de = min(d1, OH - 1);
+    f32x4 win[WIN];
+#pragma unroll
+    for (int k = 0; k < WIN; ++k) win[k] = load_row(2 * ds - 2 + k);
+    // down floats of this thread: u = t and t + 128 of the halo-extended down line
+    const int nd = (hp1 - hp0) * C;
+    // bilinear taps of this thread's four x floats (column part: fixed for the band)
+    int i0[4], i1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int f = owned ? fx + e : 2 * pd0 * C;
+        const int ox = f / C, c = f - ox * C, ix = ox >> 1;
+        const int x1 = (ox & 1) ? min(ix + 1, OW - 1) : max(ix - 1, 0);
+        i0[e] = (ix - hp0) * C + c;
+        i1[e] = (x1 - hp0) * C + c;
+    }
+    auto emit = [&](const int i, const f32x4 xa, const f32x4 xbb) {       // lap rows 2i, 2i+1 (x values xa, xbb)
+        const float* dm = dring[max(i - 1, 0) & 3];
+        const float* dc = dring[i & 3];
+        const float* dp = dring[min(i + 1, OH - 1) & 3];
+        f32x4 ra, rb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v00 = dc[i0[e]], v01 = dc[i1[e]];
+            const float m0 = dm[i0[e]], m1 = dm[i1[e]], p0 = dp[i0[e]], p1 = dp[i1[e]];
+            ra[e] = bf_axpby(-1.0f, bf_bilinear_tap(v00, v01, m0, m1), 1.0f, xa[e]);
+            rb[e] = bf_axpby(-1.0f, bf_bilinear_tap(v00, v01, p0, p1), 1.0f, xbb[e]);
+        }
+        float* o = lap + ((int64_t)b * H + 2 * i) * row_x + fx;
+        *reinterpret_cast<f32x4*>(o) = ra;
+        *reinterpret_cast<f32x4*>(o + row_x) = rb;
+    };
+    for (int d = ds; d <= de; ++d) {
+        // the two rows the NEXT step adds to the window: requested now, used at the end of the step
+        f32x4 nx0 = zero4, nx1 = zero4;
+        if (d < de) {
+            nx0 = load_row(2 * d - 2 + WIN);
+            nx1 = load_row(2 * d - 2 + WIN + 1);
+        }
+        f32x4 a = zero4;
+#pragma unroll
+        for (int k = 0; k < KH; ++k) a += win[2 - PT + k];                 // rows outside the image hold 0
+        *reinterpret_cast<f32x4*>(colsum + 4 * t) = a;
+        __syncthreads();
+        const int y0 = 2 * d - PT;
+        const int nrows = min(y0 + KH, H) - max(y0, 0);
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) {
+            const int u = t + uu * LS_NT;
+            if (u < nd) {
+                const int p = hp0 + u / C, c = u - (u / C) * C;
+                const int x0 = 2 * p - pl;
+                const int klo = max(0, -x0), khi = min(kw, W - x0);
+                const float* q = colsum + (x0 * C + c - f0);
+                float sum = 0.f;
+                for (int kx = klo; kx < khi; ++kx) sum += q[kx * C];
+                const float v = sum / (float)(nrows * (khi - klo));
+                dring[d & 3][u] = v;
+                if (d >= d0 && d < d1 && p >= pd0 && p < pd1) down[((int64_t)b * OH + d) * row_d + p * C + c] = v;
+            }
+        }
+        __syncthreads();
+        if (owned && d - 1 >= d0) emit(d - 1, win[0], win[1]);
+        if (owned && d == OH - 1 && d < d1) emit(d, win[2], win[3]);       // last image row: its lower neighbour is itself
+#pragma unroll
+        for (int k = 0; k + 2 < WIN; ++k) win[k] = win[k + 2];
+        win[WIN - 2] = nx0;
+        win[WIN - 1] = nx1;
+    }
+}
+
+// returns BF_EUNSUPPORTED (nothing launched) for shapes the fused kernel does not take: the caller runs the two-kernel form
+extern "C" int bf_laplacian_split(const float* in, float* down, float* lap, int B, int H, int W, int C, int kh, int kw, void* stream)
+{
+    if (!in || !down || !lap || B <= 0 || H <= 0 || W <= 0 || C <= 0 || kh <= 0 || kw <= 0) return BF_EINVAL;
+    if ((H & 1) || (W & 1) || (W * C) % 4 || !(kh == 3 || kh == 5 || kh == 7) || kw < 2 || kw > 15) return BF_EUNSUPPORTED;
+    if (((uintptr_t)in | (uintptr_t)lap) % 16) return BF_EUNSUPPORTED;
+    // channel counts that are a multiple of 4 keep the element-per-thread float4 kernels (another summation order: the promise of
+    // bitwise-equal results would not hold); the colour pyramids of the reference are C = 3 and C = 1
+    if (C % 4 == 0) return BF_EUNSUPPORTED;
+    int OH, OW, pt, pl;
+    same_pad(H, kh, 2, &OH, &pt);
+    same_pad(W, kw, 2, &OW, &pl);
+    if (pt != (kh - 2) / 2) return BF_EUNSUPPORTED;
+    // down pixels per chunk: the x line (2 (DP + 2) + kw) C + 3 floats fits 4 per thread, the down line (DP + 2) C fits 2 per thread
+    int dpmax = (LS_XLINE / C - kw - 1) / 2 - 2;
+    if ((LS_DLINE / C) - 2 < dpmax) dpmax = LS_DLINE / C - 2;
+    if (dpmax < 2) return BF_EUNSUPPORTED;
+    int nchunks = (OW + dpmax - 1) / dpmax;
+    int DP = (OW + nchunks - 1) / nchunks;
+    if ((DP * C) % 2) ++DP;                              // 2 DP C % 4 == 0: a thread's four floats never straddle two chunks
+    if (DP > dpmax) { DP = dpmax - (((dpmax * C) % 2) ? 1 : 0); }
+    if (DP < 1 || (2 * DP * C) % 4) return BF_EUNSUPPORTED;
+    nchunks = (OW + DP - 1) / DP;
+    // down rows per band: enough workgroups to fill the chip several times over, bands tall enough to amortise the 2 + KH halo rows
+    int DR = 32;
+    while (DR > 8 && (int64_t)B * nchunks * ((OH + DR - 1) / DR) < 2048) DR /= 2;
+    const int nbands = (OH + DR - 1) / DR;
+    const int64_t grid = (int64_t)B * nchunks * nbands;
+    if (grid > 0x7fffffff) return BF_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (kh == 3) hipLaunchKernelGGL(lap_split_kernel<3>, dim3((unsigned)grid), dim3(LS_NT), 0, s, in, down, lap, H, W, C, kw, OH, OW, pl, DP, DR, nchunks, nbands);
+    else if (kh == 5) hipLaunchKernelGGL(lap_split_kernel<5>, dim3((unsigned)grid), dim3(LS_NT), 0, s, in, down, lap, H, W, C, kw, OH, OW, pl, DP, DR, nchunks, nbands);
+    else hipLaunchKernelGGL(lap_split_kernel<7>, dim3((unsigned)grid), dim3(LS_NT), 0, s, in, down, lap, H, W, C, kw, OH, OW, pl, DP, DR, nchunks, nbands);
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
 

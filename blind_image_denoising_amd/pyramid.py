@@ -71,6 +71,23 @@ def upsample_2x(x: torch.Tensor, other: torch.Tensor = None, bilinear: bool = Tr
     return out
 
 
+def laplacian_split(x: torch.Tensor, kernel_size=DEFAULT_KERNEL_SIZE):
+    """one Laplacian level (pyramid.py:374-385): (down, x - up(down)) with down = avg_pool_s2_same(x).  One fused kernel where the
+    shape allows it (x read once: bf_laplacian_split), else the two operators; the results are bitwise the same either way."""
+    B, H, W, C = x.shape
+    if H % 2 == 0 and W % 2 == 0:
+        down = torch.empty((B, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
+        lap = torch.empty_like(x)
+        rc = N.lib().bf_laplacian_split(N.ptr(x), N.ptr(down), N.ptr(lap), B, H, W, C, int(kernel_size[0]), int(kernel_size[1]),
+                                        N.stream_ptr(x))
+        if rc == N.BF_OK:
+            return down, lap
+        if rc != N.BF_EUNSUPPORTED:
+            N.check(rc, None, "bf_laplacian_split")
+    down = avg_pool_s2_same(x, kernel_size)
+    return down, upsample_2x(down, x, True, -1.0, 1.0)               # x - up(down)
+
+
 def strided_slice_2(x: torch.Tensor) -> torch.Tensor:
     """x[:, ::2, ::2, :] (bfcnn/downsampling.py:61)."""
     B, H, W, C = x.shape
@@ -154,9 +171,8 @@ def build_laplacian_pyramid_model(input_dims, levels: int, kernel_size=DEFAULT_K
         x, was_numpy = _dev(x)
         out = []
         for _ in range(levels - 1):
-            down = avg_pool_s2_same(x, kernel_size)
-            out.append(upsample_2x(down, x, True, -1.0, 1.0))               # x - up(down)
-            x = down
+            x, lap = laplacian_split(x, kernel_size)
+            out.append(lap)
         out.append(x)
         return [o.cpu().numpy() for o in out] if was_numpy else out
     return _PyramidModel(name, levels, fn)

@@ -190,6 +190,13 @@ int bf_avgpool2_valid(const float* in, float* out, int batch, int height, int wi
  * out = up(in) [+ add][- sub...]: out = alpha*up(in) + beta*other (other may be NULL). */
 int bf_upsample2x(const float* in, const float* other, float* out, int batch, int height, int width,
                   int channels, int bilinear, float alpha, float beta, void* stream);
+/* one level of the Laplacian split in ONE kernel (bfcnn/pyramid.py:374-385): down = AveragePooling2D((kh,kw), strides 2, same)(in)
+ * [B,H/2,W/2,C] and lap = in - UpSampling2D(2, bilinear)(down) [B,H,W,C]; x is read once (2.25 n floats of traffic instead of the
+ * 3.5 n of bf_avgpool_s2_same + bf_upsample2x) and the results are bitwise those of the two calls.  Returns BF_EUNSUPPORTED
+ * without launching anything for shapes it does not take (odd H or W, W*C not a multiple of 4, C a multiple of 4, kh not in
+ * {3,5,7}, unaligned tensors): the caller then makes the two calls. */
+int bf_laplacian_split(const float* in, float* down, float* lap, int batch, int height, int width, int channels, int kh, int kw,
+                       void* stream);
 /* x[:, ::2, ::2, :] (downsampling.py:61). */
 int bf_strided_slice2(const float* in, float* out, int batch, int height, int width, int channels, void* stream);
 

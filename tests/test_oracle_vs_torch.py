@@ -249,3 +249,22 @@ def test_upsample_matches_torch():
     assert np.abs(O.upsample_bilinear_2x(x) - ref).max() < 1e-12
     ref = _nhwc(F.interpolate(_nchw(x), scale_factor=2, mode="nearest"))
     assert np.abs(O.upsample_nearest_2x(x) - ref).max() == 0
+
+
+def test_bench_torch_cpu_training_baseline_computes_the_oracles_step():
+    """bench.py --mode train's CPU baseline (torch-CPU fp32 autograd, all cores) is the SAME graph and loss as the oracle's training
+    step: its first loss equals the oracle's total loss on the same two images."""
+    import importlib.util
+    import pathlib
+    root = pathlib.Path(__file__).resolve().parent.parent
+    sp = importlib.util.spec_from_file_location("_bench", root / "bench.py")
+    bench = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(bench)
+    cfg = O.canonical_config(no_layers=3)
+    spec, ls = O.ResnetSpec.from_config(cfg["model"]), O.LossSpec.from_config(cfg["loss"])
+    params, state = O.init_params(spec, seed=42, nontrivial_bn=True)
+    rec = bench.cpu_train_baseline_torch(spec, ls, params, state, 32, budget_s=0.2, nthreads=2)
+    c1, n1 = O.synthetic_batch(2, 32, 32, sigma=20.0, seed=99)
+    want = O.train_step_single_gpu(spec, ls, params, state, c1.astype(np.float64), n1.astype(np.float64))[0]
+    assert abs(rec["first_loss"] - want) <= 2e-4 * abs(want), (rec["first_loss"], want)
+    assert rec["value"] > 0 and rec["cores"] == 2
