@@ -329,7 +329,11 @@ def pyramid_bench(args, torch, bf, O, rank, local_rank, world, dist):
             "round_trip_mean_abs_error": err,      # reference test bar: < 1e-7 (tests/bfcnn/test_pyramid.py)
             "roofline": {"bound": "hbm", "kernel": "lap_split_kernel + upsample2x_rows_kernel (one launch per level and direction)", "achieved": gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_step": nbytes},
+                         "algorithmic_bytes_per_step": nbytes,
+                         # rounds 1-2 counted the split as two kernels (3.5 n per level: x read twice, down read back); same time
+                         # against that figure, for comparison with their lines only
+                         "two_kernel_accounting": {"bytes_per_step": 4 * sum((3.5 + 2.25) * n / 4 ** l for l in range(levels - 1)),
+                                                   "gbs": 4 * sum((3.5 + 2.25) * n / 4 ** l for l in range(levels - 1)) * args.steps / elapsed / 1e9}},
             **({"cpu_baseline": cpu} if cpu is not None else {})}), flush=True)
 
 

@@ -263,6 +263,9 @@ struct BaseConvArgs {
     int* status;          // inference: forward status word, zeroed here (first kernel of a forward); may be NULL
 };
 hipError_t bf_launch_base_conv(const BaseConvArgs& a, hipStream_t s);
+bool       bf_base_conv_rows_supports(const BaseConvArgs& a);          // base_rows.hip: u8, 3x3x3 -> 16, [0, 255], split-planar out
+hipError_t bf_launch_base_conv_rows(const BaseConvArgs& a, hipStream_t s);
+void       bf_set_base_conv_rows(int on);     // 1 (default): the row-streaming matrix-core kernel where it applies; 0: vector kernel (A/B)
 // dW[k,k,cin,16] = sum xn (x) dy ; partial = [grid][k*k*cin*16]
 hipError_t bf_launch_base_wgrad(const float* in_f32, const float* dy, float* partial, float* dw,
                                 int B, int H, int W, int cin, int k, float v_min, float v_max, hipStream_t s);

@@ -120,8 +120,13 @@ static hipError_t launch_base(const BaseConvArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
+static int g_base_rows = 1;                           // 0: the vector kernel everywhere (A/B, tests)
+void bf_set_base_conv_rows(int on) { g_base_rows = on ? 1 : 0; }
+
 hipError_t bf_launch_base_conv(const BaseConvArgs& a, hipStream_t s)
 {
+    // the metric's configuration (u8 in, 3x3x3 -> 16, split-planar out): row-streaming matrix-core kernel (base_rows.hip)
+    if (g_base_rows && bf_base_conv_rows_supports(a)) return bf_launch_base_conv_rows(a, s);
 #define BF_BASE(C, KK) if (a.cin == C && a.k == KK) return launch_base<C, KK>(a, s);
     BF_BASE(3, 3) BF_BASE(3, 5) BF_BASE(3, 7) BF_BASE(3, 1)
     BF_BASE(1, 3) BF_BASE(1, 5) BF_BASE(1, 7) BF_BASE(1, 1)

@@ -206,6 +206,7 @@ extern "C" int bf_set_option(bf_handle h, const char* key, int value)
     if (!strcmp(key, "h3_zigzag")) { h->h3_zigzag = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "h3_compact")) { h->h3_compact = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "h3_pair")) { h->h3_pair = value ? 1 : 0; return BF_OK; }
+    if (!strcmp(key, "base_rows")) { bf_set_base_conv_rows(value); return BF_OK; }       // process-wide (A/B only)
     if (!strcmp(key, "h3_pair_head")) { h->h3_pair_head = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "fused_head")) { h->fused_head = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_zigzag")) { h->train_zigzag = value ? 1 : 0; return BF_OK; }

@@ -445,3 +445,25 @@ def test_random_engine_configurations_and_options_match_oracle(seed):
     x = noisy.astype(np.float32)
     _check_f32(np.asarray(m(x))[:2], O.hydra_forward(spec, params, state, x[:2].astype(np.float64)))
     _check_u8(bf.DenoiserModule(m)(noisy)[:2], O.denoiser_module_call(spec, params, state, noisy[:2]))
+
+
+@pytest.mark.parametrize("hw", [(64, 64), (17, 23), (40, 300), (1, 1), (33, 257)])
+def test_row_streaming_base_convolution_matches_the_vector_kernel_and_the_oracle(hw):
+    """base_conv_rows_kernel (u8 in, 3x3x3 -> 16 on the f16 matrix cores: exact u8 operands, the normalisation offset and the zero /
+    power-of-two padding carried by a fourth 'inside' channel) against the vector kernel (option base_rows = 0) and the oracle,
+    ragged sizes with the virtual padding on, more than one 256-column chunk."""
+    cfg, spec, params, state, m = _model(2, seed=17)
+    _, noisy = O.synthetic_batch(2, hw[0], hw[1], seed=11 + hw[0])
+    ref = O.denoiser_module_call(spec, params, state, noisy)
+    got = bf.DenoiserModule(m)(noisy)
+    _check_u8(got, ref)
+    f = bf.DenoiserModule(m, cast_to_uint8=False)(noisy)
+    _check_f32(f, O.denoiser_module_call(spec, params, state, noisy, cast_to_uint8=False))
+    m.set_option("base_rows", 0)
+    try:
+        other = bf.DenoiserModule(m)(noisy)
+        f0 = bf.DenoiserModule(m, cast_to_uint8=False)(noisy)
+    finally:
+        m.set_option("base_rows", 1)
+    assert np.abs(other.astype(int) - got.astype(int)).max() <= 1
+    assert np.abs(np.asarray(f0, np.float64) - np.asarray(f, np.float64)).mean() / 255.0 <= 2e-6
