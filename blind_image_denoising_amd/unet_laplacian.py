@@ -348,12 +348,15 @@ class UnetLaplacianHydra:
     def __init__(self, config: Dict, device=None, seed: Optional[int] = None):
         bb, dn = config["backbone"], config["denoiser"]
         self.config = config
-        for key, want in dict(use_bn=False, use_bias=False, use_concat=False,
+        for key, want in dict(use_bn=False, use_bias=False,
                               use_complex_base=False, use_value_compressor=False, use_global_pool_information=False,
                               multiple_scale_outputs=True).items():
-            default = True if key in ("use_concat", "multiple_scale_outputs") else False
+            default = True if key in ("multiple_scale_outputs",) else False
             if bb.get(key, default) != want:
                 raise NotImplementedError(f"unet_laplacian: {key}={bb.get(key, default)} is outside the built graph")
+        # Concatenate([encoder feature, upsampled]) instead of Add in the decoder nodes: the reference builder's default
+        # (backbone_unet_laplacian.py:52, 516-517); every shipped configuration sets it to false
+        self.use_concat = bool(bb.get("use_concat", True))
         self.downsample_type = bb.get("downsample_type", "strides").strip().lower()
         if self.downsample_type not in ("strides", "conv2d", "maxpool"):
             raise ValueError(f"don't know how to handle [{self.downsample_type}]")          # downsampling.py:73-75
@@ -398,6 +401,8 @@ class UnetLaplacianHydra:
         self.use_mix_project = bool(bb.get("use_mix_project", True))
         self.use_self_attention = bool(bb.get("use_self_attention", False))
         self.use_attention_gates = bool(bb.get("use_attention_gates", False))
+        if self.use_concat and self.use_attention_gates:
+            raise NotImplementedError("unet_laplacian: use_concat together with use_attention_gates is outside the built graph")
         self.use_output_normalization = bool(bb.get("use_output_normalization", False))
         # keras 2.13 cannot resolve the string "leaky_relu" ConvolutionalSelfAttention gives its Conv2D layers
         # (custom_layers.py:1272-1282); later keras resolve it to negative_slope 0.2, which is what is built here
@@ -430,6 +435,9 @@ class UnetLaplacianHydra:
                                           f"level only as the self-attention bottleneck)")
         if self.head_filters not in (32, 64, 128):
             raise NotImplementedError("denoiser head filters must be 32, 64 or 128")
+        if self.use_concat and not self.use_mix_project and 2 * self.level_filters(max(self.depth - 2, 0)) > 128 and self.depth > 1:
+            raise NotImplementedError("unet_laplacian: use_concat without use_mix_project runs the first decoder block of a level on 2 C "
+                                      "channels; the depthwise + LayerNorm operator takes up to 128")
 
         self.desc = self._Desc(self.in_channels, self.out_channels)
         self.device = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
@@ -463,7 +471,8 @@ class UnetLaplacianHydra:
         out = [("base/kernel", (5, 5, self.in_channels, self.filters), "conv")]
         A = self.filters
 
-        def block(prefix, C, k, attn):
+        def block(prefix, C, k, attn, cin=None):
+            cin = C if cin is None else cin              # first decoder block behind a Concatenate: 2 C channels in, C out
             if attn:
                 if self.use_ln:
                     out.append((f"{prefix}/ln/gamma", (C,), "ln_gamma"))
@@ -474,10 +483,10 @@ class UnetLaplacianHydra:
                 out.append((f"{prefix}/out/kernel", (1, 1, A, C), "conv"))
                 out.append((f"{prefix}/gamma/w", (C,), "multiplier"))
                 return
-            out.append((f"{prefix}/dw/kernel", (k, k, C, 1), "depthwise"))
+            out.append((f"{prefix}/dw/kernel", (k, k, cin, 1), "depthwise"))
             if self.use_ln:
-                out.append((f"{prefix}/ln/gamma", (C,), "ln_gamma"))
-            out.append((f"{prefix}/pw1/kernel", (1, 1, C, 4 * C), "conv"))
+                out.append((f"{prefix}/ln/gamma", (cin,), "ln_gamma"))
+            out.append((f"{prefix}/pw1/kernel", (1, 1, cin, 4 * C), "conv"))
             out.append((f"{prefix}/pw2/kernel", (1, 1, 4 * C, C), "conv"))
             if self.use_gamma:
                 out.append((f"{prefix}/gamma/w", (C,), "multiplier"))
@@ -506,10 +515,12 @@ class UnetLaplacianHydra:
                     out.append((f"gate{d}/y_ln/gamma", (C,), "ln_gamma"))
                 out.append((f"gate{d}/o/kernel", (1, 1, C, C), "conv"))
                 out.append((f"gate{d}/scale/w", (C,), "multiplier"))
+            cat = 2 * C if self.use_concat else C
             if self.use_mix_project:
-                out.append((f"mix{d}/kernel", (1, 1, C, C), "conv"))
+                out.append((f"mix{d}/kernel", (1, 1, cat, C), "conv"))
+                cat = C
             for w in range(self.width):
-                block(f"dec{d}_{w}", C, self.dec_k, False)
+                block(f"dec{d}_{w}", C, self.dec_k, False, cin=cat if w == 0 else C)
             if self.use_output_normalization and self.use_ln:
                 out.append((f"dec{d}/out_ln/gamma", (C,), "ln_gamma"))
         for i in range(self.depth):
@@ -582,8 +593,17 @@ class UnetLaplacianHydra:
                 P[name] = t.reshape(shape[0], shape[1], shape[2]).contiguous()
             else:
                 P[name] = t.contiguous()
+        if self.use_concat and self.use_mix_project:
+            # the 1x1 behind a Concatenate([enc, up]) = enc . W[:C] + up . W[C:]: the two halves as operands of their own, the
+            # concatenated map is never formed
+            for name, shape, kind, off in self.trainable_variables:
+                if name.startswith("mix") and name.endswith("/kernel"):
+                    C = shape[3]
+                    w = self.params[off:off + 2 * C * C].view(2 * C, C)
+                    P[name[:-len("/kernel")] + "/a"] = pack_pointwise(w[:C].contiguous().view(1, 1, C, C))
+                    P[name[:-len("/kernel")] + "/b"] = pack_pointwise(w[C:].contiguous().view(1, 1, C, C))
         for name, shape, kind, off in self.trainable_variables:
-            if name.endswith("/pw1/kernel") and shape[2] in (32, 64):
+            if name.endswith("/pw1/kernel") and shape[2] in (32, 64) and shape[3] == 4 * shape[2]:
                 prefix = name[:-len("/pw1/kernel")]
                 n1, n2 = int(np.prod(shape)), int(np.prod(shape))
                 o2 = dict((v[0], v[3]) for v in self.trainable_variables)[f"{prefix}/pw2/kernel"]
@@ -691,7 +711,8 @@ class UnetLaplacianHydra:
         for d in reversed(range(self.depth - 1)):
             low = outs[d + 1]
             C = self.level_filters(d)
-            skip = None if self.use_attention_gates else nodes[d]       # gated: the Add happens in the gate kernel
+            # gated: the Add happens in the gate kernel; Concatenate: the up-sampled map stays on its own
+            skip = None if (self.use_attention_gates or self.use_concat) else nodes[d]
             if self.upsample_type == "upsample_laplacian_conv2d":
                 # 1x1 and the bilinear resize are both linear: the 1x1 runs on the low-resolution map (1/4 of the work;
                 # upsampling.py:80-90 makes the same exchange itself when the activation is linear)
@@ -718,9 +739,24 @@ class UnetLaplacianHydra:
                 o = pointwise_ex(dwconv_ln(up, None, P.get(f"gate{d}/x_ln/gamma")) if self.use_ln else up, P[f"gate{d}/x/kernel"], C,
                                  1, "leaky_relu_01", res=y)
                 f = pointwise_ex(o, P[f"gate{d}/o/kernel"], C, 2, mult=P[f"gate{d}/scale/w"], res=enc, add=up)
-            if self.use_mix_project:
+            first = 0
+            if self.use_concat and self.use_mix_project:
+                # act(Concatenate([enc, up]) . W) = act(enc . W[:C] + up . W[C:])
+                t = pointwise(nodes[d], P[f"mix{d}/a"], C, "linear")
+                f = pointwise_ex(f, P[f"mix{d}/b"], C, 1, a, res=t)
+            elif self.use_concat:
+                # first decoder block on the 2 C channels of Concatenate([enc, up]): depthwise + LayerNorm over 2 C, 1x1 2C -> 4C,
+                # 1x1 4C -> C, multiplier, NO skip (the channel counts differ: backbone_unet_laplacian.py:557-560)
+                cat = torch.empty(f.shape[:-1] + (2 * C,), dtype=torch.float32, device=f.device)
+                _call("bf_op_concat_channels", N.ptr(nodes[d]), N.ptr(f), None, N.ptr(cat), f.numel() // C, C, C, 0, N.stream_ptr(f))
+                pre = f"dec{d}_0"
+                t = dwconv_ln(cat, P[f"{pre}/dw/kernel"], P.get(f"{pre}/ln/gamma") if self.use_ln else None)
+                hdn = pointwise(t, P[f"{pre}/pw1/kernel"], 4 * C, self.mlp_activation)
+                f = pointwise(hdn, P[f"{pre}/pw2/kernel"], C, "linear", mult=P.get(f"{pre}/gamma/w") if self.use_gamma else None)
+                first = 1
+            elif self.use_mix_project:
                 f = pointwise(f, P[f"mix{d}/kernel"], self.level_filters(d), a)
-            for w in range(self.width):
+            for w in range(first, self.width):
                 f = self._convnext(P, f"dec{d}_{w}", f)
             if self.use_output_normalization and self.use_ln and not self.output_norm_at_heads \
                     and not (defer_output_norm and d == 0):

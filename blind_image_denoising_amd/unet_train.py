@@ -124,6 +124,7 @@ class UnetTrainGraph:
             bad.append(f"upsample_type {model.upsample_type}")
         if model.activation == "gelu": bad.append("gelu outside the convnext MLP / the attention projections")
         if model.activation == "linear": bad.append("linear activation")
+        if getattr(model, "use_concat", False): bad.append("use_concat (the Concatenate decoder runs at inference only)")
         if bad:
             raise NotImplementedError("unet_laplacian training is built for the configs/unet_laplacian_v5.json graph family: " + ", ".join(bad))
         self.loss_config = dict(loss_config)

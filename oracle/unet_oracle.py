@@ -160,6 +160,7 @@ class UnetLaplacianSpec:
     use_laplacian: bool = True
     use_laplacian_averaging: bool = True
     use_mix_project: bool = False
+    use_concat: bool = False                  # the reference builder's default is True (backbone_unet_laplacian.py:52); every shipped config: false
     use_self_attention: bool = True
     use_attention_gates: bool = False
     use_output_normalization: bool = True
@@ -188,11 +189,13 @@ class UnetLaplacianSpec:
         bb, dn = model_config["backbone"], model_config["denoiser"]
         if bb["type"] != "unet_laplacian":
             raise ValueError(bb["type"])
-        unsupported = dict(use_bn=False, use_bias=False, use_concat=False,
+        unsupported = dict(use_bn=False, use_bias=False,
                            use_complex_base=False, multiple_scale_outputs=True)
         for k, v in unsupported.items():
             if bb.get(k, v) != v:
                 raise NotImplementedError(f"{k}={bb[k]} is outside the restated graph")
+        if bb.get("use_concat", True) and bb.get("use_attention_gates", False):
+            raise NotImplementedError("use_concat with use_attention_gates is outside the restated graph")
         vr = bb.get("value_range", [0, 255])
         return UnetLaplacianSpec(
             depth=bb.get("depth", 5), width=max(bb.get("width", 1) or 1, 1), filters=bb.get("filters", 32),
@@ -203,6 +206,7 @@ class UnetLaplacianSpec:
             filters_level_multiplier=float(bb.get("filters_level_multiplier", 2.0)),
             use_ln=bb.get("use_ln", True), use_gamma=bb.get("use_gamma", True), use_laplacian=bb.get("use_laplacian", True),
             use_laplacian_averaging=bb.get("use_laplacian_averaging", True), use_mix_project=bb.get("use_mix_project", True),
+            use_concat=bb.get("use_concat", True),
             use_self_attention=bb.get("use_self_attention", False),
             use_attention_gates=bb.get("use_attention_gates", False),
             use_output_normalization=bb.get("use_output_normalization", False),
@@ -222,7 +226,8 @@ class UnetLaplacianSpec:
         out = [("base/kernel", (5, 5, self.in_channels, self.filters), "conv")]       # :296-309 (always 5x5)
         A = self.filters                                                               # attention_channels=filters (:329)
 
-        def block(prefix, C, k, attention):
+        def block(prefix, C, k, attention, cin=None):
+            cin = C if cin is None else cin              # first decoder block behind a Concatenate: 2 C channels in, C out
             if attention:
                 if self.use_ln:
                     out.append((f"{prefix}/ln/gamma", (C,), "ln_gamma"))
@@ -233,10 +238,10 @@ class UnetLaplacianSpec:
                 out.append((f"{prefix}/out/kernel", (1, 1, A, C), "conv"))
                 out.append((f"{prefix}/gamma/w", (C,), "multiplier"))
                 return
-            out.append((f"{prefix}/dw/kernel", (k, k, C, 1), "depthwise"))
+            out.append((f"{prefix}/dw/kernel", (k, k, cin, 1), "depthwise"))
             if self.use_ln:
-                out.append((f"{prefix}/ln/gamma", (C,), "ln_gamma"))
-            out.append((f"{prefix}/pw1/kernel", (1, 1, C, 4 * C), "conv"))
+                out.append((f"{prefix}/ln/gamma", (cin,), "ln_gamma"))
+            out.append((f"{prefix}/pw1/kernel", (1, 1, cin, 4 * C), "conv"))
             out.append((f"{prefix}/pw2/kernel", (1, 1, 4 * C, C), "conv"))
             if self.use_gamma:
                 out.append((f"{prefix}/gamma/w", (C,), "multiplier"))
@@ -265,10 +270,12 @@ class UnetLaplacianSpec:
                     out.append((f"gate{d}/y_ln/gamma", (C,), "ln_gamma"))
                 out.append((f"gate{d}/o/kernel", (1, 1, C, C), "conv"))
                 out.append((f"gate{d}/scale/w", (C,), "multiplier"))
+            cat = 2 * C if self.use_concat else C           # Concatenate([encoder feature, upsampled]) (:516-517)
             if self.use_mix_project:
-                out.append((f"mix{d}/kernel", (1, 1, C, C), "conv"))
+                out.append((f"mix{d}/kernel", (1, 1, cat, C), "conv"))
+                cat = C
             for w in range(self.width):
-                block(f"dec{d}_{w}", C, self.decoder_kernel_size, False)
+                block(f"dec{d}_{w}", C, self.decoder_kernel_size, False, cin=cat if w == 0 else C)
             if self.use_output_normalization and self.use_ln:
                 out.append((f"dec{d}/out_ln/gamma", (C,), "ln_gamma"))
         for i in range(self.depth):
@@ -419,11 +426,12 @@ def backbone_forward(spec: UnetLaplacianSpec, P: Dict[str, np.ndarray], xn: np.n
             xg = conv(layer_norm(up, P[f"gate{d}/x_ln/gamma"]) if spec.use_ln else up, P[f"gate{d}/x/kernel"])
             o = channel_multiplier(conv(leaky(xg + yg, 0.1), P[f"gate{d}/o/kernel"]), P[f"gate{d}/scale/w"])
             enc = enc * (1.0 / (1.0 + np.exp(-4.0 * o)))
-        x = enc + up                                                     # use_concat False: Add (:514)
+        x = np.concatenate([enc, up], axis=-1) if spec.use_concat else enc + up      # Concatenate / Add (:516-519)
         if spec.use_mix_project:
             x = act(conv(x, P[f"mix{d}/kernel"]), a)
         for w in range(spec.width):
-            x = x + convnext(f"dec{d}_{w}", x)
+            y = convnext(f"dec{d}_{w}", x)
+            x = x + y if y.shape[-1] == x.shape[-1] else y               # the skip only where the channel counts agree (:557-560)
         if spec.use_output_normalization and spec.use_ln and not spec.output_norm_at_heads:
             x = layer_norm(x, P[f"dec{d}/out_ln/gamma"])
         outs[d] = x

@@ -107,6 +107,7 @@ def check_trainable_graph(spec: U.UnetLaplacianSpec):
     if spec.upsample_type not in ("upsample_laplacian_conv2d", "upsample_nearest_conv2d", "upsample_bilinear_conv2d", "bilinear", "nn", "nearest"):
         bad.append(f"upsample_type {spec.upsample_type}")
     if not (spec.use_laplacian or spec.use_laplacian_averaging): bad.append("no laplacian split")
+    if getattr(spec, "use_concat", False): bad.append("use_concat (inference only)")
     if bad:
         raise NotImplementedError("unet_laplacian training: " + ", ".join(bad))
 

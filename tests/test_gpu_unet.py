@@ -455,7 +455,7 @@ def test_shape_and_config_errors():
     cfg, spec, params, m = _model(seed=2)
     with pytest.raises(ValueError, match="multiples of 4"):
         m(np.zeros((1, 30, 64, 3), np.float32))
-    bad = U.canonical_config()["model"]; bad["backbone"]["use_concat"] = True
+    bad = U.canonical_config()["model"]; bad["backbone"]["use_complex_base"] = True
     with pytest.raises(NotImplementedError):
         bf.model_builder(bad, device="cuda")
 
@@ -484,6 +484,37 @@ def test_conv2d_transpose_matches_oracle(k, s, shape):
         assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("mix", [True, False], ids=["mix_project", "no_mix"])
+@pytest.mark.parametrize("depth,width", [(2, 1), (3, 2), (2, 3)])
+@pytest.mark.parametrize("arith", [1, 0], ids=["f16x3", "f32"])
+def test_use_concat_decoder(mix, depth, width, arith):
+    """use_concat = True, the reference builder's DEFAULT (backbone_unet_laplacian.py:52, 516-517): the decoder nodes Concatenate the
+    encoder feature and the up-sampled map instead of adding them.  With use_mix_project the 1x1 behind the Concatenate runs as two
+    half-matrices (the 2 C map is never formed); without it the first decoder block of a level works on 2 C channels (depthwise,
+    LayerNorm, 1x1 2C -> 4C -> C, no skip).  Every output scale against the oracle, u8 through the module."""
+    cfg, spec, params, m = _model(depth=depth, width=width, seed=5 + depth, arith=arith, use_concat=True, use_mix_project=mix)
+    assert spec.use_concat and m.use_concat
+    S = 16 * 2 ** (depth - 2)
+    _, noisy = O.synthetic_batch(2, 2 * S, 3 * S, seed=depth)
+    x = noisy.astype(np.float32)
+    got = m(x)
+    ref = U.hydra_forward(spec, params, x.astype(np.float64))
+    assert len(got) == len(ref)
+    for g, r in zip(got, ref):
+        _check_f32(g, r)
+    _check_u8(bf.DenoiserModule(m)(noisy), U.denoiser_module_call(spec, params, noisy))
+
+
+def test_use_concat_is_refused_where_it_is_not_built():
+    cfg = U.canonical_config(depth=3, width=1)
+    cfg["model"]["backbone"].update(use_concat=True, use_attention_gates=True)
+    with pytest.raises(NotImplementedError):
+        bf.model_builder(cfg["model"], device="cuda")
+    cfg["model"]["backbone"].update(use_attention_gates=False, use_mix_project=False, depth=4)      # level 2: 2 x 128 channels
+    with pytest.raises(NotImplementedError):
+        bf.model_builder(cfg["model"], device="cuda")
+
+
 def _random_unet_backbone(rng):
     """a random point of the unet_laplacian builder's option space (backbone_unet_laplacian.py:35-130), filters 32"""
     depth = int(rng.integers(2, 5))
@@ -493,6 +524,7 @@ def _random_unet_backbone(rng):
               use_ln=bool(rng.random() < 0.8), use_gamma=bool(rng.random() < 0.8),
               use_mix_project=bool(rng.random() < 0.3), use_self_attention=bool(rng.random() < 0.6),
               use_attention_gates=bool(rng.random() < 0.3), use_output_normalization=bool(rng.random() < 0.7),
+              use_concat=bool(rng.random() < 0.3),
               use_laplacian=True, use_laplacian_averaging=bool(rng.random() < 0.5), gaussian_kernel_size=int(rng.choice([2, 3, 5])),
               downsample_type=str(rng.choice(["strides", "conv2d", "maxpool"])),
               upsample_type=str(rng.choice(["upsample_laplacian_conv2d", "upsample_bilinear_conv2d", "upsample_nearest_conv2d", "bilinear", "nn"])))

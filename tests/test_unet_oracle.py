@@ -137,7 +137,8 @@ def test_product_rejects_what_the_reference_rejects_and_what_is_not_built():
         bf.model_builder(_cfg(convolutional_self_attention_dropout_rate=1.5), device="cpu")
     with pytest.raises(ValueError, match="only one"):
         bf.model_builder(_cfg(use_soft_orthogonal_regularization=True), device="cpu")
-    for bad in (dict(use_concat=True), dict(use_bn=True), dict(depth=4, use_self_attention=False), dict(depth=5),
+    for bad in (dict(use_concat=True, use_attention_gates=True), dict(use_concat=True, use_mix_project=False, depth=4),
+                dict(use_bn=True), dict(depth=4, use_self_attention=False), dict(depth=5),
                 dict(upsample_type="conv2d_transpose")):
         with pytest.raises(NotImplementedError):
             bf.model_builder(_cfg(**bad), device="cpu")
@@ -173,3 +174,22 @@ def test_conv2d_transpose_same_against_torch(k, s):
     y = rng.standard_normal(got.shape)
     fwd = O.conv2d_same(y, w, stride=s)                                    # [k,k,4,3] as HWIO: 4 -> 3 channels, big -> small
     assert abs((fwd * x).sum() - (y * got).sum()) < 1e-9 * max(1.0, abs((y * got).sum()))
+
+
+@pytest.mark.parametrize("mix", [True, False])
+def test_use_concat_inventory_and_shapes(mix):
+    """use_concat = True (the reference builder's default, backbone_unet_laplacian.py:52, 516-517): the model's parameter inventory is the
+    oracle's, the 1x1 behind the Concatenate takes 2 C channels, without it the first decoder block of a level does (and has no skip)."""
+    import blind_image_denoising_amd as bf
+    cfg = _cfg(depth=3, width=2, use_concat=True, use_mix_project=mix)
+    spec = U.UnetLaplacianSpec.from_config(cfg)
+    m = bf.model_builder(cfg, device="cpu", seed=0).hydra
+    assert [(v[0], tuple(v[1])) for v in m.trainable_variables] == [(n, tuple(s)) for n, s, _ in spec.tensors()]
+    shapes = dict((n, s) for n, s, _ in spec.tensors())
+    if mix:
+        assert shapes["mix0/kernel"] == (1, 1, 64, 32) and shapes["dec0_0/pw1/kernel"] == (1, 1, 32, 128)
+    else:
+        assert shapes["dec0_0/dw/kernel"][2] == 64 and shapes["dec0_0/pw1/kernel"] == (1, 1, 64, 128) and shapes["dec0_1/pw1/kernel"] == (1, 1, 32, 128)
+    x = np.random.default_rng(1).uniform(0, 255, (1, 16, 16, 3))
+    outs = U.hydra_forward(spec, U.init_params(spec, seed=1), x)
+    assert [o.shape for o in outs] == [(1, 16, 16, 3), (1, 8, 8, 3), (1, 4, 4, 3)]
