@@ -32,6 +32,32 @@
 //     not values computed from padded input).
 #include "h3v_core.h"
 
+// wave priorities (s_setprio) per role; H3W_PRIO_SET picks a preset for A/B builds: 1 = younger roles higher (0,1,2,3),
+// 2 = older roles higher (3,2,1,0), 3 = second convolutions high (0,2,0,2), 4 = first convolutions high (2,0,2,0)
+#ifndef H3W_PRIO_SET
+#define H3W_PRIO_SET 0
+#endif
+#if H3W_PRIO_SET == 1
+#define H3W_PRIO_A1 0
+#define H3W_PRIO_B1 1
+#define H3W_PRIO_A2 2
+#define H3W_PRIO_B2 3
+#elif H3W_PRIO_SET == 2
+#define H3W_PRIO_A1 3
+#define H3W_PRIO_B1 2
+#define H3W_PRIO_A2 1
+#define H3W_PRIO_B2 0
+#elif H3W_PRIO_SET == 3
+#define H3W_PRIO_A1 0
+#define H3W_PRIO_B1 2
+#define H3W_PRIO_A2 0
+#define H3W_PRIO_B2 2
+#elif H3W_PRIO_SET == 4
+#define H3W_PRIO_A1 2
+#define H3W_PRIO_B1 0
+#define H3W_PRIO_A2 2
+#define H3W_PRIO_B2 0
+#endif
 #ifndef H3W_PRIO_A1
 #define H3W_PRIO_A1 1
 #endif
@@ -120,6 +146,7 @@ struct H3WRoleA {
     int wr;                      // lane's LDS byte offset of its 8-byte hi record in mid ring slot 0, group 0 (lo: + 2 planes)
     float inv_s, relu_floor;
     float lane_scale[Gm::G];     // inv_s where the lane's column is inside the image, else 0
+    bool skip_last = false;      // timing experiment (H3V_ABLATE & 256): the role's third wave multiplies two groups only
 
     __device__ __forceinline__ void init(const void* wimg, const FusedH3WArgs& a, const float* aux, const int lane, const int gc0)
     {
@@ -170,7 +197,7 @@ struct H3WRoleA {
     {
         if constexpr (J < 15) {
             constexpr int k = J / 3, which = J % 3;
-            if (!(H3V_ABLATE & 8)) {
+            if (!(H3V_ABLATE & 8) && !(skip_last && g == Gm::G - 1)) {
                 if constexpr (which == 0) acc[g][a2] = h3v_mfma(cur, w, 2, k, acc[g][a2]);
                 else if constexpr (which == 1) acc[g][a1] = h3v_mfma(cur, w, 1, k, acc[g][a1]);
                 else c0 = h3v_mfma(cur, w, 0, k, c0);
@@ -231,6 +258,7 @@ struct H3WRoleB {
     float inv_s2;
     f32x4 shs;                   // folded BN shift of the lane's four channels times s2 (the accumulators' scale)
     float lane_scale[Gm::G];
+    bool skip_last = false;      // timing experiment (H3V_ABLATE & 256)
 
     __device__ __forceinline__ void init(const void* wimg, const FusedH3WArgs& a, const float* aux, const int lane, const int gc0,
                                          const bool out_is_ring)
@@ -286,7 +314,7 @@ struct H3WRoleB {
     __device__ __forceinline__ void mfmas(const int g, const int a1, const int a2, const H3VFrag& cur, const h8 xr, f32x4& c0, Epi* epi)
     {
         if constexpr (J < 16) {
-            if (!(H3V_ABLATE & 4)) {
+            if (!(H3V_ABLATE & 4) && !(skip_last && g == Gm::G - 1)) {
                 if constexpr (J == 0) {
                     // residual: (s2 * I) x [x_hi | x_lo], exact, on top of the folded BN shift (times s2) as the C operand
                     c0 = MFMA_H(w[12], xr, shs);
@@ -618,6 +646,7 @@ __global__ __launch_bounds__(H3WGeom::NT, 3) void fused_block2_h3w_kernel(FusedH
         H3WRoleA<Gm::X0_PLANE> R;
         R.tin = tx0; R.tmid = tm1;
         R.init(a.w1r[0], a, a.aux[0], lane, gc0);
+        R.skip_last = (H3V_ABLATE & 256) && rw == Gm::NR - 1;
         H3WMem<(HEAD && h3w_mem_kind(0) == 2) ? 3 : h3w_mem_kind(0)> M(a, tx0, tout, rw, plane_g);
         __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));               // weight / scale loads
 #define H3W_ACTIVE(s) ((s) < t.nrows + 8)
@@ -631,6 +660,7 @@ __global__ __launch_bounds__(H3WGeom::NT, 3) void fused_block2_h3w_kernel(FusedH
         H3WRoleB<Gm::X0_PLANE, Gm::X1_PLANE> R;
         R.tmid = tm1; R.tres = tx0; R.tout = tx1;
         R.init(a.w2r[0], a, a.aux[0], lane, gc0, true);
+        R.skip_last = (H3V_ABLATE & 256) && rw == Gm::NR - 1;
         H3WMem<(HEAD && h3w_mem_kind(1) == 2) ? 3 : h3w_mem_kind(1)> M(a, tx0, tout, rw, plane_g);
         __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));
 #define H3W_ACTIVE(s) (((s) >= 3) & ((s) < t.nrows + 9))
@@ -644,6 +674,7 @@ __global__ __launch_bounds__(H3WGeom::NT, 3) void fused_block2_h3w_kernel(FusedH
         H3WRoleA<Gm::X1_PLANE> R;
         R.tin = tx1; R.tmid = tm2;
         R.init(a.w1r[1], a, a.aux[1], lane, gc0);
+        R.skip_last = (H3V_ABLATE & 256) && rw == Gm::NR - 1;
         H3WMem<(HEAD && h3w_mem_kind(2) == 2) ? 3 : h3w_mem_kind(2)> M(a, tx0, tout, rw, plane_g);
         __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));
 #define H3W_ACTIVE(s) (((s) >= 6) & ((s) < t.nrows + 10))
@@ -657,6 +688,7 @@ __global__ __launch_bounds__(H3WGeom::NT, 3) void fused_block2_h3w_kernel(FusedH
         H3WRoleB<Gm::X1_PLANE, Gm::OUT_PLANE> R;
         R.tmid = tm2; R.tres = tx1; R.tout = tout;
         R.init(a.w2r[1], a, a.aux[1], lane, gc0, false);
+        R.skip_last = (H3V_ABLATE & 256) && rw == Gm::NR - 1;
         H3WMem<(HEAD && h3w_mem_kind(3) == 2) ? 3 : h3w_mem_kind(3)> M(a, tx0, tout, rw, plane_g);
         __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));
 #define H3W_ACTIVE(s) (((s) >= 9) & ((s) < t.nrows + 11))
