@@ -327,7 +327,7 @@ def pyramid_bench(args, torch, bf, O, rank, local_rank, world, dist):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"laplacian pyramid (avg-pool 5x5 s2 SAME, bilinear x2) + inverse, batch={B} {S}x{S}x{C} float32"},
             "round_trip_mean_abs_error": err,      # reference test bar: < 1e-7 (tests/bfcnn/test_pyramid.py)
-            "roofline": {"bound": "hbm", "kernel": "lap_split_kernel + upsample2x_rows_kernel (one launch per level and direction)", "achieved": gbs,
+            "roofline": {"bound": "hbm", "kernel": "lap_split_kernel + upsample2x_band_kernel (one launch per level and direction)", "achieved": gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_step": nbytes,
                          # rounds 1-2 counted the split as two kernels (3.5 n per level: x read twice, down read back); same time

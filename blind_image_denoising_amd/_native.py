@@ -172,6 +172,7 @@ SIGNATURES = {
     "bf_debug_fused_block2_h3_scratch_floats": (_I64, [_I, _I, _I]),
     "bf_debug_fused_block2_h3": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "bf_debug_set_h3_variant": (_I, [_I]),
+    "bf_debug_set_upsample_band": (_I, [_I]),
     "bf_debug_conv3x3_h3_scratch_floats": (_I64, []),
     "bf_debug_conv3x3_h3": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "bf_debug_wgrad_partial_floats": (_I64, [_I, _I, _I]),

@@ -55,6 +55,8 @@ int bf_debug_bwd3x3_h3(const float* x, const float* g, const float* c, const flo
                        const float* res, const float* bnc, float* dw, float* stats, float* scratch, int batch, int height,
                        int width, int epi, int reverse, int repack, void* stream);
 int bf_debug_mfma_probe(const float* a, const float* b, float* d, void* stream);
+/* bf_upsample2x on C % 4 != 0 maps: 1 (default) the row-walking 16-byte kernel, 0 the 4-byte row kernel (same bits; A/B and tests) */
+int bf_debug_set_upsample_band(int on);
 
 #ifdef __cplusplus
 }

@@ -149,3 +149,27 @@ def test_fused_laplacian_split_is_bitwise_the_two_kernels(shape, k):
     rd = O.avg_pool_same(x64, k)
     assert np.abs(down_f.cpu().numpy() - rd).max() < 1e-5
     assert np.abs(lap_f.cpu().numpy() - (x64 - O.upsample_bilinear_2x(rd))).max() < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32, 3), (1, 256, 256, 3), (3, 20, 28, 3), (2, 9, 10, 1), (1, 48, 65, 2), (1, 1, 2, 3), (2, 35, 18, 6),
+                                   (1, 150, 130, 3)])
+@pytest.mark.parametrize("with_other", [True, False])
+def test_upsample_band_kernel_is_bitwise_the_row_kernel(shape, with_other):
+    """bf_upsample2x on C % 4 != 0 maps: the row-walking 16-byte kernel (default) against the 4-byte row kernel -- bitwise -- and the
+    oracle; the merge step of the inverse Laplacian pyramid (alpha = beta = 1) and the bare up-sampling, shapes around the chunk / band
+    boundaries."""
+    from blind_image_denoising_amd import _native as N
+    rng = np.random.default_rng(sum(shape))
+    x = torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).cuda()
+    B, H, W, C = shape
+    other = torch.from_numpy(rng.standard_normal((B, 2 * H, 2 * W, C)).astype(np.float32)).cuda() if with_other else None
+    got = P.upsample_2x(x, other, True, 0.5 if not with_other else 1.0, 1.0)
+    N.lib().bf_debug_set_upsample_band(0)
+    try:
+        ref_rows = P.upsample_2x(x, other, True, 0.5 if not with_other else 1.0, 1.0)
+    finally:
+        N.lib().bf_debug_set_upsample_band(1)
+    assert torch.equal(got, ref_rows)
+    up = O.upsample_bilinear_2x(x.cpu().numpy().astype(np.float64))
+    want = up + other.cpu().numpy() if with_other else 0.5 * up
+    assert np.abs(got.cpu().numpy() - want).max() < 1e-5
