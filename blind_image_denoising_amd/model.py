@@ -304,6 +304,14 @@ class HydraModel:
         else:
             N.check(self._lib.bf_set_option(self._h, key.encode(), int(value)), self._h)
 
+    def block_kernel(self):
+        """(name of the kernel that ran most of the residual-block launches of the last forward, block launches of that forward),
+        as the library reports them (bf_get_block_kernel): what a profile of the run must show."""
+        import ctypes as C
+        n = C.c_int()
+        name = self._lib.bf_get_block_kernel(self._h, C.byref(n))
+        return (name.decode() if name else ""), int(n.value)
+
     # ---- execution -----------------------------------------------------------------------
     def _as_device(self, x, dtype):
         was_numpy = isinstance(x, np.ndarray)

@@ -467,3 +467,27 @@ def test_row_streaming_base_convolution_matches_the_vector_kernel_and_the_oracle
         m.set_option("base_rows", 1)
     assert np.abs(other.astype(int) - got.astype(int)).max() <= 1
     assert np.abs(np.asarray(f0, np.float64) - np.asarray(f, np.float64)).mean() / 255.0 <= 2e-6
+
+
+def test_library_reports_the_block_kernel_it_launched():
+    """bf_get_block_kernel: bench.py keys its roofline and the committed counter traffic on this name, so it must follow the
+    variant selection (batch size, options), not be derived from options by the caller."""
+    cfg, spec, params, state, m = _model(4, seed=3)
+    _, small = O.synthetic_batch(2, 32, 32, seed=1)
+    _, big = O.synthetic_batch(16, 192, 64, seed=2)             # 3 072 image rows: the streaming kernels
+    mod = bf.DenoiserModule(m)
+    mod(small)
+    assert m.block_kernel() == ("fused_block_h3r_kernel", 4)
+    mod(big)
+    assert m.block_kernel() == ("fused_block2_h3w_kernel", 2)
+    m.set_option("h3_pair", 0)
+    mod(big)
+    assert m.block_kernel() == ("fused_block_h3v_kernel", 4)
+    m.set_option("h3_pair", 1)
+    m.set_option("arith", 0)
+    mod(big)
+    assert m.block_kernel() == ("fused_block_v4_kernel", 4)
+    m.set_option("arith", 1)
+    cfg3, spec3, params3, state3, m3 = _model(3, seed=3)       # odd count: the single block first, then a pair
+    bf.DenoiserModule(m3)(big)
+    assert m3.block_kernel() == ("fused_block2_h3w_kernel", 2)
