@@ -848,6 +848,7 @@ extern "C" int bf_op_dwconv_ln(const float* in, float* out, const float* w, cons
     }
     UO_DW(32, 0) UO_DW(32, 1) UO_DW(32, 3) UO_DW(32, 5) UO_DW(64, 0) UO_DW(64, 1) UO_DW(64, 3) UO_DW(64, 5)
     UO_DW(128, 0) UO_DW(128, 1) UO_DW(128, 3) UO_DW(128, 5) UO_DW(256, 0)
+    UO_DW(256, 1) UO_DW(256, 3) UO_DW(256, 5)            // a 256-channel ConvNext level (the deepest level of a four-level model)
 #undef UO_DW
     if (!ok) return BF_EUNSUPPORTED;
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;

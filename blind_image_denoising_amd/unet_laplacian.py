@@ -429,10 +429,12 @@ class UnetLaplacianHydra:
         self.out_channels = int(dn.get("output_channels", 3))
         for d in range(self.depth):
             C = self.level_filters(d)
-            ok = C in (32, 64, 128) or (C == 256 and d == self.depth - 1 and self.use_self_attention)
+            # 256 channels: the deepest level only -- as the self-attention bottleneck, or as ConvNext blocks whose MLP runs in
+            # 128-channel slices of the hidden layer over the existing 1x1 operators (_convnext)
+            ok = C in (32, 64, 128) or (C == 256 and d == self.depth - 1)
             if not ok:
-                raise NotImplementedError(f"unet_laplacian: level {d} has {C} channels (ConvNext levels: 32/64/128; a 256-channel "
-                                          f"level only as the self-attention bottleneck)")
+                raise NotImplementedError(f"unet_laplacian: level {d} has {C} channels (ConvNext levels: 32/64/128, and 256 at the "
+                                          f"deepest level)")
         if self.head_filters not in (32, 64, 128):
             raise NotImplementedError("denoiser head filters must be 32, 64 or 128")
         if self.use_concat and not self.use_mix_project and 2 * self.level_filters(max(self.depth - 2, 0)) > 128 and self.depth > 1:
@@ -583,7 +585,9 @@ class UnetLaplacianHydra:
             if off % 4:                                          # operators want 16-byte aligned buffers
                 t = t.clone()
             t = t.view(shape)
-            if kind == "conv" and shape[0] == 1 and shape[2] % 16 == 0 and shape[3] % 16 == 0:
+            if kind == "conv" and shape[0] == 1 and shape[2] * shape[3] >= 256 * 1024:
+                P[name] = t.contiguous()                         # (256-channel MLP: packed in slices below)
+            elif kind == "conv" and shape[0] == 1 and shape[2] % 16 == 0 and shape[3] % 16 == 0:
                 P[name] = pack_pointwise(t)
             elif kind == "conv" and shape[0] > 1 and shape[2] % 16 == 0 and shape[3] % 16 == 0:
                 P[name] = pack_conv(t)
@@ -593,6 +597,16 @@ class UnetLaplacianHydra:
                 P[name] = t.reshape(shape[0], shape[1], shape[2]).contiguous()
             else:
                 P[name] = t.contiguous()
+        for name, shape, kind, off in self.trainable_variables:
+            # 256-channel ConvNext MLP (256 -> 1024 -> 256): the hidden layer in eight slices of 128 channels, each a pair of 1x1
+            # operators the library has (256 -> 128, 128 -> 256); the full kernels are not packed (no operator takes them)
+            if name.endswith("/pw1/kernel") and shape[2] == 256 and shape[3] == 1024:
+                prefix = name[:-len("/pw1/kernel")]
+                w1 = self.params[off:off + 256 * 1024].view(256, 1024)
+                o2 = dict((v[0], v[3]) for v in self.trainable_variables)[f"{prefix}/pw2/kernel"]
+                w2 = self.params[o2:o2 + 1024 * 256].view(1024, 256)
+                P[f"{prefix}/mlp256"] = [(pack_pointwise(w1[:, 128 * j:128 * (j + 1)].contiguous().view(1, 1, 256, 128)),
+                                          pack_pointwise(w2[128 * j:128 * (j + 1)].contiguous().view(1, 1, 128, 256))) for j in range(8)]
         if self.use_concat and self.use_mix_project:
             # the 1x1 behind a Concatenate([enc, up]) = enc . W[:C] + up . W[C:]: the two halves as operands of their own, the
             # concatenated map is never formed
@@ -639,6 +653,16 @@ class UnetLaplacianHydra:
         if self.arith == 1 and f"{prefix}/mlp_h3" in P and dw.shape[0] in (3, 5) and x.shape[-1] == 32:
             return convnext_block_h3(x, dw, gamma, P[f"{prefix}/mlp_h3"], mult, self.mlp_activation)
         t = dwconv_ln(x, dw, gamma)
+        if f"{prefix}/mlp256" in P:
+            # 256 channels: out = x + m * sum_j act(t . W1[:, j]) . W2[j, :] over eight 128-channel slices of the hidden layer
+            acc = None
+            for w1p, w2p in P[f"{prefix}/mlp256"]:
+                hdn = pointwise(t, w1p, 128, self.mlp_activation)
+                acc = pointwise(hdn, w2p, 256, "linear", res=acc)
+            out = torch.empty_like(x)
+            B = x.shape[0]
+            _call("bf_op_scale_add", N.ptr(x), N.ptr(acc), N.ptr(mult), None, N.ptr(out), B, x.numel() // (B * 256), 256, N.stream_ptr(x))
+            return out
         if self.arith == 1 and f"{prefix}/mlp_h3" in P:
             return convnext_mlp_h3(t, x, P[f"{prefix}/mlp_h3"], mult, self.mlp_activation)
         return convnext_mlp(t, x, P[f"{prefix}/pw1/kernel"], P[f"{prefix}/pw2/kernel"],

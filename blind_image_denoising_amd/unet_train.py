@@ -125,6 +125,8 @@ class UnetTrainGraph:
         if model.activation == "gelu": bad.append("gelu outside the convnext MLP / the attention projections")
         if model.activation == "linear": bad.append("linear activation")
         if getattr(model, "use_concat", False): bad.append("use_concat (the Concatenate decoder runs at inference only)")
+        if any(model.level_filters(d) == 256 and not model._is_attention(d) for d in range(model.depth)):
+            bad.append("a 256-channel ConvNext level (runs at inference only)")
         if bad:
             raise NotImplementedError("unet_laplacian training is built for the configs/unet_laplacian_v5.json graph family: " + ", ".join(bad))
         self.loss_config = dict(loss_config)

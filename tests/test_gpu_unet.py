@@ -505,6 +505,24 @@ def test_use_concat_decoder(mix, depth, width, arith):
     _check_u8(bf.DenoiserModule(m)(noisy), U.denoiser_module_call(spec, params, noisy))
 
 
+@pytest.mark.parametrize("width,enc_k,dec_k", [(1, 5, 3), (2, 3, 1)])
+@pytest.mark.parametrize("arith", [1, 0], ids=["f16x3", "f32"])
+def test_256_channel_convnext_level(width, enc_k, dec_k, arith):
+    """a four-level model WITHOUT the self-attention bottleneck: its deepest level is ConvNext blocks on 256 channels (depthwise +
+    LayerNorm over 256, the 256 -> 1024 -> 256 MLP in eight 128-channel slices of the hidden layer over the library's 1x1 operators).
+    Every output scale against the oracle."""
+    cfg, spec, params, m = _model(depth=4, width=width, seed=9, arith=arith, use_self_attention=False,
+                                  encoder_kernel_size=enc_k, decoder_kernel_size=dec_k)
+    assert spec.level_filters(3) == 256
+    _, noisy = O.synthetic_batch(2, 32, 48, seed=4)
+    x = noisy.astype(np.float32)
+    got = m(x)
+    ref = U.hydra_forward(spec, params, x.astype(np.float64))
+    for g, r in zip(got, ref):
+        _check_f32(g, r)
+    _check_u8(bf.DenoiserModule(m)(noisy), U.denoiser_module_call(spec, params, noisy))
+
+
 def test_use_concat_is_refused_where_it_is_not_built():
     cfg = U.canonical_config(depth=3, width=1)
     cfg["model"]["backbone"].update(use_concat=True, use_attention_gates=True)

@@ -138,7 +138,7 @@ def test_product_rejects_what_the_reference_rejects_and_what_is_not_built():
     with pytest.raises(ValueError, match="only one"):
         bf.model_builder(_cfg(use_soft_orthogonal_regularization=True), device="cpu")
     for bad in (dict(use_concat=True, use_attention_gates=True), dict(use_concat=True, use_mix_project=False, depth=4),
-                dict(use_bn=True), dict(depth=4, use_self_attention=False), dict(depth=5),
+                dict(use_bn=True), dict(depth=5, use_self_attention=False), dict(depth=5),
                 dict(upsample_type="conv2d_transpose")):
         with pytest.raises(NotImplementedError):
             bf.model_builder(_cfg(**bad), device="cpu")
