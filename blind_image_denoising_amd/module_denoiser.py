@@ -17,7 +17,16 @@ class _DeferredStatus:
     def __init__(self):
         self.host, self.pending, self.free, self.carried = None, [], [], 0
 
+    @staticmethod
+    def _capturing() -> bool:
+        # a call that is being captured into a HIP graph may neither allocate pinned memory nor query events, and an event
+        # recorded inside a capture cannot be queried afterwards: captured calls are not tracked here (after a replay, ask
+        # HydraModel.check_status(), which reads the device word)
+        return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
     def post(self, status_dev: torch.Tensor):
+        if self._capturing():
+            return
         if self.host is None:
             self.host = torch.zeros(self.SLOTS, dtype=torch.int32).pin_memory()
             self.free = list(range(self.SLOTS))
@@ -34,6 +43,8 @@ class _DeferredStatus:
 
     def poll(self, wait: bool = False) -> int:
         """OR of the status words of every posted call that is known by now (all of them with wait=True); each is reported once."""
+        if self._capturing():
+            return 0
         status, self.carried = self.carried, 0
         while self.pending:
             slot, event = self.pending[0]

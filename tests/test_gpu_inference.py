@@ -131,6 +131,16 @@ def test_two_blocks_per_launch(hw, no_layers, pair_head):
     one = bf.DenoiserModule(m)(noisy)
     _check_u8(one, ref8)
     assert np.abs(one.astype(int) - got.astype(int)).max() <= 1
+    if not pair_head:
+        # same MFMA sequence per pixel, same hi / lo rounding between the blocks: with every block walking its rows in the same
+        # direction (h3_zigzag 0) the float outputs are bit-for-bit those of the one-block kernel (the head inside the launch uses
+        # exp / rcp where the head kernel uses tanhf: not compared bitwise)
+        m.set_option("h3_zigzag", 0)
+        single_f = np.asarray(bf.DenoiserModule(m, cast_to_uint8=False)(noisy))
+        m.set_option("h3_pair", 1)
+        pair_f = np.asarray(bf.DenoiserModule(m, cast_to_uint8=False)(noisy))
+        m.set_option("h3_zigzag", 1)
+        assert np.array_equal(pair_f, single_f)
     m.set_option("h3_pair", 1)
     m.set_option("h3_pair_head", 0)
     m.set_option("h3_variant", -1)
@@ -227,6 +237,19 @@ def test_full_size_config_properties():
         out2 = mod(noisy)
         m.set_option("fused_blocks", 1)
         assert np.abs(out.astype(int) - out2.astype(int)).max() <= 1
+        # two blocks per launch (batch 128: the default) against one block per launch: the same MFMA sequence per pixel and the same
+        # hi / lo rounding of the activation between the two blocks (in LDS there, in memory here) -- with every block walking its
+        # rows in the same direction (h3_zigzag 0: a bottom-up walk sums the vertical taps in the other order) the outputs are IDENTICAL
+        m.set_option("h3_zigzag", 0)
+        out_p = mod(noisy)
+        if reps:
+            assert m.block_kernel()[0] == "fused_block2_h3w_kernel"
+        m.set_option("h3_pair", 0)
+        out_s = mod(noisy)
+        m.set_option("h3_pair", 1)
+        m.set_option("h3_zigzag", 1)
+        assert np.array_equal(out_p, out_s)
+        assert np.abs(out_p.astype(int) - out.astype(int)).max() <= 1
 
 
 @pytest.mark.parametrize("arith", [1, 0], ids=["f16x3", "f32"])
