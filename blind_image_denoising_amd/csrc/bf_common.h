@@ -231,6 +231,27 @@ struct BwdH3Args {
     int* grid_out;         // if not NULL: number of partial rows (workgroups) the launch wrote
     int tiles_x, tiles_y, ntiles;               // filled in by the launcher
 };
+// backward of BOTH convolutions of a [3,3] block (second one followed by a BatchNorm, ReLU between them) in one kernel
+// (train_bwd2_h3.hip): dT never leaves the CU
+struct Bwd2H3Args {
+    const float* t;        // [B,H,W,16] input of the second convolution = relu(conv1 A) (also the ReLU mask)
+    const float* a;        // [B,H,W,16] block input A (input of the first convolution)
+    const float* dy;       // gradient at the block's output (= at the BatchNorm's output, = the skip's gradient)
+    const float* c;        // raw output of the second convolution = BatchNorm input
+    const float* coef;     // [48] k1 | k2 | k3 of bn_bwd_finalize: dc = k1 dy + k2 c + k3
+    const float* wpack2;   // data-gradient packs (pack_h3_train) of the second / first convolution
+    const float* wpack1;
+    const float* bnc;      // input of the BatchNorm of the block in front (sums of out, out * bnc -> stats) or NULL
+    float* out;            // dA' = dgrad1(dT) + dy; must not alias any input
+    float* wpartial2;      // [grid][2304] each
+    float* wpartial1;
+    float* stats;          // [grid][32] (bnc != NULL)
+    int B, H, W, reverse;
+    int* grid_out;         // if not NULL: number of partial rows (workgroups) the launch wrote
+    int tiles_x, tiles_y, ntiles;               // filled in by the launcher
+};
+int        bf_bwd2_h3_grid(int B, int H, int W);
+hipError_t bf_launch_bwd2_h3(const Bwd2H3Args& a, hipStream_t s);
 int        bf_bwd3x3_h3_grid(int B, int H, int W);                 // partial rows of the 256-thread kernel (the larger count: sizing)
 int        bf_bwd3x3_h3_grid_ex(int B, int H, int W, int dbuf);    // partial rows a launch writes
 hipError_t bf_launch_bwd3x3_h3(const BwdH3Args& a, int epi, float* dw, hipStream_t s);

@@ -46,6 +46,8 @@ struct bf_engine {
     int train_fused_fwd = 1;        // split-f16 training: BatchNorm apply + skip Add of block i formed while block i+1's first convolution stages its tile
     int train_bwd_dbuf = 0;         // fused backward kernel: 512-thread form with double-buffered LDS images (A/B: 10 % slower)
     int train_fused_bwd = 1;        // split-f16 training: weight + data gradient (+ BatchNorm backward) of a convolution in one kernel
+    int train_fused_bwd2 = 0;       // [3,3] blocks with BatchNorm and ReLU: BOTH convolutions' backward in one kernel (bwd2_h3_kernel: 6 tensor
+                                    // passes for 9, but 348 us against 131 + 110: one workgroup per CU and a recomputed halo -- DESIGN 4.3)
     // optional HIP-event bracket around the residual-block launches of a forward (bench.py roofline)
     int timing = 0;
     // ring of event pairs: one pair per timed forward since the option was (re)set, BF_TIMING_RING forwards at most
@@ -213,6 +215,7 @@ extern "C" int bf_set_option(bf_handle h, const char* key, int value)
     if (!strcmp(key, "train_fused_fwd")) { h->train_fused_fwd = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_bwd_dbuf")) { h->train_bwd_dbuf = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_fused_bwd")) { h->train_fused_bwd = value ? 1 : 0; return BF_OK; }
+    if (!strcmp(key, "train_fused_bwd2")) { h->train_fused_bwd2 = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_arith")) { h->train_arith = value < 0 ? 1 : (value ? 1 : 0); return BF_OK; }
     if (!strcmp(key, "arith")) { h->arith = value < 0 ? 1 : (value ? 1 : 0); return BF_OK; }
     if (!strcmp(key, "timing")) {
@@ -972,7 +975,9 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     const bool fused_bwd = h3t && h->train_fused_bwd;
     // gradient buffers: dA (the head's output) and two spares; the fused kernel ping-pongs between them
     float* const gbuf[3] = {dA, ACT(N + 2 + 2 * (int64_t)N * (nb - 1)), ACT(N + 3 + 2 * (int64_t)N * (nb - 1))};
-    const int bwd_grid = bf_bwd3x3_h3_grid_ex(B, H, W, h->train_bwd_dbuf);
+    // both convolutions of a block in one launch: [3,3] blocks, BatchNorm on the second convolution, ReLU between them
+    const bool fused_bwd2 = fused_bwd && h->train_fused_bwd2 && nb == 2 && d.use_bn && relu;
+    const int bwd_grid = fused_bwd2 ? bf_bwd2_h3_grid(B, H, W) : bf_bwd3x3_h3_grid_ex(B, H, W, h->train_bwd_dbuf);
     float* bwd_stats = partial + (int64_t)bwd_grid * 2304;
     for (int i = N - 1; i >= 0; --i) {
         const float* wp = w + L.wpack + (int64_t)i * 2 * nb * BF_TRAIN_PACK_STRIDE;
@@ -995,6 +1000,27 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
                     BF_HIP(bf_launch_bn_bwd_apply(g, C(i, j), w + L.coef, C(i, j), npix, s), "bn_bwd_apply");
                     dy = C(i, j);
                 }
+            }
+            if (fused_bwd2) {
+                // one kernel for the whole block: dc = k1 g + k2 c + k3 ; dw2 = T^T dc ; dT = dgrad2(dc) * (T > 0) (LDS only) ;
+                // dw1 = A^T dT ; dA' = dgrad1(dT) + g [+ the sums of the BatchNorm in front]
+                Bwd2H3Args fa;
+                memset(&fa, 0, sizeof(fa));
+                fa.B = B; fa.H = H; fa.W = W;
+                fa.t = T(i, 1); fa.a = A(i); fa.dy = g; fa.c = C(i, 1); fa.coef = w + L.coef;
+                fa.wpack2 = wp + (int64_t)(nb + 1) * BF_TRAIN_PACK_STRIDE; fa.wpack1 = wp + (int64_t)nb * BF_TRAIN_PACK_STRIDE;
+                fa.wpartial2 = w + L.wslots + ((int64_t)i * nb + 1) * L.wslot_floats;
+                fa.wpartial1 = w + L.wslots + ((int64_t)i * nb + 0) * L.wslot_floats;
+                fa.stats = bwd_stats; fa.reverse = next_reverse();
+                if (i > 0) fa.bnc = C(i - 1, nb - 1);
+                float* out = nullptr;
+                for (int k = 0; k < 3 && !out; ++k)
+                    if (gbuf[k] != g) out = gbuf[k];
+                fa.out = out;
+                BF_HIP(bf_launch_bwd2_h3(fa, s), "bwd2_h3");
+                g = out;
+                dA = out;
+                break;                                              // both convolutions done
             }
             if (fused_bwd) {
                 // one kernel: [dc = k1 g + k2 c + k3] ; dw = x^T dc ; dx = dgrad(dc) [* mask | + skip]

@@ -65,6 +65,26 @@ def test_train_step_matches_oracle(no_layers, shape, train_arith):
     assert np.abs(m.state.cpu().numpy() - r_state).max() < 1e-5          # BN moving statistics updated
 
 
+@pytest.mark.parametrize("no_layers,shape", [(1, (2, 16, 32)), (3, (3, 33, 47)), (2, (5, 70, 150))])
+def test_two_convolution_backward_kernel_matches_oracle_and_the_two_kernel_path(no_layers, shape):
+    """train_fused_bwd2 = 1 (bwd2_h3_kernel: both convolutions' backward of a block in one launch, dT never leaves the CU):
+    the same oracle bars as the default path, and the two paths agree with each other far inside those bars."""
+    cfg, spec, ls, params, state, m, fns = _setup(no_layers)
+    clean, noisy = O.synthetic_batch(*shape, seed=23)
+    gt, x = clean.astype(np.float32), noisy.astype(np.float32)
+    got = {}
+    for v in (0, 1):
+        m.set_option("train_fused_bwd2", v)
+        total, ml, dl, pred, grads = fns.train_step_single_gpu(torch.from_numpy(gt), torch.from_numpy(x), (1.0,), 0.0, None)
+        got[v] = (total.item(), grads.cpu().numpy().astype(np.float64))
+    r_total, r_ml, r_dl, r_pred, r_grads, r_state = O.train_step_single_gpu(
+        spec, ls, params, state, gt.astype(np.float64), x.astype(np.float64))
+    assert abs(got[1][0] - r_total) <= 1e-5 * abs(r_total)
+    _cmp_grads(spec, got[1][1], r_grads)
+    assert got[0][0] == got[1][0]                                        # same forward
+    _cmp_grads(spec, got[1][1], got[0][1], rel=5e-5)
+
+
 def test_train_step_many_tiles_two_stage_reductions():
     """more than 512 tile partials per BatchNorm (the two-stage fp64 reductions) and several tiles per persistent
     weight-gradient workgroup: loss, BN state and gradients against the oracle at a larger shape."""
@@ -600,7 +620,7 @@ def test_random_training_configurations_and_options_match_oracle(seed):
         fns = bf.build_train_functions(m, bf.loss_function_builder(cfg["loss"]))
     except NotImplementedError as e:
         pytest.skip(f"refused: {e}")
-    opts = {"train_arith": int(rng.random() < 0.7), "train_fused_fwd": int(rng.integers(2)), "train_fused_bwd": int(rng.integers(2)),
+    opts = {"train_arith": int(rng.random() < 0.7), "train_fused_fwd": int(rng.integers(2)), "train_fused_bwd": int(rng.integers(2)), "train_fused_bwd2": int(rng.integers(2)),
             "train_bwd_dbuf": int(rng.random() < 0.3), "train_zigzag": int(rng.integers(2))}
     for k, v in opts.items():
         m.set_option(k, v)
