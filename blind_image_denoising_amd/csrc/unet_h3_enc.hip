@@ -355,28 +355,71 @@ __global__ __launch_bounds__(512, 1) void uh_enc32s_kernel(const float* __restri
     }
 }
 
-// uh_enc32s_kernel with the producer's row walk fully unrolled per tile (see the comment in the producer branch)
-template <int K, int ACT>
-__global__ __launch_bounds__(512, 1) void uh_enc32u_kernel(const float* __restrict__ x, float* __restrict__ out,
+#ifndef UH_ENC_ROLE_MAP
+#define UH_ENC_ROLE_MAP 0
+#endif
+#ifndef UH_ENC_STAMP
+#define UH_ENC_STAMP 0                // 1: timing build -- s_memtime stamps per phase and wave of uh_enc32u_kernel (tools/exp/enc_stamps.py)
+#endif
+#if UH_ENC_STAMP
+__device__ unsigned long long uh_enc_stamps[256 * 12 * 8];
+extern "C" int bf_debug_enc_stamps(unsigned long long* host_dst, int clear)
+{
+    if (clear) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(uh_enc_stamps)) != hipSuccess) return BF_EHIP;
+        return hipMemset(p, 0, sizeof(unsigned long long) * 256 * 12 * 8) == hipSuccess ? BF_OK : BF_EHIP;
+    }
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(uh_enc_stamps), sizeof(unsigned long long) * 256 * 12 * 8) == hipSuccess ? BF_OK : BF_EHIP;
+}
+#define UH_STAMP(k)                                                                                      \
+    do {                                                                                                 \
+        unsigned long long now_;                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");                      \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        stamp_sum[k] += now_ - stamp_prev;                                                               \
+        stamp_prev = now_;                                                                               \
+    } while (0)
+#define UH_STAMP_BEGIN()                                                                                 \
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;                              \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory")
+#define UH_STAMP_END()                                                                                   \
+    do {                                                                                                 \
+        if (lane == 0 && blockIdx.x < 256)                                                               \
+            for (int k_ = 0; k_ < 8; ++k_) uh_enc_stamps[((int)blockIdx.x * 12 + wave) * 8 + k_] += stamp_sum[k_]; \
+    } while (0)
+#else
+#define UH_STAMP(k) do { } while (0)
+#define UH_STAMP_BEGIN() do { } while (0)
+#define UH_STAMP_END() do { } while (0)
+#endif
+#ifndef UH_ENC_PD
+#define UH_ENC_PD 4                 // input rows a producer requests ahead of the one it multiplies
+#endif
+// uh_enc32s_kernel with the producer's row walk fully unrolled per tile (see the comment in the producer branch).
+// NCW = consumer waves: 4 (512 threads: one producer + one consumer per SIMD) or 8 (768 threads: one producer + TWO consumers
+// per SIMD, each taking half of a strip's batch -- a consumer wave alone on its SIMD runs its chain staging read -> split ->
+// GEMM1 -> activation / split -> GEMM2 -> store without anything to overlap it with: 25 % of the matrix pipe when timed alone).
+template <int K, int ACT, int NCW = 4>
+__global__ __launch_bounds__(256 + 64 * NCW, 1) void uh_enc32u_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                            const float* __restrict__ dww, const float* __restrict__ gamma, float eps,
                                                            const void* __restrict__ packed, const float* __restrict__ mult, int B, int H,
                                                            int W, float alpha)
 {
-    constexpr int C = 32, NP = 4, RAD = K / 2, T2 = 2, RB = 8;
+    constexpr int C = 32, NP = 16 / NCW, RAD = K / 2, T2 = 2, RB = 8, NT = 256 + 64 * NCW;
+    static_assert(NCW == 4 || (NCW == 8 && !UH_ENC_ROLE_MAP), "4 or 8 consumer waves");
     constexpr int W_BYTES = 32 * C * C, STG_FLOATS = RB * 8 * UH_STG_PITCH;       // one strip of one batch
     extern __shared__ __attribute__((aligned(16))) char lds[];
     {
         const int4* src = reinterpret_cast<const int4*>(packed);
         int4* dstv = reinterpret_cast<int4*>(lds);
-        for (int i = threadIdx.x; i < W_BYTES / 16; i += 512) dstv[i] = src[i];
+        for (int i = threadIdx.x; i < W_BYTES / 16; i += NT) dstv[i] = src[i];
     }
     const float* aux = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed) + W_BYTES);
     const float inv1 = aux[0], inv2 = aux[1];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#ifndef UH_ENC_ROLE_MAP
-#define UH_ENC_ROLE_MAP 0
-#endif
     // Waves go to the four SIMDs round-robin (wave w -> SIMD w & 3).  Map 0 (default): one wave of each role per SIMD -- the
     // producer's vector work and the consumer's matrix work share a SIMD; map 1 (producers = even waves: a SIMD hosts two waves
     // of ONE role) measured 4.5 % slower (1 002 vs 958 us): complementary pipes beat latency hiding within a role.
@@ -398,7 +441,7 @@ __global__ __launch_bounds__(512, 1) void uh_enc32u_kernel(const float* __restri
         // uh_enc32s_kernel), no arithmetic for the output rows a halo row does not reach (-20 % of the FMAs), no row-mask
         // multiplies, and no loads for rows past the tile's last one (4 of 24 issued there).
         const int cl = lane & 7, pl = lane >> 3;
-        constexpr int PD = 4, ROWF4 = (8 + 2 * RAD) * 8, HALVES = 2 * (ROWF4 - 64), NROWS = UH_ENC_ROWS + 2 * RAD;
+        constexpr int PD = UH_ENC_PD, ROWF4 = (8 + 2 * RAD) * 8, HALVES = 2 * (ROWF4 - 64), NROWS = UH_ENC_ROWS + 2 * RAD;
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         struct RowRegs { f32x4 a; f32x2 b; };
         f32x4 wk[K * K], gm = {1.f, 1.f, 1.f, 1.f}, acc[K];
@@ -408,6 +451,7 @@ __global__ __launch_bounds__(512, 1) void uh_enc32u_kernel(const float* __restri
 #pragma unroll
         for (int i = 0; i < K * K; ++i) wk[i] = *reinterpret_cast<const f32x4*>(dww + i * C + 4 * cl);
         if (gamma) gm = *reinterpret_cast<const f32x4*>(gamma + 4 * cl);
+        UH_STAMP_BEGIN();
         for (int64_t ti = 0; ti < my_tiles; ++ti) {
             const int64_t tile = blockIdx.x + ti * gridDim.x;
             const int tx = (int)(tile % tiles_x);
@@ -472,14 +516,20 @@ __global__ __launch_bounds__(512, 1) void uh_enc32u_kernel(const float* __restri
                 }
             };
             if (plive && py0 < H) rows(std::integral_constant<int, 0>{}, std::integral_constant<int, RB + 2 * RAD>{}, stg0, 0);
+            UH_STAMP(0);
             uh_step_barrier();
+            UH_STAMP(1);
             if (plive && py0 + RB < H) rows(std::integral_constant<int, RB + 2 * RAD>{}, std::integral_constant<int, NROWS>{}, stg1, RB);
+            UH_STAMP(0);
             uh_step_barrier();
+            UH_STAMP(1);
         }
         uh_step_barrier();                                   // the consumers' last step
+        UH_STAMP_END();
     } else {
         // ---- matrix-core layout
         const int q = lane >> 4, n = lane & 15;
+        const int g0 = NCW == 8 ? NP * ((wave - 4) >> 2) : 0;              // first 16-pixel group of the batch this wave takes
         f32x4 m4[T2];
 #pragma unroll
         for (int t = 0; t < T2; ++t) {
@@ -496,7 +546,7 @@ __global__ __launch_bounds__(512, 1) void uh_enc32u_kernel(const float* __restri
             return TileAt{(int64_t)(rest / tiles_y) * H * W, tx * 32 + strip * 8, (rest % tiles_y) * UH_ENC_ROWS};
         };
         auto pixel_of = [&](const TileAt& t, const int yb, const int i, bool& ok) {
-            const int py = yb + 2 * i + (n >> 3), px = t.x0 + (n & 7);
+            const int py = yb + 2 * (g0 + i) + (n >> 3), px = t.x0 + (n & 7);
             ok = py < H && px < W;
             return t.img + (int64_t)min(py, H - 1) * W + min(px, W - 1);
         };
@@ -506,6 +556,7 @@ __global__ __launch_bounds__(512, 1) void uh_enc32u_kernel(const float* __restri
 #pragma unroll
             for (int i = 0; i < NP; ++i) skn[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         TileAt cur = tile_at(0), prev = cur;
+        UH_STAMP_BEGIN();
         for (int64_t step = 0; step <= nsteps; ++step) {
             const int b = (int)(step & 1);
             if (b == 0 && step > 0) { prev = cur; cur = tile_at(step >> 1); }
@@ -526,6 +577,7 @@ __global__ __launch_bounds__(512, 1) void uh_enc32u_kernel(const float* __restri
                     }
                 }
             }
+            UH_STAMP(0);
             if (step >= 1) {
                 const int64_t cs = step - 1;                    // the batch the producers finished in the previous step
                 const float* stg = stg_base + (cs & 1) * 4 * STG_FLOATS;
@@ -541,13 +593,15 @@ __global__ __launch_bounds__(512, 1) void uh_enc32u_kernel(const float* __restri
                     bool ok[NP];
 #pragma unroll
                     for (int i = 0; i < NP; ++i) {
-                        const int s = 16 * i + n;             // staged pixel: row 2i + n / 8, column n % 8
+                        const int s = 16 * (g0 + i) + n;      // staged pixel: row 2 (g0 + i) + n / 8, column n % 8
                         const float* sp = stg + s * UH_STG_PITCH + 8 * q;
                         uh_split8(*reinterpret_cast<const f32x4*>(sp), *reinterpret_cast<const f32x4*>(sp + 4), xh[0][i], xl[0][i]);
                         pix[i] = pixel_of(tl, yb, i, ok[i]);
                     }
+                    UH_STAMP(1);
                     f32x4 acc2[T2][NP];
                     uh_mlp_core<C, NP, ACT>(xh, xl, w1l, w2l, inv1, alpha, acc2);
+                    UH_STAMP(2);
 #pragma unroll
                     for (int i = 0; i < NP; ++i) {
                         if (!ok[i] || ((UH_ROLE_ABLATE & 4) && acc2[0][i][0] != 12345.678f)) continue;
@@ -555,10 +609,13 @@ __global__ __launch_bounds__(512, 1) void uh_enc32u_kernel(const float* __restri
                         for (int t = 0; t < T2; ++t)
                             *reinterpret_cast<f32x4*>(out + pix[i] * C + 16 * t + 4 * q) = bf_acc_ready(acc2[t][i]) * m4[t] + sk[t][i];
                     }
+                    UH_STAMP(3);
                 }
             }
             uh_step_barrier();
+            UH_STAMP(4);
         }
+        UH_STAMP_END();
     }
 }
 
@@ -780,10 +837,10 @@ __global__ __launch_bounds__(512, 4) void uh_enc32w_kernel(const float* __restri
     }
 }
 
-static int g_uh_enc_variant = 2;     // 3 two workgroups per CU, 2 wave-specialised + unrolled producer (default), 1 wave-specialised, 0 one kind of wave
+static int g_uh_enc_variant = 2;     // 4 = 2 with two consumer waves per SIMD (768 threads), 3 two workgroups per CU, 2 wave-specialised + unrolled producer (default), 1 wave-specialised, 0 one kind of wave
 extern "C" int bf_op_set_variant(const char* key, int value)
 {
-    if (key && !strcmp(key, "enc32")) { g_uh_enc_variant = value < 0 ? 2 : (value > 3 ? 2 : value); return BF_OK; }
+    if (key && !strcmp(key, "enc32")) { g_uh_enc_variant = value < 0 ? 2 : (value > 4 ? 2 : value); return BF_OK; }
     return BF_EINVAL;
 }
 
@@ -810,7 +867,11 @@ extern "C" int bf_op_convnext_block_h3(const float* x, float* out, const float* 
             if (bf_set_max_lds(reinterpret_cast<const void*>(uh_enc32w_kernel<KK, A>), LDS_W) != hipSuccess) return BF_EHIP;   \
             hipLaunchKernelGGL((uh_enc32w_kernel<KK, A>), dim3(grid_w), dim3(512), LDS_W, s, x, out, dw, ln_gamma, eps, packed, mult, B, \
                                H, W, alpha);                                                                                   \
-        } else if (g_uh_enc_variant == 2) {                                                                                    \
+        } else if (g_uh_enc_variant == 4 && KK == 3) {   /* k = 5 needs 250 registers for its producers: 84 spills at the 168 of 768 threads */ \
+            if (bf_set_max_lds(reinterpret_cast<const void*>(uh_enc32u_kernel<3, A, 8>), LDS_S) != hipSuccess) return BF_EHIP;  \
+            hipLaunchKernelGGL((uh_enc32u_kernel<3, A, 8>), dim3(grid_s), dim3(768), LDS_S, s, x, out, dw, ln_gamma, eps, packed, mult, B, \
+                               H, W, alpha);                                                                                   \
+        } else if (g_uh_enc_variant == 2 || g_uh_enc_variant == 4) {                                                                                    \
             if (bf_set_max_lds(reinterpret_cast<const void*>(uh_enc32u_kernel<KK, A>), LDS_S) != hipSuccess) return BF_EHIP;   \
             hipLaunchKernelGGL((uh_enc32u_kernel<KK, A>), dim3(grid_s), dim3(512), LDS_S, s, x, out, dw, ln_gamma, eps, packed, mult, B, \
                                H, W, alpha);                                                                                   \

@@ -95,7 +95,7 @@ def test_convnext_block_with_1x1_depthwise_in_one_kernel(C, npix, use_ln):
     assert_close(host(got), ref, rel=5e-5, what="block1 h3")
 
 
-@pytest.mark.parametrize("variant", [3, 2, 1, 0], ids=["two-workgroups-per-cu", "wave-specialised-unrolled", "wave-specialised", "single-role"])
+@pytest.mark.parametrize("variant", [4, 3, 2, 1, 0], ids=["two-consumers-per-simd", "two-workgroups-per-cu", "wave-specialised-unrolled", "wave-specialised", "single-role"])
 @pytest.mark.parametrize("k", [3, 5])
 @pytest.mark.parametrize("shape", [(1, 1, 1), (1, 16, 32), (2, 20, 37), (1, 7, 70), (1, 64, 64), (1, 33, 8), (3, 48, 96)])
 @pytest.mark.parametrize("use_ln", [True, False])
