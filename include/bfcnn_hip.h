@@ -268,7 +268,8 @@ int bf_op_convnext_block_h3(const float* x, float* out, const float* dw, int k, 
                             const void* packed, const float* mult, int batch, int height, int width, int channels, int act,
                             float alpha, void* stream);
 /* A/B switch between kernel variants of one operator (process-wide; tests and tools only): key "enc32":
- * 1 = wave-specialised encoder block kernel (default), 0 = the single-role one. */
+ * 2 = wave-specialised encoder block kernel with the producers' row walk unrolled (default), 1 = wave-specialised,
+ * 0 = the single-role one, 3 = two workgroups per CU, 4 = 2 with two consumer waves per SIMD (k = 3 only; k = 5 runs 2). */
 int bf_op_set_variant(const char* key, int value);
 /* DepthwiseConv2D k x k (SAME, zero pad; w [k][k][C]; k = 0: none) -> LayerNormalization(center=False, epsilon) * gamma
  * (ln_gamma NULL: none) -> activation   (custom_layers.py:979-988; backbone_unet_laplacian.py:355-360). */
@@ -522,7 +523,8 @@ int bf_op_axpy(float* y, const float* x, float a, int overwrite, int64_t n, void
  *   f16 matrix cores; 0: exact fp32.  With it (all default 1, A/B only): "train_fused_bwd" = weight gradient, data gradient
  *   and the BatchNorm-backward apply of a convolution in one kernel; "train_fused_fwd" = a block's BatchNorm apply + skip Add
  *   formed by the next block's first convolution while it stages its tile; "train_zigzag" = consecutive tile kernels walk the
- *   tensors in opposite directions (Infinity Cache reuse).
+ *   tensors in opposite directions (Infinity Cache reuse).  "train_fused_bwd2" (default 0): [3,3] blocks with BatchNorm and
+ *   ReLU run BOTH convolutions' backward in one kernel (6 tensor passes for 9; measured slower than the two kernels).
  * "fused_head" = 1: with split-f16 blocks, a linear denoiser head and 3 output channels, the head (premultiplied 16 x 3
  *   matrix, tanh, denormalise, rounding) runs in the epilogue of the last block: no head kernel, the last block output is
  *   never written; 0 (default): separate head kernel (the two measure within 0.5 % of each other).

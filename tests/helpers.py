@@ -165,8 +165,8 @@ def compare_or_explain_by_ties(compare, oracle_step, find_ties, max_ties=6):
     of assumed: `compare(ref)` raises AssertionError on a mismatch with ref = oracle_step(flips).  On a mismatch the oracle lists
     the elements that sit within fp32 rounding of a kink of the graph (ReLU gates, hinge / cutoff thresholds, the denormaliser's
     clip: oracle.training_step_ties).  No such element -> the mismatch is a fault and is raised.  Otherwise the GPU result must
-    equal the oracle evaluated with some subset of exactly those gates taken on the other side (what fp32 may do there); if no
-    subset explains it, the mismatch is raised.  Returns the number of flipped gates (0: plain agreement)."""
+    equal the oracle evaluated with some subset of exactly those gates (the `max_ties` closest to their kink, if there are more) taken
+    on the other side (what fp32 may do there); if no subset explains it, the mismatch is raised.  Returns the number of flipped gates (0: plain agreement)."""
     import itertools
     try:
         compare(oracle_step(None))
@@ -175,16 +175,17 @@ def compare_or_explain_by_ties(compare, oracle_step, find_ties, max_ties=6):
         ties = find_ties()
         if not ties:
             raise AssertionError(f"mismatch and no element within rounding of a kink: {first}") from first
-        if len(ties) > max_ties:
-            raise AssertionError(f"mismatch with {len(ties)} near-kink elements (more than {max_ties}: not enumerated): {first}") from first
-        for n in range(1, len(ties) + 1):
-            for combo in itertools.combinations(ties, n):
+        # more candidates than can be enumerated: only the `max_ties` CLOSEST to their kink may be flipped (2^max_ties oracle steps at
+        # most); the others keep the oracle's side, so a mismatch they would explain is raised -- stricter, never more lenient
+        cand = sorted(ties, key=lambda t: abs(t[2]))[:max_ties]
+        for n in range(1, len(cand) + 1):
+            for combo in itertools.combinations(cand, n):
                 try:
                     compare(oracle_step(list(combo)))
                     return n
                 except AssertionError:
                     pass
-        raise AssertionError(f"mismatch that no side of the {len(ties)} near-kink elements explains: {first}") from first
+        raise AssertionError(f"mismatch that no side of the {len(cand)} closest of {len(ties)} near-kink elements explains: {first}") from first
 
 
 def oracle_is_on_a_kink(oracle_grads, noisy, tol_rel, segments=None, eps=2e-4, trials=3, seed=0):
