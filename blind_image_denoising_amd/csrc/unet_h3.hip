@@ -15,6 +15,12 @@
 //          k(q, i) = 32 c2 + 16 (i / 4) + 4 q + (i % 4); W2 is packed in that order.  The 4C-wide hidden tensor never
 //          exists outside a pair of accumulators.
 #include "unet_h3_core.h"
+#ifndef UH_NP32
+#define UH_NP32 2                  // 16-pixel groups a wave of the C = 32 MLP kernels carries through the two GEMMs at a time
+#endif
+#ifndef UH_NP64
+#define UH_NP64 2
+#endif
 
 // ------------------------------------------------------------------------------------------
 // packing: [W1 fragments | W2 fragments] as f16, then {1/s1, 1/s2} as fp32.
@@ -265,8 +271,8 @@ extern "C" int bf_op_convnext_mlp_h3(const float* in, const float* skip, float* 
     if (act == 2 && !(alpha >= 0.f && alpha <= 1.f)) return BF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
-    if (C == 32) e = uh_launch<32, 2, 256, 0>(in, skip, out, packed, mult, npix, act, alpha, nullptr, nullptr, 0.f, s);
-    else if (C == 64) e = uh_launch<64, 2, 512, 0>(in, skip, out, packed, mult, npix, act, alpha, nullptr, nullptr, 0.f, s);
+    if (C == 32) e = uh_launch<32, UH_NP32, 256, 0>(in, skip, out, packed, mult, npix, act, alpha, nullptr, nullptr, 0.f, s);
+    else if (C == 64) e = uh_launch<64, UH_NP64, 512, 0>(in, skip, out, packed, mult, npix, act, alpha, nullptr, nullptr, 0.f, s);
     else return BF_EUNSUPPORTED;
     if (e == hipErrorInvalidValue) return BF_EINVAL;
     return e == hipSuccess ? BF_OK : BF_EHIP;
@@ -282,8 +288,8 @@ extern "C" int bf_op_convnext_block1_h3(const float* x, float* out, const float*
     if (act == 2 && !(alpha >= 0.f && alpha <= 1.f)) return BF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
-    if (C == 32) e = uh_launch<32, 2, 256, 1>(x, x, out, packed, mult, npix, act, alpha, dw, ln_gamma, eps, s);
-    else if (C == 64) e = uh_launch<64, 2, 512, 1>(x, x, out, packed, mult, npix, act, alpha, dw, ln_gamma, eps, s);
+    if (C == 32) e = uh_launch<32, UH_NP32, 256, 1>(x, x, out, packed, mult, npix, act, alpha, dw, ln_gamma, eps, s);
+    else if (C == 64) e = uh_launch<64, UH_NP64, 512, 1>(x, x, out, packed, mult, npix, act, alpha, dw, ln_gamma, eps, s);
     else return BF_EUNSUPPORTED;
     if (e == hipErrorInvalidValue) return BF_EINVAL;
     return e == hipSuccess ? BF_OK : BF_EHIP;
