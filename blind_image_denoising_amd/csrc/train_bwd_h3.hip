@@ -21,10 +21,15 @@
 
 typedef __fp16 tb_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
+#ifndef BWD_H3_TH
+#define BWD_H3_TH 16               // tile rows: 16 = two workgroups per CU (78.8 KB of images), 8 = three (44 KB; A/B)
+#endif
 struct BwdH3Geom {
-    static constexpr int TH = 16, TW = 32, IH = TH + 2, IW = TW + 2, R = 8;
+    static constexpr int TH = BWD_H3_TH, TW = 32, IH = TH + 2, IW = TW + 2, R = TH / 2;
+    static constexpr int WG_PER_CU = TH == 16 ? 2 : 3;
+    static_assert(TH == 16 || TH == 8, "tile rows");
     // plane stride = 128 mod 256: the transposed reads of a half-wave touch planes 0 and 1 of 8 neighbouring pixels
-    static constexpr int PLANE = ((IH * IW * 16 + 255) / 256) * 256 + 128 - 256;       // 9856 >= 9792
+    static constexpr int PLANE = (IH * IW * 16 + 127) / 256 * 256 + 128;               // 9856 >= 9792 (5504 >= 5440)
     static constexpr int IMG = 4 * PLANE;
     static constexpr int LDS_BYTES = 2 * IMG;                                          // 78,848: two workgroups per CU
     static_assert(PLANE >= IH * IW * 16 && PLANE % 256 == 128, "plane stride");
@@ -75,7 +80,7 @@ struct BwdH3Epi {
 };
 
 template <bool BNAPPLY, int EPI>
-__global__ __launch_bounds__(256, 2) void bwd3x3_h3_kernel(BwdH3Args a)
+__global__ __launch_bounds__(256, BwdH3Geom::WG_PER_CU) void bwd3x3_h3_kernel(BwdH3Args a)
 {
     using G = BwdH3Geom;
     char* xs = tb_lds;
@@ -212,10 +217,10 @@ __global__ __launch_bounds__(256, 2) void bwd3x3_h3_kernel(BwdH3Args a)
             w[12] = w[0];
         }
 
-        // ---- weight gradient: wave handles rows 4w .. 4w+3 of the tile, one K chunk of 32 pixels per row ----
+        // ---- weight gradient: wave handles rows 4w .. 4w+3 of the tile (TH / 4 rows), one K chunk of 32 pixels per row ----
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int r = 4 * wave + rr;
+        for (int rr = 0; rr < G::TH / 4; ++rr) {
+            const int r = (G::TH / 4) * wave + rr;
             const int gaddr = ((r + 1) * G::IW + 1) * 16 + tr_off;
             const h8 bh = tb_tr_operand(gs, gaddr);
             const h8 bl = tb_tr_operand(gs + 2 * G::PLANE, gaddr);
@@ -464,7 +469,7 @@ int bf_bwd3x3_h3_grid_ex(int B, int H, int W, int dbuf)
 {
     using G = BwdH3Geom;
     const int64_t ntiles = (int64_t)B * ((H + G::TH - 1) / G::TH) * ((W + G::TW - 1) / G::TW);
-    const int cap = dbuf ? 256 : 512;
+    const int cap = dbuf ? 256 : 256 * G::WG_PER_CU;
     return (int)(ntiles < cap ? ntiles : cap);
 }
 
@@ -472,7 +477,7 @@ int bf_bwd3x3_h3_grid(int B, int H, int W)
 {
     using G = BwdH3Geom;
     const int64_t ntiles = (int64_t)B * ((H + G::TH - 1) / G::TH) * ((W + G::TW - 1) / G::TW);
-    return (int)(ntiles < 512 ? ntiles : 512);
+    return (int)(ntiles < 256 * G::WG_PER_CU ? ntiles : 256 * G::WG_PER_CU);
 }
 
 // a.wpartial: [grid][2304] floats, a.stats: [grid][32]; dw <- sum of the partials (fixed order; skipped when dw is nullptr).  epi: 0, EPI_MASK, EPI_RES
