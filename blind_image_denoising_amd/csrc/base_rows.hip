@@ -83,6 +83,8 @@ __global__ __launch_bounds__(BR_NT) void base_conv_rows_kernel(BaseConvArgs a, i
         if (yy >= 0 && yy < a.H && x >= 0 && x < a.W) {
             r[3] = (_Float16)1.f;                                  // inside the (padded) frame: carries the -0.5 of the normalisation
             if (!(abl & 2) && yy < a.Hs && x < a.Ws) {
+                // three byte loads: measured, they cost 41 of the kernel's 128 us (87 us without loads = the time of its 537 MB of
+                // stores, `tools/exp/base_rows_abl.sh`), but ONE unaligned 4-byte load per pixel is slower still (146 us)
                 const uint8_t* p = src + ((int64_t)yy * a.Ws + x) * 3;
                 r[0] = (_Float16)(float)p[0];
                 r[1] = (_Float16)(float)p[1];
@@ -161,9 +163,10 @@ hipError_t bf_launch_base_conv_rows(const BaseConvArgs& a, hipStream_t s)
     if (!bf_base_conv_rows_supports(a)) return hipErrorInvalidValue;
     const int nchunks = (a.W + BR_CW - 1) / BR_CW;
     // rows per band: enough workgroups to fill the chip a few times, bands tall enough to amortise the three prologue rows
+    // (128 x 256 x 256: 32 rows = 1 024 workgroups 117 us, 16 rows 128 us, 8 rows 134 us, 64 rows 158 us)
     int rows = 32;
     if (const char* e = getenv("BF_BASE_ROWS_BAND")) rows = atoi(e) > 0 ? atoi(e) : rows;      // A/B only
-    else while (rows > 8 && (int64_t)a.B * nchunks * ((a.H + rows - 1) / rows) < 2048) rows /= 2;
+    else while (rows > 8 && (int64_t)a.B * nchunks * ((a.H + rows - 1) / rows) < 1024) rows /= 2;
     const int nbands = (a.H + rows - 1) / rows;
     const int64_t grid = (int64_t)a.B * nchunks * nbands;
     if (grid > 0x7fffffff) return hipErrorInvalidValue;
