@@ -84,7 +84,9 @@ __global__ __launch_bounds__(BR_NT) void base_conv_rows_kernel(BaseConvArgs a, i
             r[3] = (_Float16)1.f;                                  // inside the (padded) frame: carries the -0.5 of the normalisation
             if (!(abl & 2) && yy < a.Hs && x < a.Ws) {
                 // three byte loads: measured, they cost 41 of the kernel's 128 us (87 us without loads = the time of its 537 MB of
-                // stores, `tools/exp/base_rows_abl.sh`), but ONE unaligned 4-byte load per pixel is slower still (146 us)
+                // stores, `tools/exp/base_rows_abl.sh`), but every other form tried was slower still: one unaligned 4-byte load per
+                // pixel 146 us, one aligned 12-byte load per four pixels on 66 threads 139 us, the row requested two steps ahead
+                // with its raw bytes held in registers 145 us
                 const uint8_t* p = src + ((int64_t)yy * a.Ws + x) * 3;
                 r[0] = (_Float16)(float)p[0];
                 r[1] = (_Float16)(float)p[1];

@@ -470,7 +470,7 @@ def test_random_engine_configurations_and_options_match_oracle(seed):
     _check_u8(bf.DenoiserModule(m)(noisy)[:2], O.denoiser_module_call(spec, params, state, noisy[:2]))
 
 
-@pytest.mark.parametrize("hw", [(64, 64), (17, 23), (40, 300), (1, 1), (33, 257)])
+@pytest.mark.parametrize("hw", [(64, 64), (17, 23), (40, 300), (1, 1), (33, 257), (20, 516), (5, 4)])
 def test_row_streaming_base_convolution_matches_the_vector_kernel_and_the_oracle(hw):
     """base_conv_rows_kernel (u8 in, 3x3x3 -> 16 on the f16 matrix cores: exact u8 operands, the normalisation offset and the zero /
     power-of-two padding carried by a fourth 'inside' channel) against the vector kernel (option base_rows = 0) and the oracle,
