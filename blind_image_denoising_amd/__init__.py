@@ -18,7 +18,7 @@ from .custom_logger import logger
 from .utilities import load_config, save_config, input_shape_fixer
 from .model import (BuilderResults, HydraModel, model_builder, describe_resnet, save_model, load_hydra,
                     build_normalize_model, build_denormalize_model)
-from .module_denoiser import DenoiserModule
+from .module_denoiser import DenoiserModule, GraphedDenoiserModule
 from .loss import loss_function_builder
 from .optimizer import optimizer_builder, schedule_builder, deep_supervision_schedule_builder
 from .train_loop import (train_loop, build_train_functions, DataParallelTrainer, NativeCommunicator, shard_batch,

@@ -129,3 +129,103 @@ class DenoiserModule:
         if st is not None:
             self._deferred.post(st)            # no synchronisation: looked at by the next call / check_status()
         return out
+
+
+class GraphedDenoiserModule:
+    """A DenoiserModule whose call is replayed as ONE captured HIP graph per input shape -- the serving form of the module.
+
+    The C ABI behind `DenoiserModule.__call__` neither allocates nor synchronises (include/bfcnn_hip.h, "graph-capturable"), so a
+    whole call -- eleven to twenty launches for resnet 1x18, about sixty operator calls from Python for unet_laplacian -- can be
+    captured once per shape and then costs the host a single launch.  What that buys is HOST time (one launch instead of a walk over
+    the graph in Python), not latency: a batch-1 call is bound by its kernels on the GPU either way (`bench.py --mode latency`:
+    resnet 1x18 172 us replayed, 177 us launched on the stream; unet_laplacian v5 at 512 x 512: 783 / 766 us).  The first call with a
+    new [B,H,W,C] runs the module twice directly (packing, workspace, kernel attributes), captures it on a static input tensor and
+    keeps the graph; later calls copy the image into that tensor and replay.  At most `max_shapes` graphs are kept (least recently
+    used goes first).  The result is a fresh tensor unless `copy_output=False` (then it is the graph's own output buffer, valid until
+    the next call with that shape).  Same argument checks, return types and f16-range status handling as DenoiserModule
+    (module_denoiser.py:43-75 is what both compute).  A graph holds the kernels, options and buffer addresses of the moment it was
+    captured: a graph whose model workspace has since been re-allocated (a larger shape came by) is re-captured by itself; after
+    `set_option` call `invalidate()` (new weights through `set_weights` are picked up: they live in the same buffers)."""
+
+    def __init__(self, module: DenoiserModule, max_shapes: int = 8, copy_output: bool = True):
+        if not isinstance(module, DenoiserModule):
+            raise ValueError("module must be a DenoiserModule")
+        if max_shapes < 1:
+            raise ValueError("max_shapes must be at least 1")
+        self._module, self._max, self._copy = module, int(max_shapes), bool(copy_output)
+        self._graphs = {}                      # shape -> (graph, static_in, static_out); insertion order = recency
+        self.name = module.name
+
+    @property
+    def model_hydra(self):
+        return self._module.model_hydra
+
+    def check_status(self, wait: bool = True) -> bool:
+        return self._module.check_status(wait)
+
+    def captured_shapes(self):
+        return list(self._graphs.keys())
+
+    def invalidate(self):
+        """drops every captured graph (after set_option: a graph replays the kernels that were selected when it was captured)"""
+        self._graphs.clear()
+
+    def _workspace_ptr(self):
+        ws = getattr(self._module.model_hydra, "_workspace", None)
+        return ws.data_ptr() if isinstance(ws, torch.Tensor) else 0
+
+    def _capture(self, image: torch.Tensor):
+        static_in = image.clone()
+        side = torch.cuda.Stream(device=image.device)
+        side.wait_stream(torch.cuda.current_stream(image.device))
+        with torch.cuda.stream(side):          # warm-up off the capture: one-time packing / workspace / attribute calls
+            self._module(static_in)
+            self._module(static_in)
+        torch.cuda.current_stream(image.device).wait_stream(side)
+        torch.cuda.synchronize(image.device)
+        self._module.check_status(wait=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_out = self._module(static_in)
+        return graph, static_in, static_out, self._workspace_ptr()
+
+    def __call__(self, image):
+        was_numpy = isinstance(image, np.ndarray)
+        if was_numpy:
+            image = torch.from_numpy(np.ascontiguousarray(image))
+        if not isinstance(image, torch.Tensor):
+            raise ValueError("image must be a torch.Tensor or numpy array")
+        if image.dtype != torch.uint8 or image.dim() != 4:
+            raise ValueError(f"input must be a uint8 tensor of shape [B,H,W,C], "
+                             f"got {image.dtype} {tuple(image.shape)}")
+        hydra = self._module.model_hydra
+        if image.shape[-1] != hydra.desc.in_channels:
+            raise ValueError(f"expected {hydra.desc.in_channels} channels, got {image.shape[-1]}")
+        if image.shape[0] == 0:
+            return self._module(image.numpy() if was_numpy else image)
+        hydra._require_gpu()
+        self._module.check_status(wait=False)
+        image = image.to(hydra.device).contiguous()
+        key = tuple(image.shape)
+        entry = self._graphs.pop(key, None)
+        if entry is not None and entry[3] != self._workspace_ptr():
+            entry = None                       # the engine's workspace moved since this graph was captured
+        if entry is None:
+            if len(self._graphs) >= self._max:
+                self._graphs.pop(next(iter(self._graphs)))
+            entry = self._capture(image)
+        self._graphs[key] = entry              # most recently used last
+        graph, static_in, static_out, _ = entry
+        static_in.copy_(image)
+        graph.replay()
+        if was_numpy:
+            out = static_out.cpu().numpy()     # synchronises: the status word of this replay can be read at once
+            if not hydra.check_status(raise_on_overflow=not hydra.auto_exact_fallback):
+                hydra.set_option("arith", 0)   # the captured graphs hold the split-f16 kernels: drop them
+                self._graphs.clear()
+                return self(image.cpu().numpy())
+            return out
+        st = hydra.status_tensor() if hasattr(hydra, "status_tensor") else None
+        if st is not None:
+            self._module._deferred.post(st)
+        return static_out.clone() if self._copy else static_out

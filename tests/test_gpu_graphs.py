@@ -80,3 +80,38 @@ def test_train_step_with_all_loss_terms_in_a_hip_graph():
     torch.cuda.synchronize()
     assert out[0].item() == ref[0].item()
     assert torch.equal(out[4], ref[4])
+
+
+@pytest.mark.parametrize("family", ["resnet", "unet_laplacian"])
+def test_graphed_denoiser_module_replays_per_shape(family):
+    """GraphedDenoiserModule: one captured graph per input shape, results identical to the direct module on every call (device and
+    host inputs, shapes revisited after others grew the engine's workspace, least-recently-used eviction)."""
+    if family == "resnet":
+        cfg = O.canonical_config(no_layers=6)
+        spec = O.ResnetSpec.from_config(cfg["model"])
+        params, state = O.init_params(spec, seed=3)
+        m = bf.model_builder(cfg["model"], device="cuda").hydra
+        m.set_weights(params, state)
+    else:
+        cfg = U.canonical_config(depth=3, width=1)
+        spec = U.UnetLaplacianSpec.from_config(cfg["model"])
+        m = bf.model_builder(cfg["model"], device="cuda").hydra
+        m.set_weights(U.init_params(spec, seed=4))
+    direct = bf.DenoiserModule(m)
+    graphed = bf.GraphedDenoiserModule(bf.DenoiserModule(m), max_shapes=2)
+    shapes = [(1, 32, 32), (2, 64, 48), (1, 32, 32), (3, 96, 128), (1, 32, 32), (2, 64, 48)]
+    for k, (B, H, W) in enumerate(shapes):
+        _, img = O.synthetic_batch(B, H, W, seed=20 + k)
+        ref = direct(img)
+        got = graphed(img)                                               # host array in, host array out
+        assert isinstance(got, np.ndarray) and np.array_equal(got, ref), (k, B, H, W)
+        dev = graphed(torch.from_numpy(img).cuda())                      # device tensor in, device tensor out
+        assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), ref)
+        assert graphed.check_status()
+        assert len(graphed.captured_shapes()) <= 2
+    assert graphed.captured_shapes()[-1] == (2, 64, 48, 3)
+    graphed.invalidate()
+    assert graphed.captured_shapes() == []
+    with pytest.raises(ValueError):
+        graphed(np.zeros((1, 8, 8, 3), np.float32))
+    assert graphed(np.zeros((0, 8, 8, 3), np.uint8)).shape == (0, 8, 8, 3)

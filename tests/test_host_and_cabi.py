@@ -256,3 +256,17 @@ def test_pyramid_type_parsing():
             PyramidType.from_string(bad)
     with pytest.raises(KeyError):
         PyramidType.from_string("pyramid")
+
+
+def test_graphed_module_argument_checks():
+    import blind_image_denoising_amd as bf
+    with pytest.raises(ValueError):
+        bf.GraphedDenoiserModule(object())
+    cfg = O.canonical_config(no_layers=1)
+    m = bf.DenoiserModule(bf.model_builder(cfg["model"], device="cpu").hydra)
+    with pytest.raises(ValueError):
+        bf.GraphedDenoiserModule(m, max_shapes=0)
+    g = bf.GraphedDenoiserModule(m)
+    assert g.captured_shapes() == [] and g.name == m.name
+    with pytest.raises(ValueError):
+        g(np.zeros((1, 8, 8, 3), np.float32))
