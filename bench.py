@@ -510,6 +510,9 @@ def latency_bench(args, torch, bf, O, rank, local_rank, world, dist):
         params, state = O.init_params(spec, seed=42, nontrivial_bn=True)
         m = bf.model_builder(cfg["model"], device=dev).hydra
         m.set_weights(params, state)
+        for kv in args.opt:
+            k, v = kv.split("=")
+            m.set_option(k, int(v))
         _, img = O.synthetic_batch(1, 256, 256, sigma=20.0, seed=1234)
         measure(f"resnet_1x{layers} 1x256x256x3", bf.DenoiserModule(m), img)
     ucfg = U.canonical_config()

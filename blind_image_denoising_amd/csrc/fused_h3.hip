@@ -1410,13 +1410,18 @@ using H3Small = H3Cfg<16, 16, 4>;
 
 // Default kernel (variant < 0 everywhere): the full-row streaming kernel (4, fused_h3v.hip) for images up to 256 columns when
 // the batch holds enough rows to amortise a band's ~10-step fill (B * H >= 3072: from ~12 rows per workgroup on; measured at
-// 256 x 256: batch 8 0.46 ms (tiles) vs 0.49, batch 16 0.78 vs 0.75, batch 128 5.5 vs 4.5), the row-streaming tile kernel (1)
-// otherwise -- a single 256 x 256 image takes 162 us through the 18 blocks on tiles, 367 us on one-row bands.
+// 256 x 256: batch 8 0.46 ms (tiles) vs 0.49, batch 16 0.78 vs 0.75, batch 128 5.5 vs 4.5), the row-streaming tile kernel (1, or
+// 2 for very small inputs) otherwise -- a single 256 x 256 image takes 162 us through the 18 blocks on tiles, 367 us on one-row bands.
 static int g_h3_variant = -1;                         // override of the default for debug entries without a handle (tests, A/B)
 void bf_set_h3_variant(int v) { g_h3_variant = v < 0 ? -1 : v; }
+// Below one 16 x 32 tile per CU (or between one and two) the 16 x 16 tiles of variant 2 -- two 4-wave workgroups per CU -- put more of
+// the chip to work: resnet 1x18 on one 256 x 256 image 149 us for 177, one 128 x 128 image 138 for 166, three 256 x 256 images 241 for
+// 267; from 512 tiles on the larger tile is 3-5 % faster (tools/exp/small_batch_variants.py).
 static int h3_default_variant(const FusedH3Args& a)
 {
-    return (!a.head_wh && bf_fused_block_h3v_supports(a.H, a.W) && (int64_t)a.B * a.H >= 3072) ? 4 : 1;
+    if (!a.head_wh && bf_fused_block_h3v_supports(a.H, a.W) && (int64_t)a.B * a.H >= 3072) return 4;
+    const int64_t tiles32 = (int64_t)a.B * ((a.H + 15) / 16) * ((a.W + 31) / 32);
+    return (!a.head_wh && !a.compact && tiles32 < 512 && tiles32 != 256) ? 2 : 1;
 }
 
 template <class Cfg, int VARIANT>
