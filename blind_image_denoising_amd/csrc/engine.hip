@@ -486,7 +486,7 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
         FusedH3Args probe;
         memset(&probe, 0, sizeof(probe));
         probe.B = B; probe.H = H; probe.W = W; probe.variant = h->h3_variant;
-        pair_ok = bf_fused_block_h3_is_streaming(probe) && bf_fused_block2_h3w_supports(H, W);
+        pair_ok = (bf_fused_block_h3_is_streaming(probe) || bf_fused_block_h3_wide_pairs(probe)) && bf_fused_block2_h3w_supports(H, W);
     }
     int launches = 0, pair_launches = 0;
     // an odd block count runs its single block FIRST, so that the last launch is a pair and can carry the head

@@ -1444,6 +1444,16 @@ bool bf_fused_block_h3_is_streaming(const FusedH3Args& a)
     return variant == 4 && !a.head_wh && bf_fused_block_h3v_supports(a.H, a.W);
 }
 
+// Images wider than the one-block streaming kernel takes (256 columns): the two-block kernel (fused_h3w.hip) walks 128-column strips of
+// any width, so with the library's default selection and enough rows per workgroup (the same ~24 strip rows as above) consecutive
+// blocks still run two per launch; an odd block count runs its single block on the tile kernel.
+bool bf_fused_block_h3_wide_pairs(const FusedH3Args& a)
+{
+    if (a.variant >= 0 || g_h3_variant >= 0 || a.head_wh || a.compact) return false;
+    const int64_t nstrips = (a.W + 127) / 128;
+    return !bf_fused_block_h3v_supports(a.H, a.W) && a.W > 256 && a.H >= 1 && (int64_t)a.B * a.H * nstrips >= 6144;
+}
+
 // name of the kernel bf_launch_fused_block_h3 launches for these arguments
 const char* bf_fused_block_h3_kernel_name(const FusedH3Args& a)
 {

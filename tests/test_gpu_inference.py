@@ -146,6 +146,30 @@ def test_two_blocks_per_launch(hw, no_layers, pair_head):
     m.set_option("h3_variant", -1)
 
 
+@pytest.mark.parametrize("no_layers", [2, 3])
+def test_wide_images_run_two_blocks_per_launch_by_default(no_layers):
+    """images wider than the 256 columns of the one-block streaming kernel: with enough rows the default selection still runs the
+    blocks two per launch (128-column strips of fused_block2_h3w_kernel; an odd count runs its single block on the tile kernel).
+    Same oracle and bars; the library reports the kernel it chose; h3_pair = 0 (tile kernel throughout) agrees to one grey level."""
+    cfg, spec, params, state, m = _model(no_layers, seed=31)
+    _, noisy = O.synthetic_batch(6, 352, 300, seed=12)                   # 6 x 352 rows x 3 strips = 6 336 strip rows
+    mod = bf.DenoiserModule(m)
+    got = mod(noisy)
+    assert m.block_kernel() == ("fused_block2_h3w_kernel", 1 + (no_layers & 1))
+    _check_u8(got[:1], O.denoiser_module_call(spec, params, state, noisy[:1]))
+    _check_u8(got[5:], O.denoiser_module_call(spec, params, state, noisy[5:]))
+    m.set_option("h3_pair", 0)
+    try:
+        tiles = mod(noisy)
+        assert m.block_kernel()[0] == "fused_block_h3r_kernel"
+    finally:
+        m.set_option("h3_pair", 1)
+    assert np.abs(tiles.astype(int) - got.astype(int)).max() <= 1
+    _, few = O.synthetic_batch(1, 64, 300, seed=13)                      # too few rows: tiles
+    mod(few)
+    assert m.block_kernel()[0] == "fused_block_h3r_kernel"
+
+
 def test_two_blocks_per_launch_status_word_with_the_head_in_the_launch():
     """activations beyond the f16 range must still reach the status word when the head runs inside the last pair launch"""
     cfg, spec, params, state, m = _model(2, seed=5)
