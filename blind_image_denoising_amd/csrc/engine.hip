@@ -207,7 +207,7 @@ extern "C" int bf_set_option(bf_handle h, const char* key, int value)
     if (!strcmp(key, "h3_variant")) { h->h3_variant = value; return BF_OK; }      // per handle; < 0 = library default
     if (!strcmp(key, "h3_zigzag")) { h->h3_zigzag = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "h3_compact")) { h->h3_compact = value ? 1 : 0; return BF_OK; }
-    if (!strcmp(key, "h3_pair")) { h->h3_pair = value ? 1 : 0; return BF_OK; }
+    if (!strcmp(key, "h3_pair")) { h->h3_pair = value == 2 ? 2 : (value ? 1 : 0); return BF_OK; }
     if (!strcmp(key, "base_rows")) { bf_set_base_conv_rows(value); return BF_OK; }       // process-wide (A/B only)
     if (!strcmp(key, "h3_pair_head")) { h->h3_pair_head = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "fused_head")) { h->fused_head = value ? 1 : 0; return BF_OK; }
@@ -486,7 +486,8 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
         FusedH3Args probe;
         memset(&probe, 0, sizeof(probe));
         probe.B = B; probe.H = H; probe.W = W; probe.variant = h->h3_variant;
-        pair_ok = (bf_fused_block_h3_is_streaming(probe) || bf_fused_block_h3_wide_pairs(probe)) && bf_fused_block2_h3w_supports(H, W);
+        pair_ok = (h->h3_pair == 2 || bf_fused_block_h3_is_streaming(probe) || bf_fused_block_h3_pairs_preferred(probe)) &&
+                  bf_fused_block2_h3w_supports(H, W);                                   // h3_pair = 2: wherever it can run (A/B only)
     }
     int launches = 0, pair_launches = 0;
     // an odd block count runs its single block FIRST, so that the last launch is a pair and can carry the head

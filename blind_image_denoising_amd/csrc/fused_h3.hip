@@ -1444,14 +1444,17 @@ bool bf_fused_block_h3_is_streaming(const FusedH3Args& a)
     return variant == 4 && !a.head_wh && bf_fused_block_h3v_supports(a.H, a.W);
 }
 
-// Images wider than the one-block streaming kernel takes (256 columns): the two-block kernel (fused_h3w.hip) walks 128-column strips of
-// any width, so with the library's default selection and enough rows per workgroup (the same ~24 strip rows as above) consecutive
-// blocks still run two per launch; an odd block count runs its single block on the tile kernel.
-bool bf_fused_block_h3_wide_pairs(const FusedH3Args& a)
+// Two blocks per launch (fused_h3w.hip) beyond the shapes of the one-block streaming kernel: its 128-column strips take any image width,
+// and at two blocks per launch a band's fill is amortised earlier -- with the library's default selection, from 4 096 rows of strips per
+// forward on (B * H * ceil(W / 128)) consecutive blocks run two per launch; an odd block count runs its single block on whatever
+// bf_launch_fused_block_h3 picks.  Measured (tools/exp/regime_sweep.py, resnet 1x18, us per forward, pairs / 16 x 32 tiles):
+// 8 x 256^2 403 / 429, 6 x 256^2 357 / 355, 2 x 512^2 404 / 424, 1 x 512^2 295 / 282, 32 x 128^2 397 / 420, 16 x 128^2 291 / 281,
+// 32 x 512^2 4 300 / 5 570, 1 x 1080 x 1920 2 207 / 2 747.
+bool bf_fused_block_h3_pairs_preferred(const FusedH3Args& a)
 {
     if (a.variant >= 0 || g_h3_variant >= 0 || a.head_wh || a.compact) return false;
     const int64_t nstrips = (a.W + 127) / 128;
-    return !bf_fused_block_h3v_supports(a.H, a.W) && a.W > 256 && a.H >= 1 && (int64_t)a.B * a.H * nstrips >= 6144;
+    return a.W >= 1 && a.H >= 1 && (int64_t)a.B * a.H * nstrips >= 4096;
 }
 
 // name of the kernel bf_launch_fused_block_h3 launches for these arguments

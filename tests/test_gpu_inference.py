@@ -240,10 +240,10 @@ def test_batch_is_independent_and_deterministic():
 
 
 def test_full_size_config_properties():
-    """BASELINE.json configs[2] at its real size (1x18, batch 128, 256x256: the full-row streaming kernel, which the default
-    picks from 3 072 image rows per batch on): size-independent properties instead of the (slow) oracle on the whole batch --
+    """BASELINE.json configs[2] at its real size (1x18, batch 128, 256x256: two blocks per launch, which the default
+    picks from 4 096 rows of 128-column strips per forward on): size-independent properties instead of the (slow) oracle on the whole batch --
     the oracle on ONE image, position independence inside the batch (the same 16 images at eight places; the reversed batch),
-    fused == unfused path within one LSB -- and the same properties at batch 8 (the tile kernel the default picks there)."""
+    fused == unfused path within one LSB -- and the same properties at batch 8 (the smallest batch that still runs two blocks per launch)."""
     cfg, spec, params, state, m = _model(18, seed=42)
     _, noisy16 = O.synthetic_batch(16, 256, 256, seed=1234)
     mod = bf.DenoiserModule(m)
@@ -266,14 +266,18 @@ def test_full_size_config_properties():
         # rows in the same direction (h3_zigzag 0: a bottom-up walk sums the vertical taps in the other order) the outputs are IDENTICAL
         m.set_option("h3_zigzag", 0)
         out_p = mod(noisy)
-        if reps:
-            assert m.block_kernel()[0] == "fused_block2_h3w_kernel"
+        assert m.block_kernel()[0] == "fused_block2_h3w_kernel"            # both batches hold >= 4 096 rows of strips
         m.set_option("h3_pair", 0)
+        m.set_option("h3_variant", 4)                                       # the one-block streaming kernel (batch 8: forced)
         out_s = mod(noisy)
+        assert m.block_kernel()[0] == "fused_block_h3v_kernel"
+        m.set_option("h3_variant", -1)
+        out_t = mod(noisy)                                                  # one block per launch, the library's choice (batch 8: tiles)
         m.set_option("h3_pair", 1)
         m.set_option("h3_zigzag", 1)
         assert np.array_equal(out_p, out_s)
         assert np.abs(out_p.astype(int) - out.astype(int)).max() <= 1
+        assert np.abs(out_t.astype(int) - out.astype(int)).max() <= 1
 
 
 @pytest.mark.parametrize("arith", [1, 0], ids=["f16x3", "f32"])
