@@ -173,7 +173,7 @@ hipError_t bf_launch_fused_block_h3(const FusedH3Args& a, hipStream_t s);
 // true when bf_launch_fused_block_h3 would run the full-row streaming kernel for these arguments (the one kernel that reads and
 // writes the compact layout)
 bool       bf_fused_block_h3_is_streaming(const FusedH3Args& a);
-bool       bf_fused_block_h3_pairs_preferred(const FusedH3Args& a);   // default selection and >= 4 096 strip rows: two blocks per launch
+bool       bf_fused_block_h3_use_pairs(const FusedH3Args& a);   // two blocks per launch: default selection with >= 4 096 strip rows of >= 24-row images, or a forced streaming variant
 const char* bf_fused_block_h3_kernel_name(const FusedH3Args& a);
 const char* bf_fused_block_kernel_name();                      // conv3x3_c16.hip: the exact-fp32 fused block
 // library default of FusedH3Args::variant (handle-less debug entries): 4 = full-row streaming kernel where it applies

@@ -486,8 +486,7 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
         FusedH3Args probe;
         memset(&probe, 0, sizeof(probe));
         probe.B = B; probe.H = H; probe.W = W; probe.variant = h->h3_variant;
-        pair_ok = (h->h3_pair == 2 || bf_fused_block_h3_is_streaming(probe) || bf_fused_block_h3_pairs_preferred(probe)) &&
-                  bf_fused_block2_h3w_supports(H, W);                                   // h3_pair = 2: wherever it can run (A/B only)
+        pair_ok = (h->h3_pair == 2 || bf_fused_block_h3_use_pairs(probe)) && bf_fused_block2_h3w_supports(H, W);   // 2: A/B only
     }
     int launches = 0, pair_launches = 0;
     // an odd block count runs its single block FIRST, so that the last launch is a pair and can carry the head

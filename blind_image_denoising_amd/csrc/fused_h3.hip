@@ -1419,7 +1419,8 @@ void bf_set_h3_variant(int v) { g_h3_variant = v < 0 ? -1 : v; }
 // 267; from 512 tiles on the larger tile is 3-5 % faster (tools/exp/small_batch_variants.py).
 static int h3_default_variant(const FusedH3Args& a)
 {
-    if (!a.head_wh && bf_fused_block_h3v_supports(a.H, a.W) && (int64_t)a.B * a.H >= 3072) return 4;
+    // (short AND narrow images -- under 24 rows, up to 128 columns -- stay on tiles: 2 000 x 4 x 64 1 186 us on tiles, 1 559 streaming)
+    if (!a.head_wh && bf_fused_block_h3v_supports(a.H, a.W) && (int64_t)a.B * a.H >= 3072 && (a.H >= 24 || a.W > 128)) return 4;
     const int64_t tiles32 = (int64_t)a.B * ((a.H + 15) / 16) * ((a.W + 31) / 32);
     return (!a.head_wh && !a.compact && tiles32 < 512 && tiles32 != 256) ? 2 : 1;
 }
@@ -1450,11 +1451,15 @@ bool bf_fused_block_h3_is_streaming(const FusedH3Args& a)
 // bf_launch_fused_block_h3 picks.  Measured (tools/exp/regime_sweep.py, resnet 1x18, us per forward, pairs / 16 x 32 tiles):
 // 8 x 256^2 403 / 429, 6 x 256^2 357 / 355, 2 x 512^2 404 / 424, 1 x 512^2 295 / 282, 32 x 128^2 397 / 420, 16 x 128^2 291 / 281,
 // 32 x 512^2 4 300 / 5 570, 1 x 1080 x 1920 2 207 / 2 747.
-bool bf_fused_block_h3_pairs_preferred(const FusedH3Args& a)
+// Images of fewer than 24 rows are the exception (a band's 12-step fill per handful of rows): 512 x 8 x 256 runs 830 us on the one-block
+// streaming kernel, 899 in pairs; 300 x 20 x 100 867 on tiles, 969 in pairs -- they keep the one-block selection of h3_default_variant.
+// A variant forced through set_option / bf_debug_set_h3_variant pairs exactly where it selects the streaming kernel (tests, A/B).
+bool bf_fused_block_h3_use_pairs(const FusedH3Args& a)
 {
-    if (a.variant >= 0 || g_h3_variant >= 0 || a.head_wh || a.compact) return false;
+    if (a.head_wh || a.compact) return false;
+    if (a.variant >= 0 || g_h3_variant >= 0) return bf_fused_block_h3_is_streaming(a);
     const int64_t nstrips = (a.W + 127) / 128;
-    return a.W >= 1 && a.H >= 1 && (int64_t)a.B * a.H * nstrips >= 4096;
+    return a.W >= 1 && a.H >= 24 && (int64_t)a.B * a.H * nstrips >= 4096;
 }
 
 // name of the kernel bf_launch_fused_block_h3 launches for these arguments
