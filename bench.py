@@ -725,8 +725,9 @@ def block_roofline(kernel, launches_per_forward, layers, B, S, launch_s, traffic
                 dtype="f32")
 
 
-def sub_record(model, module, noisy, noisy_host, spec, params, state, O, N, torch, arith, steps, warmup, S, compact=0):
-    """one more timed loop of the default workload on `model` with another arithmetic / batch / activation layout (rank 0, N = 1)."""
+def sub_record(model, module, noisy, noisy_host, spec, params, state, O, N, torch, arith, steps, warmup, S, compact=0, check=None):
+    """one more timed loop of the default workload on `model` with another arithmetic / batch / activation layout / image size (rank 0,
+    N = 1).  check: indices of the images compared with the oracle (default: parity_sample)."""
     B = int(noisy.shape[0])
     model.set_option("arith", arith)
     model.set_option("h3_compact", compact)
@@ -744,7 +745,7 @@ def sub_record(model, module, noisy, noisy_host, spec, params, state, O, N, torc
     N.check(N.lib().bf_get_timing(model._h, C.byref(ms), C.byref(ln)), model._h)
     launch_s = float(ms.value) / 1e3 / max(int(ln.value), 1)
     kernel, lpf = block_kernel_info(N, model)
-    idx = parity_sample(B)
+    idx = parity_sample(B) if check is None else list(check)
     ref = O.denoiser_module_call(spec, params, state, noisy_host[idx])
     diff = np.abs(out[idx].cpu().numpy().astype(np.int32) - ref.astype(np.int32))
     px = B * S * S
@@ -935,6 +936,17 @@ def main():
                                            arith=1, steps=max(args.steps // 2, 10), warmup=max(args.warmup // 2, 3), S=S)
             result["compact24"] = sub_record(model, module, noisy, noisy_host, spec, params, state, O, N, torch, arith=1,
                                              steps=max(args.steps // 2, 10), warmup=max(args.warmup // 2, 3), S=S, compact=1)
+            #   wide_512   : the same network and pixel count on 512 x 512 images (batch / 4): wider than the 256 columns of the one-block
+            #                streaming kernel, two blocks per launch on 128-column strips (round 3; the tile kernel before)
+            if S == 256 and B % 4 == 0:
+                _, wide4 = O.synthetic_batch(4, 512, 512, sigma=20.0, seed=4321)
+                wide_host = np.concatenate([wide4] * (B // 16 + 1), axis=0)[:B // 4]
+                result["wide_512"] = sub_record(model, module, torch.from_numpy(wide_host).cuda(), wide_host, spec, params, state, O, N, torch,
+                                                arith=1, steps=max(args.steps // 4, 10), warmup=max(args.warmup // 4, 3), S=512,
+                                                check=[0, B // 4 - 1])
+                result["wide_512"]["workload"] = f"resnet_color_1x{spec.no_layers}_bn_16x3x3 inference, batch={B // 4} 512x512x3 uint8"
+            model.set_option("arith", 1)
+            model.set_option("h3_compact", 0)
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
