@@ -170,6 +170,37 @@ def test_wide_images_run_two_blocks_per_launch_by_default(no_layers):
     assert m.block_kernel()[0] == "fused_block_h3r_kernel"
 
 
+@pytest.mark.parametrize("seed", range(max(4, int(os.environ.get("BF_SWEEP_N", 24)) // 4)))
+def test_random_large_shapes_default_selection_matches_tiles_and_oracle(seed):
+    """seeded draws of shapes that the default selection sends to two blocks per launch (>= 4 096 rows of 128-column strips: any width,
+    ragged sizes, odd and even block counts): the kernel the library reports, the oracle on the first and last image, and the tile
+    kernel (h3_pair = 0, h3_variant = 1) on the whole batch within one grey level."""
+    rng = np.random.default_rng(5000 + seed)
+    no_layers = int(rng.integers(2, 6))
+    W = int(rng.choice([rng.integers(24, 129), rng.integers(129, 257), rng.integers(257, 900)]))
+    H = int(rng.integers(24, 300))
+    Hp, Wp = 1 << (H - 1).bit_length(), 1 << (W - 1).bit_length()           # the module pads to powers of two (virtually)
+    nstrips = (Wp + 127) // 128
+    B = -(-4096 // (Hp * nstrips)) + int(rng.integers(0, 3))
+    if B * Hp * Wp > 6_000_000:
+        pytest.skip("too large for a sweep draw")
+    cfg, spec, params, state, m = _model(no_layers, seed=seed)
+    _, noisy = O.synthetic_batch(B, H, W, seed=seed)
+    mod = bf.DenoiserModule(m)
+    got = mod(noisy)
+    assert m.block_kernel()[0] == "fused_block2_h3w_kernel", (B, H, W, m.block_kernel())
+    _check_u8(got[:1], O.denoiser_module_call(spec, params, state, noisy[:1]))
+    _check_u8(got[-1:], O.denoiser_module_call(spec, params, state, noisy[-1:]))
+    m.set_option("h3_pair", 0)
+    m.set_option("h3_variant", 1)
+    try:
+        tiles = mod(noisy)
+    finally:
+        m.set_option("h3_pair", 1)
+        m.set_option("h3_variant", -1)
+    assert np.abs(tiles.astype(int) - got.astype(int)).max() <= 1
+
+
 def test_two_blocks_per_launch_status_word_with_the_head_in_the_launch():
     """activations beyond the f16 range must still reach the status word when the head runs inside the last pair launch"""
     cfg, spec, params, state, m = _model(2, seed=5)
