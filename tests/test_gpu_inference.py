@@ -2,9 +2,8 @@
 host API -> C ABI, against the fp64 oracle and the committed golden fixtures.
 Bars (BASELINE.json north_star): uint8 outputs within +-1 LSB; f32 hydra output MAE <= 1e-4 on
 the normalised [-0.5, 0.5] scale (= 0.0255 on the 0..255 scale)."""
-import pathlib
-
 import os
+import pathlib
 
 import numpy as np
 import pytest
