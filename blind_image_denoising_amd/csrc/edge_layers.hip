@@ -120,13 +120,22 @@ static hipError_t launch_base(const BaseConvArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
-static int g_base_rows = 1;                           // 0: the vector kernel everywhere (A/B, tests)
-void bf_set_base_conv_rows(int on) { g_base_rows = on ? 1 : 0; }
+static int g_base_rows = 1;                           // 0: the vector kernel everywhere, 2: the row kernel wherever it can run (A/B, tests)
+void bf_set_base_conv_rows(int on) { g_base_rows = on == 2 ? 2 : (on ? 1 : 0); }
+// The row kernel pays ~11 row steps of latency per workgroup before it streams (three ring rows + at least eight rows of a band) and
+// works on 256-column chunks: below ~8 192 rows of chunks per forward, or with chunks less than 60 % full, the tile kernel is ahead
+// (tools/exp/base_select.py, resnet 1x6 per call: 1 x 256^2 57 us for 68, 8 x 256^2 151 for 158, 16 x 256^2 237 for 239, 32 x 256^2 439
+// for 420, 64 x 64^2 138 for 154).
+static bool base_rows_preferred(const BaseConvArgs& a)
+{
+    const int64_t nchunks = (a.W + 255) / 256;
+    return (int64_t)a.B * a.H * nchunks >= 8192 && (int64_t)a.W * 5 >= nchunks * 256 * 3;
+}
 
 hipError_t bf_launch_base_conv(const BaseConvArgs& a, hipStream_t s)
 {
     // the metric's configuration (u8 in, 3x3x3 -> 16, split-planar out): row-streaming matrix-core kernel (base_rows.hip)
-    if (g_base_rows && bf_base_conv_rows_supports(a)) return bf_launch_base_conv_rows(a, s);
+    if (g_base_rows && bf_base_conv_rows_supports(a) && (g_base_rows == 2 || base_rows_preferred(a))) return bf_launch_base_conv_rows(a, s);
 #define BF_BASE(C, KK) if (a.cin == C && a.k == KK) return launch_base<C, KK>(a, s);
     BF_BASE(3, 3) BF_BASE(3, 5) BF_BASE(3, 7) BF_BASE(3, 1)
     BF_BASE(1, 3) BF_BASE(1, 5) BF_BASE(1, 7) BF_BASE(1, 1)

@@ -138,7 +138,7 @@ class GraphedDenoiserModule:
     whole call -- eleven to twenty launches for resnet 1x18, about sixty operator calls from Python for unet_laplacian -- can be
     captured once per shape and then costs the host a single launch.  What that buys is HOST time (one launch instead of a walk over
     the graph in Python), not latency: a batch-1 call is bound by its kernels on the GPU either way (`bench.py --mode latency`:
-    resnet 1x18 145 us replayed, 150 us launched on the stream; unet_laplacian v5 at 512 x 512: 750-780 us either way).  The first call with a
+    resnet 1x18 133 us replayed, 142 us launched on the stream; unet_laplacian v5 at 512 x 512: 750-780 us either way).  The first call with a
     new [B,H,W,C] runs the module twice directly (packing, workspace, kernel attributes), captures it on a static input tensor and
     keeps the graph; later calls copy the image into that tensor and replay.  At most `max_shapes` graphs are kept (least recently
     used goes first).  The result is a fresh tensor unless `copy_output=False` (then it is the graph's own output buffer, valid until

@@ -536,6 +536,7 @@ def test_row_streaming_base_convolution_matches_the_vector_kernel_and_the_oracle
     power-of-two padding carried by a fourth 'inside' channel) against the vector kernel (option base_rows = 0) and the oracle,
     ragged sizes with the virtual padding on, more than one 256-column chunk."""
     cfg, spec, params, state, m = _model(2, seed=17)
+    m.set_option("base_rows", 2)               # the row kernel wherever it can run (by default only from ~8 192 rows of chunks on)
     _, noisy = O.synthetic_batch(2, hw[0], hw[1], seed=11 + hw[0])
     ref = O.denoiser_module_call(spec, params, state, noisy)
     got = bf.DenoiserModule(m)(noisy)
