@@ -531,7 +531,9 @@ int bf_op_axpy(float* y, const float* x, float a, int overwrite, int64_t n, void
  * "h3_pair": 1 (default): wherever the full-row streaming kernel applies, consecutive residual blocks run TWO per launch
  *   (fused_block2_h3w_kernel: the activation between them stays in LDS; an odd block count runs its single block first); 0: one
  *   block per launch.  "h3_pair_head": 1: the last pair launch also runs a linear 3-channel head in its store step (no head
- *   kernel); 0 (default; the two measure the same).
+ *   kernel); 0 (default; the two measure the same).  "h3_pair" = 2 and "base_rows" = 2 (A/B and tests only) run the two-block kernel /
+ *   the row-streaming base convolution wherever they CAN run instead of where the selection prefers them ("base_rows" = 0: the
+ *   tile kernel of the base convolution everywhere; process-wide).
  * "fused_tile" / "h3_variant": kernel variants of the fused blocks (A/B only; negative = default). */
 int bf_set_option(bf_handle h, const char* key, int value);
 
