@@ -831,11 +831,18 @@ extern "C" int bf_op_dwconv_ln(const float* in, float* out, const float* w, cons
     bool ok = false;
     constexpr int RROWS = 32;          // rows per workgroup: k - 1 halo rows are re-read and re-multiplied per strip
                                        // (64 channels, 5x5, 32 x 256 x 256: 16 rows 376 us, 32 rows 350 us)
+    // small inputs: 8-row strips put four times the workgroups on the chip (one 512 x 512 image, level 1: 27 us with 128 workgroups
+    // of 32 rows; tools/exp/unet_b1_prof.sh)
+    constexpr int RSMALL = 8;
 #define UO_DWR(CC, KK)                                                                                                        \
-    if (C == CC && k == KK && B <= 65535 && (H + RROWS - 1) / RROWS <= 65535) {                                               \
+    if (C == CC && k == KK && B <= 65535 && (H + RSMALL - 1) / RSMALL <= 65535) {                                             \
         constexpr int PPB = 256 / (CC / 4);                                                                                   \
-        hipLaunchKernelGGL((uo_dwconv_ln_rows_kernel<CC, KK, RROWS>), dim3((W + PPB - 1) / PPB, (H + RROWS - 1) / RROWS, B),  \
-                           dim3(256), 0, s, in, out, w, ln_gamma, H, W, eps, act, alpha);                                      \
+        if ((int64_t)B * ((W + PPB - 1) / PPB) * ((H + RROWS - 1) / RROWS) < 512)                                             \
+            hipLaunchKernelGGL((uo_dwconv_ln_rows_kernel<CC, KK, RSMALL>), dim3((W + PPB - 1) / PPB, (H + RSMALL - 1) / RSMALL, B), \
+                               dim3(256), 0, s, in, out, w, ln_gamma, H, W, eps, act, alpha);                                  \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((uo_dwconv_ln_rows_kernel<CC, KK, RROWS>), dim3((W + PPB - 1) / PPB, (H + RROWS - 1) / RROWS, B), \
+                               dim3(256), 0, s, in, out, w, ln_gamma, H, W, eps, act, alpha);                                  \
         return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;                                                              \
     }
     UO_DWR(32, 3) UO_DWR(32, 5) UO_DWR(64, 3) UO_DWR(64, 5) UO_DWR(128, 3) UO_DWR(128, 5)
