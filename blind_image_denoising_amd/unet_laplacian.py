@@ -623,14 +623,17 @@ class UnetLaplacianHydra:
                 o2 = dict((v[0], v[3]) for v in self.trainable_variables)[f"{prefix}/pw2/kernel"]
                 P[f"{prefix}/mlp_h3"] = pack_mlp_h3(self.params[off:off + n1].clone().view(shape[2], shape[3]),
                                                    self.params[o2:o2 + n2].clone().view(shape[3], shape[2]))
-        if self.attention_rows and self.filters == 32:
-            # query | "value" operand | "key" operand side by side = query_conv | key_conv | value_conv (the archive's wiring)
+        if self.filters == 32:
+            # the three projections of an attention block as ONE 1x1 convolution 128 -> 96: query | "value" operand | "key" operand side
+            # by side = query_conv | key_conv | value_conv in the archive's wiring (attention_rows), query_conv | value_conv | key_conv in
+            # the snapshot builder's (custom_layers.py:1353-1360) -- the order `_attention` hands them to the attention operator in
             tv = {v[0]: v for v in self.trainable_variables}
+            order = ("query", "key", "value") if self.attention_rows else ("query", "value", "key")
             for name, (_, shape, _, off) in list(tv.items()):
                 if name.endswith("/query/kernel") and shape[2] == 128:
                     prefix = name[:-len("/query/kernel")]
                     mats = []
-                    for nm in ("query", "key", "value"):
+                    for nm in order:
                         o = tv[f"{prefix}/{nm}/kernel"][3]
                         mats.append(self.params[o:o + shape[2] * shape[3]].view(shape[2], shape[3]))
                     P[f"{prefix}/qvk"] = pack_pointwise(torch.cat(mats, dim=1).contiguous().view(1, 1, shape[2], 3 * shape[3]))
@@ -689,8 +692,11 @@ class UnetLaplacianHydra:
         t = resize_bilinear(x, rh, rw)
         if self.use_ln:
             t = dwconv_ln(t, None, P[f"{prefix}/ln/gamma"])
-        q, v, k = (pointwise(t, P[f"{prefix}/{n}/kernel"], A, **qkv_act).view(B, rh * rw, A) for n in ("query", "value", "key"))
-        t = attention(q, v, k).view(B, rh, rw, A)
+        if f"{prefix}/qvk" in P:                               # the three projections in one pass over t
+            t = attention_interleaved(pointwise(t, P[f"{prefix}/qvk"], 3 * A, **qkv_act).view(B, rh * rw, 3 * A), A).view(B, rh, rw, A)
+        else:
+            q, v, k = (pointwise(t, P[f"{prefix}/{n}/kernel"], A, **qkv_act).view(B, rh * rw, A) for n in ("query", "value", "key"))
+            t = attention(q, v, k).view(B, rh, rw, A)
         t = resize_bilinear(t, H, W)
         return pointwise(t, P[f"{prefix}/out/kernel"], C, "linear", mult=P[f"{prefix}/gamma/w"], res=x)
 
