@@ -145,6 +145,18 @@ def cpu_baseline_torch(spec, params, state, noisy_u8, budget_s=10.0, nthreads=No
                       f"{nthreads} threads) with the restatement's tensors"}, out1
 
 
+def all_agree(torch, dist, ok):
+    """True when EVERY rank says ok (MIN over the ranks).  A guarded stage that holds collectives must be followed by this before
+    the next collective: a rank that failed alone (RCCL dlopen, a duplicate device in a rehearsal) would otherwise leave its
+    peers inside a collective it never enters, and the bench would hang instead of recording a note."""
+    if dist is None:
+        return bool(ok)
+    dev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
 def time_gradient_exchange(torch, bf, model, prep, clean_dev, world, dist):
     """what the ONE collective of a training step costs on this box, next to the work it is supposed to hide behind
     (DataParallelTrainer.step(overlap=...): the next batch's on-device corruption): HIP-event time per call of
@@ -177,13 +189,37 @@ def time_gradient_exchange(torch, bf, model, prep, clean_dev, world, dist):
             return e0.elapsed_time(e1) * 1e3 / n
 
         out["torch_distributed_all_reduce_us"] = timed(lambda: d.all_reduce(g))
-        try:
-            comm = bf.NativeCommunicator(torch.device("cuda", torch.cuda.current_device()))
+        # the C ABI's collective: every stage that holds a collective is agreed on by all ranks before the next one starts
+        comm, note = None, None
+        if os.environ.get("BF_BENCH_REHEARSE") == "1" and world > 1:
+            note = "rehearsal (ranks share a GPU over gloo): RCCL cannot form a communicator with duplicate devices, skipped"
+        else:
+            try:
+                comm = bf.NativeCommunicator(torch.device("cuda", torch.cuda.current_device()))
+            except Exception as e:
+                note = str(e)[:200]
+        if not all_agree(torch, d if (dist is not None or own_group) else None, comm is not None):
+            if comm is not None:
+                comm.close()
+            comm = None
+            note = note or "another rank could not create its communicator"
+        if comm is not None:
             out["c_abi_bf_allreduce_grads_us"] = timed(lambda: comm.allreduce(g))
+            # the same calls seen from the communicator's OWN stream (events recorded there: the all-reduce kernels alone)
+            cs = comm._stream
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record(cs)
+            for _ in range(50):
+                comm.launch(g)
+            e1.record(cs)
+            comm.wait(g)
+            torch.cuda.synchronize()
+            out["c_abi_bf_allreduce_grads_on_its_stream_us"] = e0.elapsed_time(e1) * 1e3 / 50
             comm.close()
-        except Exception as e:
+        else:
             out["c_abi_bf_allreduce_grads_us"] = None
-            out["c_abi_note"] = str(e)[:200]
+            out["c_abi_note"] = note
         out["overlap_work_us"] = timed(lambda: prep(clean_dev), n=20)
         out["overlap_work"] = "PrepareData on the next batch (flips + truncated-normal noise on the device, bf_noise_augment)"
     except Exception as e:
@@ -356,11 +392,21 @@ def unet_flop_per_px(m):
 
 
 def unet_bench(args, torch, bf, O, rank, local_rank, world, dist):
+    rec = unet_run(args, torch, bf, O, rank, local_rank, world, dist, args.steps, args.warmup, cpu=not args.no_cpu_baseline)
+    if rec is not None:
+        print(json.dumps(rec), flush=True)
+
+
+def unet_run(args, torch, bf, O, rank, local_rank, world, dist, steps, warmup, cpu=True, B=None, S=None):
     """configs[4]: unet_laplacian (v5 graph: depth 3, width 3, 32/64/128 filters) inference, batch 32 512x512x3,
     uint8 -> uint8 through DenoiserModule.__call__ (only the full-resolution head is evaluated, as the module keeps
-    output 0).  Images are independent: N ranks = N replicas, no collective."""
+    output 0).  Images are independent: N ranks = N replicas, no collective.  Returns the record on rank 0 (`--mode unet` prints
+    it; the default mode carries a short run of it as the `unet` sub-record)."""
     from oracle import unet_oracle as U
-    B, S = (32 if args.batch == 128 else args.batch), (512 if args.size == 256 else args.size)
+    if B is None:
+        B = 32 if args.batch == 128 else args.batch
+    if S is None:
+        S = 512 if args.size == 256 else args.size
     trained = args.unet_graph == "v5.6"
     if trained:
         # the reference's trained network (graph revision and tensors of pretrained/unet_laplacian_v5.6, committed as data
@@ -383,11 +429,11 @@ def unet_bench(args, torch, bf, O, rank, local_rank, world, dist):
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         out = module(noisy)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = module(noisy)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -396,14 +442,14 @@ def unet_bench(args, torch, bf, O, rank, local_rank, world, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank != 0:
-        return
+        return None
     # parity of one small crop against the oracle (the full 512^2 image takes the fp64 NumPy oracle minutes)
     crop = base[:1, :64, :64]
     ref = U.denoiser_module_call(spec, params, crop)
     got = module(torch.from_numpy(np.ascontiguousarray(crop)).cuda()).cpu().numpy()
     diff = np.abs(got.astype(np.int32) - ref.astype(np.int32))
     flop = unet_flop_per_px(model) * B * S * S
-    tf = flop * args.steps / elapsed / 1e12
+    tf = flop * steps / elapsed / 1e12
     # dominant kernel, timed live with events on the launch stream: the level-0 encoder ConvNext block
     # (uh_enc32_kernel: x read once, out written once = 2 * C * 4 B per pixel algorithmic)
     from blind_image_denoising_amd import unet_laplacian as UL
@@ -425,9 +471,9 @@ def unet_bench(args, torch, bf, O, rank, local_rank, world, dist):
     gbs = blk_bytes / launch_us / 1e3
     blk_flop = B * S * S * (2.0 * 25 * 32 + 2 * 2.0 * 32 * 128)
     rec = {
-        "metric": "denoised images/sec (512x512x3), unet_laplacian 3-scale", "value": world * B * args.steps / elapsed,
-        "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "metric": "denoised images/sec (512x512x3), unet_laplacian 3-scale", "value": world * B * steps / elapsed,
+        "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (ConvNext MLPs: f16x2 split hi+lo, fp32 accumulate)", "data": "synthetic",
         "config": {"workload": f"unet_laplacian {'v5.6 trained archive graph' if trained else 'v5 graph'} (depth 3, width 3, "
                                f"filters 32/64/128, attention on the deepest "
@@ -447,19 +493,58 @@ def unet_bench(args, torch, bf, O, rank, local_rank, world, dist):
         den = out[:4].cpu().numpy()
         rec["denoising"] = {"mae_noisy": mae(clean, base), "mae_denoised": mae(clean, den),
                             "note": "synthetic smooth fields + truncated normal noise, std 20 (SURVEY 8d); trained weights"}
-    if not args.no_cpu_baseline:
-        import time as _t
+    if cpu:
+        # leg (i), the reported baseline: the same graph on torch-CPU fp32 with all the host cores this process may use
+        # (oracle/unet_torch.py: the restatement's forward on torch.nn.functional tensor ops; whole SxS images, no scaling);
+        # leg (ii): the fp64 NumPy oracle on one 256x256 crop, scaled by the pixel ratio, kept beside it as `other_leg`
         small = base[:1, :256, :256]
-        t0 = _t.perf_counter()
+        t0 = time.perf_counter()
         nrep = 0
-        while nrep < 1 or (_t.perf_counter() - t0 < 8.0 and nrep < 16):                  # ~10 s of CPU work
+        while nrep < 1 or (time.perf_counter() - t0 < 5.0 and nrep < 16):
             U.denoiser_module_call(spec, params, small)
             nrep += 1
-        dt = (_t.perf_counter() - t0) / nrep
-        rec["cpu_baseline"] = {"value": 1.0 / (dt * (S * S) / (256.0 * 256.0)), "unit": "images/s", "cores": 1, "kind": "port",
-                               "sample": f"{nrep} x one 256x256 crop through oracle/unet_oracle.py (fp64 NumPy restatement, not TensorFlow; "
-                                         f"BLAS threads as NumPy picks them), scaled by the pixel ratio to {S}x{S}"}
-    print(json.dumps(rec), flush=True)
+        dt = (time.perf_counter() - t0) / nrep
+        oracle_leg = {"value": 1.0 / (dt * (S * S) / (256.0 * 256.0)), "unit": "images/s", "cores": 1, "kind": "port",
+                      "sample": f"{nrep} x one 256x256 crop through oracle/unet_oracle.py (fp64 NumPy restatement, not TensorFlow; "
+                                f"BLAS threads as NumPy picks them), scaled by the pixel ratio to {S}x{S}"}
+        try:
+            rec["cpu_baseline"] = cpu_unet_baseline_torch(spec, params, base[:1], ref_crop=(crop, ref))
+            rec["cpu_baseline"]["other_leg"] = oracle_leg
+        except Exception as e:                              # the torch-CPU leg must never fail the bench
+            rec["cpu_baseline"] = dict(oracle_leg, note=f"torch-CPU leg failed: {str(e)[:200]}")
+    return rec
+
+
+def cpu_unet_baseline_torch(spec, params, image_u8, budget_s=10.0, nthreads=None, ref_crop=None):
+    """unet_laplacian inference on PyTorch-CPU, fp32, all host cores this process may use: oracle/unet_torch.py's forward (the
+    NumPy restatement on torch tensor ops: conv2d / layer norm / interpolate; first output only, round + uint8 as the module does)
+    on whole images of the bench's size.  A CPU restatement of the same graph, not TensorFlow."""
+    import torch
+    from oracle import unet_torch as UT
+    if nthreads is None:
+        nthreads = host_cores()
+    torch.set_num_threads(int(nthreads))
+    P = UT.views(spec, torch.from_numpy(np.asarray(params, np.float32)))
+
+    def forward(u8):
+        with torch.no_grad():
+            y = UT.hydra(spec, P, torch.from_numpy(u8.astype(np.float32)))[0]
+            return torch.round(y).clamp(0, 255).to(torch.uint8).numpy()
+    note = {}
+    if ref_crop is not None:                               # the leg computes what the oracle computes (+-1 LSB: fp32 against fp64)
+        c, r = ref_crop
+        note["max_abs_lsb_vs_oracle_on_the_parity_crop"] = int(np.abs(forward(c).astype(np.int32) - r.astype(np.int32)).max())
+    forward(image_u8[:1])                                  # warm-up (oneDNN primitive creation)
+    t0 = time.perf_counter()
+    nrep = 0
+    while nrep < 1 or (time.perf_counter() - t0 < budget_s and nrep < 64):
+        forward(image_u8[:1])
+        nrep += 1
+    dt = (time.perf_counter() - t0) / nrep
+    S = image_u8.shape[1]
+    return dict({"value": 1.0 / dt, "unit": "images/s", "cores": int(nthreads), "kind": "port",
+                 "sample": f"{nrep} x one {S}x{S}x3 uint8 image through oracle/unet_torch.py's forward in fp32 (torch-CPU {torch.__version__}, "
+                           f"{nthreads} threads; CPU restatement of the same graph, not TensorFlow; {dt * nrep:.1f} s)"}, **note)
 
 
 def latency_bench(args, torch, bf, O, rank, local_rank, world, dist):
@@ -532,22 +617,70 @@ def latency_bench(args, torch, bf, O, rank, local_rank, world, dist):
 
 
 def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
+    rec = train_run(args, torch, bf, O, rank, local_rank, world, dist, args.steps, args.warmup, cpu=not args.no_cpu_baseline)
+    if rec is not None:
+        print(json.dumps(rec), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def train_parity_crop(torch, bf, O, cfg, layers, device):
+    """the training step of the SAME network on a crop the fp64 oracle finishes in a second (2 x 48 x 48), head kernels scaled by
+    0.1 as in tests/test_gpu_training.py::test_config4_network_on_a_reduced_crop_matches_oracle (a freshly initialised 18-block
+    network otherwise sits on the denormaliser's clip, whose derivative is discontinuous): loss and gradient error against the oracle."""
+    spec = O.ResnetSpec.from_config(cfg["model"])
+    ls = O.LossSpec.from_config(cfg["loss"])
+    params, state = O.init_params(spec, seed=42, nontrivial_bn=True)
+    for name, (o, sh) in spec.offsets().items():
+        if name.startswith("head"):
+            params[o:o + int(np.prod(sh))] *= 0.1
+    m = bf.model_builder(cfg["model"], device=device).hydra
+    m.set_weights(params, state)
+    fns = bf.build_train_functions(m, bf.loss_function_builder(cfg["loss"]))
+    clean, noisy = O.synthetic_batch(2, 48, 48, seed=21)
+    gt, x = clean.astype(np.float32), noisy.astype(np.float32)
+    total, _, _, _, grads = fns.train_step_single_gpu(torch.from_numpy(gt), torch.from_numpy(x), (1.0,), 0.0, None)
+    r_total, _, _, _, r_grads, _ = O.train_step_single_gpu(spec, ls, params, state, gt.astype(np.float64), x.astype(np.float64))
+    g = grads.cpu().numpy().astype(np.float64)
+    worst = 0.0
+    for name, (o, sh) in spec.offsets().items():
+        n = int(np.prod(sh))
+        worst = max(worst, float(np.abs(g[o:o + n] - r_grads[o:o + n]).max() / max(np.abs(r_grads[o:o + n]).max(), 1e-6)))
+    return {"loss_rel_err": float(abs(total.item() - r_total) / abs(r_total)), "grad_max_err_of_tensor_max": worst,
+            "bars": {"loss_rel_err": 1e-5, "grad_max_err_of_tensor_max": 6e-4},
+            "checked": f"2 x 48 x 48 crop, all {layers} blocks, vs oracle/bfcnn_oracle.py train_step_single_gpu (fp64)"}
+
+
+def train_kernels(N, model):
+    """the block kernels the model's LAST bf_train_step launched, as the LIBRARY reports them (bf_get_train_kernels)"""
+    name = N.lib().bf_get_train_kernels(model._h)
+    return name.decode() if name else ""
+
+
+def train_run(args, torch, bf, O, rank, local_rank, world, dist, steps, warmup, cpu=True, exchange=True, parity=True, roofline=True,
+              native_collective=False, check_replicas=False, B=None, S=None):
     """configs[3]: resnet_color_1x18 training step, L1 loss (hinge 0.5), additive-gaussian synthetic batch, global batch =
-    --batch x world sharded over the ranks, one sum-all-reduce of the flat fp32 gradient buffer, fused clip + Adam."""
-    B = 32 if args.batch == 128 else args.batch            # per-GPU shard (256 global on 8 GPUs)
-    S = args.size
-    cfg = O.canonical_config(no_layers=args.layers)
+    --batch x world sharded over the ranks, one sum-all-reduce of the flat fp32 gradient buffer, fused clip + Adam.
+    EVERY rank calls this (it holds collectives); the record comes back on rank 0 (`--mode train` prints it; the default mode carries
+    short runs of it as the `train` / `train_dp` sub-records)."""
+    if B is None:
+        B = 32 if args.batch == 128 else args.batch        # per-GPU shard (256 global on 8 GPUs)
+    if S is None:
+        S = args.size
+    layers = args.layers
+    cfg = O.canonical_config(no_layers=layers)
     if args.loss == "shipped":        # the loss section of the reference's shipped configs (configs/unet_laplacian_v5.json)
         cfg["loss"].update({"hinge": 3.5, "cutoff": 255.0, "mae_multiplier": 1.0, "mse_multiplier": 0.5, "ssim_multiplier": 1.0})
     spec = O.ResnetSpec.from_config(cfg["model"])
-    params, state = O.init_params(spec, seed=42, nontrivial_bn=False)
+    params, state = O.init_params(spec, seed=42 + (rank if check_replicas else 0), nontrivial_bn=False)   # (replica check: ranks START different)
     model = bf.model_builder(cfg["model"], device=f"cuda:{local_rank}").hydra
     model.set_weights(params, state)
     for kv in args.opt:
         k, v = kv.split("=")
         model.set_option(k, int(v))
     opt, _ = bf.optimizer_builder(cfg["train"]["optimizer"])
-    trainer = bf.DataParallelTrainer(model, bf.loss_function_builder(cfg["loss"]), opt)
+    trainer = bf.DataParallelTrainer(model, bf.loss_function_builder(cfg["loss"]), opt, native_collective=native_collective)
     trainer.broadcast_parameters()
     clean, noisy = O.synthetic_batch(min(B, 8), S, S, sigma=20.0, seed=1234 + rank)
     reps = (B + clean.shape[0] - 1) // clean.shape[0]
@@ -566,11 +699,11 @@ def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
     # the reduced gradients
     total = None
     batch = prep(clean_dev)
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         total, _, _, _, batch = trainer.step(*batch, overlap=lambda: prep(clean_dev))
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         total, _, _, _, batch = trainer.step(*batch, overlap=lambda: prep(clean_dev))
     barrier()
     elapsed = time.perf_counter() - t0
@@ -578,93 +711,149 @@ def train_bench(args, torch, bf, O, rank, local_rank, world, dist):
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    exchange = time_gradient_exchange(torch, bf, model, prep, clean_dev, world, dist)      # every rank takes part
-    if rank == 0:
-        # algorithmic FLOPs per image: fwd + dgrad + wgrad of every 3x3 16->16 conv, fwd + wgrad of the base conv, head fwd + bwd
-        per_px = 3 * args.layers * FLOP_PER_PX_BLOCK + 2 * 2 * 9 * 3 * 16 + 3 * 2 * (16 * 32 + 32 * 3)
-        value = B * world * args.steps / elapsed
-        # dominant kernel (18 of the ~150 launches of a step, ~26 % of its time; its sibling for a block's first convolution
-        # takes as long): the fused backward of a block's second convolution -- BatchNorm-backward apply on load, weight
-        # gradient, masked data gradient.  Algorithmic bytes: dy, conv_out and x read once, dx written once (4 * 64 B per pixel).
-        # Timed live with events on the launch stream through the C ABI's single-kernel entry.
-        from blind_image_denoising_amd import _native as N
-        L = N.lib()
-        xw = torch.relu(torch.randn((B, S, S, 16), device="cuda"))
-        gw = torch.randn((B, S, S, 16), device="cuda") * 0.1
-        cw = torch.randn((B, S, S, 16), device="cuda")
-        coef = torch.cat([torch.ones(16), torch.full((16,), 0.1), torch.full((16,), 0.01)]).cuda()
-        wk = torch.randn((3, 3, 16, 16), device="cuda") * 0.1
-        dxw = torch.empty_like(xw)
-        dw = torch.empty(2304, device="cuda")
-        scr = torch.empty(int(L.bf_debug_bwd3x3_h3_scratch_floats(B, S, S)), device="cuda")
-        calls = [0]
-
-        def wg():
-            N.check(L.bf_debug_bwd3x3_h3(N.ptr(xw), N.ptr(gw), N.ptr(cw), N.ptr(coef), N.ptr(wk), N.ptr(dxw), None, None, N.ptr(dw),
-                                         None, N.ptr(scr), B, S, S, N.EPI_MASK, calls[0] & 1, 1 if calls[0] == 0 else 0,
-                                         N.stream_ptr(xw)), None, "bwd3x3_h3")
-            calls[0] += 1
-        for _ in range(3):
-            wg()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        nl = 20
-        e0.record()
-        for _ in range(nl):
-            wg()
-        e1.record()
-        torch.cuda.synchronize()
-        launch_us = e0.elapsed_time(e1) * 1e3 / nl            # the kernel + the 7 us reduction of its weight-gradient partials
-        wbytes = B * S * S * 16 * 4 * 4
-        gbs = wbytes / launch_us / 1e3
-        rec = {
-            "metric": "training images/sec (256x256x3), resnet_1x18 data-parallel step", "value": value, "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (convolutions: f16x2 split hi+lo, fp32 accumulate)",
-            "data": "synthetic",
-            "config": {"workload": f"resnet_color_1x{args.layers}_bn_16x3x3 training step ("
-                                   f"{'L1 hinge 3.5 + 0.5 RMSE + SSIM' if args.loss == 'shipped' else 'L1 hinge 0.5'}, Adam, global clipnorm 1), "
-                                   f"batch={B}/GPU {S}x{S}x3 float32 corrupted on the device every step, one all-reduce of {model.n_params} fp32 gradients",
-                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
-            "last_total_loss": float(total.item()),
-            "end_to_end_tflops": value / world * per_px * S * S / 1e12,
-            "roofline": {"bound": "hbm", "kernel": "bwd3x3_h3_kernel<true, 8> (+ reduce_partials_kernel)", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.layers, B, S, True, "bwd3x3_h3_kernel<true, 8>"), "algorithmic_bytes_per_launch": wbytes,
-                         "launch_us": launch_us, "launches_of_this_kernel_per_step": args.layers}}
-        rec["gradient_exchange"] = exchange
-        if os.environ.get("BF_BENCH_REHEARSE") == "1":
-            rec["rehearsal"] = True              # ranks shared a GPU over gloo: exercises the launch path, not a measurement
-        if dist is not None:
-            rec["world_size_seen"] = int(dist.get_world_size())
-        rec["visible_gpus"] = int(torch.cuda.device_count())
-        if world == 1 and not args.no_cpu_baseline:
-            # leg (i): the same graph on torch-CPU fp32 autograd with all host cores (the reported baseline); leg (ii): the oracle's
-            # training step (fp64 NumPy restatement) on ONE image of the same shape, kept beside it
-            ls = O.LossSpec.from_config(cfg["loss"])
-            c1, n1 = O.synthetic_batch(1, S, S, sigma=20.0, seed=99)
-            t0 = time.perf_counter()
-            nrep = 0
-            while nrep < 1 or (time.perf_counter() - t0 < 6.0 and nrep < 16):           # ~6 s of CPU work
-                O.train_step_single_gpu(spec, ls, params, state, c1.astype(np.float64), n1.astype(np.float64))
-                nrep += 1
-            dt = (time.perf_counter() - t0) / nrep
-            oracle_leg = {"value": 1.0 / dt, "unit": "images/s", "cores": 1, "kind": "port",
-                          "sample": f"{nrep} x one {S}x{S} image through oracle/bfcnn_oracle.py train_step_single_gpu (fp64 NumPy "
-                                    f"restatement of forward + loss + backward, BLAS threads as NumPy picks them; not TensorFlow)"}
-            try:
-                try:                                # the C port's OpenMP team size is what the inference legs use on this box
-                    from oracle import port
-                    nthreads = min(host_cores(), int(port.lib(rebuild=False).bfcnn_port_max_threads()))
-                except Exception:
-                    nthreads = host_cores()
-                rec["cpu_baseline"] = cpu_train_baseline_torch(spec, ls, params, state, S, nthreads=nthreads)
-                rec["cpu_baseline"]["other_leg"] = oracle_leg
-            except Exception as e:                      # the torch-CPU leg must never fail the bench
-                rec["cpu_baseline"] = dict(oracle_leg, note=f"torch-CPU leg failed: {e}")
-        print(json.dumps(rec), flush=True)
+    replicas = None
+    if check_replicas and dist is not None:
+        # data-parallel replicas must hold IDENTICAL parameters after the same all-reduced steps (local BatchNorm statistics differ by
+        # design): rank 0's vector is broadcast and every rank reports its largest difference
+        ref = model.params.clone()
+        dist.broadcast(ref, src=0)
+        dmax = (model.params - ref).abs().max().reshape(1).to(torch.float64)
+        dist.all_reduce(dmax, op=dist.ReduceOp.MAX)
+        replicas = float(dmax.item())
+    exch = time_gradient_exchange(torch, bf, model, prep, clean_dev, world, dist) if exchange else None      # every rank takes part
+    if trainer.comm is not None:
+        trainer.comm.close()
+    if rank != 0:
+        return None
+    from blind_image_denoising_amd import _native as N
+    # algorithmic FLOPs per image: fwd + dgrad + wgrad of every 3x3 16->16 conv, fwd + wgrad of the base conv, head fwd + bwd
+    per_px = 3 * layers * FLOP_PER_PX_BLOCK + 2 * 2 * 9 * 3 * 16 + 3 * 2 * (16 * 32 + 32 * 3)
+    value = B * world * steps / elapsed
+    rec = {
+        "metric": "training images/sec (256x256x3), resnet_1x18 data-parallel step", "value": value, "unit": "images/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (convolutions: f16x2 split hi+lo, fp32 accumulate)",
+        "data": "synthetic",
+        "config": {"workload": f"resnet_color_1x{layers}_bn_16x3x3 training step ("
+                               f"{'L1 hinge 3.5 + 0.5 RMSE + SSIM' if args.loss == 'shipped' else 'L1 hinge 0.5'}, Adam, global clipnorm 1), "
+                               f"batch={B}/GPU {S}x{S}x3 float32 corrupted on the device every step, one all-reduce of {model.n_params} fp32 gradients",
+                   "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                   "collective": ("bf_allreduce_grads (C ABI, RCCL, own stream)" if native_collective else "torch.distributed.all_reduce")
+                                 if world > 1 else "none (one rank)"},
+        "last_total_loss": float(total.item()),
+        "end_to_end_tflops": value / world * per_px * S * S / 1e12,
+        "block_kernels": train_kernels(N, model)}
+    if replicas is not None:
+        rec["replicas_max_abs_param_diff"] = replicas
+        rec["replicas_identical"] = replicas == 0.0
+    if roofline:
+        rec["roofline"] = train_roofline(torch, N, model, layers, B, S)
+    if parity:
+        try:
+            rec["parity"] = train_parity_crop(torch, bf, O, cfg, layers, f"cuda:{local_rank}")
+        except Exception as e:
+            rec["parity"] = {"note": f"not checked: {str(e)[:200]}"}
+    if exch is not None:
+        rec["gradient_exchange"] = exch
+    if os.environ.get("BF_BENCH_REHEARSE") == "1":
+        rec["rehearsal"] = True              # ranks shared a GPU over gloo: exercises the launch path, not a measurement
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        rec["world_size_seen"] = int(dist.get_world_size())
+    rec["visible_gpus"] = int(torch.cuda.device_count())
+    if world == 1 and cpu:
+        # leg (i): the same graph on torch-CPU fp32 autograd with all host cores (the reported baseline); leg (ii): the oracle's
+        # training step (fp64 NumPy restatement) on ONE image of the same shape, kept beside it
+        ls = O.LossSpec.from_config(cfg["loss"])
+        c1, n1 = O.synthetic_batch(1, S, S, sigma=20.0, seed=99)
+        t0 = time.perf_counter()
+        nrep = 0
+        while nrep < 1 or (time.perf_counter() - t0 < 6.0 and nrep < 16):           # ~6 s of CPU work
+            O.train_step_single_gpu(spec, ls, params, state, c1.astype(np.float64), n1.astype(np.float64))
+            nrep += 1
+        dt = (time.perf_counter() - t0) / nrep
+        oracle_leg = {"value": 1.0 / dt, "unit": "images/s", "cores": 1, "kind": "port",
+                      "sample": f"{nrep} x one {S}x{S} image through oracle/bfcnn_oracle.py train_step_single_gpu (fp64 NumPy "
+                                f"restatement of forward + loss + backward, BLAS threads as NumPy picks them; not TensorFlow)"}
+        try:
+            try:                                # the C port's OpenMP team size is what the inference legs use on this box
+                from oracle import port
+                nthreads = min(host_cores(), int(port.lib(rebuild=False).bfcnn_port_max_threads()))
+            except Exception:
+                nthreads = host_cores()
+            rec["cpu_baseline"] = cpu_train_baseline_torch(spec, ls, params, state, S, nthreads=nthreads)
+            rec["cpu_baseline"]["other_leg"] = oracle_leg
+        except Exception as e:                      # the torch-CPU leg must never fail the bench
+            rec["cpu_baseline"] = dict(oracle_leg, note=f"torch-CPU leg failed: {e}")
+    return rec
+
+
+def train_roofline(torch, N, model, layers, B, S):
+    """roofline of the training step's dominant kernel, timed live with HIP events on the launch stream through the C ABI's
+    single-kernel entry (the kernel + the 7 us reduction of its weight-gradient partials): the fused backward of a block's second
+    convolution -- BatchNorm-backward apply on load, weight gradient, masked data gradient (18 of the ~150 launches of a step, ~26 % of
+    its time; its sibling for a block's first convolution takes as long).  Algorithmic bytes: dy, conv_out and x read once, dx
+    written once (4 * 64 B per pixel)."""
+    L = N.lib()
+    xw = torch.relu(torch.randn((B, S, S, 16), device="cuda"))
+    gw = torch.randn((B, S, S, 16), device="cuda") * 0.1
+    cw = torch.randn((B, S, S, 16), device="cuda")
+    coef = torch.cat([torch.ones(16), torch.full((16,), 0.1), torch.full((16,), 0.01)]).cuda()
+    wk = torch.randn((3, 3, 16, 16), device="cuda") * 0.1
+    dxw = torch.empty_like(xw)
+    dw = torch.empty(2304, device="cuda")
+    scr = torch.empty(int(L.bf_debug_bwd3x3_h3_scratch_floats(B, S, S)), device="cuda")
+    calls = [0]
+
+    def wg():
+        N.check(L.bf_debug_bwd3x3_h3(N.ptr(xw), N.ptr(gw), N.ptr(cw), N.ptr(coef), N.ptr(wk), N.ptr(dxw), None, None, N.ptr(dw),
+                                     None, N.ptr(scr), B, S, S, N.EPI_MASK, calls[0] & 1, 1 if calls[0] == 0 else 0,
+                                     N.stream_ptr(xw)), None, "bwd3x3_h3")
+        calls[0] += 1
+    for _ in range(3):
+        wg()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    nl = 20
+    e0.record()
+    for _ in range(nl):
+        wg()
+    e1.record()
+    torch.cuda.synchronize()
+    launch_us = e0.elapsed_time(e1) * 1e3 / nl
+    wbytes = B * S * S * 16 * 4 * 4
+    gbs = wbytes / launch_us / 1e3
+    return {"bound": "hbm", "kernel": "bwd3x3_h3_kernel<true, 8> (+ reduce_partials_kernel)", "achieved": gbs, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "traffic": pmc_traffic(layers, B, S, True, "bwd3x3_h3_kernel<true, 8>"), "algorithmic_bytes_per_launch": wbytes,
+            "launch_us": launch_us, "launches_of_this_kernel_per_step": layers}
+
+
+def train_dp_record(args, torch, bf, O, rank, local_rank, world, dist, steps=10, warmup=3):
+    """N > 1 in the default mode: the data-parallel training step of configs[3] over this run's process group, once with
+    torch.distributed's all-reduce and once with the C ABI's own (bf_allreduce_grads on the communicator's stream), replicas that
+    START different checked identical afterwards, and what the exchange costs.  Every rank calls this."""
+    rec = {"world_size_seen": int(dist.get_world_size()), "backend": dist.get_backend()}
+    rehearse = os.environ.get("BF_BENCH_REHEARSE") == "1"
+    for key, native in (("torch_all_reduce", False), ("native_collective", True)):
+        if native and rehearse:
+            if rank == 0:
+                rec[key] = {"note": "rehearsal (ranks share a GPU over gloo): RCCL cannot form a communicator with duplicate devices, skipped"}
+            continue
+        ok, r, err = True, None, ""
+        try:
+            r = train_run(args, torch, bf, O, rank, local_rank, world, dist, steps, warmup, cpu=False, exchange=not native, parity=False,
+                          roofline=False, native_collective=native, check_replicas=True)
+        except Exception as e:                      # (NativeCommunicator raises on ALL ranks together, see train_loop.py)
+            ok, err = False, str(e)[:200]
+        if not all_agree(torch, dist, ok):
+            if rank == 0:
+                rec[key] = {"note": f"failed on a rank: {err}"}
+            continue
+        if rank == 0:
+            keep = ("value", "unit", "steps", "warmup", "ms_per_step", "last_total_loss", "replicas_max_abs_param_diff", "replicas_identical",
+                    "block_kernels", "gradient_exchange", "rehearsal")
+            rec[key] = {k: r[k] for k in keep if k in r}
+            rec[key]["config"] = r["config"]
+    return rec if rank == 0 else None
 
 
 def self_launch(n):
@@ -888,6 +1077,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # a >= 2 s loop of the same step behind the timed region: the package sits at its power cap, so the steady-state rate is a few
+    # percent below what a 0.1-0.5 s window shows (profiles/r03_power_probe.txt); every rank runs it, rank 0 reports its own
+    sustained = None
+    if not args.no_sub_records:
+        n_sus = max(int(2.2 / max(elapsed / args.steps, 1e-4)), args.steps)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_sus):
+            out = module(noisy)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        sustained = {"value": B * world * n_sus / dt, "unit": "images/s", "steps": n_sus, "seconds": dt, "ms_per_step": dt / n_sus * 1e3,
+                     "note": "same step, same inputs, run back to back behind the timed region (rank 0's clock, no barrier inside)"}
+    # N > 1: the ONE collective of the path -- the data-parallel training step of configs[3] over this run's process group
+    train_dp = None
+    if world > 1 and not args.no_sub_records:
+        train_dp = train_dp_record(args, torch, bf, O, rank, local_rank, world, dist)
+
     if rank == 0:
         # parity of the timed configuration: four images spread over the batch against the fp64 oracle (+-1 LSB bar)
         idx = parity_sample(B)
@@ -920,6 +1127,10 @@ def main():
         if dist is not None:
             result["world_size_seen"] = int(dist.get_world_size())
         result["visible_gpus"] = int(torch.cuda.device_count())
+        if sustained is not None:
+            result["sustained"] = sustained
+        if train_dp is not None:
+            result["train_dp"] = train_dp
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(spec, params, state, noisy_host)
         if world == 1 and not args.no_sub_records and h3 and args.h3_variant is None:
@@ -947,10 +1158,25 @@ def main():
                 result["wide_512"]["workload"] = f"resnet_color_1x{spec.no_layers}_bn_16x3x3 inference, batch={B // 4} 512x512x3 uint8"
             model.set_option("arith", 1)
             model.set_option("h3_compact", 0)
+        if world == 1 and not args.no_sub_records:
+            # BASELINE configs[3] and configs[4] in the driver-run line: short runs of `--mode train` / `--mode unet` (their own
+            # roofline, parity against the oracle on a crop, the kernels the library says it launched; CPU legs only in their modes)
+            try:
+                result["train"] = train_run(args, torch, bf, O, rank, local_rank, world, None, steps=max(args.steps // 5, 10),
+                                            warmup=max(args.warmup // 4, 3), cpu=False, exchange=False, B=32, S=256)
+            except Exception as e:
+                result["train"] = {"note": f"failed: {str(e)[:300]}"}
+            try:
+                result["unet"] = unet_run(args, torch, bf, O, rank, local_rank, world, None, steps=max(args.steps // 10, 10),
+                                          warmup=max(args.warmup // 4, 3), cpu=False, B=32, S=512)
+            except Exception as e:
+                result["unet"] = {"note": f"failed: {str(e)[:300]}"}
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if train_dp is not None and any(isinstance(v, dict) and v.get("replicas_identical") is False for v in train_dp.values()):
+        raise SystemExit("train_dp: data-parallel replicas differ after the all-reduced steps")
 
 
 if __name__ == "__main__":

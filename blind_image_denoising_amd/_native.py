@@ -164,6 +164,7 @@ SIGNATURES = {
     "bf_set_option": (_I, [_P, C.c_char_p, _I]),
     "bf_get_timing": (_I, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "bf_get_block_kernel": (C.c_char_p, [_P, C.POINTER(C.c_int)]),
+    "bf_get_train_kernels": (C.c_char_p, [_P]),
     "bf_debug_conv3x3": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "bf_debug_conv3x3_grid": (_I, [_I, _I, _I]),
     "bf_debug_fused_block": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -167,12 +167,16 @@ hipError_t bf_launch_base_conv_rows(const BaseConvArgs& a, hipStream_t s)
     // rows per band: enough workgroups to fill the chip a few times, bands tall enough to amortise the three prologue rows
     // (128 x 256 x 256: 32 rows = 1 024 workgroups 117 us, 16 rows 128 us, 8 rows 134 us, 64 rows 158 us)
     int rows = 32;
-    if (const char* e = getenv("BF_BASE_ROWS_BAND")) rows = atoi(e) > 0 ? atoi(e) : rows;      // A/B only
-    else while (rows > 8 && (int64_t)a.B * nchunks * ((a.H + rows - 1) / rows) < 1024) rows /= 2;
+    int ablate = 0;
+#ifdef BF_ABLATE            // timing builds only (tools/exp/base_rows_abl.sh builds with -DBF_ABLATE): the shipped library ignores the environment
+    if (const char* e = getenv("BF_BASE_ROWS_ABL")) ablate = atoi(e);                          // 1 = no stores, 2 = no loads
+    if (const char* e = getenv("BF_BASE_ROWS_BAND")) rows = atoi(e) > 0 ? atoi(e) : rows;
+    else
+#endif
+    while (rows > 8 && (int64_t)a.B * nchunks * ((a.H + rows - 1) / rows) < 1024) rows /= 2;
     const int nbands = (a.H + rows - 1) / rows;
     const int64_t grid = (int64_t)a.B * nchunks * nbands;
     if (grid > 0x7fffffff) return hipErrorInvalidValue;
-    const char* ea = getenv("BF_BASE_ROWS_ABL");      // timing only (1 = no stores, 2 = no loads)
-    hipLaunchKernelGGL(base_conv_rows_kernel, dim3((unsigned)grid), dim3(BR_NT), 0, s, a, nchunks, rows, nbands, ea ? atoi(ea) : 0);
+    hipLaunchKernelGGL(base_conv_rows_kernel, dim3((unsigned)grid), dim3(BR_NT), 0, s, a, nchunks, rows, nbands, ablate);
     return hipGetLastError();
 }

@@ -35,6 +35,7 @@ struct bf_engine {
                                     // vector instructions per 64 pixels cost the issue-bound launch what the head kernel's pass costs
     int block_launches = 0;         // launches of the last forward's residual blocks (bf_get_timing)
     const char* block_kernel = "";  // name of the kernel that ran most of them
+    std::string train_kernels;      // the block kernels of the last bf_train_step (bf_get_train_kernels)
                                     // (fp8 lo planes, 48 B per pixel; bf_common.h): +5 % images/s for 6e-6 instead of 2e-7 normalised MAE
     // arithmetic of the fused inference blocks: 1 = split-f16 on the f16 matrix cores (fused_h3.hip, needs
     // |activation| < 65504), 0 = exact fp32 on the f32 matrix cores (conv3x3_c16.hip)
@@ -258,6 +259,9 @@ extern "C" const char* bf_get_block_kernel(bf_handle h, int* launches_per_forwar
     if (launches_per_forward) *launches_per_forward = h->block_launches;
     return h->block_kernel;
 }
+
+// the kernels that ran the residual blocks of the handle's LAST bf_train_step: "fwd: <kernels>; bwd: <kernels>" ("" before the first)
+extern "C" const char* bf_get_train_kernels(bf_handle h) { return h ? h->train_kernels.c_str() : ""; }
 
 extern "C" int64_t bf_packed_bytes(bf_handle h) { return h ? h->k_total * 4 : -1; }
 
@@ -488,7 +492,16 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
         probe.B = B; probe.H = H; probe.W = W; probe.variant = h->h3_variant;
         pair_ok = (h->h3_pair == 2 || bf_fused_block_h3_use_pairs(probe)) && bf_fused_block2_h3w_supports(H, W);   // 2: A/B only
     }
-    int launches = 0, pair_launches = 0;
+    int launches = 0;
+    // which kernel ran how many of the blocks: noted AT each launch site (bf_get_block_kernel reports the one that ran the most)
+    const char* ran_name[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int ran_count[6] = {0, 0, 0, 0, 0, 0};
+    auto ran = [&](const char* name, int n) {
+        for (int k = 0; k < 6; ++k) {
+            if (ran_name[k] == nullptr) ran_name[k] = name;
+            if (!strcmp(ran_name[k], name)) { ran_count[k] += n; return; }
+        }
+    };
     // an odd block count runs its single block FIRST, so that the last launch is a pair and can carry the head
     const bool head_in_pair = pair_ok && !head_in_block && h->h3_pair_head && d.no_layers >= 2 &&
                               d.head_activation == BF_ACT_LINEAR && d.out_channels == 3;
@@ -512,7 +525,8 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
             BF_HIP(bf_launch_fused_block2_h3w(fa, s), "fused_block2_h3w");
             cur ^= 1;
             ++i;
-            ++launches; ++pair_launches;
+            ++launches;
+            ran("fused_block2_h3w_kernel", 2);                 // (weighted by the blocks a launch runs)
             continue;
         }
         launches += d.block_convs != 2 ? d.block_convs : ((h3 || h->fused_blocks) ? 1 : 2);
@@ -533,6 +547,7 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
                 const bool relu = !last && d.activation == BF_ACT_RELU;
                 int epi = (j >= 1 ? EPI_AFFINE : 0) | (relu ? EPI_RELU : 0) | (last ? EPI_RES : 0);
                 BF_HIP(bf_launch_conv3x3_c16(ca, epi, s), "block conv");
+                ran("conv3x3_c16_kernel", 1);
                 src = dst;
             }
             cur = src;
@@ -555,6 +570,7 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
                 fa.denormalize = d.denormalize; fa.v_min = d.v_min; fa.v_max = d.v_max; fa.status = status;
             }
             BF_HIP(bf_launch_fused_block_h3(fa, s), "fused_block_h3");
+            ran(bf_fused_block_h3_kernel_name(fa), 1);
             cur ^= 1;
         } else if (h->fused_blocks) {
             FusedBlockArgs fa;
@@ -564,6 +580,7 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
             fa.B = B; fa.H = H; fa.W = W; fa.tiles_x = fa.tiles_y = fa.ntiles = 0;
             fa.act1_relu = d.activation == BF_ACT_RELU; fa.dbg = nullptr; fa.zeros = pk + h->k_zero;
             BF_HIP(bf_launch_fused_block(fa, s), "fused_block");
+            ran(bf_fused_block_kernel_name(), 1);
             cur ^= 1;
         } else {
             // unfused: T = act(conv1 x) ; y = x + scale*conv2(T) + shift
@@ -575,6 +592,7 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
             ca.in = buf[t]; ca.out = buf[y]; ca.wpack = blk + BF_WPACK_FLOATS;
             ca.scale = blk + 2 * BF_WPACK_FLOATS; ca.shift = ca.scale + 16; ca.res = buf[cur];
             BF_HIP(bf_launch_conv3x3_c16(ca, EPI_AFFINE | EPI_RES, s), "conv2");
+            ran("conv3x3_c16_kernel", 2);
             cur = y;
         }
     }
@@ -584,14 +602,9 @@ static int forward_common(bf_handle h, const float* pk, const void* in, int in_i
         ++h->n_timed;
     }
     h->block_launches = launches;
-    if (2 * pair_launches >= launches && pair_launches) h->block_kernel = "fused_block2_h3w_kernel";
-    else if (d.block_convs != 2 || !(h3 || h->fused_blocks)) h->block_kernel = "conv3x3_c16_kernel";
-    else if (h3) {
-        FusedH3Args probe;
-        memset(&probe, 0, sizeof(probe));
-        probe.B = B; probe.H = H; probe.W = W; probe.variant = h->h3_variant;
-        h->block_kernel = bf_fused_block_h3_kernel_name(probe);
-    } else h->block_kernel = bf_fused_block_kernel_name();
+    h->block_kernel = "";
+    for (int k = 0, best = 0; k < 6 && ran_name[k]; ++k)
+        if (ran_count[k] > best) { best = ran_count[k]; h->block_kernel = ran_name[k]; }
     if (head_in_block || head_in_pair) return BF_OK;
     HeadArgs ha;
     ha.feat = buf[cur];
@@ -977,6 +990,10 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     float* const gbuf[3] = {dA, ACT(N + 2 + 2 * (int64_t)N * (nb - 1)), ACT(N + 3 + 2 * (int64_t)N * (nb - 1))};
     // both convolutions of a block in one launch: [3,3] blocks, BatchNorm on the second convolution, ReLU between them
     const bool fused_bwd2 = fused_bwd && h->train_fused_bwd2 && nb == 2 && d.use_bn && relu;
+    h->train_kernels = std::string("fwd: ") + (h3t ? (h->train_fused_fwd && nb >= 2 && d.use_bn ? "conv3x3_h3_kernel<.., PRE> + conv3x3_h3_kernel" : "conv3x3_h3_kernel")
+                                                   : "conv3x3_c16_kernel")
+                       + "; bwd: " + (fused_bwd2 ? "bwd2_h3_kernel" : fused_bwd ? "bwd3x3_h3_kernel<true, 8> + bwd3x3_h3_kernel<false, 36>"
+                                                 : h3t ? "wgrad3x3_h3_kernel + conv3x3_h3_kernel" : "wgrad3x3_c16_kernel + conv3x3_c16_kernel");
     const int bwd_grid = fused_bwd2 ? bf_bwd2_h3_grid(B, H, W) : bf_bwd3x3_h3_grid_ex(B, H, W, h->train_bwd_dbuf);
     float* bwd_stats = partial + (int64_t)bwd_grid * 2304;
     for (int i = N - 1; i >= 0; --i) {

@@ -208,6 +208,7 @@ class HydraModel:
         self.state = torch.from_numpy(state).to(self.device)
         self._packed = None
         self._packed_dirty = True
+        self.version = 0                 # bumped whenever weights, state or an option change (GraphedDenoiserModule keys on it)
         self._workspace = None
         self.outputs = [None]            # single-output hydra (len(model.outputs) == 1)
         self.inputs = [None]
@@ -272,6 +273,7 @@ class HydraModel:
     def mark_dirty(self):
         """call after params / state changed: inference re-packs the weights on next use."""
         self._packed_dirty = True
+        self.version = getattr(self, "version", 0) + 1
 
     # ---- buffers -------------------------------------------------------------------------
     def _require_gpu(self):
@@ -298,6 +300,7 @@ class HydraModel:
         return self._packed
 
     def set_option(self, key: str, value: int):
+        self.version = getattr(self, "version", 0) + 1
         if self.device.type == "cuda":
             with torch.cuda.device(self.device):       # ("timing" creates its events: on THIS model's device)
                 N.check(self._lib.bf_set_option(self._h, key.encode(), int(value)), self._h)

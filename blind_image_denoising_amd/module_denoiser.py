@@ -144,8 +144,10 @@ class GraphedDenoiserModule:
     used goes first).  The result is a fresh tensor unless `copy_output=False` (then it is the graph's own output buffer, valid until
     the next call with that shape).  Same argument checks, return types and f16-range status handling as DenoiserModule
     (module_denoiser.py:43-75 is what both compute).  A graph holds the kernels, options and buffer addresses of the moment it was
-    captured: a graph whose model workspace has since been re-allocated (a larger shape came by) is re-captured by itself; after
-    `set_option` call `invalidate()` (new weights through `set_weights` are picked up: they live in the same buffers)."""
+    captured, and the captured kernels read the PACKED weights, which only a direct call refreshes: every graph therefore remembers
+    the model's `version` (bumped by `set_weights`, `mark_dirty` -- a training or optimizer step -- and `set_option`, the automatic
+    switch to the exact-fp32 kernels included) and the address of its workspace, and a graph whose model has moved on since is
+    re-captured by itself on its next use (two direct calls + one capture); `invalidate()` drops all of them by hand."""
 
     def __init__(self, module: DenoiserModule, max_shapes: int = 8, copy_output: bool = True):
         if not isinstance(module, DenoiserModule):
@@ -174,6 +176,10 @@ class GraphedDenoiserModule:
         ws = getattr(self._module.model_hydra, "_workspace", None)
         return ws.data_ptr() if isinstance(ws, torch.Tensor) else 0
 
+    def _stamp(self):
+        """what a captured graph depends on besides the input shape: the model's weights / options and its workspace"""
+        return (getattr(self._module.model_hydra, "version", 0), self._workspace_ptr())
+
     def _capture(self, image: torch.Tensor):
         static_in = image.clone()
         side = torch.cuda.Stream(device=image.device)
@@ -187,7 +193,7 @@ class GraphedDenoiserModule:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             static_out = self._module(static_in)
-        return graph, static_in, static_out, self._workspace_ptr()
+        return graph, static_in, static_out, self._stamp()
 
     def __call__(self, image):
         was_numpy = isinstance(image, np.ndarray)
@@ -204,12 +210,12 @@ class GraphedDenoiserModule:
         if image.shape[0] == 0:
             return self._module(image.numpy() if was_numpy else image)
         hydra._require_gpu()
-        self._module.check_status(wait=False)
+        self._module.check_status(wait=False)  # (may switch the model to the exact-fp32 kernels: that bumps its version)
         image = image.to(hydra.device).contiguous()
         key = tuple(image.shape)
         entry = self._graphs.pop(key, None)
-        if entry is not None and entry[3] != self._workspace_ptr():
-            entry = None                       # the engine's workspace moved since this graph was captured
+        if entry is not None and entry[3] != self._stamp():
+            entry = None                       # weights, options or the engine's workspace changed since this graph was captured
         if entry is None:
             if len(self._graphs) >= self._max:
                 self._graphs.pop(next(iter(self._graphs)))

@@ -346,11 +346,12 @@ class GenericResnetHydra:
             if state.size != self.n_state:
                 raise ValueError(f"expected {self.n_state} state values, got {state.size}")
             self.state.copy_(torch.from_numpy(state))
-        self._packed = None
+        self.mark_dirty()
 
     def mark_dirty(self):
         """parameters or moving statistics changed in place (optimizer / training step): drop the folded operands"""
         self._packed = None
+        self.version = getattr(self, "version", 0) + 1
 
     def set_option(self, key: str, value: int):
         raise ValueError(f"unknown option {key}={value}")

@@ -225,11 +225,18 @@ class NativeCommunicator:
         import torch.distributed as dist
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         lib = N.lib()
-        box = [None]
-        if self.rank == 0:
-            buf = C.create_string_buffer(128)
-            N.check(lib.bf_comm_unique_id(buf), None, "bf_comm_unique_id")
-            box[0] = buf.raw
+        # Every rank first proves that it CAN talk to RCCL (bf_comm_unique_id binds librccl at run time), and the ranks agree on it
+        # before anything blocks: bf_comm_init_rank is itself a collective, so one rank failing alone would leave its peers waiting
+        # inside it.  After this point all ranks raise together or none does.
+        buf = C.create_string_buffer(128)
+        rc = lib.bf_comm_unique_id(buf)
+        note = "" if rc == N.BF_OK else lib.bf_comm_last_error().decode()
+        flag = torch.tensor([1 if rc == N.BF_OK else 0], dtype=torch.int32,
+                            device="cpu" if dist.get_backend(group) == "gloo" else device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) != 1:
+            raise RuntimeError("bf_comm_unique_id failed on " + ("this rank: " + note if note else "another rank"))
+        box = [buf.raw if self.rank == 0 else None]
         # `src` of a torch broadcast is a GLOBAL rank: the group's rank 0 is not global rank 0 in a sub-group
         src = dist.get_global_rank(group, 0) if group is not None else 0
         dist.broadcast_object_list(box, src=src, group=group)

@@ -344,6 +344,7 @@ class UnetLaplacianHydra:
         if key != "arith" or int(value) not in (0, 1):
             raise ValueError(f"unknown option {key}={value}")
         self.arith = int(value)
+        self.version = getattr(self, "version", 0) + 1
 
     def __init__(self, config: Dict, device=None, seed: Optional[int] = None):
         bb, dn = config["backbone"], config["denoiser"]
@@ -562,6 +563,7 @@ class UnetLaplacianHydra:
     def mark_dirty(self):
         """the flat parameter vector changed in place (optimizer step): drop the packed operands"""
         self._packed = None
+        self.version = getattr(self, "version", 0) + 1
 
     def get_weights(self) -> np.ndarray:
         return self.params.detach().cpu().numpy()
@@ -571,7 +573,7 @@ class UnetLaplacianHydra:
         if params.size != self.n_params:
             raise ValueError(f"expected {self.n_params} parameters, got {params.size}")
         self.params.copy_(torch.from_numpy(params))
-        self._packed = None
+        self.mark_dirty()
 
     # -- packing -----------------------------------------------------------------------------
     def _pack(self) -> Dict[str, torch.Tensor]:

@@ -547,6 +547,9 @@ int bf_get_timing(bf_handle h, float* ms, int* launches);
  * the number of block launches that forward made: what a profile of the run must show, and the key bench.py looks counter
  * traffic up by.  The string is static storage. */
 const char* bf_get_block_kernel(bf_handle h, int* launches_per_forward);
+/* the kernels that ran the residual blocks of the handle's LAST bf_train_step, as "fwd: <kernels>; bwd: <kernels>" ("" before the
+ * first step): what a profile of a training run must show (bench.py's train records carry it).  Valid until the next step. */
+const char* bf_get_train_kernels(bf_handle h);
 
 /* The single-kernel diagnostic entries (bf_debug_*: one kernel at a time on fp32 NHWC tensors, used by the parity tests, the
  * profiling tools and bench.py's live roofline of the training kernel) are declared in bfcnn_hip_debug.h; they are exported by

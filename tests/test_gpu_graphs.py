@@ -115,3 +115,45 @@ def test_graphed_denoiser_module_replays_per_shape(family):
     with pytest.raises(ValueError):
         graphed(np.zeros((1, 8, 8, 3), np.float32))
     assert graphed(np.zeros((0, 8, 8, 3), np.uint8)).shape == (0, 8, 8, 3)
+
+
+@pytest.mark.parametrize("family", ["resnet", "unet_laplacian"])
+def test_graphed_denoiser_module_follows_new_weights_and_options(family):
+    """A captured graph replays kernels that read the PACKED weights of the moment of capture: after set_weights / mark_dirty (a
+    training or optimizer step) / set_option the graphed module must return what the direct module returns (the graph is keyed on
+    the model's version and re-captured), never the old weights' output and never freed operands (round-3 advisor finding)."""
+    if family == "resnet":
+        cfg = O.canonical_config(no_layers=4)
+        spec = O.ResnetSpec.from_config(cfg["model"])
+        m = bf.model_builder(cfg["model"], device="cuda").hydra
+        weights = [O.init_params(spec, seed=s) for s in (3, 11)]
+        set_w = lambda k: m.set_weights(*weights[k])
+    else:
+        cfg = U.canonical_config(depth=3, width=1)
+        spec = U.UnetLaplacianSpec.from_config(cfg["model"])
+        m = bf.model_builder(cfg["model"], device="cuda").hydra
+        weights = [U.init_params(spec, seed=s) for s in (4, 12)]
+        set_w = lambda k: m.set_weights(weights[k])
+    set_w(0)
+    direct = bf.DenoiserModule(m)
+    graphed = bf.GraphedDenoiserModule(bf.DenoiserModule(m))
+    _, img = O.synthetic_batch(2, 64, 48, seed=5)
+    dev = torch.from_numpy(img).cuda()
+    first = graphed(dev).cpu().numpy()
+    assert np.array_equal(first, direct(img))
+    set_w(1)                                                             # new weights after the capture
+    ref = direct(img)
+    assert not np.array_equal(ref, first)
+    assert np.array_equal(graphed(dev).cpu().numpy(), ref)
+    assert np.array_equal(graphed(img), ref)
+    with torch.no_grad():                                                # in-place change + mark_dirty, as an optimizer step does
+        m.params.mul_(0.5)
+    m.mark_dirty()
+    ref2 = direct(img)
+    assert not np.array_equal(ref2, ref)
+    assert np.array_equal(graphed(dev).cpu().numpy(), ref2)
+    m.set_option("arith", 0)                                             # another arithmetic: the old graph holds the other kernels
+    v = m.version
+    assert np.array_equal(graphed(dev).cpu().numpy(), direct(img))
+    assert graphed._graphs[tuple(dev.shape)][3][0] == v
+    assert len(graphed.captured_shapes()) == 1
