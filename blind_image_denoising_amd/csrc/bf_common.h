@@ -251,6 +251,25 @@ struct Bwd2H3Args {
     int* grid_out;         // if not NULL: number of partial rows (workgroups) the launch wrote
     int tiles_x, tiles_y, ntiles;               // filled in by the launcher
 };
+// training-mode forward of one [3,3] block in one kernel (train_fwd_h3t.hip): A_i = x + pre_scale * pre_c + pre_shift formed on
+// load (pre_c != NULL; written to a_out), T_i = act(conv_0 A_i) kept in LDS (written to t_out when not NULL), C_i = conv_1 T_i
+// written to c_out, per-channel sum / sum of squares of C_i to stats[grid][32] (the format of EPI_STATS)
+struct FwdBlockH3Args {
+    const float* x;        // [B,H,W,16] A_{i-1} (pre_c != NULL) or the block input A_i itself
+    const float* pre_c;    // raw output of the previous block's last convolution, or NULL
+    const float* pre_scale; const float* pre_shift;     // [16] each: that block's BatchNorm as scale / shift
+    float* a_out;          // A_i (pre_c != NULL)
+    float* t_out;          // T_i or NULL
+    float* c_out;          // C_i
+    const float* wpack0;   // forward packs (pack_h3_train) of conv_0 / conv_1
+    const float* wpack1;
+    float* stats;          // [bf_fwd_block_h3t_grid][32]
+    int B, H, W, reverse, act_relu;
+    int tiles_y, ntiles, rows_per_tile;         // filled in by the launcher
+};
+bool       bf_fwd_block_h3t_supports(int H, int W);
+int        bf_fwd_block_h3t_grid(int B, int H, int W);
+hipError_t bf_launch_fwd_block_h3t(const FwdBlockH3Args& a, hipStream_t s);
 int        bf_bwd2_h3_grid(int B, int H, int W);
 hipError_t bf_launch_bwd2_h3(const Bwd2H3Args& a, hipStream_t s);
 int        bf_bwd3x3_h3_grid(int B, int H, int W);                 // partial rows of the 256-thread kernel (the larger count: sizing)

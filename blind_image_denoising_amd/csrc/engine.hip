@@ -46,6 +46,9 @@ struct bf_engine {
     int train_zigzag = 1;           // split-f16 training: consecutive kernels walk their tiles in opposite directions
     int train_fused_fwd = 1;        // split-f16 training: BatchNorm apply + skip Add of block i formed while block i+1's first convolution stages its tile
     int train_bwd_dbuf = 0;         // fused backward kernel: 512-thread form with double-buffered LDS images (A/B: 10 % slower)
+    int train_fwd_block = 1;        // [3,3] blocks with BatchNorm + ReLU, W <= 256: the whole training forward of a block in ONE row-streaming
+                                    // kernel (train_fwd_h3t.hip; T kept in LDS unless the backward pass reads it).  1 = where a forward holds
+                                    // enough rows (bf_train_step), 2 = wherever it can run (tests), 0 = the two convolution kernels
     int train_fused_bwd = 1;        // split-f16 training: weight + data gradient (+ BatchNorm backward) of a convolution in one kernel
     int train_fused_bwd2 = 0;       // [3,3] blocks with BatchNorm and ReLU: BOTH convolutions' backward in one kernel (bwd2_h3_kernel: 6 tensor
                                     // passes for 9, but 348 us against 131 + 110: one workgroup per CU and a recomputed halo -- DESIGN 4.3)
@@ -216,6 +219,7 @@ extern "C" int bf_set_option(bf_handle h, const char* key, int value)
     if (!strcmp(key, "train_fused_fwd")) { h->train_fused_fwd = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_bwd_dbuf")) { h->train_bwd_dbuf = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_fused_bwd")) { h->train_fused_bwd = value ? 1 : 0; return BF_OK; }
+    if (!strcmp(key, "train_fwd_block")) { h->train_fwd_block = value < 0 ? 1 : (value > 2 ? 2 : value); return BF_OK; }
     if (!strcmp(key, "train_fused_bwd2")) { h->train_fused_bwd2 = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_arith")) { h->train_arith = value < 0 ? 1 : (value ? 1 : 0); return BF_OK; }
     if (!strcmp(key, "arith")) { h->arith = value < 0 ? 1 : (value ? 1 : 0); return BF_OK; }
@@ -416,6 +420,7 @@ static TrainLayout train_layout(bf_handle h, int B, int H, int W)
     pf = max64(pf, 4096 * 32);
     pf = max64(pf, (int64_t)bf_wgrad_grid(B, H, W) * 2304);
     pf = max64(pf, (int64_t)bf_bwd3x3_h3_grid(B, H, W) * (2304 + 32));
+    pf = max64(pf, (int64_t)bf_fwd_block_h3t_grid(B, H, W) * 32);
     pf = max64(pf, (int64_t)bf_base_wgrad_grid(B, H, W) * h->n_base);
     pf = max64(pf, (int64_t)bf_head_train_grid(B, H, W) * 80);
     L.partial_floats = align_up(pf, 64);
@@ -887,8 +892,35 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     const int conv_grid = bf_conv3x3_c16_grid(B, H, W);
     const bool relu = d.activation == BF_ACT_RELU;
     bool pending_affine = false;
+    // whole blocks in one kernel (train_fwd_h3t.hip): [3,3] blocks, BatchNorm on the second convolution, the split-f16 arithmetic,
+    // images up to 256 columns, and a forward of enough rows that its bands (rows + 6 steps each) keep 256 workgroups busy
+    const bool fwd_block = h3t && h->train_fwd_block && h->train_fused_fwd && nb == 2 && d.use_bn && bf_fwd_block_h3t_supports(H, W) &&
+                           (h->train_fwd_block == 2 || (int64_t)B * H >= 4096);
+    const bool need_t = true;                               // the backward kernels below read T_i
     for (int i = 0; i < N; ++i) {
         const float* wp = w + L.wpack + (int64_t)i * 2 * nb * BF_TRAIN_PACK_STRIDE;        // forward packs 0..nb-1, then data-gradient packs
+        if (fwd_block) {
+            // A_i = A_{i-1} + bn(C_{i-1}) on load ; T_i = act(conv_0 A_i) ; C_i = conv_1 T_i + its batch statistics
+            FwdBlockH3Args fa;
+            memset(&fa, 0, sizeof(fa));
+            fa.B = B; fa.H = H; fa.W = W; fa.reverse = next_reverse(); fa.act_relu = relu;
+            fa.x = A(i);
+            if (pending_affine) {
+                fa.x = A(i - 1); fa.pre_c = C(i - 1, 1); fa.a_out = A(i);
+                fa.pre_scale = w + L.bn_scale + bn_idx(i - 1, 1) * 32; fa.pre_shift = fa.pre_scale + 16;
+                pending_affine = false;
+            }
+            fa.t_out = need_t ? T(i, 1) : nullptr; fa.c_out = C(i, 1);
+            fa.wpack0 = wp; fa.wpack1 = wp + BF_TRAIN_PACK_STRIDE; fa.stats = partial;
+            BF_HIP(bf_launch_fwd_block_h3t(fa, s), "fwd_block_h3t");
+            float* scale = w + L.bn_scale + bn_idx(i, 1) * 32;
+            BF_HIP(bf_launch_bn_finalize(partial, bf_fwd_block_h3t_grid(B, H, W), count, params + h->p_blocks + i * h->p_block_stride + conv_off(1) + 2304,
+                                         state + bn_idx(i, 1) * 32, state + bn_idx(i, 1) * 32 + 16, d.bn_eps, d.bn_momentum, scale,
+                                         scale + 16, w + L.bn_meaninv + bn_idx(i, 1) * 32, stage1, s), "bn_finalize");
+            if (i + 1 < N) pending_affine = true;
+            else BF_HIP(bf_launch_affine_add(A(i), C(i, 1), scale, scale + 16, A(i + 1), npix, s), "affine_add");
+            continue;
+        }
         for (int j = 0; j < nb; ++j) {
             const bool last = j == nb - 1, bn = j >= 1 && d.use_bn;
             ConvArgs ca;
@@ -990,7 +1022,7 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     float* const gbuf[3] = {dA, ACT(N + 2 + 2 * (int64_t)N * (nb - 1)), ACT(N + 3 + 2 * (int64_t)N * (nb - 1))};
     // both convolutions of a block in one launch: [3,3] blocks, BatchNorm on the second convolution, ReLU between them
     const bool fused_bwd2 = fused_bwd && h->train_fused_bwd2 && nb == 2 && d.use_bn && relu;
-    h->train_kernels = std::string("fwd: ") + (h3t ? (h->train_fused_fwd && nb >= 2 && d.use_bn ? "conv3x3_h3_kernel<.., PRE> + conv3x3_h3_kernel" : "conv3x3_h3_kernel")
+    h->train_kernels = std::string("fwd: ") + (fwd_block ? "fwd_block_h3t_kernel" : h3t ? (h->train_fused_fwd && nb >= 2 && d.use_bn ? "conv3x3_h3_kernel<.., PRE> + conv3x3_h3_kernel" : "conv3x3_h3_kernel")
                                                    : "conv3x3_c16_kernel")
                        + "; bwd: " + (fused_bwd2 ? "bwd2_h3_kernel" : fused_bwd ? "bwd3x3_h3_kernel<true, 8> + bwd3x3_h3_kernel<false, 36>"
                                                  : h3t ? "wgrad3x3_h3_kernel + conv3x3_h3_kernel" : "wgrad3x3_c16_kernel + conv3x3_c16_kernel");
@@ -1424,6 +1456,33 @@ extern "C" int bf_debug_conv3x3_h3_pre(const float* in, const float* pre_c, cons
     ca.in = in; ca.out = out; ca.wpack = scratch; ca.B = B; ca.H = H; ca.W = W; ca.reverse = reverse;
     ca.pre_c = pre_c; ca.pre_scale = pre_scale; ca.pre_shift = pre_shift; ca.pre_out = pre_out;
     return bf_launch_conv3x3_h3(ca, relu ? EPI_RELU : 0, s) == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// the training-mode forward of one [3,3] block in one kernel (train_fwd_h3t.hip): a_out = x + pre_scale * pre_c + pre_shift (pre_c
+// given), t_out = [relu] conv_0(a) (t_out given), c_out = conv_1(t), stats[32] = per-channel sum | sum of squares of c_out.
+// scratch: bf_debug_fwd_block_h3t_scratch_floats(B, H, W) floats
+extern "C" int64_t bf_debug_fwd_block_h3t_scratch_floats(int B, int H, int W)
+{
+    return 4 * (int64_t)BF_H3_TRAIN_PACK_FLOATS + 2 * 2304 + 16 + (int64_t)bf_fwd_block_h3t_grid(B, H, W) * 32;
+}
+extern "C" int bf_debug_fwd_block_h3t(const float* x, const float* pre_c, const float* pre_scale, const float* pre_shift,
+                                      const float* w0_hwio, const float* w1_hwio, float* a_out, float* t_out, float* c_out, float* stats,
+                                      float* scratch, int B, int H, int W, int relu, int reverse, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (!bf_fwd_block_h3t_supports(H, W)) return BF_EUNSUPPORTED;
+    float* params = scratch + 4 * BF_H3_TRAIN_PACK_FLOATS;
+    if (hipMemcpyAsync(params, w0_hwio, 2304 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;
+    if (hipMemcpyAsync(params + 2304, w1_hwio, 2304 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;
+    if (bf_launch_pack_h3_train(params, 0, 4608 + 16, scratch, 1, 2, 2320, s) != hipSuccess) return BF_EHIP;
+    float* partial = params + 2 * 2304 + 16;
+    FwdBlockH3Args fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.x = x; fa.pre_c = pre_c; fa.pre_scale = pre_scale; fa.pre_shift = pre_shift; fa.a_out = a_out; fa.t_out = t_out; fa.c_out = c_out;
+    fa.wpack0 = scratch; fa.wpack1 = scratch + BF_H3_TRAIN_PACK_FLOATS; fa.stats = partial;
+    fa.B = B; fa.H = H; fa.W = W; fa.reverse = reverse; fa.act_relu = relu;
+    if (bf_launch_fwd_block_h3t(fa, s) != hipSuccess) return BF_EHIP;
+    return bf_launch_reduce_partials(partial, bf_fwd_block_h3t_grid(B, H, W), 32, stats, 1.0f, s) == hipSuccess ? BF_OK : BF_EHIP;
 }
 
 // the fused backward kernel of one convolution (train_bwd_h3.hip): dw = x^T g', dx = dgrad(g') [* (x > 0) | + res], with

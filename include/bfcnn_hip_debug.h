@@ -48,6 +48,13 @@ int bf_debug_wgrad3x3_h3(const float* x, const float* dy, float* partial, float*
 int bf_debug_conv3x3_h3_pre(const float* in, const float* pre_c, const float* pre_scale, const float* pre_shift, float* pre_out,
                             const float* w_hwio, float* out, float* scratch, int batch, int height, int width, int relu,
                             int reverse, void* stream);
+/* the training-mode forward of one [3,3] block in one kernel (train_fwd_h3t.hip; bfcnn/backbone_blocks.py:174-246 under training=True):
+   a_out = x + pre_scale * pre_c + pre_shift (pre_c not NULL), t_out = [relu] conv_0(a) (t_out not NULL), c_out = conv_1(t),
+   stats[32] = per-channel sum | sum of squares of c_out.  width <= 256. */
+int64_t bf_debug_fwd_block_h3t_scratch_floats(int batch, int height, int width);
+int bf_debug_fwd_block_h3t(const float* x, const float* pre_c, const float* pre_scale, const float* pre_shift, const float* w0_hwio,
+                           const float* w1_hwio, float* a_out, float* t_out, float* c_out, float* stats, float* scratch, int batch,
+                           int height, int width, int relu, int reverse, void* stream);
 int64_t bf_debug_bwd3x3_h3_scratch_floats(int batch, int height, int width);
 int bf_debug_bwd3x3_h3_grid(int batch, int height, int width);
 int bf_debug_bwd3x3_h3_grid_ex(int batch, int height, int width, int dbuf);    /* partial rows written; `reverse` bit 1 of the call below = dbuf */

@@ -138,6 +138,27 @@ def conv3x3_h3_pre_gpu(x, c, scale, shift, w, relu=1, reverse=0):
     return host(y), host(out)
 
 
+def fwd_block_h3t_gpu(x, w0, w1, c=None, scale=None, shift=None, relu=1, reverse=0, want_t=True):
+    """the training-mode forward of one [3,3] block in one kernel (train_fwd_h3t.hip): returns (a, t, c_out, stats[32]) with
+    a = x + scale * c + shift (None without c), t = [relu] conv_0(a) (None unless want_t), c_out = conv_1(t), stats = sum | sum of squares."""
+    L = N.lib()
+    B, H, W, _ = x.shape
+    xd, w0d, w1d = dev(x), dev(w0), dev(w1)
+    cd = dev(c) if c is not None else None
+    sd = dev(scale) if c is not None else None
+    hd = dev(shift) if c is not None else None
+    nan = lambda: torch.full((B, H, W, 16), float("nan"), dtype=torch.float32, device="cuda")
+    a_out = nan() if c is not None else None
+    t_out = nan() if want_t else None
+    c_out = nan()
+    stats = torch.full((32,), float("nan"), dtype=torch.float32, device="cuda")
+    scratch = torch.full((int(L.bf_debug_fwd_block_h3t_scratch_floats(B, H, W)),), float("nan"), dtype=torch.float32, device="cuda")
+    rc = L.bf_debug_fwd_block_h3t(N.ptr(xd), N.ptr(cd), N.ptr(sd), N.ptr(hd), N.ptr(w0d), N.ptr(w1d), N.ptr(a_out), N.ptr(t_out),
+                                  N.ptr(c_out), N.ptr(stats), N.ptr(scratch), B, H, W, relu, reverse, N.stream_ptr(xd))
+    assert rc == 0, rc
+    return (host(a_out) if a_out is not None else None, host(t_out) if t_out is not None else None, host(c_out), host(stats))
+
+
 def bwd3x3_h3_gpu(x, g, w, epi, c=None, coef=None, res=None, bnc=None, reverse=0, dbuf=0):
     """the fused backward kernel of one convolution: returns (dx, dw[, stats [grid, 32]])."""
     L = N.lib()

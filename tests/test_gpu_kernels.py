@@ -6,7 +6,7 @@ import torch
 
 from oracle import bfcnn_oracle as O
 from blind_image_denoising_amd import _native as N
-from helpers import (bwd3x3_h3_gpu, conv3x3_h3_pre_gpu, assert_close, conv3x3_gpu, conv3x3_h3_gpu, dev, fused_block_gpu, fused_block_h3_gpu,
+from helpers import (bwd3x3_h3_gpu, conv3x3_h3_pre_gpu, fwd_block_h3t_gpu, assert_close, conv3x3_gpu, conv3x3_h3_gpu, dev, fused_block_gpu, fused_block_h3_gpu,
                      fused_block2_h3_gpu, host, wgrad_gpu)
 
 pytestmark = pytest.mark.gpu
@@ -372,6 +372,57 @@ def test_conv3x3_h3_affine_add_on_load(shape, relu):
     assert np.abs(y - y_ref).max() <= 4e-7 * np.abs(y_ref).max()
     ref = O.conv2d_same(y.astype(np.float64), w.astype(np.float64))
     assert_close(out, np.maximum(ref, 0) if relu else ref, what=f"conv of the formed input {shape}")
+
+
+# the whole training forward of a block in one row-streaming kernel (train_fwd_h3t.hip): full 256-column rows and narrower ones,
+# bands shorter than the pipeline (1 and 2 rows), more bands than workgroups (300 x 8 rows), both walking directions
+FWD_BLOCK_SHAPES = [(1, 1, 1), (2, 2, 5), (1, 5, 256), (3, 33, 47), (2, 64, 256), (1, 130, 255), (2, 40, 70), (300, 8, 16)]
+
+
+@pytest.mark.parametrize("shape", FWD_BLOCK_SHAPES)
+@pytest.mark.parametrize("pre", [1, 0])
+def test_fwd_block_h3t_matches_oracle(shape, pre):
+    """A_i = x + scale * c + shift on load, T_i = relu(conv_0 A_i), C_i = conv_1 T_i and the batch statistics of C_i, one kernel,
+    against the fp64 oracle (bfcnn/backbone_blocks.py:174-246 under training=True)."""
+    B, H, W = shape
+    x, c = _rand((B, H, W, 16), 70), _rand((B, H, W, 16), 71)
+    sc, sh = (1 + 0.3 * _rand(16, 72)).astype(np.float32), _rand(16, 73)
+    w0, w1 = _rand((3, 3, 16, 16), 74) * 0.1, _rand((3, 3, 16, 16), 75) * 0.1
+    relu = 1 if (B + H) % 3 else 0
+    a, t, cout, stats = fwd_block_h3t_gpu(x, w0, w1, c if pre else None, sc, sh, relu=relu, reverse=(H + W) & 1)
+    if pre:
+        a_ref = x + (sc * c + sh)                                 # fp32, the rounding of affine_add_kernel up to the fma
+        assert np.abs(a - a_ref).max() <= 6e-7 * max(np.abs(a_ref).max(), 1.0)     # stored as the hi + lo pair the convolution saw: 22 bits
+    else:
+        assert a is None
+        a = x
+    t_ref = O.conv2d_same(a.astype(np.float64), w0.astype(np.float64))
+    t_ref = np.maximum(t_ref, 0) if relu else t_ref
+    assert_close(t, t_ref, what=f"T {shape}")
+    c_ref = O.conv2d_same(t_ref, w1.astype(np.float64))
+    assert_close(cout, c_ref, what=f"C {shape}")
+    n = np.sqrt(B * H * W)
+    assert_close(stats[:16], cout.astype(np.float64).sum(axis=(0, 1, 2)), rel=1e-5 * n, what="sum C")
+    assert_close(stats[16:], (cout.astype(np.float64) ** 2).sum(axis=(0, 1, 2)), rel=1e-5 * n, what="sum C^2")
+    # without the T output the same C and sums, bit for bit; twice the same bits
+    _, t2, cout2, stats2 = fwd_block_h3t_gpu(x, w0, w1, c if pre else None, sc, sh, relu=relu, reverse=(H + W) & 1, want_t=False)
+    assert t2 is None and np.array_equal(cout2, cout) and np.array_equal(stats2, stats)
+
+
+def test_fwd_block_h3t_exact_on_integers():
+    """small integers through both convolutions: bit-exact (pins the K packing, the tap pairing, the ring bookkeeping and the
+    rows / columns outside the image, which must be conv_1's ZERO padding and not values computed from padded input)"""
+    rng = np.random.default_rng(76)
+    for shape in [(2, 37, 256), (3, 19, 100)]:
+        x = rng.integers(-2, 3, shape + (16,)).astype(np.float32)
+        w0 = rng.integers(-2, 3, (3, 3, 16, 16)).astype(np.float32)
+        w1 = rng.integers(-2, 3, (3, 3, 16, 16)).astype(np.float32)
+        for reverse in (0, 1):
+            _, t, cout, stats = fwd_block_h3t_gpu(x, w0, w1, relu=1, reverse=reverse)
+            t_ref = np.maximum(O.conv2d_same(x.astype(np.float64), w0.astype(np.float64)), 0)
+            c_ref = O.conv2d_same(t_ref, w1.astype(np.float64))
+            assert np.array_equal(t, t_ref) and np.array_equal(cout, c_ref), (shape, reverse)
+            assert_close(stats[:16], c_ref.sum(axis=(0, 1, 2)), rel=1e-6 * np.sqrt(c_ref.size), what="sum C")
 
 
 @pytest.mark.parametrize("h3", [False, True], ids=["f32", "f16x3"])
