@@ -181,6 +181,8 @@ SIGNATURES = {
     "bf_debug_wgrad3x3_h3": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "bf_debug_fwd_block_h3t_scratch_floats": (_I64, [_I, _I, _I]),
     "bf_debug_fwd_block_h3t": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "bf_debug_bwd_block_h3t_scratch_floats": (_I64, [_I, _I, _I]),
+    "bf_debug_bwd_block_h3t": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "bf_debug_conv3x3_h3_pre": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "bf_debug_bwd3x3_h3_scratch_floats": (_I64, [_I, _I, _I]),
     "bf_debug_bwd3x3_h3_grid": (_I, [_I, _I, _I]),

@@ -270,6 +270,28 @@ struct FwdBlockH3Args {
 bool       bf_fwd_block_h3t_supports(int H, int W);
 int        bf_fwd_block_h3t_grid(int B, int H, int W);
 hipError_t bf_launch_fwd_block_h3t(const FwdBlockH3Args& a, hipStream_t s);
+// backward of one [3,3] block (BatchNorm behind conv_1, [ReLU] between the convolutions) in one kernel with T RECOMPUTED from A
+// (train_bwd_h3t.hip): dc = k1 g + k2 c + k3 ; T = act(conv_0 a) ; dW1 = T^T dc ; dT = dgrad_1(dc) * (T > 0) ; dW0 = a^T dT ;
+// out = dgrad_0(dT) + g ; stats = sums of out and out * bnc (bnc != NULL)
+struct BwdBlockH3Args {
+    const float* a;        // [B,H,W,16] block input A_i
+    const float* g;        // gradient at the block's output
+    const float* c;        // raw output of conv_1 = BatchNorm input
+    const float* coef;     // [48] k1 | k2 | k3 of bn_bwd_finalize
+    const float* wfwd0;    // forward pack of conv_0 (pack_h3_train)
+    const float* wdg1;     // data-gradient packs of conv_1 / conv_0
+    const float* wdg0;
+    const float* bnc;      // input of the BatchNorm of the block in front, or NULL
+    float* out;            // must not alias a, g, c, bnc
+    float* wpartial1;      // [bf_bwd_block_h3t_grid][2304]: weight gradient of conv_1
+    float* wpartial0;      //                                 ... of conv_0
+    float* stats;          // [grid][32] (bnc != NULL)
+    int B, H, W, reverse, act_relu;
+    int nstrips, tiles_y, ntiles, rows_per_tile;       // filled in by the launcher
+};
+bool       bf_bwd_block_h3t_supports(int H, int W);
+int        bf_bwd_block_h3t_grid(int B, int H, int W);
+hipError_t bf_launch_bwd_block_h3t(const BwdBlockH3Args& a, hipStream_t s);
 int        bf_bwd2_h3_grid(int B, int H, int W);
 hipError_t bf_launch_bwd2_h3(const Bwd2H3Args& a, hipStream_t s);
 int        bf_bwd3x3_h3_grid(int B, int H, int W);                 // partial rows of the 256-thread kernel (the larger count: sizing)

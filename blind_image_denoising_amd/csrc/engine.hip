@@ -49,6 +49,9 @@ struct bf_engine {
     int train_fwd_block = 1;        // [3,3] blocks with BatchNorm + ReLU, W <= 256: the whole training forward of a block in ONE row-streaming
                                     // kernel (train_fwd_h3t.hip; T kept in LDS unless the backward pass reads it).  1 = where a forward holds
                                     // enough rows (bf_train_step), 2 = wherever it can run (tests), 0 = the two convolution kernels
+    int train_bwd_block = 1;        // [3,3] blocks with BatchNorm + ReLU: the whole backward of a block in ONE row-streaming kernel that recomputes
+                                    // T from the block input (train_bwd_h3t.hip: 5 tensor passes for 9, and the forward pass need not write T).
+                                    // 1 = where a step holds enough strip rows, 2 = wherever it can run (tests), 0 = one kernel per convolution
     int train_fused_bwd = 1;        // split-f16 training: weight + data gradient (+ BatchNorm backward) of a convolution in one kernel
     int train_fused_bwd2 = 0;       // [3,3] blocks with BatchNorm and ReLU: BOTH convolutions' backward in one kernel (bwd2_h3_kernel: 6 tensor
                                     // passes for 9, but 348 us against 131 + 110: one workgroup per CU and a recomputed halo -- DESIGN 4.3)
@@ -219,6 +222,7 @@ extern "C" int bf_set_option(bf_handle h, const char* key, int value)
     if (!strcmp(key, "train_fused_fwd")) { h->train_fused_fwd = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_bwd_dbuf")) { h->train_bwd_dbuf = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_fused_bwd")) { h->train_fused_bwd = value ? 1 : 0; return BF_OK; }
+    if (!strcmp(key, "train_bwd_block")) { h->train_bwd_block = value < 0 ? 1 : (value > 2 ? 2 : value); return BF_OK; }
     if (!strcmp(key, "train_fwd_block")) { h->train_fwd_block = value < 0 ? 1 : (value > 2 ? 2 : value); return BF_OK; }
     if (!strcmp(key, "train_fused_bwd2")) { h->train_fused_bwd2 = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_arith")) { h->train_arith = value < 0 ? 1 : (value ? 1 : 0); return BF_OK; }
@@ -421,12 +425,13 @@ static TrainLayout train_layout(bf_handle h, int B, int H, int W)
     pf = max64(pf, (int64_t)bf_wgrad_grid(B, H, W) * 2304);
     pf = max64(pf, (int64_t)bf_bwd3x3_h3_grid(B, H, W) * (2304 + 32));
     pf = max64(pf, (int64_t)bf_fwd_block_h3t_grid(B, H, W) * 32);
+    pf = max64(pf, (int64_t)bf_bwd_block_h3t_grid(B, H, W) * (2304 + 32));
     pf = max64(pf, (int64_t)bf_base_wgrad_grid(B, H, W) * h->n_base);
     pf = max64(pf, (int64_t)bf_head_train_grid(B, H, W) * 80);
     L.partial_floats = align_up(pf, 64);
     L.partial = o; o += L.partial_floats + 256;     // +256: reduced head sums / scratch
     // one weight-gradient partial slot per block convolution (fused backward kernel): summed by ONE launch at the end of the step
-    L.wslot_floats = (int64_t)bf_bwd3x3_h3_grid(B, H, W) * 2304;
+    L.wslot_floats = max64(bf_bwd3x3_h3_grid(B, H, W), bf_bwd_block_h3t_grid(B, H, W)) * 2304;
     L.wslots = o; o += L.wslot_floats * N * nb;
     o = align_up(o, 64);
     L.act_floats = (int64_t)B * H * W * 16;
@@ -896,7 +901,11 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     // images up to 256 columns, and a forward of enough rows that its bands (rows + 6 steps each) keep 256 workgroups busy
     const bool fwd_block = h3t && h->train_fwd_block && h->train_fused_fwd && nb == 2 && d.use_bn && bf_fwd_block_h3t_supports(H, W) &&
                            (h->train_fwd_block == 2 || (int64_t)B * H >= 4096);
-    const bool need_t = true;                               // the backward kernels below read T_i
+    // the whole backward of a block in one kernel that RECOMPUTES T_i from A_i (train_bwd_h3t.hip): same kind of block, any width
+    const int64_t bwd_strips = (W + 127) / 128;
+    const bool bwd_block = h3t && h->train_bwd_block && h->train_fused_bwd && nb == 2 && d.use_bn && bf_bwd_block_h3t_supports(H, W) &&
+                           (h->train_bwd_block == 2 || (int64_t)B * H * bwd_strips >= 8192);
+    const bool need_t = !bwd_block;                         // the per-convolution backward kernels read T_i
     for (int i = 0; i < N; ++i) {
         const float* wp = w + L.wpack + (int64_t)i * 2 * nb * BF_TRAIN_PACK_STRIDE;        // forward packs 0..nb-1, then data-gradient packs
         if (fwd_block) {
@@ -1024,9 +1033,9 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     const bool fused_bwd2 = fused_bwd && h->train_fused_bwd2 && nb == 2 && d.use_bn && relu;
     h->train_kernels = std::string("fwd: ") + (fwd_block ? "fwd_block_h3t_kernel" : h3t ? (h->train_fused_fwd && nb >= 2 && d.use_bn ? "conv3x3_h3_kernel<.., PRE> + conv3x3_h3_kernel" : "conv3x3_h3_kernel")
                                                    : "conv3x3_c16_kernel")
-                       + "; bwd: " + (fused_bwd2 ? "bwd2_h3_kernel" : fused_bwd ? "bwd3x3_h3_kernel<true, 8> + bwd3x3_h3_kernel<false, 36>"
+                       + "; bwd: " + (bwd_block ? "bwd_block_h3t_kernel" : fused_bwd2 ? "bwd2_h3_kernel" : fused_bwd ? "bwd3x3_h3_kernel<true, 8> + bwd3x3_h3_kernel<false, 36>"
                                                  : h3t ? "wgrad3x3_h3_kernel + conv3x3_h3_kernel" : "wgrad3x3_c16_kernel + conv3x3_c16_kernel");
-    const int bwd_grid = fused_bwd2 ? bf_bwd2_h3_grid(B, H, W) : bf_bwd3x3_h3_grid_ex(B, H, W, h->train_bwd_dbuf);
+    const int bwd_grid = bwd_block ? bf_bwd_block_h3t_grid(B, H, W) : fused_bwd2 ? bf_bwd2_h3_grid(B, H, W) : bf_bwd3x3_h3_grid_ex(B, H, W, h->train_bwd_dbuf);
     float* bwd_stats = partial + (int64_t)bwd_grid * 2304;
     for (int i = N - 1; i >= 0; --i) {
         const float* wp = w + L.wpack + (int64_t)i * 2 * nb * BF_TRAIN_PACK_STRIDE;
@@ -1049,6 +1058,27 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
                     BF_HIP(bf_launch_bn_bwd_apply(g, C(i, j), w + L.coef, C(i, j), npix, s), "bn_bwd_apply");
                     dy = C(i, j);
                 }
+            }
+            if (bwd_block) {
+                // one row-streaming kernel for the whole block, T recomputed from A(i): dc = k1 g + k2 c + k3 ; T = act(conv_0 A) ;
+                // dw1 = T^T dc ; dT = dgrad_1(dc) * (T > 0) ; dw0 = A^T dT ; dA' = dgrad_0(dT) + g [+ the sums of the BatchNorm in front]
+                BwdBlockH3Args fa;
+                memset(&fa, 0, sizeof(fa));
+                fa.B = B; fa.H = H; fa.W = W; fa.act_relu = relu; fa.reverse = next_reverse();
+                fa.a = A(i); fa.g = g; fa.c = C(i, 1); fa.coef = w + L.coef;
+                fa.wfwd0 = wp; fa.wdg0 = wp + (int64_t)nb * BF_TRAIN_PACK_STRIDE; fa.wdg1 = wp + (int64_t)(nb + 1) * BF_TRAIN_PACK_STRIDE;
+                fa.wpartial1 = w + L.wslots + ((int64_t)i * nb + 1) * L.wslot_floats;
+                fa.wpartial0 = w + L.wslots + ((int64_t)i * nb + 0) * L.wslot_floats;
+                fa.stats = bwd_stats;
+                if (i > 0) fa.bnc = C(i - 1, nb - 1);
+                float* out = nullptr;
+                for (int k = 0; k < 3 && !out; ++k)
+                    if (gbuf[k] != g) out = gbuf[k];
+                fa.out = out;
+                BF_HIP(bf_launch_bwd_block_h3t(fa, s), "bwd_block_h3t");
+                g = out;
+                dA = out;
+                break;                                              // both convolutions done
             }
             if (fused_bwd2) {
                 // one kernel for the whole block: dc = k1 g + k2 c + k3 ; dw2 = T^T dc ; dT = dgrad2(dc) * (T > 0) (LDS only) ;
@@ -1483,6 +1513,40 @@ extern "C" int bf_debug_fwd_block_h3t(const float* x, const float* pre_c, const 
     fa.B = B; fa.H = H; fa.W = W; fa.reverse = reverse; fa.act_relu = relu;
     if (bf_launch_fwd_block_h3t(fa, s) != hipSuccess) return BF_EHIP;
     return bf_launch_reduce_partials(partial, bf_fwd_block_h3t_grid(B, H, W), 32, stats, 1.0f, s) == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// the backward of one [3,3] block in one kernel with T recomputed (train_bwd_h3t.hip): dc = k1 g + k2 c + k3 (coef = k1 | k2 | k3),
+// T = [relu] conv_0(a), dw1 = T^T dc, dT = dgrad_1(dc) [* (T > 0)], dw0 = a^T dT, out = dgrad_0(dT) + g, stats[32] = sums of out |
+// out * bnc (bnc given).  scratch: bf_debug_bwd_block_h3t_scratch_floats(B, H, W) floats
+extern "C" int64_t bf_debug_bwd_block_h3t_scratch_floats(int B, int H, int W)
+{
+    return 4 * (int64_t)BF_H3_TRAIN_PACK_FLOATS + 2 * 2304 + 16 + (int64_t)bf_bwd_block_h3t_grid(B, H, W) * (2 * 2304 + 32);
+}
+extern "C" int bf_debug_bwd_block_h3t(const float* a_in, const float* g, const float* c, const float* coef, const float* w0_hwio,
+                                      const float* w1_hwio, const float* bnc, float* out, float* dw1, float* dw0, float* stats,
+                                      float* scratch, int B, int H, int W, int relu, int reverse, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (!bf_bwd_block_h3t_supports(H, W)) return BF_EUNSUPPORTED;
+    float* params = scratch + 4 * BF_H3_TRAIN_PACK_FLOATS;
+    if (hipMemcpyAsync(params, w0_hwio, 2304 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;
+    if (hipMemcpyAsync(params + 2304, w1_hwio, 2304 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;
+    if (bf_launch_pack_h3_train(params, 0, 4608 + 16, scratch, 1, 2, 2320, s) != hipSuccess) return BF_EHIP;
+    const int grid = bf_bwd_block_h3t_grid(B, H, W);
+    float* wp1 = params + 2 * 2304 + 16;
+    float* wp0 = wp1 + (int64_t)grid * 2304;
+    float* st = wp0 + (int64_t)grid * 2304;
+    BwdBlockH3Args fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.a = a_in; fa.g = g; fa.c = c; fa.coef = coef; fa.bnc = bnc; fa.out = out;
+    fa.wfwd0 = scratch; fa.wdg0 = scratch + 2 * BF_H3_TRAIN_PACK_FLOATS; fa.wdg1 = scratch + 3 * BF_H3_TRAIN_PACK_FLOATS;
+    fa.wpartial1 = wp1; fa.wpartial0 = wp0; fa.stats = st;
+    fa.B = B; fa.H = H; fa.W = W; fa.reverse = reverse; fa.act_relu = relu;
+    if (bf_launch_bwd_block_h3t(fa, s) != hipSuccess) return BF_EHIP;
+    if (bf_launch_reduce_partials(wp1, grid, 2304, dw1, 1.0f, s) != hipSuccess) return BF_EHIP;
+    if (bf_launch_reduce_partials(wp0, grid, 2304, dw0, 1.0f, s) != hipSuccess) return BF_EHIP;
+    if (bnc && stats && bf_launch_reduce_partials(st, grid, 32, stats, 1.0f, s) != hipSuccess) return BF_EHIP;
+    return BF_OK;
 }
 
 // the fused backward kernel of one convolution (train_bwd_h3.hip): dw = x^T g', dx = dgrad(g') [* (x > 0) | + res], with

@@ -1,0 +1,779 @@
+// Backward of one residual block in ONE kernel (bwd_block_h3t_kernel): split-f16 arithmetic, fp32 NHWC tensors, row streaming on
+// 128-column strips (the decomposition of fused_block2_h3w_kernel, fused_h3w.hip), T_i RECOMPUTED instead of read.
+//
+// Reference: tape.gradient (bfcnn/train_loop.py:273-294) through one iteration of the block loop of
+// bfcnn/backbone_blocks.py:167-246 -- conv_0, ReLU, conv_1, BatchNormalization, Add -- given g = dL/dA_{i+1}:
+//     dc  = k1 g + k2 C_i + k3                      (BatchNorm backward; k from bn_bwd_finalize)          formed on load
+//     T   = relu(conv_0 A_i)                        (what the forward pass computed and did not keep)      role F
+//     dW1 = T^T (*) dc                              (weight gradient of conv_1)                            role W
+//     dT  = dgrad_1(dc) * (T > 0)                                                                          role D2
+//     dW0 = A_i^T (*) dT                            (weight gradient of conv_0)                            role W
+//     dA' = dgrad_0(dT) + g                         (data gradient + the skip's)                           role D1 + epilogue
+//     sum dA', sum dA' * C_{i-1}                    (the two reductions of the NEXT BatchNorm backward)    epilogue
+// As two kernels (bwd3x3_h3_kernel<true, MASK>, <false, RES | BNBWD>) plus the forward's T_i that is 9 + 1 tensor passes at the
+// ~5 TB/s the chip sustains on mixed streams (g, C_i, T_i read, dT written; A_i, dT, g, C_{i-1} read, dA' written; T_i written
+// by the forward pass); here A_i, g, C_i, C_{i-1} are read once and dA' written once: 5 passes.  The price is matrix work: the
+// recomputed conv_0 and the halo columns of a strip (144 for 128) -- the matrix pipe was idle in the HBM-bound kernels.
+//
+// A workgroup owns a strip of 128 output columns and walks down a band of rows, one image row per step.  All five convolution-
+// shaped operators work on the same GRID of 144 columns = nine 16-pixel MFMA groups, G0 = max(X0 - 8, 0): dA' on the strip needs
+// dT on 1 column more per side, dc and T on 2, A_i on 3.  Twelve waves, three per SIMD:
+//   * F   (waves 0-2)  conv_0 + ReLU on the A ring: A row s-3 -> T row s-4 completes -> T ring (split f16)
+//   * D2  (waves 3-5)  dgrad_1 on the dc ring: dc row s-4 -> dT row s-5 completes, masked by T row s-5 -> dT ring
+//   * D1  (waves 6-8)  dgrad_0 on the dT ring: dT row s-6 -> raw dA' row s-7 completes -> staging ring (fp32)
+//   * W   (waves 9-11) both weight gradients with the transposing LDS reads of train_bwd_h3.hip (pixel index along K), own
+//     columns and own rows only, K chunks of 32 pixels: wave 9 = dW1 chunks 0-2, wave 10 = dW0 chunks 0-2, wave 11 = chunk 3 of
+//     both.  dW1 pairs T row s-5 with dc rows s-4, s-5, s-6 (vertical taps 0, 1, 2); dW0 pairs dT row s-6 with A rows s-7..s-5.
+//     Accumulators stay in registers for the whole launch and leave as per-workgroup partials (fixed order: bitwise reproducible).
+// The memory instructions ride on the matrix waves, loads and stores on DIFFERENT waves (fused_h3v.hip on why):
+//   * F and D2 waves load: one 16-pixel unit of a row per register quad, converted a step later into the hi / lo planes of the
+//     A ring (row s-2) and of the dc ring (row s-3: dc = k1 g + k2 c + k3), re-loaded at once with the next row (the in-place
+//     prefetch of train_fwd_h3t.hip);
+//   * W waves run the epilogue of staged row s-8: + g, the two sums against C_{i-1}, written back to the staging ring;
+//   * D1 waves store staged row s-9.
+// LDS rings (ring column = grid column + 1; columns 0 and 145 are never written): A 6 rows, dc 4, T 2, dT 2 (split f16, plane
+// stride = 128 mod 256 for the transposed reads) + staging 3 rows of fp32 = 157 KB.  ONE barrier per step, nrows + 9 steps per band.
+#include "bf_common.h"
+#include "h3_core.h"
+#include "h3v_core.h"
+
+typedef __fp16 hu_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+// plane stride of a ring: the smallest size >= bytes that is 128 mod 256 (the transposed reads of a half-wave touch planes 0 and 1
+// of 8 neighbouring pixels: train_bwd_h3.hip)
+constexpr int h3u_plane(const int bytes) { return bytes / 256 * 256 + 128 >= bytes ? bytes / 256 * 256 + 128 : bytes / 256 * 256 + 384; }
+
+struct H3UGeom {
+    static constexpr int NG = 9, GW = 16 * NG;         // grid: nine 16-column groups
+    static constexpr int G = 3;                        // groups per F / D wave
+    static constexpr int NW = 12, NT = 768;
+    static constexpr int SW = 128;                     // output columns of a strip
+    static constexpr int PITCH = (GW + 2) * 16;        // 2336 bytes per plane-row of a ring
+    static constexpr int NRA = 6, NRC = 4, NRT = 2, NRD = 2, NRS = 3;       // ring depths (rows)
+    static constexpr int UNROLL = 6;                   // steps per loop iteration: accumulator rotation and the 2- / 3-row rings static
+    static constexpr int A_PLANE = h3u_plane(NRA * PITCH), C_PLANE = h3u_plane(NRC * PITCH), T_PLANE = h3u_plane(NRT * PITCH), D_PLANE = h3u_plane(NRD * PITCH);
+    static constexpr int S_QUAD = GW * 16 + 64, S_SLOT = 4 * S_QUAD;         // staging: [slot][channel quad][grid column] 16-byte records
+    static constexpr int A_OFF = 0, C_OFF = A_OFF + 4 * A_PLANE, T_OFF = C_OFF + 4 * C_PLANE, D_OFF = T_OFF + 4 * T_PLANE;
+    static constexpr int S_OFF = D_OFF + 4 * D_PLANE, K_OFF = S_OFF + NRS * S_SLOT, LDS_BYTES = K_OFF + 256;    // K: k1 | k2 | k3 (48 floats)
+    static constexpr int LEAD = 9;                     // steps from the first A row of a band to the store of its first output row
+    static_assert(A_PLANE >= NRA * PITCH && C_PLANE >= NRC * PITCH && T_PLANE >= NRT * PITCH && D_PLANE >= NRD * PITCH, "planes");
+    static_assert(A_PLANE % 256 == 128 && C_PLANE % 256 == 128 && T_PLANE % 256 == 128 && D_PLANE % 256 == 128, "plane stride");
+    static_assert(UNROLL % NRT == 0 && UNROLL % NRD == 0 && UNROLL % NRS == 0 && UNROLL % NRA == 0 && UNROLL % 3 == 0, "static slots");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+struct H3UTile {
+    int nrows;
+    size_t img;                  // byte offset of the image in an fp32 NHWC tensor of 16 channels
+    int ybase, ystep;            // image row of band-relative row k: ybase + ystep * k (a reversed band walks bottom-up)
+    int X0, X1;                  // own (output) columns [X0, X1)
+    int G0, go;                  // image column of grid column 0; grid column of X0
+    __device__ __forceinline__ int y(const int k) const { return ybase + ystep * k; }
+};
+
+__device__ __forceinline__ H3UTile h3u_tile(const BwdBlockH3Args& a, const int t)
+{
+    H3UTile r;
+    const int tt = a.reverse ? a.ntiles - 1 - t : t;
+    const int sx = tt % a.nstrips, rest = tt / a.nstrips;
+    const int b = rest / a.tiles_y, ty = rest - b * a.tiles_y;
+    const int y0 = ty * a.rows_per_tile;
+    r.nrows = min(a.rows_per_tile, a.H - y0);
+    r.img = (size_t)b * a.H * a.W * 64;
+    r.ybase = a.reverse ? y0 + r.nrows - 1 : y0;
+    r.ystep = a.reverse ? -1 : 1;
+    r.X0 = sx * H3UGeom::SW;
+    r.X1 = min(a.W, r.X0 + H3UGeom::SW);
+    r.G0 = max(r.X0 - 8, 0);
+    r.go = r.X0 - r.G0;
+    return r;
+}
+
+__device__ __forceinline__ int h3u_wimage(const BwdBlockH3Args& a, const int i) { return a.reverse ? (2 - i / 4) * 4 + i % 4 : i; }
+__device__ __forceinline__ int h3u_mod(const int v, const int n) { return ((v % n) + n) % n; }
+
+// the 15 MFMAs of one 16-pixel group and step (see train_fwd_h3t.hip)
+template <int J, class Epi>
+__device__ __forceinline__ void h3u_mfmas(const h8 (&w)[13], f32x4& acc2, f32x4& acc1, f32x4& c0, const H3VFrag& cur, Epi* epi)
+{
+    if constexpr (J < 15) {
+        constexpr int k = J / 3, which = J % 3;
+        if constexpr (which == 0) acc2 = h3v_mfma(cur, w, 2, k, acc2);
+        else if constexpr (which == 1) acc1 = h3v_mfma(cur, w, 1, k, acc1);
+        else c0 = h3v_mfma(cur, w, 0, k, c0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (J >= 2) {
+            if (epi) epi->template pair<J - 2>();
+        }
+        h3u_mfmas<J + 1>(w, acc2, acc1, c0, cur, epi);
+    }
+}
+
+// ---- epilogues as micro-ops (h3v_core.h on why) ------------------------------------------------------------------------------
+// D2: hi / lo of v * sc as H3VEpi<false>, then AND with the ReLU mask of the recomputed T (T > 0 <=> its f16 hi half is not zero:
+// the F role's epilogue never writes a negative zero), then the two 8-byte records
+typedef unsigned short hu_us2 __attribute__((ext_vector_type(2)));
+struct H3UEpiMask {
+    static constexpr int NOPS = 14;
+    f32x4 v;
+    float sc;
+    unsigned h0, h1, l0, l1, t0, t1;          // t0 / t1: the T hi record of the lane's four channels (all ones when there is no ReLU)
+    char* p;
+    int lo_off;
+    template <int I> __device__ __forceinline__ void op()
+    {
+        if constexpr (I == 0) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h0) : "v"(v.x), "v"(sc));
+        else if constexpr (I == 1) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h1) : "v"(v.z), "v"(sc));
+        else if constexpr (I == 2) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h0) : "v"(v.y), "v"(sc));
+        else if constexpr (I == 3) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h1) : "v"(v.w), "v"(sc));
+        else if constexpr (I == 4) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(v.x), "v"(sc), "v"(h0));
+        else if constexpr (I == 5) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(v.z), "v"(sc), "v"(h1));
+        else if constexpr (I == 6) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l0) : "v"(v.y), "v"(sc), "v"(h0));
+        else if constexpr (I == 7) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l1) : "v"(v.w), "v"(sc), "v"(h1));
+        else if constexpr (I == 8) {
+            // 0xffff where the half is not zero, else 0: 0 - min(bits, 1) on packed 16-bit lanes
+            const hu_us2 one = {1, 1}, zero = {0, 0};
+            t0 = __builtin_bit_cast(unsigned, zero - __builtin_elementwise_min(__builtin_bit_cast(hu_us2, t0), one));
+        } else if constexpr (I == 9) {
+            const hu_us2 one = {1, 1}, zero = {0, 0};
+            t1 = __builtin_bit_cast(unsigned, zero - __builtin_elementwise_min(__builtin_bit_cast(hu_us2, t1), one));
+        } else if constexpr (I == 10) { h0 &= t0; l0 &= t0; }
+        else if constexpr (I == 11) { h1 &= t1; l1 &= t1; }
+        else if constexpr (I == 12) *reinterpret_cast<h3v_u2*>(p) = (h3v_u2){h0, h1};
+        else *reinterpret_cast<h3v_u2*>(p + lo_off) = (h3v_u2){l0, l1};
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <int SLOT> __device__ __forceinline__ void pair()
+    {
+        if constexpr (2 * SLOT < NOPS) op<2 * SLOT>();
+        if constexpr (2 * SLOT + 1 < NOPS) op<2 * SLOT + 1>();
+    }
+    template <int I = 0> __device__ __forceinline__ void all()
+    {
+        if constexpr (I < NOPS) {
+            op<I>();
+            all<I + 1>();
+        }
+    }
+};
+
+// D1: v * sc as one 16-byte fp32 record to the staging ring
+struct H3UEpiStage {
+    static constexpr int NOPS = 5;
+    f32x4 v;
+    float sc;
+    char* p;
+    template <int I> __device__ __forceinline__ void op()
+    {
+        if constexpr (I < 4) v[I] *= sc;
+        else *reinterpret_cast<f32x4*>(p) = v;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <int SLOT> __device__ __forceinline__ void pair()
+    {
+        if constexpr (2 * SLOT < NOPS) op<2 * SLOT>();
+        if constexpr (2 * SLOT + 1 < NOPS) op<2 * SLOT + 1>();
+    }
+    template <int I = 0> __device__ __forceinline__ void all()
+    {
+        if constexpr (I < NOPS) {
+            op<I>();
+            all<I + 1>();
+        }
+    }
+};
+
+// ---- one convolution-shaped role (F, D2, D1): a ring row in, three vertical-tap contributions, one completed row out ------------
+// KIND 0 = F (ReLU, split f16 out), 1 = D2 (mask, split f16 out), 2 = D1 (fp32 out to the staging ring)
+template <int KIND, int INP>
+struct H3UConv {
+    using Gm = H3UGeom;
+    const char* tin;             // input ring
+    char* tdst;                  // output ring
+    const char* tmask;           // D2: the T ring
+    h8 w[13];
+    f32x4 acc[Gm::G][3];
+    int rp, rs;                  // lane's byte offset in input-ring slot 0, group 0: pair fragment (hi planes), single fragment
+    int wr;                      // lane's byte offset of its record in output slot 0, group 0
+    int mr;                      // D2: lane's byte offset of its 8-byte T hi record in T-ring slot 0, group 0
+    float inv_s, relu_floor;
+    bool relu;
+    float lane_scale[Gm::G];
+
+    __device__ __forceinline__ void init(const float* pack, const BwdBlockH3Args& a, const int lane, const int gc0)
+    {
+        const int q = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) w[i] = reinterpret_cast<const h8*>(pack)[h3u_wimage(a, i) * 64 + lane];
+        w[12] = w[0];
+        inv_s = pack[BF_H3R_WPACK_FLOATS];
+        relu = a.act_relu != 0;
+        relu_floor = relu ? 0.f : -__builtin_inff();
+        rp = (q & 1) * INP + (gc0 + (q >> 1)) * 16;
+        rs = ((q & 1) + 2 * (q >> 1)) * INP + (gc0 + 2) * 16;
+        if (KIND == 0) wr = (q >> 1) * Gm::T_PLANE + (gc0 + 1) * 16 + (q & 1) * 8;
+        else if (KIND == 1) wr = (q >> 1) * Gm::D_PLANE + (gc0 + 1) * 16 + (q & 1) * 8;
+        else wr = q * Gm::S_QUAD + gc0 * 16;
+        mr = (q >> 1) * Gm::T_PLANE + (gc0 + 1) * 16 + (q & 1) * 8;
+#pragma unroll
+        for (int g = 0; g < Gm::G; ++g)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc[g][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __device__ __forceinline__ void set_tile(const H3UTile& t, const int W, const int gc0)
+    {
+#pragma unroll
+        for (int g = 0; g < Gm::G; ++g) lane_scale[g] = (t.G0 + gc0 + 16 * g < W) ? inv_s : 0.f;
+    }
+    __device__ __forceinline__ H3VFrag load(const int islot_bytes, const int g) const
+    {
+        H3VFrag f;
+        const char* p = tin + rp + islot_bytes;
+        f.ph = *reinterpret_cast<const h8*>(p + g * 256);
+        f.pl = *reinterpret_cast<const h8*>(p + g * 256 + 2 * INP);
+        f.s = *reinterpret_cast<const h8*>(tin + rs + islot_bytes + g * 256);
+        return f;
+    }
+    // step: consumes the input ring row at byte offset islot_bytes; the row that completes goes to byte offset oslot_bytes of the
+    // output ring (rowok: inside the image -- rows / columns outside are the next operator's zero padding); D2: mslot_bytes = the
+    // T ring row of the completing row
+    template <int PH>
+    __device__ __forceinline__ void step(const int islot_bytes, const int oslot_bytes, const int mslot_bytes, const bool rowok)
+    {
+        constexpr int a0 = PH % 3, a1 = (PH + 2) % 3, a2 = (PH + 1) % 3;
+        H3VFrag cur = load(islot_bytes, 0);
+        h3v_u2 mrec[Gm::G];
+        if (KIND == 1) {
+#pragma unroll
+            for (int g = 0; g < Gm::G; ++g) {
+                mrec[g] = (h3v_u2){0x3c003c00u, 0x3c003c00u};
+                if (relu) mrec[g] = *reinterpret_cast<const h3v_u2*>(tmask + mr + mslot_bytes + g * 256);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < Gm::G; ++g) {
+            H3VFrag nx;
+            if (g + 1 < Gm::G) nx = load(islot_bytes, g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (KIND == 0) {
+                if (g > 0) {
+                    H3VEpi<true> e = epi_f(g - 1, oslot_bytes, acc[g - 1][a2], rowok);
+                    h3u_mfmas<0>(w, acc[g][a2], acc[g][a1], c0, cur, &e);
+                } else h3u_mfmas<0>(w, acc[g][a2], acc[g][a1], c0, cur, (H3VEpi<true>*)nullptr);
+            } else if constexpr (KIND == 1) {
+                if (g > 0) {
+                    H3UEpiMask e = epi_m(g - 1, oslot_bytes, acc[g - 1][a2], rowok, mrec[g - 1]);
+                    h3u_mfmas<0>(w, acc[g][a2], acc[g][a1], c0, cur, &e);
+                } else h3u_mfmas<0>(w, acc[g][a2], acc[g][a1], c0, cur, (H3UEpiMask*)nullptr);
+            } else {
+                if (g > 0) {
+                    H3UEpiStage e = epi_s(g - 1, oslot_bytes, acc[g - 1][a2], rowok);
+                    h3u_mfmas<0>(w, acc[g][a2], acc[g][a1], c0, cur, &e);
+                } else h3u_mfmas<0>(w, acc[g][a2], acc[g][a1], c0, cur, (H3UEpiStage*)nullptr);
+            }
+            acc[g][a0] = c0;
+            if (g + 1 < Gm::G) cur = nx;
+        }
+        const f32x4 last = bf_acc_ready(acc[Gm::G - 1][a2]);
+        if constexpr (KIND == 0) { H3VEpi<true> e = epi_f(Gm::G - 1, oslot_bytes, last, rowok); e.all(); }
+        else if constexpr (KIND == 1) { H3UEpiMask e = epi_m(Gm::G - 1, oslot_bytes, last, rowok, mrec[Gm::G - 1]); e.all(); }
+        else { H3UEpiStage e = epi_s(Gm::G - 1, oslot_bytes, last, rowok); e.all(); }
+    }
+    __device__ __forceinline__ H3VEpi<true> epi_f(const int g, const int oslot_bytes, const f32x4 v, const bool rowok) const
+    {
+        H3VEpi<true> e;
+        e.v = v;
+        e.sc = rowok ? lane_scale[g] : 0.f;
+        e.floor_ = relu_floor;
+        e.p = tdst + wr + oslot_bytes + g * 256;
+        e.lo_off = 2 * Gm::T_PLANE;
+        return e;
+    }
+    __device__ __forceinline__ H3UEpiMask epi_m(const int g, const int oslot_bytes, const f32x4 v, const bool rowok, const h3v_u2 m) const
+    {
+        H3UEpiMask e;
+        e.v = v;
+        e.sc = rowok ? lane_scale[g] : 0.f;
+        e.t0 = m[0];
+        e.t1 = m[1];
+        e.p = tdst + wr + oslot_bytes + g * 256;
+        e.lo_off = 2 * Gm::D_PLANE;
+        return e;
+    }
+    __device__ __forceinline__ H3UEpiStage epi_s(const int g, const int oslot_bytes, const f32x4 v, const bool rowok) const
+    {
+        H3UEpiStage e;
+        e.v = v;
+        e.sc = rowok ? lane_scale[g] : 0.f;
+        e.p = tdst + wr + oslot_bytes + g * 256;
+        return e;
+    }
+};
+
+// ---- loads that ride on the F / D2 waves: one UNIT = the 16 pixels x 4 channel quads of grid group `unit` of a ring row; lane l
+// owns pixel l >> 2, quad l & 3.  The registers of a unit are converted a step after they were loaded and re-loaded at once.
+// UNCONDITIONAL loads from clamped addresses, zeroed at the conversion (a branch around a load makes hipcc wait for vmcnt(0)). ----
+template <bool DC>               // false: A unit (x -> A ring); true: dc unit (k1 g + k2 c + k3 -> dc ring)
+struct H3ULoadUnit {
+    using Gm = H3UGeom;
+    f32x4 x, c;
+    bool ok;                     // the row in the registers lies inside the image and inside the rows the band needs
+    int unit;
+
+    __device__ __forceinline__ void load(const BwdBlockH3Args& a, const H3UTile& t, const int k, const int lane)
+    {
+        const int y = min(max(t.y(k), 0), a.H - 1);
+        const int col = min(t.G0 + 16 * unit + (lane >> 2), a.W - 1);
+        const size_t off = t.img + ((size_t)y * a.W + col) * 64 + (lane & 3) * 16;
+        x = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(DC ? a.g : a.a) + off);
+        if (DC) c = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.c) + off);
+    }
+    __device__ __forceinline__ bool row_ok(const BwdBlockH3Args& a, const H3UTile& t, const int k) const
+    {
+        const int y = t.y(k);
+        return (y >= 0) && (y < a.H) && (k >= (DC ? -2 : -3)) && (k < t.nrows + (DC ? 2 : 3));
+    }
+    // registers -> ring row at byte offset slot_bytes of `ring` (plane stride PL); then the registers take band row kn
+    // kq: the BatchNorm-backward coefficients k1 | k2 | k3 of the lane's channel quad in LDS (three 16-byte reads per conversion: 12
+    // registers that would otherwise be live through the whole step)
+    template <int PL>
+    __device__ __forceinline__ void commit_and_reload(const BwdBlockH3Args& a, const H3UTile& t, char* ring, const int slot_bytes, const int kn,
+                                                      const int lane, const char* kq)
+    {
+        const int quad = lane & 3, gcol = 16 * unit + (lane >> 2);
+        const bool in = ok && (t.G0 + gcol < a.W);
+        f32x4 v;
+        if (DC) {
+            const f32x4 k1 = *reinterpret_cast<const f32x4*>(kq), k2 = *reinterpret_cast<const f32x4*>(kq + 64), k3 = *reinterpret_cast<const f32x4*>(kq + 128);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = in ? fmaf(k1[i], x[i], fmaf(k2[i], c[i], k3[i])) : 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = in ? x[i] : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ok = row_ok(a, t, kn);
+        load(a, t, kn, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        h4 hi, lo;
+        h3_split(v, hi, lo);
+        char* p = ring + (quad >> 1) * PL + slot_bytes + (gcol + 1) * 16 + (quad & 1) * 8;
+        *reinterpret_cast<h4*>(p) = hi;
+        *reinterpret_cast<h4*>(p + 2 * PL) = lo;
+    }
+};
+
+// ---- weight gradients: operands through the transposing LDS read (train_bwd_h3.hip) ----------------------------------------------
+template <int PL>
+__device__ __forceinline__ h8 h3u_tr(const char* img, const int addr)
+{
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const hu_fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hu_fp16x4*)(img + addr));
+    const hu_fp16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hu_fp16x4*)(img + addr + 16 * 16));
+    const u2 ua = __builtin_bit_cast(u2, a), ub = __builtin_bit_cast(u2, b);
+    return __builtin_bit_cast(h8, (u4){ua[0], ua[1], ub[0], ub[1]});
+}
+
+// the x-side operands of one vertical tap row of one chunk: x(row, shifted by dx - 1)^T for dx = 0, 1, 2, hi and lo.
+// xaddr: lane's byte offset of the chunk's first pixel (tap dx = 1) in the hi image of the ring
+template <int XPL>
+__device__ __forceinline__ void h3u_load_x(const char* xring, const int xaddr, h8 (&ah)[3], h8 (&al)[3])
+{
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        ah[dx] = h3u_tr<XPL>(xring, xaddr + (dx - 1) * 16);
+        al[dx] = h3u_tr<XPL>(xring + 2 * XPL, xaddr + (dx - 1) * 16);
+    }
+}
+// acc[dx] += x(dx)^T . g, three split products each
+__device__ __forceinline__ void h3u_mfma9(const h8 (&ah)[3], const h8 (&al)[3], const h8 bh, const h8 bl, f32x4& a0, f32x4& a1, f32x4& a2)
+{
+    a0 = MFMA_H(ah[0], bh, a0); a1 = MFMA_H(ah[1], bh, a1); a2 = MFMA_H(ah[2], bh, a2);
+    a0 = MFMA_H(al[0], bh, a0); a1 = MFMA_H(al[1], bh, a1); a2 = MFMA_H(al[2], bh, a2);
+    a0 = MFMA_H(ah[0], bl, a0); a1 = MFMA_H(ah[1], bl, a1); a2 = MFMA_H(ah[2], bl, a2);
+}
+
+extern __shared__ __attribute__((aligned(16))) char h3u_lds[];
+
+// One function per role, all inlined into the kernel.  (Tried: not inlined, so that the register allocator treats the roles
+// separately.  The callee then sees its arguments as per-lane values -- uniform branches became exec-mask loops, the tensor pointers
+// generic, every load a flat_load behind vmcnt(0) -- far worse than the few spills of the inlined form, none of which is in a loop.)
+#define H3U_IN_IMAGE(k) ((t.y(k) >= 0) && (t.y(k) < a.H))
+    // per band: PRO = prologue statements, BODY(PH) = the role's work of step s = s0 + PH; every role runs the same barriers
+#define H3U_BAND(PRO, BODY)                                                                                   \
+    for (int ti = blockIdx.x; ti < a.ntiles; ti += gridDim.x) {                                               \
+        const H3UTile t = h3u_tile(a, ti);                                                                    \
+        PRO;                                                                                                  \
+        h3_barrier();                                                                                         \
+        const int nsteps = t.nrows + Gm::LEAD;                                                                \
+        for (int s0 = 0; s0 < nsteps; s0 += Gm::UNROLL) {                                                     \
+            BODY(0); BODY(1); BODY(2); BODY(3); BODY(4); BODY(5);                                             \
+        }                                                                                                     \
+        h3_barrier();                                                                                         \
+    }
+
+__device__ __forceinline__ void h3u_role_f(const BwdBlockH3Args& a, const int lane, const int rw)
+{
+    using Gm = H3UGeom;
+    char* ta = h3u_lds + Gm::A_OFF;
+    char* tc = h3u_lds + Gm::C_OFF;
+    char* tt = h3u_lds + Gm::T_OFF;
+    char* td = h3u_lds + Gm::D_OFF;
+    char* ts = h3u_lds + Gm::S_OFF;
+    const int n = lane & 15, q = lane >> 4;
+    const int gc0 = 16 * Gm::G * rw + n;                        // F / D waves: lane's grid column in its wave's group 0
+    (void)ta; (void)tc; (void)tt; (void)td; (void)ts; (void)q; (void)gc0;
+        // ================= F: T = relu(conv_0 A) ; loads: A units 3 rw .. 3 rw + 2, dc unit rw =================
+        __builtin_amdgcn_s_setprio(1);
+        H3UConv<0, Gm::A_PLANE> R;
+        R.tin = ta; R.tdst = tt; R.tmask = nullptr;
+        R.init(a.wfwd0, a, lane, gc0);
+        H3ULoadUnit<false> ua[3];
+        H3ULoadUnit<true> uc;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ua[i].unit = 3 * rw + i;
+        uc.unit = rw;
+        const char* kq = h3u_lds + Gm::K_OFF + (lane & 3) * 16;
+#define H3U_PRO_F                                                                                             \
+        R.set_tile(t, a.W, gc0);                                                                              \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                       \
+            ua[i].ok = ua[i].row_ok(a, t, -3);                                                                \
+            ua[i].load(a, t, -3, lane);                                                                       \
+            ua[i].template commit_and_reload<Gm::A_PLANE>(a, t, ta, h3u_mod(-3, Gm::NRA) * Gm::PITCH, -2, lane, kq); \
+        }                                                                                                     \
+        uc.ok = false;                                                                                        \
+        uc.load(a, t, -3, lane);
+#define H3U_BODY_F(PH)                                                                                        \
+        do {                                                                                                  \
+            const int s = s0 + PH;                                                                            \
+            /* A row s-2 -> its slot, registers <- A row s-1 ; dc row s-3 -> its slot, registers <- row s-2 */ \
+            _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                     \
+                ua[i].template commit_and_reload<Gm::A_PLANE>(a, t, ta, h3u_mod(s - 2, Gm::NRA) * Gm::PITCH, s - 1, lane, kq); \
+            uc.template commit_and_reload<Gm::C_PLANE>(a, t, tc, h3u_mod(s - 3, Gm::NRC) * Gm::PITCH, s - 2, lane, kq); \
+            if (s < t.nrows + 6)                             /* A rows -3 .. nrows+2 */                       \
+                R.template step<PH>(h3u_mod(s - 3, Gm::NRA) * Gm::PITCH, (PH % Gm::NRT) * Gm::PITCH, 0, H3U_IN_IMAGE(s - 4)); \
+            h3_barrier();                                                                                     \
+        } while (0)
+        __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));
+        H3U_BAND(H3U_PRO_F, H3U_BODY_F)
+#undef H3U_PRO_F
+#undef H3U_BODY_F
+        h3_barrier();
+        h3_barrier();
+}
+
+__device__ __forceinline__ void h3u_role_d2(const BwdBlockH3Args& a, const int lane, const int rw)
+{
+    using Gm = H3UGeom;
+    char* ta = h3u_lds + Gm::A_OFF;
+    char* tc = h3u_lds + Gm::C_OFF;
+    char* tt = h3u_lds + Gm::T_OFF;
+    char* td = h3u_lds + Gm::D_OFF;
+    char* ts = h3u_lds + Gm::S_OFF;
+    const int n = lane & 15, q = lane >> 4;
+    const int gc0 = 16 * Gm::G * rw + n;                        // F / D waves: lane's grid column in its wave's group 0
+    (void)ta; (void)tc; (void)tt; (void)td; (void)ts; (void)q; (void)gc0;
+        // ================= D2: dT = dgrad_1(dc) * (T > 0) ; loads: dc units 3 + 2 rw, 4 + 2 rw =================
+        __builtin_amdgcn_s_setprio(1);
+        H3UConv<1, Gm::C_PLANE> R;
+        R.tin = tc; R.tdst = td; R.tmask = tt;
+        R.init(a.wdg1, a, lane, gc0);
+        H3ULoadUnit<true> uc[2];
+        uc[0].unit = 3 + 2 * rw;
+        uc[1].unit = 4 + 2 * rw;
+        const char* kq = h3u_lds + Gm::K_OFF + (lane & 3) * 16;
+#define H3U_PRO_D2                                                                                            \
+        R.set_tile(t, a.W, gc0);                                                                              \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                       \
+            uc[i].ok = false;                                                                                 \
+            uc[i].load(a, t, -3, lane);                                                                       \
+        }
+#define H3U_BODY_D2(PH)                                                                                       \
+        do {                                                                                                  \
+            const int s = s0 + PH;                                                                            \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                     \
+                uc[i].template commit_and_reload<Gm::C_PLANE>(a, t, tc, h3u_mod(s - 3, Gm::NRC) * Gm::PITCH, s - 2, lane, kq); \
+            /* dc row s-4 in; dT row s-5 completes (slot (s-5) mod 2 = (PH+1) mod 2), masked by T row s-5 (same parity) */ \
+            if ((s >= 2) && (s < t.nrows + 6))                                                                 \
+                R.template step<PH>(h3u_mod(s - 4, Gm::NRC) * Gm::PITCH, ((PH + 1) % Gm::NRD) * Gm::PITCH, ((PH + 1) % Gm::NRT) * Gm::PITCH, \
+                                    H3U_IN_IMAGE(s - 5));                                                     \
+            h3_barrier();                                                                                     \
+        } while (0)
+        __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));
+        H3U_BAND(H3U_PRO_D2, H3U_BODY_D2)
+#undef H3U_PRO_D2
+#undef H3U_BODY_D2
+        h3_barrier();
+        h3_barrier();
+}
+
+__device__ __forceinline__ void h3u_role_d1(const BwdBlockH3Args& a, const int lane, const int rw)
+{
+    using Gm = H3UGeom;
+    char* ta = h3u_lds + Gm::A_OFF;
+    char* tc = h3u_lds + Gm::C_OFF;
+    char* tt = h3u_lds + Gm::T_OFF;
+    char* td = h3u_lds + Gm::D_OFF;
+    char* ts = h3u_lds + Gm::S_OFF;
+    const int n = lane & 15, q = lane >> 4;
+    const int gc0 = 16 * Gm::G * rw + n;                        // F / D waves: lane's grid column in its wave's group 0
+    (void)ta; (void)tc; (void)tt; (void)td; (void)ts; (void)q; (void)gc0;
+        // ================= D1: raw dA' = dgrad_0(dT) -> staging ; stores: staged row s-9 =================
+        __builtin_amdgcn_s_setprio(1);
+        H3UConv<2, Gm::D_PLANE> R;
+        R.tin = td; R.tdst = ts; R.tmask = nullptr;
+        R.init(a.wdg0, a, lane, gc0);
+        // own elements e = 64 we + lane, we = rw, rw + 3, rw + 6 (< 8): pixel e >> 2 of the strip, quad e & 3
+        __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));
+#define H3U_PRO_D1 R.set_tile(t, a.W, gc0);
+#define H3U_BODY_D1(PH)                                                                                       \
+        do {                                                                                                  \
+            const int s = s0 + PH;                                                                            \
+            const int ko = s - 9;                                                                             \
+            if ((ko >= 0) && (ko < t.nrows)) {               /* staged row s-9 (slot PH mod 3) -> global memory, before the matrix work: nothing live across it */ \
+                char* dst = reinterpret_cast<char*>(a.out) + t.img + ((size_t)t.y(ko) * a.W + t.X0) * 64;     \
+                /* elements e = 64 we + lane, we = rw, rw + 3, rw + 6: pixel e >> 2 of the strip (we = 8: past the strip, masked), quad e & 3 */ \
+                _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                               \
+                    const int e = 64 * (rw + 3 * i) + lane;                                                   \
+                    const f32x4 sv = *reinterpret_cast<const f32x4*>(ts + (PH % Gm::NRS) * Gm::S_SLOT + (e & 3) * Gm::S_QUAD + (t.go + (e >> 2)) * 16); \
+                    if (t.X0 + (e >> 2) < t.X1) *reinterpret_cast<f32x4*>(dst + (size_t)e * 16) = sv;         \
+                }                                                                                             \
+                __builtin_amdgcn_sched_barrier(0);                                                            \
+            }                                                                                                 \
+            /* dT row s-6 in (slot (s-6) mod 2 = PH mod 2); raw row s-7 completes -> staging slot (s-7) mod 3 = (PH+2) mod 3 */ \
+            if ((s >= 5) && (s < t.nrows + 7))                                                                \
+                R.template step<PH>((PH % Gm::NRD) * Gm::PITCH, ((PH + 2) % Gm::NRS) * Gm::S_SLOT, 0, true);  \
+            h3_barrier();                                                                                     \
+        } while (0)
+        H3U_BAND(H3U_PRO_D1, H3U_BODY_D1)
+#undef H3U_PRO_D1
+#undef H3U_BODY_D1
+        h3_barrier();
+        h3_barrier();
+}
+
+template <bool BNC>
+__device__ __forceinline__ void h3u_role_w(const BwdBlockH3Args& a, const int lane, const int rw)
+{
+    using Gm = H3UGeom;
+    char* ta = h3u_lds + Gm::A_OFF;
+    char* tc = h3u_lds + Gm::C_OFF;
+    char* tt = h3u_lds + Gm::T_OFF;
+    char* td = h3u_lds + Gm::D_OFF;
+    char* ts = h3u_lds + Gm::S_OFF;
+    const int n = lane & 15, q = lane >> 4;
+    const int gc0 = 16 * Gm::G * rw + n;                        // F / D waves: lane's grid column in its wave's group 0
+    (void)ta; (void)tc; (void)tt; (void)td; (void)ts; (void)q; (void)gc0;
+        // ================= W: dW1 (T x dc), dW0 (A x dT) ; epilogue of staged row s-8 =================
+        // The 18 (convolution, vertical tap) rows of the two weight gradients are dealt to the three waves, six 16 x 16 accumulators
+        // (three horizontal taps each for two rows) per wave, 72 MFMAs per wave and step:
+        //   rw = 0: dW1 rows 0, 1 (share the T operands) ; rw = 1: dW1 row 2, dW0 row 0 ; rw = 2: dW0 rows 1, 2 (share the dT operands)
+        // (vertical taps in BAND order; a reversed band walks bottom-up and its rows are swapped when they are written out)
+        f32x4 acc[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // transposed-read offset of this lane inside a 32-pixel chunk: pixel 4 (lane >> 4) + ((lane & 15) >> 2), channels 4 j .. 4 j + 3
+        // with j = lane & 3: plane j >> 1, half-record j & 1 (the plane stride is a template argument of the reads)
+        const int tr_px = (4 * (lane >> 4) + ((lane & 15) >> 2)) * 16 + (lane & 1) * 8;
+        const int tr_hi = (lane & 3) >> 1;
+        // epilogue elements of this wave: e = 64 we + lane, we = rw, rw + 3, rw + 6: pixel e >> 2 of the strip (we = 8: past it), quad e & 3
+        f32x4 eg[3], eb[BNC ? 3 : 1];
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        auto ep_load = [&](const H3UTile& t, const int k) {
+            const int y = min(max(t.y(k), 0), a.H - 1);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int e = 64 * (rw + 3 * i) + lane;
+                const int col = min(t.X0 + (e >> 2), a.W - 1);
+                const size_t off = t.img + ((size_t)y * a.W + col) * 64 + (e & 3) * 16;
+                eg[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.g) + off);
+                if (BNC) eb[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.bnc) + off);
+            }
+        };
+#define H3U_PRO_W ep_load(t, 0);
+#define H3U_BODY_W(PH)                                                                                        \
+        do {                                                                                                  \
+            const int s = s0 + PH;                                                                            \
+            /* ---- epilogue of staged row s-8 (slot (s-8) mod 3 = (PH+1) mod 3): + g, sums, back to the ring ---- */ \
+            {                                                                                                 \
+                const int ke = s - 8;                                                                         \
+                const bool have = (ke >= 0) && (ke < t.nrows);                                                \
+                if (have) {                                                                                   \
+                    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                           \
+                        const int e = 64 * (rw + 3 * i) + lane;                                               \
+                        char* p = ts + ((PH + 1) % Gm::NRS) * Gm::S_SLOT + (e & 3) * Gm::S_QUAD + (t.go + (e >> 2)) * 16; \
+                        const bool in = t.X0 + (e >> 2) < t.X1;                                               \
+                        f32x4 v = *reinterpret_cast<const f32x4*>(p) + eg[i];                                 \
+                        _Pragma("unroll") for (int j = 0; j < 4; ++j) v[j] = in ? v[j] : 0.f;                 \
+                        s1 += v;                                                                              \
+                        if (BNC) s2 += v * eb[i];                                                             \
+                        if (in) *reinterpret_cast<f32x4*>(p) = v;                                             \
+                    }                                                                                         \
+                    __builtin_amdgcn_sched_barrier(0);                                                        \
+                    ep_load(t, ke + 1);                      /* registers <- row s-7 (consumed in the next step) */ \
+                    __builtin_amdgcn_sched_barrier(0);                                                        \
+                }                                                                                             \
+            }                                                                                                 \
+            {                                                                                                 \
+                const int r = s - 5;                         /* dW1: T row r (slot (PH+1) mod 2) with dc row r - dyb + 1 */ \
+                const int k0 = s - 6;                        /* dW0: dT row k0 (slot PH mod 2) with A row k0 + dyb - 1 */ \
+                const bool own0 = (k0 >= 0) && (k0 < t.nrows);                                                \
+                const int tbase = tr_hi * Gm::T_PLANE + ((PH + 1) % Gm::NRT) * Gm::PITCH;                     \
+                const int dbase = tr_hi * Gm::D_PLANE + (PH % Gm::NRD) * Gm::PITCH;                           \
+                _Pragma("nounroll") for (int ch = 0; ch < 4; ++ch) {                                          \
+                    const int col = (t.go + 32 * ch + 1) * 16 + tr_px;                                        \
+                    h8 ah[3], al[3];                                                                          \
+                    if (rw == 0) {                                                                            \
+                        /* (one load of the T operands for both rows; written as two plain blocks: with the shared load under its own   \
+                           condition hipcc kept the operands in scratch memory) */                                                     \
+                        const bool v0 = (r + 1 >= 0) && (r + 1 < t.nrows), v1 = (r >= 0) && (r < t.nrows);    \
+                        const int ga0 = tr_hi * Gm::C_PLANE + h3u_mod(r + 1, Gm::NRC) * Gm::PITCH + col;      \
+                        const int ga1 = tr_hi * Gm::C_PLANE + h3u_mod(r, Gm::NRC) * Gm::PITCH + col;          \
+                        if (v0 && v1) {                                                                       \
+                            h3u_load_x<Gm::T_PLANE>(tt, tbase + col, ah, al);                                 \
+                            h3u_mfma9(ah, al, h3u_tr<Gm::C_PLANE>(tc, ga0), h3u_tr<Gm::C_PLANE>(tc + 2 * Gm::C_PLANE, ga0), acc[0], acc[1], acc[2]); \
+                            h3u_mfma9(ah, al, h3u_tr<Gm::C_PLANE>(tc, ga1), h3u_tr<Gm::C_PLANE>(tc + 2 * Gm::C_PLANE, ga1), acc[3], acc[4], acc[5]); \
+                        } else if (v0) {                                                                      \
+                            h3u_load_x<Gm::T_PLANE>(tt, tbase + col, ah, al);                                 \
+                            h3u_mfma9(ah, al, h3u_tr<Gm::C_PLANE>(tc, ga0), h3u_tr<Gm::C_PLANE>(tc + 2 * Gm::C_PLANE, ga0), acc[0], acc[1], acc[2]); \
+                        } else if (v1) {                                                                      \
+                            h3u_load_x<Gm::T_PLANE>(tt, tbase + col, ah, al);                                 \
+                            h3u_mfma9(ah, al, h3u_tr<Gm::C_PLANE>(tc, ga1), h3u_tr<Gm::C_PLANE>(tc + 2 * Gm::C_PLANE, ga1), acc[3], acc[4], acc[5]); \
+                        }                                                                                     \
+                    } else if (rw == 1) {                                                                     \
+                        if ((r - 1 >= 0) && (r - 1 < t.nrows)) {                                              \
+                            const int ga = tr_hi * Gm::C_PLANE + h3u_mod(r - 1, Gm::NRC) * Gm::PITCH + col;   \
+                            h3u_load_x<Gm::T_PLANE>(tt, tbase + col, ah, al);                                 \
+                            h3u_mfma9(ah, al, h3u_tr<Gm::C_PLANE>(tc, ga), h3u_tr<Gm::C_PLANE>(tc + 2 * Gm::C_PLANE, ga), acc[0], acc[1], acc[2]); \
+                        }                                                                                     \
+                        if (own0) {                                                                           \
+                            h3u_load_x<Gm::A_PLANE>(ta, tr_hi * Gm::A_PLANE + h3u_mod(k0 - 1, Gm::NRA) * Gm::PITCH + col, ah, al); \
+                            h3u_mfma9(ah, al, h3u_tr<Gm::D_PLANE>(td, dbase + col), h3u_tr<Gm::D_PLANE>(td + 2 * Gm::D_PLANE, dbase + col), acc[3], acc[4], acc[5]); \
+                        }                                                                                     \
+                    } else if (own0) {                                                                        \
+                        const h8 bh = h3u_tr<Gm::D_PLANE>(td, dbase + col), bl = h3u_tr<Gm::D_PLANE>(td + 2 * Gm::D_PLANE, dbase + col); \
+                        h3u_load_x<Gm::A_PLANE>(ta, tr_hi * Gm::A_PLANE + h3u_mod(k0, Gm::NRA) * Gm::PITCH + col, ah, al); \
+                        h3u_mfma9(ah, al, bh, bl, acc[0], acc[1], acc[2]);                                    \
+                        h3u_load_x<Gm::A_PLANE>(ta, tr_hi * Gm::A_PLANE + h3u_mod(k0 + 1, Gm::NRA) * Gm::PITCH + col, ah, al); \
+                        h3u_mfma9(ah, al, bh, bl, acc[3], acc[4], acc[5]);                                    \
+                    }                                                                                         \
+                }                                                                                             \
+            }                                                                                                 \
+            h3_barrier();                                                                                     \
+        } while (0)
+        H3U_BAND(H3U_PRO_W, H3U_BODY_W)
+#undef H3U_PRO_W
+#undef H3U_BODY_W
+        // ---- per-workgroup partials.  Weight gradients: D[ci = 4 q + j][co = n] per lane and tap, every (convolution, tap) owned by
+        // exactly one wave: written straight from the registers (band order -> image order of the vertical taps) ----
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            // (convolution, band-order vertical tap) of accumulators 3 half .. 3 half + 2
+            const int conv1 = rw == 0 || (rw == 1 && half == 0);
+            const int dyb = rw == 0 ? half : (rw == 1 ? (half == 0 ? 2 : 0) : 1 + half);
+            const int dy = a.reverse ? 2 - dyb : dyb;
+            float* dst = (conv1 ? a.wpartial1 : a.wpartial0) + (size_t)blockIdx.x * 2304 + dy * 3 * 256;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const f32x4 v = bf_acc_ready(acc[3 * half + dx]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[dx * 256 + (4 * q + j) * 16 + n] = v[j];
+            }
+        }
+        // the two sums: over the 16 lanes that share a channel quad (lane & 3), then over the three waves
+#pragma unroll
+        for (int m = 4; m < 64; m <<= 1) {
+#pragma unroll
+            for (int cidx = 0; cidx < 4; ++cidx) {
+                s1[cidx] += __shfl_xor(s1[cidx], m);
+                s2[cidx] += __shfl_xor(s2[cidx], m);
+            }
+        }
+        float* sred = reinterpret_cast<float*>(h3u_lds);     // [3 waves][32]
+        if (lane < 4) {
+#pragma unroll
+            for (int cidx = 0; cidx < 4; ++cidx) {
+                sred[rw * 32 + lane * 4 + cidx] = s1[cidx];
+                sred[rw * 32 + 16 + lane * 4 + cidx] = s2[cidx];
+            }
+        }
+        h3_barrier();
+        if (BNC && rw == 0 && lane < 32) a.stats[(size_t)blockIdx.x * 32 + lane] = (sred[lane] + sred[32 + lane]) + sred[64 + lane];
+        h3_barrier();
+}
+
+#undef H3U_BAND
+#undef H3U_IN_IMAGE
+
+template <bool BNC>
+__global__ __launch_bounds__(H3UGeom::NT, 3) void bwd_block_h3t_kernel(BwdBlockH3Args a)
+{
+    using Gm = H3UGeom;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = wave / 3, rw = wave - role * 3;
+
+    // ring columns 0 and 145 are the zero padding at an image edge: cleared once, never written
+    for (int i = tid * 16; i < Gm::LDS_BYTES; i += Gm::NT * 16) *reinterpret_cast<f32x4*>(h3u_lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    if (tid < 48) reinterpret_cast<float*>(h3u_lds + Gm::K_OFF)[tid] = a.coef[tid];
+    __syncthreads();
+    if (role == 0) h3u_role_f(a, lane, rw);
+    else if (role == 1) h3u_role_d2(a, lane, rw);
+    else if (role == 2) h3u_role_d1(a, lane, rw);
+    else h3u_role_w<BNC>(a, lane, rw);
+}
+
+static int h3u_nstrips(const int W) { return (W + H3UGeom::SW - 1) / H3UGeom::SW; }
+
+// bands: every strip of every image is cut into ceil(H / rows) bands; one band of one strip = one unit of work of a workgroup
+static int h3u_rows_per_tile(const int B, const int H, const int nstrips, const int cus)
+{
+    int best = H;
+    long best_cost = -1;
+    for (int ty = 1; ty <= (H + 7) / 8; ++ty) {
+        const int rows = (H + ty - 1) / ty;
+        if ((H + rows - 1) / rows != ty) continue;
+        const long tiles = (long)B * ty * nstrips;
+        const long cost = ((tiles + cus - 1) / cus) * (rows + H3UGeom::LEAD + 2);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = rows;
+        }
+    }
+    return best;
+}
+
+bool bf_bwd_block_h3t_supports(int H, int W) { return W >= 1 && H >= 1; }
+
+// workgroups (= rows of wpartial0 / wpartial1 / stats) a launch uses
+int bf_bwd_block_h3t_grid(int B, int H, int W)
+{
+    const int ns = h3u_nstrips(W);
+    const int rows = h3u_rows_per_tile(B, H, ns, 256);
+    const long tiles = (long)B * ((H + rows - 1) / rows) * ns;
+    return (int)(tiles < 256 ? tiles : 256);
+}
+
+hipError_t bf_launch_bwd_block_h3t(const BwdBlockH3Args& args, hipStream_t s)
+{
+    using Gm = H3UGeom;
+    BwdBlockH3Args a = args;
+    if (!bf_bwd_block_h3t_supports(a.H, a.W) || !a.a || !a.g || !a.c || !a.coef || !a.wfwd0 || !a.wdg1 || !a.wdg0 || !a.out || !a.wpartial0 ||
+        !a.wpartial1)
+        return hipErrorInvalidValue;
+    if (a.out == a.a || a.out == a.g || a.out == a.c || (a.bnc && (!a.stats || a.out == a.bnc))) return hipErrorInvalidValue;
+    const int cus = 256;
+    a.nstrips = h3u_nstrips(a.W);
+    a.rows_per_tile = h3u_rows_per_tile(a.B, a.H, a.nstrips, cus);
+    a.tiles_y = (a.H + a.rows_per_tile - 1) / a.rows_per_tile;
+    a.ntiles = a.B * a.tiles_y * a.nstrips;
+    const int grid = a.ntiles < cus ? a.ntiles : cus;
+    void (*kernel)(BwdBlockH3Args) = a.bnc ? bwd_block_h3t_kernel<true> : bwd_block_h3t_kernel<false>;
+    const hipError_t e = bf_set_max_lds(reinterpret_cast<const void*>(kernel), Gm::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(Gm::NT), Gm::LDS_BYTES, s, a);
+    return hipGetLastError();
+}

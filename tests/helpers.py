@@ -159,6 +159,25 @@ def fwd_block_h3t_gpu(x, w0, w1, c=None, scale=None, shift=None, relu=1, reverse
     return (host(a_out) if a_out is not None else None, host(t_out) if t_out is not None else None, host(c_out), host(stats))
 
 
+def bwd_block_h3t_gpu(a, g, c, coef, w0, w1, bnc=None, relu=1, reverse=0):
+    """the backward of one [3,3] block in one kernel with T recomputed (train_bwd_h3t.hip): returns (out, dw1, dw0[, stats[32]])."""
+    L = N.lib()
+    B, H, W, _ = a.shape
+    ad, gd, cd, kd, w0d, w1d = dev(a), dev(g), dev(c), dev(coef), dev(w0), dev(w1)
+    bd = dev(bnc) if bnc is not None else None
+    out = torch.full((B, H, W, 16), float("nan"), dtype=torch.float32, device="cuda")
+    dw1 = torch.full((3, 3, 16, 16), float("nan"), dtype=torch.float32, device="cuda")
+    dw0 = torch.full((3, 3, 16, 16), float("nan"), dtype=torch.float32, device="cuda")
+    stats = torch.full((32,), float("nan"), dtype=torch.float32, device="cuda") if bnc is not None else None
+    scratch = torch.full((int(L.bf_debug_bwd_block_h3t_scratch_floats(B, H, W)),), float("nan"), dtype=torch.float32, device="cuda")
+    rc = L.bf_debug_bwd_block_h3t(N.ptr(ad), N.ptr(gd), N.ptr(cd), N.ptr(kd), N.ptr(w0d), N.ptr(w1d), N.ptr(bd), N.ptr(out), N.ptr(dw1),
+                                  N.ptr(dw0), N.ptr(stats), N.ptr(scratch), B, H, W, relu, reverse, N.stream_ptr(ad))
+    assert rc == 0, rc
+    if stats is not None:
+        return host(out), host(dw1), host(dw0), host(stats)
+    return host(out), host(dw1), host(dw0)
+
+
 def bwd3x3_h3_gpu(x, g, w, epi, c=None, coef=None, res=None, bnc=None, reverse=0, dbuf=0):
     """the fused backward kernel of one convolution: returns (dx, dw[, stats [grid, 32]])."""
     L = N.lib()

@@ -6,7 +6,7 @@ import torch
 
 from oracle import bfcnn_oracle as O
 from blind_image_denoising_amd import _native as N
-from helpers import (bwd3x3_h3_gpu, conv3x3_h3_pre_gpu, fwd_block_h3t_gpu, assert_close, conv3x3_gpu, conv3x3_h3_gpu, dev, fused_block_gpu, fused_block_h3_gpu,
+from helpers import (bwd3x3_h3_gpu, bwd_block_h3t_gpu, conv3x3_h3_pre_gpu, fwd_block_h3t_gpu, assert_close, conv3x3_gpu, conv3x3_h3_gpu, dev, fused_block_gpu, fused_block_h3_gpu,
                      fused_block2_h3_gpu, host, wgrad_gpu)
 
 pytestmark = pytest.mark.gpu
@@ -423,6 +423,75 @@ def test_fwd_block_h3t_exact_on_integers():
             c_ref = O.conv2d_same(t_ref, w1.astype(np.float64))
             assert np.array_equal(t, t_ref) and np.array_equal(cout, c_ref), (shape, reverse)
             assert_close(stats[:16], c_ref.sum(axis=(0, 1, 2)), rel=1e-6 * np.sqrt(c_ref.size), what="sum C")
+
+
+def _block_backward_oracle(a, g, c, coef, w0, w1, relu):
+    """fp64 restatement of what bwd_block_h3t_kernel computes, from the oracle's convolution primitives"""
+    a64, g64, c64, w0_64, w1_64 = (v.astype(np.float64) for v in (a, g, c, w0, w1))
+    k1, k2, k3 = coef[:16].astype(np.float64), coef[16:32].astype(np.float64), coef[32:].astype(np.float64)
+    dc = k1 * g64 + k2 * c64 + k3
+    pre = O.conv2d_same(a64, w0_64)
+    t = np.maximum(pre, 0) if relu else pre
+    dw1 = O.conv2d_same_grad_kernel(t, dc, 3, 3)
+    dt = O.conv2d_same_grad_input(dc, w1_64) * ((t > 0) if relu else 1.0)
+    dw0 = O.conv2d_same_grad_kernel(a64, dt, 3, 3)
+    out = O.conv2d_same_grad_input(dt, w0_64) + g64
+    return out, dw1, dw0, pre
+
+
+# one to three strips of 128 columns, grids clamped to the left edge, partial last strips, bands shorter than the pipeline,
+# more units than workgroups (70 x 40 x 256 = 280 strips x bands), both walking directions
+BWD_BLOCK_SHAPES = [(1, 1, 1), (2, 3, 7), (1, 12, 128), (3, 33, 47), (2, 40, 200), (1, 70, 256), (2, 24, 300), (70, 40, 256)]
+
+
+@pytest.mark.parametrize("shape", BWD_BLOCK_SHAPES)
+@pytest.mark.parametrize("bn_in_front", [1, 0])
+def test_bwd_block_h3t_matches_oracle(shape, bn_in_front):
+    """BatchNorm backward on load, T recomputed, both weight gradients, the masked data gradient of conv_1 kept in LDS, the data
+    gradient of conv_0 + the skip's gradient and the sums of the next BatchNorm backward: one kernel against the fp64 oracle
+    (tape.gradient of bfcnn/train_loop.py:273-294 through one block of bfcnn/backbone_blocks.py:174-246)."""
+    B, H, W = shape
+    a, g, c = _rand((B, H, W, 16), 80), _rand((B, H, W, 16), 81) * 0.1, _rand((B, H, W, 16), 82)
+    bnc = _rand((B, H, W, 16), 83) if bn_in_front else None
+    coef = np.concatenate([1 + 0.2 * _rand(16, 84), 0.1 * _rand(16, 85), 0.01 * _rand(16, 86)]).astype(np.float32)
+    w0, w1 = _rand((3, 3, 16, 16), 87) * 0.1, _rand((3, 3, 16, 16), 88) * 0.1
+    relu = 1 if (B + W) % 4 else 0
+    got = bwd_block_h3t_gpu(a, g, c, coef, w0, w1, bnc=bnc, relu=relu, reverse=(H + W) & 1)
+    out, dw1, dw0, pre = _block_backward_oracle(a, g, c, coef, w0, w1, relu)
+    # an element of conv_0's output within fp32 rounding of the ReLU's kink may take either side (its whole gradient flips): the
+    # comparison of the data gradient is skipped when the oracle itself names such an element (rare: |pre| < 1e-6)
+    near = np.abs(pre) < 1e-6 if relu else np.zeros_like(pre, bool)
+    assert near.mean() < 1e-4
+    n = np.sqrt(B * H * W)
+    if not near.any():
+        assert_close(got[0], out, what=f"dA' {shape}")
+    assert_close(got[1], dw1, rel=3e-6 * n, what=f"dW1 {shape}")
+    assert_close(got[2], dw0, rel=3e-6 * n, what=f"dW0 {shape}")
+    if bn_in_front:
+        o64 = got[0].astype(np.float64)
+        assert_close(got[3][:16], o64.sum(axis=(0, 1, 2)), rel=1e-5 * np.sqrt(o64.size), what="sum dA'")
+        assert_close(got[3][16:], (o64 * bnc).sum(axis=(0, 1, 2)), rel=1e-5 * np.sqrt(o64.size), what="sum dA' * c")
+    again = bwd_block_h3t_gpu(a, g, c, coef, w0, w1, bnc=bnc, relu=relu, reverse=(H + W) & 1)
+    assert all(np.array_equal(x, y) for x, y in zip(got, again))               # fixed-order reductions: bitwise reproducible
+
+
+def test_bwd_block_h3t_exact_on_integers():
+    """small integers through all five operators: bit-exact (pins the K packing of both kinds of operand, the ring bookkeeping, the
+    own-rows / own-columns rule of the weight gradients and the zero padding of every intermediate)"""
+    rng = np.random.default_rng(89)
+    coef = np.concatenate([np.ones(16), np.zeros(16), np.zeros(16)]).astype(np.float32)
+    for shape in [(2, 37, 256), (3, 19, 100), (1, 9, 300)]:
+        a = rng.integers(-2, 3, shape + (16,)).astype(np.float32)
+        g = rng.integers(-2, 3, shape + (16,)).astype(np.float32)
+        c = rng.integers(-2, 3, shape + (16,)).astype(np.float32)
+        w0 = rng.integers(-1, 2, (3, 3, 16, 16)).astype(np.float32)
+        w1 = rng.integers(-1, 2, (3, 3, 16, 16)).astype(np.float32)
+        for reverse in (0, 1):
+            got = bwd_block_h3t_gpu(a, g, c, coef, w0, w1, relu=1, reverse=reverse)
+            out, dw1, dw0, _ = _block_backward_oracle(a, g, c, coef, w0, w1, 1)
+            assert np.array_equal(got[0], out), (shape, reverse)
+            assert_close(got[1], dw1, rel=1e-6, what="dW1")
+            assert_close(got[2], dw0, rel=1e-6, what="dW0")
 
 
 @pytest.mark.parametrize("h3", [False, True], ids=["f32", "f16x3"])

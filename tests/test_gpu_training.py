@@ -91,7 +91,7 @@ def test_block_forward_kernel_matches_oracle_and_the_two_kernel_path(no_layers, 
     conv_1 + batch statistics in ONE row-streaming launch; bf_train_step picks it by itself from 4 096 image rows per step on):
     the same oracle bars as the two-kernel forward, the two paths agree far inside them, and the library says which one ran."""
     cfg, spec, ls, params, state, m, fns = _setup(no_layers)
-    clean, noisy = O.synthetic_batch(*shape, seed=29)
+    clean, noisy = O.synthetic_batch(*shape, seed=23)
     gt, x = clean.astype(np.float32), noisy.astype(np.float32)
     got = {}
     for v in (0, 2):
@@ -112,6 +112,39 @@ def test_block_forward_kernel_matches_oracle_and_the_two_kernel_path(no_layers, 
             assert np.abs(got[v][2] - r_state).max() < 1e-5
         compare_or_explain_by_ties(compare, lambda flips: O.train_step_single_gpu(spec, ls, params, state, gt64, x64, flips=flips),
                                    lambda: O.training_step_ties(spec, ls, params, state, gt64, x64))
+    assert abs(got[2][0] - got[0][0]) <= 1e-6 * abs(got[0][0])
+    _cmp_grads(spec, got[2][1], got[0][1], rel=6e-4)
+
+
+@pytest.mark.parametrize("no_layers,shape", [(1, (2, 16, 32)), (3, (3, 33, 47)), (2, (5, 70, 150)), (4, (2, 40, 256)), (2, (1, 24, 300))])
+@pytest.mark.parametrize("fwd_block", [0, 2])
+def test_block_backward_kernel_matches_oracle_and_the_per_convolution_path(no_layers, shape, fwd_block):
+    """train_bwd_block = 2 (bwd_block_h3t_kernel wherever it can run: BatchNorm backward on load, T RECOMPUTED from the block input,
+    both weight gradients, both data gradients, the skip's gradient and the next BatchNorm's sums in ONE row-streaming launch per
+    block; bf_train_step picks it by itself from 8 192 strip rows per step on), with the two-kernel forward (which still writes T) and
+    with the one-kernel forward (which then does not): the same oracle bars, and the library says which kernels ran."""
+    cfg, spec, ls, params, state, m, fns = _setup(no_layers)
+    clean, noisy = O.synthetic_batch(*shape, seed=23)
+    gt, x = clean.astype(np.float32), noisy.astype(np.float32)
+    got = {}
+    for v in (0, 2):
+        m.set_weights(params, state)
+        m.set_option("train_fwd_block", fwd_block if v else 0)
+        m.set_option("train_bwd_block", v)
+        total, ml, dl, pred, grads = fns.train_step_single_gpu(torch.from_numpy(gt), torch.from_numpy(x), (1.0,), 0.0, None)
+        got[v] = (total.item(), grads.cpu().numpy().astype(np.float64), m.state.cpu().numpy().copy())
+        kernels = N.lib().bf_get_train_kernels(m._h).decode()
+        assert ("bwd_block_h3t_kernel" in kernels) == (v == 2), kernels
+        assert ("fwd_block_h3t_kernel" in kernels) == (v == 2 and fwd_block == 2 and shape[2] <= 256), kernels
+    gt64, x64 = gt.astype(np.float64), x.astype(np.float64)
+
+    def compare(ref):
+        r_total, r_ml, r_dl, r_pred, r_grads, r_state = ref
+        assert abs(got[2][0] - r_total) <= 1e-5 * abs(r_total)
+        _cmp_grads(spec, got[2][1], r_grads)
+        assert np.abs(got[2][2] - r_state).max() < 1e-5
+    compare_or_explain_by_ties(compare, lambda flips: O.train_step_single_gpu(spec, ls, params, state, gt64, x64, flips=flips),
+                               lambda: O.training_step_ties(spec, ls, params, state, gt64, x64))
     assert abs(got[2][0] - got[0][0]) <= 1e-6 * abs(got[0][0])
     _cmp_grads(spec, got[2][1], got[0][1], rel=6e-4)
 
@@ -652,7 +685,7 @@ def test_random_training_configurations_and_options_match_oracle(seed):
     except NotImplementedError as e:
         pytest.skip(f"refused: {e}")
     opts = {"train_arith": int(rng.random() < 0.7), "train_fused_fwd": int(rng.integers(2)), "train_fused_bwd": int(rng.integers(2)), "train_fused_bwd2": int(rng.integers(2)),
-            "train_fwd_block": int(rng.integers(3)), "train_bwd_dbuf": int(rng.random() < 0.3), "train_zigzag": int(rng.integers(2))}
+            "train_fwd_block": int(rng.integers(3)), "train_bwd_block": int(rng.integers(3)), "train_bwd_dbuf": int(rng.random() < 0.3), "train_zigzag": int(rng.integers(2))}
     for k, v in opts.items():
         m.set_option(k, v)
     B, H, W = int(rng.integers(1, 4)), int(rng.integers(8, 60)), int(rng.integers(8, 70))
