@@ -288,6 +288,7 @@ struct BwdBlockH3Args {
     float* stats;          // [grid][32] (bnc != NULL)
     int B, H, W, reverse, act_relu;
     int nstrips, tiles_y, ntiles, rows_per_tile;       // filled in by the launcher
+    unsigned long long* dbg;   // diagnostic builds only (per-wave phase cycle sums), else NULL
 };
 bool       bf_bwd_block_h3t_supports(int H, int W);
 int        bf_bwd_block_h3t_grid(int B, int H, int W);

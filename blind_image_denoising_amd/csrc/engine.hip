@@ -1541,7 +1541,7 @@ extern "C" int bf_debug_bwd_block_h3t(const float* a_in, const float* g, const f
     fa.a = a_in; fa.g = g; fa.c = c; fa.coef = coef; fa.bnc = bnc; fa.out = out;
     fa.wfwd0 = scratch; fa.wdg0 = scratch + 2 * BF_H3_TRAIN_PACK_FLOATS; fa.wdg1 = scratch + 3 * BF_H3_TRAIN_PACK_FLOATS;
     fa.wpartial1 = wp1; fa.wpartial0 = wp0; fa.stats = st;
-    fa.B = B; fa.H = H; fa.W = W; fa.reverse = reverse; fa.act_relu = relu;
+    fa.B = B; fa.H = H; fa.W = W; fa.reverse = reverse; fa.act_relu = relu; fa.dbg = g_fused_dbg;
     if (bf_launch_bwd_block_h3t(fa, s) != hipSuccess) return BF_EHIP;
     if (bf_launch_reduce_partials(wp1, grid, 2304, dw1, 1.0f, s) != hipSuccess) return BF_EHIP;
     if (bf_launch_reduce_partials(wp0, grid, 2304, dw0, 1.0f, s) != hipSuccess) return BF_EHIP;

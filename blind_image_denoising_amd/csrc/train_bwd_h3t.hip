@@ -39,6 +39,40 @@
 
 typedef __fp16 hu_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
+// timing-only ablations (tools/ablate_unit.sh train_bwd_h3t H3U_ABLATE ...; results are WRONG when any is set):
+// 1 = no weight-gradient work (W waves: no transposed reads, no MFMAs), 2 = the loaders do not re-load (no global loads on F / D2),
+// 4 = no epilogue of the staged row (no g / C_{i-1} loads), 8 = no global stores, 16 = no convolution steps on F / D2 / D1,
+// 32 = the W waves' operand loads but none of their MFMAs, 64 = no LDS conversion in the loaders (loads only)
+// 128 = s_memtime stamps: per wave the cycles of [matrix work | memory duty | barrier] (BwdBlockH3Args::dbg, tools/exp/stamp_bwd_block.py)
+#ifndef H3U_ABLATE
+#define H3U_ABLATE 0
+#endif
+#if H3U_ABLATE & 128
+#define H3U_STAMP_DECL unsigned long long stamp_sum[4] = {0, 0, 0, 0}, stamp_prev, real0; \
+    asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(real0), "=s"(stamp_prev)::"memory");
+#define H3U_STAMP(k)                                                                                     \
+    do {                                                                                                 \
+        unsigned long long now_;                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");                      \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        stamp_sum[k] += now_ - stamp_prev;                                                               \
+        stamp_prev = now_;                                                                               \
+    } while (0)
+#define H3U_STAMP_OUT                                                                                    \
+    do {                                                                                                 \
+        unsigned long long real1;                                                                        \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real1)::"memory");                 \
+        stamp_sum[3] = real1 - real0;                                                                    \
+        if (a.dbg && lane == 0)                                                                          \
+            for (int k = 0; k < 4; ++k) a.dbg[((size_t)blockIdx.x * 12 + (threadIdx.x >> 6)) * 8 + k] = stamp_sum[k]; \
+    } while (0)
+#else
+#define H3U_STAMP_DECL
+#define H3U_STAMP(k) do { } while (0)
+#define H3U_STAMP_OUT do { } while (0)
+#endif
+
 // plane stride of a ring: the smallest size >= bytes that is 128 mod 256 (the transposed reads of a half-wave touch planes 0 and 1
 // of 8 neighbouring pixels: train_bwd_h3.hip)
 constexpr int h3u_plane(const int bytes) { return bytes / 256 * 256 + 128 >= bytes ? bytes / 256 * 256 + 128 : bytes / 256 * 256 + 384; }
@@ -335,17 +369,16 @@ struct H3ULoadUnit {
         return (y >= 0) && (y < a.H) && (k >= (DC ? -2 : -3)) && (k < t.nrows + (DC ? 2 : 3));
     }
     // registers -> ring row at byte offset slot_bytes of `ring` (plane stride PL); then the registers take band row kn
-    // kq: the BatchNorm-backward coefficients k1 | k2 | k3 of the lane's channel quad in LDS (three 16-byte reads per conversion: 12
-    // registers that would otherwise be live through the whole step)
+    // k1 | k2 | k3: the BatchNorm-backward coefficients of the lane's channel quad (read from LDS once per step, behind the matrix work:
+    // 12 registers that would otherwise be live through it)
     template <int PL>
     __device__ __forceinline__ void commit_and_reload(const BwdBlockH3Args& a, const H3UTile& t, char* ring, const int slot_bytes, const int kn,
-                                                      const int lane, const char* kq)
+                                                      const int lane, const f32x4 k1, const f32x4 k2, const f32x4 k3)
     {
         const int quad = lane & 3, gcol = 16 * unit + (lane >> 2);
         const bool in = ok && (t.G0 + gcol < a.W);
         f32x4 v;
         if (DC) {
-            const f32x4 k1 = *reinterpret_cast<const f32x4*>(kq), k2 = *reinterpret_cast<const f32x4*>(kq + 64), k3 = *reinterpret_cast<const f32x4*>(kq + 128);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = in ? fmaf(k1[i], x[i], fmaf(k2[i], c[i], k3[i])) : 0.f;
         } else {
@@ -354,8 +387,9 @@ struct H3ULoadUnit {
         }
         __builtin_amdgcn_sched_barrier(0);
         ok = row_ok(a, t, kn);
-        load(a, t, kn, lane);
+        if (!(H3U_ABLATE & 2)) load(a, t, kn, lane);
         __builtin_amdgcn_sched_barrier(0);
+        if (H3U_ABLATE & 64) return;
         h4 hi, lo;
         h3_split(v, hi, lo);
         char* p = ring + (quad >> 1) * PL + slot_bytes + (gcol + 1) * 16 + (quad & 1) * 8;
@@ -365,37 +399,49 @@ struct H3ULoadUnit {
 };
 
 // ---- weight gradients: operands through the transposing LDS read (train_bwd_h3.hip) ----------------------------------------------
-template <int PL>
-__device__ __forceinline__ h8 h3u_tr(const char* img, const int addr)
+
+extern __shared__ __attribute__((aligned(16))) char h3u_lds[];
+
+// operand through the transposing LDS read: lane's 8-byte chunk at LDS offset addr, and the one 16 pixels further
+__device__ __forceinline__ h8 h3u_tr(const int addr)
 {
     typedef unsigned u2 __attribute__((ext_vector_type(2)));
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
-    const hu_fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hu_fp16x4*)(img + addr));
-    const hu_fp16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hu_fp16x4*)(img + addr + 16 * 16));
+    const hu_fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hu_fp16x4*)(h3u_lds + addr));
+    const hu_fp16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hu_fp16x4*)(h3u_lds + addr + 16 * 16));
     const u2 ua = __builtin_bit_cast(u2, a), ub = __builtin_bit_cast(u2, b);
     return __builtin_bit_cast(h8, (u4){ua[0], ua[1], ub[0], ub[1]});
 }
 
-// the x-side operands of one vertical tap row of one chunk: x(row, shifted by dx - 1)^T for dx = 0, 1, 2, hi and lo.
-// xaddr: lane's byte offset of the chunk's first pixel (tap dx = 1) in the hi image of the ring
-template <int XPL>
-__device__ __forceinline__ void h3u_load_x(const char* xring, const int xaddr, h8 (&ah)[3], h8 (&al)[3])
-{
+// the operands of one (chunk, vertical tap row) of a weight gradient: x(row, shifted by dx - 1)^T for dx = 0, 1, 2 (hi, lo) and the
+// gradient row (hi, lo).  xa / ga: lane's LDS offsets of the chunk's first pixel in the hi images; xl / gl: offsets of the lo images
+struct H3UOps {
+    h8 ah[3], al[3], bh, bl;
+    __device__ __forceinline__ void load(const int xa, const int xl, const int ga, const int gl)
+    {
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-        ah[dx] = h3u_tr<XPL>(xring, xaddr + (dx - 1) * 16);
-        al[dx] = h3u_tr<XPL>(xring + 2 * XPL, xaddr + (dx - 1) * 16);
+        for (int dx = 0; dx < 3; ++dx) {
+            ah[dx] = h3u_tr(xa + (dx - 1) * 16);
+            al[dx] = h3u_tr(xa + xl + (dx - 1) * 16);
+        }
+        bh = h3u_tr(ga);
+        bl = h3u_tr(ga + gl);
     }
-}
-// acc[dx] += x(dx)^T . g, three split products each
-__device__ __forceinline__ void h3u_mfma9(const h8 (&ah)[3], const h8 (&al)[3], const h8 bh, const h8 bl, f32x4& a0, f32x4& a1, f32x4& a2)
-{
-    a0 = MFMA_H(ah[0], bh, a0); a1 = MFMA_H(ah[1], bh, a1); a2 = MFMA_H(ah[2], bh, a2);
-    a0 = MFMA_H(al[0], bh, a0); a1 = MFMA_H(al[1], bh, a1); a2 = MFMA_H(al[2], bh, a2);
-    a0 = MFMA_H(ah[0], bl, a0); a1 = MFMA_H(ah[1], bl, a1); a2 = MFMA_H(ah[2], bl, a2);
-}
-
-extern __shared__ __attribute__((aligned(16))) char h3u_lds[];
+    // acc[dx] += x(dx)^T . g, three split products each; !valid: a gradient row outside the band's own rows, multiplied as zeros
+    // (straight-line code: a branch around the MFMAs cost the register allocator 28 spilled registers)
+    __device__ __forceinline__ void mfma(f32x4& a0, f32x4& a1, f32x4& a2, const bool valid)
+    {
+        const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        const h8 bh = valid ? this->bh : zero, bl = valid ? this->bl : zero;
+        if (H3U_ABLATE & 32) {                               // keeps the operand reads live
+            a0[0] += (float)ah[0][0] + (float)ah[1][1] + (float)ah[2][2] + (float)al[0][3] + (float)al[1][4] + (float)al[2][5] + (float)bh[6] + (float)bl[7];
+            return;
+        }
+        a0 = MFMA_H(ah[0], bh, a0); a1 = MFMA_H(ah[1], bh, a1); a2 = MFMA_H(ah[2], bh, a2);
+        a0 = MFMA_H(al[0], bh, a0); a1 = MFMA_H(al[1], bh, a1); a2 = MFMA_H(al[2], bh, a2);
+        a0 = MFMA_H(ah[0], bl, a0); a1 = MFMA_H(ah[1], bl, a1); a2 = MFMA_H(ah[2], bl, a2);
+    }
+};
 
 // One function per role, all inlined into the kernel.  (Tried: not inlined, so that the register allocator treats the roles
 // separately.  The callee then sees its arguments as per-lane values -- uniform branches became exec-mask loops, the tensor pointers
@@ -425,6 +471,7 @@ __device__ __forceinline__ void h3u_role_f(const BwdBlockH3Args& a, const int la
     const int n = lane & 15, q = lane >> 4;
     const int gc0 = 16 * Gm::G * rw + n;                        // F / D waves: lane's grid column in its wave's group 0
     (void)ta; (void)tc; (void)tt; (void)td; (void)ts; (void)q; (void)gc0;
+    H3U_STAMP_DECL
         // ================= F: T = relu(conv_0 A) ; loads: A units 3 rw .. 3 rw + 2, dc unit rw =================
         __builtin_amdgcn_s_setprio(1);
         H3UConv<0, Gm::A_PLANE> R;
@@ -441,25 +488,33 @@ __device__ __forceinline__ void h3u_role_f(const BwdBlockH3Args& a, const int la
         _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                       \
             ua[i].ok = ua[i].row_ok(a, t, -3);                                                                \
             ua[i].load(a, t, -3, lane);                                                                       \
-            ua[i].template commit_and_reload<Gm::A_PLANE>(a, t, ta, h3u_mod(-3, Gm::NRA) * Gm::PITCH, -2, lane, kq); \
+            ua[i].template commit_and_reload<Gm::A_PLANE>(a, t, ta, h3u_mod(-3, Gm::NRA) * Gm::PITCH, -2, lane, f32x4{}, f32x4{}, f32x4{}); \
         }                                                                                                     \
         uc.ok = false;                                                                                        \
         uc.load(a, t, -3, lane);
 #define H3U_BODY_F(PH)                                                                                        \
         do {                                                                                                  \
             const int s = s0 + PH;                                                                            \
-            /* A row s-2 -> its slot, registers <- A row s-1 ; dc row s-3 -> its slot, registers <- row s-2 */ \
-            _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                     \
-                ua[i].template commit_and_reload<Gm::A_PLANE>(a, t, ta, h3u_mod(s - 2, Gm::NRA) * Gm::PITCH, s - 1, lane, kq); \
-            uc.template commit_and_reload<Gm::C_PLANE>(a, t, tc, h3u_mod(s - 3, Gm::NRC) * Gm::PITCH, s - 2, lane, kq); \
-            if (s < t.nrows + 6)                             /* A rows -3 .. nrows+2 */                       \
+            if (!(H3U_ABLATE & 16) && s < t.nrows + 6)       /* A rows -3 .. nrows+2 */                       \
                 R.template step<PH>(h3u_mod(s - 3, Gm::NRA) * Gm::PITCH, (PH % Gm::NRT) * Gm::PITCH, 0, H3U_IN_IMAGE(s - 4)); \
+            H3U_STAMP(0);                                                                                     \
+            /* BEHIND the matrix work (the loads then have the whole step to land before anything waits for them): A row s-2 -> its     \
+               slot, registers <- A row s-1 ; dc row s-3 -> its slot, registers <- row s-2 */                  \
+            {                                                                                                 \
+                const f32x4 k1 = *reinterpret_cast<const f32x4*>(kq), k2 = *reinterpret_cast<const f32x4*>(kq + 64), k3 = *reinterpret_cast<const f32x4*>(kq + 128); \
+                _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                 \
+                    ua[i].template commit_and_reload<Gm::A_PLANE>(a, t, ta, h3u_mod(s - 2, Gm::NRA) * Gm::PITCH, s - 1, lane, k1, k2, k3); \
+                uc.template commit_and_reload<Gm::C_PLANE>(a, t, tc, h3u_mod(s - 3, Gm::NRC) * Gm::PITCH, s - 2, lane, k1, k2, k3); \
+            }                                                                                                 \
+            H3U_STAMP(1);                                                                                     \
             h3_barrier();                                                                                     \
+            H3U_STAMP(2);                                                                                     \
         } while (0)
         __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));
         H3U_BAND(H3U_PRO_F, H3U_BODY_F)
 #undef H3U_PRO_F
 #undef H3U_BODY_F
+        H3U_STAMP_OUT;
         h3_barrier();
         h3_barrier();
 }
@@ -475,6 +530,7 @@ __device__ __forceinline__ void h3u_role_d2(const BwdBlockH3Args& a, const int l
     const int n = lane & 15, q = lane >> 4;
     const int gc0 = 16 * Gm::G * rw + n;                        // F / D waves: lane's grid column in its wave's group 0
     (void)ta; (void)tc; (void)tt; (void)td; (void)ts; (void)q; (void)gc0;
+    H3U_STAMP_DECL
         // ================= D2: dT = dgrad_1(dc) * (T > 0) ; loads: dc units 3 + 2 rw, 4 + 2 rw =================
         __builtin_amdgcn_s_setprio(1);
         H3UConv<1, Gm::C_PLANE> R;
@@ -493,22 +549,30 @@ __device__ __forceinline__ void h3u_role_d2(const BwdBlockH3Args& a, const int l
 #define H3U_BODY_D2(PH)                                                                                       \
         do {                                                                                                  \
             const int s = s0 + PH;                                                                            \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                     \
-                uc[i].template commit_and_reload<Gm::C_PLANE>(a, t, tc, h3u_mod(s - 3, Gm::NRC) * Gm::PITCH, s - 2, lane, kq); \
             /* dc row s-4 in; dT row s-5 completes (slot (s-5) mod 2 = (PH+1) mod 2), masked by T row s-5 (same parity) */ \
-            if ((s >= 2) && (s < t.nrows + 6))                                                                 \
+            if (!(H3U_ABLATE & 16) && (s >= 2) && (s < t.nrows + 6))                                          \
                 R.template step<PH>(h3u_mod(s - 4, Gm::NRC) * Gm::PITCH, ((PH + 1) % Gm::NRD) * Gm::PITCH, ((PH + 1) % Gm::NRT) * Gm::PITCH, \
                                     H3U_IN_IMAGE(s - 5));                                                     \
+            H3U_STAMP(0);                                                                                     \
+            {                                                /* behind the matrix work: dc row s-3 -> its slot, registers <- row s-2 */ \
+                const f32x4 k1 = *reinterpret_cast<const f32x4*>(kq), k2 = *reinterpret_cast<const f32x4*>(kq + 64), k3 = *reinterpret_cast<const f32x4*>(kq + 128); \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
+                    uc[i].template commit_and_reload<Gm::C_PLANE>(a, t, tc, h3u_mod(s - 3, Gm::NRC) * Gm::PITCH, s - 2, lane, k1, k2, k3); \
+            }                                                                                                 \
+            H3U_STAMP(1);                                                                                     \
             h3_barrier();                                                                                     \
+            H3U_STAMP(2);                                                                                     \
         } while (0)
         __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));
         H3U_BAND(H3U_PRO_D2, H3U_BODY_D2)
 #undef H3U_PRO_D2
 #undef H3U_BODY_D2
+        H3U_STAMP_OUT;
         h3_barrier();
         h3_barrier();
 }
 
+template <bool BNC>
 __device__ __forceinline__ void h3u_role_d1(const BwdBlockH3Args& a, const int lane, const int rw)
 {
     using Gm = H3UGeom;
@@ -520,65 +584,14 @@ __device__ __forceinline__ void h3u_role_d1(const BwdBlockH3Args& a, const int l
     const int n = lane & 15, q = lane >> 4;
     const int gc0 = 16 * Gm::G * rw + n;                        // F / D waves: lane's grid column in its wave's group 0
     (void)ta; (void)tc; (void)tt; (void)td; (void)ts; (void)q; (void)gc0;
-        // ================= D1: raw dA' = dgrad_0(dT) -> staging ; stores: staged row s-9 =================
+    H3U_STAMP_DECL
+        // ================= D1: raw dA' = dgrad_0(dT) -> staging ; epilogue of staged row s-8 (loads: g, C_{i-1}) =================
         __builtin_amdgcn_s_setprio(1);
         H3UConv<2, Gm::D_PLANE> R;
         R.tin = td; R.tdst = ts; R.tmask = nullptr;
         R.init(a.wdg0, a, lane, gc0);
-        // own elements e = 64 we + lane, we = rw, rw + 3, rw + 6 (< 8): pixel e >> 2 of the strip, quad e & 3
-        __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));
-#define H3U_PRO_D1 R.set_tile(t, a.W, gc0);
-#define H3U_BODY_D1(PH)                                                                                       \
-        do {                                                                                                  \
-            const int s = s0 + PH;                                                                            \
-            const int ko = s - 9;                                                                             \
-            if ((ko >= 0) && (ko < t.nrows)) {               /* staged row s-9 (slot PH mod 3) -> global memory, before the matrix work: nothing live across it */ \
-                char* dst = reinterpret_cast<char*>(a.out) + t.img + ((size_t)t.y(ko) * a.W + t.X0) * 64;     \
-                /* elements e = 64 we + lane, we = rw, rw + 3, rw + 6: pixel e >> 2 of the strip (we = 8: past the strip, masked), quad e & 3 */ \
-                _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                               \
-                    const int e = 64 * (rw + 3 * i) + lane;                                                   \
-                    const f32x4 sv = *reinterpret_cast<const f32x4*>(ts + (PH % Gm::NRS) * Gm::S_SLOT + (e & 3) * Gm::S_QUAD + (t.go + (e >> 2)) * 16); \
-                    if (t.X0 + (e >> 2) < t.X1) *reinterpret_cast<f32x4*>(dst + (size_t)e * 16) = sv;         \
-                }                                                                                             \
-                __builtin_amdgcn_sched_barrier(0);                                                            \
-            }                                                                                                 \
-            /* dT row s-6 in (slot (s-6) mod 2 = PH mod 2); raw row s-7 completes -> staging slot (s-7) mod 3 = (PH+2) mod 3 */ \
-            if ((s >= 5) && (s < t.nrows + 7))                                                                \
-                R.template step<PH>((PH % Gm::NRD) * Gm::PITCH, ((PH + 2) % Gm::NRS) * Gm::S_SLOT, 0, true);  \
-            h3_barrier();                                                                                     \
-        } while (0)
-        H3U_BAND(H3U_PRO_D1, H3U_BODY_D1)
-#undef H3U_PRO_D1
-#undef H3U_BODY_D1
-        h3_barrier();
-        h3_barrier();
-}
-
-template <bool BNC>
-__device__ __forceinline__ void h3u_role_w(const BwdBlockH3Args& a, const int lane, const int rw)
-{
-    using Gm = H3UGeom;
-    char* ta = h3u_lds + Gm::A_OFF;
-    char* tc = h3u_lds + Gm::C_OFF;
-    char* tt = h3u_lds + Gm::T_OFF;
-    char* td = h3u_lds + Gm::D_OFF;
-    char* ts = h3u_lds + Gm::S_OFF;
-    const int n = lane & 15, q = lane >> 4;
-    const int gc0 = 16 * Gm::G * rw + n;                        // F / D waves: lane's grid column in its wave's group 0
-    (void)ta; (void)tc; (void)tt; (void)td; (void)ts; (void)q; (void)gc0;
-        // ================= W: dW1 (T x dc), dW0 (A x dT) ; epilogue of staged row s-8 =================
-        // The 18 (convolution, vertical tap) rows of the two weight gradients are dealt to the three waves, six 16 x 16 accumulators
-        // (three horizontal taps each for two rows) per wave, 72 MFMAs per wave and step:
-        //   rw = 0: dW1 rows 0, 1 (share the T operands) ; rw = 1: dW1 row 2, dW0 row 0 ; rw = 2: dW0 rows 1, 2 (share the dT operands)
-        // (vertical taps in BAND order; a reversed band walks bottom-up and its rows are swapped when they are written out)
-        f32x4 acc[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // transposed-read offset of this lane inside a 32-pixel chunk: pixel 4 (lane >> 4) + ((lane & 15) >> 2), channels 4 j .. 4 j + 3
-        // with j = lane & 3: plane j >> 1, half-record j & 1 (the plane stride is a template argument of the reads)
-        const int tr_px = (4 * (lane >> 4) + ((lane & 15) >> 2)) * 16 + (lane & 1) * 8;
-        const int tr_hi = (lane & 3) >> 1;
-        // epilogue elements of this wave: e = 64 we + lane, we = rw, rw + 3, rw + 6: pixel e >> 2 of the strip (we = 8: past it), quad e & 3
+        // epilogue elements of this wave: e = 64 we + lane, we = rw, rw + 3, rw + 6: pixel e >> 2 of the strip (we = 8: past it), quad e & 3;
+        // g and C_{i-1} of a row are requested one step before the row is staged-complete (the in-place prefetch of the loaders)
         f32x4 eg[3], eb[BNC ? 3 : 1];
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
         auto ep_load = [&](const H3UTile& t, const int k) {
@@ -592,14 +605,19 @@ __device__ __forceinline__ void h3u_role_w(const BwdBlockH3Args& a, const int la
                 if (BNC) eb[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.bnc) + off);
             }
         };
-#define H3U_PRO_W ep_load(t, 0);
-#define H3U_BODY_W(PH)                                                                                        \
+        __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));
+#define H3U_PRO_D1 R.set_tile(t, a.W, gc0); if (!(H3U_ABLATE & 4)) ep_load(t, 0);
+#define H3U_BODY_D1(PH)                                                                                       \
         do {                                                                                                  \
             const int s = s0 + PH;                                                                            \
-            /* ---- epilogue of staged row s-8 (slot (s-8) mod 3 = (PH+1) mod 3): + g, sums, back to the ring ---- */ \
+            /* dT row s-6 in (slot (s-6) mod 2 = PH mod 2); raw row s-7 completes -> staging slot (s-7) mod 3 = (PH+2) mod 3 */ \
+            if (!(H3U_ABLATE & 16) && (s >= 5) && (s < t.nrows + 7))                                          \
+                R.template step<PH>((PH % Gm::NRD) * Gm::PITCH, ((PH + 2) % Gm::NRS) * Gm::S_SLOT, 0, true);  \
+            H3U_STAMP(0);                                                                                     \
+            /* ---- BEHIND the matrix work: epilogue of staged row s-8 (slot (s-8) mod 3 = (PH+1) mod 3): + g, sums, back to the ring ---- */ \
             {                                                                                                 \
                 const int ke = s - 8;                                                                         \
-                const bool have = (ke >= 0) && (ke < t.nrows);                                                \
+                const bool have = !(H3U_ABLATE & 4) && (ke >= 0) && (ke < t.nrows);                           \
                 if (have) {                                                                                   \
                     _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                           \
                         const int e = 64 * (rw + 3 * i) + lane;                                               \
@@ -616,56 +634,138 @@ __device__ __forceinline__ void h3u_role_w(const BwdBlockH3Args& a, const int la
                     __builtin_amdgcn_sched_barrier(0);                                                        \
                 }                                                                                             \
             }                                                                                                 \
-            {                                                                                                 \
-                const int r = s - 5;                         /* dW1: T row r (slot (PH+1) mod 2) with dc row r - dyb + 1 */ \
-                const int k0 = s - 6;                        /* dW0: dT row k0 (slot PH mod 2) with A row k0 + dyb - 1 */ \
-                const bool own0 = (k0 >= 0) && (k0 < t.nrows);                                                \
-                const int tbase = tr_hi * Gm::T_PLANE + ((PH + 1) % Gm::NRT) * Gm::PITCH;                     \
-                const int dbase = tr_hi * Gm::D_PLANE + (PH % Gm::NRD) * Gm::PITCH;                           \
-                _Pragma("nounroll") for (int ch = 0; ch < 4; ++ch) {                                          \
-                    const int col = (t.go + 32 * ch + 1) * 16 + tr_px;                                        \
-                    h8 ah[3], al[3];                                                                          \
-                    if (rw == 0) {                                                                            \
-                        /* (one load of the T operands for both rows; written as two plain blocks: with the shared load under its own   \
-                           condition hipcc kept the operands in scratch memory) */                                                     \
-                        const bool v0 = (r + 1 >= 0) && (r + 1 < t.nrows), v1 = (r >= 0) && (r < t.nrows);    \
-                        const int ga0 = tr_hi * Gm::C_PLANE + h3u_mod(r + 1, Gm::NRC) * Gm::PITCH + col;      \
-                        const int ga1 = tr_hi * Gm::C_PLANE + h3u_mod(r, Gm::NRC) * Gm::PITCH + col;          \
-                        if (v0 && v1) {                                                                       \
-                            h3u_load_x<Gm::T_PLANE>(tt, tbase + col, ah, al);                                 \
-                            h3u_mfma9(ah, al, h3u_tr<Gm::C_PLANE>(tc, ga0), h3u_tr<Gm::C_PLANE>(tc + 2 * Gm::C_PLANE, ga0), acc[0], acc[1], acc[2]); \
-                            h3u_mfma9(ah, al, h3u_tr<Gm::C_PLANE>(tc, ga1), h3u_tr<Gm::C_PLANE>(tc + 2 * Gm::C_PLANE, ga1), acc[3], acc[4], acc[5]); \
-                        } else if (v0) {                                                                      \
-                            h3u_load_x<Gm::T_PLANE>(tt, tbase + col, ah, al);                                 \
-                            h3u_mfma9(ah, al, h3u_tr<Gm::C_PLANE>(tc, ga0), h3u_tr<Gm::C_PLANE>(tc + 2 * Gm::C_PLANE, ga0), acc[0], acc[1], acc[2]); \
-                        } else if (v1) {                                                                      \
-                            h3u_load_x<Gm::T_PLANE>(tt, tbase + col, ah, al);                                 \
-                            h3u_mfma9(ah, al, h3u_tr<Gm::C_PLANE>(tc, ga1), h3u_tr<Gm::C_PLANE>(tc + 2 * Gm::C_PLANE, ga1), acc[3], acc[4], acc[5]); \
-                        }                                                                                     \
-                    } else if (rw == 1) {                                                                     \
-                        if ((r - 1 >= 0) && (r - 1 < t.nrows)) {                                              \
-                            const int ga = tr_hi * Gm::C_PLANE + h3u_mod(r - 1, Gm::NRC) * Gm::PITCH + col;   \
-                            h3u_load_x<Gm::T_PLANE>(tt, tbase + col, ah, al);                                 \
-                            h3u_mfma9(ah, al, h3u_tr<Gm::C_PLANE>(tc, ga), h3u_tr<Gm::C_PLANE>(tc + 2 * Gm::C_PLANE, ga), acc[0], acc[1], acc[2]); \
-                        }                                                                                     \
-                        if (own0) {                                                                           \
-                            h3u_load_x<Gm::A_PLANE>(ta, tr_hi * Gm::A_PLANE + h3u_mod(k0 - 1, Gm::NRA) * Gm::PITCH + col, ah, al); \
-                            h3u_mfma9(ah, al, h3u_tr<Gm::D_PLANE>(td, dbase + col), h3u_tr<Gm::D_PLANE>(td + 2 * Gm::D_PLANE, dbase + col), acc[3], acc[4], acc[5]); \
-                        }                                                                                     \
-                    } else if (own0) {                                                                        \
-                        const h8 bh = h3u_tr<Gm::D_PLANE>(td, dbase + col), bl = h3u_tr<Gm::D_PLANE>(td + 2 * Gm::D_PLANE, dbase + col); \
-                        h3u_load_x<Gm::A_PLANE>(ta, tr_hi * Gm::A_PLANE + h3u_mod(k0, Gm::NRA) * Gm::PITCH + col, ah, al); \
-                        h3u_mfma9(ah, al, bh, bl, acc[0], acc[1], acc[2]);                                    \
-                        h3u_load_x<Gm::A_PLANE>(ta, tr_hi * Gm::A_PLANE + h3u_mod(k0 + 1, Gm::NRA) * Gm::PITCH + col, ah, al); \
-                        h3u_mfma9(ah, al, bh, bl, acc[3], acc[4], acc[5]);                                    \
+            H3U_STAMP(1);                                                                                     \
+            h3_barrier();                                                                                     \
+            H3U_STAMP(2);                                                                                     \
+        } while (0)
+        H3U_BAND(H3U_PRO_D1, H3U_BODY_D1)
+#undef H3U_PRO_D1
+#undef H3U_BODY_D1
+        H3U_STAMP_OUT;
+        // the two sums: over the 16 lanes that share a channel quad (lane & 3), then over the three waves (fixed order)
+#pragma unroll
+        for (int m = 4; m < 64; m <<= 1) {
+#pragma unroll
+            for (int cidx = 0; cidx < 4; ++cidx) {
+                s1[cidx] += __shfl_xor(s1[cidx], m);
+                s2[cidx] += __shfl_xor(s2[cidx], m);
+            }
+        }
+        float* sred = reinterpret_cast<float*>(h3u_lds);     // [3 waves][32]; the rings are free after the last band
+        if (lane < 4) {
+#pragma unroll
+            for (int cidx = 0; cidx < 4; ++cidx) {
+                sred[rw * 32 + lane * 4 + cidx] = s1[cidx];
+                sred[rw * 32 + 16 + lane * 4 + cidx] = s2[cidx];
+            }
+        }
+        h3_barrier();
+        if (BNC && rw == 0 && lane < 32) a.stats[(size_t)blockIdx.x * 32 + lane] = (sred[lane] + sred[32 + lane]) + sred[64 + lane];
+        h3_barrier();
+}
+
+template <bool BNC>
+__device__ __forceinline__ void h3u_role_w(const BwdBlockH3Args& a, const int lane, const int rw)
+{
+    using Gm = H3UGeom;
+    char* ta = h3u_lds + Gm::A_OFF;
+    char* tc = h3u_lds + Gm::C_OFF;
+    char* tt = h3u_lds + Gm::T_OFF;
+    char* td = h3u_lds + Gm::D_OFF;
+    char* ts = h3u_lds + Gm::S_OFF;
+    const int n = lane & 15, q = lane >> 4;
+    const int gc0 = 16 * Gm::G * rw + n;                        // F / D waves: lane's grid column in its wave's group 0
+    (void)ta; (void)tc; (void)tt; (void)td; (void)ts; (void)q; (void)gc0;
+    H3U_STAMP_DECL
+        // ================= W: dW1 (T x dc), dW0 (A x dT) ; epilogue of staged row s-8 =================
+        // The 18 (convolution, vertical tap) rows of the two weight gradients are dealt to the three waves, six 16 x 16 accumulators
+        // (three horizontal taps each for two rows) per wave, 72 MFMAs per wave and step:
+        //   rw = 0: dW1 rows 0, 1 (share the T operands) ; rw = 1: dW1 row 2, dW0 row 0 ; rw = 2: dW0 rows 1, 2 (share the dT operands)
+        // (vertical taps in BAND order; a reversed band walks bottom-up and its rows are swapped when they are written out)
+        f32x4 acc[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // transposed-read offset of this lane inside a 32-pixel chunk: pixel 4 (lane >> 4) + ((lane & 15) >> 2), channels 4 j .. 4 j + 3
+        // with j = lane & 3: plane j >> 1, half-record j & 1 (the plane stride is a template argument of the reads)
+        const int tr_px = (4 * (lane >> 4) + ((lane & 15) >> 2)) * 16 + (lane & 1) * 8;
+        const int tr_hi = (lane & 3) >> 1;
+// request the operands of a later (chunk, job) pair into NXT, then the nine MFMAs of the pair in CUR
+#define H3U_WPAIR(NXT, XB, XL, GB, GL, COLOFF, CUR, VAL, A0)                                                  \
+        do {                                                                                                  \
+            NXT.load(XB + c0 + COLOFF, XL, GB + c0 + COLOFF, GL);                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+            CUR.mfma(acc[A0], acc[A0 + 1], acc[A0 + 2], VAL);                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+        } while (0)
+#define H3U_PRO_W
+#define H3U_BODY_W(PH)                                                                                        \
+        do {                                                                                                  \
+            const int s = s0 + PH;                                                                            \
+            {                                                /* staged row s-9 (slot PH mod 3) -> global memory, in front of the matrix work: nothing live across it */ \
+                const int ko = s - 9;                                                                         \
+                if (!(H3U_ABLATE & 8) && (ko >= 0) && (ko < t.nrows)) {                                       \
+                    char* dst = reinterpret_cast<char*>(a.out) + t.img + ((size_t)t.y(ko) * a.W + t.X0) * 64; \
+                    /* elements e = 64 we + lane, we = rw, rw + 3, rw + 6: pixel e >> 2 of the strip (we = 8: past the strip, masked), quad e & 3 */ \
+                    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                           \
+                        const int e = 64 * (rw + 3 * i) + lane;                                               \
+                        const f32x4 sv = *reinterpret_cast<const f32x4*>(ts + (PH % Gm::NRS) * Gm::S_SLOT + (e & 3) * Gm::S_QUAD + (t.go + (e >> 2)) * 16); \
+                        if (t.X0 + (e >> 2) < t.X1) *reinterpret_cast<f32x4*>(dst + (size_t)e * 16) = sv;     \
                     }                                                                                         \
+                    __builtin_amdgcn_sched_barrier(0);                                                        \
                 }                                                                                             \
             }                                                                                                 \
+            H3U_STAMP(1);                                                                                     \
+            {                                                                                                 \
+                /* the wave's two (convolution, vertical tap) rows of this step as jobs: x-side operands at LDS offset xb (lo image at    \
+                   + xl), gradient-side operands at gb (+ gl), valid: own rows only.  dW1: T row r = s-5 (slot (PH+1) mod 2) with dc      \
+                   row r - dyb + 1 ; dW0: dT row k0 = s-6 (slot PH mod 2) with A row k0 + dyb - 1 */            \
+                const int r = s - 5, k0 = s - 6;                                                              \
+                const bool own0 = (k0 >= 0) && (k0 < t.nrows);                                                \
+                const int tb = Gm::T_OFF + tr_hi * Gm::T_PLANE + ((PH + 1) % Gm::NRT) * Gm::PITCH;            \
+                const int db = Gm::D_OFF + tr_hi * Gm::D_PLANE + (PH % Gm::NRD) * Gm::PITCH;                  \
+                int xb0, xl0, gb0, gl0, xb1, xl1, gb1, gl1;                                                   \
+                bool val0, val1;                                                                              \
+                if (rw == 0) {                                                                                \
+                    xb0 = xb1 = tb; xl0 = xl1 = 2 * Gm::T_PLANE; gl0 = gl1 = 2 * Gm::C_PLANE;                 \
+                    gb0 = Gm::C_OFF + tr_hi * Gm::C_PLANE + h3u_mod(r + 1, Gm::NRC) * Gm::PITCH; val0 = (r + 1 >= 0) && (r + 1 < t.nrows); \
+                    gb1 = Gm::C_OFF + tr_hi * Gm::C_PLANE + h3u_mod(r, Gm::NRC) * Gm::PITCH; val1 = (r >= 0) && (r < t.nrows); \
+                } else if (rw == 1) {                                                                         \
+                    xb0 = tb; xl0 = 2 * Gm::T_PLANE; gl0 = 2 * Gm::C_PLANE;                                   \
+                    gb0 = Gm::C_OFF + tr_hi * Gm::C_PLANE + h3u_mod(r - 1, Gm::NRC) * Gm::PITCH; val0 = (r - 1 >= 0) && (r - 1 < t.nrows); \
+                    xb1 = Gm::A_OFF + tr_hi * Gm::A_PLANE + h3u_mod(k0 - 1, Gm::NRA) * Gm::PITCH; xl1 = 2 * Gm::A_PLANE; \
+                    gb1 = db; gl1 = 2 * Gm::D_PLANE; val1 = own0;                                             \
+                } else {                                                                                      \
+                    xb0 = Gm::A_OFF + tr_hi * Gm::A_PLANE + h3u_mod(k0, Gm::NRA) * Gm::PITCH;                 \
+                    xb1 = Gm::A_OFF + tr_hi * Gm::A_PLANE + h3u_mod(k0 + 1, Gm::NRA) * Gm::PITCH;             \
+                    xl0 = xl1 = 2 * Gm::A_PLANE; gb0 = gb1 = db; gl0 = gl1 = 2 * Gm::D_PLANE; val0 = val1 = own0; \
+                }                                                                                             \
+                if (!(H3U_ABLATE & 1) && (val0 || val1)) {                                                    \
+                    /* software pipeline over the 8 (chunk, job) pairs, THREE operand sets: the operands of pair i + 2 are requested       \
+                       before the MFMAs of pair i (an in-order wave otherwise pays one LDS round trip -- ~500 cycles with twelve waves on \
+                       the LDS -- per nine MFMAs: stamps, 3 900 cycles per step on these waves where the others need 2 300-3 100) */        \
+                    const int c0 = (t.go + 1) * 16 + tr_px;                                                   \
+                    H3UOps o0, o1, o2;                                                                        \
+                    o0.load(xb0 + c0, xl0, gb0 + c0, gl0);                                                    \
+                    o1.load(xb1 + c0, xl1, gb1 + c0, gl1);                                                    \
+                    __builtin_amdgcn_sched_barrier(0);                                                        \
+                    H3U_WPAIR(o2, xb0, xl0, gb0, gl0, 512, o0, val0, 0);                                      \
+                    H3U_WPAIR(o0, xb1, xl1, gb1, gl1, 512, o1, val1, 3);                                      \
+                    H3U_WPAIR(o1, xb0, xl0, gb0, gl0, 1024, o2, val0, 0);                                     \
+                    H3U_WPAIR(o2, xb1, xl1, gb1, gl1, 1024, o0, val1, 3);                                     \
+                    H3U_WPAIR(o0, xb0, xl0, gb0, gl0, 1536, o1, val0, 0);                                     \
+                    H3U_WPAIR(o1, xb1, xl1, gb1, gl1, 1536, o2, val1, 3);                                     \
+                    o0.mfma(acc[0], acc[1], acc[2], val0);                                                    \
+                    o1.mfma(acc[3], acc[4], acc[5], val1);                                                    \
+                }                                                                                             \
+            }                                                                                                 \
+            H3U_STAMP(0);                                                                                     \
             h3_barrier();                                                                                     \
+            H3U_STAMP(2);                                                                                     \
         } while (0)
         H3U_BAND(H3U_PRO_W, H3U_BODY_W)
 #undef H3U_PRO_W
 #undef H3U_BODY_W
+        H3U_STAMP_OUT;
         // ---- per-workgroup partials.  Weight gradients: D[ci = 4 q + j][co = n] per lane and tap, every (convolution, tap) owned by
         // exactly one wave: written straight from the registers (band order -> image order of the vertical taps) ----
 #pragma unroll
@@ -682,25 +782,7 @@ __device__ __forceinline__ void h3u_role_w(const BwdBlockH3Args& a, const int la
                 for (int j = 0; j < 4; ++j) dst[dx * 256 + (4 * q + j) * 16 + n] = v[j];
             }
         }
-        // the two sums: over the 16 lanes that share a channel quad (lane & 3), then over the three waves
-#pragma unroll
-        for (int m = 4; m < 64; m <<= 1) {
-#pragma unroll
-            for (int cidx = 0; cidx < 4; ++cidx) {
-                s1[cidx] += __shfl_xor(s1[cidx], m);
-                s2[cidx] += __shfl_xor(s2[cidx], m);
-            }
-        }
-        float* sred = reinterpret_cast<float*>(h3u_lds);     // [3 waves][32]
-        if (lane < 4) {
-#pragma unroll
-            for (int cidx = 0; cidx < 4; ++cidx) {
-                sred[rw * 32 + lane * 4 + cidx] = s1[cidx];
-                sred[rw * 32 + 16 + lane * 4 + cidx] = s2[cidx];
-            }
-        }
         h3_barrier();
-        if (BNC && rw == 0 && lane < 32) a.stats[(size_t)blockIdx.x * 32 + lane] = (sred[lane] + sred[32 + lane]) + sred[64 + lane];
         h3_barrier();
 }
 
@@ -722,7 +804,7 @@ __global__ __launch_bounds__(H3UGeom::NT, 3) void bwd_block_h3t_kernel(BwdBlockH
     __syncthreads();
     if (role == 0) h3u_role_f(a, lane, rw);
     else if (role == 1) h3u_role_d2(a, lane, rw);
-    else if (role == 2) h3u_role_d1(a, lane, rw);
+    else if (role == 2) h3u_role_d1<BNC>(a, lane, rw);
     else h3u_role_w<BNC>(a, lane, rw);
 }
 

@@ -1,0 +1,42 @@
+"""Per-role cycles of bwd_block_h3t_kernel (train_bwd_h3t.hip) at the configs[3] shape from an H3U_ABLATE=128 build
+(BFCNN_HIP_LIB=.../libbfcnn_hip_H3U_ABLATE128.so): s_memtime stamps per wave, summed over the launch, as
+[matrix work | memory duty (loader conversions / staged-row epilogue / stores) | barrier].  Read the SHARES: stamps add fences."""
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from blind_image_denoising_amd import _native as N
+
+L = N.lib()
+L.bf_debug_set_fused_dbg.argtypes = [C.c_void_p]
+B, H, W = 32, 256, 256
+r = lambda *s: torch.randn(*s, device="cuda")
+a, gr, c, bnc = r(B, H, W, 16), r(B, H, W, 16) * 0.1, r(B, H, W, 16), r(B, H, W, 16)
+coef = torch.cat([torch.ones(16), torch.full((16,), 0.1), torch.full((16,), 0.01)]).cuda()
+w0, w1 = r(3, 3, 16, 16) * 0.1, r(3, 3, 16, 16) * 0.1
+out, dw1, dw0, st = torch.empty_like(a), torch.empty(2304, device="cuda"), torch.empty(2304, device="cuda"), torch.empty(32, device="cuda")
+scr = torch.empty(int(L.bf_debug_bwd_block_h3t_scratch_floats(B, H, W)), device="cuda")
+NWG, NW = 256, 12
+dbg = torch.zeros(NWG * NW * 8, dtype=torch.int64, device="cuda")
+L.bf_debug_set_fused_dbg(C.c_void_p(dbg.data_ptr()))
+call = lambda: N.check(L.bf_debug_bwd_block_h3t(N.ptr(a), N.ptr(gr), N.ptr(c), N.ptr(coef), N.ptr(w0), N.ptr(w1), N.ptr(bnc), N.ptr(out), N.ptr(dw1),
+                                                 N.ptr(dw0), N.ptr(st), N.ptr(scr), B, H, W, 1, 0, N.stream_ptr(a)), None, "bwd_block")
+for _ in range(3):
+    call()
+torch.cuda.synchronize()
+dbg.zero_()
+call()
+torch.cuda.synchronize()
+d = dbg.cpu().numpy().reshape(NWG, NW, 8).astype(np.float64)
+if d.sum() == 0:
+    sys.exit("no stamps: not an H3U_ABLATE=128 build")
+cyc, ticks = d[:, :, :3].sum(axis=2), d[:, :, 3]
+live = ticks > 0
+mhz = np.median(cyc[live] / ticks[live]) * 100
+nsteps = 64 + 9
+print(f"cycles per wave: mean {cyc[live].mean():.0f} max {cyc.max():.0f}; in-kernel clock {mhz:.0f} MHz -> {cyc[live].mean() / mhz:.1f} us; {cyc[live].mean() / nsteps:.0f} cycles per step")
+names = ["matrix work", "memory duty", "barrier"]
+for role, wv in (("F  conv_0 + loads (3 A, 1 dc unit)", slice(0, 3)), ("D2 dgrad_1 + loads (2 dc units)", slice(3, 6)), ("D1 dgrad_0 + stores", slice(6, 9)), ("W  weight gradients + staged-row epilogue", slice(9, 12))):
+    dd = d[:, wv, :3]
+    print(f"role {role}: {dd.sum(axis=2).mean() / nsteps:.0f} cycles per step")
+    for k in range(3):
+        print(f"  {names[k]:12s} {dd[:, :, k].mean() / nsteps:8.0f} per step ({dd[:, :, k].sum() / dd.sum() * 100:5.1f} %)   by wave: " + " ".join(f"{v / nsteps:7.0f}" for v in dd[:, :, k].mean(axis=0)))
