@@ -83,16 +83,16 @@ struct H3UGeom {
     static constexpr int NW = 12, NT = 768;
     static constexpr int SW = 128;                     // output columns of a strip
     static constexpr int PITCH = (GW + 2) * 16;        // 2336 bytes per plane-row of a ring
-    static constexpr int NRA = 6, NRC = 4, NRT = 2, NRD = 2, NRS = 3;       // ring depths (rows)
+    static constexpr int NRA = 6, NRC = 4, NRT = 2, NRD = 4;               // ring depths (rows)
     static constexpr int UNROLL = 6;                   // steps per loop iteration: accumulator rotation and the 2- / 3-row rings static
     static constexpr int A_PLANE = h3u_plane(NRA * PITCH), C_PLANE = h3u_plane(NRC * PITCH), T_PLANE = h3u_plane(NRT * PITCH), D_PLANE = h3u_plane(NRD * PITCH);
-    static constexpr int S_QUAD = GW * 16 + 64, S_SLOT = 4 * S_QUAD;         // staging: [slot][channel quad][grid column] 16-byte records
     static constexpr int A_OFF = 0, C_OFF = A_OFF + 4 * A_PLANE, T_OFF = C_OFF + 4 * C_PLANE, D_OFF = T_OFF + 4 * T_PLANE;
-    static constexpr int S_OFF = D_OFF + 4 * D_PLANE, K_OFF = S_OFF + NRS * S_SLOT, LDS_BYTES = K_OFF + 256;    // K: k1 | k2 | k3 (48 floats)
-    static constexpr int LEAD = 9;                     // steps from the first A row of a band to the store of its first output row
+    static constexpr int K_OFF = D_OFF + 4 * D_PLANE, LDS_BYTES = K_OFF + 256;    // K: k1 | k2 | k3 (48 floats)
+    static constexpr int LEAD = 8;                     // steps of a band beyond its rows: the last row is stored in step nrows + 6, the weight
+                                                       // gradient of conv_0 pairs A row nrows (step nrows + 7) with the last dT row
     static_assert(A_PLANE >= NRA * PITCH && C_PLANE >= NRC * PITCH && T_PLANE >= NRT * PITCH && D_PLANE >= NRD * PITCH, "planes");
     static_assert(A_PLANE % 256 == 128 && C_PLANE % 256 == 128 && T_PLANE % 256 == 128 && D_PLANE % 256 == 128, "plane stride");
-    static_assert(UNROLL % NRT == 0 && UNROLL % NRD == 0 && UNROLL % NRS == 0 && UNROLL % NRA == 0 && UNROLL % 3 == 0, "static slots");
+    static_assert(UNROLL % NRT == 0 && UNROLL % NRA == 0 && UNROLL % 3 == 0, "static slots");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
@@ -191,16 +191,22 @@ struct H3UEpiMask {
     }
 };
 
-// D1: v * sc as one 16-byte fp32 record to the staging ring
-struct H3UEpiStage {
-    static constexpr int NOPS = 5;
-    f32x4 v;
+// D1: the finished row straight from the accumulator: v * sc + g (the skip's gradient), the two sums of the next BatchNorm backward
+// (own rows and columns only), one 16-byte store per lane (4 channels of one pixel; 16 lanes = 1 KiB contiguous)
+template <bool BNC>
+struct H3UEpiOut {
+    static constexpr int NOPS = BNC ? 17 : 13;
+    f32x4 v, g, b, s1, s2;
     float sc;
+    bool own;
     char* p;
     template <int I> __device__ __forceinline__ void op()
     {
-        if constexpr (I < 4) v[I] *= sc;
-        else *reinterpret_cast<f32x4*>(p) = v;
+        if constexpr (I < 4) v[I] = fmaf(v[I], sc, g[I]);                    // (sc is a power of two: the product is exact, one rounding as v * sc + g)
+        else if constexpr (I < 8) g[I - 4] = own ? v[I - 4] : 0.f;           // g now holds the row masked to the strip's own pixels
+        else if constexpr (I < 12) s1[I - 8] += g[I - 8];
+        else if constexpr (I == 12) { if (own && !(H3U_ABLATE & 8)) *reinterpret_cast<f32x4*>(p) = v; }
+        else s2[I - 13] = fmaf(g[I - 13], b[I - 13], s2[I - 13]);
         __builtin_amdgcn_sched_barrier(0);
     }
     template <int SLOT> __device__ __forceinline__ void pair()
@@ -217,8 +223,29 @@ struct H3UEpiStage {
     }
 };
 
+// D1's state across steps: the skip gradient g and C_{i-1} of the row that completes NEXT, in the accumulator layout (lane (n, q): pixel
+// n of its group, channels 4 q .. 4 q + 3: 16 bytes), the running sums, the addresses of the step
+template <bool BNC>
+struct H3UOutState {
+    static constexpr int G = 3;
+    f32x4 eg[G], eb[BNC ? G : 1], s1, s2;
+    bool own[G];
+    char* prow;                  // lane's store address of group 0 in the completing row
+    const char* gnext;           // lane's load address of group 0 of the NEXT row in g (C_{i-1}: + bdelta)
+    ptrdiff_t bdelta;
+    int goff[G];                 // byte offset of group g from group 0 (columns clamped to the image)
+    // UNCONDITIONAL loads, each issued right behind the epilogue that read its registers, one step before the next use (a branch around
+    // them makes hipcc wait at the join; requested at the END of the step they had ~700 cycles to land: stamps)
+    __device__ __forceinline__ void reload(const int g)
+    {
+        if (H3U_ABLATE & 4) return;
+        eg[g] = *reinterpret_cast<const f32x4*>(gnext + goff[g]);
+        if (BNC) eb[g] = *reinterpret_cast<const f32x4*>(gnext + bdelta + goff[g]);
+    }
+};
+
 // ---- one convolution-shaped role (F, D2, D1): a ring row in, three vertical-tap contributions, one completed row out ------------
-// KIND 0 = F (ReLU, split f16 out), 1 = D2 (mask, split f16 out), 2 = D1 (fp32 out to the staging ring)
+// KIND 0 = F (ReLU, split f16 out), 1 = D2 (mask, split f16 out), 2 = D1 (finished rows straight to global memory: step_out)
 template <int KIND, int INP>
 struct H3UConv {
     using Gm = H3UGeom;
@@ -247,7 +274,7 @@ struct H3UConv {
         rs = ((q & 1) + 2 * (q >> 1)) * INP + (gc0 + 2) * 16;
         if (KIND == 0) wr = (q >> 1) * Gm::T_PLANE + (gc0 + 1) * 16 + (q & 1) * 8;
         else if (KIND == 1) wr = (q >> 1) * Gm::D_PLANE + (gc0 + 1) * 16 + (q & 1) * 8;
-        else wr = q * Gm::S_QUAD + gc0 * 16;
+        else wr = 0;
         mr = (q >> 1) * Gm::T_PLANE + (gc0 + 1) * 16 + (q & 1) * 8;
 #pragma unroll
         for (int g = 0; g < Gm::G; ++g)
@@ -300,11 +327,6 @@ struct H3UConv {
                     H3UEpiMask e = epi_m(g - 1, oslot_bytes, acc[g - 1][a2], rowok, mrec[g - 1]);
                     h3u_mfmas<0>(w, acc[g][a2], acc[g][a1], c0, cur, &e);
                 } else h3u_mfmas<0>(w, acc[g][a2], acc[g][a1], c0, cur, (H3UEpiMask*)nullptr);
-            } else {
-                if (g > 0) {
-                    H3UEpiStage e = epi_s(g - 1, oslot_bytes, acc[g - 1][a2], rowok);
-                    h3u_mfmas<0>(w, acc[g][a2], acc[g][a1], c0, cur, &e);
-                } else h3u_mfmas<0>(w, acc[g][a2], acc[g][a1], c0, cur, (H3UEpiStage*)nullptr);
             }
             acc[g][a0] = c0;
             if (g + 1 < Gm::G) cur = nx;
@@ -312,7 +334,49 @@ struct H3UConv {
         const f32x4 last = bf_acc_ready(acc[Gm::G - 1][a2]);
         if constexpr (KIND == 0) { H3VEpi<true> e = epi_f(Gm::G - 1, oslot_bytes, last, rowok); e.all(); }
         else if constexpr (KIND == 1) { H3UEpiMask e = epi_m(Gm::G - 1, oslot_bytes, last, rowok, mrec[Gm::G - 1]); e.all(); }
-        else { H3UEpiStage e = epi_s(Gm::G - 1, oslot_bytes, last, rowok); e.all(); }
+    }
+    // D1: the same walk with the output epilogue (st: the skip gradient / C_{i-1} fragments of the completing row, the running sums,
+    // the lane's store address of group 0 in that row; rowok: the completing row is one of the band's own)
+    template <int PH, bool BNC, class State>
+    __device__ __forceinline__ void step_out(const int islot_bytes, State& st, const bool rowok)
+    {
+        constexpr int a0 = PH % 3, a1 = (PH + 2) % 3, a2 = (PH + 1) % 3;
+        H3VFrag cur = load(islot_bytes, 0);
+#pragma unroll
+        for (int g = 0; g < Gm::G; ++g) {
+            H3VFrag nx;
+            if (g + 1 < Gm::G) nx = load(islot_bytes, g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
+            if (g > 0) {
+                H3UEpiOut<BNC> e = epi_o<BNC>(g - 1, acc[g - 1][a2], rowok, st);
+                h3u_mfmas<0>(w, acc[g][a2], acc[g][a1], c0, cur, &e);
+                st.s1 = e.s1;
+                st.s2 = e.s2;
+                st.reload(g - 1);              // the operands of the NEXT row take the registers this epilogue just read
+            } else h3u_mfmas<0>(w, acc[g][a2], acc[g][a1], c0, cur, (H3UEpiOut<BNC>*)nullptr);
+            acc[g][a0] = c0;
+            if (g + 1 < Gm::G) cur = nx;
+        }
+        H3UEpiOut<BNC> e = epi_o<BNC>(Gm::G - 1, bf_acc_ready(acc[Gm::G - 1][a2]), rowok, st);
+        e.all();
+        st.s1 = e.s1;
+        st.s2 = e.s2;
+        st.reload(Gm::G - 1);
+    }
+    template <bool BNC, class State>
+    __device__ __forceinline__ H3UEpiOut<BNC> epi_o(const int g, const f32x4 v, const bool rowok, const State& st) const
+    {
+        H3UEpiOut<BNC> e;
+        e.v = v;
+        e.g = st.eg[g];
+        e.b = BNC ? st.eb[g] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        e.s1 = st.s1;
+        e.s2 = st.s2;
+        e.sc = inv_s;
+        e.own = rowok && st.own[g];
+        e.p = st.prow + g * 1024;
+        return e;
     }
     __device__ __forceinline__ H3VEpi<true> epi_f(const int g, const int oslot_bytes, const f32x4 v, const bool rowok) const
     {
@@ -333,14 +397,6 @@ struct H3UConv {
         e.t1 = m[1];
         e.p = tdst + wr + oslot_bytes + g * 256;
         e.lo_off = 2 * Gm::D_PLANE;
-        return e;
-    }
-    __device__ __forceinline__ H3UEpiStage epi_s(const int g, const int oslot_bytes, const f32x4 v, const bool rowok) const
-    {
-        H3UEpiStage e;
-        e.v = v;
-        e.sc = rowok ? lane_scale[g] : 0.f;
-        e.p = tdst + wr + oslot_bytes + g * 256;
         return e;
     }
 };
@@ -413,35 +469,90 @@ __device__ __forceinline__ h8 h3u_tr(const int addr)
     return __builtin_bit_cast(h8, (u4){ua[0], ua[1], ub[0], ub[1]});
 }
 
-// the operands of one (chunk, vertical tap row) of a weight gradient: x(row, shifted by dx - 1)^T for dx = 0, 1, 2 (hi, lo) and the
-// gradient row (hi, lo).  xa / ga: lane's LDS offsets of the chunk's first pixel in the hi images; xl / gl: offsets of the lo images
-struct H3UOps {
-    h8 ah[3], al[3], bh, bl;
-    __device__ __forceinline__ void load(const int xa, const int xl, const int ga, const int gl)
+// Operands of a weight gradient (pixel index along K, train_bwd_h3.hip): the x side of one 32-pixel chunk of one ring row -- the row
+// shifted by dx - 1 pixels for dx = 0, 1, 2, hi and lo image -- and the gradient side of one chunk of one ring row (hi, lo).  One x set
+// serves the three gradient rows of its chunk (27 MFMAs): 12 operands where a per-tap-row split needs 24.
+struct H3UOpsX {
+    h8 ah[3], al[3];
+    // xa: lane's LDS offset of the chunk's first pixel in the hi image; xl: offset of the lo image
+    __device__ __forceinline__ void load(const int xa, const int xl)
     {
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             ah[dx] = h3u_tr(xa + (dx - 1) * 16);
             al[dx] = h3u_tr(xa + xl + (dx - 1) * 16);
         }
+    }
+};
+struct H3UOpsG {
+    h8 bh, bl;
+    __device__ __forceinline__ void load(const int ga, const int gl)
+    {
         bh = h3u_tr(ga);
         bl = h3u_tr(ga + gl);
     }
-    // acc[dx] += x(dx)^T . g, three split products each; !valid: a gradient row outside the band's own rows, multiplied as zeros
-    // (straight-line code: a branch around the MFMAs cost the register allocator 28 spilled registers)
-    __device__ __forceinline__ void mfma(f32x4& a0, f32x4& a1, f32x4& a2, const bool valid)
-    {
-        const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-        const h8 bh = valid ? this->bh : zero, bl = valid ? this->bl : zero;
-        if (H3U_ABLATE & 32) {                               // keeps the operand reads live
-            a0[0] += (float)ah[0][0] + (float)ah[1][1] + (float)ah[2][2] + (float)al[0][3] + (float)al[1][4] + (float)al[2][5] + (float)bh[6] + (float)bl[7];
-            return;
-        }
-        a0 = MFMA_H(ah[0], bh, a0); a1 = MFMA_H(ah[1], bh, a1); a2 = MFMA_H(ah[2], bh, a2);
-        a0 = MFMA_H(al[0], bh, a0); a1 = MFMA_H(al[1], bh, a1); a2 = MFMA_H(al[2], bh, a2);
-        a0 = MFMA_H(ah[0], bl, a0); a1 = MFMA_H(ah[1], bl, a1); a2 = MFMA_H(ah[2], bl, a2);
-    }
 };
+// acc[dx] += x(dx)^T . g, three split products each; !valid: a gradient row outside the band's own rows, multiplied as zeros
+// (straight-line code: a branch around the MFMAs cost the register allocator dearly)
+__device__ __forceinline__ void h3u_mfma9(const H3UOpsX& x, const H3UOpsG& g, f32x4& a0, f32x4& a1, f32x4& a2, const bool valid)
+{
+    if (H3U_ABLATE & 32) {                                   // keeps the operand reads live
+        a0[0] += (float)x.ah[0][0] + (float)x.ah[1][1] + (float)x.ah[2][2] + (float)x.al[0][3] + (float)x.al[1][4] + (float)x.al[2][5] + (float)g.bh[6] + (float)g.bl[7];
+        return;
+    }
+    const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    const h8 bh = valid ? g.bh : zero, bl = valid ? g.bl : zero;
+    a0 = MFMA_H(x.ah[0], bh, a0); a1 = MFMA_H(x.ah[1], bh, a1); a2 = MFMA_H(x.ah[2], bh, a2);
+    a0 = MFMA_H(x.al[0], bh, a0); a1 = MFMA_H(x.al[1], bh, a1); a2 = MFMA_H(x.al[2], bh, a2);
+    a0 = MFMA_H(x.ah[0], bl, a0); a1 = MFMA_H(x.ah[1], bl, a1); a2 = MFMA_H(x.ah[2], bl, a2);
+}
+
+// One UNIT of weight-gradient work = (convolution, chunk) at one step: its x set and its three gradient rows (band-order vertical taps
+// 0, 1, 2).  A convolution's operands at chunk 0 (scalars only: arrays of these structs ended up in scratch memory):
+struct H3UConvOps {
+    int xa, xl, ga0, ga1, ga2, gl;      // lane's LDS offsets (hi images) of chunk 0's first pixel: x row, the three gradient rows; lo-image offsets
+    bool v0, v1, v2;                    // the gradient row is one of the band's own
+};
+// NU units back to back, software-pipelined: the x set of the next unit and the gradient set two rows ahead are requested before the
+// MFMAs of the current row (two x sets, two gradient sets in registers).  Unit i: convolution P (CI = 1, accumulators acc1) or Q (CI = 0,
+// acc0) at byte offset OFFi from chunk 0.
+template <int NU, int C0, int C1, int C2, int OFF0, int OFF1, int OFF2>
+__device__ __forceinline__ void h3u_units(const H3UConvOps& P, const H3UConvOps& Q, f32x4 (&acc1)[9], f32x4 (&acc0)[9])
+{
+#define H3U_U(I) (((I) == 0 ? C0 : ((I) == 1 ? C1 : C2)) ? P : Q)
+#define H3U_O(I) ((I) == 0 ? OFF0 : ((I) == 1 ? OFF1 : OFF2))
+    H3UOpsX x0, x1;
+    H3UOpsG g0, g1;
+    x0.load(H3U_U(0).xa + H3U_O(0), H3U_U(0).xl);
+    g0.load(H3U_U(0).ga0 + H3U_O(0), H3U_U(0).gl);
+    g1.load(H3U_U(0).ga1 + H3U_O(0), H3U_U(0).gl);
+    __builtin_amdgcn_sched_barrier(0);
+#define H3U_ROW(X, G, UI, DYB, VAL, NEXT)                                                                     \
+    do {                                                                                                      \
+        constexpr int c_ = UI == 0 ? C0 : (UI == 1 ? C1 : C2);                                                \
+        if constexpr (c_) h3u_mfma9(X, G, acc1[3 * (DYB)], acc1[3 * (DYB) + 1], acc1[3 * (DYB) + 2], VAL);    \
+        else h3u_mfma9(X, G, acc0[3 * (DYB)], acc0[3 * (DYB) + 1], acc0[3 * (DYB) + 2], VAL);                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        NEXT;                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    } while (0)
+    H3U_ROW(x0, g0, 0, 0, H3U_U(0).v0, { g0.load(H3U_U(0).ga2 + H3U_O(0), H3U_U(0).gl); if (NU > 1) x1.load(H3U_U(1).xa + H3U_O(1), H3U_U(1).xl); });
+    H3U_ROW(x0, g1, 0, 1, H3U_U(0).v1, { if (NU > 1) g1.load(H3U_U(1).ga0 + H3U_O(1), H3U_U(1).gl); });
+    H3U_ROW(x0, g0, 0, 2, H3U_U(0).v2, { if (NU > 1) g0.load(H3U_U(1).ga1 + H3U_O(1), H3U_U(1).gl); });
+    if (NU > 1) {
+        H3U_ROW(x1, g1, 1, 0, H3U_U(1).v0, { g1.load(H3U_U(1).ga2 + H3U_O(1), H3U_U(1).gl); if (NU > 2) x0.load(H3U_U(2).xa + H3U_O(2), H3U_U(2).xl); });
+        H3U_ROW(x1, g0, 1, 1, H3U_U(1).v1, { if (NU > 2) g0.load(H3U_U(2).ga0 + H3U_O(2), H3U_U(2).gl); });
+        H3U_ROW(x1, g1, 1, 2, H3U_U(1).v2, { if (NU > 2) g1.load(H3U_U(2).ga1 + H3U_O(2), H3U_U(2).gl); });
+    }
+    if (NU > 2) {
+        H3U_ROW(x0, g0, 2, 0, H3U_U(2).v0, { g0.load(H3U_U(2).ga2 + H3U_O(2), H3U_U(2).gl); });
+        H3U_ROW(x0, g1, 2, 1, H3U_U(2).v1, { });
+        H3U_ROW(x0, g0, 2, 2, H3U_U(2).v2, { });
+    }
+#undef H3U_ROW
+#undef H3U_U
+#undef H3U_O
+}
 
 // One function per role, all inlined into the kernel.  (Tried: not inlined, so that the register allocator treats the roles
 // separately.  The callee then sees its arguments as per-lane values -- uniform branches became exec-mask loops, the tensor pointers
@@ -467,10 +578,9 @@ __device__ __forceinline__ void h3u_role_f(const BwdBlockH3Args& a, const int la
     char* tc = h3u_lds + Gm::C_OFF;
     char* tt = h3u_lds + Gm::T_OFF;
     char* td = h3u_lds + Gm::D_OFF;
-    char* ts = h3u_lds + Gm::S_OFF;
     const int n = lane & 15, q = lane >> 4;
     const int gc0 = 16 * Gm::G * rw + n;                        // F / D waves: lane's grid column in its wave's group 0
-    (void)ta; (void)tc; (void)tt; (void)td; (void)ts; (void)q; (void)gc0;
+    (void)ta; (void)tc; (void)tt; (void)td; (void)q; (void)gc0;
     H3U_STAMP_DECL
         // ================= F: T = relu(conv_0 A) ; loads: A units 3 rw .. 3 rw + 2, dc unit rw =================
         __builtin_amdgcn_s_setprio(1);
@@ -526,10 +636,9 @@ __device__ __forceinline__ void h3u_role_d2(const BwdBlockH3Args& a, const int l
     char* tc = h3u_lds + Gm::C_OFF;
     char* tt = h3u_lds + Gm::T_OFF;
     char* td = h3u_lds + Gm::D_OFF;
-    char* ts = h3u_lds + Gm::S_OFF;
     const int n = lane & 15, q = lane >> 4;
     const int gc0 = 16 * Gm::G * rw + n;                        // F / D waves: lane's grid column in its wave's group 0
-    (void)ta; (void)tc; (void)tt; (void)td; (void)ts; (void)q; (void)gc0;
+    (void)ta; (void)tc; (void)tt; (void)td; (void)q; (void)gc0;
     H3U_STAMP_DECL
         // ================= D2: dT = dgrad_1(dc) * (T > 0) ; loads: dc units 3 + 2 rw, 4 + 2 rw =================
         __builtin_amdgcn_s_setprio(1);
@@ -549,9 +658,9 @@ __device__ __forceinline__ void h3u_role_d2(const BwdBlockH3Args& a, const int l
 #define H3U_BODY_D2(PH)                                                                                       \
         do {                                                                                                  \
             const int s = s0 + PH;                                                                            \
-            /* dc row s-4 in; dT row s-5 completes (slot (s-5) mod 2 = (PH+1) mod 2), masked by T row s-5 (same parity) */ \
+            /* dc row s-4 in; dT row s-5 completes (slot (s-5) mod 4), masked by T row s-5 (slot (PH+1) mod 2) */ \
             if (!(H3U_ABLATE & 16) && (s >= 2) && (s < t.nrows + 6))                                          \
-                R.template step<PH>(h3u_mod(s - 4, Gm::NRC) * Gm::PITCH, ((PH + 1) % Gm::NRD) * Gm::PITCH, ((PH + 1) % Gm::NRT) * Gm::PITCH, \
+                R.template step<PH>(h3u_mod(s - 4, Gm::NRC) * Gm::PITCH, h3u_mod(s - 5, Gm::NRD) * Gm::PITCH, ((PH + 1) % Gm::NRT) * Gm::PITCH, \
                                     H3U_IN_IMAGE(s - 5));                                                     \
             H3U_STAMP(0);                                                                                     \
             {                                                /* behind the matrix work: dc row s-3 -> its slot, registers <- row s-2 */ \
@@ -580,59 +689,45 @@ __device__ __forceinline__ void h3u_role_d1(const BwdBlockH3Args& a, const int l
     char* tc = h3u_lds + Gm::C_OFF;
     char* tt = h3u_lds + Gm::T_OFF;
     char* td = h3u_lds + Gm::D_OFF;
-    char* ts = h3u_lds + Gm::S_OFF;
     const int n = lane & 15, q = lane >> 4;
     const int gc0 = 16 * Gm::G * rw + n;                        // F / D waves: lane's grid column in its wave's group 0
-    (void)ta; (void)tc; (void)tt; (void)td; (void)ts; (void)q; (void)gc0;
+    (void)ta; (void)tc; (void)tt; (void)td; (void)q; (void)gc0;
     H3U_STAMP_DECL
-        // ================= D1: raw dA' = dgrad_0(dT) -> staging ; epilogue of staged row s-8 (loads: g, C_{i-1}) =================
+        // ================= D1: dA' = dgrad_0(dT) + g, the two sums against C_{i-1}, stored straight from the accumulators =================
         __builtin_amdgcn_s_setprio(1);
         H3UConv<2, Gm::D_PLANE> R;
-        R.tin = td; R.tdst = ts; R.tmask = nullptr;
+        R.tin = td; R.tdst = nullptr; R.tmask = nullptr;
         R.init(a.wdg0, a, lane, gc0);
-        // epilogue elements of this wave: e = 64 we + lane, we = rw, rw + 3, rw + 6: pixel e >> 2 of the strip (we = 8: past it), quad e & 3;
-        // g and C_{i-1} of a row are requested one step before the row is staged-complete (the in-place prefetch of the loaders)
-        f32x4 eg[3], eb[BNC ? 3 : 1];
-        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-        auto ep_load = [&](const H3UTile& t, const int k) {
+        // the skip gradient g and C_{i-1} of the row that completes in the NEXT step, in the accumulator layout (lane (n, q): pixel n of
+        // its group, channels 4 q .. 4 q + 3: 16 bytes): requested one step ahead, right behind the epilogues that consumed the last ones
+        H3UOutState<BNC> st;
+        st.s1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        st.s2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        st.bdelta = BNC ? reinterpret_cast<const char*>(a.bnc) - reinterpret_cast<const char*>(a.g) : 0;
+        auto next_row = [&](const H3UTile& t, const int k) {   // lane's address of group 0 of band row k (clamped to the image) in g
             const int y = min(max(t.y(k), 0), a.H - 1);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int e = 64 * (rw + 3 * i) + lane;
-                const int col = min(t.X0 + (e >> 2), a.W - 1);
-                const size_t off = t.img + ((size_t)y * a.W + col) * 64 + (e & 3) * 16;
-                eg[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.g) + off);
-                if (BNC) eb[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.bnc) + off);
-            }
+            return reinterpret_cast<const char*>(a.g) + t.img + ((size_t)y * a.W + min(t.G0 + gc0, a.W - 1)) * 64 + q * 16;
         };
         __builtin_amdgcn_s_waitcnt(h3_vmcnt(0));
-#define H3U_PRO_D1 R.set_tile(t, a.W, gc0); if (!(H3U_ABLATE & 4)) ep_load(t, 0);
+#define H3U_PRO_D1                                                                                            \
+        R.set_tile(t, a.W, gc0);                                                                              \
+        _Pragma("unroll") for (int g = 0; g < Gm::G; ++g) {                                                   \
+            st.own[g] = (t.G0 + gc0 + 16 * g >= t.X0) && (t.G0 + gc0 + 16 * g < t.X1);                         \
+            st.goff[g] = (min(t.G0 + gc0 + 16 * g, a.W - 1) - min(t.G0 + gc0, a.W - 1)) * 64;                  \
+        }                                                                                                     \
+        st.gnext = next_row(t, 0);                                                                            \
+        _Pragma("unroll") for (int g = 0; g < Gm::G; ++g) st.reload(g);
 #define H3U_BODY_D1(PH)                                                                                       \
         do {                                                                                                  \
             const int s = s0 + PH;                                                                            \
-            /* dT row s-6 in (slot (s-6) mod 2 = PH mod 2); raw row s-7 completes -> staging slot (s-7) mod 3 = (PH+2) mod 3 */ \
-            if (!(H3U_ABLATE & 16) && (s >= 5) && (s < t.nrows + 7))                                          \
-                R.template step<PH>((PH % Gm::NRD) * Gm::PITCH, ((PH + 2) % Gm::NRS) * Gm::S_SLOT, 0, true);  \
-            H3U_STAMP(0);                                                                                     \
-            /* ---- BEHIND the matrix work: epilogue of staged row s-8 (slot (s-8) mod 3 = (PH+1) mod 3): + g, sums, back to the ring ---- */ \
-            {                                                                                                 \
-                const int ke = s - 8;                                                                         \
-                const bool have = !(H3U_ABLATE & 4) && (ke >= 0) && (ke < t.nrows);                           \
-                if (have) {                                                                                   \
-                    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                           \
-                        const int e = 64 * (rw + 3 * i) + lane;                                               \
-                        char* p = ts + ((PH + 1) % Gm::NRS) * Gm::S_SLOT + (e & 3) * Gm::S_QUAD + (t.go + (e >> 2)) * 16; \
-                        const bool in = t.X0 + (e >> 2) < t.X1;                                               \
-                        f32x4 v = *reinterpret_cast<const f32x4*>(p) + eg[i];                                 \
-                        _Pragma("unroll") for (int j = 0; j < 4; ++j) v[j] = in ? v[j] : 0.f;                 \
-                        s1 += v;                                                                              \
-                        if (BNC) s2 += v * eb[i];                                                             \
-                        if (in) *reinterpret_cast<f32x4*>(p) = v;                                             \
-                    }                                                                                         \
-                    __builtin_amdgcn_sched_barrier(0);                                                        \
-                    ep_load(t, ke + 1);                      /* registers <- row s-7 (consumed in the next step) */ \
-                    __builtin_amdgcn_sched_barrier(0);                                                        \
-                }                                                                                             \
+            /* dT row s-6 in (slot (s-6) mod 4); row s-7 completes: + g, sums, store */                        \
+            if (!(H3U_ABLATE & 16) && (s >= 5) && (s < t.nrows + 7)) {                                        \
+                const int k = s - 7;                                                                          \
+                const bool rowok = (k >= 0) && (k < t.nrows);                                                 \
+                st.prow = reinterpret_cast<char*>(a.out) + t.img + ((size_t)t.y(rowok ? k : 0) * a.W + t.G0 + gc0) * 64 + q * 16; \
+                st.gnext = next_row(t, k + 1);                                                                \
+                R.template step_out<PH, BNC>(h3u_mod(s - 6, Gm::NRD) * Gm::PITCH, st, rowok);                 \
+                H3U_STAMP(0);                                                                                 \
             }                                                                                                 \
             H3U_STAMP(1);                                                                                     \
             h3_barrier();                                                                                     \
@@ -642,21 +737,21 @@ __device__ __forceinline__ void h3u_role_d1(const BwdBlockH3Args& a, const int l
 #undef H3U_PRO_D1
 #undef H3U_BODY_D1
         H3U_STAMP_OUT;
-        // the two sums: over the 16 lanes that share a channel quad (lane & 3), then over the three waves (fixed order)
+        // the two sums: over the 16 pixel lanes that share a channel quad (q = lane >> 4), then over the three waves (fixed order)
 #pragma unroll
-        for (int m = 4; m < 64; m <<= 1) {
+        for (int m = 1; m < 16; m <<= 1) {
 #pragma unroll
             for (int cidx = 0; cidx < 4; ++cidx) {
-                s1[cidx] += __shfl_xor(s1[cidx], m);
-                s2[cidx] += __shfl_xor(s2[cidx], m);
+                st.s1[cidx] += __shfl_xor(st.s1[cidx], m);
+                st.s2[cidx] += __shfl_xor(st.s2[cidx], m);
             }
         }
         float* sred = reinterpret_cast<float*>(h3u_lds);     // [3 waves][32]; the rings are free after the last band
-        if (lane < 4) {
+        if (n == 0) {
 #pragma unroll
             for (int cidx = 0; cidx < 4; ++cidx) {
-                sred[rw * 32 + lane * 4 + cidx] = s1[cidx];
-                sred[rw * 32 + 16 + lane * 4 + cidx] = s2[cidx];
+                sred[rw * 32 + q * 4 + cidx] = st.s1[cidx];
+                sred[rw * 32 + 16 + q * 4 + cidx] = st.s2[cidx];
             }
         }
         h3_barrier();
@@ -664,101 +759,61 @@ __device__ __forceinline__ void h3u_role_d1(const BwdBlockH3Args& a, const int l
         h3_barrier();
 }
 
-template <bool BNC>
-__device__ __forceinline__ void h3u_role_w(const BwdBlockH3Args& a, const int lane, const int rw)
+// (one instance per wave of the role: with the wave index as a run-time value hipcc merged the three shapes of the step into code that
+// spilled 235 registers; apart they need 122 / 116 / 154 and none)
+template <int RW>
+__device__ __forceinline__ void h3u_role_w(const BwdBlockH3Args& a, const int lane)
 {
     using Gm = H3UGeom;
     char* ta = h3u_lds + Gm::A_OFF;
     char* tc = h3u_lds + Gm::C_OFF;
     char* tt = h3u_lds + Gm::T_OFF;
     char* td = h3u_lds + Gm::D_OFF;
-    char* ts = h3u_lds + Gm::S_OFF;
+    constexpr int rw = RW;
     const int n = lane & 15, q = lane >> 4;
     const int gc0 = 16 * Gm::G * rw + n;                        // F / D waves: lane's grid column in its wave's group 0
-    (void)ta; (void)tc; (void)tt; (void)td; (void)ts; (void)q; (void)gc0;
+    (void)ta; (void)tc; (void)tt; (void)td; (void)q; (void)gc0;
     H3U_STAMP_DECL
-        // ================= W: dW1 (T x dc), dW0 (A x dT) ; epilogue of staged row s-8 =================
-        // The 18 (convolution, vertical tap) rows of the two weight gradients are dealt to the three waves, six 16 x 16 accumulators
-        // (three horizontal taps each for two rows) per wave, 72 MFMAs per wave and step:
-        //   rw = 0: dW1 rows 0, 1 (share the T operands) ; rw = 1: dW1 row 2, dW0 row 0 ; rw = 2: dW0 rows 1, 2 (share the dT operands)
-        // (vertical taps in BAND order; a reversed band walks bottom-up and its rows are swapped when they are written out)
-        f32x4 acc[6];
+        // ================= W: dW1 = T^T dc, dW0 = A^T dT =================
+        // K chunks of 32 pixels of the strip's own columns; a wave owns ALL nine taps of its (convolution, chunk) units, so that one set
+        // of x operands serves the three gradient rows of a chunk (the kernel is bound by LDS traffic and these transposed reads were
+        // half of it when the work was dealt by tap rows):   rw = 0: dW1 chunks 0, 1, 2 ; rw = 1: dW0 chunks 0, 1, 2 ; rw = 2: chunk 3 of both.
+        // dW1 at step s: T row r = s-5 (slot (PH+1) mod 2) against dc rows r - dyb + 1; dW0: A row a = s-7 against dT rows a - dyb + 1
+        // (dyb = vertical tap in BAND order; a reversed band walks bottom-up and its tap rows are swapped when they are written out).
+        f32x4 acc1[9], acc0[9];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 9; ++i) {
+            acc1[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc0[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
         // transposed-read offset of this lane inside a 32-pixel chunk: pixel 4 (lane >> 4) + ((lane & 15) >> 2), channels 4 j .. 4 j + 3
-        // with j = lane & 3: plane j >> 1, half-record j & 1 (the plane stride is a template argument of the reads)
+        // with j = lane & 3: plane j >> 1, half-record j & 1
         const int tr_px = (4 * (lane >> 4) + ((lane & 15) >> 2)) * 16 + (lane & 1) * 8;
         const int tr_hi = (lane & 3) >> 1;
-// request the operands of a later (chunk, job) pair into NXT, then the nine MFMAs of the pair in CUR
-#define H3U_WPAIR(NXT, XB, XL, GB, GL, COLOFF, CUR, VAL, A0)                                                  \
-        do {                                                                                                  \
-            NXT.load(XB + c0 + COLOFF, XL, GB + c0 + COLOFF, GL);                                             \
-            __builtin_amdgcn_sched_barrier(0);                                                                \
-            CUR.mfma(acc[A0], acc[A0 + 1], acc[A0 + 2], VAL);                                                 \
-            __builtin_amdgcn_sched_barrier(0);                                                                \
-        } while (0)
 #define H3U_PRO_W
 #define H3U_BODY_W(PH)                                                                                        \
         do {                                                                                                  \
             const int s = s0 + PH;                                                                            \
-            {                                                /* staged row s-9 (slot PH mod 3) -> global memory, in front of the matrix work: nothing live across it */ \
-                const int ko = s - 9;                                                                         \
-                if (!(H3U_ABLATE & 8) && (ko >= 0) && (ko < t.nrows)) {                                       \
-                    char* dst = reinterpret_cast<char*>(a.out) + t.img + ((size_t)t.y(ko) * a.W + t.X0) * 64; \
-                    /* elements e = 64 we + lane, we = rw, rw + 3, rw + 6: pixel e >> 2 of the strip (we = 8: past the strip, masked), quad e & 3 */ \
-                    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                           \
-                        const int e = 64 * (rw + 3 * i) + lane;                                               \
-                        const f32x4 sv = *reinterpret_cast<const f32x4*>(ts + (PH % Gm::NRS) * Gm::S_SLOT + (e & 3) * Gm::S_QUAD + (t.go + (e >> 2)) * 16); \
-                        if (t.X0 + (e >> 2) < t.X1) *reinterpret_cast<f32x4*>(dst + (size_t)e * 16) = sv;     \
-                    }                                                                                         \
-                    __builtin_amdgcn_sched_barrier(0);                                                        \
-                }                                                                                             \
-            }                                                                                                 \
-            H3U_STAMP(1);                                                                                     \
-            {                                                                                                 \
-                /* the wave's two (convolution, vertical tap) rows of this step as jobs: x-side operands at LDS offset xb (lo image at    \
-                   + xl), gradient-side operands at gb (+ gl), valid: own rows only.  dW1: T row r = s-5 (slot (PH+1) mod 2) with dc      \
-                   row r - dyb + 1 ; dW0: dT row k0 = s-6 (slot PH mod 2) with A row k0 + dyb - 1 */            \
-                const int r = s - 5, k0 = s - 6;                                                              \
-                const bool own0 = (k0 >= 0) && (k0 < t.nrows);                                                \
-                const int tb = Gm::T_OFF + tr_hi * Gm::T_PLANE + ((PH + 1) % Gm::NRT) * Gm::PITCH;            \
-                const int db = Gm::D_OFF + tr_hi * Gm::D_PLANE + (PH % Gm::NRD) * Gm::PITCH;                  \
-                int xb0, xl0, gb0, gl0, xb1, xl1, gb1, gl1;                                                   \
-                bool val0, val1;                                                                              \
-                if (rw == 0) {                                                                                \
-                    xb0 = xb1 = tb; xl0 = xl1 = 2 * Gm::T_PLANE; gl0 = gl1 = 2 * Gm::C_PLANE;                 \
-                    gb0 = Gm::C_OFF + tr_hi * Gm::C_PLANE + h3u_mod(r + 1, Gm::NRC) * Gm::PITCH; val0 = (r + 1 >= 0) && (r + 1 < t.nrows); \
-                    gb1 = Gm::C_OFF + tr_hi * Gm::C_PLANE + h3u_mod(r, Gm::NRC) * Gm::PITCH; val1 = (r >= 0) && (r < t.nrows); \
-                } else if (rw == 1) {                                                                         \
-                    xb0 = tb; xl0 = 2 * Gm::T_PLANE; gl0 = 2 * Gm::C_PLANE;                                   \
-                    gb0 = Gm::C_OFF + tr_hi * Gm::C_PLANE + h3u_mod(r - 1, Gm::NRC) * Gm::PITCH; val0 = (r - 1 >= 0) && (r - 1 < t.nrows); \
-                    xb1 = Gm::A_OFF + tr_hi * Gm::A_PLANE + h3u_mod(k0 - 1, Gm::NRA) * Gm::PITCH; xl1 = 2 * Gm::A_PLANE; \
-                    gb1 = db; gl1 = 2 * Gm::D_PLANE; val1 = own0;                                             \
-                } else {                                                                                      \
-                    xb0 = Gm::A_OFF + tr_hi * Gm::A_PLANE + h3u_mod(k0, Gm::NRA) * Gm::PITCH;                 \
-                    xb1 = Gm::A_OFF + tr_hi * Gm::A_PLANE + h3u_mod(k0 + 1, Gm::NRA) * Gm::PITCH;             \
-                    xl0 = xl1 = 2 * Gm::A_PLANE; gb0 = gb1 = db; gl0 = gl1 = 2 * Gm::D_PLANE; val0 = val1 = own0; \
-                }                                                                                             \
-                if (!(H3U_ABLATE & 1) && (val0 || val1)) {                                                    \
-                    /* software pipeline over the 8 (chunk, job) pairs, THREE operand sets: the operands of pair i + 2 are requested       \
-                       before the MFMAs of pair i (an in-order wave otherwise pays one LDS round trip -- ~500 cycles with twelve waves on \
-                       the LDS -- per nine MFMAs: stamps, 3 900 cycles per step on these waves where the others need 2 300-3 100) */        \
-                    const int c0 = (t.go + 1) * 16 + tr_px;                                                   \
-                    H3UOps o0, o1, o2;                                                                        \
-                    o0.load(xb0 + c0, xl0, gb0 + c0, gl0);                                                    \
-                    o1.load(xb1 + c0, xl1, gb1 + c0, gl1);                                                    \
-                    __builtin_amdgcn_sched_barrier(0);                                                        \
-                    H3U_WPAIR(o2, xb0, xl0, gb0, gl0, 512, o0, val0, 0);                                      \
-                    H3U_WPAIR(o0, xb1, xl1, gb1, gl1, 512, o1, val1, 3);                                      \
-                    H3U_WPAIR(o1, xb0, xl0, gb0, gl0, 1024, o2, val0, 0);                                     \
-                    H3U_WPAIR(o2, xb1, xl1, gb1, gl1, 1024, o0, val1, 3);                                     \
-                    H3U_WPAIR(o0, xb0, xl0, gb0, gl0, 1536, o1, val0, 0);                                     \
-                    H3U_WPAIR(o1, xb1, xl1, gb1, gl1, 1536, o2, val1, 3);                                     \
-                    o0.mfma(acc[0], acc[1], acc[2], val0);                                                    \
-                    o1.mfma(acc[3], acc[4], acc[5], val1);                                                    \
-                }                                                                                             \
+            if (!(H3U_ABLATE & 1) && (s >= 4) && (s < t.nrows + 9)) {                                         \
+                const int r = s - 5, ar = s - 7;                                                              \
+                const int c0 = (t.go + 1) * 16 + tr_px;                                                       \
+                const int tb = Gm::T_OFF + tr_hi * Gm::T_PLANE + ((PH + 1) % Gm::NRT) * Gm::PITCH + c0;       \
+                const int ab = Gm::A_OFF + tr_hi * Gm::A_PLANE + h3u_mod(ar, Gm::NRA) * Gm::PITCH + c0;       \
+                H3UConvOps P, Q;                             /* dW1 / dW0 at chunk 0 */                        \
+                P.xa = tb; P.xl = 2 * Gm::T_PLANE; P.gl = 2 * Gm::C_PLANE;                                    \
+                Q.xa = ab; Q.xl = 2 * Gm::A_PLANE; Q.gl = 2 * Gm::D_PLANE;                                    \
+                P.ga0 = Gm::C_OFF + tr_hi * Gm::C_PLANE + h3u_mod(r + 1, Gm::NRC) * Gm::PITCH + c0; P.v0 = (r + 1 >= 0) && (r + 1 < t.nrows); \
+                P.ga1 = Gm::C_OFF + tr_hi * Gm::C_PLANE + h3u_mod(r, Gm::NRC) * Gm::PITCH + c0;     P.v1 = (r >= 0) && (r < t.nrows);         \
+                P.ga2 = Gm::C_OFF + tr_hi * Gm::C_PLANE + h3u_mod(r - 1, Gm::NRC) * Gm::PITCH + c0; P.v2 = (r - 1 >= 0) && (r - 1 < t.nrows); \
+                Q.ga0 = Gm::D_OFF + tr_hi * Gm::D_PLANE + h3u_mod(ar + 1, Gm::NRD) * Gm::PITCH + c0; Q.v0 = (ar + 1 >= 0) && (ar + 1 < t.nrows); \
+                Q.ga1 = Gm::D_OFF + tr_hi * Gm::D_PLANE + h3u_mod(ar, Gm::NRD) * Gm::PITCH + c0;     Q.v1 = (ar >= 0) && (ar < t.nrows);         \
+                Q.ga2 = Gm::D_OFF + tr_hi * Gm::D_PLANE + h3u_mod(ar - 1, Gm::NRD) * Gm::PITCH + c0; Q.v2 = (ar - 1 >= 0) && (ar - 1 < t.nrows); \
+                if constexpr (RW == 0) h3u_units<3, 1, 1, 1, 0, 512, 1024>(P, Q, acc1, acc0);                 \
+                else if constexpr (RW == 1) h3u_units<3, 0, 0, 0, 0, 512, 1024>(P, Q, acc1, acc0);            \
+                else h3u_units<2, 1, 0, 0, 1536, 1536, 0>(P, Q, acc1, acc0);                                  \
             }                                                                                                 \
             H3U_STAMP(0);                                                                                     \
+            H3U_STAMP(1);                                                                                     \
             h3_barrier();                                                                                     \
             H3U_STAMP(2);                                                                                     \
         } while (0)
@@ -766,23 +821,25 @@ __device__ __forceinline__ void h3u_role_w(const BwdBlockH3Args& a, const int la
 #undef H3U_PRO_W
 #undef H3U_BODY_W
         H3U_STAMP_OUT;
-        // ---- per-workgroup partials.  Weight gradients: D[ci = 4 q + j][co = n] per lane and tap, every (convolution, tap) owned by
-        // exactly one wave: written straight from the registers (band order -> image order of the vertical taps) ----
+        // ---- per-workgroup partials.  Weight gradients: D[ci = 4 q + j][co = n] per lane and tap; band order -> image order of the
+        // vertical taps; dW1 = wave 0 + wave 2, dW0 = wave 1 + wave 2 through LDS (fixed order: bitwise reproducible) ----
+        float* red = reinterpret_cast<float*>(h3u_lds) + 128;    // [4][2304]: dW1 of wave 0, dW1 of wave 2, dW0 of wave 1, dW0 of wave 2 (behind the D1 sums)
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            // (convolution, band-order vertical tap) of accumulators 3 half .. 3 half + 2
-            const int conv1 = rw == 0 || (rw == 1 && half == 0);
-            const int dyb = rw == 0 ? half : (rw == 1 ? (half == 0 ? 2 : 0) : 1 + half);
-            const int dy = a.reverse ? 2 - dyb : dyb;
-            float* dst = (conv1 ? a.wpartial1 : a.wpartial0) + (size_t)blockIdx.x * 2304 + dy * 3 * 256;
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dyb = tap / 3, dx = tap % 3;
+            const int ti = (a.reverse ? 2 - dyb : dyb) * 3 + dx;
+            const f32x4 v1 = bf_acc_ready(acc1[tap]), v0 = bf_acc_ready(acc0[tap]);
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const f32x4 v = bf_acc_ready(acc[3 * half + dx]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dst[dx * 256 + (4 * q + j) * 16 + n] = v[j];
+            for (int j = 0; j < 4; ++j) {
+                if (rw != 1) red[(rw == 0 ? 0 : 1) * 2304 + ti * 256 + (4 * q + j) * 16 + n] = v1[j];
+                if (rw != 0) red[(rw == 1 ? 2 : 3) * 2304 + ti * 256 + (4 * q + j) * 16 + n] = v0[j];
             }
         }
         h3_barrier();
+        for (int i = rw * 64 + lane; i < 2304; i += 192) {
+            a.wpartial1[(size_t)blockIdx.x * 2304 + i] = red[i] + red[2304 + i];
+            a.wpartial0[(size_t)blockIdx.x * 2304 + i] = red[2 * 2304 + i] + red[3 * 2304 + i];
+        }
         h3_barrier();
 }
 
@@ -805,7 +862,9 @@ __global__ __launch_bounds__(H3UGeom::NT, 3) void bwd_block_h3t_kernel(BwdBlockH
     if (role == 0) h3u_role_f(a, lane, rw);
     else if (role == 1) h3u_role_d2(a, lane, rw);
     else if (role == 2) h3u_role_d1<BNC>(a, lane, rw);
-    else h3u_role_w<BNC>(a, lane, rw);
+    else if (rw == 0) h3u_role_w<0>(a, lane);
+    else if (rw == 1) h3u_role_w<1>(a, lane);
+    else h3u_role_w<2>(a, lane);
 }
 
 static int h3u_nstrips(const int W) { return (W + H3UGeom::SW - 1) / H3UGeom::SW; }

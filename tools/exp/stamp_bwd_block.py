@@ -32,10 +32,10 @@ if d.sum() == 0:
 cyc, ticks = d[:, :, :3].sum(axis=2), d[:, :, 3]
 live = ticks > 0
 mhz = np.median(cyc[live] / ticks[live]) * 100
-nsteps = 64 + 9
+nsteps = 64 + 8
 print(f"cycles per wave: mean {cyc[live].mean():.0f} max {cyc.max():.0f}; in-kernel clock {mhz:.0f} MHz -> {cyc[live].mean() / mhz:.1f} us; {cyc[live].mean() / nsteps:.0f} cycles per step")
 names = ["matrix work", "memory duty", "barrier"]
-for role, wv in (("F  conv_0 + loads (3 A, 1 dc unit)", slice(0, 3)), ("D2 dgrad_1 + loads (2 dc units)", slice(3, 6)), ("D1 dgrad_0 + stores", slice(6, 9)), ("W  weight gradients + staged-row epilogue", slice(9, 12))):
+for role, wv in (("F  conv_0 + loads (3 A, 1 dc unit)", slice(0, 3)), ("D2 dgrad_1 + loads (2 dc units)", slice(3, 6)), ("D1 dgrad_0 + skip + sums + stores (loads g, C_{i-1})", slice(6, 9)), ("W  weight gradients", slice(9, 12))):
     dd = d[:, wv, :3]
     print(f"role {role}: {dd.sum(axis=2).mean() / nsteps:.0f} cycles per step")
     for k in range(3):
