@@ -720,6 +720,21 @@ def train_run(args, torch, bf, O, rank, local_rank, world, dist, steps, warmup, 
         dmax = (model.params - ref).abs().max().reshape(1).to(torch.float64)
         dist.all_reduce(dmax, op=dist.ReduceOp.MAX)
         replicas = float(dmax.item())
+    # the dominant kernel INSIDE real steps: option "timing" brackets every bwd_block_h3t_kernel launch with its own HIP-event pair
+    # on the launch stream (a debug-entry loop on the same tensors runs 20 % slower: there the 671 MB of operands never sit in the
+    # 256 MB Infinity Cache, in a step the gradient was written by the launch before)
+    live = None
+    if roofline:                                           # (every rank: the steps hold the collective)
+        import ctypes as C
+        from blind_image_denoising_amd import _native as N0
+        model.set_option("timing", 1)
+        for _ in range(max(min(steps, 10), 5)):
+            total, _, _, _, batch = trainer.step(*batch, overlap=lambda: prep(clean_dev))
+        torch.cuda.synchronize()
+        ms, ln = C.c_float(), C.c_int()
+        if N0.lib().bf_get_timing(model._h, C.byref(ms), C.byref(ln)) == 0 and int(ln.value) > 0:
+            live = (float(ms.value) * 1e3 / int(ln.value), int(ln.value))
+        model.set_option("timing", 0)
     exch = time_gradient_exchange(torch, bf, model, prep, clean_dev, world, dist) if exchange else None      # every rank takes part
     if trainer.comm is not None:
         trainer.comm.close()
@@ -747,7 +762,7 @@ def train_run(args, torch, bf, O, rank, local_rank, world, dist, steps, warmup, 
         rec["replicas_max_abs_param_diff"] = replicas
         rec["replicas_identical"] = replicas == 0.0
     if roofline:
-        rec["roofline"] = train_roofline(torch, N, model, layers, B, S)
+        rec["roofline"] = train_roofline(torch, N, model, layers, B, S, rec["block_kernels"], live)
     if parity:
         try:
             rec["parity"] = train_parity_crop(torch, bf, O, cfg, layers, f"cuda:{local_rank}")
@@ -787,13 +802,54 @@ def train_run(args, torch, bf, O, rank, local_rank, world, dist, steps, warmup, 
     return rec
 
 
-def train_roofline(torch, N, model, layers, B, S):
+def train_roofline(torch, N, model, layers, B, S, kernels="", live=None):
     """roofline of the training step's dominant kernel, timed live with HIP events on the launch stream through the C ABI's
-    single-kernel entry (the kernel + the 7 us reduction of its weight-gradient partials): the fused backward of a block's second
-    convolution -- BatchNorm-backward apply on load, weight gradient, masked data gradient (18 of the ~150 launches of a step, ~26 % of
-    its time; its sibling for a block's first convolution takes as long).  Algorithmic bytes: dy, conv_out and x read once, dx
-    written once (4 * 64 B per pixel)."""
+    single-kernel entry.  With the one-kernel block backward (bwd_block_h3t_kernel: BatchNorm backward on load, T recomputed, both
+    weight gradients, both data gradients, the skip's gradient and the next BatchNorm's sums; one launch per block, ~55 % of the step):
+    algorithmic bytes = A_i, g, C_i, C_{i-1} read once and dA' written once (5 * 64 B per pixel).  Otherwise (option / shape): the fused
+    backward of a block's second convolution, bwd3x3_h3_kernel<true, 8> (dy, conv_out and x read, dx written: 4 * 64 B per pixel)."""
     L = N.lib()
+    px = B * S * S
+    if "bwd_block_h3t_kernel" in kernels:
+        r = lambda *sh: torch.randn(*sh, device="cuda")
+        a, g, c, bnc = r(B, S, S, 16), r(B, S, S, 16) * 0.1, r(B, S, S, 16), r(B, S, S, 16)
+        coef = torch.cat([torch.ones(16), torch.full((16,), 0.1), torch.full((16,), 0.01)]).cuda()
+        w0, w1 = r(3, 3, 16, 16) * 0.1, r(3, 3, 16, 16) * 0.1
+        out, dw1, dw0, st = torch.empty_like(a), torch.empty(2304, device="cuda"), torch.empty(2304, device="cuda"), torch.empty(32, device="cuda")
+        scr = torch.empty(int(L.bf_debug_bwd_block_h3t_scratch_floats(B, S, S)), device="cuda")
+        calls = [0]
+
+        def run(flags):
+            N.check(L.bf_debug_bwd_block_h3t(N.ptr(a), N.ptr(g), N.ptr(c), N.ptr(coef), N.ptr(w0), N.ptr(w1), N.ptr(bnc), N.ptr(out), N.ptr(dw1),
+                                             N.ptr(dw0), N.ptr(st), N.ptr(scr), B, S, S, 1, flags | (calls[0] & 1), N.stream_ptr(a)), None, "bwd_block_h3t")
+            calls[0] += 1
+        run(0)                                             # packs the weights into the scratch
+        for _ in range(3):
+            run(2)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        nl = 20
+        e0.record()
+        for _ in range(nl):
+            run(2)                                         # the kernel alone, alternating walking directions as the step does
+        e1.record()
+        torch.cuda.synchronize()
+        alone_us = e0.elapsed_time(e1) * 1e3 / nl
+        launch_us, timed_launches = live if live is not None else (alone_us, nl)
+        nbytes = px * 64 * 5
+        gbs = nbytes / launch_us / 1e3
+        # matrix work: data + weight gradient of both convolutions = 4 * 4 608 FLOP per pixel algorithmic; issued on the f16 matrix pipe per
+        # row of a 128-column strip: 27 groups x 15 MFMAs (recomputed conv_0 and the two data gradients on the 144-column grid, 3 split
+        # products) + 216 MFMAs of the two weight gradients, 16 384 FLOP each
+        alg = px * 4 * 4608 / launch_us / 1e6
+        issued = px * (27 * 15 + 216) * 16384 / 128 / launch_us / 1e6
+        return {"bound": "hbm", "kernel": "bwd_block_h3t_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "traffic": pmc_traffic(layers, B, S, True, "bwd_block_h3t_kernel"), "algorithmic_bytes_per_launch": nbytes,
+                "launch_us": launch_us, "launches_of_this_kernel_per_step": layers, "launches_timed": timed_launches,
+                "timed": "one HIP-event pair per launch inside real training steps (option timing)" if live is not None else "single-kernel entry, back to back",
+                "launch_us_alone_cold_operands": alone_us,
+                "note": "the launch is bound by matrix / LDS issue at three waves per SIMD (stamps: profiles/r04_bwd_block_stamps.txt), not by HBM",
+                "mfma": {"dtype": "f16 (split hi/lo, 3 products)", "algorithmic_tflops": alg, "issued_tflops": issued,
+                         "peak_tflops": MFMA_F16_PEAK_TFLOPS, "issued_frac": issued / MFMA_F16_PEAK_TFLOPS}}
     xw = torch.relu(torch.randn((B, S, S, 16), device="cuda"))
     gw = torch.randn((B, S, S, 16), device="cuda") * 0.1
     cw = torch.randn((B, S, S, 16), device="cuda")
@@ -819,7 +875,7 @@ def train_roofline(torch, N, model, layers, B, S):
     e1.record()
     torch.cuda.synchronize()
     launch_us = e0.elapsed_time(e1) * 1e3 / nl
-    wbytes = B * S * S * 16 * 4 * 4
+    wbytes = px * 16 * 4 * 4
     gbs = wbytes / launch_us / 1e3
     return {"bound": "hbm", "kernel": "bwd3x3_h3_kernel<true, 8> (+ reduce_partials_kernel)", "achieved": gbs, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,

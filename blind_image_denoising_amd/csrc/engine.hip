@@ -1075,7 +1075,16 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
                 for (int k = 0; k < 3 && !out; ++k)
                     if (gbuf[k] != g) out = gbuf[k];
                 fa.out = out;
+                // option "timing": one HIP-event pair around EVERY launch of this kernel (ring of BF_TIMING_RING pairs; bf_get_timing
+                // returns their sum and count: bench.py's live roofline of the training step, measured inside real steps)
+                const int64_t tslot = h->timing ? h->n_timed % BF_TIMING_RING : 0;
+                if (h->timing) BF_HIP(hipEventRecord(h->ev[2 * tslot], s), "hipEventRecord");
                 BF_HIP(bf_launch_bwd_block_h3t(fa, s), "bwd_block_h3t");
+                if (h->timing) {
+                    BF_HIP(hipEventRecord(h->ev[2 * tslot + 1], s), "hipEventRecord");
+                    h->timed_launches = 1;
+                    ++h->n_timed;
+                }
                 g = out;
                 dA = out;
                 break;                                              // both convolutions done
@@ -1526,12 +1535,18 @@ extern "C" int bf_debug_bwd_block_h3t(const float* a_in, const float* g, const f
                                       const float* w1_hwio, const float* bnc, float* out, float* dw1, float* dw0, float* stats,
                                       float* scratch, int B, int H, int W, int relu, int reverse, void* stream)
 {
+    // reverse: bit 0 = walk the bands bottom-up; bit 1 = the KERNEL ALONE (weights packed by an earlier call with the same scratch, no
+    // reduction of the partials: bench.py's live timing of the launch)
     hipStream_t s = (hipStream_t)stream;
     if (!bf_bwd_block_h3t_supports(H, W)) return BF_EUNSUPPORTED;
+    const bool alone = (reverse & 2) != 0;
+    reverse &= 1;
     float* params = scratch + 4 * BF_H3_TRAIN_PACK_FLOATS;
-    if (hipMemcpyAsync(params, w0_hwio, 2304 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;
-    if (hipMemcpyAsync(params + 2304, w1_hwio, 2304 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;
-    if (bf_launch_pack_h3_train(params, 0, 4608 + 16, scratch, 1, 2, 2320, s) != hipSuccess) return BF_EHIP;
+    if (!alone) {
+        if (hipMemcpyAsync(params, w0_hwio, 2304 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;
+        if (hipMemcpyAsync(params + 2304, w1_hwio, 2304 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return BF_EHIP;
+        if (bf_launch_pack_h3_train(params, 0, 4608 + 16, scratch, 1, 2, 2320, s) != hipSuccess) return BF_EHIP;
+    }
     const int grid = bf_bwd_block_h3t_grid(B, H, W);
     float* wp1 = params + 2 * 2304 + 16;
     float* wp0 = wp1 + (int64_t)grid * 2304;
@@ -1543,6 +1558,7 @@ extern "C" int bf_debug_bwd_block_h3t(const float* a_in, const float* g, const f
     fa.wpartial1 = wp1; fa.wpartial0 = wp0; fa.stats = st;
     fa.B = B; fa.H = H; fa.W = W; fa.reverse = reverse; fa.act_relu = relu; fa.dbg = g_fused_dbg;
     if (bf_launch_bwd_block_h3t(fa, s) != hipSuccess) return BF_EHIP;
+    if (alone) return BF_OK;
     if (bf_launch_reduce_partials(wp1, grid, 2304, dw1, 1.0f, s) != hipSuccess) return BF_EHIP;
     if (bf_launch_reduce_partials(wp0, grid, 2304, dw0, 1.0f, s) != hipSuccess) return BF_EHIP;
     if (bnc && stats && bf_launch_reduce_partials(st, grid, 32, stats, 1.0f, s) != hipSuccess) return BF_EHIP;

@@ -58,7 +58,8 @@ int bf_debug_fwd_block_h3t(const float* x, const float* pre_c, const float* pre_
 /* the backward of one [3,3] block in one kernel, T recomputed from the block input (train_bwd_h3t.hip; tape.gradient of
    bfcnn/train_loop.py:273-294 through bfcnn/backbone_blocks.py:174-246): dc = coef[0:16] * g + coef[16:32] * c + coef[32:48],
    T = [relu] conv_0(a), dw1 = T^T dc, dT = dgrad_1(dc) [* (T > 0)], dw0 = a^T dT, out = dgrad_0(dT) + g, stats[32] = per-channel sums
-   of out | out * bnc (bnc not NULL). */
+   of out | out * bnc (bnc not NULL).  reverse: bit 0 = bands bottom-up, bit 1 = the kernel alone (weights packed by an earlier call on the
+   same scratch, partials not reduced: live timing of the launch). */
 int64_t bf_debug_bwd_block_h3t_scratch_floats(int batch, int height, int width);
 int bf_debug_bwd_block_h3t(const float* a, const float* g, const float* c, const float* coef, const float* w0_hwio, const float* w1_hwio,
                            const float* bnc, float* out, float* dw1, float* dw0, float* stats, float* scratch, int batch, int height,

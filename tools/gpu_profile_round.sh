@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 # fp32_b128 / fp32_b64: the exact-fp32 arithmetic at the bench batch and at the north star's batch (the ">= 60 % MFMA roofline" figure)
 declare -A ARGS=( [inference]="" [train]="--mode train" [unet]="--mode unet" [unet56]="--mode unet --unet-graph v5.6" [pyramid]="--mode pyramid"
                   [fp32_b128]="--arith 0 --no-sub-records" [fp32_b64]="--arith 0 --batch 64 --no-sub-records" [onepair0]="--opt h3_pair=0 --no-sub-records" )
-declare -A KERNEL=( [inference]="fused_block2_h3w_kernel" [train]="bwd3x3_h3_kernel" [unet]="uh_enc32u_kernel" [unet56]="uh_enc32u_kernel" [pyramid]="lap_split_kernel"
+declare -A KERNEL=( [inference]="fused_block2_h3w_kernel" [train]="bwd_block_h3t_kernel" [unet]="uh_enc32u_kernel" [unet56]="uh_enc32u_kernel" [pyramid]="lap_split_kernel"
                     [fp32_b128]="fused_block_v4_kernel" [fp32_b64]="fused_block_v4_kernel" [onepair0]="fused_block_h3v_kernel" )
 rc_all=0
 for m in "${modes[@]}"; do
@@ -31,6 +31,10 @@ for m in "${modes[@]}"; do
     if [ -z "$picked" ]; then echo "no kernel_stats.csv names ${KERNEL[$m]}"; rc_all=1; continue; fi
     cp "$picked" "$out/${tag}_${m}_kernel_stats.csv"
     head -n 6 "$out/${tag}_${m}_kernel_stats.csv" | cut -c1-160
+    # the summary's AverageNs includes the warm-up calls (cold caches, clocks ramping): the same kernel over the TIMED calls only --
+    # the last (steps x launches per step) of the trace -- with its median, next to it
+    trace="${picked%_kernel_stats.csv}_kernel_trace.csv"
+    [ -f "$trace" ] && python "$repo/tools/kstats_timed.py" "$trace" "${KERNEL[$m]}" > "$out/${tag}_${m}_kernel_timed.json" && cat "$out/${tag}_${m}_kernel_timed.json"
     rm -rf "$out/prof_$m"
 done
 exit $rc_all
