@@ -547,6 +547,125 @@ def cpu_unet_baseline_torch(spec, params, image_u8, budget_s=10.0, nthreads=None
                            f"{nthreads} threads; CPU restatement of the same graph, not TensorFlow; {dt * nrep:.1f} s)"}, **note)
 
 
+def generic_bench(args, torch, bf, O, rank, local_rank, world, dist):
+    """The one resnet configuration the reference ships (bfcnn/configs/resnet_color_1x6_bn_32x128x32_1x3x1_128x128_depthwise_l1_relu.json:
+    7x7 base 3->32, six blocks of 1x1 32->32 + ReLU, depthwise 3x3 x4 + BN + ReLU, grouped 1x1 128->32 + BN, Add; backbone_resnet.py:149-176)
+    through the generic operator path (resnet_generic.py; exact fp32 on the fp32 matrix cores): inference, batch 64, 256 x 256 uint8 ->
+    uint8 through DenoiserModule.__call__, random-init weights.  Images are independent: N ranks = N replicas, no collective."""
+    from oracle import resnet_generic_oracle as G
+    from blind_image_denoising_amd import _native as N
+    B, S = (64 if args.batch == 128 else args.batch), args.size
+    cfg = G.shipped_config()
+    spec = G.GenericResnetSpec.from_config(cfg)
+    params, state = G.init_params(spec, seed=42)
+    model = bf.model_builder(cfg, device=f"cuda:{local_rank}").hydra
+    model.set_weights(params, state)
+    module = bf.DenoiserModule(model)
+    _, base = O.synthetic_batch(4, S, S, sigma=20.0, seed=1234 + rank)
+    noisy = torch.from_numpy(np.concatenate([base] * ((B + 3) // 4), axis=0)[:B]).cuda()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(max(args.warmup, 1)):
+        out = module(noisy)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = module(noisy)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return
+    crop = base[:1, :64, :64]
+    ref = G.denoiser_module_call(spec, params, state, crop)
+    got = module(torch.from_numpy(np.ascontiguousarray(crop)).cuda()).cpu().numpy()
+    diff = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+    # dominant kernel, timed live with events on the launch stream through its C-ABI operator: depthwise 3x3 x4 (+ folded BN + ReLU) and
+    # the 1x1 128 -> 32 behind it in one kernel (uo_dwmult_pw_kernel: the 128-channel tensor never leaves the registers); six launches
+    # per forward.  Algorithmic bytes: 32-channel input read, 32-channel output written + the skip it adds = 3 * 128 B per pixel
+    L = N.lib()
+    px = B * S * S
+    x = torch.randn((B, S, S, 32), device="cuda")
+    res = torch.randn((B, S, S, 32), device="cuda")
+    y = torch.empty_like(x)
+    wd, b1 = torch.randn((3, 3, 32, 4), device="cuda") * 0.1, torch.randn(128, device="cuda") * 0.1
+    wp, b2 = torch.randn((128, 32), device="cuda") * 0.1, torch.randn(32, device="cuda") * 0.1
+    blk = lambda: N.check(L.bf_op_dwmult_pointwise(N.ptr(x), N.ptr(y), N.ptr(wd), N.ptr(b1), 1, 0.0, N.ptr(wp), N.ptr(b2), 0, 0.0, N.ptr(res),
+                                                    B, S, S, 32, 4, 3, 32, N.stream_ptr(x)), None, "bf_op_dwmult_pointwise")
+    for _ in range(3):
+        blk()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    nl = 20
+    e0.record()
+    for _ in range(nl):
+        blk()
+    e1.record()
+    torch.cuda.synchronize()
+    launch_us = e0.elapsed_time(e1) * 1e3 / nl
+    nbytes = px * 32 * 4 * 3
+    flop = px * (2.0 * 9 * 128 + 2.0 * 128 * 32)
+    per_px = 2.0 * 49 * 3 * 32 + 6 * (2.0 * 32 * 32 + 2.0 * 9 * 128 + 2.0 * 128 * 32) + 2.0 * (32 * 32 + 32 * 3)
+    value = world * B * args.steps / elapsed
+    rec = {
+        "metric": "denoised images/sec (256x256x3), shipped resnet bottleneck config", "value": value, "unit": "images/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"resnet_color_1x6_bn_32x128x32_1x3x1 (7x7 base, 1x1 -> depthwise 3x3 x4 -> grouped 1x1, BN, ReLU) inference, "
+                               f"batch={B}/GPU {S}x{S}x3 uint8->uint8 (DenoiserModule.__call__)", "batch_per_gpu": B,
+                   "parallelism": f"replicas x{world}, no collective"},
+        "parity": {"max_abs_lsb": int(diff.max()), "mean_abs_lsb": float(diff.mean()), "checked": "one 64x64 crop vs oracle/resnet_generic_oracle.py"},
+        "end_to_end_tflops": value / world * per_px * S * S / 1e12,
+        "roofline": {"bound": "mfma", "kernel": "uo_dwmult_pw_kernel<32, 4, 32, 3> (depthwise 3x3 x4 + BN + ReLU + 1x1 128 -> 32 + BN + Add; 6 launches per forward)",
+                     "achieved": flop / launch_us / 1e6, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / launch_us / 1e6 / MFMA_F32_PEAK_TFLOPS,
+                     "dtype": "f32", "traffic": None, "launch_us": launch_us, "algorithmic_gflop_per_launch": flop / 1e9,
+                     "hbm": {"achieved": nbytes / launch_us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / launch_us / 1e3 / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_launch": nbytes}}}
+    if not args.no_cpu_baseline:
+        # the same graph on torch-CPU fp32 with the host cores this process may use (oracle/resnet_generic_torch.py's forward: the
+        # restatement on torch.nn.functional ops), whole images; the fp64 NumPy oracle on the parity crop beside it
+        try:
+            rec["cpu_baseline"] = cpu_generic_baseline_torch(spec, params, state, base[:2], ref_crop=(crop, ref))
+        except Exception as e:
+            rec["cpu_baseline"] = {"note": f"torch-CPU leg failed: {str(e)[:200]}"}
+    print(json.dumps(rec), flush=True)
+
+
+def cpu_generic_baseline_torch(spec, params, state, images_u8, budget_s=10.0, nthreads=None, ref_crop=None):
+    import torch
+    from oracle import resnet_generic_torch as GT
+    if nthreads is None:
+        nthreads = host_cores()
+    torch.set_num_threads(int(nthreads))
+    P = GT.views(spec, torch.from_numpy(np.asarray(params, np.float32)))
+    St = GT.state_views(spec, torch.from_numpy(np.asarray(state, np.float32)))
+
+    def forward(u8):
+        with torch.no_grad():
+            y = GT.hydra(spec, P, St, torch.from_numpy(u8.astype(np.float32)), False)[0]
+            return torch.round(y).clamp(0, 255).to(torch.uint8).numpy()
+    note = {}
+    if ref_crop is not None:
+        c, r = ref_crop
+        note["max_abs_lsb_vs_oracle_on_the_parity_crop"] = int(np.abs(forward(c).astype(np.int32) - r.astype(np.int32)).max())
+    forward(images_u8)
+    t0 = time.perf_counter()
+    nrep = 0
+    while nrep < 1 or (time.perf_counter() - t0 < budget_s and nrep < 64):
+        forward(images_u8)
+        nrep += 1
+    dt = (time.perf_counter() - t0) / nrep
+    S = images_u8.shape[1]
+    return dict({"value": images_u8.shape[0] / dt, "unit": "images/s", "cores": int(nthreads), "kind": "port",
+                 "sample": f"{nrep} x {images_u8.shape[0]} {S}x{S}x3 uint8 images through oracle/resnet_generic_torch.py's forward in fp32 (torch-CPU "
+                           f"{torch.__version__}, {nthreads} threads; CPU restatement of the same graph, not TensorFlow; {dt * nrep:.1f} s)"}, **note)
+
+
 def latency_bench(args, torch, bf, O, rank, local_rank, world, dist):
     """configs[0]/[1] territory: single-image latency of DenoiserModule.__call__ (uint8 256x256x3 -> uint8), launched
     op by op on the stream and as ONE captured HIP graph (the C ABI neither allocates nor synchronises, so the whole call
@@ -680,6 +799,15 @@ def train_run(args, torch, bf, O, rank, local_rank, world, dist, steps, warmup, 
         k, v = kv.split("=")
         model.set_option(k, int(v))
     opt, _ = bf.optimizer_builder(cfg["train"]["optimizer"])
+    own_group = False
+    if getattr(args, "force_collective", False) and dist is None:
+        import socket
+        import torch.distributed as d1
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        d1.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        own_group, native_collective = True, "force"
     trainer = bf.DataParallelTrainer(model, bf.loss_function_builder(cfg["loss"]), opt, native_collective=native_collective)
     trainer.broadcast_parameters()
     clean, noisy = O.synthetic_batch(min(B, 8), S, S, sigma=20.0, seed=1234 + rank)
@@ -735,6 +863,12 @@ def train_run(args, torch, bf, O, rank, local_rank, world, dist, steps, warmup, 
         if N0.lib().bf_get_timing(model._h, C.byref(ms), C.byref(ln)) == 0 and int(ln.value) > 0:
             live = (float(ms.value) * 1e3 / int(ln.value), int(ln.value))
         model.set_option("timing", 0)
+    if own_group:
+        if trainer.comm is not None:
+            trainer.comm.close()
+            trainer.comm = None
+        import torch.distributed as d1
+        d1.destroy_process_group()
     exch = time_gradient_exchange(torch, bf, model, prep, clean_dev, world, dist) if exchange else None      # every rank takes part
     if trainer.comm is not None:
         trainer.comm.close()
@@ -1028,9 +1162,12 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT", help="bf_set_option on the model (A/B only)")
     ap.add_argument("--loss", choices=["l1", "shipped"], default="l1",
                     help="--mode train: l1 = BASELINE configs[3] (L1 only); shipped = L1 + RMSE + SSIM as the reference's configs")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="--mode train with one GPU: run the step's gradient all-reduce anyway, through the C ABI's communicator in a one-rank "
+                         "RCCL group (the two-stream trace of a data-parallel step, tools/dp_trace.py)")
     ap.add_argument("--unet-graph", choices=["v5", "v5.6"], default="v5",
                     help="--mode unet: v5 = snapshot builder graph, random weights; v5.6 = the reference's trained network")
-    ap.add_argument("--mode", choices=["inference", "train", "pyramid", "unet", "latency"], default="inference",
+    ap.add_argument("--mode", choices=["inference", "train", "pyramid", "unet", "latency", "generic"], default="inference",
                     help="train: BASELINE.json configs[3] -- one data-parallel training step per step (L1 loss, "
                          "batch sharded over the ranks, ONE gradient all-reduce, clip + Adam); not the headline metric")
     args = ap.parse_args()
@@ -1081,6 +1218,8 @@ def main():
         return unet_bench(args, torch, bf, O, rank, local_rank, world, dist)
     if args.mode == "latency":
         return latency_bench(args, torch, bf, O, rank, local_rank, world, dist)
+    if args.mode == "generic":
+        return generic_bench(args, torch, bf, O, rank, local_rank, world, dist)
     cfg = O.canonical_config(no_layers=args.layers)
     spec = O.ResnetSpec.from_config(cfg["model"])
     params, state = O.init_params(spec, seed=42, nontrivial_bn=True)

@@ -287,7 +287,9 @@ class DataParallelTrainer:
         self.model, self.optimizer, self.group = model, optimizer, group
         self.fns = build_train_functions(model, loss_fn_map)
         self.world_size = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        self.comm = NativeCommunicator(model.device, group) if (native_collective and self.world_size > 1) else None
+        # native_collective="force": the C ABI's collective even in a world of one (a one-rank RCCL group still launches its kernel on the
+        # communicator's stream: bench.py --force-collective, the two-stream trace of a step under profiles/)
+        self.comm = NativeCommunicator(model.device, group) if (native_collective == "force" or (native_collective and self.world_size > 1)) else None
 
     def broadcast_parameters(self, src: int = 0):
         import torch.distributed as dist
