@@ -101,12 +101,20 @@ extern "C" int bf_op_pack_mlp_h3(const float* w1, const float* w2, void* packed,
 // PRE = 1: the whole ConvNextBlock with a 1x1 depthwise convolution (the decoder blocks, decoder_kernel_size 1): `in` is
 // the block input x; t = LayerNorm(x * dw) * gamma is formed in registers (the 4 lanes (q, n) of a pixel hold all its
 // channels: two cross-row shuffles per reduction) and never written; skip = x.
+// PRE = 2 (C = 32; round 4): the FIRST decoder block of a level with the node in front of it formed while the pixels are loaded:
+// x = in + act_up(UpSampling2D(2, bilinear)(low)) (in = the encoder's skip map [B, OH, OW, C], low = the 1x1-projected map of the level
+// below [B, OH / 2, OW / 2, C]; backbone_unet_laplacian.py:438-568, upsampling.py:80-90) -- what uo_upsample_act_add_kernel wrote and this
+// kernel read back (2.1 GB of a batch-32 forward and one launch).  The residual needs x in the OUTPUT lane layout (tile t, lane q:
+// channels 16 t + 4 q ..): it is fetched from the lanes that hold it in the input layout (lane 2 t + (q >> 1), half q & 1) with
+// ds_bpermute instead of being re-read.
 template <int C, int NP, int ACT, int NT, int PRE>
 __global__ __launch_bounds__(NT, 512 / NT) void uh_mlp_kernel(const float* __restrict__ in, const float* __restrict__ skip, float* __restrict__ out,
                                                     const void* __restrict__ packed, const float* __restrict__ mult, int64_t npix,
                                                     float alpha, const float* __restrict__ dw, const float* __restrict__ gamma,
-                                                    float eps)
+                                                    float eps, const float* __restrict__ low = nullptr, int OH = 0, int OW = 0, int act_up = 0,
+                                                    float alpha_up = 0.f)
 {
+    static_assert(PRE != 2 || C == 32, "the fused up-sampling form is built for 32 channels");
     constexpr int KC1 = C / 32, T1 = 4 * C / 16, KC2 = 4 * C / 32, T2 = C / 16;
     constexpr int W1_BYTES = KC1 * T1 * 2 * 1024, W2_BYTES = KC2 * T2 * 2 * 1024;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -142,6 +150,7 @@ __global__ __launch_bounds__(NT, 512 / NT) void uh_mlp_kernel(const float* __res
     // raw input of the NEXT group is requested as soon as the current one has been converted: its latency hides behind
     // the matrix work of the current group instead of sitting in front of it
     f32x4 xr[NP][KC1][2];
+    f32x4 tap[PRE == 2 ? NP : 1][PRE == 2 ? 4 : 1][2];          // PRE = 2: the four low-resolution taps of every pixel (C = 32: one chunk)
     auto load_raw = [&](int64_t gg) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -152,6 +161,25 @@ __global__ __launch_bounds__(NT, 512 / NT) void uh_mlp_kernel(const float* __res
             for (int c = 0; c < KC1; ++c)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) xr[i][c][u] = *reinterpret_cast<const f32x4*>(src + 32 * c + 4 * u);
+            if (PRE == 2) {
+                // output pixel (b, oy, ox) -> its 2 x 2 low-resolution taps (tf.image.resize half-pixel centres at factor 2: weights
+                // 0.75 / 0.25, indices clamped to the map: uo_upsample_act_add_kernel's expression)
+                const int LH = OH >> 1, LW = OW >> 1;
+                const int hw = OH * OW;
+                const int b = (int)(p / hw), r = (int)(p - (int64_t)b * hw);
+                const int oy = r / OW, ox = r - oy * OW;
+                const int iy = oy >> 1, ix = ox >> 1;
+                const int y1 = (oy & 1) ? min(iy + 1, LH - 1) : max(iy - 1, 0);
+                const int x1 = (ox & 1) ? min(ix + 1, LW - 1) : max(ix - 1, 0);
+                const float* lb = low + (int64_t)b * LH * LW * C + 8 * q;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    tap[i][0][u] = *reinterpret_cast<const f32x4*>(lb + ((int64_t)iy * LW + ix) * C + 4 * u);
+                    tap[i][1][u] = *reinterpret_cast<const f32x4*>(lb + ((int64_t)iy * LW + x1) * C + 4 * u);
+                    tap[i][2][u] = *reinterpret_cast<const f32x4*>(lb + ((int64_t)y1 * LW + ix) * C + 4 * u);
+                    tap[i][3][u] = *reinterpret_cast<const f32x4*>(lb + ((int64_t)y1 * LW + x1) * C + 4 * u);
+                }
+            }
         }
     };
     if (wave < ngroups) load_raw(wave);
@@ -164,8 +192,19 @@ __global__ __launch_bounds__(NT, 512 / NT) void uh_mlp_kernel(const float* __res
         const char* w1l = lds + wl;
         const char* w2l = lds + W1_BYTES + wl;
         uh8 xh[KC1][NP], xl[KC1][NP];
+        f32x4 xv[PRE == 2 ? NP : 1][2];                          // PRE = 2: the block input x (input lane layout), kept for the residual
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
+            if (PRE == 2) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    f32x4 r = 0.75f * (0.75f * tap[i][0][u] + 0.25f * tap[i][2][u]) + 0.25f * (0.75f * tap[i][1][u] + 0.25f * tap[i][3][u]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) r[j] = act_up == 1 ? fmaxf(r[j], 0.f) : (act_up == 2 ? (r[j] > 0.f ? r[j] : alpha_up * r[j]) : r[j]);
+                    xr[i][0][u] += r;
+                    xv[i][u] = xr[i][0][u];
+                }
+            }
             if (PRE) {
                 f32x4 v[KC1][2];
                 float sum = 0.f;
@@ -206,7 +245,20 @@ __global__ __launch_bounds__(NT, 512 / NT) void uh_mlp_kernel(const float* __res
         __builtin_amdgcn_sched_barrier(0);
         if (g + nwaves < ngroups) load_raw(g + nwaves);
         f32x4 sk[T2][NP];
-        if (skip) {
+        if (PRE == 2) {
+            // output tile t, lane (q, n): channels 16 t + 4 q .. + 3 = half (q & 1) of input-layout lane (2 t + (q >> 1), n)
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+#pragma unroll
+                for (int t = 0; t < T2; ++t) {
+                    const int srcl = 16 * (2 * t + (q >> 1)) + n;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float a0 = __shfl(xv[i][0][j], srcl, 64), a1 = __shfl(xv[i][1][j], srcl, 64);
+                        sk[t][i][j] = (q & 1) ? a1 : a0;
+                    }
+                }
+        } else if (skip) {
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 int64_t p = p0 + 16 * i + n;
@@ -226,7 +278,7 @@ __global__ __launch_bounds__(NT, 512 / NT) void uh_mlp_kernel(const float* __res
             for (int t = 0; t < T2; ++t) {
                 f32x4 v = bf_acc_ready(acc2[t][i]) * m4[t];
                 const int co = 16 * t + 4 * q;
-                if (skip) v += sk[t][i];
+                if (PRE == 2 || skip) v += sk[t][i];
                 *reinterpret_cast<f32x4*>(out + p * C + co) = v;
             }
         }
@@ -235,7 +287,8 @@ __global__ __launch_bounds__(NT, 512 / NT) void uh_mlp_kernel(const float* __res
 
 template <int C, int NP, int NT, int PRE>
 static hipError_t uh_launch(const float* in, const float* skip, float* out, const void* packed, const float* mult, int64_t npix, int act,
-                            float alpha, const float* dw, const float* gamma, float eps, hipStream_t s)
+                            float alpha, const float* dw, const float* gamma, float eps, hipStream_t s, const float* low = nullptr, int OH = 0,
+                            int OW = 0, int act_up = 0, float alpha_up = 0.f)
 {
     constexpr int LDS = 32 * C * C;
     const int64_t ngroups = (npix + 16 * NP - 1) / (16 * NP);
@@ -250,7 +303,7 @@ static hipError_t uh_launch(const float* in, const float* skip, float* out, cons
             if (e != hipSuccess) return e;                                                                                    \
         }                                                                                                                     \
         hipLaunchKernelGGL((uh_mlp_kernel<C, NP, A, NT, PRE>), dim3((int)grid), dim3(NT), LDS, s, in, skip, out, packed, mult, npix,   \
-                           alpha, dw, gamma, eps);                                                                            \
+                           alpha, dw, gamma, eps, low, OH, OW, act_up, alpha_up);                                             \
     }
     switch (act) {
     case 0: UH_LAUNCH(0) break;
@@ -274,6 +327,22 @@ extern "C" int bf_op_convnext_mlp_h3(const float* in, const float* skip, float* 
     if (C == 32) e = uh_launch<32, UH_NP32, 256, 0>(in, skip, out, packed, mult, npix, act, alpha, nullptr, nullptr, 0.f, s);
     else if (C == 64) e = uh_launch<64, UH_NP64, 512, 0>(in, skip, out, packed, mult, npix, act, alpha, nullptr, nullptr, 0.f, s);
     else return BF_EUNSUPPORTED;
+    if (e == hipErrorInvalidValue) return BF_EINVAL;
+    return e == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// the first decoder block of a level, its input formed on load: x = enc + act_up(UpSampling2D(2, bilinear)(low)), out = x + ConvNextBlock(x)
+// (1x1 depthwise, C = 32).  enc [B, OH, OW, 32], low [B, OH / 2, OW / 2, 32]; act_up: 0 linear, 1 relu, 2 leaky relu (alpha_up)
+extern "C" int bf_op_convnext_block1_up_h3(const float* enc, const float* low, float* out, const float* dw, const float* ln_gamma, float eps,
+                                           const void* packed, const float* mult, int B, int OH, int OW, int C, int act, float alpha,
+                                           int act_up, float alpha_up, void* stream)
+{
+    if (!enc || !low || !out || !dw || !packed || B <= 0 || OH <= 0 || OW <= 0) return BF_EINVAL;
+    if (C != 32 || (OH & 1) || (OW & 1) || act_up < 0 || act_up > 2 || (int64_t)B * OH * OW >= ((int64_t)1 << 31)) return BF_EUNSUPPORTED;
+    if (((uintptr_t)enc | (uintptr_t)low | (uintptr_t)out | (uintptr_t)packed | (uintptr_t)mult | (uintptr_t)dw | (uintptr_t)ln_gamma) % 16) return BF_EINVAL;
+    if (act == 2 && !(alpha >= 0.f && alpha <= 1.f)) return BF_EINVAL;
+    const hipError_t e = uh_launch<32, UH_NP32, 256, 2>(enc, nullptr, out, packed, mult, (int64_t)B * OH * OW, act, alpha, dw, ln_gamma, eps,
+                                                        (hipStream_t)stream, low, OH, OW, act_up, alpha_up);
     if (e == hipErrorInvalidValue) return BF_EINVAL;
     return e == hipSuccess ? BF_OK : BF_EHIP;
 }

@@ -111,6 +111,21 @@ def convnext_block1_h3(x: torch.Tensor, dw: torch.Tensor, gamma: Optional[torch.
     return out
 
 
+def convnext_block1_up_h3(enc: torch.Tensor, low: torch.Tensor, dw: torch.Tensor, gamma: Optional[torch.Tensor], packed: torch.Tensor,
+                          mult: Optional[torch.Tensor], act: str, act_up: str = "linear", eps: float = LN_EPSILON) -> torch.Tensor:
+    """x = enc + act_up(bilinear 2x of low); x + ConvNextBlock(x) (1x1 depthwise, 32 channels): upsample_act_add and
+    convnext_block1_h3 as one kernel -- x is never written."""
+    B, OH, OW, C = enc.shape
+    if tuple(low.shape) != (B, OH // 2, OW // 2, C) or OH % 2 or OW % 2:
+        raise ValueError(f"low-resolution map {tuple(low.shape)} does not sit under {tuple(enc.shape)}")
+    out = torch.empty_like(enc)
+    code, a = _act(act)
+    ucode, ua = _act(act_up)
+    _call("bf_op_convnext_block1_up_h3", N.ptr(enc), N.ptr(low), N.ptr(out), N.ptr(dw), N.ptr(gamma), eps, N.ptr(packed), N.ptr(mult),
+          B, OH, OW, C, code, a, ucode, ua, N.stream_ptr(enc))
+    return out
+
+
 def convnext_block_h3(x: torch.Tensor, dw: torch.Tensor, gamma: Optional[torch.Tensor], packed: torch.Tensor,
                       mult: Optional[torch.Tensor], act: str, eps: float = LN_EPSILON) -> torch.Tensor:
     """x + ConvNextBlock(x) for a 32-channel block with a k x k depthwise convolution (dw [k,k,C], k = 3 | 5), one kernel."""
@@ -341,9 +356,9 @@ class UnetLaplacianHydra:
         return False
 
     def set_option(self, key: str, value: int):
-        if key != "arith" or int(value) not in (0, 1):
+        if key not in ("arith", "fuse_up_block") or int(value) not in (0, 1):
             raise ValueError(f"unknown option {key}={value}")
-        self.arith = int(value)
+        setattr(self, key, int(value))
         self.version = getattr(self, "version", 0) + 1
 
     def __init__(self, config: Dict, device=None, seed: Optional[int] = None):
@@ -447,6 +462,9 @@ class UnetLaplacianHydra:
         # 1: ConvNext MLPs with 32 / 64 channels on the f16 matrix cores with split-f16 operands (csrc/unet_h3.hip);
         # 0: every GEMM in exact fp32 (csrc/unet_ops.hip).  Same tests, same bars.
         self.arith = 1
+        # 1: a level's first decoder block forms its input enc + act(up(low)) while loading it (32 channels, 1x1 depthwise:
+        # bf_op_convnext_block1_up_h3); 0: upsample_act_add writes the node and the block reads it back.  Same bits either way.
+        self.fuse_up_block = 1
         self._inventory = self._build_inventory()
         self.n_params = sum(int(np.prod(s)) for _, s, _ in self._inventory)
         self.params = torch.from_numpy(self._initial_values(seed)).to(self.device)
@@ -649,6 +667,20 @@ class UnetLaplacianHydra:
         if self.device.type != "cuda":
             raise RuntimeError("unet_laplacian inference needs the GPU: there is no CPU execution path")
 
+    def _fused_up_block(self, P, d: int, C: int, skip, low: torch.Tensor, up_act: str) -> bool:
+        """the node enc + act(up(low)) can be formed inside the level's first decoder block (bf_op_convnext_block1_up_h3): 32 channels,
+        split-f16 MLP, 1x1 depthwise, nothing between the Add and the block (no gate, no Concatenate, no mix projection)"""
+        prefix = f"dec{d}_0"
+        return bool(self.fuse_up_block and skip is not None and C == 32 and self.arith == 1 and self.width >= 1
+                    and not self.use_mix_project and f"{prefix}/mlp_h3" in P and P[f"{prefix}/dw/kernel"].shape[0] == 1
+                    and _act(up_act)[0] in (0, 1, 2) and low.shape[1] * 2 == skip.shape[1] and low.shape[2] * 2 == skip.shape[2])
+
+    def _convnext_up(self, P, prefix: str, enc: torch.Tensor, low: torch.Tensor, up_act: str) -> torch.Tensor:
+        mult = P.get(f"{prefix}/gamma/w") if self.use_gamma else None
+        gamma = P.get(f"{prefix}/ln/gamma") if self.use_ln else None
+        return convnext_block1_up_h3(enc, low, P[f"{prefix}/dw/kernel"].view(-1), gamma, P[f"{prefix}/mlp_h3"], mult, self.mlp_activation,
+                                     up_act)
+
     def _convnext(self, P, prefix: str, x: torch.Tensor) -> torch.Tensor:
         mult = P.get(f"{prefix}/gamma/w") if self.use_gamma else None
         gamma = P.get(f"{prefix}/ln/gamma") if self.use_ln else None
@@ -745,11 +777,16 @@ class UnetLaplacianHydra:
             C = self.level_filters(d)
             # gated: the Add happens in the gate kernel; Concatenate: the up-sampled map stays on its own
             skip = None if (self.use_attention_gates or self.use_concat) else nodes[d]
+            first_done = 0                                                 # 1: block dec{d}_0 already ran, fused with the up-sampling
             if self.upsample_type == "upsample_laplacian_conv2d":
                 # 1x1 and the bilinear resize are both linear: the 1x1 runs on the low-resolution map (1/4 of the work;
                 # upsampling.py:80-90 makes the same exchange itself when the activation is linear)
                 low = pointwise(low, P[f"up{d}/kernel"], C, "linear")
-                f = upsample_act_add(low, skip, "linear" if self.upsample_linear else a)
+                up_act = "linear" if self.upsample_linear else a
+                if self._fused_up_block(P, d, C, skip, low, up_act):
+                    f, first_done = self._convnext_up(P, f"dec{d}_0", skip, low, up_act), 1
+                else:
+                    f = upsample_act_add(low, skip, up_act)
             elif self.upsample_type in ("upsample_bilinear_conv2d", "upsample_nearest_conv2d"):
                 from .pyramid import upsample_2x                           # UpSampling2D, then Conv2D 3x3 + activation
                 up = upsample_2x(low, bilinear=self.upsample_type == "upsample_bilinear_conv2d")
@@ -758,7 +795,9 @@ class UnetLaplacianHydra:
                 if low.shape[-1] != nodes[d].shape[-1]:
                     raise ValueError(f"Add of [{nodes[d].shape[-1]}] and [{low.shape[-1]}] channels: upsample_type "
                                      f"[{self.upsample_type}] needs equal filters on both levels")
-                if self.upsample_type == "bilinear":
+                if self.upsample_type == "bilinear" and self._fused_up_block(P, d, C, skip, low, "linear"):
+                    f, first_done = self._convnext_up(P, f"dec{d}_0", skip, low, "linear"), 1
+                elif self.upsample_type == "bilinear":
                     f = upsample_act_add(low, skip, "linear")
                 else:
                     from .pyramid import upsample_2x
@@ -771,7 +810,7 @@ class UnetLaplacianHydra:
                 o = pointwise_ex(dwconv_ln(up, None, P.get(f"gate{d}/x_ln/gamma")) if self.use_ln else up, P[f"gate{d}/x/kernel"], C,
                                  1, "leaky_relu_01", res=y)
                 f = pointwise_ex(o, P[f"gate{d}/o/kernel"], C, 2, mult=P[f"gate{d}/scale/w"], res=enc, add=up)
-            first = 0
+            first = first_done
             if self.use_concat and self.use_mix_project:
                 # act(Concatenate([enc, up]) . W) = act(enc . W[:C] + up . W[C:])
                 t = pointwise(nodes[d], P[f"mix{d}/a"], C, "linear")

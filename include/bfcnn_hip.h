@@ -261,6 +261,13 @@ int bf_op_convnext_mlp_h3(const float* in, const float* skip, float* out, const 
  * out = x + mult * (act(LayerNormalization(x * dw) * ln_gamma . w1) . w2); dw [C], ln_gamma [C] or NULL. */
 int bf_op_convnext_block1_h3(const float* x, float* out, const float* dw, const float* ln_gamma, float eps, const void* packed,
                              const float* mult, int64_t npix, int channels, int act, float alpha, void* stream);
+/* The first decoder block of a level with the node in front of it formed while its pixels are loaded (32 channels, 1x1 depthwise):
+ * x = enc + act_up(UpSampling2D(2, "bilinear")(low)); out = x + ConvNextBlock(x)  (backbone_unet_laplacian.py:438-568, upsampling.py:80-90:
+ * replaces bf_op_upsample_act_add followed by bf_op_convnext_block1_h3, bit for bit).  enc, out [B, OH, OW, 32]; low [B, OH/2, OW/2, 32];
+ * OH, OW even; act_up 0 linear / 1 relu / 2 leaky relu (alpha_up).  BF_EUNSUPPORTED for other channel counts or odd sizes. */
+int bf_op_convnext_block1_up_h3(const float* enc, const float* low, float* out, const float* dw, const float* ln_gamma, float eps,
+                                const void* packed, const float* mult, int batch, int out_height, int out_width, int channels, int act,
+                                float alpha, int act_up, float alpha_up, void* stream);
 /* A whole encoder ConvNextBlock (k x k depthwise, k = 3 or 5, 32 channels) plus the residual Add, one kernel
  * (custom_layers.py:975-1008; backbone_unet_laplacian.py:336-354):
  * out = x + mult * (act(LayerNormalization(DepthwiseConv2D_kxk(x)) * ln_gamma . w1) . w2); dw [k][k][C]; out != x. */

@@ -95,6 +95,45 @@ def test_convnext_block_with_1x1_depthwise_in_one_kernel(C, npix, use_ln):
     assert_close(host(got), ref, rel=5e-5, what="block1 h3")
 
 
+@pytest.mark.parametrize("shape", [(1, 2, 2), (1, 4, 6), (2, 10, 14), (1, 34, 62), (3, 64, 64), (1, 2, 130)])
+@pytest.mark.parametrize("act_up", ["linear", "relu", "leaky_relu"])
+@pytest.mark.parametrize("use_ln", [True, False])
+def test_first_decoder_block_forms_its_node_on_load(shape, act_up, use_ln):
+    """bf_op_convnext_block1_up_h3 = bf_op_upsample_act_add then bf_op_convnext_block1_h3, bit for bit (the same expressions in the same
+    order), and both against the fp64 restatement"""
+    B, OH, OW = shape
+    C = 32
+    r = _rng(OH * 7 + OW + B)
+    enc = r.normal(size=(B, OH, OW, C)) * 1.5
+    low = r.normal(size=(B, OH // 2, OW // 2, C)) * 2 - 0.2
+    dw, g = r.normal(size=(1, 1, C, 1)), r.uniform(0.5, 1.5, C)
+    w1, w2 = r.normal(size=(1, 1, C, 4 * C)) / np.sqrt(C), r.normal(size=(1, 1, 4 * C, C)) / np.sqrt(4 * C)
+    mult = r.uniform(0.2, 1.0, C)
+    pk = UL.pack_mlp_h3(dev(w1.reshape(C, 4 * C)), dev(w2.reshape(4 * C, C)))
+    gd = dev(g) if use_ln else None
+    node = UL.upsample_act_add(dev(low), dev(enc), act_up)
+    two = UL.convnext_block1_h3(node, dev(dw.reshape(C)), gd, pk, dev(mult), "leaky_relu_01")
+    one = UL.convnext_block1_up_h3(dev(enc), dev(low), dev(dw.reshape(C)), gd, pk, dev(mult), "leaky_relu_01", act_up)
+    assert np.array_equal(host(one), host(two)), f"max |fused - two kernels| = {np.abs(host(one) - host(two)).max():.3e}"
+    x = enc + U.act(U.resize_bilinear(low, OH, OW), act_up)
+    t = U.depthwise_same(x, dw)
+    if use_ln:
+        t = U.layer_norm(t, g)
+    ref = x + mult * O.conv2d_same(U.act(O.conv2d_same(t, w1), "leaky_relu_01"), w2)
+    assert_close(host(one), ref, rel=5e-5, what="fused first decoder block")
+
+
+def test_first_decoder_block_operator_refuses_what_it_was_not_built_for():
+    x = torch.zeros((1, 4, 4, 64), device="cuda")
+    low = torch.zeros((1, 2, 2, 64), device="cuda")
+    pk = torch.zeros(UL.N.lib().bf_op_mlp_h3_pack_bytes(64), dtype=torch.uint8, device="cuda")
+    with pytest.raises(Exception):
+        UL.convnext_block1_up_h3(x, low, torch.ones(64, device="cuda"), None, pk, None, "relu")          # 64 channels
+    x32, pk32 = torch.zeros((1, 3, 4, 32), device="cuda"), torch.zeros(UL.N.lib().bf_op_mlp_h3_pack_bytes(32), dtype=torch.uint8, device="cuda")
+    with pytest.raises(ValueError):
+        UL.convnext_block1_up_h3(x32, torch.zeros((1, 1, 2, 32), device="cuda"), torch.ones(32, device="cuda"), None, pk32, None, "relu")
+
+
 @pytest.mark.parametrize("variant", [4, 3, 2, 1, 0], ids=["two-consumers-per-simd", "two-workgroups-per-cu", "wave-specialised-unrolled", "wave-specialised", "single-role"])
 @pytest.mark.parametrize("k", [3, 5])
 @pytest.mark.parametrize("shape", [(1, 1, 1), (1, 16, 32), (2, 20, 37), (1, 7, 70), (1, 64, 64), (1, 33, 8), (3, 48, 96)])
@@ -346,6 +385,18 @@ def test_v5_hydra_all_scales_match_oracle(shape, arith):
     assert len(got) == 3
     for g, r in zip(got, ref):
         _check_f32(g, r)
+
+
+def test_v5_hydra_same_bits_with_and_without_the_fused_first_decoder_block():
+    cfg, spec, params, m = _model(arith=1)
+    _, noisy = O.synthetic_batch(2, 64, 96, seed=5)
+    x = noisy.astype(np.float32)
+    assert m.fuse_up_block == 1
+    fused = [np.array(t) for t in m(x)]
+    m.set_option("fuse_up_block", 0)
+    plain = [np.array(t) for t in m(x)]
+    for a, b in zip(fused, plain):
+        assert np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("bb", [dict(use_self_attention=False, depth=2), dict(use_laplacian_averaging=False),
