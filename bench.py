@@ -586,18 +586,20 @@ def generic_bench(args, torch, bf, O, rank, local_rank, world, dist):
     ref = G.denoiser_module_call(spec, params, state, crop)
     got = module(torch.from_numpy(np.ascontiguousarray(crop)).cuda()).cpu().numpy()
     diff = np.abs(got.astype(np.int32) - ref.astype(np.int32))
-    # dominant kernel, timed live with events on the launch stream through its C-ABI operator: depthwise 3x3 x4 (+ folded BN + ReLU) and
-    # the 1x1 128 -> 32 behind it in one kernel (uo_dwmult_pw_kernel: the 128-channel tensor never leaves the registers); six launches
-    # per forward.  Algorithmic bytes: 32-channel input read, 32-channel output written + the skip it adds = 3 * 128 B per pixel
+    # dominant kernel, timed live with events on the launch stream through its C-ABI operator: the whole bottleneck block (1x1 32 -> 32,
+    # depthwise 3x3 x4 + folded BN + ReLU, 1x1 128 -> 32 + folded BN + Add) in one kernel, ug_bneck_kernel (csrc/generic_h3.hip; split-f16
+    # GEMMs, the 128-channel tensor never leaves the registers); six launches per forward.  Algorithmic bytes: the 32-channel map read
+    # once (it is also the skip) and written once = 2 * 128 B per pixel.  Matrix work counted as issued: 3 f16 products per fp32 one.
     L = N.lib()
     px = B * S * S
     x = torch.randn((B, S, S, 32), device="cuda")
-    res = torch.randn((B, S, S, 32), device="cuda")
     y = torch.empty_like(x)
-    wd, b1 = torch.randn((3, 3, 32, 4), device="cuda") * 0.1, torch.randn(128, device="cuda") * 0.1
-    wp, b2 = torch.randn((128, 32), device="cuda") * 0.1, torch.randn(32, device="cuda") * 0.1
-    blk = lambda: N.check(L.bf_op_dwmult_pointwise(N.ptr(x), N.ptr(y), N.ptr(wd), N.ptr(b1), 1, 0.0, N.ptr(wp), N.ptr(b2), 0, 0.0, N.ptr(res),
-                                                    B, S, S, 32, 4, 3, 32, N.stream_ptr(x)), None, "bf_op_dwmult_pointwise")
+    from blind_image_denoising_amd import unet_laplacian as UL
+    pk = UL.pack_bneck_h3(torch.randn((32, 32), device="cuda") * 0.2, torch.randn((3, 3, 32, 4), device="cuda") * 0.1,
+                          torch.randn((128, 32), device="cuda") * 0.1)
+    b1, b2 = torch.randn(128, device="cuda") * 0.1, torch.randn(32, device="cuda") * 0.1
+    blk = lambda: N.check(L.bf_op_bneck_block_h3(N.ptr(x), N.ptr(y), N.ptr(pk), None, 1, 0.0, N.ptr(b1), 1, 0.0, N.ptr(b2), 1, 0.0, 1, B, S, S,
+                                                  N.stream_ptr(x)), None, "bf_op_bneck_block_h3")
     for _ in range(3):
         blk()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -608,24 +610,28 @@ def generic_bench(args, torch, bf, O, rank, local_rank, world, dist):
     e1.record()
     torch.cuda.synchronize()
     launch_us = e0.elapsed_time(e1) * 1e3 / nl
-    nbytes = px * 32 * 4 * 3
-    flop = px * (2.0 * 9 * 128 + 2.0 * 128 * 32)
+    nbytes = px * 32 * 4 * 2
+    flop = px * (2.0 * 32 * 32 + 2.0 * 9 * 128 + 2.0 * 128 * 32)
+    issued = px * 3 * (2.0 * 32 * 32 * (340.0 / 256.0) + 2.0 * 128 * 32)          # split-f16 products, the leading 1x1 on the haloed tile
     per_px = 2.0 * 49 * 3 * 32 + 6 * (2.0 * 32 * 32 + 2.0 * 9 * 128 + 2.0 * 128 * 32) + 2.0 * (32 * 32 + 32 * 3)
     value = world * B * args.steps / elapsed
     rec = {
         "metric": "denoised images/sec (256x256x3), shipped resnet bottleneck config", "value": value, "unit": "images/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 (block 1x1 convolutions: f16x2 split hi+lo, fp32 accumulate)", "data": "synthetic",
         "config": {"workload": f"resnet_color_1x6_bn_32x128x32_1x3x1 (7x7 base, 1x1 -> depthwise 3x3 x4 -> grouped 1x1, BN, ReLU) inference, "
                                f"batch={B}/GPU {S}x{S}x3 uint8->uint8 (DenoiserModule.__call__)", "batch_per_gpu": B,
                    "parallelism": f"replicas x{world}, no collective"},
         "parity": {"max_abs_lsb": int(diff.max()), "mean_abs_lsb": float(diff.mean()), "checked": "one 64x64 crop vs oracle/resnet_generic_oracle.py"},
         "end_to_end_tflops": value / world * per_px * S * S / 1e12,
-        "roofline": {"bound": "mfma", "kernel": "uo_dwmult_pw_kernel<32, 4, 32, 3> (depthwise 3x3 x4 + BN + ReLU + 1x1 128 -> 32 + BN + Add; 6 launches per forward)",
-                     "achieved": flop / launch_us / 1e6, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / launch_us / 1e6 / MFMA_F32_PEAK_TFLOPS,
-                     "dtype": "f32", "traffic": None, "launch_us": launch_us, "algorithmic_gflop_per_launch": flop / 1e9,
-                     "hbm": {"achieved": nbytes / launch_us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / launch_us / 1e3 / HBM_PEAK_GBS,
-                             "algorithmic_bytes_per_launch": nbytes}}}
+        "roofline": {"bound": "hbm", "kernel": "ug_bneck_kernel (1x1 32 -> 32 + depthwise 3x3 x4 + BN + ReLU + 1x1 128 -> 32 + BN + Add; 6 launches per forward)",
+                     "achieved": nbytes / launch_us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / launch_us / 1e3 / HBM_PEAK_GBS,
+                     "dtype": "f16x2 split operands, fp32 accumulate; depthwise in fp32", "traffic": None, "launch_us": launch_us,
+                     "algorithmic_bytes_per_launch": nbytes,
+                     "mfma": {"issued_tflops": issued / launch_us / 1e6, "peak": MFMA_F16_PEAK_TFLOPS, "frac": issued / launch_us / 1e6 / MFMA_F16_PEAK_TFLOPS,
+                              "useful_gflop_per_launch": flop / 1e9},
+                     "valu": {"depthwise_fma_per_launch": px * 9.0 * 128, "note": "fp32 FMAs of the depthwise on the vector ALU: 36 v_pk_fma_f32 "
+                              "per pixel group and chunk; the kernel's longest pipe (DESIGN.md 4.6)"}}}
     if not args.no_cpu_baseline:
         # the same graph on torch-CPU fp32 with the host cores this process may use (oracle/resnet_generic_torch.py's forward: the
         # restatement on torch.nn.functional ops), whole images; the fp64 NumPy oracle on the parity crop beside it

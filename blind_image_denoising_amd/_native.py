@@ -84,6 +84,9 @@ SIGNATURES = {
     "bf_op_smooth_split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "bf_op_conv2d": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "bf_op_dwconv_mult": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "bf_op_bneck_h3_pack_bytes": (C.c_int64, []),
+    "bf_op_pack_bneck_h3": (_I, [_P, _P, _P, _P, _P]),
+    "bf_op_bneck_block_h3": (_I, [_P, _P, _P, _P, _I, _F, _P, _I, _F, _P, _I, _F, _I, _I, _I, _I, _P]),
     "bf_op_dwmult_pointwise": (_I, [_P, _P, _P, _P, _I, _F, _P, _P, _I, _F, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "bf_op_maxpool2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "bf_op_maxpool2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
@@ -94,6 +97,7 @@ SIGNATURES = {
     "bf_op_attention_ld": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "bf_op_first_conv": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _F, _P]),
     "bf_op_first_conv_h3": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _I, _F, _P]),
+    "bf_op_first_conv_h3k": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _F, _P]),
     "bf_op_head_out": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P]),
     "bf_op_head_fused": (_I, [_P, _P, _F, _P, _I, _F, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P]),
     "bf_op_fill32": (_I, [_P, _I, _I64, _P]),

@@ -6,14 +6,20 @@
 // fp32 matrix pipe (0.59 ms at 32 x 512 x 512) to the 128 B/px it writes.
 #include "unet_h3_core.h"
 
-constexpr int UF_TH = 8, UF_TW = 64, UF_KS = 5, UF_CIN = 3, UF_KT = UF_KS * UF_KS * UF_CIN, UF_COUT = 32;
-constexpr int UF_IH = UF_TH + UF_KS - 1, UF_IW = UF_TW + UF_KS - 1, UF_NE = UF_IH * UF_IW * UF_CIN;
+//
+// Round 4: the kernel size is a template parameter (3, 5, 7): the base convolution of the resnet configs is the same operator with
+// kernel_size 7 (resnet_color_1x6_bn_32x128x32_1x3x1.json: 147-long contraction = 5 chunks of 32; the fp32 kernel took 829 us per
+// batch of 64 x 256 x 256, more than two of that model's blocks).
+constexpr int UF_TH = 8, UF_TW = 64, UF_CIN = 3, UF_COUT = 32;
 typedef unsigned uf_u4 __attribute__((ext_vector_type(4)));
 
+template <int UF_KS>
 __global__ __launch_bounds__(256) void uf_first_conv_kernel(const void* __restrict__ in, int in_is_u8, float* __restrict__ out,
                                                             const float* __restrict__ w, int Hs, int Ws, int H, int W, int normalize,
                                                             float v_min, float v_max, int act, float alpha)
 {
+    constexpr int UF_KT = UF_KS * UF_KS * UF_CIN, UF_NS = (UF_KT + 31) / 32;
+    constexpr int UF_IH = UF_TH + UF_KS - 1, UF_IW = UF_TW + UF_KS - 1, UF_NE = UF_IH * UF_IW * UF_CIN;
     __shared__ unsigned tile[UF_NE];                   // f16 hi in the low half, f16 lo in the high half
     __shared__ float red[256];
     const int x0 = blockIdx.x * UF_TW, y0 = blockIdx.y * UF_TH;
@@ -64,11 +70,11 @@ __global__ __launch_bounds__(256) void uf_first_conv_kernel(const void* __restri
     }
     const float inv = 1.f / scale;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, n = lane & 15;
-    // contraction index k = 32 s + 8 q + i  (tap = k / 3, channel = k % 3; k >= 75: zero weight)
-    uh8 wh[3][2], wl[3][2];
-    int koff[3][8];
+    // contraction index k = 32 s + 8 q + i  (tap = k / 3, channel = k % 3; k >= UF_KT: zero weight)
+    uh8 wh[UF_NS][2], wl[UF_NS][2];
+    int koff[UF_NS][8];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < UF_NS; ++s) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int k = 32 * s + 8 * q + i;
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(256) void uf_first_conv_kernel(const void* __restri
         const unsigned* base = tile + (ry * UF_IW + cx) * UF_CIN;
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
+        for (int s = 0; s < UF_NS; ++s) {
             unsigned e[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) e[i] = base[koff[s][i]];
@@ -130,17 +136,27 @@ __global__ __launch_bounds__(256) void uf_first_conv_kernel(const void* __restri
     }
 }
 
-// bf_op_first_conv for the one shape the unet_laplacian builder emits (5x5, 3 -> 32), split-f16 arithmetic
-extern "C" int bf_op_first_conv_h3(const void* in, int in_is_u8, float* out, const float* w, int B, int Hs, int Ws, int H, int W,
-                                   int normalize, float v_min, float v_max, int act, float alpha, void* stream)
+// bf_op_first_conv for k x k, 3 -> 32 (k = 3, 5, 7), split-f16 arithmetic
+extern "C" int bf_op_first_conv_h3k(const void* in, int in_is_u8, float* out, const float* w, int B, int Hs, int Ws, int H, int W, int k,
+                                    int normalize, float v_min, float v_max, int act, float alpha, void* stream)
 {
     if (!in || !out || !w || B <= 0 || Hs <= 0 || Ws <= 0 || H < Hs || W < Ws) return BF_EINVAL;
     if (normalize && !(v_max > v_min)) return BF_EINVAL;
     if ((uintptr_t)out % 16) return BF_EINVAL;
     if (act < 0 || act > 3) return BF_EINVAL;
     if (act == 2 && !(alpha >= 0.f && alpha <= 1.f)) return BF_EINVAL;
-    if (B > 65535 || (H + UF_TH - 1) / UF_TH > 65535) return BF_EUNSUPPORTED;
-    hipLaunchKernelGGL(uf_first_conv_kernel, dim3((W + UF_TW - 1) / UF_TW, (H + UF_TH - 1) / UF_TH, B), dim3(256), 0,
-                       (hipStream_t)stream, in, in_is_u8, out, w, Hs, Ws, H, W, normalize, v_min, v_max, act, alpha);
+    if (B > 65535 || (H + UF_TH - 1) / UF_TH > 65535 || (k != 3 && k != 5 && k != 7)) return BF_EUNSUPPORTED;
+    const dim3 grid((W + UF_TW - 1) / UF_TW, (H + UF_TH - 1) / UF_TH, B);
+    hipStream_t s = (hipStream_t)stream;
+    if (k == 3) hipLaunchKernelGGL(uf_first_conv_kernel<3>, grid, dim3(256), 0, s, in, in_is_u8, out, w, Hs, Ws, H, W, normalize, v_min, v_max, act, alpha);
+    else if (k == 5) hipLaunchKernelGGL(uf_first_conv_kernel<5>, grid, dim3(256), 0, s, in, in_is_u8, out, w, Hs, Ws, H, W, normalize, v_min, v_max, act, alpha);
+    else hipLaunchKernelGGL(uf_first_conv_kernel<7>, grid, dim3(256), 0, s, in, in_is_u8, out, w, Hs, Ws, H, W, normalize, v_min, v_max, act, alpha);
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// the shape the unet_laplacian builder emits (5x5, 3 -> 32)
+extern "C" int bf_op_first_conv_h3(const void* in, int in_is_u8, float* out, const float* w, int B, int Hs, int Ws, int H, int W,
+                                   int normalize, float v_min, float v_max, int act, float alpha, void* stream)
+{
+    return bf_op_first_conv_h3k(in, in_is_u8, out, w, B, Hs, Ws, H, W, 5, normalize, v_min, v_max, act, alpha, stream);
 }

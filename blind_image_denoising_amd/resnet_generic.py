@@ -249,6 +249,8 @@ class GenericResnetHydra:
         st = np.concatenate([np.zeros(s, np.float32).ravel() if n.endswith("mean") else np.ones(s, np.float32).ravel()
                              for n, s in self._state_inventory]) if self._state_inventory else np.zeros(0, np.float32)
         self.state = torch.from_numpy(st).to(self.device)
+        self.fuse_bottleneck = 1                 # see set_option
+        self.arith = 1
         self._packed = None
 
     # -- inventory ---------------------------------------------------------------------------
@@ -354,7 +356,14 @@ class GenericResnetHydra:
         self.version = getattr(self, "version", 0) + 1
 
     def set_option(self, key: str, value: int):
-        raise ValueError(f"unknown option {key}={value}")
+        """fuse_bottleneck: 1 (default) a block of the shape 1x1 32 -> 32, depthwise 3x3 x4, 1x1 128 -> 32 runs as one kernel with split-f16
+        GEMMs (bf_op_bneck_block_h3); 0: the fp32 operators (bf_op_pointwise, bf_op_dwmult_pointwise).
+        arith: 1 (default) the base convolution (k x k, 3 -> 32, k = 3 / 5 / 7) on the f16 matrix cores with split-f16 operands
+        (bf_op_first_conv_h3k) and the fused bottleneck block where it applies; 0: every product in exact fp32."""
+        if key not in ("fuse_bottleneck", "arith") or int(value) not in (0, 1):
+            raise ValueError(f"unknown option {key}={value}")
+        setattr(self, key, int(value))
+        self.version = getattr(self, "version", 0) + 1
 
     def check_status(self, raise_on_overflow: bool = True) -> bool:
         return True
@@ -388,6 +397,7 @@ class GenericResnetHydra:
         nb_ = len(self.block_kernels)
         for i in range(self.no_layers):
             cin = self.filters
+            raw = []                                                      # (kind, folded fp32 kernel, shift) per convolution
             for j, (kk, cf, dm, g) in enumerate(zip(self.block_kernels, self.block_filters, self.block_depthwise, self.block_groups)):
                 k = W[f"block{i}/conv{j}/kernel"]
                 cout = cin * dm if dm != -1 else cf
@@ -409,6 +419,7 @@ class GenericResnetHydra:
                 if dm != -1:
                     kf = (k * scale.reshape(cin, dm)[None, None]).reshape(kk, kk, cin * dm)
                     P[f"b{i}c{j}"] = ("dw", dev(kf.reshape(kk, kk, cin, dm)), None if shift is None else dev(shift))
+                    raw.append(("dw", kf.reshape(kk, kk, cin, dm), shift))
                 else:
                     dense = np.zeros((kk, kk, cin, cf))     # grouped convolution as a block-diagonal dense one
                     ci_g, co_g = cin // g, cf // g
@@ -417,9 +428,16 @@ class GenericResnetHydra:
                     dense = dense * scale[None, None, None, :]
                     packed = UL.pack_pointwise(dev(dense[0, 0])) if kk == 1 else UL.pack_conv(dev(dense))
                     P[f"b{i}c{j}"] = ("pw" if kk == 1 else "conv", packed, None if shift is None else dev(shift))
+                    raw.append(("pw" if kk == 1 else "conv", dense, shift))
                 if j == 1 and self.add_gates:
                     P[f"b{i}gate"] = (dev(W[f"block{i}/gate/dense0/kernel"]), dev(W[f"block{i}/gate/dense1/kernel"]))
                 cin = cout
+            if ([r[0] for r in raw] == ["pw", "dw", "pw"] and raw[0][1].shape[2:] == (32, 32) and raw[1][1].shape == (3, 3, 32, 4)
+                    and raw[2][1].shape[2:] == (128, 32) and not self.add_gates and not self.selector and f"b{i}scale" not in P
+                    and all(a in ("linear", "relu") or a.startswith("leaky") for a in self.block_activation[:3])):
+                # the shipped bottleneck shape: the whole block as one kernel
+                P[f"b{i}bneck"] = (UL.pack_bneck_h3(dev(raw[0][1][0, 0]), dev(raw[1][1]), dev(raw[2][1][0, 0])),
+                                   tuple(None if r[2] is None else dev(r[2]) for r in raw))
             if self.selector:
                 kind = "dense" if self.selector["scale_type"] == "global" else "conv"
                 w0, w1 = W[f"block{i}/selector/{kind}0/kernel"], W[f"block{i}/selector/{kind}1/kernel"]
@@ -453,12 +471,16 @@ class GenericResnetHydra:
 
     def _features(self, x: torch.Tensor, H: int, W: int) -> torch.Tensor:
         P = self._pack()
-        f = UL.first_conv(x, P["base"], H, W, self.base_activation, True, self.v_min, self.v_max)
+        f = UL.first_conv(x, P["base"], H, W, self.base_activation, True, self.v_min, self.v_max, arith=self.arith)
         if self.add_initial_bn:
             f = UL.dwconv_mult(f, P["initial_bn"][0], P["initial_bn"][1])
         nb = len(self.block_kernels)
         fused = {(32, 4, 32, 3), (32, 2, 32, 3), (64, 2, 64, 3), (32, 4, 64, 3), (32, 1, 32, 3), (64, 1, 64, 3)}   # built instances
         for i in range(self.no_layers):
+            if self.arith and self.fuse_bottleneck and f"b{i}bneck" in P:
+                packed, (s0, s1, s2) = P[f"b{i}bneck"]
+                f = UL.bneck_block_h3(f, packed, s0, self.block_activation[0], s1, self.block_activation[1], s2, self.block_activation[2])
+                continue
             t = f
             first = None
             j = 0

@@ -198,6 +198,26 @@ def dwmult_pointwise(x: torch.Tensor, wd: torch.Tensor, bias1: Optional[torch.Te
     return out
 
 
+def pack_bneck_h3(w0: torch.Tensor, wd: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """operand of bneck_block_h3: w0 [32,32], wd [3,3,32,4], w2 [128,32] (fp32, BatchNorm scales folded in)"""
+    if tuple(w0.shape) != (32, 32) or tuple(wd.shape) != (3, 3, 32, 4) or tuple(w2.shape) != (128, 32):
+        raise ValueError(f"bottleneck operands {tuple(w0.shape)}, {tuple(wd.shape)}, {tuple(w2.shape)}: built for 32 -> 32 -> 3x3 x4 -> 32")
+    packed = torch.empty(int(N.lib().bf_op_bneck_h3_pack_bytes()), dtype=torch.uint8, device=w0.device)
+    _call("bf_op_pack_bneck_h3", N.ptr(w0.contiguous()), N.ptr(wd.contiguous()), N.ptr(w2.contiguous()), N.ptr(packed), N.stream_ptr(w0))
+    return packed
+
+
+def bneck_block_h3(x: torch.Tensor, packed: torch.Tensor, shift0: Optional[torch.Tensor], act0: str, shift1: Optional[torch.Tensor],
+                   act1: str, shift2: Optional[torch.Tensor], act2: str, add_res: bool = True) -> torch.Tensor:
+    """[x +] act2(act1(depthwise3x3_x4(act0(x . w0 + shift0)) + shift1) . w2 + shift2), one kernel, split-f16 GEMMs"""
+    B, H, W, C = x.shape
+    out = torch.empty_like(x)
+    (c0, a0), (c1, a1), (c2, a2) = _act(act0), _act(act1), _act(act2)
+    _call("bf_op_bneck_block_h3", N.ptr(x), N.ptr(out), N.ptr(packed), N.ptr(shift0), c0, a0, N.ptr(shift1), c1, a1, N.ptr(shift2), c2, a2,
+          int(bool(add_res)), B, H, W, N.stream_ptr(x))
+    return out
+
+
 def maxpool2(x: torch.Tensor) -> torch.Tensor:
     B, H, W, C = x.shape
     out = torch.empty((B, (H + 1) // 2, (W + 1) // 2, C), dtype=torch.float32, device=x.device)
@@ -266,13 +286,13 @@ def attention_interleaved(qvk: torch.Tensor, A: int) -> torch.Tensor:
 def first_conv(x: torch.Tensor, w: torch.Tensor, H: int, W: int, act: str, normalize: bool, v_min: float, v_max: float,
                arith: int = 0) -> torch.Tensor:
     """x [B,Hs,Ws,cin] uint8 / float32 (0..255 scale), zero-padded to [H,W] before normalisation.
-    arith 1: split-f16 matrix-core kernel for the 5x5 3 -> 32 shape (csrc/unet_h3_first.hip); 0: exact fp32."""
+    arith 1: split-f16 matrix-core kernel for the k x k 3 -> 32 shapes, k = 3, 5, 7 (csrc/unet_h3_first.hip); 0: exact fp32."""
     B, Hs, Ws, cin = x.shape
     k, cout = int(w.shape[0]), int(w.shape[-1])
     out = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device)
     code, a = _act(act)
-    if arith == 1 and (k, cin, cout) == (5, 3, 32):
-        _call("bf_op_first_conv_h3", N.ptr(x), int(x.dtype == torch.uint8), N.ptr(out), N.ptr(w), B, Hs, Ws, H, W, int(normalize),
+    if arith == 1 and k in (3, 5, 7) and (cin, cout) == (3, 32):
+        _call("bf_op_first_conv_h3k", N.ptr(x), int(x.dtype == torch.uint8), N.ptr(out), N.ptr(w), B, Hs, Ws, H, W, k, int(normalize),
               v_min, v_max, code, a, N.stream_ptr(x))
         return out
     _call("bf_op_first_conv", N.ptr(x), int(x.dtype == torch.uint8), N.ptr(out), N.ptr(w), B, Hs, Ws, H, W, cin, cout, k,

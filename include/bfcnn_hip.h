@@ -239,6 +239,18 @@ int bf_op_dwconv_mult(const float* in, float* out, const float* w, const float* 
 int bf_op_dwmult_pointwise(const float* in, float* out, const float* wd, const float* bias1, int act1, float alpha1,
                            const float* wp, const float* bias2, int act2, float alpha2, const float* res, int batch, int height,
                            int width, int cin, int multiplier, int k, int cout, void* stream);
+/* The whole bottleneck block of the shipped resnet config (resnet_color_1x6_bn_32x128x32_1x3x1.json; backbone_resnet.py:149-178,
+ * backbone_blocks.py:160-243) in one kernel, its two 1x1 convolutions on the f16 matrix cores with split-f16 operands (hi + lo, three
+ * products, fp32 accumulation -- DESIGN.md 4.2):
+ *   out = [x +] act2(act1(depthwise3x3_x4(act0(x . w0 + shift0)) + shift1) . w2 + shift2)        32 -> 32 -> 128 -> 32 channels
+ * replaces bf_op_pointwise followed by bf_op_dwmult_pointwise.  w0 [32][32], wd [3][3][32][4], w2 [128][32] (grouped 1x1 as a block-
+ * diagonal dense matrix), BatchNorm scales folded into wd / w2 and offsets passed as shift0 [32] / shift1 [128] / shift2 [32] (or NULL).
+ * Activations: 0 linear, 1 relu, 2 leaky relu (0 <= alpha <= 1); BF_EUNSUPPORTED for others.  out != x. */
+int64_t bf_op_bneck_h3_pack_bytes(void);
+int bf_op_pack_bneck_h3(const float* w0, const float* wd, const float* w2, void* packed, void* stream);
+int bf_op_bneck_block_h3(const float* x, float* out, const void* packed, const float* shift0, int act0, float alpha0,
+                         const float* shift1, int act1, float alpha1, const float* shift2, int act2, float alpha2, int add_res,
+                         int batch, int height, int width, void* stream);
 /* MaxPooling2D(2, 2, padding="same") (downsampling.py:56-58). */
 int bf_op_maxpool2(const float* in, float* out, int batch, int height, int width, int channels, void* stream);
 /* The same 1x1 convolution with the epilogues of AdditiveAttentionGate (custom_layers.py:805-832):
@@ -314,6 +326,9 @@ int bf_op_first_conv(const void* in, int in_is_u8, float* out, const float* w, i
  * operands (three products, fp32 accumulation: the arithmetic of bf_op_convnext_mlp_h3). */
 int bf_op_first_conv_h3(const void* in, int in_is_u8, float* out, const float* w, int batch, int src_height, int src_width,
                         int height, int width, int normalize, float v_min, float v_max, int act, float alpha, void* stream);
+/* The same for kernel sizes 3, 5 and 7 (the base convolution of the resnet configs: kernel_size 7). */
+int bf_op_first_conv_h3k(const void* in, int in_is_u8, float* out, const float* w, int batch, int src_height, int src_width,
+                         int height, int width, int k, int normalize, float v_min, float v_max, int act, float alpha, void* stream);
 /* last Conv2D 1x1 of a denoiser head + tanh(2x)*0.51 [+ denormalise][+ round, uint8], cropped to [Ho,Wo]
  * (model.py:321-342, 136-139; module_denoiser.py:62-73). */
 int bf_op_head_out(const float* in, const float* w, void* out, int out_is_u8, int batch, int height, int width, int out_height,

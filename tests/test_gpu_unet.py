@@ -275,13 +275,14 @@ def test_first_conv_normalise_and_virtual_padding(u8):
 
 
 @pytest.mark.parametrize("u8", [True, False])
+@pytest.mark.parametrize("ks", [5, 7, 3])
 @pytest.mark.parametrize("shape,padded_hw", [((2, 13, 21), (16, 32)), ((1, 70, 130), (128, 256)), ((3, 64, 64), (64, 64))])
-def test_first_conv_split_f16(u8, shape, padded_hw):
+def test_first_conv_split_f16(u8, shape, padded_hw, ks):
     """csrc/unet_h3_first.hip against the same reference and tolerance as the fp32 kernel; all four activations; tiles that
     straddle the source image, the padded image and the launch grid."""
     r = _rng(12 + shape[1])
     img = r.integers(0, 256, size=shape + (3,)).astype(np.uint8)
-    w = r.normal(size=(5, 5, 3, 32)) * 0.2
+    w = r.normal(size=(ks, ks, 3, 32)) * 0.2
     H, W = padded_hw
     padded = np.zeros((shape[0], H, W, 3)); padded[:, :shape[1], :shape[2]] = img
     pre = O.conv2d_same(O.layer_normalize(padded, 0.0, 255.0), w)
@@ -289,7 +290,7 @@ def test_first_conv_split_f16(u8, shape, padded_hw):
     for act in ("leaky_relu_01", "linear", "relu", "gelu"):
         got = UL.first_conv(x, dev(w), H, W, act, True, 0.0, 255.0, arith=1)
         assert_close(host(got), U.act(pre, act), what=f"first conv f16x3 {act}")
-    ints = r.integers(-3, 4, size=(5, 5, 3, 32)).astype(np.float64)            # exact on small integers without normalisation
+    ints = r.integers(-3, 4, size=(ks, ks, 3, 32)).astype(np.float64)          # exact on small integers without normalisation
     got = UL.first_conv(x, dev(ints), H, W, "linear", False, 0.0, 255.0, arith=1)
     assert np.array_equal(host(got), O.conv2d_same(padded, ints))
 

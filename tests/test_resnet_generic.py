@@ -228,6 +228,80 @@ def test_fused_depthwise_multiplier_pointwise_kernel(cin, m, cout, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 1, 1), (1, 8, 32), (2, 9, 37), (1, 40, 70), (3, 64, 64), (1, 17, 130)])
+@pytest.mark.parametrize("acts", [("relu", "relu", "relu"), ("linear", "leaky_relu_01", "linear"), ("leaky_relu", "relu", "leaky_relu_01")])
+def test_bottleneck_block_in_one_kernel(shape, acts):
+    """bf_op_bneck_block_h3 (split-f16 GEMMs) against the fp64 restatement of 1x1 -> depthwise 3x3 x4 -> 1x1 + skip, with and without
+    the folded BatchNorm offsets"""
+    from blind_image_denoising_amd import unet_laplacian as UL
+    from helpers import dev, host, assert_close
+    r = np.random.default_rng(shape[1] * 131 + shape[2])
+    x = r.normal(size=shape + (32,)) * 1.5
+    w0, b0 = r.normal(size=(1, 1, 32, 32)) / np.sqrt(32), r.normal(size=32) * 0.2
+    wd, b1 = r.normal(size=(3, 3, 32, 4)) * 0.3, r.normal(size=128) * 0.1
+    w2, b2 = r.normal(size=(1, 1, 128, 32)) / np.sqrt(128), r.normal(size=32) * 0.1
+    pk = UL.pack_bneck_h3(dev(w0[0, 0]), dev(wd), dev(w2[0, 0]))
+    for shifts in ((b0, b1, b2), (None, b1, None), (None, None, None)):
+        z = lambda b: 0.0 if b is None else b
+        t = O.activation_fwd(O.conv2d_same(x, w0) + z(shifts[0]), acts[0])
+        hid = O.activation_fwd(G.depthwise_mult_same(t, wd) + z(shifts[1]), acts[1])
+        y = O.activation_fwd(O.conv2d_same(hid, w2) + z(shifts[2]), acts[2])
+        d = lambda b: None if b is None else dev(b)
+        got = UL.bneck_block_h3(dev(x), pk, d(shifts[0]), acts[0], d(shifts[1]), acts[1], d(shifts[2]), acts[2], True)
+        assert_close(host(got), x + y, rel=2e-5, what="bottleneck block")
+        got = UL.bneck_block_h3(dev(x), pk, d(shifts[0]), acts[0], d(shifts[1]), acts[1], d(shifts[2]), acts[2], False)
+        assert_close(host(got), y, rel=2e-5, what="bottleneck block, no skip")
+
+
+@pytest.mark.gpu
+def test_bottleneck_block_is_exact_on_small_integers():
+    """integers that fit f16 exactly: the split arithmetic has nothing to round, the result equals the integer one bit for bit"""
+    from blind_image_denoising_amd import unet_laplacian as UL
+    from helpers import dev, host
+    r = np.random.default_rng(3)
+    x = r.integers(-3, 4, size=(2, 19, 45, 32)).astype(np.float64)
+    w0 = r.integers(-1, 2, size=(1, 1, 32, 32)).astype(np.float64) * (r.random((1, 1, 32, 32)) < 0.3)
+    wd = r.integers(-2, 3, size=(3, 3, 32, 4)).astype(np.float64)
+    w2 = r.integers(-1, 2, size=(1, 1, 128, 32)).astype(np.float64) * (r.random((1, 1, 128, 32)) < 0.2)
+    b1 = r.integers(-4, 5, size=128).astype(np.float64)
+    pk = UL.pack_bneck_h3(dev(w0[0, 0]), dev(wd), dev(w2[0, 0]))
+    hid = np.maximum(G.depthwise_mult_same(np.maximum(O.conv2d_same(x, w0), 0.0), wd) + b1, 0.0)
+    ref = x + O.conv2d_same(hid, w2)
+    assert np.abs(hid).max() < 2 ** 22
+    got = UL.bneck_block_h3(dev(x), pk, None, "relu", dev(b1), "relu", None, "linear", True)
+    assert np.array_equal(host(got).astype(np.float64), ref)
+
+
+@pytest.mark.gpu
+def test_bottleneck_block_operator_argument_checks():
+    from blind_image_denoising_amd import unet_laplacian as UL
+    x = torch.zeros((1, 4, 4, 32), device="cuda")
+    pk = UL.pack_bneck_h3(torch.eye(32, device="cuda"), torch.zeros((3, 3, 32, 4), device="cuda"), torch.zeros((128, 32), device="cuda"))
+    with pytest.raises(Exception):
+        UL.bneck_block_h3(x, pk, None, "gelu", None, "relu", None, "relu")
+    with pytest.raises(ValueError):
+        UL.pack_bneck_h3(torch.zeros((64, 64), device="cuda"), torch.zeros((3, 3, 32, 4), device="cuda"), torch.zeros((128, 32), device="cuda"))
+
+
+@pytest.mark.gpu
+def test_shipped_config_fused_and_unfused_blocks_agree():
+    cfg = G.shipped_config()
+    m = _check(cfg, (2, 48, 80), seed=4)
+    assert m.fuse_bottleneck == 1 and any(k.endswith("bneck") for k in m._pack())
+    _, noisy = O.synthetic_batch(2, 48, 80, seed=4)
+    x = noisy.astype(np.float32)
+    fused = np.asarray(m(x), np.float64)
+    m.set_option("fuse_bottleneck", 0)
+    plain = np.asarray(m(x), np.float64)
+    assert np.abs(fused - plain).max() <= 2e-3 and not np.array_equal(fused, plain)       # 0..255 scale; two arithmetics
+    m.set_option("arith", 0)                                                              # + the base convolution in exact fp32
+    exact = np.asarray(m(x), np.float64)
+    assert np.abs(exact - plain).max() <= 2e-3 and not np.array_equal(exact, plain)
+    ref = G.hydra_forward(G.GenericResnetSpec.from_config(cfg), *G.init_params(G.GenericResnetSpec.from_config(cfg), seed=4), x.astype(np.float64))
+    assert np.abs(exact - ref).mean() / 255.0 <= 1e-4
+
+
+@pytest.mark.gpu
 def test_generic_resnet_save_and_load_roundtrip(tmp_path):
     m = _check(G.shipped_config(), (1, 32, 32), seed=9)
     bf.save_model(m, str(tmp_path / "r"))

@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 # fp32_b128 / fp32_b64: the exact-fp32 arithmetic at the bench batch and at the north star's batch (the ">= 60 % MFMA roofline" figure)
 declare -A ARGS=( [inference]="" [train]="--mode train" [unet]="--mode unet" [unet56]="--mode unet --unet-graph v5.6" [pyramid]="--mode pyramid" [generic]="--mode generic"
                   [fp32_b128]="--arith 0 --no-sub-records" [fp32_b64]="--arith 0 --batch 64 --no-sub-records" [onepair0]="--opt h3_pair=0 --no-sub-records" )
-declare -A KERNEL=( [inference]="fused_block2_h3w_kernel" [train]="bwd_block_h3t_kernel" [unet]="uh_enc32u_kernel" [unet56]="uh_enc32u_kernel" [pyramid]="lap_split_kernel" [generic]="uo_dwmult_pw_kernel"
+declare -A KERNEL=( [inference]="fused_block2_h3w_kernel" [train]="bwd_block_h3t_kernel" [unet]="uh_enc32u_kernel" [unet56]="uh_enc32u_kernel" [pyramid]="lap_split_kernel" [generic]="ug_bneck_kernel"
                     [fp32_b128]="fused_block_v4_kernel" [fp32_b64]="fused_block_v4_kernel" [onepair0]="fused_block_h3v_kernel" )
 rc_all=0
 for m in "${modes[@]}"; do
