@@ -28,7 +28,9 @@ static_assert(UG_TILE_OFF % 16 == 0 && 2 * UG_LDS_BYTES <= 160 * 1024, "two work
 
 // linear / relu / leaky relu without a branch or a template instance per combination: max(v, slope v) with slope 1 / 0 / alpha
 // (0 <= alpha <= 1).  relu of a negative number comes out as -0 instead of +0.
-__device__ __forceinline__ float ug_act(float v, float slope) { return fmaxf(v, slope * v); }
+// RELU: all three activations are relu (the shipped config): one instruction instead of two
+template <bool RELU>
+__device__ __forceinline__ float ug_act(float v, float slope) { return RELU ? fmaxf(v, 0.f) : fmaxf(v, slope * v); }
 
 // power of two s with max |w| s in [2^13, 2^14): the lo halves of the scaled weights stay normal f16 numbers
 __device__ float ug_block_scale(const float* __restrict__ w, int n, float* red)
@@ -100,6 +102,7 @@ constexpr int UG_UC = UG_UNROLL_C;
 #define UG_ABLATE 0       // timing builds (results wrong): 1 no phase A, 2 no depthwise FMAs, 4 no closing MFMAs, 8 no residual / store
 #endif
 
+template <bool RELU>
 __global__ __launch_bounds__(256, 2) void ug_bneck_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                           const char* __restrict__ packed, const float* __restrict__ shift0,
                                                           const float* __restrict__ shift1, const float* __restrict__ shift2,
@@ -139,17 +142,22 @@ __global__ __launch_bounds__(256, 2) void ug_bneck_kernel(const float* __restric
     constexpr int NG = 6;                                          // groups wave + 4 k of the 22 (340 pixels) of a haloed tile
     f32x4 xa[NG][2];
     bool inimg[NG];
+    int pyk[NG], pxk[NG];                                          // the lane's pixel of group k inside the haloed tile: the same for every tile
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        const int e = 16 * (wave + 4 * k) + n;
+        pyk[k] = e < UG_NPX ? e / UG_IW - 1 : -(1 << 20);         // past the 340th pixel: never inside an image
+        pxk[k] = e - UG_IW * (e / UG_IW) - 1;
+    }
     auto request = [&](const int tile_id) {
         const int tx = tile_id % tiles_x, rest = tile_id / tiles_x, ty = rest % tiles_y;
-        const int64_t img = (int64_t)(rest / tiles_y) * H * W;
+        const float* ib = x + (int64_t)(rest / tiles_y) * H * W * 32 + 8 * q;
         const int x0 = tx * UG_TW, y0 = ty * UG_TH;
 #pragma unroll
         for (int k = 0; k < NG; ++k) {
-            const int e = 16 * (wave + 4 * k) + n;
-            const int py = e / UG_IW, pxx = e - UG_IW * py;
-            const int yy = y0 + py - 1, xx = x0 + pxx - 1;
-            inimg[k] = e < UG_NPX && yy >= 0 && yy < H && xx >= 0 && xx < W;
-            const float* src = x + (img + (int64_t)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)) * 32 + 8 * q;
+            const int yy = y0 + pyk[k], xx = x0 + pxk[k];
+            inimg[k] = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const float* src = ib + (min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)) * 32;
             xa[k][0] = *reinterpret_cast<const f32x4*>(src);
             xa[k][1] = *reinterpret_cast<const f32x4*>(src + 4);
         }
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void ug_bneck_kernel(const float* __restric
                     a = UH_MFMA_REAL(ah, xl, a);
                     f32x4 v = a * inv0 + *reinterpret_cast<const f32x4*>(sh0 + 16 * t + 4 * q);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = inimg[k] ? ug_act(v[r], slope0) : 0.f;
+                    for (int r = 0; r < 4; ++r) v[r] = inimg[k] ? ug_act<RELU>(v[r], slope0) : 0.f;
                     if (e < UG_NPX) *reinterpret_cast<f32x4*>(tile + e * UG_PITCH + 16 * t + 4 * q) = v;
                 }
             }
@@ -244,8 +252,8 @@ __global__ __launch_bounds__(256, 2) void ug_bneck_kernel(const float* __restric
                 for (int o = 0; o < 4; ++o) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        hv[o][0][r] = ug_act(hv[o][0][r], slope1);
-                        hv[o][1][r] = ug_act(hv[o][1][r], slope1);
+                        hv[o][0][r] = ug_act<RELU>(hv[o][0][r], slope1);
+                        hv[o][1][r] = ug_act<RELU>(hv[o][1][r], slope1);
                     }
                     uh_split8(hv[o][0], hv[o][1], bh[o], bl[o]);
                 }
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void ug_bneck_kernel(const float* __restric
                     for (int t = 0; t < 2; ++t) {
                         f32x4 v = acc[o][t] * inv2 + *reinterpret_cast<const f32x4*>(sh2 + 16 * t + 4 * q);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = ug_act(v[r], slope2);
+                        for (int r = 0; r < 4; ++r) v[r] = ug_act<RELU>(v[r], slope2);
                         if (add_res) v += res[o][t];
                         *reinterpret_cast<f32x4*>(dst + 16 * t) = v;
                     }
@@ -310,11 +318,18 @@ extern "C" int bf_op_bneck_block_h3(const float* x, float* out, const void* pack
         slope[i] = acts[i] == 0 ? 1.f : (acts[i] == 1 ? 0.f : alphas[i]);
     }
     const int64_t ntiles = (int64_t)B * ((H + UG_TH - 1) / UG_TH) * ((W + UG_TW - 1) / UG_TW);
-    if (ntiles >= ((int64_t)1 << 31) || (int64_t)B * H * W >= ((int64_t)1 << 31)) return BF_EUNSUPPORTED;
-    if (bf_set_max_lds(reinterpret_cast<const void*>(ug_bneck_kernel), UG_LDS_BYTES) != hipSuccess) return BF_EHIP;
+    if (ntiles >= ((int64_t)1 << 31) || (int64_t)B * H * W >= ((int64_t)1 << 31) || (int64_t)H * W * 32 >= ((int64_t)1 << 31))
+        return BF_EUNSUPPORTED;                                    // 32-bit element offsets inside an image
+    const bool relu = act0 == 1 && act1 == 1 && act2 == 1;
+    const void* fn = relu ? reinterpret_cast<const void*>(ug_bneck_kernel<true>) : reinterpret_cast<const void*>(ug_bneck_kernel<false>);
+    if (bf_set_max_lds(fn, UG_LDS_BYTES) != hipSuccess) return BF_EHIP;
     const int per_xcd = (int)((ntiles + 7) / 8);
     const int grid = 8 * (int)std::min<int64_t>(per_xcd, 64);      // 512 workgroups: two per CU, a multiple of the 8 XCDs
-    hipLaunchKernelGGL(ug_bneck_kernel, dim3(grid), dim3(256), UG_LDS_BYTES, (hipStream_t)stream, x, out, (const char*)packed, shift0,
-                       shift1, shift2, slope[0], slope[1], slope[2], add_res, B, H, W);
+    if (relu)
+        hipLaunchKernelGGL(ug_bneck_kernel<true>, dim3(grid), dim3(256), UG_LDS_BYTES, (hipStream_t)stream, x, out, (const char*)packed, shift0,
+                           shift1, shift2, slope[0], slope[1], slope[2], add_res, B, H, W);
+    else
+        hipLaunchKernelGGL(ug_bneck_kernel<false>, dim3(grid), dim3(256), UG_LDS_BYTES, (hipStream_t)stream, x, out, (const char*)packed, shift0,
+                           shift1, shift2, slope[0], slope[1], slope[2], add_res, B, H, W);
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }

@@ -12,46 +12,23 @@
 // batch of 64 x 256 x 256, more than two of that model's blocks).
 constexpr int UF_TH = 8, UF_TW = 64, UF_CIN = 3, UF_COUT = 32;
 typedef unsigned uf_u4 __attribute__((ext_vector_type(4)));
+#ifndef UF_GRID
+// workgroups of the launch.  k = 7: persistent, two per CU (252 registers): 418 -> 340 us at 64 x 256 x 256.  k = 3, 5: one tile per
+// workgroup as before -- persistent workgroups measured SLOWER for k = 5 (509 vs 463 us at 32 x 512 x 512: with two resident workgroups
+// per CU the per-tile load -> barrier -> compute chain is exposed, and 48 weight loads per lane are cheap enough to repeat)
+#define UF_GRID(k) ((k) == 7 ? (int64_t)512 : ((int64_t)1 << 31))
+#endif
 
 template <int UF_KS>
 __global__ __launch_bounds__(256) void uf_first_conv_kernel(const void* __restrict__ in, int in_is_u8, float* __restrict__ out,
                                                             const float* __restrict__ w, int Hs, int Ws, int H, int W, int normalize,
-                                                            float v_min, float v_max, int act, float alpha)
+                                                            float v_min, float v_max, int act, float alpha, int ntiles)
 {
     constexpr int UF_KT = UF_KS * UF_KS * UF_CIN, UF_NS = (UF_KT + 31) / 32;
     constexpr int UF_IH = UF_TH + UF_KS - 1, UF_IW = UF_TW + UF_KS - 1, UF_NE = UF_IH * UF_IW * UF_CIN;
     __shared__ unsigned tile[UF_NE];                   // f16 hi in the low half, f16 lo in the high half
     __shared__ float red[256];
-    const int x0 = blockIdx.x * UF_TW, y0 = blockIdx.y * UF_TH;
-    const int64_t b = blockIdx.z;
     const float range = v_max - v_min;
-    {
-        constexpr int NE = (UF_NE + 255) / 256;
-        float rv[NE];
-        bool inpad[NE];
-#pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const int e = threadIdx.x + i * 256;
-            const int ci = e % UF_CIN, px = (e / UF_CIN) % UF_IW, py = e / (UF_CIN * UF_IW);
-            const int yy = y0 + py - UF_KS / 2, xx = x0 + px - UF_KS / 2;
-            inpad[i] = e < UF_NE && yy >= 0 && yy < H && xx >= 0 && xx < W;      // inside the (virtually padded) image
-            rv[i] = 0.f;
-            if (inpad[i] && yy < Hs && xx < Ws) {
-                const int64_t o = ((b * Hs + yy) * Ws + xx) * UF_CIN + ci;
-                rv[i] = in_is_u8 ? (float)reinterpret_cast<const unsigned char*>(in)[o] : reinterpret_cast<const float*>(in)[o];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const int e = threadIdx.x + i * 256;
-            float v = rv[i];
-            if (inpad[i] && normalize) v = (fminf(fmaxf(v, v_min), v_max) - v_min) / range - 0.5f;
-            if (!inpad[i]) v = 0.f;
-            const _Float16 hi = (_Float16)v;
-            const _Float16 lo = (_Float16)(v - (float)hi);
-            if (e < UF_NE) tile[e] = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
-        }
-    }
     // power-of-two scale that puts the largest weight in [2^13, 2^14): the lo parts stay normal f16 numbers
     float mx = 0.f;
     for (int i = threadIdx.x; i < UF_KT * UF_COUT; i += 256) mx = fmaxf(mx, fabsf(w[i]));
@@ -94,6 +71,40 @@ __global__ __launch_bounds__(256) void uf_first_conv_kernel(const void* __restri
             uh_split8(a0, a1, wh[s][t], wl[s][t]);
         }
     }
+    // The workgroup prepares its weight fragments ONCE (a max reduction over the kernel + 16 * UF_NS scalar loads per lane: as much L2
+    // traffic per 8 x 64 tile as the tile's output when every tile was a workgroup of its own) and then walks tiles.
+    const int tiles_x = (W + UF_TW - 1) / UF_TW, tiles_y = (H + UF_TH - 1) / UF_TH;
+    for (int tid = blockIdx.x; tid < ntiles; tid += gridDim.x) {
+        const int x0 = (tid % tiles_x) * UF_TW, y0 = ((tid / tiles_x) % tiles_y) * UF_TH;
+        const int64_t b = tid / (tiles_x * tiles_y);
+        {
+            constexpr int NE = (UF_NE + 255) / 256;
+            float rv[NE];
+            bool inpad[NE];
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const int e = threadIdx.x + i * 256;
+                const int ci = e % UF_CIN, px = (e / UF_CIN) % UF_IW, py = e / (UF_CIN * UF_IW);
+                const int yy = y0 + py - UF_KS / 2, xx = x0 + px - UF_KS / 2;
+                inpad[i] = e < UF_NE && yy >= 0 && yy < H && xx >= 0 && xx < W;      // inside the (virtually padded) image
+                rv[i] = 0.f;
+                if (inpad[i] && yy < Hs && xx < Ws) {
+                    const int64_t o = ((b * Hs + yy) * Ws + xx) * UF_CIN + ci;
+                    rv[i] = in_is_u8 ? (float)reinterpret_cast<const unsigned char*>(in)[o] : reinterpret_cast<const float*>(in)[o];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const int e = threadIdx.x + i * 256;
+                float v = rv[i];
+                if (inpad[i] && normalize) v = (fminf(fmaxf(v, v_min), v_max) - v_min) / range - 0.5f;
+                if (!inpad[i]) v = 0.f;
+                const _Float16 hi = (_Float16)v;
+                const _Float16 lo = (_Float16)(v - (float)hi);
+                if (e < UF_NE) tile[e] = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+            }
+        }
+        __syncthreads();
     // 8 rows x 4 column groups of 16 pixels = 32 groups, 8 per wave
     for (int gi = wave; gi < UF_TH * (UF_TW / 16); gi += 4) {
         const int ry = gi / (UF_TW / 16), cx = (gi % (UF_TW / 16)) * 16 + n;
@@ -134,6 +145,8 @@ __global__ __launch_bounds__(256) void uf_first_conv_kernel(const void* __restri
             }
         }
     }
+        __syncthreads();                                 // the next tile's patch overwrites this one
+    }
 }
 
 // bf_op_first_conv for k x k, 3 -> 32 (k = 3, 5, 7), split-f16 arithmetic
@@ -145,12 +158,15 @@ extern "C" int bf_op_first_conv_h3k(const void* in, int in_is_u8, float* out, co
     if ((uintptr_t)out % 16) return BF_EINVAL;
     if (act < 0 || act > 3) return BF_EINVAL;
     if (act == 2 && !(alpha >= 0.f && alpha <= 1.f)) return BF_EINVAL;
-    if (B > 65535 || (H + UF_TH - 1) / UF_TH > 65535 || (k != 3 && k != 5 && k != 7)) return BF_EUNSUPPORTED;
-    const dim3 grid((W + UF_TW - 1) / UF_TW, (H + UF_TH - 1) / UF_TH, B);
+    if (k != 3 && k != 5 && k != 7) return BF_EUNSUPPORTED;
+    const int64_t nt = (int64_t)B * ((H + UF_TH - 1) / UF_TH) * ((W + UF_TW - 1) / UF_TW);
+    if (nt >= ((int64_t)1 << 31)) return BF_EUNSUPPORTED;
+    const int ntiles = (int)nt;
+    const dim3 grid((unsigned)std::min<int64_t>(nt, UF_GRID(k)));
     hipStream_t s = (hipStream_t)stream;
-    if (k == 3) hipLaunchKernelGGL(uf_first_conv_kernel<3>, grid, dim3(256), 0, s, in, in_is_u8, out, w, Hs, Ws, H, W, normalize, v_min, v_max, act, alpha);
-    else if (k == 5) hipLaunchKernelGGL(uf_first_conv_kernel<5>, grid, dim3(256), 0, s, in, in_is_u8, out, w, Hs, Ws, H, W, normalize, v_min, v_max, act, alpha);
-    else hipLaunchKernelGGL(uf_first_conv_kernel<7>, grid, dim3(256), 0, s, in, in_is_u8, out, w, Hs, Ws, H, W, normalize, v_min, v_max, act, alpha);
+    if (k == 3) hipLaunchKernelGGL(uf_first_conv_kernel<3>, grid, dim3(256), 0, s, in, in_is_u8, out, w, Hs, Ws, H, W, normalize, v_min, v_max, act, alpha, ntiles);
+    else if (k == 5) hipLaunchKernelGGL(uf_first_conv_kernel<5>, grid, dim3(256), 0, s, in, in_is_u8, out, w, Hs, Ws, H, W, normalize, v_min, v_max, act, alpha, ntiles);
+    else hipLaunchKernelGGL(uf_first_conv_kernel<7>, grid, dim3(256), 0, s, in, in_is_u8, out, w, Hs, Ws, H, W, normalize, v_min, v_max, act, alpha, ntiles);
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
 

@@ -13,7 +13,7 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
             k = row.get("Kernel_Name", "?").split("(")[0]
             agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, counters in sorted(agg.items()):
-    if not any(s in k for s in ("fused_block", "conv3x3", "base_conv", "head_kernel", "wgrad", "bwd3x3", "fwd_block", "bwd_block", "uh_", "uo_")):
+    if not any(s in k for s in ("fused_block", "conv3x3", "base_conv", "head_kernel", "wgrad", "bwd3x3", "fwd_block", "bwd_block", "uh_", "uo_", "ug_", "uf_")):
         continue
     print(k)
     for c, vals in sorted(counters.items()):
