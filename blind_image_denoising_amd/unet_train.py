@@ -124,7 +124,8 @@ class UnetTrainGraph:
             bad.append(f"upsample_type {model.upsample_type}")
         if model.activation == "gelu": bad.append("gelu outside the convnext MLP / the attention projections")
         if model.activation == "linear": bad.append("linear activation")
-        if getattr(model, "use_concat", False): bad.append("use_concat (the Concatenate decoder runs at inference only)")
+        if getattr(model, "use_concat", False) and not model.use_mix_project and model.dec_k not in (1, 3, 5):
+            bad.append(f"use_concat without use_mix_project and decoder_kernel_size {model.dec_k}")
         if any(model.level_filters(d) == 256 and not model._is_attention(d) for d in range(model.depth)):
             bad.append("a 256-channel ConvNext level (runs at inference only)")
         if bad:
@@ -193,15 +194,19 @@ class UnetTrainGraph:
 
         # -- blocks -------------------------------------------------------------------------------------------------------
         def convnext(prefix, x, k):
-            Cc = x.shape[-1]
-            wdw = self.W(f"{prefix}/dw/kernel")                                    # [k,k,C,1]
-            w1, w2 = self.W(f"{prefix}/pw1/kernel").view(Cc, 4 * Cc), self.W(f"{prefix}/pw2/kernel").view(4 * Cc, Cc)
+            """ConvNextBlock + the residual Add (+ depth scale).  The first decoder block behind a Concatenate without mix projection
+            maps 2 C -> C channels: no Add, no StochasticDepth there (backbone_unet_laplacian.py:557-560)"""
+            Cin = x.shape[-1]
+            wdw = self.W(f"{prefix}/dw/kernel")                                    # [k,k,Cin,1]
+            Hh = int(self.off[f"{prefix}/pw1/kernel"][1][-1])
+            Cc = int(self.off[f"{prefix}/pw2/kernel"][1][-1])
+            skip = Cin == Cc
+            w1, w2 = self.W(f"{prefix}/pw1/kernel").view(Cin, Hh), self.W(f"{prefix}/pw2/kernel").view(Hh, Cc)
             t1 = UL.dwconv_mult(x, wdw, None)
             gamma = self.W(f"{prefix}/ln/gamma") if m.use_ln else None
             t2 = UL.dwconv_ln(t1, None, gamma) if m.use_ln else t1
             # the hidden layer in chunks of at most 256 units (the widest 1x1 convolution of the operator library): one chunk up
             # to 64 channels, two for the 128-channel levels of the 4-level models
-            Hh = 4 * Cc
             Hc = min(Hh, 256)
             chunks = range(Hh // Hc)
             w1c = [w1 if Hc == Hh else w1[:, j * Hc:(j + 1) * Hc].contiguous() for j in chunks]
@@ -213,15 +218,15 @@ class UnetTrainGraph:
                 t4 = UL.pointwise(t3[j], pack(w2c[j]), Cc, res=t4)
             wm = self.W(f"{prefix}/gamma/w") if m.use_gamma else None
             mult = UL.channel_multiplier(wm) if m.use_gamma else None
-            s = depth_scale.get(prefix)
-            out = ops.scale_add(x, t4, mult, s)
+            s = depth_scale.get(prefix) if skip else None
+            out = ops.scale_add(x if skip else None, t4, mult, s)
 
             def bwd(dout):
                 dm = torch.empty(Cc, dtype=torch.float32, device=dev) if m.use_gamma else None
                 dt4 = ops.scale_add_bwd(t4, mult, s, dout, dm)
                 if m.use_gamma:
                     _call("bf_op_multiplier_bwd", N.ptr(wm), N.ptr(dm), N.ptr(self.G(f"{prefix}/gamma/w", grads)), Cc, N.stream_ptr(dm))
-                gw2, gw1 = self.G(f"{prefix}/pw2/kernel", grads).view(Hh, Cc), self.G(f"{prefix}/pw1/kernel", grads).view(Cc, Hh)
+                gw2, gw1 = self.G(f"{prefix}/pw2/kernel", grads).view(Hh, Cc), self.G(f"{prefix}/pw1/kernel", grads).view(Cin, Hh)
                 dt2 = None
                 for j in chunks:
                     ops.matmul_wgrad(t3[j], dt4, gw2[j * Hc:(j + 1) * Hc])
@@ -229,15 +234,16 @@ class UnetTrainGraph:
                     if Hc == Hh:
                         ops.matmul_wgrad(t2, dt3, gw1)
                     else:                                          # a column block of the kernel gradient: staged, then copied in
-                        blk = torch.empty((Cc, Hc), dtype=torch.float32, device=dev)
+                        blk = torch.empty((Cin, Hc), dtype=torch.float32, device=dev)
                         ops.matmul_wgrad(t2, dt3, blk)
                         gw1[:, j * Hc:(j + 1) * Hc].copy_(blk)
-                    dt2 = UL.pointwise(dt3, pack(ops.transpose(w1c[j])), Cc, res=dt2)
+                    dt2 = UL.pointwise(dt3, pack(ops.transpose(w1c[j])), Cin, res=dt2)
                 dt1 = ops.layernorm_bwd(t1, gamma, dt2, self.G(f"{prefix}/ln/gamma", grads)) if m.use_ln else dt2
                 ops.dwconv_wgrad(x, dt1, self.G(f"{prefix}/dw/kernel", grads), k)
                 wf = torch.empty_like(wdw)
-                _call("bf_op_flip_hw", N.ptr(wdw), N.ptr(wf), k, Cc, N.stream_ptr(wdw))
-                return ops.add(dout, UL.dwconv_mult(dt1, wf, None))
+                _call("bf_op_flip_hw", N.ptr(wdw), N.ptr(wf), k, Cin, N.stream_ptr(wdw))
+                dx = UL.dwconv_mult(dt1, wf, None)
+                return ops.add(dout, dx) if skip else dx
             return out, bwd
 
         def attention(prefix, x):
@@ -480,6 +486,9 @@ class UnetTrainGraph:
             b_gate = None
             if m.use_attention_gates:
                 x, b_gate = attention_gate(d, lap[d], up)
+            elif m.use_concat:                                                # Concatenate([encoder feature, upsampled]) (:516-517)
+                x = torch.empty(up.shape[:-1] + (2 * Cc,), dtype=torch.float32, device=dev)
+                _call("bf_op_concat_channels", N.ptr(lap[d]), N.ptr(up), None, N.ptr(x), up.numel() // Cc, Cc, Cc, 0, N.stream_ptr(up))
             else:
                 x = ops.add(lap[d], up)
             chain = [("up", b_up, low.shape, bil, b_gate, conv_first)]
@@ -547,6 +556,12 @@ class UnetTrainGraph:
             _, b_up, low_shape, bil, b_gate, conv_first = chain[0]
             if b_gate is not None:
                 dlap[d], g = b_gate(g)                                   # x = gate(lap[d], up) + up
+            elif m.use_concat:                                          # x = [lap[d] | up]: the two halves of the gradient
+                Ch = g.shape[-1] // 2
+                halves = [torch.empty(g.shape[:-1] + (Ch,), dtype=torch.float32, device=dev) for _ in range(2)]
+                for h_, o_ in zip(halves, (0, Ch)):
+                    _call("bf_op_slice_channels", N.ptr(g), N.ptr(h_), g.numel() // (2 * Ch), 2 * Ch, o_, Ch, N.stream_ptr(g))
+                dlap[d], g = halves
             else:
                 dlap[d] = g                                             # x = lap[d] + up
             if conv_first:                                              # up = resize(conv(low))

@@ -107,7 +107,7 @@ def check_trainable_graph(spec: U.UnetLaplacianSpec):
     if spec.upsample_type not in ("upsample_laplacian_conv2d", "upsample_nearest_conv2d", "upsample_bilinear_conv2d", "bilinear", "nn", "nearest"):
         bad.append(f"upsample_type {spec.upsample_type}")
     if not (spec.use_laplacian or spec.use_laplacian_averaging): bad.append("no laplacian split")
-    if getattr(spec, "use_concat", False): bad.append("use_concat (inference only)")
+    if getattr(spec, "use_concat", False) and spec.use_attention_gates: bad.append("use_concat with use_attention_gates")
     if bad:
         raise NotImplementedError("unet_laplacian training: " + ", ".join(bad))
 
@@ -196,12 +196,15 @@ def backbone(spec, P, xn, depth_scale=None, attn_scale=None):
             z = xg + yg
             o = _multiplier(_conv(torch.where(z > 0, z, 0.1 * z), P[f"gate{d}/o/kernel"]), P[f"gate{d}/scale/w"])
             enc = enc * torch.sigmoid(4.0 * o)
-        x = enc + up
+        x = torch.cat([enc, up], dim=-1) if getattr(spec, "use_concat", False) else enc + up      # Concatenate / Add (:516-519)
         if spec.use_mix_project:                                      # backbone_unet_laplacian.py:521-527
             x = _act(_conv(x, P[f"mix{d}/kernel"]), a)
         for w in range(spec.width):
             pre = f"dec{d}_{w}"
-            x = x + branch(pre, convnext(pre, x))
+            y = convnext(pre, x)
+            # the Add (and the StochasticDepth in front of it) exists only when the channel counts agree: the first block behind a
+            # Concatenate without mix projection maps 2 C -> C and stands alone (:557-560)
+            x = x + branch(pre, y) if y.shape[-1] == x.shape[-1] else y
         if spec.use_output_normalization and spec.use_ln and not spec.output_norm_at_heads:
             x = _layer_norm(x, P[f"dec{d}/out_ln/gamma"])
         outs[d] = x

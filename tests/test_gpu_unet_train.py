@@ -242,6 +242,24 @@ def test_train_step_with_the_remaining_graph_options(backbone):
     _check_step(spec, params, model, clean, noisy, LOSS_V5, [1.0, 0.6, 0.3])
 
 
+@pytest.mark.parametrize("depth,width,backbone", [(3, 1, {"use_concat": True, "use_mix_project": True}),
+                                                  (3, 2, {"use_concat": True, "use_mix_project": False}),
+                                                  (2, 2, {"use_concat": True, "use_mix_project": False, "decoder_kernel_size": 3,
+                                                          "upsample_type": "upsample_bilinear_conv2d"}),
+                                                  (3, 1, {"use_concat": True, "use_mix_project": True, "use_self_attention": False,
+                                                          "downsample_type": "conv2d", "activation": "relu"})],
+                         ids=["builder-defaults", "concat-no-mix", "concat-no-mix-k3", "concat-mix-relu"])
+def test_train_step_with_the_concatenate_decoder(depth, width, backbone):
+    """use_concat -- the reference builder's default (backbone_unet_laplacian.py:52, 516-517): Concatenate([encoder feature, upsampled])
+    instead of Add; with use_mix_project (also a builder default) a 1x1 2C -> C + activation follows, without it the level's first
+    ConvNextBlock maps 2C -> C and has no residual Add and no StochasticDepth (:557-560)"""
+    cfg, spec, params, model, clean, noisy = _setup(depth, width, 32, 32, backbone=backbone)
+    assert model.use_concat and spec.use_concat
+    rng = np.random.default_rng(5)
+    ds = {f"dec{d}_{w}": (rng.random(2) < 0.7).astype(np.float64) / 0.7 for d in range(depth - 1) for w in range(width)}
+    _check_step(spec, params, model, clean, noisy, LOSS_V5, [1.0, 0.6, 0.3][:depth], depth_scale=ds)
+
+
 def test_train_step_with_stochastic_depth_and_attention_dropout():
     """training-mode randomness as explicit inputs: per-sample StochasticDepth scales (0 or 1 / (1 - rate)) and the attention's
     dropout keep-mask / keep-probability"""

@@ -62,8 +62,10 @@ def test_soft_orthonormal_matches_its_definition():
                                      {"use_attention_gates": True, "upsample_type": "upsample_nearest_conv2d"},
                                      {"use_mix_project": True, "downsample_type": "maxpool"},
                                      {"upsample_type": "bilinear", "filters_level_multiplier": 1.0},
-                                     {"upsample_type": "nn", "filters_level_multiplier": 1.0, "activation": "relu"}],
-                         ids=["v6", "v3", "mix-maxpool", "plain-bilinear", "plain-nearest"])
+                                     {"upsample_type": "nn", "filters_level_multiplier": 1.0, "activation": "relu"},
+                                     {"use_concat": True, "use_mix_project": True},
+                                     {"use_concat": True, "use_mix_project": False, "decoder_kernel_size": 3}],
+                         ids=["v6", "v3", "mix-maxpool", "plain-bilinear", "plain-nearest", "concat-mix (builder defaults)", "concat-no-mix"])
 def test_forward_of_the_other_shipped_graphs_equals_the_numpy_restatement(options):
     """the options of configs/unet_laplacian_v6.json (2 x 2 averaging, conv2d down-sampling, nearest + 3 x 3 up-sampling, 5 x 5
     decoder depthwise) and v3 / v4 (AdditiveAttentionGate) in the torch gradient oracle against unet_oracle.py"""
