@@ -36,9 +36,6 @@ class GenericResnetTrainGraph:
         self.loss_config = dict(loss_config)
         self.off = {name: (off, shape, kind) for name, shape, kind, off in model.trainable_variables}
         self.soff = {name: (off, shape) for name, shape, off in model.non_trainable_variables}
-        for j, (kk, g) in enumerate(zip(model.block_kernels, model.block_groups)):
-            if g != 1 and kk != 1:
-                raise NotImplementedError("training: grouped convolutions are built for 1x1 kernels")
         self.ops = None
         self.totals = None
 
@@ -159,14 +156,27 @@ class GenericResnetTrainGraph:
                         _call("bf_op_group_kernel", N.ptr(gw), N.ptr(dd), cin, cf, g, 1, N.stream_ptr(dd))
                     return UL.pointwise(dy, pack(ops.transpose(dense)), cin)
                 return y, bwd
-            # k x k dense convolution
-            y = UL.conv2d(x, UL.pack_conv(w.contiguous()), cf, kk, 1, "linear")
+            # k x k convolution; Conv2D(groups = g) as the block-diagonal dense one, tap by tap (keras kernel [k][k][cin / g][cf]): the
+            # kernel gradient is taken dense and its diagonal blocks are written back (backbone_blocks.py:196-205, conv2d groups)
+            wd = w
+            if g != 1:
+                wd = torch.empty((kk, kk, cin, cf), **f32)
+                for t_ in range(kk * kk):
+                    _call("bf_op_group_kernel", N.ptr(w.view(kk * kk, cin // g, cf)[t_]), N.ptr(wd.view(kk * kk, cin, cf)[t_]), cin, cf, g, 0,
+                          N.stream_ptr(w))
+            y = UL.conv2d(x, UL.pack_conv(wd.contiguous()), cf, kk, 1, "linear")
 
-            def bwd(dy):
+            def bwd(dy, w=wd):
                 Bc, Hc, Wc, _ = x.shape
                 sp, sn = ops._s()
-                _call("bf_op_conv2d_wgrad", N.ptr(x), 0, N.ptr(dy), N.ptr(self.G(name, grads)), Bc, Hc, Wc, cin, cf, kk, 0, 0.0, 0.0,
+                gw = self.G(name, grads)
+                gd = gw if g == 1 else torch.empty((kk, kk, cin, cf), **f32)
+                _call("bf_op_conv2d_wgrad", N.ptr(x), 0, N.ptr(dy), N.ptr(gd), Bc, Hc, Wc, cin, cf, kk, 0, 0.0, 0.0,
                       sp, sn, N.stream_ptr(dy))
+                if g != 1:
+                    for t_ in range(kk * kk):
+                        _call("bf_op_group_kernel", N.ptr(gw.view(kk * kk, cin // g, cf)[t_]), N.ptr(gd.view(kk * kk, cin, cf)[t_]), cin, cf, g, 1,
+                              N.stream_ptr(gd))
                 # data gradient = convolution with the taps flipped and every tap transposed
                 wf = torch.empty_like(w)
                 _call("bf_op_flip_hw", N.ptr(w), N.ptr(wf), kk, cin * cf, N.stream_ptr(w))

@@ -97,6 +97,12 @@ CONFIGS = {
     "bottleneck-64-groups-nobn": dict(filters=64, kernel_size=5, block_kernels=[1, 3, 1], block_filters=[64, 128, 64],
                                       block_depthwise=[-1, 2, -1], block_groups=[2, 1, 4], block_activation=["relu", "relu", "linear"],
                                       block_regularizer=["l1", "l1", "l1"], no_layers=1, use_bn=False),
+    # Conv2D(groups) with a 3 x 3 / 5 x 5 kernel: trained as the block-diagonal dense convolution, the kernel gradient's diagonal blocks kept
+    "grouped-3x3": dict(filters=32, kernel_size=3, block_kernels=[3, 3], block_filters=[64, 32], block_depthwise=[-1, -1],
+                        block_groups=[2, 4], block_activation=["relu", "relu"], block_regularizer=["l1", "l2"], no_layers=2),
+    "grouped-5x5-bottleneck-nobn": dict(filters=32, kernel_size=3, block_kernels=[1, 5, 1], block_filters=[32, 32, 32],
+                                        block_depthwise=[-1, -1, -1], block_groups=[1, 8, 2], block_activation=["relu", "relu", "linear"],
+                                        block_regularizer=["l1", "l1", "l1"], no_layers=1, use_bn=False),
     # the builder's remaining flags (backbone_resnet.py:225-242, 264-287): BatchNorm around the blocks, ChannelwiseMultiplier and
     # Multiplier closing every block and the backbone, RandomOnOff on the branches
     "bn-around-blocks": dict(no_layers=2, add_initial_bn=True, add_final_bn=True),
@@ -233,8 +239,6 @@ def test_random_builder_configurations_train(seed):
     rng = np.random.default_rng(5000 + seed)
     bb = rg._random_resnet_config(rng)
     bb["no_layers"] = min(bb["no_layers"], 2)
-    if any(k != 1 and g != 1 for k, g in zip(bb["block_kernels"], bb["block_groups"])):
-        pytest.skip("training: grouped convolutions are built for 1x1 kernels")
     cfg = R.shipped_config()
     cfg["backbone"].update(bb)
     spec = R.GenericResnetSpec.from_config(cfg)
