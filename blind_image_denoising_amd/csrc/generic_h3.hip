@@ -91,18 +91,12 @@ extern "C" int bf_op_pack_bneck_h3(const float* w0, const float* wd, const float
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
 
-#ifndef UG_UNROLL_C
-#define UG_UNROLL_C 1
-#endif
-constexpr int UG_UC = UG_UNROLL_C;
-#ifndef UG_PREFETCH
-#define UG_PREFETCH 1     // 0: phase A's pixels requested when phase A starts (the first form: 522 us per launch at batch 64 x 256 x 256)
-#endif
 #ifndef UG_ABLATE
 #define UG_ABLATE 0       // timing builds (results wrong): 1 no phase A, 2 no depthwise FMAs, 4 no closing MFMAs, 8 no residual / store
 #endif
 
-template <bool RELU>
+// RELU: all three activations are ReLU; FAST: every tile is full (height % 8 == 0, width % 32 == 0) and the skip is on
+template <bool RELU, bool FAST>
 __global__ __launch_bounds__(256, 2) void ug_bneck_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                           const char* __restrict__ packed, const float* __restrict__ shift0,
                                                           const float* __restrict__ shift1, const float* __restrict__ shift2,
@@ -162,43 +156,106 @@ __global__ __launch_bounds__(256, 2) void ug_bneck_kernel(const float* __restric
             xa[k][1] = *reinterpret_cast<const f32x4*>(src + 4);
         }
     };
-    if (slot < per_xcd && xcd * per_xcd + slot < ntiles) request(xcd * per_xcd + slot);
+    // ---- phase A: the leading 1x1 on the haloed tile whose pixels `request` fetched
+    auto phase_a = [&]() {
+        if (UG_ABLATE & 1) return;
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            if (16 * (wave + 4 * k) >= UG_NPX) continue;           // wave-uniform
+            uh8 xh, xl;
+            uh_split8(xa[k][0], xa[k][1], xh, xl);
+            const int e = 16 * (wave + 4 * k) + n;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uh8 ah = *reinterpret_cast<const uh8*>(w0l + (2 * t) * 1024);
+                const uh8 al = *reinterpret_cast<const uh8*>(w0l + (2 * t + 1) * 1024);
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                a = UH_MFMA_REAL(ah, xh, a);
+                a = UH_MFMA_REAL(al, xh, a);
+                a = UH_MFMA_REAL(ah, xl, a);
+                f32x4 v = a * inv0 + *reinterpret_cast<const f32x4*>(sh0 + 16 * t + 4 * q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = inimg[k] ? ug_act<RELU>(v[r], slope0) : 0.f;
+                if (e < UG_NPX) *reinterpret_cast<f32x4*>(tile + e * UG_PITCH + 16 * t + 4 * q) = v;
+            }
+        }
+    };
+    // One chunk of 32 hidden channels of phase B (no memory instruction inside: the chunk loops below do not disturb hipcc's count of
+    // what is in flight)
+    auto chunk = [&](const int c, const float* tb, f32x4 (&acc)[4][2]) {
+        f32x2 px[6][3];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) px[r][kx] = *reinterpret_cast<const f32x2*>(tb + (r * UG_IW + kx) * UG_PITCH + 8 * c);
+        const int h0 = 32 * c + 8 * q;
+        f32x4 hv[4][2];
+        {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sh1 + h0), b1 = *reinterpret_cast<const f32x4*>(sh1 + h0 + 4);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) { hv[o][0] = b0; hv[o][1] = b1; }
+        }
+        if (!(UG_ABLATE & 2)) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const f32x4 wa = *reinterpret_cast<const f32x4*>(dwl + (ky * 3 + kx) * 128 + h0);
+                    const f32x4 wb = *reinterpret_cast<const f32x4*>(dwl + (ky * 3 + kx) * 128 + h0 + 4);
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        hv[o][0] += wa * px[o + ky][kx][0];
+                        hv[o][1] += wb * px[o + ky][kx][1];
+                    }
+                }
+        }
+        uh8 bh[4], bl[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                hv[o][0][r] = ug_act<RELU>(hv[o][0][r], slope1);
+                hv[o][1][r] = ug_act<RELU>(hv[o][1][r], slope1);
+            }
+            uh_split8(hv[o][0], hv[o][1], bh[o], bl[o]);
+        }
+        if (!(UG_ABLATE & 4)) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uh8 ah = *reinterpret_cast<const uh8*>(w2l + ((c * 2 + t) * 2) * 1024);
+                const uh8 al = *reinterpret_cast<const uh8*>(w2l + ((c * 2 + t) * 2 + 1) * 1024);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) acc[o][t] = UH_MFMA_REAL(ah, bh[o], acc[o][t]);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) acc[o][t] = UH_MFMA_REAL(al, bh[o], acc[o][t]);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) acc[o][t] = UH_MFMA_REAL(ah, bl[o], acc[o][t]);
+            }
+        } else {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) acc[o][0] += __builtin_bit_cast(f32x4, bh[o]) + __builtin_bit_cast(f32x4, bl[o]);
+        }
+    };
 
-    for (int tl = slot; tl < per_xcd; tl += nslots) {
-        const int tile_id = xcd * per_xcd + tl;
-        if (tile_id >= ntiles) break;                              // workgroup-uniform
+    // The tile loop is rotated: [request tile k+1] [phase B of tile k] [barrier] [phase A of tile k+1] [barrier].  gfx950 counts loads and
+    // stores in one queue (vmcnt): with the request and the phase A that consumes it in ONE straight-line iteration -- and, in the FAST
+    // instance (full tiles, skip on), no branch around the skip's loads and the stores in between -- hipcc knows that 8 loads and 8 stores
+    // were issued behind the request and waits with vmcnt(26) .. vmcnt(16); in the first form (request consumed across the loop's back
+    // edge, conditional stores) it waited with vmcnt(10) .. (0): every tile waited for its own stores to land before phase A could start.
+    int tl = slot, tile_id = xcd * per_xcd + tl;
+    bool valid = tl < per_xcd && tile_id < ntiles;
+    if (valid) {
+        request(tile_id);
+        phase_a();
+    }
+    __syncthreads();
+    while (valid) {                                                // workgroup-uniform
         const int tx = tile_id % tiles_x, rest = tile_id / tiles_x, ty = rest % tiles_y;
         const int64_t img = (int64_t)(rest / tiles_y) * H * W;
         const int x0 = tx * UG_TW, y0 = ty * UG_TH;
-
-        // ---- phase A: the leading 1x1 on the haloed tile
-        if (!(UG_ABLATE & 1)) {
-#pragma unroll
-            for (int k = 0; k < NG; ++k) {
-                if (16 * (wave + 4 * k) >= UG_NPX) continue;       // wave-uniform
-                uh8 xh, xl;
-                uh_split8(xa[k][0], xa[k][1], xh, xl);
-                const int e = 16 * (wave + 4 * k) + n;
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const uh8 ah = *reinterpret_cast<const uh8*>(w0l + (2 * t) * 1024);
-                    const uh8 al = *reinterpret_cast<const uh8*>(w0l + (2 * t + 1) * 1024);
-                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                    a = UH_MFMA_REAL(ah, xh, a);
-                    a = UH_MFMA_REAL(al, xh, a);
-                    a = UH_MFMA_REAL(ah, xl, a);
-                    f32x4 v = a * inv0 + *reinterpret_cast<const f32x4*>(sh0 + 16 * t + 4 * q);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = inimg[k] ? ug_act<RELU>(v[r], slope0) : 0.f;
-                    if (e < UG_NPX) *reinterpret_cast<f32x4*>(tile + e * UG_PITCH + 16 * t + 4 * q) = v;
-                }
-            }
-        }
-        __syncthreads();
-        if (UG_PREFETCH) {
-            const int tn = tl + nslots, idn = xcd * per_xcd + tn;
-            request(tn < per_xcd && idn < ntiles ? idn : tile_id);
-        }
+        const int tn = tl + nslots, idn = xcd * per_xcd + tn;
+        const bool has_next = tn < per_xcd && idn < ntiles;
+        request(has_next ? idn : tile_id);
 
         // ---- phase B: depthwise x4 -> activation -> closing 1x1 on 4 rows x 16 columns per wave
         {
@@ -210,82 +267,31 @@ __global__ __launch_bounds__(256, 2) void ug_bneck_kernel(const float* __restric
 #pragma unroll
                 for (int t = 0; t < 2; ++t) acc[o][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const float* tb = tile + ((4 * rq) * UG_IW + 16 * cw + n) * UG_PITCH + 2 * q;
-#pragma unroll UG_UC
-            for (int c = 0; c < 4; ++c) {
-                if (c == 2 && add_res && !(UG_ABLATE & 8)) {           // the skip: two chunks of work ahead of its use, out of the way before
-#pragma unroll
-                    for (int o = 0; o < 4; ++o) {
-                        const int gy = y0 + 4 * rq + o;
-                        const float* src = x + (img + (int64_t)min(gy, H - 1) * W + min(gx, W - 1)) * 32 + 4 * q;
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) res[o][t] = *reinterpret_cast<const f32x4*>(src + 16 * t);
-                    }
-                }
-                f32x2 px[6][3];
-#pragma unroll
-                for (int r = 0; r < 6; ++r)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) px[r][kx] = *reinterpret_cast<const f32x2*>(tb + (r * UG_IW + kx) * UG_PITCH + 8 * c);
-                const int h0 = 32 * c + 8 * q;
-                f32x4 hv[4][2];
-                {
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(sh1 + h0), b1 = *reinterpret_cast<const f32x4*>(sh1 + h0 + 4);
-#pragma unroll
-                    for (int o = 0; o < 4; ++o) { hv[o][0] = b0; hv[o][1] = b1; }
-                }
-                if (!(UG_ABLATE & 2)) {
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const f32x4 wa = *reinterpret_cast<const f32x4*>(dwl + (ky * 3 + kx) * 128 + h0);
-                            const f32x4 wb = *reinterpret_cast<const f32x4*>(dwl + (ky * 3 + kx) * 128 + h0 + 4);
-#pragma unroll
-                            for (int o = 0; o < 4; ++o) {
-                                hv[o][0] += wa * px[o + ky][kx][0];
-                                hv[o][1] += wb * px[o + ky][kx][1];
-                            }
-                        }
-                }
-                uh8 bh[4], bl[4];
+#pragma unroll 1
+            for (int c = 0; c < 2; ++c) chunk(c, tb, acc);
+            if ((FAST || add_res) && !(UG_ABLATE & 8)) {           // the skip: two chunks of work ahead of its use, out of the way before
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
+                    const int gy = y0 + 4 * rq + o;
+                    const float* src = x + (img + (int64_t)min(gy, H - 1) * W + min(gx, W - 1)) * 32 + 4 * q;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        hv[o][0][r] = ug_act<RELU>(hv[o][0][r], slope1);
-                        hv[o][1][r] = ug_act<RELU>(hv[o][1][r], slope1);
-                    }
-                    uh_split8(hv[o][0], hv[o][1], bh[o], bl[o]);
-                }
-                if (!(UG_ABLATE & 4)) {
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const uh8 ah = *reinterpret_cast<const uh8*>(w2l + ((c * 2 + t) * 2) * 1024);
-                        const uh8 al = *reinterpret_cast<const uh8*>(w2l + ((c * 2 + t) * 2 + 1) * 1024);
-#pragma unroll
-                        for (int o = 0; o < 4; ++o) acc[o][t] = UH_MFMA_REAL(ah, bh[o], acc[o][t]);
-#pragma unroll
-                        for (int o = 0; o < 4; ++o) acc[o][t] = UH_MFMA_REAL(al, bh[o], acc[o][t]);
-#pragma unroll
-                        for (int o = 0; o < 4; ++o) acc[o][t] = UH_MFMA_REAL(ah, bl[o], acc[o][t]);
-                    }
-                } else {
-#pragma unroll
-                    for (int o = 0; o < 4; ++o) acc[o][0] += __builtin_bit_cast(f32x4, bh[o]) + __builtin_bit_cast(f32x4, bl[o]);
+                    for (int t = 0; t < 2; ++t) res[o][t] = *reinterpret_cast<const f32x4*>(src + 16 * t);
                 }
             }
+#pragma unroll 1
+            for (int c = 2; c < 4; ++c) chunk(c, tb, acc);
             if (!(UG_ABLATE & 8)) {
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
                     const int gy = y0 + 4 * rq + o;
-                    if (gy >= H || gx >= W) continue;
+                    if (!FAST && (gy >= H || gx >= W)) continue;
                     float* dst = out + (img + (int64_t)gy * W + gx) * 32 + 4 * q;
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         f32x4 v = acc[o][t] * inv2 + *reinterpret_cast<const f32x4*>(sh2 + 16 * t + 4 * q);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = ug_act<RELU>(v[r], slope2);
-                        if (add_res) v += res[o][t];
+                        if (FAST || add_res) v += res[o][t];
                         *reinterpret_cast<f32x4*>(dst + 16 * t) = v;
                     }
                 }
@@ -293,11 +299,12 @@ __global__ __launch_bounds__(256, 2) void ug_bneck_kernel(const float* __restric
                 out[lane] = acc[1][0][0] + acc[2][1][1] + acc[3][0][2];
             }
         }
-        __syncthreads();                                           // the next tile's phase A overwrites the staged map
-        if (!UG_PREFETCH) {
-            const int tn = tl + nslots, idn = xcd * per_xcd + tn;
-            request(tn < per_xcd && idn < ntiles ? idn : tile_id);
-        }
+        __syncthreads();                                           // phase A of the next tile overwrites the staged map
+        if (has_next) phase_a();
+        __syncthreads();
+        tl = tn;
+        tile_id = idn;
+        valid = has_next;
     }
 }
 
@@ -321,15 +328,19 @@ extern "C" int bf_op_bneck_block_h3(const float* x, float* out, const void* pack
     if (ntiles >= ((int64_t)1 << 31) || (int64_t)B * H * W >= ((int64_t)1 << 31) || (int64_t)H * W * 32 >= ((int64_t)1 << 31))
         return BF_EUNSUPPORTED;                                    // 32-bit element offsets inside an image
     const bool relu = act0 == 1 && act1 == 1 && act2 == 1;
-    const void* fn = relu ? reinterpret_cast<const void*>(ug_bneck_kernel<true>) : reinterpret_cast<const void*>(ug_bneck_kernel<false>);
-    if (bf_set_max_lds(fn, UG_LDS_BYTES) != hipSuccess) return BF_EHIP;
+    const bool fast = add_res && H % UG_TH == 0 && W % UG_TW == 0;
     const int per_xcd = (int)((ntiles + 7) / 8);
     const int grid = 8 * (int)std::min<int64_t>(per_xcd, 64);      // 512 workgroups: two per CU, a multiple of the 8 XCDs
-    if (relu)
-        hipLaunchKernelGGL(ug_bneck_kernel<true>, dim3(grid), dim3(256), UG_LDS_BYTES, (hipStream_t)stream, x, out, (const char*)packed, shift0,
-                           shift1, shift2, slope[0], slope[1], slope[2], add_res, B, H, W);
-    else
-        hipLaunchKernelGGL(ug_bneck_kernel<false>, dim3(grid), dim3(256), UG_LDS_BYTES, (hipStream_t)stream, x, out, (const char*)packed, shift0,
-                           shift1, shift2, slope[0], slope[1], slope[2], add_res, B, H, W);
+#define UG_LAUNCH(R, F)                                                                                                        \
+    do {                                                                                                                       \
+        if (bf_set_max_lds(reinterpret_cast<const void*>(ug_bneck_kernel<R, F>), UG_LDS_BYTES) != hipSuccess) return BF_EHIP;  \
+        hipLaunchKernelGGL((ug_bneck_kernel<R, F>), dim3(grid), dim3(256), UG_LDS_BYTES, (hipStream_t)stream, x, out,          \
+                           (const char*)packed, shift0, shift1, shift2, slope[0], slope[1], slope[2], add_res, B, H, W);       \
+    } while (0)
+    if (relu && fast) UG_LAUNCH(true, true);
+    else if (relu) UG_LAUNCH(true, false);
+    else if (fast) UG_LAUNCH(false, true);
+    else UG_LAUNCH(false, false);
+#undef UG_LAUNCH
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }

@@ -13,9 +13,12 @@
 constexpr int UF_TH = 8, UF_TW = 64, UF_CIN = 3, UF_COUT = 32;
 typedef unsigned uf_u4 __attribute__((ext_vector_type(4)));
 #ifndef UF_GRID
-// workgroups of the launch.  k = 7: persistent, two per CU (252 registers): 418 -> 340 us at 64 x 256 x 256.  k = 3, 5: one tile per
-// workgroup as before -- persistent workgroups measured SLOWER for k = 5 (509 vs 463 us at 32 x 512 x 512: with two resident workgroups
-// per CU the per-tile load -> barrier -> compute chain is exposed, and 48 weight loads per lane are cheap enough to repeat)
+// workgroups of the launch.  k = 7: persistent, two per CU (256 registers), the next tile's patch requested a tile ahead: 418 -> 298 us at
+// 64 x 256 x 256.  k = 3, 5: one tile per workgroup as before -- persistent workgroups measured SLOWER for k = 5 (509 us, with the
+// prefetch 535 us, against 463 us at 32 x 512 x 512): gfx950 counts loads and stores in one queue (vmcnt), the stores of a tile are conditional
+// (edge tiles), so hipcc waits for the prefetched patch with vmcnt(0) -- every tile waits for its own stores to land.  Unrolling the eight
+// pixel groups to make the store count static took 331 / 503 registers.  A loader wave of its own (it never stores) is the form that
+// would fix it; not built.
 #define UF_GRID(k) ((k) == 7 ? (int64_t)512 : ((int64_t)1 << 31))
 #endif
 
@@ -72,79 +75,91 @@ __global__ __launch_bounds__(256) void uf_first_conv_kernel(const void* __restri
         }
     }
     // The workgroup prepares its weight fragments ONCE (a max reduction over the kernel + 16 * UF_NS scalar loads per lane: as much L2
-    // traffic per 8 x 64 tile as the tile's output when every tile was a workgroup of its own) and then walks tiles.
+    // traffic per 8 x 64 tile as the tile's output when every tile was a workgroup of its own) and then walks tiles; the raw values of the
+    // NEXT tile's patch are requested before the current tile is multiplied (unconditional loads from clamped addresses, masked when they
+    // are converted: with two or three resident workgroups per CU nothing else covers the load -> barrier -> multiply chain of a tile).
     const int tiles_x = (W + UF_TW - 1) / UF_TW, tiles_y = (H + UF_TH - 1) / UF_TH;
+    constexpr int NE = (UF_NE + 255) / 256;
+    float rv[NE];
+    int pyk[NE], pxk[NE];                              // the element's row / column inside the patch (-UF_KS / 2 applied); same for every tile
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = min((int)threadIdx.x + i * 256, UF_NE - 1);
+        pxk[i] = (e / UF_CIN) % UF_IW - UF_KS / 2;
+        pyk[i] = e / (UF_CIN * UF_IW) - UF_KS / 2;
+    }
+    const int ci = (threadIdx.x % UF_CIN);             // 256 % 3 = 1: the channel of element threadIdx.x + 256 i is (ci + i) % 3
+    auto request = [&](const int tid) {
+        const int x0 = (tid % tiles_x) * UF_TW, y0 = ((tid / tiles_x) % tiles_y) * UF_TH;
+        const int64_t b = tid / (tiles_x * tiles_y);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int yy = min(max(y0 + pyk[i], 0), Hs - 1), xx = min(max(x0 + pxk[i], 0), Ws - 1);
+            const int64_t o = ((b * Hs + yy) * Ws + xx) * UF_CIN + (ci + i) % UF_CIN;
+            rv[i] = in_is_u8 ? (float)reinterpret_cast<const unsigned char*>(in)[o] : reinterpret_cast<const float*>(in)[o];
+        }
+    };
+    if ((int)blockIdx.x < ntiles) request(blockIdx.x);
     for (int tid = blockIdx.x; tid < ntiles; tid += gridDim.x) {
         const int x0 = (tid % tiles_x) * UF_TW, y0 = ((tid / tiles_x) % tiles_y) * UF_TH;
         const int64_t b = tid / (tiles_x * tiles_y);
-        {
-            constexpr int NE = (UF_NE + 255) / 256;
-            float rv[NE];
-            bool inpad[NE];
 #pragma unroll
-            for (int i = 0; i < NE; ++i) {
-                const int e = threadIdx.x + i * 256;
-                const int ci = e % UF_CIN, px = (e / UF_CIN) % UF_IW, py = e / (UF_CIN * UF_IW);
-                const int yy = y0 + py - UF_KS / 2, xx = x0 + px - UF_KS / 2;
-                inpad[i] = e < UF_NE && yy >= 0 && yy < H && xx >= 0 && xx < W;      // inside the (virtually padded) image
-                rv[i] = 0.f;
-                if (inpad[i] && yy < Hs && xx < Ws) {
-                    const int64_t o = ((b * Hs + yy) * Ws + xx) * UF_CIN + ci;
-                    rv[i] = in_is_u8 ? (float)reinterpret_cast<const unsigned char*>(in)[o] : reinterpret_cast<const float*>(in)[o];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NE; ++i) {
-                const int e = threadIdx.x + i * 256;
-                float v = rv[i];
-                if (inpad[i] && normalize) v = (fminf(fmaxf(v, v_min), v_max) - v_min) / range - 0.5f;
-                if (!inpad[i]) v = 0.f;
-                const _Float16 hi = (_Float16)v;
-                const _Float16 lo = (_Float16)(v - (float)hi);
-                if (e < UF_NE) tile[e] = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
-            }
+        for (int i = 0; i < NE; ++i) {
+            const int e = threadIdx.x + i * 256;
+            const int yy = y0 + pyk[i], xx = x0 + pxk[i];
+            const bool inpad = yy >= 0 && yy < H && xx >= 0 && xx < W;           // inside the (virtually padded) image
+            float v = (inpad && yy < Hs && xx < Ws) ? rv[i] : 0.f;               // the pad band between the source and [H, W] is value 0
+            if (inpad && normalize) v = (fminf(fmaxf(v, v_min), v_max) - v_min) / range - 0.5f;
+            if (!inpad) v = 0.f;
+            const _Float16 hi = (_Float16)v;
+            const _Float16 lo = (_Float16)(v - (float)hi);
+            if (e < UF_NE) tile[e] = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
         }
         __syncthreads();
-    // 8 rows x 4 column groups of 16 pixels = 32 groups, 8 per wave
-    for (int gi = wave; gi < UF_TH * (UF_TW / 16); gi += 4) {
-        const int ry = gi / (UF_TW / 16), cx = (gi % (UF_TW / 16)) * 16 + n;
-        const unsigned* base = tile + (ry * UF_IW + cx) * UF_CIN;
-        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int s = 0; s < UF_NS; ++s) {
-            unsigned e[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) e[i] = base[koff[s][i]];
-            uf_u4 ph, pl;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ph[j] = __builtin_amdgcn_perm(e[2 * j + 1], e[2 * j], 0x05040100u);     // the two hi halves
-                pl[j] = __builtin_amdgcn_perm(e[2 * j + 1], e[2 * j], 0x07060302u);     // the two lo halves
-            }
-            const uh8 xh = __builtin_bit_cast(uh8, ph), xl = __builtin_bit_cast(uh8, pl);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                acc[t] = UH_MFMA(wh[s][t], xh, acc[t]);
-                acc[t] = UH_MFMA(wl[s][t], xh, acc[t]);
-                acc[t] = UH_MFMA(wh[s][t], xl, acc[t]);
-            }
+        if ((int)gridDim.x < ntiles) {                   // kernel-uniform: a launch with one tile per workgroup has nothing to request
+            const int nxt = tid + (int)gridDim.x;
+            request(nxt < ntiles ? nxt : tid);
         }
-        const int gy = y0 + ry, gx = x0 + cx;
-        if (gy < H && gx < W) {
-            float* op = out + ((b * H + gy) * (int64_t)W + gx) * UF_COUT + 4 * q;
+        // 8 rows x 4 column groups of 16 pixels = 32 groups, 8 per wave
+        for (int gi = wave; gi < UF_TH * (UF_TW / 16); gi += 4) {
+            const int ry = gi / (UF_TW / 16), cx = (gi % (UF_TW / 16)) * 16 + n;
+            const unsigned* base = tile + (ry * UF_IW + cx) * UF_CIN;
+            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                f32x4 v = bf_acc_ready(acc[t]) * inv;
+            for (int s = 0; s < UF_NS; ++s) {
+                unsigned e[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (act == 1) v[r] = fmaxf(v[r], 0.f);
-                    else if (act == 2) v[r] = fmaxf(v[r], alpha * v[r]);
-                    else if (act == 3) v[r] = uh_act<3>(v[r], 0.f);
+                for (int i = 0; i < 8; ++i) e[i] = base[koff[s][i]];
+                uf_u4 ph, pl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ph[j] = __builtin_amdgcn_perm(e[2 * j + 1], e[2 * j], 0x05040100u);     // the two hi halves
+                    pl[j] = __builtin_amdgcn_perm(e[2 * j + 1], e[2 * j], 0x07060302u);     // the two lo halves
                 }
-                *reinterpret_cast<f32x4*>(op + 16 * t) = v;
+                const uh8 xh = __builtin_bit_cast(uh8, ph), xl = __builtin_bit_cast(uh8, pl);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    acc[t] = UH_MFMA(wh[s][t], xh, acc[t]);
+                    acc[t] = UH_MFMA(wl[s][t], xh, acc[t]);
+                    acc[t] = UH_MFMA(wh[s][t], xl, acc[t]);
+                }
+            }
+            const int gy = y0 + ry, gx = x0 + cx;
+            if (gy < H && gx < W) {
+                float* op = out + ((b * H + gy) * (int64_t)W + gx) * UF_COUT + 4 * q;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 v = bf_acc_ready(acc[t]) * inv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (act == 1) v[r] = fmaxf(v[r], 0.f);
+                        else if (act == 2) v[r] = fmaxf(v[r], alpha * v[r]);
+                        else if (act == 3) v[r] = uh_act<3>(v[r], 0.f);
+                    }
+                    *reinterpret_cast<f32x4*>(op + 16 * t) = v;
+                }
             }
         }
-    }
         __syncthreads();                                 // the next tile's patch overwrites this one
     }
 }
@@ -164,9 +179,11 @@ extern "C" int bf_op_first_conv_h3k(const void* in, int in_is_u8, float* out, co
     const int ntiles = (int)nt;
     const dim3 grid((unsigned)std::min<int64_t>(nt, UF_GRID(k)));
     hipStream_t s = (hipStream_t)stream;
-    if (k == 3) hipLaunchKernelGGL(uf_first_conv_kernel<3>, grid, dim3(256), 0, s, in, in_is_u8, out, w, Hs, Ws, H, W, normalize, v_min, v_max, act, alpha, ntiles);
-    else if (k == 5) hipLaunchKernelGGL(uf_first_conv_kernel<5>, grid, dim3(256), 0, s, in, in_is_u8, out, w, Hs, Ws, H, W, normalize, v_min, v_max, act, alpha, ntiles);
-    else hipLaunchKernelGGL(uf_first_conv_kernel<7>, grid, dim3(256), 0, s, in, in_is_u8, out, w, Hs, Ws, H, W, normalize, v_min, v_max, act, alpha, ntiles);
+#define UF_LAUNCH(KK) hipLaunchKernelGGL((uf_first_conv_kernel<KK>), grid, dim3(256), 0, s, in, in_is_u8, out, w, Hs, Ws, H, W, normalize, v_min, v_max, act, alpha, ntiles)
+    if (k == 3) UF_LAUNCH(3);
+    else if (k == 5) UF_LAUNCH(5);
+    else UF_LAUNCH(7);
+#undef UF_LAUNCH
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
 
