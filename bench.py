@@ -626,7 +626,8 @@ def generic_bench(args, torch, bf, O, rank, local_rank, world, dist):
         "end_to_end_tflops": value / world * per_px * S * S / 1e12,
         "roofline": {"bound": "hbm", "kernel": "ug_bneck_kernel (1x1 32 -> 32 + depthwise 3x3 x4 + BN + ReLU + 1x1 128 -> 32 + BN + Add; 6 launches per forward)",
                      "achieved": nbytes / launch_us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / launch_us / 1e3 / HBM_PEAK_GBS,
-                     "dtype": "f16x2 split operands, fp32 accumulate; depthwise in fp32", "traffic": None, "launch_us": launch_us,
+                     "dtype": "f16x2 split operands, fp32 accumulate; depthwise in fp32", "traffic": pmc_traffic(6, B, S, True, "ug_bneck_kernel"),
+                     "launch_us": launch_us,
                      "algorithmic_bytes_per_launch": nbytes,
                      "mfma": {"issued_tflops": issued / launch_us / 1e6, "peak": MFMA_F16_PEAK_TFLOPS, "frac": issued / launch_us / 1e6 / MFMA_F16_PEAK_TFLOPS,
                               "useful_gflop_per_launch": flop / 1e9},
