@@ -108,6 +108,21 @@ __global__ __launch_bounds__(256, 2) void uo_pointwise_kernel(const float* __res
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int i = 0; i < NP; ++i) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // mode 0 with a residual (the attention block's output projection 32 -> 128 reads four times the bytes it multiplies): the
+        // residual is requested BEFORE the matrix work instead of tile by tile in the epilogue (each of those loads waited a full
+        // memory round trip with two workgroups per CU: 188 us for 604 MB).  Where the tiles fit the registers (T * NP <= 16).
+        constexpr bool PRERES = T * NP <= 16;
+        f32x4 rs[PRERES ? T : 1][PRERES ? NP : 1];
+        const bool pre_res = PRERES && mode == 0 && res != nullptr;
+        if (pre_res) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                int64_t p = p0 + 16 * i + n;
+                p = p < npix ? p : npix - 1;
+#pragma unroll
+                for (int t = 0; t < T; ++t) rs[PRERES ? t : 0][PRERES ? i : 0] = *reinterpret_cast<const f32x4*>(res + p * COUT + 16 * t + 4 * q);
+            }
+        }
         // weight tiles stream through a ring of D registers (requested D steps ahead), the pixel chunks through a
         // double buffer; a scheduling barrier per step keeps hipcc from hoisting every load to the top (it spills)
         constexpr int S = KC * T, D = UO_RING;
@@ -149,7 +164,8 @@ __global__ __launch_bounds__(256, 2) void uo_pointwise_kernel(const float* __res
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = uo_act<ACT>(v[r], alpha);
                     if (mult) v *= *reinterpret_cast<const f32x4*>(mult + co);
-                    if (res) v += *reinterpret_cast<const f32x4*>(res + p * COUT + co);
+                    if (pre_res) v += rs[PRERES ? t : 0][PRERES ? i : 0];
+                    else if (res) v += *reinterpret_cast<const f32x4*>(res + p * COUT + co);
                 } else if (mode == 1) {
                     if (res) v += *reinterpret_cast<const f32x4*>(res + p * COUT + co);
 #pragma unroll
