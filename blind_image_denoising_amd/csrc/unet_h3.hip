@@ -192,7 +192,12 @@ __global__ __launch_bounds__(NT, 512 / NT) void uh_mlp_kernel(const float* __res
         const char* w1l = lds + wl;
         const char* w2l = lds + W1_BYTES + wl;
         uh8 xh[KC1][NP], xl[KC1][NP];
-        f32x4 xv[PRE == 2 ? NP : 1][2];                          // PRE = 2: the block input x (input lane layout), kept for the residual
+        // XSKIP: the residual IS the block input, already in registers in the INPUT lane layout: the lanes of the output layout fetch it
+        // from there (ds_bpermute) instead of reading x a second time -- by the counters that second read missed L2 half the time (FETCH
+        // 1.6 GB for a 1.07 GB tensor: the 32-channel decoder block moved 3.2 GB where 2.15 are needed).  PRE = 2 always; PRE = 1 for 32
+        // channels (the 64-channel instance has no 32 registers to keep the copy in)
+        constexpr bool XSKIP = PRE == 2 || (PRE == 1 && C == 32);
+        f32x4 xv[XSKIP ? NP : 1][2];                             // the block input x (input lane layout), kept for the residual
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             if (PRE == 2) {
@@ -202,8 +207,11 @@ __global__ __launch_bounds__(NT, 512 / NT) void uh_mlp_kernel(const float* __res
 #pragma unroll
                     for (int j = 0; j < 4; ++j) r[j] = act_up == 1 ? fmaxf(r[j], 0.f) : (act_up == 2 ? (r[j] > 0.f ? r[j] : alpha_up * r[j]) : r[j]);
                     xr[i][0][u] += r;
-                    xv[i][u] = xr[i][0][u];
                 }
+            }
+            if (XSKIP) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) xv[i][u] = xr[i][0][u];
             }
             if (PRE) {
                 f32x4 v[KC1][2];
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(NT, 512 / NT) void uh_mlp_kernel(const float* __res
         __builtin_amdgcn_sched_barrier(0);
         if (g + nwaves < ngroups) load_raw(g + nwaves);
         f32x4 sk[T2][NP];
-        if (PRE == 2) {
+        if (XSKIP) {
             // output tile t, lane (q, n): channels 16 t + 4 q .. + 3 = half (q & 1) of input-layout lane (2 t + (q >> 1), n)
 #pragma unroll
             for (int i = 0; i < NP; ++i)
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(NT, 512 / NT) void uh_mlp_kernel(const float* __res
             for (int t = 0; t < T2; ++t) {
                 f32x4 v = bf_acc_ready(acc2[t][i]) * m4[t];
                 const int co = 16 * t + 4 * q;
-                if (PRE == 2 || skip) v += sk[t][i];
+                if (XSKIP || skip) v += sk[t][i];
                 *reinterpret_cast<f32x4*>(out + p * C + co) = v;
             }
         }
