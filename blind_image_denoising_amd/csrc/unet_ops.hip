@@ -768,6 +768,9 @@ __global__ __launch_bounds__(256) void uo_dwconv_ln_kernel(const float* __restri
 // Column-walking form for k >= 3: a thread owns 4 channels of one image column and walks down R output rows; every input
 // row it loads (k 16-byte loads) is multiplied into the k output rows it touches, which are held as k rotating
 // accumulators: k (R + k - 1) / R loads per output instead of k^2 (5x5, R = 16: 6.25 instead of 25; 3.4 ms -> see DESIGN).
+#ifndef UO_DWR_PD
+#define UO_DWR_PD 2
+#endif
 template <int C, int K, int R>
 __global__ __launch_bounds__(256) void uo_dwconv_ln_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                                 const float* __restrict__ w, const float* __restrict__ gamma, int H,
@@ -805,35 +808,46 @@ __global__ __launch_bounds__(256) void uo_dwconv_ln_rows_kernel(const float* __r
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) v[kx] = *reinterpret_cast<const f32x4*>(row + xo[kx]);
     };
-    f32x4 vn[K];
-    load_row(y0 - RAD, vn);
-    for (int yi = y0 - RAD; yi < yend + RAD; ++yi) {
-        f32x4 v[K];
-        const float ym = (yi >= 0 && yi < H) ? 1.f : 0.f;
+    // The k loads of an input row are requested PD rows ahead of the row that is multiplied (round 4; one row ahead before: a row step
+    // is ~160 vector instructions, a memory round trip is several times that, and the 100 weight registers leave two waves per SIMD to
+    // cover it -- the kernel ran at the latency, 358 us for 1.07 GB at 64 channels).  Rows outside the image load row 0 / H-1 and are
+    // masked, the requests are unconditional: the loop body has no divergent memory path.
+    constexpr int PD = UO_DWR_PD;
+    f32x4 ring[PD][K];
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) v[kx] = vn[kx] * (xm[kx] * ym);
-        load_row(yi + 1, vn);
-        // input row yi is tap row ky of output row yi - ky + RAD = accumulator ky
+    for (int d = 0; d < PD; ++d) load_row(y0 - RAD + d, ring[d]);
+    const int nrows = yend + RAD - (y0 - RAD);
+    for (int base = 0; base < nrows; base += PD) {
 #pragma unroll
-        for (int ky = 0; ky < K; ++ky)
+        for (int d = 0; d < PD; ++d) {
+            const int yi = y0 - RAD + base + d;
+            f32x4 v[K];
+            const float ym = (yi >= 0 && yi < H) ? 1.f : 0.f;
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) acc[ky] += wk[ky * K + kx] * v[kx];
-        const int yo = yi - RAD;                       // acc[K-1] is complete
-        if (yo >= y0) {
-            f32x4 r = acc[K - 1];
-            if (gamma) {
-                const float mean = uo_pixel_sum<LPP>(r[0] + r[1] + r[2] + r[3]) * (1.f / C);
-                const f32x4 d = r - mean;
-                const float var = uo_pixel_sum<LPP>(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / C);
-                r = d * (gm * rsqrtf(var + eps));
+            for (int kx = 0; kx < K; ++kx) v[kx] = ring[d][kx] * (xm[kx] * ym);
+            load_row(yi + PD, ring[d]);
+            // input row yi is tap row ky of output row yi - ky + RAD = accumulator ky
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) acc[ky] += wk[ky * K + kx] * v[kx];
+            const int yo = yi - RAD;                       // acc[K-1] is complete
+            if (yo >= y0 && yo < yend) {                   // (the last pass of PD rows may run past the strip)
+                f32x4 r = acc[K - 1];
+                if (gamma) {
+                    const float mean = uo_pixel_sum<LPP>(r[0] + r[1] + r[2] + r[3]) * (1.f / C);
+                    const f32x4 dd = r - mean;
+                    const float var = uo_pixel_sum<LPP>(dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2] + dd[3] * dd[3]) * (1.f / C);
+                    r = dd * (gm * rsqrtf(var + eps));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[j] = uo_act_rt(r[j], act, alpha);
+                if (xlive) *reinterpret_cast<f32x4*>(out + ((img + (int64_t)yo * W) + x) * C + c0) = r;
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] = uo_act_rt(r[j], act, alpha);
-            if (xlive) *reinterpret_cast<f32x4*>(out + ((img + (int64_t)yo * W) + x) * C + c0) = r;
+            for (int j = K - 1; j > 0; --j) acc[j] = acc[j - 1];
+            acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-#pragma unroll
-        for (int j = K - 1; j > 0; --j) acc[j] = acc[j - 1];
-        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 }
 
