@@ -100,6 +100,7 @@ SIGNATURES = {
     "bf_op_first_conv_h3k": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _F, _P]),
     "bf_op_head_out": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P]),
     "bf_op_head_fused": (_I, [_P, _P, _F, _P, _I, _F, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P]),
+    "bf_op_head_fused_h3": (_I, [_P, _P, _F, _P, _I, _F, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P]),
     "bf_op_fill32": (_I, [_P, _I, _I64, _P]),
     "bf_op_axpy": (_I, [_P, _P, _F, _I, _I64, _P]),
     "bf_op_conv2d_transpose": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),

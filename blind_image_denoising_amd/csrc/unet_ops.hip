@@ -12,6 +12,7 @@
 //   * depthwise k x k + LayerNorm, LayerNorm + activation, the Laplacian split, resize and the heads are HBM-bound
 //     vector kernels: C/4 lanes per pixel, 16-byte accesses, channel reductions with DPP shuffles inside a wave.
 #include "bf_common.h"
+#include "unet_h3_core.h"
 #include <math.h>
 
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -1619,6 +1620,188 @@ extern "C" int bf_op_head_fused(const float* in, const float* ln_gamma, float ep
     else if (cin == 256) UO_HEAD(256);
     else return BF_EUNSUPPORTED;
 #undef UO_HEAD
+    return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
+}
+
+// The same head with its first 1x1 (CIN -> 32) on the f16 matrix cores with split-f16 operands (three products, fp32 accumulation: the
+// arithmetic of unet_h3.hip) for CIN = 32 / 64: 6 / 12 MFMAs of 16 cycles per 16 pixels where the fp32 form above issues 16 / 32 of 32
+// cycles (433 us per batch of 32 x 512 x 512 at 32 channels: the fp32 matrix chain and the epilogue's vector work did not overlap).
+// Lane (q, n) loads channels 32c + 8q .. + 7 of pixel n (the B fragment of K chunk c); the weight fragments are built once per wave from
+// the fp32 operand bf_op_pack_pointwise wrote (element W0[16 c16 + 4 q' + j][16 t + m] at ((c16 * 2 + t) * 64 + 16 q' + m) * 4 + j),
+// scaled by a power of two that puts the largest weight in [2^13, 2^14).
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void uo_head_fused_h3_kernel(const float* __restrict__ in, const float* __restrict__ gamma, float eps,
+                                                                  const float* __restrict__ w0p, int act, float alpha,
+                                                                  const float* __restrict__ w1, void* __restrict__ out, int out_is_u8,
+                                                                  int B, int H, int W, int Ho, int Wo, int cout, int denormalize,
+                                                                  float v_min, float v_max, int* __restrict__ status)
+{
+    constexpr int KC = CIN / 32, T = 2, NP = 2;
+    __shared__ float red[256];
+    float mx = 0.f;
+    for (int i = threadIdx.x; i < CIN * 32; i += 256) mx = fmaxf(mx, fabsf(w0p[i]));
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+        __syncthreads();
+    }
+    mx = red[0];
+    float scale = 1.f;
+    if (mx > 0.f && isfinite(mx)) {
+        int ex;
+        (void)frexpf(mx, &ex);
+        scale = ldexpf(1.f, 14 - max(-100, min(100, ex)));
+    }
+    const float inv = 1.f / scale;
+    const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
+    uh8 wh[KC][T], wlo[KC][T];
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            f32x4 a0, a1;
+            const int c16 = 2 * c + (q >> 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a0[i] = w0p[((c16 * T + t) * 64 + 16 * (2 * (q & 1)) + n) * 4 + i] * scale;          // k = 32c + 8q + i
+                a1[i] = w0p[((c16 * T + t) * 64 + 16 * (2 * (q & 1) + 1) + n) * 4 + i] * scale;      // k = 32c + 8q + 4 + i
+            }
+            uh_split8(a0, a1, wh[c][t], wlo[c][t]);
+        }
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t npix = (int64_t)B * Ho * Wo;
+    const int64_t ngroups = (npix + 16 * NP - 1) / (16 * NP);
+    float wl[T][4][4];                                             // rows 16t + 4q + r of the last kernel [32][cout]
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) wl[t][r][o] = o < cout ? w1[(16 * t + 4 * q + r) * cout + o] : 0.f;
+    f32x4 gm[KC][2];
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            gm[c][u] = gamma ? *reinterpret_cast<const f32x4*>(gamma + 32 * c + 8 * q + 4 * u) : (f32x4){1.f, 1.f, 1.f, 1.f};
+    f32x4 raw[NP][KC][2];
+    auto load_raw = [&](int64_t gg) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            int64_t p = gg * 16 * NP + 16 * i + n;
+            p = p < npix ? p : npix - 1;
+            const int x = (int)(p % Wo);
+            const int y = (int)((p / Wo) % Ho);
+            const int64_t bi = p / ((int64_t)Wo * Ho);
+            const float* src = in + ((bi * H + y) * W + x) * CIN + 8 * q;
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) raw[i][c][u] = *reinterpret_cast<const f32x4*>(src + 32 * c + 4 * u);
+        }
+    };
+    if (wave < ngroups) load_raw(wave);
+    for (int64_t g = wave; g < ngroups; g += nwaves) {
+        const int64_t p0 = g * 16 * NP;
+        f32x4 b[NP][KC][2];
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) b[i][c][u] = raw[i][c][u];
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int64_t gn = g + nwaves;
+            load_raw(gn < ngroups ? gn : g);                       // unconditional: no branch around the loads
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[T][NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (gamma) {
+                float sum = 0.f;
+#pragma unroll
+                for (int c = 0; c < KC; ++c)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) sum += b[i][c][u][0] + b[i][c][u][1] + b[i][c][u][2] + b[i][c][u][3];
+                sum = uo_sum_q(sum);
+                const float mean = sum * (1.f / CIN);
+                float sq = 0.f;
+#pragma unroll
+                for (int c = 0; c < KC; ++c)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        b[i][c][u] = b[i][c][u] - mean;
+                        sq += b[i][c][u][0] * b[i][c][u][0] + b[i][c][u][1] * b[i][c][u][1] + b[i][c][u][2] * b[i][c][u][2] + b[i][c][u][3] * b[i][c][u][3];
+                    }
+                sq = uo_sum_q(sq);
+                const float rs = rsqrtf(sq * (1.f / CIN) + eps);
+#pragma unroll
+                for (int c = 0; c < KC; ++c)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) b[i][c][u] = b[i][c][u] * (gm[c][u] * rs);
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                uh8 xh, xl;
+                uh_split8(b[i][c][0], b[i][c][1], xh, xl);
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    acc[t][i] = UH_MFMA_REAL(wh[c][t], xh, acc[t][i]);
+                    acc[t][i] = UH_MFMA_REAL(wlo[c][t], xh, acc[t][i]);
+                    acc[t][i] = UH_MFMA_REAL(wh[c][t], xl, acc[t][i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const f32x4 hv = bf_acc_ready(acc[t][i]) * inv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float hh = uo_act_rt(hv[r], act, alpha);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] += hh * wl[t][r][k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = uo_sum_q(o[k]);
+            const int64_t p = p0 + 16 * i + n;
+            const float ok = q == 0 ? o[0] : (q == 1 ? o[1] : (q == 2 ? o[2] : o[3]));
+            if (status && !(fabsf(ok) <= 3.0e38f)) atomicOr(status, BF_STATUS_F16_RANGE);
+            float r = (1.0f - 2.0f / (__expf(4.0f * ok) + 1.0f)) * 0.51f;
+            if (denormalize) r = (fminf(fmaxf(r, -0.5f), 0.5f) + 0.5f) * (v_max - v_min) + v_min;
+            if (q < cout && p < npix) {
+                if (out_is_u8) reinterpret_cast<unsigned char*>(out)[p * cout + q] = (unsigned char)fminf(fmaxf(rintf(r), 0.f), 255.f);
+                else reinterpret_cast<float*>(out)[p * cout + q] = r;
+            }
+        }
+    }
+}
+
+extern "C" int bf_op_head_fused_h3(const float* in, const float* ln_gamma, float eps, const float* w0p, int act, float alpha,
+                                   const float* w1, void* out, int out_is_u8, int B, int H, int W, int Ho, int Wo, int cin, int hf,
+                                   int cout, int denormalize, float v_min, float v_max, int* status, void* stream)
+{
+    if (!in || !w0p || !w1 || !out || B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Ho > H || Wo > W) return BF_EINVAL;
+    if (hf != 32 || cout <= 0 || cout > 4 || (cin != 32 && cin != 64)) return BF_EUNSUPPORTED;
+    if (((uintptr_t)in | (uintptr_t)w0p | (uintptr_t)ln_gamma) % 16) return BF_EINVAL;
+    const int64_t npix = (int64_t)B * Ho * Wo;
+    const int grid = uo_grid(npix, 4 * 32, 256 * 4);               // persistent: the weight fragments are built once per wave
+    hipStream_t s = (hipStream_t)stream;
+    if (cin == 32)
+        hipLaunchKernelGGL((uo_head_fused_h3_kernel<32>), dim3(grid), dim3(256), 0, s, in, ln_gamma, eps, w0p, act, alpha, w1, out, out_is_u8, B, H,
+                           W, Ho, Wo, cout, denormalize, v_min, v_max, status);
+    else
+        hipLaunchKernelGGL((uo_head_fused_h3_kernel<64>), dim3(grid), dim3(256), 0, s, in, ln_gamma, eps, w0p, act, alpha, w1, out, out_is_u8, B, H,
+                           W, Ho, Wo, cout, denormalize, v_min, v_max, status);
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
 

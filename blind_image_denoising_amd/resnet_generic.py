@@ -544,7 +544,7 @@ class GenericResnetHydra:
         B, H, W, _ = x.shape
         P = self._pack()
         out = UL.head_fused(self._features(x, H, W), None, P["head0"], self.head_activation, P["head1"], H, W, False, True,
-                            self.v_min, self.v_max)
+                            self.v_min, self.v_max, arith=self.arith)
         if was_numpy:
             torch.cuda.synchronize(self.device)
             return out.cpu().numpy()
@@ -560,4 +560,4 @@ class GenericResnetHydra:
         H, W = next_power_of_2(Hs), next_power_of_2(Ws)
         P = self._pack()
         return UL.head_fused(self._features(image, H, W), None, P["head0"], self.head_activation, P["head1"], Hs, Ws, bool(cast_to_uint8), True,
-                             self.v_min, self.v_max)
+                             self.v_min, self.v_max, arith=self.arith)

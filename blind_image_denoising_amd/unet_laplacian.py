@@ -312,14 +312,16 @@ def head_out(x: torch.Tensor, w: torch.Tensor, Ho: int, Wo: int, as_uint8: bool,
 
 def head_fused(x: torch.Tensor, gamma: Optional[torch.Tensor], w0p: torch.Tensor, act: str, w1: torch.Tensor, Ho: int, Wo: int,
                as_uint8: bool, denormalize: bool, v_min: float, v_max: float, hf: int = 32, eps: float = LN_EPSILON,
-               status: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """[LayerNorm * gamma] -> 1x1 C->hf + act -> 1x1 hf->cout -> tanh(2x)*0.51 -> denormalise [-> uint8], one kernel."""
+               status: Optional[torch.Tensor] = None, arith: int = 0) -> torch.Tensor:
+    """[LayerNorm * gamma] -> 1x1 C->hf + act -> 1x1 hf->cout -> tanh(2x)*0.51 -> denormalise [-> uint8], one kernel.
+    arith 1: the first 1x1 with split-f16 operands on the f16 matrix cores for C = 32 / 64 (bf_op_head_fused_h3); 0: exact fp32."""
     B, H, W, C = x.shape
     cout = int(w1.shape[-1])
     out = torch.empty((B, Ho, Wo, cout), dtype=torch.uint8 if as_uint8 else torch.float32, device=x.device)
     code, a = _act(act)
-    _call("bf_op_head_fused", N.ptr(x), N.ptr(gamma), eps, N.ptr(w0p), code, a, N.ptr(w1), N.ptr(out), int(as_uint8), B, H, W,
-          Ho, Wo, C, hf, cout, int(denormalize), v_min, v_max, N.ptr(status), N.stream_ptr(x))
+    _call("bf_op_head_fused_h3" if arith == 1 and C in (32, 64) and hf == 32 else "bf_op_head_fused", N.ptr(x), N.ptr(gamma), eps,
+          N.ptr(w0p), code, a, N.ptr(w1), N.ptr(out), int(as_uint8), B, H, W, Ho, Wo, C, hf, cout, int(denormalize), v_min, v_max,
+          N.ptr(status), N.stream_ptr(x))
     return out
 
 
@@ -874,7 +876,7 @@ class UnetLaplacianHydra:
                 gamma = P[f"dec{i}/out_ln/gamma"]
         if self.head_filters == 32:
             return head_fused(f, gamma, P[f"head{i}/conv0/kernel"], self.head_activation, P[f"head{i}/conv1/kernel"], Ho, Wo,
-                              as_uint8, True, self.v_min, self.v_max, status=status)
+                              as_uint8, True, self.v_min, self.v_max, status=status, arith=self.arith)
         if gamma is not None:
             f = dwconv_ln(f, None, gamma)
         h = pointwise(f, P[f"head{i}/conv0/kernel"], self.head_filters, self.head_activation)

@@ -339,6 +339,11 @@ int bf_op_head_out(const float* in, const float* w, void* out, int out_is_u8, in
 int bf_op_head_fused(const float* in, const float* ln_gamma, float eps, const float* w0p, int act, float alpha, const float* w1,
                      void* out, int out_is_u8, int batch, int height, int width, int out_height, int out_width, int cin,
                      int head_filters, int cout, int denormalize, float v_min, float v_max, int* status, void* stream);
+/* The same head with its first 1x1 on the f16 matrix cores (split-f16 operands, three products, fp32 accumulation) for cin = 32 / 64;
+ * same arguments, same operand from bf_op_pack_pointwise; BF_EUNSUPPORTED for other channel counts. */
+int bf_op_head_fused_h3(const float* in, const float* ln_gamma, float eps, const float* w0p, int act, float alpha, const float* w1,
+                        void* out, int out_is_u8, int batch, int height, int width, int out_height, int out_width, int cin, int hf,
+                        int cout, int denormalize, float v_min, float v_max, int* status, void* stream);
 /* status (both heads above; may be NULL): int32 on the device, |= BF_STATUS_F16_RANGE when the value in front of the tanh is
  * not finite -- an activation left the f16 range inside a split-f16 operator upstream; clear it with bf_op_fill32. */
 int bf_op_fill32(void* p, int value, int64_t n, void* stream);

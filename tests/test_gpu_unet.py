@@ -307,7 +307,8 @@ def test_head_out_f32_u8_and_crop():
 
 @pytest.mark.parametrize("C", [32, 64, 128])
 @pytest.mark.parametrize("use_ln", [True, False])
-def test_head_fused_layernorm_two_convs_tanh(C, use_ln):
+@pytest.mark.parametrize("arith", [0, 1], ids=["f32", "f16x3"])
+def test_head_fused_layernorm_two_convs_tanh(C, use_ln, arith):
     r = _rng(C + 12)
     x = r.normal(size=(2, 9, 11, C)) * 2 + 0.2
     g = r.uniform(0.5, 1.5, C)
@@ -315,11 +316,31 @@ def test_head_fused_layernorm_two_convs_tanh(C, use_ln):
     t = U.layer_norm(x, g) if use_ln else x
     ref = O.layer_denormalize(np.tanh(2 * O.conv2d_same(U.act(O.conv2d_same(t, w0), "leaky_relu_01"), w1)) * 0.51, 0.0, 255.0)
     w0p = UL.pack_pointwise(dev(w0))
-    got = UL.head_fused(dev(x), dev(g) if use_ln else None, w0p, "leaky_relu_01", dev(w1), 9, 11, False, True, 0.0, 255.0)
+    got = UL.head_fused(dev(x), dev(g) if use_ln else None, w0p, "leaky_relu_01", dev(w1), 9, 11, False, True, 0.0, 255.0, arith=arith)
     assert_close(host(got), ref, rel=3e-5 * 255 / max(1.0, np.abs(ref).max()), what="fused head f32")
-    got = host(UL.head_fused(dev(x), dev(g) if use_ln else None, w0p, "leaky_relu_01", dev(w1), 6, 7, True, True, 0.0, 255.0))
+    got = host(UL.head_fused(dev(x), dev(g) if use_ln else None, w0p, "leaky_relu_01", dev(w1), 6, 7, True, True, 0.0, 255.0, arith=arith))
     want = np.clip(np.rint(ref[:, :6, :7]), 0, 255)
     assert got.dtype == np.uint8 and np.abs(got.astype(int) - want).max() <= 1 and (got != want).mean() < 0.02
+
+
+def test_head_fused_split_f16_on_a_large_ragged_map_and_exact_on_integers():
+    """bf_op_head_fused_h3 on a map that spans many wave iterations with a ragged tail and a crop, both channel counts; and with integer
+    operands that fit f16 (nothing to round in the first 1x1) the result equals the fp32 kernel's"""
+    r = _rng(77)
+    for C in (32, 64):
+        x = r.normal(size=(3, 70, 61, C)) * 1.5
+        g = r.uniform(0.5, 1.5, C)
+        w0, w1 = r.normal(size=(1, 1, C, 32)) / np.sqrt(C), r.normal(size=(1, 1, 32, 3)) * 0.3
+        w0p = UL.pack_pointwise(dev(w0))
+        ref = O.layer_denormalize(np.tanh(2 * O.conv2d_same(U.act(O.conv2d_same(U.layer_norm(x, g), w0), "relu"), w1)) * 0.51, 0.0, 255.0)
+        got = UL.head_fused(dev(x), dev(g), w0p, "relu", dev(w1), 67, 59, False, True, 0.0, 255.0, arith=1)
+        assert_close(host(got), ref[:, :67, :59], rel=3e-5 * 255 / max(1.0, np.abs(ref).max()), what="fused head f16x3, large")
+        xi = r.integers(-8, 9, size=(1, 33, 47, C)).astype(np.float64)
+        wi = r.integers(-4, 5, size=(1, 1, C, 32)).astype(np.float64)
+        wip = UL.pack_pointwise(dev(wi))
+        a = host(UL.head_fused(dev(xi), None, wip, "linear", dev(w1 * 0.01), 33, 47, False, True, 0.0, 255.0, arith=1))
+        b = host(UL.head_fused(dev(xi), None, wip, "linear", dev(w1 * 0.01), 33, 47, False, True, 0.0, 255.0, arith=0))
+        assert np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 128), (128, 64), (128, 128)])
