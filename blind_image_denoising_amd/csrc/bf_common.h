@@ -266,6 +266,17 @@ struct FwdBlockH3Args {
     float* stats;          // [bf_fwd_block_h3t_grid][32]
     int B, H, W, reverse, act_relu;
     int tiles_y, ntiles, rows_per_tile;         // filled in by the launcher
+    // round 4: the BatchNorm finalisation of the block in FRONT (bn_finalize_kernel: 6 us + two kernel boundaries per block) done by every
+    // workgroup in its prologue instead: fin_partial = that block's [fin_nblk][32] sums (a DIFFERENT buffer than `stats`), scale | shift |
+    // mean | 1 / sigma and the moving statistics written by workgroup 0.  NULL: pre_scale / pre_shift are read as given.
+    const float* fin_partial;
+    int fin_nblk;
+    double fin_count;
+    const float* fin_gamma;
+    float *fin_mm, *fin_mv;        // moving mean / variance [16]
+    float fin_eps, fin_momentum;
+    float* fin_scale;              // [32] scale | shift (out)
+    float* fin_meaninv;            // [32] mean | 1 / sigma (out)
 };
 bool       bf_fwd_block_h3t_supports(int H, int W);
 int        bf_fwd_block_h3t_grid(int B, int H, int W);
@@ -289,6 +300,15 @@ struct BwdBlockH3Args {
     int B, H, W, reverse, act_relu;
     int nstrips, tiles_y, ntiles, rows_per_tile;       // filled in by the launcher
     unsigned long long* dbg;   // diagnostic builds only (per-wave phase cycle sums), else NULL
+    // round 4: bn_bwd_finalize_kernel in the prologue of every workgroup: fin_partial = [fin_nblk][32] sums (sum g | sum g * c) the
+    // launch before this one wrote (a DIFFERENT buffer than `stats`); k1 | k2 | k3 go to LDS, d gamma is written by workgroup 0.
+    // NULL: `coef` is read as given.
+    const float* fin_partial;
+    int fin_nblk;
+    double fin_count;
+    const float* fin_gamma;
+    const float* fin_meaninv;      // [32] mean | 1 / sigma of this block's BatchNorm
+    float* fin_dgamma;             // [16] (out)
 };
 bool       bf_bwd_block_h3t_supports(int H, int W);
 int        bf_bwd_block_h3t_grid(int B, int H, int W);

@@ -52,6 +52,8 @@ struct bf_engine {
     int train_bwd_block = 1;        // [3,3] blocks with BatchNorm + ReLU: the whole backward of a block in ONE row-streaming kernel that recomputes
                                     // T from the block input (train_bwd_h3t.hip: 5 tensor passes for 9, and the forward pass need not write T).
                                     // 1 = where a step holds enough strip rows, 2 = wherever it can run (tests), 0 = one kernel per convolution
+    int train_fold_finalize = 1;    // block kernels: the BatchNorm finalisation kernels between the blocks (bn_finalize / bn_bwd_finalize, ~6 us +
+                                    // two kernel boundaries each, 34 per step of 1x18) run in the prologue of the next block kernel instead
     int train_fused_bwd = 1;        // split-f16 training: weight + data gradient (+ BatchNorm backward) of a convolution in one kernel
     int train_fused_bwd2 = 0;       // [3,3] blocks with BatchNorm and ReLU: BOTH convolutions' backward in one kernel (bwd2_h3_kernel: 6 tensor
                                     // passes for 9, but 348 us against 131 + 110: one workgroup per CU and a recomputed halo -- DESIGN 4.3)
@@ -225,6 +227,7 @@ extern "C" int bf_set_option(bf_handle h, const char* key, int value)
     if (!strcmp(key, "train_bwd_block")) { h->train_bwd_block = value < 0 ? 1 : (value > 2 ? 2 : value); return BF_OK; }
     if (!strcmp(key, "train_fwd_block")) { h->train_fwd_block = value < 0 ? 1 : (value > 2 ? 2 : value); return BF_OK; }
     if (!strcmp(key, "train_fused_bwd2")) { h->train_fused_bwd2 = value ? 1 : 0; return BF_OK; }
+    if (!strcmp(key, "train_fold_finalize")) { h->train_fold_finalize = value ? 1 : 0; return BF_OK; }
     if (!strcmp(key, "train_arith")) { h->train_arith = value < 0 ? 1 : (value ? 1 : 0); return BF_OK; }
     if (!strcmp(key, "arith")) { h->arith = value < 0 ? 1 : (value ? 1 : 0); return BF_OK; }
     if (!strcmp(key, "timing")) {
@@ -425,7 +428,7 @@ static TrainLayout train_layout(bf_handle h, int B, int H, int W)
     pf = max64(pf, (int64_t)bf_wgrad_grid(B, H, W) * 2304);
     pf = max64(pf, (int64_t)bf_bwd3x3_h3_grid(B, H, W) * (2304 + 32));
     pf = max64(pf, (int64_t)bf_fwd_block_h3t_grid(B, H, W) * 32);
-    pf = max64(pf, (int64_t)bf_bwd_block_h3t_grid(B, H, W) * (2304 + 32));
+    pf = max64(pf, (int64_t)bf_bwd_block_h3t_grid(B, H, W) * (2304 + 64));           // + two sets of BatchNorm sums in turn
     pf = max64(pf, (int64_t)bf_base_wgrad_grid(B, H, W) * h->n_base);
     pf = max64(pf, (int64_t)bf_head_train_grid(B, H, W) * 80);
     L.partial_floats = align_up(pf, 64);
@@ -909,7 +912,13 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
     for (int i = 0; i < N; ++i) {
         const float* wp = w + L.wpack + (int64_t)i * 2 * nb * BF_TRAIN_PACK_STRIDE;        // forward packs 0..nb-1, then data-gradient packs
         if (fwd_block) {
-            // A_i = A_{i-1} + bn(C_{i-1}) on load ; T_i = act(conv_0 A_i) ; C_i = conv_1 T_i + its batch statistics
+            // A_i = A_{i-1} + bn(C_{i-1}) on load ; T_i = act(conv_0 A_i) ; C_i = conv_1 T_i + its batch statistics.
+            // train_fold_finalize: the BatchNorm finalisation of block i - 1 runs in THIS launch's prologue (every workgroup sums that
+            // block's partials itself; two partial buffers in turn), so a forward is one launch per block instead of two
+            const int fgrid = bf_fwd_block_h3t_grid(B, H, W);
+            const int64_t pp = ((int64_t)fgrid * 32 + 63) / 64 * 64;
+            const bool fold = h->train_fold_finalize != 0;
+            float* part_i = fold ? partial + (i & 1) * pp : partial;
             FwdBlockH3Args fa;
             memset(&fa, 0, sizeof(fa));
             fa.B = B; fa.H = H; fa.W = W; fa.reverse = next_reverse(); fa.act_relu = relu;
@@ -917,13 +926,24 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
             if (pending_affine) {
                 fa.x = A(i - 1); fa.pre_c = C(i - 1, 1); fa.a_out = A(i);
                 fa.pre_scale = w + L.bn_scale + bn_idx(i - 1, 1) * 32; fa.pre_shift = fa.pre_scale + 16;
+                if (fold) {
+                    fa.fin_partial = partial + ((i - 1) & 1) * pp; fa.fin_nblk = fgrid; fa.fin_count = count;
+                    fa.fin_gamma = params + h->p_blocks + (i - 1) * h->p_block_stride + conv_off(1) + 2304;
+                    fa.fin_mm = state + bn_idx(i - 1, 1) * 32; fa.fin_mv = fa.fin_mm + 16;
+                    fa.fin_eps = d.bn_eps; fa.fin_momentum = d.bn_momentum;
+                    fa.fin_scale = w + L.bn_scale + bn_idx(i - 1, 1) * 32; fa.fin_meaninv = w + L.bn_meaninv + bn_idx(i - 1, 1) * 32;
+                }
                 pending_affine = false;
             }
             fa.t_out = need_t ? T(i, 1) : nullptr; fa.c_out = C(i, 1);
-            fa.wpack0 = wp; fa.wpack1 = wp + BF_TRAIN_PACK_STRIDE; fa.stats = partial;
+            fa.wpack0 = wp; fa.wpack1 = wp + BF_TRAIN_PACK_STRIDE; fa.stats = part_i;
             BF_HIP(bf_launch_fwd_block_h3t(fa, s), "fwd_block_h3t");
+            if (fold && i + 1 < N) {
+                pending_affine = true;                              // block i + 1 finalises this BatchNorm itself
+                continue;
+            }
             float* scale = w + L.bn_scale + bn_idx(i, 1) * 32;
-            BF_HIP(bf_launch_bn_finalize(partial, bf_fwd_block_h3t_grid(B, H, W), count, params + h->p_blocks + i * h->p_block_stride + conv_off(1) + 2304,
+            BF_HIP(bf_launch_bn_finalize(part_i, fgrid, count, params + h->p_blocks + i * h->p_block_stride + conv_off(1) + 2304,
                                          state + bn_idx(i, 1) * 32, state + bn_idx(i, 1) * 32 + 16, d.bn_eps, d.bn_momentum, scale,
                                          scale + 16, w + L.bn_meaninv + bn_idx(i, 1) * 32, stage1, s), "bn_finalize");
             if (i + 1 < N) pending_affine = true;
@@ -1037,6 +1057,10 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
                                                  : h3t ? "wgrad3x3_h3_kernel + conv3x3_h3_kernel" : "wgrad3x3_c16_kernel + conv3x3_c16_kernel");
     const int bwd_grid = bwd_block ? bf_bwd_block_h3t_grid(B, H, W) : fused_bwd2 ? bf_bwd2_h3_grid(B, H, W) : bf_bwd3x3_h3_grid_ex(B, H, W, h->train_bwd_dbuf);
     float* bwd_stats = partial + (int64_t)bwd_grid * 2304;
+    // train_fold_finalize with the block backward kernel: launch i reads the sums launch i + 1 wrote and finalises them in its prologue,
+    // so the sums go to two buffers in turn (both behind the weight-gradient slots inside `partial`)
+    const bool bfold = bwd_block && h->train_fold_finalize != 0 && (int64_t)bwd_grid * 2304 + 2 * (int64_t)bwd_grid * 32 <= L.partial_floats;
+    auto bstats = [&](int i) { return bfold ? bwd_stats + (int64_t)(i & 1) * bwd_grid * 32 : bwd_stats; };
     for (int i = N - 1; i >= 0; --i) {
         const float* wp = w + L.wpack + (int64_t)i * 2 * nb * BF_TRAIN_PACK_STRIDE;
         float* gblk = grads + h->p_blocks + i * h->p_block_stride;
@@ -1049,7 +1073,8 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
                 // when it produced dA (split-f16 path: its epilogue accumulates them), else from the reduction kernel
                 const bool fused_sums = h3t && last && i < N - 1;
                 if (!fused_sums) BF_HIP(bf_launch_bn_bwd_reduce(g, C(i, j), partial, npix, bgrid, s), "bn_bwd_reduce");
-                BF_HIP(bf_launch_bn_bwd_finalize(fused_sums && fused_bwd ? bwd_stats : partial,
+                if (!(bfold && fused_sums))
+                BF_HIP(bf_launch_bn_bwd_finalize(fused_sums && fused_bwd ? bstats(i + 1) : partial,
                                                  fused_sums ? (fused_bwd ? bwd_grid : conv_grid) : bgrid, count,
                                                  params + h->p_blocks + i * h->p_block_stride + conv_off(j) + 2304,
                                                  w + L.bn_meaninv + bn_idx(i, j) * 32, w + L.coef, gblk + conv_off(j) + 2304, stage1, s),
@@ -1066,10 +1091,16 @@ extern "C" int bf_train_step(bf_handle h, const float* params, float* state, con
                 memset(&fa, 0, sizeof(fa));
                 fa.B = B; fa.H = H; fa.W = W; fa.act_relu = relu; fa.reverse = next_reverse();
                 fa.a = A(i); fa.g = g; fa.c = C(i, 1); fa.coef = w + L.coef;
+                if (bfold && i < N - 1) {                           // the sums came from launch i + 1: finalised in this launch's prologue
+                    fa.fin_partial = bstats(i + 1); fa.fin_nblk = bwd_grid; fa.fin_count = count;
+                    fa.fin_gamma = params + h->p_blocks + i * h->p_block_stride + conv_off(1) + 2304;
+                    fa.fin_meaninv = w + L.bn_meaninv + bn_idx(i, 1) * 32;
+                    fa.fin_dgamma = gblk + conv_off(1) + 2304;
+                }
                 fa.wfwd0 = wp; fa.wdg0 = wp + (int64_t)nb * BF_TRAIN_PACK_STRIDE; fa.wdg1 = wp + (int64_t)(nb + 1) * BF_TRAIN_PACK_STRIDE;
                 fa.wpartial1 = w + L.wslots + ((int64_t)i * nb + 1) * L.wslot_floats;
                 fa.wpartial0 = w + L.wslots + ((int64_t)i * nb + 0) * L.wslot_floats;
-                fa.stats = bwd_stats;
+                fa.stats = bstats(i);
                 if (i > 0) fa.bnc = C(i - 1, nb - 1);
                 float* out = nullptr;
                 for (int k = 0; k < 3 && !out; ++k)

@@ -860,10 +860,44 @@ __global__ __launch_bounds__(H3UGeom::NT, 3) void bwd_block_h3t_kernel(BwdBlockH
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int role = wave / 3, rw = wave - role * 3;
 
+    // bn_bwd_finalize_kernel in the prologue (BwdBlockH3Args::fin_partial): every workgroup sums the [fin_nblk][32] partials of the launch
+    // before (fp64, fixed order) and forms k1 | k2 | k3 itself; workgroup 0 writes d gamma.  The LDS used is cleared right below.
+    float kk[3] = {0.f, 0.f, 0.f};
+    if (a.fin_partial) {
+        double* red = reinterpret_cast<double*>(h3u_lds);       // [24][32]
+        {
+            const int ch = tid & 31, stripe = tid >> 5;
+            double sum = 0.0;
+            for (int r = stripe; r < a.fin_nblk; r += Gm::NT / 32) sum += (double)a.fin_partial[(size_t)r * 32 + ch];
+            red[stripe * 32 + ch] = sum;
+        }
+        __syncthreads();
+        if (tid < 16) {
+            double sdy = 0.0, sdyc = 0.0;
+            for (int k = 0; k < Gm::NT / 32; ++k) { sdy += red[k * 32 + tid]; sdyc += red[k * 32 + 16 + tid]; }
+            const double mean = a.fin_meaninv[tid], inv = a.fin_meaninv[16 + tid], g = a.fin_gamma[tid], count = a.fin_count;
+            const double sdyx = (sdyc - mean * sdy) * inv;      // sum dy * xhat
+            if (blockIdx.x == 0) a.fin_dgamma[tid] = (float)sdyx;
+            const double mdy = sdy / count, mdyx = sdyx / count;
+            kk[0] = (float)(g * inv);
+            kk[1] = (float)(-g * inv * inv * mdyx);
+            kk[2] = (float)(-g * inv * mdy + g * inv * inv * mean * mdyx);
+        }
+        __syncthreads();
+    }
     // ring columns 0 and 145 are the zero padding at an image edge: cleared once, never written
     for (int i = tid * 16; i < Gm::LDS_BYTES; i += Gm::NT * 16) *reinterpret_cast<f32x4*>(h3u_lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
-    if (tid < 48) reinterpret_cast<float*>(h3u_lds + Gm::K_OFF)[tid] = a.coef[tid];
+    if (a.fin_partial) {
+        if (tid < 16) {
+            float* K = reinterpret_cast<float*>(h3u_lds + Gm::K_OFF);
+            K[tid] = kk[0];
+            K[16 + tid] = kk[1];
+            K[32 + tid] = kk[2];
+        }
+    } else if (tid < 48) {
+        reinterpret_cast<float*>(h3u_lds + Gm::K_OFF)[tid] = a.coef[tid];
+    }
     __syncthreads();
     if (role == 0) h3u_role_f(a, lane, rw);
     else if (role == 1) h3u_role_d2(a, lane, rw);
@@ -908,8 +942,10 @@ hipError_t bf_launch_bwd_block_h3t(const BwdBlockH3Args& args, hipStream_t s)
 {
     using Gm = H3UGeom;
     BwdBlockH3Args a = args;
-    if (!bf_bwd_block_h3t_supports(a.H, a.W) || !a.a || !a.g || !a.c || !a.coef || !a.wfwd0 || !a.wdg1 || !a.wdg0 || !a.out || !a.wpartial0 ||
-        !a.wpartial1)
+    if (!bf_bwd_block_h3t_supports(a.H, a.W) || !a.a || !a.g || !a.c || (!a.coef && !a.fin_partial) || !a.wfwd0 || !a.wdg1 || !a.wdg0 || !a.out ||
+        !a.wpartial0 || !a.wpartial1)
+        return hipErrorInvalidValue;
+    if (a.fin_partial && (a.fin_partial == a.stats || a.fin_nblk <= 0 || !(a.fin_count > 0.0) || !a.fin_gamma || !a.fin_meaninv || !a.fin_dgamma))
         return hipErrorInvalidValue;
     if (a.out == a.a || a.out == a.g || a.out == a.c || (a.bnc && (!a.stats || a.out == a.bnc))) return hipErrorInvalidValue;
     const int cus = 256;

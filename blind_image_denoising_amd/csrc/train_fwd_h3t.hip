@@ -395,6 +395,46 @@ __global__ __launch_bounds__(H3TGeom::NT, 3) void fwd_block_h3t_kernel(FwdBlockH
     const int n = lane & 15, q = lane >> 4;
     const int role = wave >> 2, rw = wave & 3;
 
+    // The BatchNorm of the block in front, finalised here (FwdBlockH3Args::fin_partial): the arithmetic of bn_finalize_kernel (fp64, fixed
+    // order: 24 stripes of rows, then the stripes) in every workgroup -- they all arrive at the same scale / shift --, the results and the
+    // moving statistics written by workgroup 0.  The LDS it uses is cleared right below.
+    f32x4 fin_sc = {0.f, 0.f, 0.f, 0.f}, fin_sh = {0.f, 0.f, 0.f, 0.f};
+    if (PRE && a.fin_partial) {
+        double* red = reinterpret_cast<double*>(h3t_lds);       // [24][32]
+        float* fin = reinterpret_cast<float*>(h3t_lds + 24 * 32 * 8);
+        {
+            const int ch = tid & 31, stripe = tid >> 5;
+            double sum = 0.0;
+            for (int r = stripe; r < a.fin_nblk; r += Gm::NT / 32) sum += (double)a.fin_partial[(size_t)r * 32 + ch];
+            red[stripe * 32 + ch] = sum;
+        }
+        __syncthreads();
+        if (tid < 16) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = 0; k < Gm::NT / 32; ++k) { s1 += red[k * 32 + tid]; s2 += red[k * 32 + 16 + tid]; }
+            const double count = a.fin_count;
+            const double mean = s1 / count;
+            double var = s2 / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const double inv = 1.0 / sqrt(var + (double)a.fin_eps);
+            const double g = a.fin_gamma ? (double)a.fin_gamma[tid] : 1.0;
+            fin[tid] = (float)(g * inv);
+            fin[16 + tid] = (float)(-g * inv * mean);
+            if (blockIdx.x == 0) {
+                a.fin_scale[tid] = fin[tid];
+                a.fin_scale[16 + tid] = fin[16 + tid];
+                a.fin_meaninv[tid] = (float)mean;
+                a.fin_meaninv[16 + tid] = (float)inv;
+                const double unbiased = var * (count / (count > 1.0 ? count - 1.0 : 1.0)), mo = (double)a.fin_momentum;
+                a.fin_mm[tid] = (float)((double)a.fin_mm[tid] * mo + mean * (1.0 - mo));
+                a.fin_mv[tid] = (float)((double)a.fin_mv[tid] * mo + unbiased * (1.0 - mo));
+            }
+        }
+        __syncthreads();
+        fin_sc = *reinterpret_cast<const f32x4*>(fin + (lane & 3) * 4);
+        fin_sh = *reinterpret_cast<const f32x4*>(fin + 16 + (lane & 3) * 4);
+        __syncthreads();
+    }
     // ring columns 0 and W+1.. of the input and intermediate rings are the zero padding: cleared once, never written
     for (int i = tid * 16; i < Gm::LDS_BYTES; i += Gm::NT * 16) *reinterpret_cast<f32x4*>(h3t_lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
@@ -502,7 +542,10 @@ __global__ __launch_bounds__(H3TGeom::NT, 3) void fwd_block_h3t_kernel(FwdBlockH
         H3TLoader<FULLW, PRE> L{a, tin, 64 * rw + lane};
         L.psc = (f32x4){0.f, 0.f, 0.f, 0.f};
         L.psh = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (PRE) {
+        if (PRE && a.fin_partial) {
+            L.psc = fin_sc;
+            L.psh = fin_sh;
+        } else if (PRE) {
             L.psc = *reinterpret_cast<const f32x4*>(a.pre_scale + (lane & 3) * 4);
             L.psh = *reinterpret_cast<const f32x4*>(a.pre_shift + (lane & 3) * 4);
         }
@@ -588,7 +631,9 @@ hipError_t bf_launch_fwd_block_h3t(const FwdBlockH3Args& args, hipStream_t s)
     using Gm = H3TGeom;
     FwdBlockH3Args a = args;
     if (!bf_fwd_block_h3t_supports(a.H, a.W) || !a.x || !a.c_out || !a.wpack0 || !a.wpack1 || !a.stats) return hipErrorInvalidValue;
-    if (a.pre_c && (!a.pre_scale || !a.pre_shift || !a.a_out || a.a_out == a.x || a.a_out == a.pre_c)) return hipErrorInvalidValue;
+    if (a.pre_c && ((!a.fin_partial && (!a.pre_scale || !a.pre_shift)) || !a.a_out || a.a_out == a.x || a.a_out == a.pre_c)) return hipErrorInvalidValue;
+    if (a.fin_partial && (!a.pre_c || a.fin_partial == a.stats || a.fin_nblk <= 0 || !(a.fin_count > 0.0) || !a.fin_mm || !a.fin_mv || !a.fin_scale || !a.fin_meaninv))
+        return hipErrorInvalidValue;
     if (a.c_out == a.x || a.c_out == a.pre_c || a.t_out == a.x || (a.t_out && a.t_out == a.pre_c)) return hipErrorInvalidValue;
     const int cus = 256;
     a.rows_per_tile = h3t_rows_per_tile(a.B, a.H, cus);

@@ -116,6 +116,28 @@ def test_block_forward_kernel_matches_oracle_and_the_two_kernel_path(no_layers, 
     _cmp_grads(spec, got[2][1], got[0][1], rel=6e-4)
 
 
+@pytest.mark.parametrize("no_layers,shape", [(3, (3, 33, 47)), (5, (2, 40, 256)), (2, (1, 24, 300))])
+def test_batchnorm_finalisation_inside_the_block_kernels(no_layers, shape):
+    """train_fold_finalize: bn_finalize / bn_bwd_finalize computed in the prologue of the next block kernel (every workgroup sums the
+    partials itself, workgroup 0 writes scale / shift / moving statistics / d gamma) against the same step with the two finalisation
+    kernels between the blocks: same loss, gradients and moving statistics to rounding (24 stripes of rows instead of 32), twice the same bits"""
+    cfg, spec, ls, params, state, m, fns = _setup(no_layers)
+    clean, noisy = O.synthetic_batch(*shape, seed=31)
+    gt, x = clean.astype(np.float32), noisy.astype(np.float32)
+    got = {}
+    for v in (0, 1, 11):
+        m.set_weights(params, state)
+        m.set_option("train_fwd_block", 2)
+        m.set_option("train_bwd_block", 2)
+        m.set_option("train_fold_finalize", v % 10)
+        total, ml, dl, pred, grads = fns.train_step_single_gpu(torch.from_numpy(gt), torch.from_numpy(x), (1.0,), 0.0, None)
+        got[v] = (total.item(), grads.cpu().numpy().astype(np.float64), m.state.cpu().numpy().copy())
+    assert got[1][0] == got[11][0] and np.array_equal(got[1][1], got[11][1]) and np.array_equal(got[1][2], got[11][2])
+    assert abs(got[1][0] - got[0][0]) <= 1e-6 * abs(got[0][0])
+    _cmp_grads(spec, got[1][1], got[0][1], rel=2e-5)
+    assert np.abs(got[1][2] - got[0][2]).max() < 1e-6
+
+
 @pytest.mark.parametrize("no_layers,shape", [(1, (2, 16, 32)), (3, (3, 33, 47)), (2, (5, 70, 150)), (4, (2, 40, 256)), (2, (1, 24, 300))])
 @pytest.mark.parametrize("fwd_block", [0, 2])
 def test_block_backward_kernel_matches_oracle_and_the_per_convolution_path(no_layers, shape, fwd_block):
@@ -685,7 +707,7 @@ def test_random_training_configurations_and_options_match_oracle(seed):
     except NotImplementedError as e:
         pytest.skip(f"refused: {e}")
     opts = {"train_arith": int(rng.random() < 0.7), "train_fused_fwd": int(rng.integers(2)), "train_fused_bwd": int(rng.integers(2)), "train_fused_bwd2": int(rng.integers(2)),
-            "train_fwd_block": int(rng.integers(3)), "train_bwd_block": int(rng.integers(3)), "train_bwd_dbuf": int(rng.random() < 0.3), "train_zigzag": int(rng.integers(2))}
+            "train_fwd_block": int(rng.integers(3)), "train_bwd_block": int(rng.integers(3)), "train_fold_finalize": int(rng.integers(2)), "train_bwd_dbuf": int(rng.random() < 0.3), "train_zigzag": int(rng.integers(2))}
     for k, v in opts.items():
         m.set_option(k, v)
     B, H, W = int(rng.integers(1, 4)), int(rng.integers(8, 60)), int(rng.integers(8, 70))
