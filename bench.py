@@ -421,6 +421,12 @@ def unet_run(args, torch, bf, O, rank, local_rank, world, dist, steps, warmup, c
         params = U.init_params(spec, seed=42)
     model = bf.model_builder(cfg["model"], device=f"cuda:{local_rank}").hydra
     model.set_weights(params)
+    for kv in args.opt:                                   # A/B switches of the unet host (fuse_chain, fuse_up_block, arith)
+        k, v = kv.split("=")
+        try:
+            model.set_option(k, int(v))
+        except ValueError:
+            pass                                          # an option of another mode's model
     module = bf.DenoiserModule(model)
     clean, base = O.synthetic_batch(4, S, S, sigma=20.0, seed=1234 + rank)
     noisy = torch.from_numpy(np.concatenate([base] * ((B + 3) // 4), axis=0)[:B]).cuda()

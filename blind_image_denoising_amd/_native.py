@@ -77,6 +77,8 @@ SIGNATURES = {
     "bf_op_pack_mlp_h3": (_I, [_P, _P, _P, _I, _P]),
     "bf_op_convnext_mlp_h3": (_I, [_P, _P, _P, _P, _P, C.c_int64, _I, _I, _F, _P]),
     "bf_op_convnext_block1_h3": (_I, [_P, _P, _P, _P, _F, _P, _P, C.c_int64, _I, _I, _F, _P]),
+    "bf_op_pack_mlp_h3_chain": (_I, [_P, _P, _P, _I, _P]),
+    "bf_op_convnext_chain32_h3": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _F, _I, _I, _I, _I, _F, _I, _F, _P]),
     "bf_op_convnext_block1_up_h3": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _P]),
     "bf_op_convnext_block_h3": (_I, [_P, _P, _P, _I, _P, _F, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "bf_op_set_variant": (_I, [C.c_char_p, _I]),

@@ -66,6 +66,19 @@ __device__ __forceinline__ float uh_pixel_sum8(float v)
     return uh_dpp_add<0x141>(v);
 }
 
+// v + (v of lane ^ 16) + (v of lane ^ 32) + (v of lane ^ 48): the sum over the four lanes (q = 0..3) that hold one pixel in the matrix-core
+// layouts, on the vector ALU (v_permlane16_swap / v_permlane32_swap, gfx950) instead of two ds_bpermute round trips through the LDS
+// crossbar (unet_ops.hip: uo_sum_q).  swap(a, b): rows 1, 3 (16-lane groups) of a <-> rows 0, 2 of b.
+__device__ __forceinline__ float uh_sum_q(float v)
+{
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    float s = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);          // rows 0, 1: r0 + r1 ; rows 2, 3: r2 + r3
+    a = __builtin_bit_cast(unsigned, s); b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));   // lanes 32..63 of a <-> lanes 0..31 of b
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+
 template <int ACT>
 __device__ __forceinline__ float uh_act(float v, float alpha)
 {

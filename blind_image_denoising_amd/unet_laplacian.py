@@ -126,6 +126,35 @@ def convnext_block1_up_h3(enc: torch.Tensor, low: torch.Tensor, dw: torch.Tensor
     return out
 
 
+def pack_mlp_h3_chain(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """[32,128] and [128,32] fp32 kernels -> the split-f16 operand of convnext_chain32_h3"""
+    if int(w1.shape[-2]) != 32:
+        raise NotImplementedError("the chain kernel is built for 32 channels")
+    out = torch.empty(int(N.lib().bf_op_mlp_h3_pack_bytes(32)), dtype=torch.uint8, device=w1.device)
+    _call("bf_op_pack_mlp_h3_chain", N.ptr(w1.contiguous()), N.ptr(w2.contiguous()), N.ptr(out), 32, N.stream_ptr(w1))
+    return out
+
+
+def convnext_chain32_h3(x: torch.Tensor, low: Optional[torch.Tensor], blocks, act: str, act_up: str = "linear",
+                        eps: float = LN_EPSILON) -> torch.Tensor:
+    """1..3 pixel-wise ConvNext blocks of 32 channels in one kernel; blocks = [(packed, dw [32], gamma [32] | None, mult [32] | None)];
+    low: the first block's input is x + act_up(bilinear 2x of low)"""
+    import ctypes as C
+    B, OH, OW, Cc = x.shape
+    n = len(blocks)
+    if Cc != 32 or not 1 <= n <= 3:
+        raise ValueError(f"chain of {n} blocks on {Cc} channels: built for 1..3 blocks of 32 channels")
+    if low is not None and (tuple(low.shape) != (B, OH // 2, OW // 2, Cc) or OH % 2 or OW % 2):
+        raise ValueError(f"low-resolution map {tuple(low.shape)} does not sit under {tuple(x.shape)}")
+    out = torch.empty_like(x)
+    code, a = _act(act)
+    ucode, ua = _act(act_up)
+    arr = lambda k: (C.c_void_p * n)(*[N.ptr(b[k]) for b in blocks])
+    _call("bf_op_convnext_chain32_h3", N.ptr(x), N.ptr(low), N.ptr(out), n, arr(0), arr(1), arr(2), arr(3), eps, B, OH, OW, code, a,
+          ucode, ua, N.stream_ptr(x))
+    return out
+
+
 def convnext_block_h3(x: torch.Tensor, dw: torch.Tensor, gamma: Optional[torch.Tensor], packed: torch.Tensor,
                       mult: Optional[torch.Tensor], act: str, eps: float = LN_EPSILON) -> torch.Tensor:
     """x + ConvNextBlock(x) for a 32-channel block with a k x k depthwise convolution (dw [k,k,C], k = 3 | 5), one kernel."""
@@ -378,7 +407,7 @@ class UnetLaplacianHydra:
         return False
 
     def set_option(self, key: str, value: int):
-        if key not in ("arith", "fuse_up_block") or int(value) not in (0, 1):
+        if key not in ("arith", "fuse_up_block", "fuse_chain") or int(value) not in (0, 1):
             raise ValueError(f"unknown option {key}={value}")
         setattr(self, key, int(value))
         self.version = getattr(self, "version", 0) + 1
@@ -487,6 +516,9 @@ class UnetLaplacianHydra:
         # 1: a level's first decoder block forms its input enc + act(up(low)) while loading it (32 channels, 1x1 depthwise:
         # bf_op_convnext_block1_up_h3); 0: upsample_act_add writes the node and the block reads it back.  Same bits either way.
         self.fuse_up_block = 1
+        # 1: the pixel-wise decoder blocks of a 32-channel level (decoder_kernel_size 1) run up to three per launch, the level's node formed
+        # on load (bf_op_convnext_chain32_h3); 0: one launch per block
+        self.fuse_chain = 1
         self._inventory = self._build_inventory()
         self.n_params = sum(int(np.prod(s)) for _, s, _ in self._inventory)
         self.params = torch.from_numpy(self._initial_values(seed)).to(self.device)
@@ -665,6 +697,9 @@ class UnetLaplacianHydra:
                 o2 = dict((v[0], v[3]) for v in self.trainable_variables)[f"{prefix}/pw2/kernel"]
                 P[f"{prefix}/mlp_h3"] = pack_mlp_h3(self.params[off:off + n1].clone().view(shape[2], shape[3]),
                                                    self.params[o2:o2 + n2].clone().view(shape[3], shape[2]))
+                if shape[2] == 32 and prefix.startswith("dec") and self.dec_k == 1:      # pixel-wise decoder blocks: the chain kernel's operand
+                    P[f"{prefix}/mlp_h3c"] = pack_mlp_h3_chain(self.params[off:off + n1].clone().view(shape[2], shape[3]),
+                                                               self.params[o2:o2 + n2].clone().view(shape[3], shape[2]))
         if self.filters == 32:
             # the three projections of an attention block as ONE 1x1 convolution 128 -> 96: query | "value" operand | "key" operand side
             # by side = query_conv | key_conv | value_conv in the archive's wiring (attention_rows), query_conv | value_conv | key_conv in
@@ -696,6 +731,19 @@ class UnetLaplacianHydra:
         return bool(self.fuse_up_block and skip is not None and C == 32 and self.arith == 1 and self.width >= 1
                     and not self.use_mix_project and f"{prefix}/mlp_h3" in P and P[f"{prefix}/dw/kernel"].shape[0] == 1
                     and _act(up_act)[0] in (0, 1, 2) and low.shape[1] * 2 == skip.shape[1] and low.shape[2] * 2 == skip.shape[2])
+
+    def _chain_len(self, P, d: int, w: int, C: int) -> int:
+        """how many of the level's decoder blocks from block w on run in one launch of the chain kernel (0: none)"""
+        if not (self.fuse_chain and self.arith == 1 and C == 32 and self.dec_k == 1):
+            return 0
+        n = 0
+        while n < 3 and w + n < self.width and f"dec{d}_{w + n}/mlp_h3c" in P and tuple(P[f"dec{d}_{w + n}/dw/kernel"].shape) == (1, 1, 32):
+            n += 1
+        return n
+
+    def _chain_block(self, P, prefix: str):
+        return (P[f"{prefix}/mlp_h3c"], P[f"{prefix}/dw/kernel"].view(-1), P.get(f"{prefix}/ln/gamma") if self.use_ln else None,
+                P.get(f"{prefix}/gamma/w") if self.use_gamma else None)
 
     def _convnext_up(self, P, prefix: str, enc: torch.Tensor, low: torch.Tensor, up_act: str) -> torch.Tensor:
         mult = P.get(f"{prefix}/gamma/w") if self.use_gamma else None
@@ -805,7 +853,11 @@ class UnetLaplacianHydra:
                 # upsampling.py:80-90 makes the same exchange itself when the activation is linear)
                 low = pointwise(low, P[f"up{d}/kernel"], C, "linear")
                 up_act = "linear" if self.upsample_linear else a
-                if self._fused_up_block(P, d, C, skip, low, up_act):
+                if self._fused_up_block(P, d, C, skip, low, up_act) and self._chain_len(P, d, 0, C):
+                    first_done = self._chain_len(P, d, 0, C)                # the node and the level's first blocks in one launch
+                    f = convnext_chain32_h3(skip, low, [self._chain_block(P, f"dec{d}_{j}") for j in range(first_done)],
+                                            self.mlp_activation, up_act)
+                elif self._fused_up_block(P, d, C, skip, low, up_act):
                     f, first_done = self._convnext_up(P, f"dec{d}_0", skip, low, up_act), 1
                 else:
                     f = upsample_act_add(low, skip, up_act)
@@ -817,7 +869,11 @@ class UnetLaplacianHydra:
                 if low.shape[-1] != nodes[d].shape[-1]:
                     raise ValueError(f"Add of [{nodes[d].shape[-1]}] and [{low.shape[-1]}] channels: upsample_type "
                                      f"[{self.upsample_type}] needs equal filters on both levels")
-                if self.upsample_type == "bilinear" and self._fused_up_block(P, d, C, skip, low, "linear"):
+                if self.upsample_type == "bilinear" and self._fused_up_block(P, d, C, skip, low, "linear") and self._chain_len(P, d, 0, C):
+                    first_done = self._chain_len(P, d, 0, C)
+                    f = convnext_chain32_h3(skip, low, [self._chain_block(P, f"dec{d}_{j}") for j in range(first_done)],
+                                            self.mlp_activation, "linear")
+                elif self.upsample_type == "bilinear" and self._fused_up_block(P, d, C, skip, low, "linear"):
                     f, first_done = self._convnext_up(P, f"dec{d}_0", skip, low, "linear"), 1
                 elif self.upsample_type == "bilinear":
                     f = upsample_act_add(low, skip, "linear")
@@ -849,8 +905,15 @@ class UnetLaplacianHydra:
                 first = 1
             elif self.use_mix_project:
                 f = pointwise(f, P[f"mix{d}/kernel"], self.level_filters(d), a)
-            for w in range(first, self.width):
-                f = self._convnext(P, f"dec{d}_{w}", f)
+            w = first
+            while w < self.width:
+                nb = self._chain_len(P, d, w, C)
+                if nb:                                                      # pixel-wise blocks of 32 channels: up to three per launch
+                    f = convnext_chain32_h3(f, None, [self._chain_block(P, f"dec{d}_{w + j}") for j in range(nb)], self.mlp_activation)
+                    w += nb
+                else:
+                    f = self._convnext(P, f"dec{d}_{w}", f)
+                    w += 1
             if self.use_output_normalization and self.use_ln and not self.output_norm_at_heads \
                     and not (defer_output_norm and d == 0):
                 f = dwconv_ln(f, None, P[f"dec{d}/out_ln/gamma"])

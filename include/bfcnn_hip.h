@@ -280,6 +280,17 @@ int bf_op_convnext_block1_h3(const float* x, float* out, const float* dw, const 
 int bf_op_convnext_block1_up_h3(const float* enc, const float* low, float* out, const float* dw, const float* ln_gamma, float eps,
                                 const void* packed, const float* mult, int batch, int out_height, int out_width, int channels, int act,
                                 float alpha, int act_up, float alpha_up, void* stream);
+/* A CHAIN of 1..3 pixel-wise ConvNext blocks (1x1 depthwise: decoder_kernel_size 1, 32 channels) in one kernel -- the `width` decoder
+ * blocks of a level (backbone_unet_laplacian.py:538-560) without a round trip through memory between them:
+ *   for b in 0 .. nblocks-1:  x = x + mult[b] * (act(LayerNormalization(x * dw[b]) * gamma[b] . w1[b]) . w2[b])
+ * low != NULL: the first block's input is x + act_up(UpSampling2D(2, "bilinear")(low)) (x = the encoder's skip map [B, OH, OW, 32], low
+ * [B, OH/2, OW/2, 32]; OH, OW even) -- bf_op_convnext_block1_up_h3 followed by nblocks - 1 times bf_op_convnext_block1_h3.  The arrays
+ * are HOST arrays of nblocks device pointers; packed[b] from bf_op_pack_mlp_h3_chain (the operand of bf_op_pack_mlp_h3 with the first
+ * kernel's rows in the order the chain kernel holds a pixel's channels; same size); gamma[b] / mult[b] may be NULL.  out may alias x. */
+int bf_op_pack_mlp_h3_chain(const float* w1, const float* w2, void* packed, int channels, void* stream);
+int bf_op_convnext_chain32_h3(const float* x, const float* low, float* out, int nblocks, const void* const* packed,
+                              const float* const* dw, const float* const* ln_gamma, const float* const* mult, float eps, int batch,
+                              int out_height, int out_width, int act, float alpha, int act_up, float alpha_up, void* stream);
 /* A whole encoder ConvNextBlock (k x k depthwise, k = 3 or 5, 32 channels) plus the residual Add, one kernel
  * (custom_layers.py:975-1008; backbone_unet_laplacian.py:336-354):
  * out = x + mult * (act(LayerNormalization(DepthwiseConv2D_kxk(x)) * ln_gamma . w1) . w2); dw [k][k][C]; out != x. */

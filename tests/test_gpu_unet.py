@@ -123,6 +123,56 @@ def test_first_decoder_block_forms_its_node_on_load(shape, act_up, use_ln):
     assert_close(host(one), ref, rel=5e-5, what="fused first decoder block")
 
 
+@pytest.mark.parametrize("shape", [(1, 2, 2), (2, 10, 14), (1, 34, 62), (3, 64, 64)])
+@pytest.mark.parametrize("nblocks", [1, 2, 3])
+@pytest.mark.parametrize("up,use_ln,act", [(True, True, "leaky_relu_01"), (False, True, "gelu"), (True, False, "relu"), (False, False, "leaky_relu_01")])
+def test_decoder_chain_kernel(shape, nblocks, up, use_ln, act):
+    """bf_op_convnext_chain32_h3: 1..3 pixel-wise ConvNext blocks (and the node in front of them) in one launch, against the fp64
+    restatement and against the same blocks launched one by one (equal to rounding: the LayerNorm sums run in another order)"""
+    B, OH, OW = shape
+    C = 32
+    r = _rng(OH * 5 + OW + nblocks)
+    enc = r.normal(size=(B, OH, OW, C)) * 1.5
+    low = r.normal(size=(B, OH // 2, OW // 2, C)) * 2 - 0.2
+    blocks, dev_blocks, one_by_one = [], [], []
+    for b in range(nblocks):
+        dw, g = r.normal(size=(1, 1, C, 1)), r.uniform(0.5, 1.5, C)
+        w1, w2 = r.normal(size=(1, 1, C, 4 * C)) / np.sqrt(C), r.normal(size=(1, 1, 4 * C, C)) / np.sqrt(4 * C)
+        mult = r.uniform(0.2, 1.0, C) if b != 1 else None
+        blocks.append((dw, g, w1, w2, mult))
+        gd = dev(g) if use_ln else None
+        md = None if mult is None else dev(mult)
+        dev_blocks.append((UL.pack_mlp_h3_chain(dev(w1.reshape(C, 4 * C)), dev(w2.reshape(4 * C, C))), dev(dw.reshape(C)), gd, md))
+        one_by_one.append((UL.pack_mlp_h3(dev(w1.reshape(C, 4 * C)), dev(w2.reshape(4 * C, C))), dev(dw.reshape(C)), gd, md))
+    x = enc + U.act(U.resize_bilinear(low, OH, OW), "relu") if up else enc
+    ref = x
+    for dw, g, w1, w2, mult in blocks:
+        t = U.depthwise_same(ref, dw)
+        if use_ln:
+            t = U.layer_norm(t, g)
+        y = O.conv2d_same(U.act(O.conv2d_same(t, w1), act), w2)
+        ref = ref + (y if mult is None else mult * y)
+    got = UL.convnext_chain32_h3(dev(enc), dev(low) if up else None, dev_blocks, act, "relu")
+    assert_close(host(got), ref, rel=8e-5, what=f"chain of {nblocks}")
+    seq = UL.upsample_act_add(dev(low), dev(enc), "relu") if up else dev(enc)
+    for pk, dwd, gd, md in one_by_one:
+        seq = UL.convnext_block1_h3(seq, dwd, gd, pk, md, act)
+    assert_close(host(got), host(seq).astype(np.float64), rel=2e-5, what="chain vs one launch per block")
+
+
+def test_v5_hydra_with_and_without_the_decoder_chain():
+    cfg, spec, params, m = _model(arith=1)
+    _, noisy = O.synthetic_batch(2, 64, 96, seed=6)
+    x = noisy.astype(np.float32)
+    assert m.fuse_chain == 1 and any(k.endswith("mlp_h3c") for k in m._pack())
+    chained = [np.array(t) for t in m(x)]
+    m.set_option("fuse_chain", 0)
+    single = [np.array(t) for t in m(x)]
+    for a, b in zip(chained, single):
+        assert np.abs(a - b).max() <= 2e-3                                       # 0..255 scale
+    assert not np.array_equal(chained[0], single[0])                            # level 0 is the 32-channel one: two summation orders
+
+
 def test_first_decoder_block_operator_refuses_what_it_was_not_built_for():
     x = torch.zeros((1, 4, 4, 64), device="cuda")
     low = torch.zeros((1, 2, 2, 64), device="cuda")
