@@ -35,7 +35,7 @@ __device__ __forceinline__ float uh_sum_q_shfl(float v)
 #define UH_SUM_Q(v) uh_sum_q_shfl(v)
 #endif
 #ifndef UH_CHAIN_NT
-#define UH_CHAIN_NT 512            // threads of uh_chain32_kernel's workgroup (one per CU: its LDS holds up to 96 KB of weights)
+#define UH_CHAIN_NT 1024           // threads of uh_chain32_kernel's workgroup (one per CU: its LDS holds up to 96 KB of weights); 122 registers
 #endif
 #ifndef UH_CHAIN_NT_UP
 #define UH_CHAIN_NT_UP 512         // ... of the instance that forms the level's node on load (64 more registers for the taps)
