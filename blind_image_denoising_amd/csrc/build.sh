@@ -10,7 +10,7 @@ name="${BF_BUILD_NAME:-libbfcnn_hip.so}"
 obj="$out/obj${BF_BUILD_NAME:+_${BF_BUILD_NAME%.so}}"
 mkdir -p "$out" "$obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-units=(conv3x3_c16 fused_h3 fused_h3v fused_h3w train_bwd_h3 train_bwd2_h3 train_fwd_h3t train_bwd_h3t edge_layers base_rows train_ops pyramid augment loss_terms unet_ops unet_h3 unet_h3_enc unet_h3_first generic_h3 train_prims train_generic collective engine)
+units=(conv3x3_c16 fused_h3 fused_h3v fused_h3w train_bwd_h3 train_bwd2_h3 train_fwd_h3t train_bwd_h3t edge_layers base_rows train_ops pyramid augment loss_terms unet_ops unet_h3 unet_h3_chain unet_h3_enc unet_h3_first generic_h3 train_prims train_generic collective engine)
 # incremental: a unit is recompiled when its source, any header or the flag set is newer than / differs from its object
 flags_sig="$*"
 [ -f "$obj/.flags" ] && [ "$(cat "$obj/.flags")" = "$flags_sig" ] || { rm -f "$obj"/*.o; printf '%s' "$flags_sig" > "$obj/.flags"; }

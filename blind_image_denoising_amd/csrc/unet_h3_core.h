@@ -177,3 +177,17 @@ __device__ __forceinline__ void uh_mlp_core(const uh8 (&xh)[C / 32][NP], const u
         }
     }
 }
+
+#ifndef UH_LN_PERMLANE
+#define UH_LN_PERMLANE 1           // LayerNorm sums over the four lanes of a pixel: 1 = v_permlane swaps on the vector ALU, 0 = ds_bpermute
+#endif
+#if UH_LN_PERMLANE
+#define UH_SUM_Q(v) uh_sum_q(v)
+#else
+__device__ __forceinline__ float uh_sum_q_shfl(float v)
+{
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+#define UH_SUM_Q(v) uh_sum_q_shfl(v)
+#endif

@@ -734,7 +734,7 @@ class UnetLaplacianHydra:
 
     def _chain_len(self, P, d: int, w: int, C: int) -> int:
         """how many of the level's decoder blocks from block w on run in one launch of the chain kernel (0: none)"""
-        if not (self.fuse_chain and self.arith == 1 and C == 32 and self.dec_k == 1):
+        if not (self.fuse_chain and self.arith == 1 and C == 32 and self.dec_k == 1) or _act(self.mlp_activation)[0] == 0:
             return 0
         n = 0
         while n < 3 and w + n < self.width and f"dec{d}_{w + n}/mlp_h3c" in P and tuple(P[f"dec{d}_{w + n}/dw/kernel"].shape) == (1, 1, 32):
