@@ -1107,7 +1107,11 @@ def block_roofline(kernel, launches_per_forward, layers, B, S, launch_s, traffic
         return dict(common, bound="mfma", achieved=tf, peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / MFMA_F16_PEAK_TFLOPS,
                     dtype="f16 (split hi/lo, 3 products), fp32 accumulate", issued_tflops=issued,
                     issued_frac=issued / MFMA_F16_PEAK_TFLOPS,
-                    hbm={"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
+                    hbm={"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
+                    bound_note="neither roof is reached: the launch is limited by the issue rate of its MFMA + ds_read + epilogue mix at three "
+                               "waves per SIMD (~21 cycles per MFMA slot) under the 1 400 W package cap (clock 1.9 GHz); of the two roofs the "
+                               "matrix pipe is the nearer (issued_frac against hbm.frac) -- DESIGN 4.1c, profiles/r03_mfma_mix.txt, "
+                               "r03_power_probe.txt, r04_mfma_fp8_mix.txt")
     if kernel.startswith("fused_block_h3"):
         issued = px * H3_MFMA_FLOP_PER_PX * blocks_per_launch / launch_s / 1e12
         return dict(common, bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
