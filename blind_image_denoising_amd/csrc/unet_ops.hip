@@ -1629,7 +1629,8 @@ extern "C" int bf_op_head_fused(const float* in, const float* ln_gamma, float ep
 // Lane (q, n) loads channels 32c + 8q .. + 7 of pixel n (the B fragment of K chunk c); the weight fragments are built once per wave from
 // the fp32 operand bf_op_pack_pointwise wrote (element W0[16 c16 + 4 q' + j][16 t + m] at ((c16 * 2 + t) * 64 + 16 q' + m) * 4 + j),
 // scaled by a power of two that puts the largest weight in [2^13, 2^14).
-template <int CIN>
+// NO = output channels the per-pixel epilogue carries (3 for the colour models: a quarter of its multiplies and one of its four lane sums less than 4)
+template <int CIN, int NO>
 __global__ __launch_bounds__(256, 2) void uo_head_fused_h3_kernel(const float* __restrict__ in, const float* __restrict__ gamma, float eps,
                                                                   const float* __restrict__ w0p, int act, float alpha,
                                                                   const float* __restrict__ w1, void* __restrict__ out, int out_is_u8,
@@ -1673,13 +1674,13 @@ __global__ __launch_bounds__(256, 2) void uo_head_fused_h3_kernel(const float* _
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const int64_t npix = (int64_t)B * Ho * Wo;
     const int64_t ngroups = (npix + 16 * NP - 1) / (16 * NP);
-    float wl[T][4][4];                                             // rows 16t + 4q + r of the last kernel [32][cout]
+    float wl[T][4][NO];                                            // rows 16t + 4q + r of the last kernel [32][cout]
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int o = 0; o < 4; ++o) wl[t][r][o] = o < cout ? w1[(16 * t + 4 * q + r) * cout + o] : 0.f;
+            for (int o = 0; o < NO; ++o) wl[t][r][o] = o < cout ? w1[(16 * t + 4 * q + r) * cout + o] : 0.f;
     f32x4 gm[KC][2];
 #pragma unroll
     for (int c = 0; c < KC; ++c)
@@ -1760,7 +1761,7 @@ __global__ __launch_bounds__(256, 2) void uo_head_fused_h3_kernel(const float* _
         }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            float o[4] = {0.f, 0.f, 0.f, 0.f};
+            float o[4] = {0.f, 0.f, 0.f, 0.f};                   // o[NO ..] stay 0
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 const f32x4 hv = bf_acc_ready(acc[t][i]) * inv;
@@ -1768,11 +1769,11 @@ __global__ __launch_bounds__(256, 2) void uo_head_fused_h3_kernel(const float* _
                 for (int r = 0; r < 4; ++r) {
                     const float hh = uo_act_rt(hv[r], act, alpha);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] += hh * wl[t][r][k];
+                    for (int k = 0; k < NO; ++k) o[k] += hh * wl[t][r][k];
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = uo_sum_q(o[k]);
+            for (int k = 0; k < NO; ++k) o[k] = uo_sum_q(o[k]);
             const int64_t p = p0 + 16 * i + n;
             const float ok = q == 0 ? o[0] : (q == 1 ? o[1] : (q == 2 ? o[2] : o[3]));
             if (status && !(fabsf(ok) <= 3.0e38f)) atomicOr(status, BF_STATUS_F16_RANGE);
@@ -1796,12 +1797,12 @@ extern "C" int bf_op_head_fused_h3(const float* in, const float* ln_gamma, float
     const int64_t npix = (int64_t)B * Ho * Wo;
     const int grid = uo_grid(npix, 4 * 32, 256 * 4);               // persistent: the weight fragments are built once per wave
     hipStream_t s = (hipStream_t)stream;
-    if (cin == 32)
-        hipLaunchKernelGGL((uo_head_fused_h3_kernel<32>), dim3(grid), dim3(256), 0, s, in, ln_gamma, eps, w0p, act, alpha, w1, out, out_is_u8, B, H,
-                           W, Ho, Wo, cout, denormalize, v_min, v_max, status);
-    else
-        hipLaunchKernelGGL((uo_head_fused_h3_kernel<64>), dim3(grid), dim3(256), 0, s, in, ln_gamma, eps, w0p, act, alpha, w1, out, out_is_u8, B, H,
-                           W, Ho, Wo, cout, denormalize, v_min, v_max, status);
+#define UO_HEAD_H3(CC, NN)                                                                                                        \
+    hipLaunchKernelGGL((uo_head_fused_h3_kernel<CC, NN>), dim3(grid), dim3(256), 0, s, in, ln_gamma, eps, w0p, act, alpha, w1, out, out_is_u8, \
+                       B, H, W, Ho, Wo, cout, denormalize, v_min, v_max, status)
+    if (cin == 32) { if (cout <= 3) UO_HEAD_H3(32, 3); else UO_HEAD_H3(32, 4); }
+    else { if (cout <= 3) UO_HEAD_H3(64, 3); else UO_HEAD_H3(64, 4); }
+#undef UO_HEAD_H3
     return hipGetLastError() == hipSuccess ? BF_OK : BF_EHIP;
 }
 

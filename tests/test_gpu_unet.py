@@ -197,6 +197,13 @@ def test_encoder_convnext_block_in_one_kernel(k, shape, use_ln, variant):
         N.lib().bf_op_set_variant(b"enc32", -1)               # back to the default
 
 
+@pytest.mark.parametrize("shape", [(7, 112, 192), (8, 128, 128), (9, 100, 90)])
+def test_encoder_convnext_block_tile_order_over_the_xcds(shape):
+    """more tiles than workgroups: every XCD walks its own contiguous range of tiles (294 tiles: 37 per XCD, 35 on the last; 256: one per
+    workgroup; 9 x 7 x 3 = 189 < 256: the round-robin order) -- every pixel written once, against the fp64 restatement"""
+    _encoder_block_case(5, shape, True)
+
+
 def _encoder_block_case(k, shape, use_ln):
     C = 32
     r = _rng(k + shape[1] + shape[2])
