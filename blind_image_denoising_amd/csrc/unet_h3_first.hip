@@ -13,13 +13,13 @@
 constexpr int UF_TH = 8, UF_TW = 64, UF_CIN = 3, UF_COUT = 32;
 typedef unsigned uf_u4 __attribute__((ext_vector_type(4)));
 #ifndef UF_GRID
-// workgroups of the launch.  k = 7: persistent, two per CU (256 registers), the next tile's patch requested a tile ahead: 418 -> 298 us at
-// 64 x 256 x 256.  k = 3, 5: one tile per workgroup as before -- persistent workgroups measured SLOWER for k = 5 (509 us, with the
-// prefetch 535 us, against 463 us at 32 x 512 x 512): gfx950 counts loads and stores in one queue (vmcnt), the stores of a tile are conditional
-// (edge tiles), so hipcc waits for the prefetched patch with vmcnt(0) -- every tile waits for its own stores to land.  Unrolling the eight
-// pixel groups to make the store count static took 331 / 503 registers.  A loader wave of its own (it never stores) is the form that
-// would fix it; not built.
-#define UF_GRID(k) ((k) == 7 ? (int64_t)512 : ((int64_t)1 << 31))
+// workgroups of the persistent launch (k = 7 only: two per CU at 256 registers; the next tile's patch is requested a tile ahead: 418 -> 298 us
+// at 64 x 256 x 256).  k = 3, 5 run uf_first_conv_tile_kernel, one tile per workgroup: at k = 5 it needs 128 registers (four waves per
+// SIMD) where this kernel's loop form needs 188 (two), and measures 460 us against 522 us persistent / 667 us for this code with one tile per
+// workgroup (tools/exp/first_conv_ab.sh).  Note for whoever tunes the persistent form further: gfx950 counts loads and stores in one queue
+// (vmcnt) and the stores of a tile are conditional (edge tiles), so hipcc waits for the prefetched patch with vmcnt(0) -- every tile waits
+// for its own stores to land; unrolling the eight pixel groups to make the store count static took 331 / 503 registers.
+#define UF_GRID(k) ((int64_t)512)
 #endif
 
 // One tile per workgroup (the form of rounds 2-3 with the kernel size as a template parameter): the patch loads are the first thing a
