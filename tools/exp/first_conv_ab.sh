@@ -1,3 +1,6 @@
+# (timing-only ablations of the one-tile kernel on one box: as built 457 us; without the max reduction and its eight barriers 432 us; with the
+# weight fragments as 16-byte loads on top of that 380-522 us, bimodal -- the workgroup preamble is at most a tenth of the kernel: no
+# prepared-operand entry point was added)
 # uf_first_conv_kernel<5> (the unet's first convolution): one tile per workgroup (default) against 512 persistent workgroups with the next
 # tile's patch requested a tile ahead (-D'UF_GRID(k)=512'), SAME box, alternating: rocprofv3 average of the kernel's full-size calls inside
 # bench.py --mode unet, and ms per forward
