@@ -26,6 +26,9 @@ typedef unsigned uf_u4 __attribute__((ext_vector_type(4)));
 // workgroup issues, and the weight preparation runs behind them.  k = 3, 5 take this kernel: for k = 5 it measures 460 us at 32 x 512 x 512
 // against 522 us for the persistent kernel below and 667 us for that kernel launched with one tile per workgroup (same box, alternating:
 // tools/exp/first_conv_ab.sh) -- a regression the persistent form brought in mid-round and a same-box comparison found.
+#ifndef UF_TILE_ABLATE
+#define UF_TILE_ABLATE 0      // timing builds (results wrong): 1 gathers without bank conflicts, 2 no stores, 4 no MFMAs
+#endif
 template <int UF_KS>
 __global__ __launch_bounds__(256) void uf_first_conv_tile_kernel(const void* __restrict__ in, int in_is_u8, float* __restrict__ out,
                                                             const float* __restrict__ w, int Hs, int Ws, int H, int W, int normalize,
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void uf_first_conv_tile_kernel(const void* __r
         for (int s = 0; s < UF_NS; ++s) {
             unsigned e[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) e[i] = base[koff[s][i]];
+            for (int i = 0; i < 8; ++i) e[i] = (UF_TILE_ABLATE & 1) ? base[8 * s + i] : base[koff[s][i]];
             uf_u4 ph, pl;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -126,9 +129,10 @@ __global__ __launch_bounds__(256) void uf_first_conv_tile_kernel(const void* __r
             const uh8 xh = __builtin_bit_cast(uh8, ph), xl = __builtin_bit_cast(uh8, pl);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
+                if (UF_TILE_ABLATE & 4) { acc[t][0] += (float)xh[0] + (float)xl[1] + (float)wh[s][t][2] + (float)wl[s][t][3]; } else {
                 acc[t] = UH_MFMA(wh[s][t], xh, acc[t]);
                 acc[t] = UH_MFMA(wl[s][t], xh, acc[t]);
-                acc[t] = UH_MFMA(wh[s][t], xl, acc[t]);
+                acc[t] = UH_MFMA(wh[s][t], xl, acc[t]); }
             }
         }
         const int gy = y0 + ry, gx = x0 + cx;
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256) void uf_first_conv_tile_kernel(const void* __r
                     else if (act == 2) v[r] = fmaxf(v[r], alpha * v[r]);
                     else if (act == 3) v[r] = uh_act<3>(v[r], 0.f);
                 }
-                *reinterpret_cast<f32x4*>(op + 16 * t) = v;
+                if (!(UF_TILE_ABLATE & 2) || v[0] == 12345.678f) *reinterpret_cast<f32x4*>(op + 16 * t) = v;
             }
         }
     }
